@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- tokens/s of the llama2.zig forward pass on MI355X, -t 0 (argmax).
+
+Metric (BASELINE.json): "tokens/s (argmax, -t 0) + matvec achieved HBM GB/s vs peak".
+A "step" is one pass of the hot path = one generated position: transformer()
+(src/main.zig:285) + argmax (:715) + the loop hand-over (:999-1036), all on the
+device.  Weights are already resident in HBM when the timed region starts
+(synthetic llama2.c-v0 checkpoint of the named shape, generated on device).
+
+  python bench.py                       # N=1, llama2-7b shape, 255 steps after 1 warm-up
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N   # rows/heads sharded over N GPUs (RCCL, strong scaling)
+
+The default (steps=255, warmup=1) is exactly the reference's `-n 256 -t 0 -v`
+figure: its clock starts after the first token and the rate is (pos-1)/elapsed
+(src/main.zig:1039-1047).
+
+Rank 0 prints ONE JSON line.  It carries `roofline` for the dominant kernel
+(HIP-event time measured in situ by l2z_profile_forward) and, at N=1,
+`cpu_baseline`: the C oracle (a port, 1 thread -- the reference is single
+threaded, main.zig:5 / README.md:107) timed on this box's host cores on a
+bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E vendor peak (MI355X_MICROARCH.md); ~6300 measured copy
+
+
+def weight_bytes_by_kind(cfg, world: int = 1) -> dict:
+    """Algorithmic HBM bytes ONE launch of each kernel kind must stream:
+    a (d,n) mat-vec moves 4*d*n bytes; attention reads K and V rows 0..pos."""
+    dim, hid, V = cfg.dim, cfg.hidden_dim, cfg.vocab_size
+    kvd = cfg.kv_dim
+    return {
+        "qkv": 4 * (dim * dim + 2 * kvd * dim) // world,
+        "wo": 4 * dim * dim // world,
+        "ffn13": 4 * 2 * hid * dim // world,
+        "ffn2": 4 * dim * hid // world,
+        "cls": 4 * V * dim // world,
+    }
+
+
+def cpu_baseline(ck, cfg, shared, name: str) -> dict:
+    """Time the C oracle (port of src/main.zig, 1 thread) on a bounded sample."""
+    orc = ge.load_oracle()
+    orc.set_mode(8, True, True)  # AVX2 width, fused -- the fastest reading of the reference
+    ncpu = os.cpu_count() or 1
+    if cfg.n_layers <= 12 and ck.weights_count(cfg, shared) * 4 < (1 << 30):
+        blob = orc.synth_fill(cfg.as_i32(), shared, 1, ncpu)
+        m = orc.Model(cfg.as_i32(), blob, shared)
+        n_tok = 64
+        t0 = time.perf_counter()
+        toks, _ = m.generate_greedy([], n_tok)
+        dt = time.perf_counter() - t0
+        m.close()
+        return {"value": len(toks) / dt, "unit": "tokens/s", "cores": 1, "kind": "port",
+                "sample": f"{name}: full model, {len(toks)} greedy tokens from BOS, C oracle "
+                          f"(oracle/llama2_oracle.c, gcc -O3 AVX2+FMA), 1 thread of {ncpu}"}
+    # big shape: time 1-layer and 3-layer models of the same dims, extrapolate layers linearly
+    times = {}
+    n_tok = 3
+    for L in (1, 3):
+        c = ck.Config(cfg.dim, cfg.hidden_dim, L, cfg.n_heads, cfg.n_kv_heads, cfg.vocab_size,
+                      cfg.seq_len)
+        blob = orc.synth_fill(c.as_i32(), shared, 1, ncpu)
+        m = orc.Model(c.as_i32(), blob, shared)
+        m.transformer(1, 0)  # touch everything once
+        t0 = time.perf_counter()
+        for p in range(1, 1 + n_tok):
+            m.transformer(7 * p, p)
+        times[L] = (time.perf_counter() - t0) / n_tok
+        m.close()
+        del blob
+    t_layer = (times[3] - times[1]) / 2
+    t_rest = max(times[1] - t_layer, 0.0)
+    t_full = t_rest + cfg.n_layers * t_layer
+    return {"value": 1.0 / t_full, "unit": "tokens/s", "cores": 1, "kind": "port",
+            "sample": f"{name}: same dims with 1 and 3 layers, {n_tok} tokens each, C oracle 1 thread "
+                      f"of {ncpu}; per-layer {t_layer*1e3:.1f} ms, classifier+rest {t_rest*1e3:.1f} ms, "
+                      f"extrapolated to {cfg.n_layers} layers"}
+
+
+def run_once(B, cfg, shared, seed, steps, warmup, comm=None, barrier=None):
+    """Returns (tokens produced in the timed region, elapsed seconds, runstate, weights)."""
+    w = B.Weights(cfg, None, shared, seed=seed, comm=comm)
+    s = B.RunState(cfg, comm=comm)
+    s.greedy_begin([])
+    if warmup > 0:
+        s.greedy_run(w, warmup)
+    s.synchronize()
+    if barrier:
+        barrier()
+    t0 = time.perf_counter()
+    toks = s.greedy_run(w, steps)  # synchronises before returning the tokens
+    s.synchronize()
+    if barrier:
+        barrier()
+    dt = time.perf_counter() - t0
+    return len(toks), dt, s, w
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=255)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="llama2-7b",
+                    choices=["llama2-7b", "stories110M", "stories15M"])
+    ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the stories15M side measurement")
+    args = ap.parse_args()
+
+    pkg = ge.load_package()
+    B, ck = pkg.binding, pkg.checkpoint
+    shapes = {n: (c, sh) for n, c, sh in ck.iter_configs()}
+    cfg, shared = shapes[args.workload]
+    steps = max(1, min(args.steps, cfg.seq_len - args.warmup))
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    comm, barrier, dist = None, None, None
+    if args.gpus > 1 or world > 1:
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with "
+                             "python -m torch.distributed.run --nproc-per-node N ...)")
+        import torch
+        import torch.distributed as dist
+        # control plane only (barrier, id broadcast, max-reduce of the clock): gloo on CPU.
+        # The data path's collectives are RCCL calls made by libllama2_hip.so itself.
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        uid = [B.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = B.Comm(rank, world, uid[0], local_rank)
+        barrier = dist.barrier
+
+    if B.device_count() < 1:
+        raise SystemExit("bench.py: no HIP device visible (the HIP path has no CPU fallback)")
+
+    n_tok, dt, s, w = run_once(B, cfg, shared, args.seed, steps, args.warmup, comm, barrier)
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline of the dominant kernel, HIP events in situ ----
+    by_kind = {k: [0.0, 0] for k in B.KINDS}
+    pos0 = args.warmup + n_tok
+    n_prof = 4
+    for i in range(n_prof):
+        p = min(pos0 + i, cfg.seq_len - 1)
+        for k, (ms, cnt) in s.profile_forward(1 + i, p, w).items():
+            by_kind[k][0] += ms
+            by_kind[k][1] += cnt
+    wb = weight_bytes_by_kind(cfg, world)
+    dom = max(wb, key=lambda k: by_kind[k][0])
+    avg_ms = by_kind[dom][0] / max(by_kind[dom][1], 1)
+    achieved = wb[dom] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
+        except Exception:
+            traffic = None
+    kernels = {k: {"ms_per_launch": by_kind[k][0] / max(by_kind[k][1], 1),
+                   "launches_per_token": by_kind[k][1] // n_prof,
+                   "GBps": (wb[k] / (by_kind[k][0] / max(by_kind[k][1], 1) * 1e-3) / 1e9)
+                   if k in wb and by_kind[k][0] > 0 else None}
+               for k in B.KINDS}
+    roofline = {"bound": "hbm", "kernel": f"matvec[{dom}]", "achieved": achieved,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "algorithmic_bytes_per_launch": wb[dom],
+                "avg_launch_ms": avg_ms, "by_kind": kernels}
+    s.close()
+    w.close()
+
+    out = {
+        "metric": "tokens/s (argmax, -t 0)", "value": n_tok / dt, "unit": "tokens/s",
+        "n_gpus": args.gpus, "steps": n_tok, "warmup": args.warmup,
+        "ms_per_step": dt / n_tok * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload} shape, fp32 llama2.c-v0 checkpoint "
+                               f"(dim {cfg.dim}, hidden {cfg.hidden_dim}, L {cfg.n_layers}, "
+                               f"H {cfg.n_heads}, kv {cfg.n_kv_heads}, V {cfg.vocab_size}, "
+                               f"S {cfg.seq_len}), greedy from BOS, seeded synthetic weights",
+                   "parallelism": f"rows/heads sharded x{args.gpus}" if args.gpus > 1 else "1 GPU",
+                   "weight_bytes_per_token": sum(
+                       wb[k] * (1 if k == "cls" else cfg.n_layers) for k in wb) * world},
+        "roofline": roofline,
+    }
+    if rank == 0 and args.gpus == 1:
+        if not args.no_extra and args.workload != "stories15M":
+            c15, sh15 = shapes["stories15M"]
+            n15, dt15, s15, w15 = run_once(B, c15, sh15, args.seed, 255, 1)
+            s15.close(); w15.close()
+            out["extra"] = {"stories15M_tokens_per_s": n15 / dt15, "stories15M_steps": n15,
+                            "note": "stories15M shape, -t 0 -n 256; weights fit the on-die "
+                                    "cache, launch/latency bound, no HBM fraction quoted"}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ck, cfg, shared, args.workload)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

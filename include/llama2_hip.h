@@ -1,0 +1,184 @@
+/*
+ * llama2_hip.h -- C ABI of the MI355X (gfx950) forward pass for cgbur/llama2.zig.
+ *
+ * The reference has no FFI today: the boundary is the Zig-internal call
+ *     transformer(token, pos, *Config, *RunState, *Weights) void     src/main.zig:285
+ * with its sole call site at src/main.zig:996.  This header gives that call,
+ * and the three objects it takes, a C ABI with the same names, argument
+ * meaning and ownership, so a maintainer replaces each Zig call by the
+ * matching extern (INTEGRATION.md shows the Zig `extern fn` block).
+ *
+ *   reference (src/main.zig)                 this library
+ *   ---------------------------------------  -----------------------------------
+ *   ConfigReader / Config        :17-49      l2z_config (same 7 x i32 layout)
+ *   Weights.init(config,data,shared) :73     l2z_weights_init      (uploads to HBM)
+ *   RunState.init(alloc,config)  :137        l2z_runstate_init     (device buffers)
+ *   RunState.deinit              :156        l2z_runstate_free
+ *   transformer(token,pos,c,s,w) :285        l2z_transformer
+ *   argmax(state.logits)         :715,:1003  l2z_argmax            (on device)
+ *   state.logits after return    :1005-1012  l2z_logits_read       (D2H, for samplers)
+ *   while (pos < seq_len) loop at -t 0 :995  l2z_greedy_begin / l2z_greedy_run
+ *   matmul / matmul_fused        :485,:530   l2z_matmul / l2z_matmul_fused   (test hooks)
+ *   rmsnorm                      :432        l2z_rmsnorm                     (test hook)
+ *   softmax                      :687        l2z_softmax                     (test hook)
+ *   vector_dot_product           :503        l2z_vector_dot_product          (test hook)
+ *   vector_weighted_sum_rows     :657        l2z_vector_weighted_sum_rows    (test hook)
+ *
+ * Ownership: the caller owns config; weights and runstate handles own their
+ * device memory.  The host blob passed to l2z_weights_init may be freed (or
+ * un-mmapped) as soon as the call returns.  One runstate = one sequence, used
+ * from one thread at a time, pos strictly increasing from 0 -- exactly the
+ * reference's contract (main.zig:994-995).
+ *
+ * Errors: the reference's transformer() cannot fail; a device path can.  Every
+ * entry point returns L2Z_OK (0) or a negative l2z_status; l2z_last_error()
+ * returns a thread-local message.  There is NO CPU fallback: without a gfx950
+ * device every compute entry point fails with L2Z_ERR_NO_DEVICE.
+ *
+ * All floats are IEEE f32, exactly as in the checkpoint.
+ */
+#ifndef LLAMA2_HIP_H
+#define LLAMA2_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define L2Z_ABI_VERSION 1
+
+typedef enum l2z_status {
+    L2Z_OK = 0,
+    L2Z_ERR_INVALID = -1,    /* bad argument / shape the kernels do not support */
+    L2Z_ERR_NO_DEVICE = -2,  /* no HIP device, or device is not usable */
+    L2Z_ERR_HIP = -3,        /* a HIP runtime call failed */
+    L2Z_ERR_OOM = -4,        /* device or host allocation failed */
+    L2Z_ERR_COMM = -5,       /* RCCL failure (multi-GPU only) */
+    L2Z_ERR_STATE = -6       /* call sequence violates the contract (e.g. pos out of range) */
+} l2z_status;
+
+/* src/main.zig:17-25 ConfigReader: 7 x i32, little endian, the first 28 bytes
+ * of a checkpoint.  vocab_size here is already abs()'d (main.zig:944); the
+ * sign is passed separately as `shared_weights` (main.zig:943). */
+typedef struct l2z_config {
+    int32_t dim;        /* transformer dimension */
+    int32_t hidden_dim; /* ffn hidden dimension */
+    int32_t n_layers;
+    int32_t n_heads;
+    int32_t n_kv_heads; /* <= n_heads, divides it (GQA) */
+    int32_t vocab_size;
+    int32_t seq_len;    /* max sequence length = KV-cache rows per layer */
+} l2z_config;
+
+typedef struct l2z_weights l2z_weights;   /* src/main.zig:53  Weights, resident in HBM */
+typedef struct l2z_runstate l2z_runstate; /* src/main.zig:119 RunState, resident in HBM */
+typedef struct l2z_comm l2z_comm;         /* multi-GPU shard group (no reference equivalent) */
+
+/* ---- library / device ---- */
+int l2z_abi_version(void);
+const char *l2z_last_error(void);
+int l2z_device_count(int *out_n);
+/* name (<= cap bytes), CU count, HBM bytes of device `dev` */
+int l2z_device_info(int dev, char *name, size_t cap, int *out_cus, uint64_t *out_hbm_bytes);
+
+/* ---- Weights: src/main.zig:73 Weights.init(config, data, shared_weights) ----
+ * `data` is the f32 blob that follows the 28-byte header, n_floats long, in
+ * the Weights.init carve order (main.zig:85-112) including the unused
+ * freq_cis region.  comm == NULL: the whole blob is uploaded as ONE device
+ * allocation with the same layout.  comm != NULL: only this rank's rows of
+ * every matrix are uploaded (heads / output rows, DESIGN.md "Sharding"). */
+int l2z_weights_init(const l2z_config *config, const float *data, size_t n_floats,
+                     int shared_weights, const l2z_comm *comm, l2z_weights **out);
+/* Same layout, filled ON DEVICE by the seeded generator of DESIGN.md
+ * "Synthetic checkpoints" (no checkpoint exists in the build image, and a 27 GB
+ * PCIe upload is not part of the measured path). */
+int l2z_weights_init_synthetic(const l2z_config *config, int shared_weights, uint64_t seed,
+                               const l2z_comm *comm, l2z_weights **out);
+/* Copy `count` floats starting at blob index `offset` back to the host
+ * (single-GPU weights only; used by tests to check uploads / the generator). */
+int l2z_weights_read(const l2z_weights *w, size_t offset, size_t count, float *out);
+void l2z_weights_free(l2z_weights *w);
+
+/* ---- RunState: src/main.zig:137 RunState.init / :156 deinit ----
+ * Allocates x, xb, hb, q, att, logits and the (layer, seq_len, kv_dim) key and
+ * value caches in HBM, plus the RoPE cos/sin table (seq_len, head_size/2) that
+ * replaces the per-layer pow/cos/sin of main.zig:338-342. */
+int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm, l2z_runstate **out);
+void l2z_runstate_free(l2z_runstate *s);
+
+/* ---- src/main.zig:285 transformer(token, pos, config, s, w) ----
+ * One decoder forward pass; on return the logits for `pos` are in the
+ * runstate (device) and the KV-cache rows `pos` are written in every layer.
+ * Asynchronous on the runstate's stream; l2z_argmax / l2z_logits_read sync. */
+int l2z_transformer(int token, int pos, const l2z_config *config, l2z_runstate *s,
+                    const l2z_weights *w);
+/* src/main.zig:715 argmax over s.logits, on device (strict '>' : lowest index wins ties) */
+int l2z_argmax(l2z_runstate *s, int *out_token);
+/* copy s.logits (vocab_size floats) to the host */
+int l2z_logits_read(l2z_runstate *s, float *out_logits);
+/* copy a named RunState buffer to the host: "x","xb","hb","q","att","logits",
+ * "key_cache","value_cache" (tests only) */
+int l2z_runstate_read(l2z_runstate *s, const char *name, size_t offset, size_t count, float *out);
+
+/* ---- src/main.zig:987-1042, the generation loop at temperature 0 ----
+ * Runs entirely on the device: the forward pass, argmax, the prompt override
+ * (main.zig:999-1000) and the token/pos hand-over to the next step are one
+ * hipGraph replayed per position, with no host round trip per token.
+ *   l2z_greedy_begin : token = BOS(1), pos = 0, install the prompt
+ *   l2z_greedy_run   : run `n_steps` more positions, write `next` of each to
+ *                      out_tokens; stops early after a BOS (main.zig:1017) and
+ *                      at seq_len; *out_n = positions actually produced.
+ */
+int l2z_greedy_begin(l2z_runstate *s, const int32_t *prompt, int n_prompt);
+int l2z_greedy_run(const l2z_config *config, l2z_runstate *s, const l2z_weights *w, int n_steps,
+                   int32_t *out_tokens, int *out_n);
+
+/* ---- measurement support ----
+ * l2z_profile_forward runs ONE forward pass (+ argmax/hand-over) eagerly with
+ * a HIP event pair around every kernel launch, recorded on the runstate's own
+ * stream, and returns per-kind total device time (ms) and launch count.
+ * Kinds, in slot order (l2z_kind_name): 0 "qkv", 1 "attn", 2 "wo", 3 "ffn13",
+ * 4 "ffn2", 5 "cls", 6 "argmax"; n_kinds must be >= 7.  bench.py derives the
+ * roofline of the dominant kernel from this, in situ: every layer streams
+ * its own weights, so nothing is re-read from cache between launches.  The
+ * numbers must agree with rocprofv3 --kernel-trace --stats (profiles/). */
+#define L2Z_N_KINDS 7
+int l2z_profile_forward(int token, int pos, const l2z_config *config, l2z_runstate *s,
+                        const l2z_weights *w, double *ms_by_kind, int *launches_by_kind,
+                        int n_kinds);
+int l2z_kind_name(int kind, char *out, size_t cap);
+int l2z_synchronize(l2z_runstate *s);
+
+/* ---- kernel-level test hooks (host pointers in and out; same device code
+ *      the forward pass runs).  Names follow src/main.zig. ---- */
+int l2z_matmul(float *xout, const float *x, const float *w, size_t n, size_t d);      /* :485 */
+int l2z_matmul_fused(int N, float *const *outs, const float *x, const float *const *ws, size_t n,
+                     size_t d);                                                        /* :530 */
+int l2z_rmsnorm(float *o, const float *x, const float *w, size_t n);                   /* :432 */
+int l2z_softmax(float *x, size_t n);                                                   /* :687 */
+int l2z_vector_dot_product(float *out, const float *x, const float *y, size_t n);      /* :503 */
+int l2z_vector_weighted_sum_rows(float *xout, size_t xout_len, const float *rows, size_t rows_len,
+                                 size_t row_stride, const float *weights, size_t n_weights); /* :657 */
+int l2z_argmax_host(const float *x, size_t n, size_t *out_index);                      /* :715 */
+
+/* ---- multi-GPU shard group: one process per GPU, RCCL over xGMI ----
+ * The reference is single-threaded and single-device; this is what the build
+ * adds.  id is an opaque 128-byte ncclUniqueId made on rank 0
+ * and distributed by the launcher (bench.py uses torch.distributed for that).
+ */
+#define L2Z_COMM_ID_BYTES 128
+int l2z_comm_unique_id(void *out_id);
+int l2z_comm_init(int rank, int world, const void *id, int device, l2z_comm **out);
+int l2z_comm_rank(const l2z_comm *c, int *rank, int *world);
+void l2z_comm_free(l2z_comm *c);
+/* Pure host logic, no GPU needed: the row range [*r0,*r1) of a `rows`-row
+ * tensor owned by `rank` of `world`, in units of `granule` rows (head_size for
+ * q/k/v so shards are whole heads, 1 otherwise).  Fails if not divisible. */
+int l2z_shard_range(int64_t rows, int64_t granule, int rank, int world, int64_t *r0, int64_t *r1);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LLAMA2_HIP_H */

@@ -1,0 +1,309 @@
+"""ctypes binding over libllama2_hip.so (include/llama2_hip.h).
+
+This is what tests/ and bench.py call: every compute path goes through the
+C ABI into the hand-written HIP kernels.  There is no Python or CPU fallback
+here -- if the library is missing or no gfx950 device is present the calls
+raise (`L2ZError`), they never silently compute on the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libllama2_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "llama2_hip.h")
+
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_COMM, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
+COMM_ID_BYTES = 128
+KINDS = ["qkv", "attn", "wo", "ffn13", "ffn2", "cls", "argmax"]
+
+
+class L2ZError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"llama2_hip error {code}: {msg}")
+        self.code = code
+
+
+class L2ZConfig(C.Structure):
+    """src/main.zig:17-25 ConfigReader layout."""
+
+    _fields_ = [(n, C.c_int32) for n in
+                ("dim", "hidden_dim", "n_layers", "n_heads", "n_kv_heads", "vocab_size", "seq_len")]
+
+
+def declared_symbols() -> list[str]:
+    """Every function include/llama2_hip.h declares (for the export check)."""
+    txt = open(HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(l2z_[a-z0-9_]+)\s*\(", txt)))
+
+
+_lib = None
+
+
+def lib():
+    """Load the library (raises if it was not built -- run __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    fp, sz, vp = C.POINTER(C.c_float), C.c_size_t, C.c_void_p
+    cfgp = C.POINTER(L2ZConfig)
+    i32p, ip = C.POINTER(C.c_int32), C.POINTER(C.c_int)
+    L.l2z_last_error.restype = C.c_char_p
+    L.l2z_device_count.argtypes = [ip]
+    L.l2z_device_info.argtypes = [C.c_int, C.c_char_p, sz, ip, C.POINTER(C.c_uint64)]
+    L.l2z_weights_init.argtypes = [cfgp, fp, sz, C.c_int, vp, C.POINTER(vp)]
+    L.l2z_weights_init_synthetic.argtypes = [cfgp, C.c_int, C.c_uint64, vp, C.POINTER(vp)]
+    L.l2z_weights_read.argtypes = [vp, sz, sz, fp]
+    L.l2z_weights_free.argtypes = [vp]
+    L.l2z_weights_free.restype = None
+    L.l2z_runstate_init.argtypes = [cfgp, vp, C.POINTER(vp)]
+    L.l2z_runstate_free.argtypes = [vp]
+    L.l2z_runstate_free.restype = None
+    L.l2z_transformer.argtypes = [C.c_int, C.c_int, cfgp, vp, vp]
+    L.l2z_argmax.argtypes = [vp, ip]
+    L.l2z_logits_read.argtypes = [vp, fp]
+    L.l2z_runstate_read.argtypes = [vp, C.c_char_p, sz, sz, fp]
+    L.l2z_greedy_begin.argtypes = [vp, i32p, C.c_int]
+    L.l2z_greedy_run.argtypes = [cfgp, vp, vp, C.c_int, i32p, ip]
+    L.l2z_profile_forward.argtypes = [C.c_int, C.c_int, cfgp, vp, vp, C.POINTER(C.c_double), ip,
+                                      C.c_int]
+    L.l2z_kind_name.argtypes = [C.c_int, C.c_char_p, sz]
+    L.l2z_synchronize.argtypes = [vp]
+    L.l2z_matmul.argtypes = [fp, fp, fp, sz, sz]
+    L.l2z_matmul_fused.argtypes = [C.c_int, C.POINTER(fp), fp, C.POINTER(fp), sz, sz]
+    L.l2z_rmsnorm.argtypes = [fp, fp, fp, sz]
+    L.l2z_softmax.argtypes = [fp, sz]
+    L.l2z_vector_dot_product.argtypes = [fp, fp, fp, sz]
+    L.l2z_vector_weighted_sum_rows.argtypes = [fp, sz, fp, sz, sz, fp, sz]
+    L.l2z_argmax_host.argtypes = [fp, sz, C.POINTER(sz)]
+    L.l2z_comm_unique_id.argtypes = [vp]
+    L.l2z_comm_init.argtypes = [C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp)]
+    L.l2z_comm_rank.argtypes = [vp, ip, ip]
+    L.l2z_comm_free.argtypes = [vp]
+    L.l2z_comm_free.restype = None
+    L.l2z_shard_range.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64),
+                                  C.POINTER(C.c_int64)]
+    _lib = L
+    return L
+
+
+def _chk(code: int) -> None:
+    if code != OK:
+        raise L2ZError(code, lib().l2z_last_error().decode(errors="replace"))
+
+
+def _fp(a: np.ndarray):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _chk(lib().l2z_device_count(C.byref(n)))
+    return n.value
+
+
+def device_info(dev: int = 0):
+    name = C.create_string_buffer(256)
+    cus, hbm = C.c_int(0), C.c_uint64(0)
+    _chk(lib().l2z_device_info(dev, name, 256, C.byref(cus), C.byref(hbm)))
+    return name.value.decode(), cus.value, hbm.value
+
+
+def shard_range(rows: int, granule: int, rank: int, world: int):
+    r0, r1 = C.c_int64(0), C.c_int64(0)
+    _chk(lib().l2z_shard_range(rows, granule, rank, world, C.byref(r0), C.byref(r1)))
+    return r0.value, r1.value
+
+
+def _cfg(cfg) -> L2ZConfig:
+    if isinstance(cfg, L2ZConfig):
+        return cfg
+    vals = cfg.as_i32() if hasattr(cfg, "as_i32") else cfg
+    return L2ZConfig(*[int(v) for v in vals])
+
+
+class Comm:
+    """Multi-GPU shard group (l2z_comm_*)."""
+
+    def __init__(self, rank: int, world: int, uid: bytes | None, device: int):
+        self.h = C.c_void_p()
+        buf = C.create_string_buffer(uid, COMM_ID_BYTES) if uid is not None else None
+        _chk(lib().l2z_comm_init(rank, world, buf, device, C.byref(self.h)))
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        _chk(lib().l2z_comm_unique_id(buf))
+        return buf.raw
+
+    def close(self):
+        if self.h:
+            lib().l2z_comm_free(self.h)
+            self.h = C.c_void_p()
+
+
+class Weights:
+    """src/main.zig:53 Weights, device resident."""
+
+    def __init__(self, cfg, blob: np.ndarray | None, shared: bool, *, seed: int | None = None,
+                 comm: Comm | None = None):
+        self.cfg = _cfg(cfg)
+        self.h = C.c_void_p()
+        ch = comm.h if comm is not None else None
+        if blob is not None:
+            b = blob if (blob.dtype == np.float32 and blob.flags["C_CONTIGUOUS"]) else _f32(blob)
+            _chk(lib().l2z_weights_init(C.byref(self.cfg), _fp(b), b.size, int(shared), ch,
+                                        C.byref(self.h)))
+        else:
+            assert seed is not None
+            _chk(lib().l2z_weights_init_synthetic(C.byref(self.cfg), int(shared), seed, ch,
+                                                  C.byref(self.h)))
+
+    def read(self, offset: int, count: int) -> np.ndarray:
+        out = np.empty(count, np.float32)
+        _chk(lib().l2z_weights_read(self.h, offset, count, _fp(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().l2z_weights_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RunState:
+    """src/main.zig:119 RunState, device resident."""
+
+    def __init__(self, cfg, comm: Comm | None = None):
+        self.cfg = _cfg(cfg)
+        self.h = C.c_void_p()
+        _chk(lib().l2z_runstate_init(C.byref(self.cfg), comm.h if comm is not None else None,
+                                     C.byref(self.h)))
+
+    def transformer(self, token: int, pos: int, w: Weights) -> None:
+        """src/main.zig:285"""
+        _chk(lib().l2z_transformer(token, pos, C.byref(self.cfg), self.h, w.h))
+
+    def argmax(self) -> int:
+        t = C.c_int(0)
+        _chk(lib().l2z_argmax(self.h, C.byref(t)))
+        return t.value
+
+    def logits(self) -> np.ndarray:
+        out = np.empty(self.cfg.vocab_size, np.float32)
+        _chk(lib().l2z_logits_read(self.h, _fp(out)))
+        return out
+
+    def read(self, name: str, offset: int, count: int) -> np.ndarray:
+        out = np.empty(count, np.float32)
+        _chk(lib().l2z_runstate_read(self.h, name.encode(), offset, count, _fp(out)))
+        return out
+
+    def greedy_begin(self, prompt=()) -> None:
+        p = np.ascontiguousarray(prompt, np.int32)
+        _chk(lib().l2z_greedy_begin(self.h, p.ctypes.data_as(C.POINTER(C.c_int32)), p.size))
+
+    def greedy_run(self, w: Weights, n_steps: int) -> np.ndarray:
+        out = np.zeros(max(n_steps, 1), np.int32)
+        n = C.c_int(0)
+        _chk(lib().l2z_greedy_run(C.byref(self.cfg), self.h, w.h, n_steps,
+                                  out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n)))
+        return out[: n.value].copy()
+
+    def profile_forward(self, token: int, pos: int, w: Weights):
+        ms = (C.c_double * len(KINDS))()
+        cnt = (C.c_int * len(KINDS))()
+        _chk(lib().l2z_profile_forward(token, pos, C.byref(self.cfg), self.h, w.h, ms, cnt,
+                                       len(KINDS)))
+        return {k: (ms[i], cnt[i]) for i, k in enumerate(KINDS)}
+
+    def synchronize(self) -> None:
+        _chk(lib().l2z_synchronize(self.h))
+
+    def close(self):
+        if self.h:
+            lib().l2z_runstate_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- kernel-level hooks (names follow src/main.zig) ----
+def matmul(x, w) -> np.ndarray:
+    x, w = _f32(x), _f32(w)
+    d, n = w.shape
+    out = np.empty(d, np.float32)
+    _chk(lib().l2z_matmul(_fp(out), _fp(x), _fp(w), n, d))
+    return out
+
+
+def matmul_fused(x, ws) -> list[np.ndarray]:
+    x = _f32(x)
+    ws = [_f32(w) for w in ws]
+    d, n = ws[0].shape
+    outs = [np.empty(d, np.float32) for _ in ws]
+    FP = C.POINTER(C.c_float)
+    N = len(ws)
+    _chk(lib().l2z_matmul_fused(N, (FP * N)(*[_fp(o) for o in outs]), _fp(x),
+                                (FP * N)(*[_fp(w) for w in ws]), n, d))
+    return outs
+
+
+def rmsnorm(x, w) -> np.ndarray:
+    x, w = _f32(x), _f32(w)
+    o = np.empty_like(x)
+    _chk(lib().l2z_rmsnorm(_fp(o), _fp(x), _fp(w), x.size))
+    return o
+
+
+def softmax(x) -> np.ndarray:
+    o = np.array(x, np.float32, copy=True)
+    _chk(lib().l2z_softmax(_fp(o), o.size))
+    return o
+
+
+def vector_dot_product(x, y) -> np.float32:
+    x, y = _f32(x), _f32(y)
+    o = np.zeros(1, np.float32)
+    _chk(lib().l2z_vector_dot_product(_fp(o), _fp(x), _fp(y), x.size))
+    return o[0]
+
+
+def vector_weighted_sum_rows(xout_len: int, rows, row_stride: int, weights) -> np.ndarray:
+    rows, weights = _f32(rows), _f32(weights)
+    o = np.empty(xout_len, np.float32)
+    _chk(lib().l2z_vector_weighted_sum_rows(_fp(o), xout_len, _fp(rows), rows.size, row_stride,
+                                            _fp(weights), weights.size))
+    return o
+
+
+def argmax(x) -> int:
+    x = _f32(x)
+    i = C.c_size_t(0)
+    _chk(lib().l2z_argmax_host(_fp(x), x.size, C.byref(i)))
+    return int(i.value)

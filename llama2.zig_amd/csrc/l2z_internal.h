@@ -1,0 +1,120 @@
+// l2z_internal.h -- shared declarations for the HIP forward-pass library.
+// Product code: never includes anything under oracle/.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/llama2_hip.h"
+
+namespace l2z {
+
+void set_error(const char *fmt, ...);
+
+#define L2Z_HIP(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            ::l2z::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
+                             __FILE__, __LINE__);                                        \
+            return _e == hipErrorOutOfMemory ? L2Z_ERR_OOM                               \
+                   : (_e == hipErrorNoDevice || _e == hipErrorInvalidDevice)             \
+                       ? L2Z_ERR_NO_DEVICE                                               \
+                       : L2Z_ERR_HIP;                                                    \
+        }                                                                                \
+    } while (0)
+
+#define L2Z_CHECK(cond, code, ...)          \
+    do {                                    \
+        if (!(cond)) {                      \
+            ::l2z::set_error(__VA_ARGS__);  \
+            return (code);                  \
+        }                                   \
+    } while (0)
+
+#define L2Z_TRY(expr)              \
+    do {                           \
+        int _s = (expr);           \
+        if (_s != L2Z_OK) return _s; \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// Kernel argument blocks (passed by value; all pointers are device pointers)
+// ---------------------------------------------------------------------------
+
+enum Prologue { PRO_NONE = 0, PRO_RMS = 1 };
+enum Epilogue { EPI_STORE = 0, EPI_ROPE = 1, EPI_RESID = 2, EPI_SWIGLU = 3 };
+
+constexpr int kMaxSeg = 3;
+
+// One fused mat-vec launch: up to 3 row-major (rows[j], n) matrices sharing x.
+// main.zig:530 matmul_fused(N) -- plus what the reference does right before
+// (rmsnorm, :305/:398/:426) and right after (RoPE+KV write :336-358, accum
+// :395/:422, SiLU*mul :411-416) each call.
+struct MatvecArgs {
+    const float *w[kMaxSeg];
+    float *out[kMaxSeg];
+    int rows[kMaxSeg];
+    int pos_stride[kMaxSeg];  // out[j] += pos * pos_stride[j] (KV-cache row select)
+    int nseg;
+    int n;                    // columns = length of x
+    const float *x;
+    const float *rms_w;       // PRO_RMS: rmsnorm weight (n)
+    const float *resid;       // EPI_RESID: out = resid + W.x (may alias out[0])
+    const int *pos_ptr;       // device int: current position
+    const float2 *rope;       // (seq_len, head_size/2) {cos, sin}
+    int head_size;
+    int rope_segs;            // leading segments that get rotated (q, k -> 2)
+};
+
+// main.zig:361-389: scores, softmax, att.V for the local heads of one layer
+struct AttnArgs {
+    const float *q;        // (n_heads_local * head_size)
+    const float *kcache;   // this layer: (seq_len, kv_dim_local)
+    const float *vcache;
+    float *xb;             // (n_heads_local * head_size)
+    const int *pos_ptr;
+    int head_size;
+    int kv_dim;            // local row stride of the caches
+    int kv_mul;
+    int seq_len;
+};
+
+// main.zig:715 argmax + main.zig:999-1000,1036 hand-over to the next step
+struct ArgmaxArgs {
+    const float *logits;
+    int vocab;
+    int *token_ptr;          // in/out: current token
+    int *pos_ptr;            // in/out
+    const int *prompt;       // forced tokens (n_prompt)
+    const int *n_prompt_ptr;
+    int *out_tokens;         // out_tokens[pos] = next
+    int *argmax_out;         // plain argmax result
+    const float *tok_emb;    // (vocab, dim): next step's embedding row -> x
+    float *x;
+    int dim;
+    int advance;             // 1: greedy step (write token/pos/x), 0: argmax only
+};
+
+// Launchers (kernels.hip).  All return a hipError_t from the launch.
+hipError_t launch_matvec(const MatvecArgs &a, int pro, int epi, int max_blocks, hipStream_t st);
+hipError_t launch_attention(const AttnArgs &a, int n_heads_local, hipStream_t st);
+hipError_t launch_argmax(const ArgmaxArgs &a, hipStream_t st);
+hipError_t launch_set_state(int token, int pos, int *token_ptr, int *pos_ptr, const float *tok_emb,
+                            float *x, int dim, hipStream_t st);
+hipError_t launch_rmsnorm(float *o, const float *x, const float *w, int n, hipStream_t st);
+hipError_t launch_softmax(float *x, int n, hipStream_t st);
+hipError_t launch_dot(float *out, const float *x, const float *y, int n, hipStream_t st);
+hipError_t launch_weighted_sum_rows(float *xout, int xout_len, const float *rows, int row_stride,
+                                    const float *weights, int n_weights, hipStream_t st);
+hipError_t launch_synth_fill(float *dst, uint64_t base_idx, uint64_t count, uint64_t seed,
+                             float scale, float bias, hipStream_t st);
+size_t attention_lds_bytes(int head_size, int seq_len, bool vec);
+size_t matvec_lds_bytes(int n);
+
+}  // namespace l2z

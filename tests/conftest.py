@@ -1,0 +1,51 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import __graft_entry__ as ge  # noqa: E402
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return ge.load_package()
+
+
+@pytest.fixture(scope="session")
+def ck(pkg):
+    return pkg.checkpoint
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU oracle (C restatement of src/main.zig) -- the checker."""
+    o = ge.load_oracle()
+    o.lib()
+    yield o
+    o.set_mode(8, False, False)
+
+
+@pytest.fixture(scope="session")
+def B(pkg):
+    """ctypes binding over libllama2_hip.so; builds it if missing."""
+    if not os.path.exists(pkg.binding.LIB_PATH):
+        ge.build()
+    pkg.binding.lib()
+    return pkg.binding
+
+
+@pytest.fixture(scope="session")
+def gpu(B):
+    """The HIP path.  Fails (does not skip) when no device is visible: GPU tests
+    must never pass on a fallback."""
+    n = B.device_count()
+    assert n >= 1, "gpu-marked test started without a HIP device"
+    return B
