@@ -534,13 +534,13 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         float *vc = s->value_cache + (size_t)l * c.seq_len * sh.kvd_loc;
         {   // rmsnorm (:305) + q,k,v (:308-320) + RoPE (:336-351) + KV write (:354-358)
             MatvecArgs a = {};
-            a.w[0] = w->wq + (size_t)l * sh.dim_loc * dim;
-            a.w[1] = w->wk + (size_t)l * sh.kvd_loc * dim;
-            a.w[2] = w->wv + (size_t)l * sh.kvd_loc * dim;
-            a.out[0] = s->q; a.out[1] = kc; a.out[2] = vc;
-            a.rows[0] = sh.dim_loc; a.rows[1] = sh.kvd_loc; a.rows[2] = sh.kvd_loc;
-            a.pos_stride[0] = 0; a.pos_stride[1] = sh.kvd_loc; a.pos_stride[2] = sh.kvd_loc;
-            a.nseg = 3; a.n = c.dim; a.x = s->x; a.rms_w = w->rms_att + (size_t)l * dim;
+            a.w0 = w->wq + (size_t)l * sh.dim_loc * dim;
+            a.w1 = w->wk + (size_t)l * sh.kvd_loc * dim;
+            a.w2 = w->wv + (size_t)l * sh.kvd_loc * dim;
+            a.out0 = s->q; a.out1 = kc; a.out2 = vc;
+            a.rows0 = sh.dim_loc; a.rows1 = sh.kvd_loc; a.rows2 = sh.kvd_loc;
+            a.pos_stride1 = sh.kvd_loc; a.pos_stride2 = sh.kvd_loc;
+            a.n = c.dim; a.x = s->x; a.rms_w = w->rms_att + (size_t)l * dim;
             a.pos_ptr = s->d_pos; a.rope = s->rope; a.head_size = sh.hs; a.rope_segs = 2;
             L2Z_LAUNCH(KIND_QKV, launch_matvec(a, PRO_RMS, EPI_ROPE, mb, st));
         }
@@ -554,35 +554,35 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         L2Z_TRY(comm_allgather_inplace(s->comm, s->xb, sh.dim_loc, st));
         {   // wo (:392) + residual (:395)
             MatvecArgs a = {};
-            a.w[0] = w->wo + (size_t)l * sh.dim_loc * dim;
-            a.out[0] = s->x + sh.dim0; a.resid = s->x + sh.dim0;
-            a.rows[0] = sh.dim_loc; a.nseg = 1; a.n = c.dim; a.x = s->xb;
+            a.w0 = w->wo + (size_t)l * sh.dim_loc * dim;
+            a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0;
+            a.rows0 = sh.dim_loc; a.n = c.dim; a.x = s->xb;
             L2Z_LAUNCH(KIND_WO, launch_matvec(a, PRO_NONE, EPI_RESID, mb, st));
         }
         L2Z_TRY(comm_allgather_inplace(s->comm, s->x, sh.dim_loc, st));
         {   // rmsnorm (:398) + w1,w3 (:405-408) + SiLU*mul (:411-416)
             MatvecArgs a = {};
-            a.w[0] = w->w1 + (size_t)l * sh.hid_loc * dim;
-            a.w[1] = w->w3 + (size_t)l * sh.hid_loc * dim;
-            a.out[0] = s->hb + sh.hid0;
-            a.rows[0] = sh.hid_loc; a.rows[1] = sh.hid_loc; a.nseg = 2; a.n = c.dim;
+            a.w0 = w->w1 + (size_t)l * sh.hid_loc * dim;
+            a.w1 = w->w3 + (size_t)l * sh.hid_loc * dim;
+            a.out0 = s->hb + sh.hid0;
+            a.rows0 = sh.hid_loc; a.rows1 = sh.hid_loc; a.n = c.dim;
             a.x = s->x; a.rms_w = w->rms_ffn + (size_t)l * dim;
             L2Z_LAUNCH(KIND_FFN13, launch_matvec(a, PRO_RMS, EPI_SWIGLU, mb, st));
         }
         L2Z_TRY(comm_allgather_inplace(s->comm, s->hb, sh.hid_loc, st));
         {   // w2 (:419) + residual (:422)
             MatvecArgs a = {};
-            a.w[0] = w->w2 + (size_t)l * sh.dim_loc * hid;
-            a.out[0] = s->x + sh.dim0; a.resid = s->x + sh.dim0;
-            a.rows[0] = sh.dim_loc; a.nseg = 1; a.n = c.hidden_dim; a.x = s->hb;
+            a.w0 = w->w2 + (size_t)l * sh.dim_loc * hid;
+            a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0;
+            a.rows0 = sh.dim_loc; a.n = c.hidden_dim; a.x = s->hb;
             L2Z_LAUNCH(KIND_FFN2, launch_matvec(a, PRO_NONE, EPI_RESID, mb, st));
         }
         L2Z_TRY(comm_allgather_inplace(s->comm, s->x, sh.dim_loc, st));
     }
     {   // final rmsnorm (:426) + classifier (:429)
         MatvecArgs a = {};
-        a.w[0] = w->wcls; a.out[0] = s->logits + sh.v0;
-        a.rows[0] = sh.v_loc; a.nseg = 1; a.n = c.dim; a.x = s->x; a.rms_w = w->rms_final;
+        a.w0 = w->wcls; a.out0 = s->logits + sh.v0;
+        a.rows0 = sh.v_loc; a.n = c.dim; a.x = s->x; a.rms_w = w->rms_final;
         L2Z_LAUNCH(KIND_CLS, launch_matvec(a, PRO_RMS, EPI_STORE, mb, st));
     }
     L2Z_TRY(comm_allgather_inplace(s->comm, s->logits, sh.v_loc, st));
@@ -844,13 +844,15 @@ extern "C" int l2z_matmul_fused(int N, float *const *outs, const float *x, const
     L2Z_TRY(dx.alloc(n));
     L2Z_TRY(dx.up(x, n));
     MatvecArgs a = {};
-    a.nseg = N; a.n = (int)n; a.x = dx.p;
+    a.n = (int)n; a.x = dx.p;
     for (int j = 0; j < N; j++) {
         L2Z_TRY(dw[j].alloc(n * d));
         L2Z_TRY(dw[j].up(ws[j], n * d));
         L2Z_TRY(dout[j].alloc(d));
-        a.w[j] = dw[j].p; a.out[j] = dout[j].p; a.rows[j] = (int)d;
     }
+    a.w0 = dw[0].p; a.out0 = dout[0].p; a.rows0 = (int)d;
+    if (N > 1) { a.w1 = dw[1].p; a.out1 = dout[1].p; a.rows1 = (int)d; }
+    if (N > 2) { a.w2 = dw[2].p; a.out2 = dout[2].p; a.rows2 = (int)d; }
     L2Z_HIP(launch_matvec(a, PRO_NONE, EPI_STORE, g_cus * 8, nullptr));
     L2Z_HIP(hipDeviceSynchronize());
     for (int j = 0; j < N; j++) L2Z_TRY(dout[j].down(outs[j], d));

@@ -138,67 +138,48 @@ __device__ __forceinline__ void stage_x(const float *__restrict__ x, const float
     __syncthreads();
 }
 
-// Resolve a row index in the concatenated row space of the launch's segments.
-__device__ __forceinline__ void resolve_row(const MatvecArgs &a, int g, int &seg, int &row)
-{
-    seg = 0;
-    if (a.nseg > 1 && g >= a.rows[0]) {
-        g -= a.rows[0];
-        seg = 1;
-        if (a.nseg > 2 && g >= a.rows[1]) {
-            g -= a.rows[1];
-            seg = 2;
-        }
-    }
-    row = g;
-}
-
-__device__ __forceinline__ const float *seg_w(const MatvecArgs &a, int seg)
-{
-    return seg == 0 ? a.w[0] : (seg == 1 ? a.w[1] : a.w[2]);
-}
-__device__ __forceinline__ float *seg_out(const MatvecArgs &a, int seg, int pos)
-{
-    float *o = seg == 0 ? a.out[0] : (seg == 1 ? a.out[1] : a.out[2]);
-    const int ps = seg == 0 ? a.pos_stride[0] : (seg == 1 ? a.pos_stride[1] : a.pos_stride[2]);
-    return o + (size_t)pos * (size_t)ps;
-}
-
 // Two dot products against the staged x: rows pa and pb.  main.zig:553-604,
 // summation order: lane l takes float4 columns l, l+64, ... in increasing
 // order into 4 component accumulators, then (x+y)+(z+w), then xor-shuffle.
+// The order depends only on n, never on the grid or on how rows are sharded.
 template <bool VEC>
 __device__ __forceinline__ void dot2(const float *__restrict__ pa, const float *__restrict__ pb,
                                      const float *xs, int n, float &ra, float &rb)
 {
     const int lane = threadIdx.x & 63;
     if (VEC) {
-        constexpr int U = 4;
-        const v4f *a4 = (const v4f *)pa;
-        const v4f *b4 = (const v4f *)pb;
-        const v4f *xs4 = (const v4f *)xs;
+        constexpr int U = 4;  // 2 rows x 4 x 16 B = 8 loads (8 KiB per wave) in flight
+        const v4f *a4 = (const v4f *)pa + lane;
+        const v4f *b4 = (const v4f *)pb + lane;
+        const v4f *xs4 = (const v4f *)xs + lane;
         const int n4 = n >> 2;
         v4f acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
         int j = lane;
         for (; j + kWave * (U - 1) < n4; j += kWave * U) {
             v4f wa[U], wb[U];
 #pragma unroll
-            for (int k = 0; k < U; k++) {
-                wa[k] = ldg_nt(a4 + j + kWave * k);
-                wb[k] = ldg_nt(b4 + j + kWave * k);
+            for (int k = 0; k < U; k++) {  // constant 1 KiB strides -> immediate offsets
+                wa[k] = ldg_nt(a4 + kWave * k);
+                wb[k] = ldg_nt(b4 + kWave * k);
             }
 #pragma unroll
             for (int k = 0; k < U; k++) {
-                const v4f xv = xs4[j + kWave * k];
+                const v4f xv = xs4[kWave * k];
                 acc_a = fma4(wa[k], xv, acc_a);
                 acc_b = fma4(wb[k], xv, acc_b);
             }
+            a4 += kWave * U;
+            b4 += kWave * U;
+            xs4 += kWave * U;
         }
         for (; j < n4; j += kWave) {
-            const v4f wa = ldg_nt(a4 + j), wb = ldg_nt(b4 + j);
-            const v4f xv = xs4[j];
+            const v4f wa = ldg_nt(a4), wb = ldg_nt(b4);
+            const v4f xv = *xs4;
             acc_a = fma4(wa, xv, acc_a);
             acc_b = fma4(wb, xv, acc_b);
+            a4 += kWave;
+            b4 += kWave;
+            xs4 += kWave;
         }
         ra = wave_sum(hsum4(acc_a));
         rb = wave_sum(hsum4(acc_b));
@@ -220,6 +201,9 @@ __device__ __forceinline__ void dot2(const float *__restrict__ pa, const float *
 //   EPI_ROPE   RoPE on q,k + KV-cache row write    :336-358
 //   EPI_RESID  accum into the residual stream      :395 / :422
 //   EPI_SWIGLU silu(w1.x) * (w3.x)                 :411-416
+// All kernel arguments are read into scalars up front and selected with plain
+// arithmetic: indexing the by-value argument block dynamically would push it
+// into scratch memory (136 B/lane and half the occupancy in the first build).
 // ---------------------------------------------------------------------------
 template <int PRO, int EPI, bool VEC>
 __global__ __launch_bounds__(kBlock) void matvec_kernel(const MatvecArgs a)
@@ -231,27 +215,40 @@ __global__ __launch_bounds__(kBlock) void matvec_kernel(const MatvecArgs a)
     stage_x<PRO, VEC>(a.x, a.rms_w, n, xs, scratch);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int total_rows = a.rows[0];
-    if (a.nseg > 1) total_rows += a.rows[1];
-    if (a.nseg > 2) total_rows += a.rows[2];
-    const int n_units = (EPI == EPI_SWIGLU) ? a.rows[0] : (total_rows + 1) >> 1;
-    const int pos = (EPI == EPI_ROPE || a.pos_ptr != nullptr) ? *a.pos_ptr : 0;
+    const float *const w0 = a.w0, *const w1 = a.w1, *const w2 = a.w2;
+    float *const out0 = a.out0, *const out1 = a.out1, *const out2 = a.out2;
+    const int rows0 = a.rows0, rows1 = a.rows1, rows2 = a.rows2;
+    const int total_rows = rows0 + rows1 + rows2;
+    const int n_units = (EPI == EPI_SWIGLU) ? rows0 : (total_rows + 1) >> 1;
+    const int pos = (EPI == EPI_ROPE) ? *a.pos_ptr : 0;
+    const size_t ps1 = (size_t)pos * (size_t)a.pos_stride1, ps2 = (size_t)pos * (size_t)a.pos_stride2;
 
     for (int u = blockIdx.x * kWaves + wave; u < n_units; u += gridDim.x * kWaves) {
-        int seg_a, row_a, seg_b, row_b;
+        // rows ga, gb in the concatenated row space [0, rows0+rows1+rows2)
+        const float *pa, *pb;
+        float *oa, *ob;
+        int row_a, row_b, seg_a;
         bool valid_b = true;
         if (EPI == EPI_SWIGLU) {
-            seg_a = 0; row_a = u; seg_b = 1; row_b = u;
+            row_a = u; row_b = u; seg_a = 0;
+            pa = w0 + (size_t)u * (size_t)n;
+            pb = w1 + (size_t)u * (size_t)n;
+            oa = out0; ob = out0;
         } else {
-            resolve_row(a, 2 * u, seg_a, row_a);
-            if (2 * u + 1 < total_rows) {
-                resolve_row(a, 2 * u + 1, seg_b, row_b);
-            } else {
-                seg_b = seg_a; row_b = row_a; valid_b = false;
-            }
+            const int ga = 2 * u;
+            int gb = ga + 1;
+            if (gb >= total_rows) { gb = ga; valid_b = false; }
+            // segment select by comparison arithmetic on scalars (no indexed loads)
+            const bool a1 = ga >= rows0, a2 = ga >= rows0 + rows1;
+            const bool b1 = gb >= rows0, b2 = gb >= rows0 + rows1;
+            row_a = ga - (a2 ? rows0 + rows1 : (a1 ? rows0 : 0));
+            row_b = gb - (b2 ? rows0 + rows1 : (b1 ? rows0 : 0));
+            seg_a = a2 ? 2 : (a1 ? 1 : 0);
+            pa = (a2 ? w2 : (a1 ? w1 : w0)) + (size_t)row_a * (size_t)n;
+            pb = (b2 ? w2 : (b1 ? w1 : w0)) + (size_t)row_b * (size_t)n;
+            oa = a2 ? out2 + ps2 : (a1 ? out1 + ps1 : out0);
+            ob = b2 ? out2 + ps2 : (b1 ? out1 + ps1 : out0);
         }
-        const float *pa = seg_w(a, seg_a) + (size_t)row_a * (size_t)n;
-        const float *pb = seg_w(a, seg_b) + (size_t)row_b * (size_t)n;
         float sa, sb;
         dot2<VEC>(pa, pb, xs, n, sa, sb);
 
@@ -259,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void matvec_kernel(const MatvecArgs a)
             float v = sa;
             v = v * (1.0f / (1.0f + expf(-v)));  // :412
             v = v * sb;                          // :416
-            if (lane == 0) a.out[0][u] = v;
+            if (lane == 0) oa[u] = v;
         } else if (EPI == EPI_ROPE) {
             // rows (row_a, row_a+1) of one segment: the pair (i, i+1) of :346-349
             float o0 = sa, o1 = sb;
@@ -269,21 +266,19 @@ __global__ __launch_bounds__(kBlock) void matvec_kernel(const MatvecArgs a)
                 o0 = sa * cs.x - sb * cs.y;  // :348
                 o1 = sa * cs.y + sb * cs.x;  // :349
             }
+            if (lane == 0) {  // q, or the pos row of the K / V cache (:354-358)
+                oa[row_a] = o0;
+                if (valid_b) ob[row_b] = o1;
+            }
+        } else if (EPI == EPI_RESID) {
             if (lane == 0) {
-                float *o = seg_out(a, seg_a, pos);  // q, or the pos row of the K / V cache (:354-358)
-                o[row_a] = o0;
-                if (valid_b) o[row_b] = o1;
+                oa[row_a] = a.resid[row_a] + sa;  // :711 a[i] += b[i]
+                if (valid_b) ob[row_b] = a.resid[row_b] + sb;
             }
         } else {
             if (lane == 0) {
-                float *oa = seg_out(a, seg_a, pos);
-                if (EPI == EPI_RESID) {
-                    oa[row_a] = a.resid[row_a] + sa;  // :711 a[i] += b[i]
-                    if (valid_b) seg_out(a, seg_b, pos)[row_b] = a.resid[row_b] + sb;
-                } else {
-                    oa[row_a] = sa;
-                    if (valid_b) seg_out(a, seg_b, pos)[row_b] = sb;
-                }
+                oa[row_a] = sa;
+                if (valid_b) ob[row_b] = sb;
             }
         }
     }
@@ -583,14 +578,13 @@ size_t attention_lds_bytes(int head_size, int seq_len, bool vec)
 
 hipError_t launch_matvec(const MatvecArgs &a, int pro, int epi, int max_blocks, hipStream_t st)
 {
-    bool vec = (a.n % 4) == 0 && aligned16(a.x);
-    int total_rows = 0;
-    for (int j = 0; j < a.nseg; j++) {
-        vec = vec && aligned16(a.w[j]);
-        total_rows += a.rows[j];
-    }
+    bool vec = (a.n % 4) == 0 && aligned16(a.x) && aligned16(a.w0);
+    if (a.rows1 > 0) vec = vec && aligned16(a.w1);
+    if (a.rows2 > 0) vec = vec && aligned16(a.w2);
     if (pro == PRO_RMS) vec = vec && aligned16(a.rms_w);
-    const int n_units = (epi == EPI_SWIGLU) ? a.rows[0] : (total_rows + 1) / 2;
+    if (epi == EPI_SWIGLU && a.rows1 != a.rows0) return hipErrorInvalidValue;
+    const int total_rows = a.rows0 + a.rows1 + a.rows2;
+    const int n_units = (epi == EPI_SWIGLU) ? a.rows0 : (total_rows + 1) / 2;
     if (n_units <= 0) return hipErrorInvalidValue;
     // Even split: every wave gets the same number of units (+-1).
     int blocks_needed = (n_units + kWaves - 1) / kWaves;

@@ -52,21 +52,21 @@ enum Epilogue { EPI_STORE = 0, EPI_ROPE = 1, EPI_RESID = 2, EPI_SWIGLU = 3 };
 
 constexpr int kMaxSeg = 3;
 
-// One fused mat-vec launch: up to 3 row-major (rows[j], n) matrices sharing x.
+// One fused mat-vec launch: up to 3 row-major (rowsJ, n) matrices sharing x.
 // main.zig:530 matmul_fused(N) -- plus what the reference does right before
 // (rmsnorm, :305/:398/:426) and right after (RoPE+KV write :336-358, accum
-// :395/:422, SiLU*mul :411-416) each call.
+// :395/:422, SiLU*mul :411-416) each call.  Named scalar fields on purpose:
+// arrays here get indexed dynamically by the optimiser and land in scratch.
 struct MatvecArgs {
-    const float *w[kMaxSeg];
-    float *out[kMaxSeg];
-    int rows[kMaxSeg];
-    int pos_stride[kMaxSeg];  // out[j] += pos * pos_stride[j] (KV-cache row select)
-    int nseg;
+    const float *w0, *w1, *w2;   // unused segments: null, rows = 0
+    float *out0, *out1, *out2;
+    int rows0, rows1, rows2;
+    int pos_stride1, pos_stride2;  // out1/out2 += pos * stride (KV-cache row select)
     int n;                    // columns = length of x
     const float *x;
     const float *rms_w;       // PRO_RMS: rmsnorm weight (n)
-    const float *resid;       // EPI_RESID: out = resid + W.x (may alias out[0])
-    const int *pos_ptr;       // device int: current position
+    const float *resid;       // EPI_RESID: out = resid + W.x (may alias out0)
+    const int *pos_ptr;       // EPI_ROPE: device int, current position
     const float2 *rope;       // (seq_len, head_size/2) {cos, sin}
     int head_size;
     int rope_segs;            // leading segments that get rotated (q, k -> 2)
