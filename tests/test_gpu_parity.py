@@ -289,3 +289,23 @@ def test_errors_are_loud(gpu, ck):
     with pytest.raises(gpu.L2ZError):
         s.transformer(cfg.vocab_size, 0, w)  # token out of range
     s.close(); w.close()
+
+
+# ---------------------------------------------------------------- committed golden fixtures
+def test_golden_toy_checkpoints_on_gpu(gpu, ck):
+    """tests/golden/*.bin through l2z_weights_init (file layout) -> token ids identical to
+    the committed expectation, logits within tolerance."""
+    import json
+    import os
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    meta = json.load(open(os.path.join(gdir, "toy_models.json")))
+    for ent in meta["models"]:
+        c, shared, blob = ck.read_checkpoint(os.path.join(gdir, ent["checkpoint"]))
+        exp = np.load(os.path.join(gdir, ent["expected"]))
+        w, s = gpu.Weights(c, np.asarray(blob), shared), gpu.RunState(c)
+        s.greedy_begin(ent["prompt"])
+        assert s.greedy_run(w, c.seq_len).tolist() == exp["tokens"].tolist()
+        for pos, t in enumerate(exp["fed_tokens"]):
+            s.transformer(int(t), pos, w)
+            np.testing.assert_allclose(s.logits(), exp["logits"][pos], rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
+        s.close(); w.close()
