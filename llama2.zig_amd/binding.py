@@ -14,7 +14,7 @@ import re
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libllama2_hip.so")
+LIB_PATH = os.environ.get("L2Z_LIB") or os.path.join(_HERE, "libllama2_hip.so")  # L2Z_LIB: A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "llama2_hip.h")
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_COMM, ERR_STATE = 0, -1, -2, -3, -4, -5, -6

@@ -188,6 +188,9 @@ struct l2z_runstate {
     // loop state on the device
     int *d_token = nullptr, *d_pos = nullptr, *d_prompt = nullptr, *d_n_prompt = nullptr;
     int *d_out_tokens = nullptr, *d_argmax = nullptr;
+    float *d_part_val = nullptr;  // classifier launch's per-block argmax candidates
+    int *d_part_idx = nullptr;
+    int n_part = 0;               // 0: argmax scans the logits instead
     // graphs, keyed by the weights they were captured with
     const l2z_weights *graph_w = nullptr;
     hipGraphExec_t g_forward = nullptr, g_step = nullptr;
@@ -410,10 +413,10 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
     s->device = dev;
     s->sh = sh;
     s->comm = comm;
-    s->max_blocks = g_cus * 8;
+    s->max_blocks = 8;  // per CU; the launcher also caps at the occupancy query
     if (const char *e = getenv("L2Z_MAX_BLOCKS_PER_CU")) {
         const int v = atoi(e);
-        if (v > 0) s->max_blocks = g_cus * v;
+        if (v > 0) s->max_blocks = v;
     }
     if (const char *e = getenv("L2Z_NO_GRAPH")) s->use_graphs = atoi(e) == 0;
     if (comm && comm->world > 1) s->use_graphs = false;  // RCCL calls are launched eagerly
@@ -438,6 +441,8 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
     alloc((void **)&s->d_argmax, 4);
     alloc((void **)&s->d_prompt, (size_t)c.seq_len * 4);
     alloc((void **)&s->d_out_tokens, (size_t)c.seq_len * 4);
+    alloc((void **)&s->d_part_val, (size_t)matvec_max_grid(g_cus) * 4);
+    alloc((void **)&s->d_part_idx, (size_t)matvec_max_grid(g_cus) * 4);
     if (e != hipSuccess) {
         set_error("RunState allocation failed: %s", hipGetErrorString(e));
         l2z_runstate_free(s);
@@ -477,7 +482,8 @@ extern "C" void l2z_runstate_free(l2z_runstate *s)
     if (s->g_forward) (void)hipGraphExecDestroy(s->g_forward);
     if (s->g_step) (void)hipGraphExecDestroy(s->g_step);
     void *ptrs[] = {s->x, s->xb, s->hb, s->q, s->logits, s->key_cache, s->value_cache, s->rope,
-                    s->d_token, s->d_pos, s->d_prompt, s->d_n_prompt, s->d_out_tokens, s->d_argmax};
+                    s->d_token, s->d_pos, s->d_prompt, s->d_n_prompt, s->d_out_tokens, s->d_argmax,
+                    s->d_part_val, s->d_part_idx};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -542,7 +548,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.pos_stride1 = sh.kvd_loc; a.pos_stride2 = sh.kvd_loc;
             a.n = c.dim; a.x = s->x; a.rms_w = w->rms_att + (size_t)l * dim;
             a.pos_ptr = s->d_pos; a.rope = s->rope; a.head_size = sh.hs; a.rope_segs = 2;
-            L2Z_LAUNCH(KIND_QKV, launch_matvec(a, PRO_RMS, EPI_ROPE, mb, st));
+            L2Z_LAUNCH(KIND_QKV, launch_matvec(a, PRO_RMS, EPI_ROPE, mb, g_cus, st));
         }
         {   // attention (:361-389) over the local heads
             AttnArgs a = {};
@@ -557,7 +563,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.w0 = w->wo + (size_t)l * sh.dim_loc * dim;
             a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0;
             a.rows0 = sh.dim_loc; a.n = c.dim; a.x = s->xb;
-            L2Z_LAUNCH(KIND_WO, launch_matvec(a, PRO_NONE, EPI_RESID, mb, st));
+            L2Z_LAUNCH(KIND_WO, launch_matvec(a, PRO_NONE, EPI_RESID, mb, g_cus, st));
         }
         L2Z_TRY(comm_allgather_inplace(s->comm, s->x, sh.dim_loc, st));
         {   // rmsnorm (:398) + w1,w3 (:405-408) + SiLU*mul (:411-416)
@@ -567,7 +573,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.out0 = s->hb + sh.hid0;
             a.rows0 = sh.hid_loc; a.rows1 = sh.hid_loc; a.n = c.dim;
             a.x = s->x; a.rms_w = w->rms_ffn + (size_t)l * dim;
-            L2Z_LAUNCH(KIND_FFN13, launch_matvec(a, PRO_RMS, EPI_SWIGLU, mb, st));
+            L2Z_LAUNCH(KIND_FFN13, launch_matvec(a, PRO_RMS, EPI_SWIGLU, mb, g_cus, st));
         }
         L2Z_TRY(comm_allgather_inplace(s->comm, s->hb, sh.hid_loc, st));
         {   // w2 (:419) + residual (:422)
@@ -575,7 +581,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.w0 = w->w2 + (size_t)l * sh.dim_loc * hid;
             a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0;
             a.rows0 = sh.dim_loc; a.n = c.hidden_dim; a.x = s->hb;
-            L2Z_LAUNCH(KIND_FFN2, launch_matvec(a, PRO_NONE, EPI_RESID, mb, st));
+            L2Z_LAUNCH(KIND_FFN2, launch_matvec(a, PRO_NONE, EPI_RESID, mb, g_cus, st));
         }
         L2Z_TRY(comm_allgather_inplace(s->comm, s->x, sh.dim_loc, st));
     }
@@ -583,12 +589,19 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         MatvecArgs a = {};
         a.w0 = w->wcls; a.out0 = s->logits + sh.v0;
         a.rows0 = sh.v_loc; a.n = c.dim; a.x = s->x; a.rms_w = w->rms_final;
-        L2Z_LAUNCH(KIND_CLS, launch_matvec(a, PRO_RMS, EPI_STORE, mb, st));
+        a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.row_offset = sh.v0;
+        // single GPU, vector path: the launch also leaves one argmax candidate per block
+        const bool fuse = sh.world == 1 && c.dim % 4 == 0;
+        int grid = 0;
+        L2Z_LAUNCH(KIND_CLS, launch_matvec(a, PRO_RMS, fuse ? EPI_ARGMAX : EPI_STORE, mb, g_cus, st,
+                                           &grid));
+        s->n_part = fuse ? grid : 0;
     }
     L2Z_TRY(comm_allgather_inplace(s->comm, s->logits, sh.v_loc, st));
     if (with_step) {
         ArgmaxArgs a = {};
         a.logits = s->logits; a.vocab = c.vocab_size; a.token_ptr = s->d_token;
+        if (s->n_part > 0) { a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.n_part = s->n_part; }
         a.pos_ptr = s->d_pos; a.prompt = s->d_prompt; a.n_prompt_ptr = s->d_n_prompt;
         a.out_tokens = s->d_out_tokens; a.argmax_out = s->d_argmax; a.tok_emb = w->tok_emb;
         a.x = s->x; a.dim = c.dim; a.advance = 1;
@@ -669,6 +682,7 @@ extern "C" int l2z_argmax(l2z_runstate *s, int *out_token)
     L2Z_HIP(hipSetDevice(s->device));
     ArgmaxArgs a = {};
     a.logits = s->logits; a.vocab = s->cfg.vocab_size; a.argmax_out = s->d_argmax; a.advance = 0;
+    if (s->n_part > 0) { a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.n_part = s->n_part; }
     L2Z_HIP(launch_argmax(a, s->stream));
     L2Z_HIP(hipMemcpyAsync(out_token, s->d_argmax, sizeof(int), hipMemcpyDeviceToHost, s->stream));
     L2Z_HIP(hipStreamSynchronize(s->stream));
@@ -853,7 +867,7 @@ extern "C" int l2z_matmul_fused(int N, float *const *outs, const float *x, const
     a.w0 = dw[0].p; a.out0 = dout[0].p; a.rows0 = (int)d;
     if (N > 1) { a.w1 = dw[1].p; a.out1 = dout[1].p; a.rows1 = (int)d; }
     if (N > 2) { a.w2 = dw[2].p; a.out2 = dout[2].p; a.rows2 = (int)d; }
-    L2Z_HIP(launch_matvec(a, PRO_NONE, EPI_STORE, g_cus * 8, nullptr));
+    L2Z_HIP(launch_matvec(a, PRO_NONE, EPI_STORE, 8, g_cus, nullptr));
     L2Z_HIP(hipDeviceSynchronize());
     for (int j = 0; j < N; j++) L2Z_TRY(dout[j].down(outs[j], d));
     return L2Z_OK;

@@ -26,6 +26,8 @@ constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / kWave;
 constexpr int kScratch = 32;  // floats of LDS scratch for block reductions
 
+
+
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ v4f ldg_nt(const v4f *p) { return __builtin_nontemporal_load(p); }
@@ -84,115 +86,139 @@ __device__ __forceinline__ float hsum4(v4f a) { return (a.x + a.y) + (a.z + a.w)
 // ---------------------------------------------------------------------------
 // x staging, optionally with rmsnorm (main.zig:432-468): xs = (x*rsqrt(mean(x^2)+1e-5))*w
 // eps is added AFTER the divide by n (:452-453); (x*scale)*w order as :462.
+// Generic form (any n, any alignment), used by the scalar kernel and the hooks.
 // ---------------------------------------------------------------------------
-template <int PRO, bool VEC>
-__device__ __forceinline__ void stage_x(const float *__restrict__ x, const float *__restrict__ rms_w,
-                                        int n, float *xs, float *scratch)
+template <int PRO>
+__device__ __forceinline__ void stage_x_scalar(const float *__restrict__ x,
+                                               const float *__restrict__ rms_w, int n, float *xs,
+                                               float *scratch)
 {
     const int tid = threadIdx.x, nt = blockDim.x;
     float ss = 0.0f;
-    if (VEC) {
-        const v4f *x4 = (const v4f *)x;
-        v4f *xs4 = (v4f *)xs;
-        const int n4 = n >> 2;
-        for (int j = tid; j < n4; j += nt) {
-            const v4f v = x4[j];
-            xs4[j] = v;
-            if (PRO == PRO_RMS) {
-                ss = fmaf(v.x, v.x, ss);
-                ss = fmaf(v.y, v.y, ss);
-                ss = fmaf(v.z, v.z, ss);
-                ss = fmaf(v.w, v.w, ss);
-            }
+    for (int j = tid; j < n; j += nt) {
+        const float v = x[j];
+        xs[j] = v;
+        if (PRO == PRO_RMS) ss = fmaf(v, v, ss);
+    }
+    if (PRO == PRO_RMS) {
+        const float tot = block_sum(ss, scratch);
+        float s = tot / (float)n;
+        s += 1e-5f;
+        s = 1.0f / sqrtf(s);
+        for (int j = tid; j < n; j += nt) xs[j] = (xs[j] * s) * rms_w[j];
+    }
+    __syncthreads();
+}
+
+// Vector form, split in two so the caller can put its first weight loads
+// between the halves: xload_issue() only ISSUES the global loads of x (they
+// return first: VMEM returns in order), xstage_finish() stores them to LDS,
+// normalises and barriers.  XC float4 per thread are held in registers
+// (XC*1024 floats); longer x falls back to a load+store loop for the rest.
+template <int PRO, int XC>
+__device__ __forceinline__ void xload_issue(const float *__restrict__ x,
+                                            const float *__restrict__ rms_w, int n4,
+                                            v4f (&xr)[XC], v4f (&gr)[XC])
+{
+    const v4f *x4 = (const v4f *)x;
+    const v4f *g4 = (const v4f *)rms_w;
+#pragma unroll
+    for (int k = 0; k < XC; k++) {
+        const int j = threadIdx.x + kBlock * k;
+        xr[k] = (j < n4) ? x4[j] : v4f{0.f, 0.f, 0.f, 0.f};
+    }
+    if (PRO == PRO_RMS) {  // the rmsnorm weights travel with x, ahead of the weight stream
+#pragma unroll
+        for (int k = 0; k < XC; k++) {
+            const int j = threadIdx.x + kBlock * k;
+            gr[k] = (j < n4) ? g4[j] : v4f{0.f, 0.f, 0.f, 0.f};
         }
+    }
+}
+
+template <int PRO, int XC>
+__device__ __forceinline__ void xstage_finish(const float *__restrict__ x,
+                                              const float *__restrict__ rms_w, int n, int n4_pad,
+                                              v4f (&xr)[XC], v4f (&gr)[XC], float *xs,
+                                              float *scratch)
+{
+    const int tid = threadIdx.x;
+    const int n4 = n >> 2;
+    const v4f *x4 = (const v4f *)x;
+    v4f *xs4 = (v4f *)xs;
+    float ss = 0.0f;
+#pragma unroll
+    for (int k = 0; k < XC; k++) {
+        const int j = tid + kBlock * k;
+        if (j < n4_pad) xs4[j] = xr[k];  // pad region [n4, n4_pad) is zero: 0*w adds nothing
         if (PRO == PRO_RMS) {
-            const float tot = block_sum(ss, scratch);
-            float s = tot / (float)n;
-            s += 1e-5f;
-            s = 1.0f / sqrtf(s);
-            const v4f *g4 = (const v4f *)rms_w;
-            for (int j = tid; j < n4; j += nt) {  // same j this thread wrote above
-                v4f v = xs4[j];
-                const v4f g = g4[j];
-                v.x = (v.x * s) * g.x;
-                v.y = (v.y * s) * g.y;
-                v.z = (v.z * s) * g.z;
-                v.w = (v.w * s) * g.w;
+            ss = fmaf(xr[k].x, xr[k].x, ss);
+            ss = fmaf(xr[k].y, xr[k].y, ss);
+            ss = fmaf(xr[k].z, xr[k].z, ss);
+            ss = fmaf(xr[k].w, xr[k].w, ss);
+        }
+    }
+    for (int j = tid + kBlock * XC; j < n4_pad; j += kBlock) {  // n > XC*1024 floats
+        const v4f v = (j < n4) ? x4[j] : v4f{0.f, 0.f, 0.f, 0.f};
+        xs4[j] = v;
+        if (PRO == PRO_RMS) {
+            ss = fmaf(v.x, v.x, ss);
+            ss = fmaf(v.y, v.y, ss);
+            ss = fmaf(v.z, v.z, ss);
+            ss = fmaf(v.w, v.w, ss);
+        }
+    }
+    if (PRO == PRO_RMS) {
+        // scratch is not in use yet: partials -> one barrier -> everyone sums them in wave order
+        ss = wave_sum(ss);
+        if ((tid & 63) == 0) scratch[tid >> 6] = ss;
+        __syncthreads();
+        float tot = scratch[0];
+#pragma unroll
+        for (int i = 1; i < kWaves; i++) tot += scratch[i];
+        float s = tot / (float)n;  // :452
+        s += 1e-5f;                // :453
+        s = 1.0f / sqrtf(s);       // :454
+        const v4f *g4 = (const v4f *)rms_w;
+#pragma unroll
+        for (int k = 0; k < XC; k++) {  // the same j this thread stored above; x, g in registers
+            const int j = tid + kBlock * k;
+            if (j < n4) {
+                v4f v = xr[k];
+                v.x = (v.x * s) * gr[k].x;  // :462 values * scale * weights
+                v.y = (v.y * s) * gr[k].y;
+                v.z = (v.z * s) * gr[k].z;
+                v.w = (v.w * s) * gr[k].w;
                 xs4[j] = v;
             }
         }
-    } else {
-        for (int j = tid; j < n; j += nt) {
-            const float v = x[j];
-            xs[j] = v;
-            if (PRO == PRO_RMS) ss = fmaf(v, v, ss);
-        }
-        if (PRO == PRO_RMS) {
-            const float tot = block_sum(ss, scratch);
-            float s = tot / (float)n;
-            s += 1e-5f;
-            s = 1.0f / sqrtf(s);
-            for (int j = tid; j < n; j += nt) xs[j] = (xs[j] * s) * rms_w[j];
+        for (int j = tid + kBlock * XC; j < n4; j += kBlock) {  // n > XC*1024 floats
+            v4f v = xs4[j];
+            const v4f g = g4[j];
+            v.x = (v.x * s) * g.x;
+            v.y = (v.y * s) * g.y;
+            v.z = (v.z * s) * g.z;
+            v.w = (v.w * s) * g.w;
+            xs4[j] = v;
         }
     }
     __syncthreads();
 }
 
-// Two dot products against the staged x: rows pa and pb.  main.zig:553-604,
-// summation order: lane l takes float4 columns l, l+64, ... in increasing
-// order into 4 component accumulators, then (x+y)+(z+w), then xor-shuffle.
-// The order depends only on n, never on the grid or on how rows are sharded.
-template <bool VEC>
-__device__ __forceinline__ void dot2(const float *__restrict__ pa, const float *__restrict__ pb,
-                                     const float *xs, int n, float &ra, float &rb)
+// Two dot products against the staged x, generic scalar form (any n / alignment).
+__device__ __forceinline__ void dot2_scalar(const float *__restrict__ pa,
+                                            const float *__restrict__ pb, const float *xs, int n,
+                                            float &ra, float &rb)
 {
     const int lane = threadIdx.x & 63;
-    if (VEC) {
-        constexpr int U = 4;  // 2 rows x 4 x 16 B = 8 loads (8 KiB per wave) in flight
-        const v4f *a4 = (const v4f *)pa + lane;
-        const v4f *b4 = (const v4f *)pb + lane;
-        const v4f *xs4 = (const v4f *)xs + lane;
-        const int n4 = n >> 2;
-        v4f acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
-        int j = lane;
-        for (; j + kWave * (U - 1) < n4; j += kWave * U) {
-            v4f wa[U], wb[U];
-#pragma unroll
-            for (int k = 0; k < U; k++) {  // constant 1 KiB strides -> immediate offsets
-                wa[k] = ldg_nt(a4 + kWave * k);
-                wb[k] = ldg_nt(b4 + kWave * k);
-            }
-#pragma unroll
-            for (int k = 0; k < U; k++) {
-                const v4f xv = xs4[kWave * k];
-                acc_a = fma4(wa[k], xv, acc_a);
-                acc_b = fma4(wb[k], xv, acc_b);
-            }
-            a4 += kWave * U;
-            b4 += kWave * U;
-            xs4 += kWave * U;
-        }
-        for (; j < n4; j += kWave) {
-            const v4f wa = ldg_nt(a4), wb = ldg_nt(b4);
-            const v4f xv = *xs4;
-            acc_a = fma4(wa, xv, acc_a);
-            acc_b = fma4(wb, xv, acc_b);
-            a4 += kWave;
-            b4 += kWave;
-            xs4 += kWave;
-        }
-        ra = wave_sum(hsum4(acc_a));
-        rb = wave_sum(hsum4(acc_b));
-    } else {
-        float sa = 0.0f, sb = 0.0f;
-        for (int j = lane; j < n; j += kWave) {
-            const float xv = xs[j];
-            sa = fmaf(pa[j], xv, sa);
-            sb = fmaf(pb[j], xv, sb);
-        }
-        ra = wave_sum(sa);
-        rb = wave_sum(sb);
+    float sa = 0.0f, sb = 0.0f;
+    for (int j = lane; j < n; j += kWave) {
+        const float xv = xs[j];
+        sa = fmaf(pa[j], xv, sa);
+        sb = fmaf(pb[j], xv, sb);
     }
+    ra = wave_sum(sa);
+    rb = wave_sum(sb);
 }
 
 // ---------------------------------------------------------------------------
@@ -201,86 +227,299 @@ __device__ __forceinline__ void dot2(const float *__restrict__ pa, const float *
 //   EPI_ROPE   RoPE on q,k + KV-cache row write    :336-358
 //   EPI_RESID  accum into the residual stream      :395 / :422
 //   EPI_SWIGLU silu(w1.x) * (w3.x)                 :411-416
-// All kernel arguments are read into scalars up front and selected with plain
-// arithmetic: indexing the by-value argument block dynamically would push it
-// into scratch memory (136 B/lane and half the occupancy in the first build).
+//
+// Work decomposition.  A "pair" is two weight rows that share x reads (rows
+// 2p,2p+1 of the concatenated row space -- exactly the RoPE pair (i,i+1) -- or
+// row p of w1 and of w3 for SwiGLU).  LPR lanes cooperate on one pair, so a
+// wave works on 64/LPR pairs at once:
+//   LPR = 64 : large n (7B shapes): one pair per wave, 1 KiB per load instruction
+//   LPR < 64 : small n (stories15M/110M): several pairs per wave so that all 64
+//              lanes load 16 B and a whole row is in flight at once
+// Lane cl of a group takes float4 columns cl, cl+LPR, ... in increasing order
+// into 4 component accumulators, then (x+y)+(z+w), then an xor-shuffle over the
+// group.  LPR is a function of n only, so a row's summation order never
+// depends on the grid, the row count or how rows are sharded over GPUs.
+//
+// Latency.  Each wave issues the loads of its first weight batch BEFORE the
+// block stages x (x's own loads are issued first and return first), so HBM
+// latency overlaps the rmsnorm prologue instead of following it.
+//
+// All kernel arguments are read into scalars and selected with arithmetic:
+// indexing the by-value argument block dynamically pushes it into scratch.
 // ---------------------------------------------------------------------------
-template <int PRO, int EPI, bool VEC>
+// Kernel arguments copied into plain locals once (keeps them out of scratch).
+struct MvLocals {
+    const float *w0, *w1, *w2;
+    float *out0, *out1, *out2;
+    const float *resid;
+    const float2 *rope;
+    int rows0, r01, total_rows, n_pairs, n, head_size, rope_segs, pos;
+    size_t ps1, ps2;
+};
+
+template <int EPI>
+__device__ __forceinline__ MvLocals mv_locals(const MatvecArgs &a)
+{
+    MvLocals m;
+    m.w0 = a.w0; m.w1 = a.w1; m.w2 = a.w2;
+    m.out0 = a.out0; m.out1 = a.out1; m.out2 = a.out2;
+    m.resid = a.resid; m.rope = a.rope;
+    m.rows0 = a.rows0; m.r01 = a.rows0 + a.rows1; m.total_rows = a.rows0 + a.rows1 + a.rows2;
+    m.n_pairs = (EPI == EPI_SWIGLU) ? a.rows0 : (m.total_rows + 1) >> 1;
+    m.n = a.n; m.head_size = a.head_size; m.rope_segs = a.rope_segs;
+    m.pos = (EPI == EPI_ROPE) ? *a.pos_ptr : 0;
+    m.ps1 = (size_t)m.pos * (size_t)a.pos_stride1;
+    m.ps2 = (size_t)m.pos * (size_t)a.pos_stride2;
+    return m;
+}
+
+// the two weight rows of pair p (clamped to the last pair for idle lane groups)
+template <int EPI>
+__device__ __forceinline__ void pair_rows(const MvLocals &m, int p, const float *&pa,
+                                          const float *&pb)
+{
+    if (p >= m.n_pairs) p = m.n_pairs - 1;
+    if (EPI == EPI_SWIGLU) {
+        pa = m.w0 + (size_t)p * (size_t)m.n;
+        pb = m.w1 + (size_t)p * (size_t)m.n;
+    } else {
+        const int ga = 2 * p;
+        const int gb = (ga + 1 < m.total_rows) ? ga + 1 : ga;
+        const bool a1 = ga >= m.rows0, a2 = ga >= m.r01;
+        const bool b1 = gb >= m.rows0, b2 = gb >= m.r01;
+        const int row_a = ga - (a2 ? m.r01 : (a1 ? m.rows0 : 0));
+        const int row_b = gb - (b2 ? m.r01 : (b1 ? m.rows0 : 0));
+        const float *wa = a1 ? m.w1 : m.w0;
+        wa = a2 ? m.w2 : wa;
+        const float *wb = b1 ? m.w1 : m.w0;
+        wb = b2 ? m.w2 : wb;
+        pa = wa + (size_t)row_a * (size_t)m.n;
+        pb = wb + (size_t)row_b * (size_t)m.n;
+    }
+}
+
+template <int EPI>
+__device__ __forceinline__ void pair_epilogue(const MvLocals &m, int p, float sa, float sb,
+                                              bool writer)
+{
+    const bool valid_a = p < m.n_pairs;
+    if (EPI == EPI_SWIGLU) {
+        float v = sa;
+        v = v * (1.0f / (1.0f + expf(-v)));  // :412
+        v = v * sb;                          // :416
+        if (writer && valid_a) m.out0[p] = v;
+        return;
+    }
+    const int ga = 2 * p, gb = ga + 1;
+    const bool valid_b = valid_a && gb < m.total_rows;
+    const bool a1 = ga >= m.rows0, a2 = ga >= m.r01;
+    const bool b1 = gb >= m.rows0, b2 = gb >= m.r01;
+    const int row_a = ga - (a2 ? m.r01 : (a1 ? m.rows0 : 0));
+    const int row_b = gb - (b2 ? m.r01 : (b1 ? m.rows0 : 0));
+    float *oa = a1 ? m.out1 + m.ps1 : m.out0;
+    oa = a2 ? m.out2 + m.ps2 : oa;
+    float *ob = b1 ? m.out1 + m.ps1 : m.out0;
+    ob = b2 ? m.out2 + m.ps2 : ob;
+    if (EPI == EPI_ROPE) {
+        // rows (row_a, row_a+1) of one segment: the pair (i, i+1) of :346-349
+        float o0 = sa, o1 = sb;
+        const int seg_a = a2 ? 2 : (a1 ? 1 : 0);
+        if (seg_a < m.rope_segs) {
+            const int hs = m.head_size;
+            const float2 cs = m.rope[(size_t)m.pos * (size_t)(hs >> 1) + (size_t)((row_a % hs) >> 1)];
+            o0 = sa * cs.x - sb * cs.y;  // :348
+            o1 = sa * cs.y + sb * cs.x;  // :349
+        }
+        if (writer && valid_a) {  // q, or the pos row of the K / V cache (:354-358)
+            oa[row_a] = o0;
+            if (valid_b) ob[row_b] = o1;
+        }
+    } else if (EPI == EPI_RESID) {
+        if (writer && valid_a) {
+            oa[row_a] = m.resid[row_a] + sa;  // :711 a[i] += b[i]
+            if (valid_b) ob[row_b] = m.resid[row_b] + sb;
+        }
+    } else {
+        if (writer && valid_a) {
+            oa[row_a] = sa;
+            if (valid_b) ob[row_b] = sb;
+        }
+    }
+}
+
+template <int LPR>
+struct MvGeom {
+    static constexpr int RW = kWave / LPR;          // pairs per wave
+    static constexpr int U = (LPR == 64) ? 4 : 6;   // float4 per row per lane per batch
+};
+
+// Issue one batch: U float4 of row a and of row b at columns c0 + k*LPR.  Columns past
+// the row end are clamped to its last float4: the matching x entries in LDS are the
+// zero padding, so they add exactly 0 (weights are finite) -- no predicated loads.
+template <int LPR>
+__device__ __forceinline__ void mv_load(const float *pa, const float *pb, int c0, int cb, int n4,
+                                        v4f (&wa)[MvGeom<LPR>::U], v4f (&wb)[MvGeom<LPR>::U])
+{
+    constexpr int U = MvGeom<LPR>::U;
+    const v4f *a4 = (const v4f *)pa, *b4 = (const v4f *)pb;
+    if (LPR == 64) {
+        // n4 % 64 == 0 (checked by the launcher): whether step k of the batch that starts
+        // at column cb is inside the row is the same for every lane.  Out-of-row steps
+        // re-read step 0 (their x entries are the zero padding).
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const int off = (cb + 64 * k < n4) ? 64 * k : 0;  // wave-uniform
+            wa[k] = ldg_nt(a4 + c0 + off);
+            wb[k] = ldg_nt(b4 + c0 + off);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            int c = c0 + LPR * k;
+            c = c < n4 ? c : n4 - 1;
+            wa[k] = ldg_nt(a4 + c);
+            wb[k] = ldg_nt(b4 + c);
+        }
+    }
+}
+
+template <int LPR>
+__device__ __forceinline__ void mv_consume(const v4f *xs4, int c0, const v4f (&wa)[MvGeom<LPR>::U],
+                                           const v4f (&wb)[MvGeom<LPR>::U], v4f &acc_a, v4f &acc_b)
+{
+    constexpr int U = MvGeom<LPR>::U;
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+        const v4f xv = xs4[c0 + LPR * k];  // zero padded to whole batches
+        acc_a = fma4(wa[k], xv, acc_a);
+        acc_b = fma4(wb[k], xv, acc_b);
+    }
+}
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v)
+{
+#pragma unroll
+    for (int o = LPR >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int PRO, int EPI, int LPR, int XC>
 __global__ __launch_bounds__(kBlock) void matvec_kernel(const MatvecArgs a)
 {
+    using G = MvGeom<LPR>;
+    constexpr int U = G::U, RW = G::RW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int n = a.n;
+    const MvLocals m = mv_locals<EPI>(a);
+    const int n4 = m.n >> 2;
+    const int n_batches = (n4 + LPR * U - 1) / (LPR * U);
+    const int n4_pad = n_batches * (LPR * U);
     float *xs = lds;
-    float *scratch = lds + ((n + 3) & ~3);
-    stage_x<PRO, VEC>(a.x, a.rms_w, n, xs, scratch);
+    float *scratch = lds + 4 * n4_pad;
+    const v4f *xs4 = (const v4f *)xs;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float *const w0 = a.w0, *const w1 = a.w1, *const w2 = a.w2;
-    float *const out0 = a.out0, *const out1 = a.out1, *const out2 = a.out2;
-    const int rows0 = a.rows0, rows1 = a.rows1, rows2 = a.rows2;
-    const int total_rows = rows0 + rows1 + rows2;
-    const int n_units = (EPI == EPI_SWIGLU) ? rows0 : (total_rows + 1) >> 1;
-    const int pos = (EPI == EPI_ROPE) ? *a.pos_ptr : 0;
-    const size_t ps1 = (size_t)pos * (size_t)a.pos_stride1, ps2 = (size_t)pos * (size_t)a.pos_stride2;
+    const int grp = lane / LPR, cl = lane % LPR;
+    const int n_units = (m.n_pairs + RW - 1) / RW;
+    const int ustride = gridDim.x * kWaves;
 
-    for (int u = blockIdx.x * kWaves + wave; u < n_units; u += gridDim.x * kWaves) {
-        // rows ga, gb in the concatenated row space [0, rows0+rows1+rows2)
+    // 1. issue x loads (they return first), 2. issue the first weight batch, 3. stage x
+    v4f xr[XC], gr[XC];
+    xload_issue<PRO, XC>(a.x, a.rms_w, n4, xr, gr);
+    int u = blockIdx.x * kWaves + wave;
+    const bool has_unit = u < n_units;
+    const float *pa, *pb;
+    pair_rows<EPI>(m, (has_unit ? u : 0) * RW + grp, pa, pb);
+    v4f wa[U], wb[U];
+    mv_load<LPR>(pa, pb, cl, 0, n4, wa, wb);
+    xstage_finish<PRO, XC>(a.x, a.rms_w, m.n, n4_pad, xr, gr, xs, scratch);
+    if (EPI != EPI_ARGMAX && !has_unit) return;
+
+    // flat loop over (unit, batch): consume the batch in registers, then immediately
+    // issue the next one -- the next unit's first batch included -- before reducing
+    v4f acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
+    float best_v = -INFINITY;  // EPI_ARGMAX: running (max, first index) of this lane's rows
+    int best_i = 0x7fffffff;
+    int b = 0;
+    while (has_unit) {
+        mv_consume<LPR>(xs4, cl + b * (LPR * U), wa, wb, acc_a, acc_b);
+        const bool unit_done = (b + 1 == n_batches);
+        const int u_next = unit_done ? u + ustride : u;
+        const int b_next = unit_done ? 0 : b + 1;
+        const bool more = u_next < n_units;
+        if (more) {
+            if (unit_done) pair_rows<EPI>(m, u_next * RW + grp, pa, pb);
+            mv_load<LPR>(pa, pb, cl + b_next * (LPR * U), b_next * (LPR * U), n4, wa, wb);
+        }
+        if (unit_done) {
+            const float sa = group_sum<LPR>(hsum4(acc_a));
+            const float sb = group_sum<LPR>(hsum4(acc_b));
+            pair_epilogue<EPI>(m, u * RW + grp, sa, sb, cl == 0);
+            if (EPI == EPI_ARGMAX) {  // single segment: pair p = rows 2p, 2p+1
+                const int ra_ = 2 * (u * RW + grp), rb_ = ra_ + 1;
+                if (ra_ < m.total_rows && (sa > best_v || best_i == 0x7fffffff)) {
+                    best_v = sa; best_i = ra_ + a.row_offset;
+                }
+                if (rb_ < m.total_rows && sb > best_v) {  // strict '>' : first index wins ties
+                    best_v = sb; best_i = rb_ + a.row_offset;
+                }
+            }
+            acc_a = v4f{0.f, 0.f, 0.f, 0.f};
+            acc_b = v4f{0.f, 0.f, 0.f, 0.f};
+        }
+        if (!more) break;
+        u = u_next;
+        b = b_next;
+    }
+    if (EPI == EPI_ARGMAX) {
+        // block candidate: larger value wins, equal values -> lower index (main.zig:720)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best_v, o, 64);
+            const int oi = __shfl_xor(best_i, o, 64);
+            if (oi != 0x7fffffff && (best_i == 0x7fffffff || ov > best_v || (ov == best_v && oi < best_i))) {
+                best_v = ov; best_i = oi;
+            }
+        }
+        __syncthreads();
+        if (lane == 0) {
+            scratch[wave] = best_v;
+            scratch[kWaves + wave] = __int_as_float(best_i);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float bv = scratch[0];
+            int bi = __float_as_int(scratch[kWaves]);
+            for (int w = 1; w < kWaves; w++) {
+                const float ov = scratch[w];
+                const int oi = __float_as_int(scratch[kWaves + w]);
+                if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) {
+                    bv = ov; bi = oi;
+                }
+            }
+            a.part_val[blockIdx.x] = bv;
+            a.part_idx[blockIdx.x] = bi;
+        }
+    }
+}
+
+// Generic form: any n, any alignment (the reference's 3x3 / 2x12 known-answer
+// tests land here).  One pair per wave, scalar loads.
+template <int PRO, int EPI>
+__global__ __launch_bounds__(kBlock) void matvec_scalar_kernel(const MatvecArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const MvLocals m = mv_locals<EPI>(a);
+    float *xs = lds;
+    float *scratch = lds + ((m.n + 3) & ~3);
+    stage_x_scalar<PRO>(a.x, a.rms_w, m.n, xs, scratch);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int u = blockIdx.x * kWaves + wave; u < m.n_pairs; u += gridDim.x * kWaves) {
         const float *pa, *pb;
-        float *oa, *ob;
-        int row_a, row_b, seg_a;
-        bool valid_b = true;
-        if (EPI == EPI_SWIGLU) {
-            row_a = u; row_b = u; seg_a = 0;
-            pa = w0 + (size_t)u * (size_t)n;
-            pb = w1 + (size_t)u * (size_t)n;
-            oa = out0; ob = out0;
-        } else {
-            const int ga = 2 * u;
-            int gb = ga + 1;
-            if (gb >= total_rows) { gb = ga; valid_b = false; }
-            // segment select by comparison arithmetic on scalars (no indexed loads)
-            const bool a1 = ga >= rows0, a2 = ga >= rows0 + rows1;
-            const bool b1 = gb >= rows0, b2 = gb >= rows0 + rows1;
-            row_a = ga - (a2 ? rows0 + rows1 : (a1 ? rows0 : 0));
-            row_b = gb - (b2 ? rows0 + rows1 : (b1 ? rows0 : 0));
-            seg_a = a2 ? 2 : (a1 ? 1 : 0);
-            pa = (a2 ? w2 : (a1 ? w1 : w0)) + (size_t)row_a * (size_t)n;
-            pb = (b2 ? w2 : (b1 ? w1 : w0)) + (size_t)row_b * (size_t)n;
-            oa = a2 ? out2 + ps2 : (a1 ? out1 + ps1 : out0);
-            ob = b2 ? out2 + ps2 : (b1 ? out1 + ps1 : out0);
-        }
+        pair_rows<EPI>(m, u, pa, pb);
         float sa, sb;
-        dot2<VEC>(pa, pb, xs, n, sa, sb);
-
-        if (EPI == EPI_SWIGLU) {
-            float v = sa;
-            v = v * (1.0f / (1.0f + expf(-v)));  // :412
-            v = v * sb;                          // :416
-            if (lane == 0) oa[u] = v;
-        } else if (EPI == EPI_ROPE) {
-            // rows (row_a, row_a+1) of one segment: the pair (i, i+1) of :346-349
-            float o0 = sa, o1 = sb;
-            if (seg_a < a.rope_segs) {
-                const int hs = a.head_size;
-                const float2 cs = a.rope[(size_t)pos * (size_t)(hs >> 1) + (size_t)((row_a % hs) >> 1)];
-                o0 = sa * cs.x - sb * cs.y;  // :348
-                o1 = sa * cs.y + sb * cs.x;  // :349
-            }
-            if (lane == 0) {  // q, or the pos row of the K / V cache (:354-358)
-                oa[row_a] = o0;
-                if (valid_b) ob[row_b] = o1;
-            }
-        } else if (EPI == EPI_RESID) {
-            if (lane == 0) {
-                oa[row_a] = a.resid[row_a] + sa;  // :711 a[i] += b[i]
-                if (valid_b) ob[row_b] = a.resid[row_b] + sb;
-            }
-        } else {
-            if (lane == 0) {
-                oa[row_a] = sa;
-                if (valid_b) ob[row_b] = sb;
-            }
-        }
+        dot2_scalar(pa, pb, xs, m.n, sa, sb);
+        pair_epilogue<EPI>(m, u, sa, sb, lane == 0);
     }
 }
 
@@ -306,7 +545,12 @@ __host__ __device__ inline AttnGeom attn_geom(int head_size, bool vec)
     return g;
 }
 
-// scores for timesteps t < T: att[t] = dot(q, K[t]) / sqrt(head_size)   (:367-375)
+// scores for timesteps t < T: att[t] = dot(q, K[t]) / div   (:367-375).
+// Group g walks t = g, g+G, ...; kAttnUB timesteps are loaded before any is
+// used so kAttnUB K rows are in flight per lane (the first build did one
+// dependent load per step: 16 serial round trips at pos 255).
+constexpr int kAttnUB = 4;
+
 template <bool VEC>
 __device__ __forceinline__ void attn_scores(const float *qs, const float *__restrict__ kbase,
                                             int kv_stride, int head_size, int T, float div,
@@ -314,19 +558,46 @@ __device__ __forceinline__ void attn_scores(const float *qs, const float *__rest
 {
     const AttnGeom ge = attn_geom(head_size, VEC);
     const int g = threadIdx.x / ge.TPR, c0 = threadIdx.x % ge.TPR;
-    for (int t = g; t < T; t += ge.G) {
-        float p = 0.0f;
-        const float *krow = kbase + (size_t)t * (size_t)kv_stride;
-        if (VEC) {
-            v4f acc = {0.f, 0.f, 0.f, 0.f};
-            for (int c = c0; c < ge.E; c += ge.TPR)
-                acc = fma4(((const v4f *)qs)[c], ((const v4f *)krow)[c], acc);
-            p = hsum4(acc);
-        } else {
-            for (int c = c0; c < ge.E; c += ge.TPR) p = fmaf(qs[c], krow[c], p);
+    for (int t0 = g; t0 < T; t0 += ge.G * kAttnUB) {
+        float p[kAttnUB];
+#pragma unroll
+        for (int i = 0; i < kAttnUB; i++) p[i] = 0.0f;
+        for (int c = c0; c < ge.E; c += ge.TPR) {  // one trip unless head_size > 256
+            if (VEC) {
+                v4f kv[kAttnUB];
+#pragma unroll
+                for (int i = 0; i < kAttnUB; i++) {
+                    int t = t0 + ge.G * i;
+                    t = t < T ? t : T - 1;  // clamped: result discarded below
+                    kv[i] = ((const v4f *)(kbase + (size_t)t * (size_t)kv_stride))[c];
+                }
+                const v4f qv = ((const v4f *)qs)[c];
+#pragma unroll
+                for (int i = 0; i < kAttnUB; i++) {
+                    v4f acc = {0.f, 0.f, 0.f, 0.f};
+                    acc = fma4(qv, kv[i], acc);
+                    p[i] += hsum4(acc);
+                }
+            } else {
+                float kv[kAttnUB];
+#pragma unroll
+                for (int i = 0; i < kAttnUB; i++) {
+                    int t = t0 + ge.G * i;
+                    t = t < T ? t : T - 1;
+                    kv[i] = kbase[(size_t)t * (size_t)kv_stride + c];
+                }
+                const float qv = qs[c];
+#pragma unroll
+                for (int i = 0; i < kAttnUB; i++) p[i] = fmaf(qv, kv[i], p[i]);
+            }
         }
-        for (int o = ge.TPR >> 1; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
-        if (c0 == 0) att[t] = p / div;  // :372 divide, not multiply by reciprocal
+#pragma unroll
+        for (int i = 0; i < kAttnUB; i++) {
+            float v = p[i];
+            for (int o = ge.TPR >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            const int t = t0 + ge.G * i;
+            if (c0 == 0 && t < T) att[t] = v / div;  // :372 divide, not multiply by reciprocal
+        }
     }
 }
 
@@ -350,6 +621,7 @@ __device__ __forceinline__ void block_softmax(float *att, int T, float *scratch)
 
 // out[i] = sum_t att[t] * V[t][i]   (main.zig:657-685): G interleaved partial
 // sums per column (t = g, g+G, ... in increasing t), combined in g order.
+// kAttnUB V rows are loaded ahead of their use.
 template <bool VEC>
 __device__ __forceinline__ void attn_weighted_sum(const float *att, const float *__restrict__ vbase,
                                                   int kv_stride, int head_size, int T, float *part,
@@ -360,19 +632,39 @@ __device__ __forceinline__ void attn_weighted_sum(const float *att, const float 
     for (int c = c0; c < ge.E; c += ge.TPR) {
         if (VEC) {
             v4f acc = {0.f, 0.f, 0.f, 0.f};
-            for (int t = g; t < T; t += ge.G) {
-                const v4f v = ((const v4f *)(vbase + (size_t)t * (size_t)kv_stride))[c];
-                const float w = att[t];
-                acc.x = fmaf(v.x, w, acc.x);
-                acc.y = fmaf(v.y, w, acc.y);
-                acc.z = fmaf(v.z, w, acc.z);
-                acc.w = fmaf(v.w, w, acc.w);
+            for (int t0 = g; t0 < T; t0 += ge.G * kAttnUB) {
+                v4f vv[kAttnUB];
+                float w[kAttnUB];
+#pragma unroll
+                for (int i = 0; i < kAttnUB; i++) {
+                    const int t = t0 + ge.G * i;
+                    const int tc = t < T ? t : T - 1;
+                    vv[i] = ((const v4f *)(vbase + (size_t)tc * (size_t)kv_stride))[c];
+                    w[i] = t < T ? att[tc] : 0.0f;
+                }
+#pragma unroll
+                for (int i = 0; i < kAttnUB; i++) {  // increasing t
+                    acc.x = fmaf(vv[i].x, w[i], acc.x);
+                    acc.y = fmaf(vv[i].y, w[i], acc.y);
+                    acc.z = fmaf(vv[i].z, w[i], acc.z);
+                    acc.w = fmaf(vv[i].w, w[i], acc.w);
+                }
             }
             ((v4f *)(part + (size_t)g * head_size))[c] = acc;
         } else {
             float acc = 0.0f;
-            for (int t = g; t < T; t += ge.G)
-                acc = fmaf(vbase[(size_t)t * (size_t)kv_stride + c], att[t], acc);
+            for (int t0 = g; t0 < T; t0 += ge.G * kAttnUB) {
+                float vv[kAttnUB], w[kAttnUB];
+#pragma unroll
+                for (int i = 0; i < kAttnUB; i++) {
+                    const int t = t0 + ge.G * i;
+                    const int tc = t < T ? t : T - 1;
+                    vv[i] = vbase[(size_t)tc * (size_t)kv_stride + c];
+                    w[i] = t < T ? att[tc] : 0.0f;
+                }
+#pragma unroll
+                for (int i = 0; i < kAttnUB; i++) acc = fmaf(vv[i], w[i], acc);
+            }
             part[(size_t)g * head_size + c] = acc;
         }
     }
@@ -384,6 +676,117 @@ __device__ __forceinline__ void attn_weighted_sum(const float *att, const float 
     }
 }
 
+// Softmax over att[0..T) (main.zig:687-706) computed redundantly by every wave --
+// each wave reduces max and sum over ALL T with the same instruction sequence, so
+// all waves hold bit-identical (max, sum) without any cross-wave barrier -- and
+// wave w normalises the entries t = w*64 + lane, + blockDim, ...
+__device__ __forceinline__ void wave_softmax(float *att, int T)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    float m = -INFINITY;
+    for (int t = lane; t < T; t += kWave) m = fmaxf(m, att[t]);
+    m = wave_max(m);
+    float s = 0.0f;
+    for (int t = lane; t < T; t += kWave) s += expf(att[t] - m);  // :699
+    s = wave_sum(s);
+    __syncthreads();  // every wave has read the raw scores before any is overwritten
+    for (int t = wave * kWave + lane; t < T; t += nw * kWave) att[t] = expf(att[t] - m) / s;  // :704
+    __syncthreads();
+}
+
+// Fast path (head_size % 4 == 0, head_size <= 256).  The first kFastUB timesteps of
+// every group -- K rows AND V rows -- are requested up front, WITHOUT waiting for pos:
+// rows past pos exist (the cache has seq_len rows, zero-initialised or holding finite
+// values of an earlier sequence) and are masked, so pos, q, K and V travel in one
+// round trip and the V rows arrive while the softmax runs.  Same arithmetic and
+// summation order as attn_scores / attn_weighted_sum.  Kept compact on purpose: at
+// stories15M sizes this kernel's time is launch + instruction fetch, not data.
+constexpr int kFastUB = 8;
+
+__global__ __launch_bounds__(kBlock) void attention_fast_kernel(const AttnArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int hs = a.head_size;
+    const AttnGeom ge = attn_geom(hs, true);
+    float *att = lds;                                  // seq_len
+    float *part = att + ((a.seq_len + 3) & ~3);        // G*hs
+    const int h = blockIdx.x;
+    const int kvh = h / a.kv_mul;                      // :369 (h / kv_mul) * head_size
+    const float *kbase = a.kcache + (size_t)kvh * hs;
+    const float *vbase = a.vcache + (size_t)kvh * hs;
+    const size_t stride = (size_t)a.kv_dim;
+    const int g = threadIdx.x / ge.TPR, c0 = threadIdx.x % ge.TPR;
+    const bool active = c0 < ge.E;
+    const int cc = active ? c0 : 0;
+    const int step = ge.G * kFastUB;
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+
+    const int T = *a.pos_ptr + 1;  // timesteps 0..pos inclusive (:367); first used after the loads
+    const v4f qv = active ? ((const v4f *)(a.q + (size_t)h * hs))[cc] : zero;
+    v4f kr[kFastUB], vr[kFastUB];
+#pragma unroll
+    for (int i = 0; i < kFastUB; i++) {
+        int t = g + ge.G * i;
+        t = t < a.seq_len ? t : a.seq_len - 1;
+        kr[i] = ((const v4f *)(kbase + (size_t)t * stride))[cc];
+    }
+#pragma unroll
+    for (int i = 0; i < kFastUB; i++) {
+        int t = g + ge.G * i;
+        t = t < a.seq_len ? t : a.seq_len - 1;
+        vr[i] = ((const v4f *)(vbase + (size_t)t * stride))[cc];
+    }
+    const float div = sqrtf((float)hs);
+    for (int t0 = g;;) {  // scores (:367-375)
+#pragma unroll
+        for (int i = 0; i < kFastUB; i++) {
+            float p = hsum4(fma4(qv, kr[i], zero));
+            for (int o = ge.TPR >> 1; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
+            const int t = t0 + ge.G * i;
+            if (c0 == 0 && t < T) att[t] = p / div;  // :372 divide
+        }
+        t0 += step;
+        if (t0 >= T) break;
+#pragma unroll
+        for (int i = 0; i < kFastUB; i++) {
+            int t = t0 + ge.G * i;
+            t = t < T ? t : T - 1;
+            kr[i] = ((const v4f *)(kbase + (size_t)t * stride))[cc];
+        }
+    }
+    __syncthreads();
+    wave_softmax(att, T);  // :378
+    v4f acc = zero;
+    for (int t0 = g;;) {  // att . V (:381-388), increasing t within the group
+#pragma unroll
+        for (int i = 0; i < kFastUB; i++) {
+            const int t = t0 + ge.G * i;
+            const float w = t < T ? att[t] : 0.0f;
+            acc.x = fmaf(vr[i].x, w, acc.x);
+            acc.y = fmaf(vr[i].y, w, acc.y);
+            acc.z = fmaf(vr[i].z, w, acc.z);
+            acc.w = fmaf(vr[i].w, w, acc.w);
+        }
+        t0 += step;
+        if (t0 >= T) break;
+#pragma unroll
+        for (int i = 0; i < kFastUB; i++) {
+            int t = t0 + ge.G * i;
+            t = t < T ? t : T - 1;
+            vr[i] = ((const v4f *)(vbase + (size_t)t * stride))[cc];
+        }
+    }
+    if (active) ((v4f *)(part + (size_t)g * hs))[cc] = acc;
+    __syncthreads();
+    float *out = a.xb + (size_t)h * hs;
+    for (int i = threadIdx.x; i < hs; i += blockDim.x) {
+        float s = part[i];
+        for (int gg = 1; gg < ge.G; gg++) s += part[(size_t)gg * hs + i];
+        out[i] = s;
+    }
+}
+
+// Generic path: any head_size / alignment.
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void attention_kernel(const AttnArgs a)
 {
@@ -418,11 +821,22 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const ArgmaxArgs a)
     const int tid = threadIdx.x;
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = tid; i < a.vocab; i += blockDim.x) {
-        const float v = a.logits[i];
-        if (v > best || bi == 0x7fffffff) {  // strict '>' keeps the lowest index (:720)
-            best = v;
-            bi = i;
+    if (a.part_val != nullptr) {  // per-block candidates left by the classifier launch
+        for (int i = tid; i < a.n_part; i += blockDim.x) {
+            const float v = a.part_val[i];
+            const int id = a.part_idx[i];
+            if (id != 0x7fffffff && (bi == 0x7fffffff || v > best || (v == best && id < bi))) {
+                best = v;
+                bi = id;
+            }
+        }
+    } else {
+        for (int i = tid; i < a.vocab; i += blockDim.x) {
+            const float v = a.logits[i];
+            if (v > best || bi == 0x7fffffff) {  // strict '>' keeps the lowest index (:720)
+                best = v;
+                bi = i;
+            }
         }
     }
     // wave reduce: larger value wins, equal values -> lower index
@@ -430,7 +844,7 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const ArgmaxArgs a)
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(best, o, 64);
         const int oi = __shfl_xor(bi, o, 64);
-        if (ov > best || (ov == best && oi < bi)) {
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) {
             best = ov;
             bi = oi;
         }
@@ -443,7 +857,8 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const ArgmaxArgs a)
     if (tid == 0) {
         const int nw = blockDim.x >> 6;
         for (int w = 1; w < nw; w++) {
-            if (s_val[w] > best || (s_val[w] == best && s_idx[w] < bi)) {
+            if (s_idx[w] != 0x7fffffff &&
+                (bi == 0x7fffffff || s_val[w] > best || (s_val[w] == best && s_idx[w] < bi))) {
                 best = s_val[w];
                 bi = s_idx[w];
             }
@@ -484,14 +899,24 @@ __global__ void set_state_kernel(int token, int pos, int *token_ptr, int *pos_pt
 // ---------------------------------------------------------------------------
 // Stand-alone wrappers for the test hooks: same device functions as above.
 // ---------------------------------------------------------------------------
+// VEC: the vector staging path the fused mat-vec uses (XC = 4, zero padded)
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void rmsnorm_kernel(float *o, const float *x, const float *w,
                                                          int n)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *xs = lds, *scratch = lds + ((n + 3) & ~3);
-    stage_x<PRO_RMS, VEC>(x, w, n, xs, scratch);
-    for (int j = threadIdx.x; j < n; j += blockDim.x) o[j] = xs[j];
+    if (VEC) {
+        const int n4 = n >> 2, n4_pad = (n4 + 255) & ~255;
+        float *xs = lds, *scratch = lds + 4 * n4_pad;
+        v4f xr[4], gr[4];
+        xload_issue<PRO_RMS, 4>(x, w, n4, xr, gr);
+        xstage_finish<PRO_RMS, 4>(x, w, n, n4_pad, xr, gr, xs, scratch);
+        for (int j = threadIdx.x; j < n; j += blockDim.x) o[j] = xs[j];
+    } else {
+        float *xs = lds, *scratch = lds + ((n + 3) & ~3);
+        stage_x_scalar<PRO_RMS>(x, w, n, xs, scratch);
+        for (int j = threadIdx.x; j < n; j += blockDim.x) o[j] = xs[j];
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void softmax_kernel(float *x, int n)
@@ -550,24 +975,56 @@ hipError_t ensure_lds(K kernel, size_t bytes)
     return hipSuccess;
 }
 
-template <int PRO, int EPI>
-hipError_t launch_matvec_pe(const MatvecArgs &a, bool vec, int grid, size_t lds, hipStream_t st)
+// lanes per pair for a row of n4 float4: the smallest power of two that puts a
+// whole row in one batch of 6 loads per lane, clamped to [8, 64].  A function of
+// n only (see the kernel header).
+int lpr_for(int n4)
 {
-    if (vec) {
-        hipError_t e = ensure_lds(matvec_kernel<PRO, EPI, true>, lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((matvec_kernel<PRO, EPI, true>), dim3(grid), dim3(kBlock), lds, st, a);
-    } else {
-        hipError_t e = ensure_lds(matvec_kernel<PRO, EPI, false>, lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((matvec_kernel<PRO, EPI, false>), dim3(grid), dim3(kBlock), lds, st, a);
-    }
-    return hipGetLastError();
+    int l = 8;
+    while (l < 64 && l * 6 < n4) l <<= 1;
+    return l;
+}
+
+struct MvLaunch {
+    const void *fn;
+    int lpr, u;
+};
+
+template <int PRO, int EPI, int LPR, int XC>
+MvLaunch mv_entry()
+{
+    return {reinterpret_cast<const void *>(&matvec_kernel<PRO, EPI, LPR, XC>), LPR, MvGeom<LPR>::U};
+}
+
+template <int PRO, int EPI>
+MvLaunch mv_pick(int lpr, bool big_x)
+{
+    if (lpr == 8) return mv_entry<PRO, EPI, 8, 4>();
+    if (lpr == 16) return mv_entry<PRO, EPI, 16, 4>();
+    if (lpr == 32) return mv_entry<PRO, EPI, 32, 4>();
+    return big_x ? mv_entry<PRO, EPI, 64, 12>() : mv_entry<PRO, EPI, 64, 4>();
+}
+
+MvLaunch mv_pick_pe(int pro, int epi, int lpr, bool big_x, bool vec)
+{
+#define L2Z_MV(P, E)                                                                      \
+    if (pro == P && epi == E)                                                             \
+        return vec ? mv_pick<P, E>(lpr, big_x)                                            \
+                   : MvLaunch{reinterpret_cast<const void *>(&matvec_scalar_kernel<P, E>), 0, 0};
+    L2Z_MV(PRO_NONE, EPI_STORE)
+    L2Z_MV(PRO_NONE, EPI_RESID)
+    L2Z_MV(PRO_RMS, EPI_STORE)
+    L2Z_MV(PRO_RMS, EPI_ROPE)
+    L2Z_MV(PRO_RMS, EPI_SWIGLU)
+#undef L2Z_MV
+    if (pro == PRO_RMS && epi == EPI_ARGMAX && vec) return mv_pick<PRO_RMS, EPI_ARGMAX>(lpr, big_x);
+    return {nullptr, 0, 0};
 }
 
 }  // namespace
 
-size_t matvec_lds_bytes(int n) { return (size_t)(((n + 3) & ~3) + kScratch) * sizeof(float); }
+// upper bound over every instantiation (n4 padded to whole batches of <= 384 float4)
+size_t matvec_lds_bytes(int n) { return (size_t)(4 * ((n >> 2) + 384) + kScratch + 4) * sizeof(float); }
 
 size_t attention_lds_bytes(int head_size, int seq_len, bool vec)
 {
@@ -576,33 +1033,58 @@ size_t attention_lds_bytes(int head_size, int seq_len, bool vec)
            sizeof(float);
 }
 
-hipError_t launch_matvec(const MatvecArgs &a, int pro, int epi, int max_blocks, hipStream_t st)
+int matvec_max_grid(int n_cus) { return n_cus * 8; }
+
+hipError_t launch_matvec(const MatvecArgs &a, int pro, int epi, int max_blocks_per_cu, int n_cus,
+                         hipStream_t st, int *out_grid)
 {
+    if (max_blocks_per_cu > 8) max_blocks_per_cu = 8;
     bool vec = (a.n % 4) == 0 && aligned16(a.x) && aligned16(a.w0);
     if (a.rows1 > 0) vec = vec && aligned16(a.w1);
     if (a.rows2 > 0) vec = vec && aligned16(a.w2);
     if (pro == PRO_RMS) vec = vec && aligned16(a.rms_w);
     if (epi == EPI_SWIGLU && a.rows1 != a.rows0) return hipErrorInvalidValue;
     const int total_rows = a.rows0 + a.rows1 + a.rows2;
-    const int n_units = (epi == EPI_SWIGLU) ? a.rows0 : (total_rows + 1) / 2;
-    if (n_units <= 0) return hipErrorInvalidValue;
-    // Even split: every wave gets the same number of units (+-1).
-    int blocks_needed = (n_units + kWaves - 1) / kWaves;
+    const int n_pairs = (epi == EPI_SWIGLU) ? a.rows0 : (total_rows + 1) / 2;
+    if (n_pairs <= 0 || a.n <= 0) return hipErrorInvalidValue;
+    const int n4 = a.n >> 2;
+    const int lpr = lpr_for(n4);
+    if (lpr == 64 && (n4 % 64) != 0) vec = false;  // rare odd widths: generic scalar kernel
+    if (epi == EPI_ARGMAX && (!vec || a.rows1 != 0 || a.rows2 != 0)) return hipErrorNotSupported;
+    const MvLaunch k = mv_pick_pe(pro, epi, lpr, a.n > 4096, vec);
+    if (k.fn == nullptr) return hipErrorInvalidValue;
+    size_t lds;
+    int n_units;
+    if (vec) {
+        const int batch = k.lpr * k.u;
+        const int n4_pad = ((n4 + batch - 1) / batch) * batch;
+        lds = (size_t)(4 * n4_pad + kScratch) * sizeof(float);
+        const int rw = kWave / k.lpr;
+        n_units = (n_pairs + rw - 1) / rw;
+    } else {
+        lds = (size_t)(((a.n + 3) & ~3) + kScratch) * sizeof(float);
+        n_units = n_pairs;
+    }
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    // Grid: at most what is resident at once (so every wave's prologue is paid
+    // once), units dealt round-robin so every wave gets the same count +-1.
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k.fn, kBlock, lds) != hipSuccess || occ < 1)
+        occ = 1;
+    if (occ > max_blocks_per_cu) occ = max_blocks_per_cu;
+    const int resident = occ * n_cus;
+    const int blocks_needed = (n_units + kWaves - 1) / kWaves;
     int grid = blocks_needed;
-    if (grid > max_blocks) {
-        const int per_wave = (n_units + max_blocks * kWaves - 1) / (max_blocks * kWaves);
+    if (grid > resident) {
+        const int per_wave = (n_units + resident * kWaves - 1) / (resident * kWaves);
         grid = (n_units + per_wave * kWaves - 1) / (per_wave * kWaves);
     }
-    const size_t lds = matvec_lds_bytes(a.n);
-#define L2Z_MV(P, E) \
-    if (pro == P && epi == E) return launch_matvec_pe<P, E>(a, vec, grid, lds, st);
-    L2Z_MV(PRO_NONE, EPI_STORE)
-    L2Z_MV(PRO_NONE, EPI_RESID)
-    L2Z_MV(PRO_RMS, EPI_STORE)
-    L2Z_MV(PRO_RMS, EPI_ROPE)
-    L2Z_MV(PRO_RMS, EPI_SWIGLU)
-#undef L2Z_MV
-    return hipErrorInvalidValue;
+    if (out_grid) *out_grid = grid;
+    void *args[] = {const_cast<MatvecArgs *>(&a)};
+    return hipLaunchKernel(k.fn, dim3(grid), dim3(kBlock), args, lds, st);
 }
 
 hipError_t launch_attention(const AttnArgs &a, int n_heads_local, hipStream_t st)
@@ -610,6 +1092,12 @@ hipError_t launch_attention(const AttnArgs &a, int n_heads_local, hipStream_t st
     const bool vec = (a.head_size % 4) == 0 && (a.kv_dim % 4) == 0 && aligned16(a.q) &&
                      aligned16(a.kcache) && aligned16(a.vcache);
     const size_t lds = attention_lds_bytes(a.head_size, a.seq_len, vec);
+    if (vec && a.head_size <= 256) {
+        hipError_t e = ensure_lds(attention_fast_kernel, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(attention_fast_kernel, dim3(n_heads_local), dim3(kBlock), lds, st, a);
+        return hipGetLastError();
+    }
     if (vec) {
         hipError_t e = ensure_lds(attention_kernel<true>, lds);
         if (e != hipSuccess) return e;
@@ -685,7 +1173,7 @@ hipError_t launch_weighted_sum_rows(float *xout, int xout_len, const float *rows
                            rows, row_stride, weights, n_weights, part);
     e = hipGetLastError();
     hipError_t e2 = hipStreamSynchronize(st);
-    hipFree(part);
+    (void)hipFree(part);
     return e != hipSuccess ? e : e2;
 }
 

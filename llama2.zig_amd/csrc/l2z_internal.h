@@ -48,7 +48,7 @@ void set_error(const char *fmt, ...);
 // ---------------------------------------------------------------------------
 
 enum Prologue { PRO_NONE = 0, PRO_RMS = 1 };
-enum Epilogue { EPI_STORE = 0, EPI_ROPE = 1, EPI_RESID = 2, EPI_SWIGLU = 3 };
+enum Epilogue { EPI_STORE = 0, EPI_ROPE = 1, EPI_RESID = 2, EPI_SWIGLU = 3, EPI_ARGMAX = 4 };
 
 constexpr int kMaxSeg = 3;
 
@@ -70,6 +70,11 @@ struct MatvecArgs {
     const float2 *rope;       // (seq_len, head_size/2) {cos, sin}
     int head_size;
     int rope_segs;            // leading segments that get rotated (q, k -> 2)
+    // EPI_ARGMAX (classifier): store logits AND one (max, first index) per block,
+    // so main.zig:715 argmax only has to scan gridDim.x candidates afterwards
+    float *part_val;
+    int *part_idx;
+    int row_offset;           // global index of row 0 (vocab shard offset)
 };
 
 // main.zig:361-389: scores, softmax, att.V for the local heads of one layer
@@ -89,6 +94,9 @@ struct AttnArgs {
 struct ArgmaxArgs {
     const float *logits;
     int vocab;
+    const float *part_val;   // if non-null: scan n_part (value, index) candidates instead
+    const int *part_idx;
+    int n_part;
     int *token_ptr;          // in/out: current token
     int *pos_ptr;            // in/out
     const int *prompt;       // forced tokens (n_prompt)
@@ -102,7 +110,9 @@ struct ArgmaxArgs {
 };
 
 // Launchers (kernels.hip).  All return a hipError_t from the launch.
-hipError_t launch_matvec(const MatvecArgs &a, int pro, int epi, int max_blocks, hipStream_t st);
+hipError_t launch_matvec(const MatvecArgs &a, int pro, int epi, int max_blocks_per_cu, int n_cus,
+                         hipStream_t st, int *out_grid = nullptr);
+int matvec_max_grid(int n_cus);  // upper bound of the grid launch_matvec picks
 hipError_t launch_attention(const AttnArgs &a, int n_heads_local, hipStream_t st);
 hipError_t launch_argmax(const ArgmaxArgs &a, hipStream_t st);
 hipError_t launch_set_state(int token, int pos, int *token_ptr, int *pos_ptr, const float *tok_emb,
