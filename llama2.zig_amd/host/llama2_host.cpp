@@ -1,0 +1,299 @@
+// llama2_host.cpp -- see llama2_host.hpp.  Citations: /root/reference/src/main.zig.
+#include "llama2_host.hpp"
+
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace l2zhost {
+
+bool Tokenizer::from_file(const std::string &path, size_t vocab_size, std::string *err)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) {
+        if (err) *err = "cannot open tokenizer '" + path + "'";
+        return false;
+    }
+    auto fail = [&](const char *what) {
+        if (err) *err = std::string("tokenizer '") + path + "': " + what;
+        fclose(f);
+        return false;
+    };
+    tokens.assign(vocab_size, std::string());
+    scores.assign(vocab_size, 0.0f);
+    first_index_.clear();
+    if (fread(&max_token_len, sizeof(uint32_t), 1, f) != 1) return fail("truncated header");  // :186
+    for (size_t i = 0; i < vocab_size; i++) {                                                 // :188
+        uint32_t len = 0;
+        if (fread(&scores[i], sizeof(float), 1, f) != 1) return fail("truncated score");      // :189
+        if (fread(&len, sizeof(uint32_t), 1, f) != 1) return fail("truncated length");        // :190
+        if (len > (1u << 20)) return fail("implausible token length");
+        tokens[i].resize(len);
+        if (len && fread(tokens[i].data(), 1, len, f) != len) return fail("truncated token"); // :192
+        first_index_.emplace(tokens[i], (int)i);  // emplace keeps the FIRST index, like :209-213
+    }
+    fclose(f);
+    return true;
+}
+
+int Tokenizer::lookup(std::string_view str) const
+{
+    auto it = first_index_.find(std::string(str));
+    return it == first_index_.end() ? -1 : it->second;
+}
+
+static int utf8_len(unsigned char c)
+{
+    if (c < 0x80) return 1;
+    if ((c & 0xE0) == 0xC0) return 2;
+    if ((c & 0xF0) == 0xE0) return 3;
+    if ((c & 0xF8) == 0xF0) return 4;
+    return -1;  // std.unicode.utf8ByteSequenceLength error
+}
+
+bool Tokenizer::encode(std::string_view input, std::vector<int32_t> *out, std::string *err) const
+{
+    out->clear();
+    if (max_token_len * 2 > 128) {  // :222-225 TokensTooLong
+        if (err) *err = "TokensTooLong";
+        return false;
+    }
+    // :236-245 one token per UTF-8 code point
+    size_t idx = 0;
+    while (idx < input.size()) {
+        const int n = utf8_len((unsigned char)input[idx]);
+        if (n < 0 || idx + (size_t)n > input.size()) {
+            if (err) *err = "Utf8InvalidStartByte";
+            return false;
+        }
+        const int id = lookup(input.substr(idx, (size_t)n));
+        if (id < 0) {
+            if (err) *err = "TokenNotFound";  // :240-242
+            return false;
+        }
+        out->push_back(id);
+        idx += (size_t)n;
+    }
+    // :247-278 merge the best-scoring adjacent pair until none merges
+    std::string cat;
+    while (out->size() >= 2) {
+        float best_score = -1e10f;  // :248
+        int best_id = 0;
+        long best_idx = -1;
+        for (size_t i = 0; i + 1 < out->size(); i++) {
+            cat.assign(tokens[(*out)[i]]);
+            cat.append(tokens[(*out)[i + 1]]);
+            const int id = lookup(cat);
+            if (id >= 0 && scores[id] > best_score) {  // :261 strict: the earliest pair wins ties
+                best_score = scores[id];
+                best_id = id;
+                best_idx = (long)i;
+            }
+        }
+        if (best_idx < 0) break;  // :274-277
+        (*out)[(size_t)best_idx] = best_id;
+        out->erase(out->begin() + best_idx + 1);  // :272-273
+    }
+    return true;
+}
+
+// ---- PRNG: Xoshiro256++ / SplitMix64 as in Zig's std.Random ----
+static inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+void Prng::seed_with(uint64_t seed)
+{
+    uint64_t sm = seed;
+    for (int i = 0; i < 4; i++) {  // SplitMix64.next()
+        sm += 0x9E3779B97F4A7C15ULL;
+        uint64_t z = sm;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        s_[i] = z ^ (z >> 31);
+    }
+}
+
+uint64_t Prng::next_u64()
+{
+    const uint64_t r = rotl(s_[0] + s_[3], 23) + s_[0];
+    const uint64_t t = s_[1] << 17;
+    s_[2] ^= s_[0];
+    s_[3] ^= s_[1];
+    s_[1] ^= s_[2];
+    s_[0] ^= s_[3];
+    s_[2] ^= t;
+    s_[3] = rotl(s_[3], 45);
+    return r;
+}
+
+float Prng::next_f32()
+{
+    // std.Random.float(f32): 23 mantissa bits, exponent from the count of leading zeros
+    const uint64_t rnd = next_u64();
+    int lz = rnd ? __builtin_clzll(rnd) : 64;
+    if (lz >= 41) {
+        const uint64_t r2 = next_u64();
+        lz = 41 + (r2 ? __builtin_clzll(r2) : 64);
+        if (lz == 41 + 64) {
+            const uint32_t r3 = (uint32_t)next_u64() | 1u;
+            lz += __builtin_clz(r3);
+        }
+    }
+    const uint32_t mantissa = (uint32_t)rnd & 0x7FFFFFu;
+    const uint32_t exponent = (uint32_t)(126 - lz) << 23;
+    const uint32_t bits = exponent | mantissa;
+    float f;
+    std::memcpy(&f, &bits, sizeof f);
+    return f;
+}
+
+void softmax(float *x, size_t n)
+{
+    float max = x[0];
+    for (size_t i = 1; i < n; i++)
+        if (x[i] > max) max = x[i];
+    float sum = 0.0f;
+    for (size_t i = 0; i < n; i++) {
+        x[i] = expf(x[i] - max);
+        sum += x[i];
+    }
+    for (size_t i = 0; i < n; i++) x[i] /= sum;
+}
+
+size_t argmax(const float *x, size_t n)
+{
+    float max = x[0];
+    size_t maxi = 0;
+    for (size_t i = 1; i < n; i++)
+        if (x[i] > max) {
+            max = x[i];
+            maxi = i;
+        }
+    return maxi;
+}
+
+size_t sample(const float *probs, size_t n, Prng &rng)
+{
+    const float r = rng.next_f32();  // :731
+    float cdf = 0.0f;
+    for (size_t i = 0; i < n; i++) {
+        cdf += probs[i];
+        if (r < cdf) return i;
+    }
+    return n - 1;  // :740
+}
+
+size_t sample_top_p(const float *probs, size_t n, float p, std::vector<IndexedF32> &scratch,
+                    Prng &rng)
+{
+    // :759-770 candidates below (1-p)/(n-1) cannot be in the nucleus
+    const float cutoff = (1.0f - p) / ((float)n - 1.0f);
+    scratch.clear();
+    for (size_t i = 0; i < n; i++)
+        if (probs[i] >= cutoff) scratch.push_back({(uint32_t)i, probs[i]});
+    if (scratch.empty()) return argmax(probs, n);  // reference asserts; be safe in release
+    std::sort(scratch.begin(), scratch.end(),
+              [](const IndexedF32 &a, const IndexedF32 &b) { return a.value > b.value; });  // :774
+    float cumulative = 0.0f;
+    size_t cutoff_index = scratch.size() - 1;  // :778
+    for (size_t i = 0; i < scratch.size(); i++) {
+        cumulative += scratch[i].value;
+        if (cumulative > p) {  // :781
+            cutoff_index = i;
+            break;
+        }
+    }
+    const float r = rng.next_f32() * cumulative;  // :789
+    float cdf = 0.0f;
+    for (size_t i = 0; i <= cutoff_index; i++) {
+        cdf += scratch[i].value;
+        if (r < cdf) return scratch[i].index;
+    }
+    return scratch[cutoff_index].index;  // :797
+}
+
+int is_raw_byte(std::string_view s)
+{
+    if (s.size() != 6) return -1;
+    if (s[0] != '<' || s[1] != '0' || s[2] != 'x' || s[5] != '>') return -1;
+    int byte = 0;
+    for (int i = 3; i < 5; i++) {
+        const char c = s[(size_t)i];
+        byte *= 16;
+        if (c >= '0' && c <= '9') byte += c - '0';
+        else if (c >= 'a' && c <= 'f') byte += c - 'a' + 10;
+        else if (c >= 'A' && c <= 'F') byte += c - 'A' + 10;
+        else return -1;
+    }
+    // std.ascii.isPrint (0x20..0x7e) or isWhitespace (' ', \t \n \r \v \f)
+    const bool print = byte >= 0x20 && byte <= 0x7e;
+    const bool space = byte == ' ' || (byte >= 9 && byte <= 13);
+    return (print || space) ? byte : -1;
+}
+
+}  // namespace l2zhost
+
+// ---- C hooks so the tests can drive the host logic through ctypes ----
+using namespace l2zhost;
+
+extern "C" {
+
+void *l2zh_tokenizer_open(const char *path, size_t vocab_size, char *err, size_t err_cap)
+{
+    auto *t = new Tokenizer();
+    std::string e;
+    if (!t->from_file(path, vocab_size, &e)) {
+        if (err && err_cap) snprintf(err, err_cap, "%s", e.c_str());
+        delete t;
+        return nullptr;
+    }
+    return t;
+}
+void l2zh_tokenizer_close(void *t) { delete static_cast<Tokenizer *>(t); }
+int l2zh_tokenizer_lookup(void *t, const char *bytes, size_t n)
+{
+    return static_cast<Tokenizer *>(t)->lookup(std::string_view(bytes, n));
+}
+uint32_t l2zh_tokenizer_max_token_len(void *t) { return static_cast<Tokenizer *>(t)->max_token_len; }
+size_t l2zh_tokenizer_token(void *t, int id, char *out, size_t cap)
+{
+    const std::string &s = static_cast<Tokenizer *>(t)->tokens[(size_t)id];
+    const size_t n = s.size() < cap ? s.size() : cap;
+    std::memcpy(out, s.data(), n);
+    return s.size();
+}
+// returns the token count, or -1 on error
+long l2zh_tokenizer_encode(void *t, const char *bytes, size_t n, int32_t *out, size_t cap)
+{
+    std::vector<int32_t> v;
+    std::string e;
+    if (!static_cast<Tokenizer *>(t)->encode(std::string_view(bytes, n), &v, &e)) return -1;
+    for (size_t i = 0; i < v.size() && i < cap; i++) out[i] = v[i];
+    return (long)v.size();
+}
+int l2zh_is_raw_byte(const char *s, size_t n) { return is_raw_byte(std::string_view(s, n)); }
+void l2zh_prng_floats(uint64_t seed, float *out, size_t n)
+{
+    Prng r(seed);
+    for (size_t i = 0; i < n; i++) out[i] = r.next_f32();
+}
+uint64_t l2zh_prng_u64(uint64_t seed, size_t skip)
+{
+    Prng r(seed);
+    for (size_t i = 0; i < skip; i++) r.next_u64();
+    return r.next_u64();
+}
+size_t l2zh_sample(const float *probs, size_t n, uint64_t seed)
+{
+    Prng r(seed);
+    return sample(probs, n, r);
+}
+size_t l2zh_sample_top_p(const float *probs, size_t n, float p, uint64_t seed)
+{
+    Prng r(seed);
+    std::vector<IndexedF32> scratch;
+    return sample_top_p(probs, n, p, scratch, r);
+}
+void l2zh_softmax(float *x, size_t n) { softmax(x, n); }
+}

@@ -1,0 +1,278 @@
+// llama2_main.cpp -- the reference's command line (src/main.zig:800-1051) over the
+// MI355X forward pass.  Same flags, defaults, clamping, output and tokens/s rule;
+// transformer() runs on the GPU through include/llama2_hip.h.
+//
+//   llama2 <checkpoint> [-t temp] [-p top_p] [-n steps] [-i prompt] [-s seed] [-v] [-z tokenizer]
+//
+// At -t 0 the whole generation loop runs on the device (l2z_greedy_run) and the host
+// only prints; otherwise one l2z_transformer + l2z_logits_read per position feeds the
+// reference's host-side samplers.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/llama2_hip.h"
+#include "llama2_host.hpp"
+
+using namespace l2zhost;
+
+// main.zig:800-813
+static const char *usage_text =
+    "Usage:   llama2 <checkpoint> [options]\n"
+    "Example: llama2 checkpoint.bin -n 256 -i \"Once upon a time\"\n"
+    "Options:\n"
+    " -h, --help                print this help message\n"
+    " -t, --temperature <float> temperature, default 1.0 (0.0, 1]\n"
+    " -p, --top-p <float>       p value in top-p (nucleus) sampling. default 0.9, 0 || 1 = off\n"
+    " -n, --seq-len <int>       number of steps to run for, default 256. 0 = max_seq_len\n"
+    " -i, --input <string>      input text for the prompt, default \"\"\n"
+    " -s, --seed <int>          random seed, default to time\n"
+    " -v, --verbose             print model info and tokens/s\n"
+    " -z, --tokenizer <path>    path to the tokenizer to use, default to \"tokenizer.bin\"\n"
+    " --tokens                  (extension) also print the token ids to stderr, one line\n";
+
+static bool verbose = false;
+#define LOGV(...)                                 \
+    do {                                          \
+        if (verbose) fprintf(stderr, __VA_ARGS__); \
+    } while (0)
+
+static int die(const char *what)
+{
+    fprintf(stderr, "error: %s: %s\n", what, l2z_last_error());
+    return 1;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) {  // :833-836
+        fputs(usage_text, stdout);
+        return 0;
+    }
+    const char *bin_path = nullptr;
+    const char *input = nullptr;
+    float temperature = 1.0f, top_p = 0.9f;  // :840-841
+    size_t seq_len = 0;
+    std::string tokenizer_path = "tokenizer.bin";
+    bool dump_tokens = false;
+    Prng prng((uint64_t)std::chrono::system_clock::now().time_since_epoch().count());  // :844-845
+
+    auto need = [&](int &i, const char *what) -> const char * {  // :863-867 etc.
+        if (++i >= argc) {
+            fprintf(stderr, "error: missing argument for %s\n", what);
+            exit(1);
+        }
+        return argv[i];
+    };
+    for (int i = 1; i < argc; i++) {  // :848-934
+        const std::string a = argv[i];
+        if (a == "-h" || a == "--help") {
+            fputs(usage_text, stdout);
+            return 0;
+        }
+        if (a.empty() || a[0] != '-') {
+            if (bin_path) {  // :856-858
+                fprintf(stderr, "error: multiple checkpoint paths specified\n");
+                return 1;
+            }
+            bin_path = argv[i];
+        } else if (a == "-t" || a == "--temperature") {
+            const char *v = need(i, "temperature");
+            char *end = nullptr;
+            temperature = strtof(v, &end);
+            if (end == v || *end) {
+                fprintf(stderr, "unable to parse --temperature argument '%s'\n", v);
+                return 1;
+            }  // not clamped, :874
+        } else if (a == "-n" || a == "--seq-len") {
+            const char *v = need(i, "seq-len");
+            char *end = nullptr;
+            const long long n = strtoll(v, &end, 10);
+            if (end == v || *end || n < 0) {
+                fprintf(stderr, "unable to parse --seq-len argument '%s'\n", v);
+                return 1;
+            }
+            seq_len = (size_t)n;
+        } else if (a == "-p" || a == "--top-p") {
+            const char *v = need(i, "top-p");
+            char *end = nullptr;
+            top_p = strtof(v, &end);
+            if (end == v || *end) {
+                fprintf(stderr, "unable to parse --top-p argument '%s'\n", v);
+                return 1;
+            }
+            top_p = top_p < 0.0f ? 0.0f : (top_p > 1.0f ? 1.0f : top_p);  // :899
+        } else if (a == "-i" || a == "--input") {
+            input = need(i, "input");
+        } else if (a == "-z" || a == "--tokenizer") {
+            tokenizer_path = need(i, "tokenizer");
+        } else if (a == "-s" || a == "--seed") {
+            const char *v = need(i, "seed");
+            char *end = nullptr;
+            const unsigned long long s = strtoull(v, &end, 10);
+            if (end == v || *end) {
+                fprintf(stderr, "unable to parse --seed argument '%s'\n", v);
+                return 1;
+            }
+            prng.seed_with((uint64_t)s);  // :926
+        } else if (a == "-v" || a == "--verbose") {
+            verbose = true;
+        } else if (a == "--tokens") {
+            dump_tokens = true;
+        } else {  // :929-933
+            fprintf(stderr, "error: unknown argument '%s'\n", argv[i]);
+            fputs(usage_text, stdout);
+            return 0;
+        }
+    }
+    if (!bin_path) {
+        fputs(usage_text, stdout);
+        return 1;
+    }
+
+    // ---- checkpoint: 28-byte header + f32 blob (:936-967); mmap instead of a heap copy:
+    // l2z_weights_init streams it to the GPU once and the mapping is dropped
+    const int fd = open(bin_path, O_RDONLY);
+    if (fd < 0) {
+        fprintf(stderr, "error: cannot open checkpoint '%s'\n", bin_path);
+        return 1;
+    }
+    struct stat st;
+    if (fstat(fd, &st) != 0 || (size_t)st.st_size < sizeof(l2z_config)) {
+        fprintf(stderr, "error: checkpoint '%s' is too small\n", bin_path);
+        return 1;
+    }
+    void *map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (map == MAP_FAILED) {
+        fprintf(stderr, "error: mmap of '%s' failed\n", bin_path);
+        return 1;
+    }
+    l2z_config cfg;
+    memcpy(&cfg, map, sizeof cfg);                       // :941
+    const bool shared_weights = cfg.vocab_size > 0;      // :943
+    cfg.vocab_size = abs(cfg.vocab_size);                // :944
+    LOGV("config: dim %d hidden_dim %d n_layers %d n_heads %d n_kv_heads %d vocab_size %d seq_len %d\n",
+         cfg.dim, cfg.hidden_dim, cfg.n_layers, cfg.n_heads, cfg.n_kv_heads, cfg.vocab_size, cfg.seq_len);
+    LOGV("shared weights: %s\ntemperature: %g\ntop-p: %g\n", shared_weights ? "true" : "false",
+         temperature, top_p);
+    {
+        char name[256] = "";
+        int cus = 0;
+        uint64_t hbm = 0;
+        if (l2z_device_info(0, name, sizeof name, &cus, &hbm) != L2Z_OK) return die("no GPU");
+        LOGV("device: %s, %d CUs, %.0f GB HBM\n\n", name, cus, (double)hbm / 1e9);
+    }
+    const float *data = reinterpret_cast<const float *>(static_cast<const char *>(map) + sizeof cfg);
+    const size_t n_floats = ((size_t)st.st_size - sizeof cfg) / sizeof(float);
+    l2z_weights *w = nullptr;
+    if (l2z_weights_init(&cfg, data, n_floats, shared_weights, nullptr, &w) != L2Z_OK)
+        return die("Weights.init");
+    munmap(map, (size_t)st.st_size);
+    close(fd);
+
+    Tokenizer tok;  // :970
+    std::string err;
+    if (!tok.from_file(tokenizer_path, (size_t)cfg.vocab_size, &err)) {
+        fprintf(stderr, "error: %s\n", err.c_str());
+        return 1;
+    }
+    l2z_runstate *s = nullptr;  // :974
+    if (l2z_runstate_init(&cfg, nullptr, &s) != L2Z_OK) return die("RunState.init");
+
+    std::vector<int32_t> prompt;  // :978-985
+    if (input && !tok.encode(input, &prompt, &err)) {
+        fprintf(stderr, "error: cannot encode the prompt: %s\n", err.c_str());
+        return 1;
+    }
+    const size_t prompt_len = prompt.size();
+
+    seq_len = seq_len == 0 ? (size_t)cfg.seq_len : seq_len;                        // :992
+    seq_len = seq_len < 1 ? 1 : (seq_len > (size_t)cfg.seq_len ? (size_t)cfg.seq_len : seq_len);  // :993
+
+    std::vector<float> logits((size_t)cfg.vocab_size);
+    std::vector<IndexedF32> logits_indexed;
+    std::vector<int32_t> produced;
+    bool timer_started = false;
+    std::chrono::steady_clock::time_point t0;
+    size_t token = 1, pos = 0;  // :988, :994
+
+    // print one token exactly as :1022-1041 does; returns false if the sequence ended
+    auto emit = [&](size_t next) -> bool {
+        produced.push_back((int32_t)next);
+        if (next == 1) return false;  // :1017
+        std::string_view piece = tok.tokens[next];
+        if (token == 1 && !piece.empty() && piece[0] == ' ') piece.remove_prefix(1);  // :1022-1025
+        const int byte = is_raw_byte(piece);
+        if (byte >= 0) {  // :1028-1031: printed, but the timer is not started on this path
+            fputc(byte, stdout);
+            token = next;
+            return true;
+        }
+        fwrite(piece.data(), 1, piece.size(), stdout);
+        token = next;
+        if (!timer_started) {  // :1039-1041
+            fflush(stdout);
+            timer_started = true;
+            t0 = std::chrono::steady_clock::now();
+        }
+        return true;
+    };
+
+    if (temperature == 0.0f) {
+        // the loop of :995-1042 on the device; prompt override included
+        if (l2z_greedy_begin(s, prompt.data(), (int)prompt_len) != L2Z_OK) return die("greedy_begin");
+        std::vector<int32_t> chunk(64);
+        bool alive = true;
+        while (alive && pos < seq_len) {
+            // first token alone so the clock starts where the reference starts it
+            const int want = pos == 0 ? 1 : (int)std::min<size_t>(chunk.size(), seq_len - pos);
+            int got = 0;
+            if (l2z_greedy_run(&cfg, s, w, want, chunk.data(), &got) != L2Z_OK) return die("greedy_run");
+            if (got == 0) break;
+            for (int i = 0; i < got && alive; i++) {
+                alive = emit((size_t)chunk[(size_t)i]);
+                if (alive) pos++;
+            }
+        }
+    } else {
+        for (; pos < seq_len; pos++) {
+            if (l2z_transformer((int)token, (int)pos, &cfg, s, w) != L2Z_OK) return die("transformer");  // :996
+            size_t next;
+            if (pos < prompt_len) {
+                next = (size_t)prompt[pos];  // :999-1000
+            } else {
+                if (l2z_logits_read(s, logits.data()) != L2Z_OK) return die("logits_read");
+                if (temperature != 1.0f)
+                    for (float &v : logits) v /= temperature;  // :1005-1007
+                softmax(logits.data(), logits.size());          // :1008
+                next = (top_p == 0.0f || top_p == 1.0f)         // :1009-1012
+                           ? sample(logits.data(), logits.size(), prng)
+                           : sample_top_p(logits.data(), logits.size(), top_p, logits_indexed, prng);
+            }
+            if (!emit(next)) break;
+        }
+    }
+    fflush(stdout);
+    if (timer_started) {  // :1043-1050 (the reference panics when no token was ever printed)
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const double tps = pos >= 1 ? (double)(pos - 1) / el : 0.0;
+        LOGV("\n\n%u tokens per second\n", (unsigned)tps);
+    }
+    if (dump_tokens) {
+        fprintf(stderr, "tokens:");
+        for (int32_t t : produced) fprintf(stderr, " %d", t);
+        fprintf(stderr, "\n");
+    }
+    l2z_runstate_free(s);
+    l2z_weights_free(w);
+    return 0;
+}

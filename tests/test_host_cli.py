@@ -1,0 +1,201 @@
+"""Host side above the C ABI (llama2.zig_amd/host): tokenizer against the reference's
+`bpe` test vectors (src/main.zig:1152-1180, fixture tests/golden/tokenizer.bin is the
+reference's own data file), samplers, raw-byte formatting, CLI flag handling; and, on
+the GPU, the `llama2` binary end to end against the oracle."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "llama2.zig_amd", "host")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+TOK = os.path.join(GOLDEN, "tokenizer.bin")
+
+
+@pytest.fixture(scope="module")
+def H(B):  # B builds everything if needed
+    if not os.path.exists(os.path.join(HOST, "libllama2_host.so")):
+        subprocess.check_call(["make", "-C", HOST, "-s"])
+    L = C.CDLL(os.path.join(HOST, "libllama2_host.so"))
+    L.l2zh_tokenizer_open.restype = C.c_void_p
+    L.l2zh_tokenizer_open.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    L.l2zh_tokenizer_close.argtypes = [C.c_void_p]
+    L.l2zh_tokenizer_lookup.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.l2zh_tokenizer_max_token_len.argtypes = [C.c_void_p]
+    L.l2zh_tokenizer_max_token_len.restype = C.c_uint32
+    L.l2zh_tokenizer_token.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
+    L.l2zh_tokenizer_token.restype = C.c_size_t
+    L.l2zh_tokenizer_encode.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.c_size_t]
+    L.l2zh_tokenizer_encode.restype = C.c_long
+    L.l2zh_is_raw_byte.argtypes = [C.c_char_p, C.c_size_t]
+    L.l2zh_prng_floats.argtypes = [C.c_uint64, C.POINTER(C.c_float), C.c_size_t]
+    L.l2zh_prng_u64.argtypes = [C.c_uint64, C.c_size_t]
+    L.l2zh_prng_u64.restype = C.c_uint64
+    L.l2zh_sample.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_uint64]
+    L.l2zh_sample.restype = C.c_size_t
+    L.l2zh_sample_top_p.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_float, C.c_uint64]
+    L.l2zh_sample_top_p.restype = C.c_size_t
+    L.l2zh_softmax.argtypes = [C.POINTER(C.c_float), C.c_size_t]
+    return L
+
+
+@pytest.fixture(scope="module")
+def tok(H):
+    err = C.create_string_buffer(256)
+    t = H.l2zh_tokenizer_open(TOK.encode(), 32000, err, 256)
+    assert t, err.value
+    yield t
+    H.l2zh_tokenizer_close(t)
+
+
+def encode(H, tok, text: str):
+    b = text.encode("utf-8")
+    out = (C.c_int32 * (len(b) + 1))()
+    n = H.l2zh_tokenizer_encode(tok, b, len(b), out, len(b) + 1)
+    return None if n < 0 else list(out[:n])
+
+
+def test_bpe_reference_vectors(H, tok):
+    """src/main.zig:1152-1180, every assertion of the reference's `bpe` test"""
+    ae = "æ".encode()
+    assert H.l2zh_tokenizer_lookup(tok, ae, len(ae)) == 233
+    buf = C.create_string_buffer(64)
+    assert H.l2zh_tokenizer_token(tok, 100, buf, 64) == 1 and buf.raw[:1] == b"a"
+    assert H.l2zh_tokenizer_max_token_len(tok) == 27
+    assert H.l2zh_tokenizer_lookup(tok, b"a", 1) == 100
+    assert encode(H, tok, "A man dying of thirst is suddenly a mineral water critic?") == \
+        [68, 767, 27116, 310, 266, 765, 338, 11584, 263, 1375, 13537, 4094, 11164, 66]
+    assert encode(H, tok, "中") == [30275]
+
+
+def test_tokenizer_edges(H, tok):
+    assert encode(H, tok, "") == []
+    assert encode(H, tok, "a") == [100]
+    b = b"\xff"  # invalid UTF-8 start byte -> error like std.unicode
+    out = (C.c_int32 * 4)()
+    assert H.l2zh_tokenizer_encode(tok, b, 1, out, 4) == -1
+    err = C.create_string_buffer(256)
+    assert not H.l2zh_tokenizer_open(b"/nonexistent/tokenizer.bin", 10, err, 256)
+    assert b"cannot open" in err.value
+    # truncated vocabulary (main.zig:173 reads only vocab_size entries)
+    t = H.l2zh_tokenizer_open(TOK.encode(), 512, err, 256)
+    assert t and H.l2zh_tokenizer_lookup(t, b"a", 1) == 100
+    H.l2zh_tokenizer_close(t)
+
+
+def test_is_raw_byte(H):
+    """src/main.zig:1055-1076"""
+    f = lambda s: H.l2zh_is_raw_byte(s, len(s))
+    assert f(b"<0x41>") == 0x41 and f(b"<0x0A>") == 10 and f(b"<0x0a>") == 10
+    assert f(b"<0x00>") == -1 and f(b"<0x7F>") == -1     # not printable, not whitespace
+    assert f(b"<0xZZ>") == -1 and f(b"<0x4>") == -1 and f(b"hello!") == -1
+
+
+def test_prng_is_xoshiro256pp(H):
+    """Independent Python restatement of SplitMix64 -> Xoshiro256++ (Zig DefaultPrng)."""
+    M = (1 << 64) - 1
+
+    def stream(seed, n):
+        s, sm = [], seed
+        for _ in range(4):
+            sm = (sm + 0x9E3779B97F4A7C15) & M
+            z = sm
+            z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+            z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+            s.append(z ^ (z >> 31))
+        rot = lambda x, k: ((x << k) | (x >> (64 - k))) & M
+        out = []
+        for _ in range(n):
+            out.append((rot((s[0] + s[3]) & M, 23) + s[0]) & M)
+            t = (s[1] << 17) & M
+            s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rot(s[3], 45)
+        return out
+
+    for seed in (0, 1, 42, 2**63 + 5):
+        exp = stream(seed, 5)
+        assert [H.l2zh_prng_u64(seed, k) for k in range(5)] == exp
+    fl = (C.c_float * 10000)()
+    H.l2zh_prng_floats(7, fl, 10000)
+    a = np.array(fl[:])
+    assert a.min() >= 0.0 and a.max() < 1.0 and abs(a.mean() - 0.5) < 0.02
+
+
+def test_samplers(H):
+    """main.zig:728-798: cdf sampling, nucleus sampling restricted to the top-p set"""
+    p = np.array([0.05, 0.6, 0.05, 0.3], np.float32)
+    pp = p.ctypes.data_as(C.POINTER(C.c_float))
+    draws = [H.l2zh_sample(pp, 4, s) for s in range(400)]
+    assert set(draws) <= {0, 1, 2, 3} and 180 < draws.count(1) < 300
+    nuc = [H.l2zh_sample_top_p(pp, 4, 0.8, s) for s in range(400)]
+    assert set(nuc) <= {1, 3}           # 0.6 + 0.3 > 0.8: tokens 0 and 2 can never be drawn
+    one = np.array([0, 0, 1, 0], np.float32)
+    assert H.l2zh_sample(one.ctypes.data_as(C.POINTER(C.c_float)), 4, 3) == 2
+    x = np.array([1, 2, 3, 4], np.float32)
+    H.l2zh_softmax(x.ctypes.data_as(C.POINTER(C.c_float)), 4)
+    assert abs(float(x.sum()) - 1) < 1e-6 and np.all(np.diff(x) > 0)
+
+
+def test_cli_usage_and_errors():
+    exe = os.path.join(HOST, "llama2")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("Usage:   llama2 <checkpoint> [options]")
+    r = subprocess.run([exe, "-h"], capture_output=True, text=True)
+    assert "-z, --tokenizer <path>" in r.stdout
+    r = subprocess.run([exe, "a.bin", "b.bin"], capture_output=True, text=True)
+    assert r.returncode == 1 and "multiple checkpoint paths" in r.stderr          # main.zig:857
+    r = subprocess.run([exe, "a.bin", "-t"], capture_output=True, text=True)
+    assert r.returncode == 1 and "missing argument for temperature" in r.stderr   # main.zig:865
+    r = subprocess.run([exe, "a.bin", "-n", "abc"], capture_output=True, text=True)
+    assert r.returncode == 1 and "unable to parse --seq-len" in r.stderr
+    r = subprocess.run([exe, "a.bin", "--bogus"], capture_output=True, text=True)
+    assert "unknown argument '--bogus'" in r.stderr and r.stdout.startswith("Usage")  # :930
+    r = subprocess.run([exe, "/nonexistent.bin"], capture_output=True, text=True)
+    assert r.returncode == 1 and "cannot open checkpoint" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_greedy_matches_oracle(gpu, ck, orc, tmp_path):
+    """`llama2 ckpt -t 0 -n N [-i prompt]` prints the oracle's greedy tokens."""
+    exe = os.path.join(HOST, "llama2")
+    ckpt = os.path.join(GOLDEN, "toy_gqa_unshared.bin")
+    c, shared, blob = ck.read_checkpoint(ckpt, mmap=False)
+    H = C.CDLL(os.path.join(HOST, "libllama2_host.so"))
+    for prompt_text in (None, "a b"):
+        args = [exe, ckpt, "-t", "0", "-n", "24", "-z", TOK, "-v", "--tokens"]
+        prompt = []
+        if prompt_text:
+            args += ["-i", prompt_text]
+            err = C.create_string_buffer(64)
+            H.l2zh_tokenizer_open.restype = C.c_void_p
+            t = H.l2zh_tokenizer_open(TOK.encode(), c.vocab_size, err, 64)
+            out = (C.c_int32 * 16)()
+            H.l2zh_tokenizer_encode.restype = C.c_long
+            n = H.l2zh_tokenizer_encode(C.c_void_p(t), prompt_text.encode(), len(prompt_text), out, 16)
+            prompt = list(out[:n])
+            assert all(p < c.vocab_size for p in prompt)
+        r = subprocess.run(args, capture_output=True, timeout=120)
+        assert r.returncode == 0, r.stderr.decode(errors="replace")
+        line = [l for l in r.stderr.decode(errors="replace").splitlines() if l.startswith("tokens:")][0]
+        got = [int(v) for v in line.split()[1:]]
+        m = orc.Model(c.as_i32(), blob, shared)
+        ref, _ = m.generate_greedy(prompt, 24)
+        assert got == ref.tolist()
+        assert b"tokens per second" in r.stderr
+        m.close()
+
+
+@pytest.mark.gpu
+def test_cli_sampling_runs(gpu):
+    """-t 1.0 -p 0.9 (BASELINE config 3 flags): the sampled path runs and is seed-deterministic."""
+    exe = os.path.join(HOST, "llama2")
+    ckpt = os.path.join(GOLDEN, "toy_mha_shared.bin")
+    outs = []
+    for _ in range(2):
+        r = subprocess.run([exe, ckpt, "-t", "1.0", "-p", "0.9", "-n", "16", "-s", "123", "-z", TOK,
+                            "--tokens"], capture_output=True, timeout=120)
+        assert r.returncode == 0, r.stderr.decode(errors="replace")
+        outs.append([l for l in r.stderr.decode().splitlines() if l.startswith("tokens:")][0])
+    assert outs[0] == outs[1] and len(outs[0].split()) > 2
