@@ -133,7 +133,11 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     comm, barrier, dist = None, None, None
-    if args.gpus > 1 or world > 1:
+    # Load libllama2_hip.so (and with it the system HIP runtime) BEFORE torch, so that both
+    # share one libamdhip64 -- the one the kernels were built against.
+    B.lib()
+    force_dist = os.environ.get("L2Z_BENCH_FORCE_DIST") == "1"  # 1-rank RCCL + gloo, for testing
+    if args.gpus > 1 or world > 1 or force_dist:
         if world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with "
                              "python -m torch.distributed.run --nproc-per-node N ...)")

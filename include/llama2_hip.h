@@ -173,6 +173,14 @@ int l2z_comm_unique_id(void *out_id);
 int l2z_comm_init(int rank, int world, const void *id, int device, l2z_comm **out);
 int l2z_comm_rank(const l2z_comm *c, int *rank, int *world);
 void l2z_comm_free(l2z_comm *c);
+/* Testing support: N emulated ranks in ONE process on ONE GPU (RCCL refuses two ranks on
+ * one device).  l2z_comm_init_emulated makes a rank descriptor without a communicator;
+ * weights / runstates built with it hold exactly rank r's shard; l2z_emu_transformer runs
+ * one forward pass for all ranks, interleaved stage by stage, doing each all-gather as
+ * device-to-device copies.  Afterwards every rank's logits must equal the unsharded pass. */
+int l2z_comm_init_emulated(int rank, int world, int device, l2z_comm **out);
+int l2z_emu_transformer(int n_ranks, l2z_runstate *const *ss, const l2z_weights *const *ws,
+                        int token, int pos);
 /* Pure host logic, no GPU needed: the row range [*r0,*r1) of a `rows`-row
  * tensor owned by `rank` of `world`, in units of `granule` rows (head_size for
  * q/k/v so shards are whole heads, 1 otherwise).  Fails if not divisible. */

@@ -91,6 +91,8 @@ def lib():
     L.l2z_comm_rank.argtypes = [vp, ip, ip]
     L.l2z_comm_free.argtypes = [vp]
     L.l2z_comm_free.restype = None
+    L.l2z_comm_init_emulated.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.l2z_emu_transformer.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int]
     L.l2z_shard_range.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64),
                                   C.POINTER(C.c_int64)]
     _lib = L
@@ -140,10 +142,13 @@ def _cfg(cfg) -> L2ZConfig:
 class Comm:
     """Multi-GPU shard group (l2z_comm_*)."""
 
-    def __init__(self, rank: int, world: int, uid: bytes | None, device: int):
+    def __init__(self, rank: int, world: int, uid: bytes | None, device: int, emulated=False):
         self.h = C.c_void_p()
-        buf = C.create_string_buffer(uid, COMM_ID_BYTES) if uid is not None else None
-        _chk(lib().l2z_comm_init(rank, world, buf, device, C.byref(self.h)))
+        if emulated:  # rank descriptor only (l2z_emu_transformer), no RCCL
+            _chk(lib().l2z_comm_init_emulated(rank, world, device, C.byref(self.h)))
+        else:
+            buf = C.create_string_buffer(uid, COMM_ID_BYTES) if uid is not None else None
+            _chk(lib().l2z_comm_init(rank, world, buf, device, C.byref(self.h)))
         self.rank, self.world = rank, world
 
     @staticmethod
@@ -251,6 +256,14 @@ class RunState:
             self.close()
         except Exception:
             pass
+
+
+def emu_transformer(states, weights, token: int, pos: int) -> None:
+    """One forward pass of N emulated ranks on one GPU (l2z_emu_transformer)."""
+    n = len(states)
+    ss = (C.c_void_p * n)(*[s.h for s in states])
+    ws = (C.c_void_p * n)(*[w.h for w in weights])
+    _chk(lib().l2z_emu_transformer(n, ss, ws, token, pos))
 
 
 # ---- kernel-level hooks (names follow src/main.zig) ----

@@ -419,7 +419,7 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
         if (v > 0) s->max_blocks = v;
     }
     if (const char *e = getenv("L2Z_NO_GRAPH")) s->use_graphs = atoi(e) == 0;
-    if (comm && comm->world > 1) s->use_graphs = false;  // RCCL calls are launched eagerly
+    if (comm && (comm->nccl || comm->world > 1)) s->use_graphs = false;  // collectives are launched eagerly
 
     const size_t kv = (size_t)c.n_layers * c.seq_len * sh.kvd_loc;
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
@@ -528,17 +528,29 @@ int check_pair(const l2z_config *config, const l2z_runstate *s, const l2z_weight
 
 // The forward pass (main.zig:285-430) as 5 launches per layer + classifier
 // (+ argmax/hand-over).  Token and pos are read from device memory.
-int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof *prof)
+// `only_stage` >= 0 runs just the launches between two gather points (and no collective):
+// the single-process multi-rank emulation (l2z_emu_transformer) interleaves the ranks
+// stage by stage and performs the gathers itself.  Stages: 4 per layer (after attention,
+// wo, ffn13, ffn2), then the classifier, then argmax.
+int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof *prof,
+                    int only_stage = -1)
 {
     const l2z_config &c = s->cfg;
     const Shard &sh = s->sh;
     hipStream_t st = s->stream;
     const size_t dim = c.dim, hid = c.hidden_dim;
     const int mb = s->max_blocks;
+    int stage = 0;
+    auto want = [&]() { return only_stage < 0 || only_stage == stage; };
+    auto gather = [&](float *buf, size_t count_per_rank) -> int {
+        stage++;
+        if (only_stage >= 0) return L2Z_OK;
+        return comm_allgather_inplace(s->comm, buf, count_per_rank, st);
+    };
     for (int l = 0; l < c.n_layers; l++) {
         float *kc = s->key_cache + (size_t)l * c.seq_len * sh.kvd_loc;  // :354 loff
         float *vc = s->value_cache + (size_t)l * c.seq_len * sh.kvd_loc;
-        {   // rmsnorm (:305) + q,k,v (:308-320) + RoPE (:336-351) + KV write (:354-358)
+        if (want()) {   // rmsnorm (:305) + q,k,v (:308-320) + RoPE (:336-351) + KV write (:354-358)
             MatvecArgs a = {};
             a.w0 = w->wq + (size_t)l * sh.dim_loc * dim;
             a.w1 = w->wk + (size_t)l * sh.kvd_loc * dim;
@@ -550,23 +562,23 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.pos_ptr = s->d_pos; a.rope = s->rope; a.head_size = sh.hs; a.rope_segs = 2;
             L2Z_LAUNCH(KIND_QKV, launch_matvec(a, PRO_RMS, EPI_ROPE, mb, g_cus, st));
         }
-        {   // attention (:361-389) over the local heads
+        if (want()) {   // attention (:361-389) over the local heads
             AttnArgs a = {};
             a.q = s->q; a.kcache = kc; a.vcache = vc; a.xb = s->xb + sh.dim0;
             a.pos_ptr = s->d_pos; a.head_size = sh.hs; a.kv_dim = sh.kvd_loc;
             a.kv_mul = c.n_heads / c.n_kv_heads; a.seq_len = c.seq_len;
             L2Z_LAUNCH(KIND_ATTN, launch_attention(a, sh.heads_loc, st));
         }
-        L2Z_TRY(comm_allgather_inplace(s->comm, s->xb, sh.dim_loc, st));
-        {   // wo (:392) + residual (:395)
+        L2Z_TRY(gather(s->xb, sh.dim_loc));
+        if (want()) {   // wo (:392) + residual (:395)
             MatvecArgs a = {};
             a.w0 = w->wo + (size_t)l * sh.dim_loc * dim;
             a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0;
             a.rows0 = sh.dim_loc; a.n = c.dim; a.x = s->xb;
             L2Z_LAUNCH(KIND_WO, launch_matvec(a, PRO_NONE, EPI_RESID, mb, g_cus, st));
         }
-        L2Z_TRY(comm_allgather_inplace(s->comm, s->x, sh.dim_loc, st));
-        {   // rmsnorm (:398) + w1,w3 (:405-408) + SiLU*mul (:411-416)
+        L2Z_TRY(gather(s->x, sh.dim_loc));
+        if (want()) {   // rmsnorm (:398) + w1,w3 (:405-408) + SiLU*mul (:411-416)
             MatvecArgs a = {};
             a.w0 = w->w1 + (size_t)l * sh.hid_loc * dim;
             a.w1 = w->w3 + (size_t)l * sh.hid_loc * dim;
@@ -575,17 +587,17 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.x = s->x; a.rms_w = w->rms_ffn + (size_t)l * dim;
             L2Z_LAUNCH(KIND_FFN13, launch_matvec(a, PRO_RMS, EPI_SWIGLU, mb, g_cus, st));
         }
-        L2Z_TRY(comm_allgather_inplace(s->comm, s->hb, sh.hid_loc, st));
-        {   // w2 (:419) + residual (:422)
+        L2Z_TRY(gather(s->hb, sh.hid_loc));
+        if (want()) {   // w2 (:419) + residual (:422)
             MatvecArgs a = {};
             a.w0 = w->w2 + (size_t)l * sh.dim_loc * hid;
             a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0;
             a.rows0 = sh.dim_loc; a.n = c.hidden_dim; a.x = s->hb;
             L2Z_LAUNCH(KIND_FFN2, launch_matvec(a, PRO_NONE, EPI_RESID, mb, g_cus, st));
         }
-        L2Z_TRY(comm_allgather_inplace(s->comm, s->x, sh.dim_loc, st));
+        L2Z_TRY(gather(s->x, sh.dim_loc));
     }
-    {   // final rmsnorm (:426) + classifier (:429)
+    if (want()) {   // final rmsnorm (:426) + classifier (:429)
         MatvecArgs a = {};
         a.w0 = w->wcls; a.out0 = s->logits + sh.v0;
         a.rows0 = sh.v_loc; a.n = c.dim; a.x = s->x; a.rms_w = w->rms_final;
@@ -597,8 +609,8 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
                                            &grid));
         s->n_part = fuse ? grid : 0;
     }
-    L2Z_TRY(comm_allgather_inplace(s->comm, s->logits, sh.v_loc, st));
-    if (with_step) {
+    L2Z_TRY(gather(s->logits, sh.v_loc));
+    if (with_step && want()) {
         ArgmaxArgs a = {};
         a.logits = s->logits; a.vocab = c.vocab_size; a.token_ptr = s->d_token;
         if (s->n_part > 0) { a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.n_part = s->n_part; }
@@ -824,6 +836,53 @@ extern "C" int l2z_profile_forward(int token, int pos, const l2z_config *config,
     s->host_pos = pos + 1;
     if (rc != L2Z_OK) return rc;
     L2Z_HIP(e);
+    return L2Z_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Single-process emulation of an N-rank shard group on ONE GPU (testing support): the
+// dev box has one GPU and RCCL refuses two ranks on one device, so this runs the exact
+// per-rank launches of enqueue_forward for every emulated rank, stage by stage, and does
+// each all-gather as device-to-device copies.  Validates sharded upload, shard offsets,
+// KV-cache sharding and GQA head mapping of the real HIP code without a second GPU.
+extern "C" int l2z_emu_transformer(int n_ranks, l2z_runstate *const *ss,
+                                   const l2z_weights *const *ws, int token, int pos)
+{
+    L2Z_CHECK(n_ranks >= 1 && ss && ws, L2Z_ERR_INVALID, "l2z_emu_transformer: bad arguments");
+    const l2z_config &c = ss[0]->cfg;
+    for (int r = 0; r < n_ranks; r++) {
+        L2Z_TRY(check_pair(&c, ss[r], ws[r]));
+        L2Z_CHECK(ss[r]->sh.world == n_ranks && ss[r]->sh.rank == r, L2Z_ERR_INVALID,
+                  "l2z_emu_transformer: runstate %d is not rank %d of %d", r, r, n_ranks);
+        L2Z_HIP(launch_set_state(token, pos, ss[r]->d_token, ss[r]->d_pos, ws[r]->tok_emb, ss[r]->x,
+                                 c.dim, ss[r]->stream));
+    }
+    const int n_stages = 4 * c.n_layers + 1;
+    for (int stage = 0; stage < n_stages; stage++) {
+        for (int r = 0; r < n_ranks; r++) L2Z_TRY(enqueue_forward(ss[r], ws[r], false, nullptr, stage));
+        for (int r = 0; r < n_ranks; r++) L2Z_HIP(hipStreamSynchronize(ss[r]->stream));
+        // which buffer this stage produced, and the per-rank slice length
+        const Shard &sh0 = ss[0]->sh;
+        size_t count;
+        int which;  // 0 xb, 1 x, 2 hb, 3 logits
+        if (stage == n_stages - 1) { which = 3; count = sh0.v_loc; }
+        else if (stage % 4 == 0) { which = 0; count = sh0.dim_loc; }
+        else if (stage % 4 == 2) { which = 2; count = sh0.hid_loc; }
+        else { which = 1; count = sh0.dim_loc; }
+        auto buf = [&](l2z_runstate *s) {
+            return which == 0 ? s->xb : which == 1 ? s->x : which == 2 ? s->hb : s->logits;
+        };
+        for (int src = 0; src < n_ranks; src++)
+            for (int dst = 0; dst < n_ranks; dst++)
+                if (dst != src)
+                    L2Z_HIP(hipMemcpy(buf(ss[dst]) + (size_t)src * count,
+                                      buf(ss[src]) + (size_t)src * count, count * sizeof(float),
+                                      hipMemcpyDeviceToDevice));
+        // D2D hipMemcpy runs on the null stream and may return early; the ranks' streams are
+        // non-blocking, so order the next stage behind the copies explicitly
+        L2Z_HIP(hipDeviceSynchronize());
+    }
+    for (int r = 0; r < n_ranks; r++) ss[r]->host_pos = pos + 1;
     return L2Z_OK;
 }
 

@@ -52,7 +52,7 @@ int load_rccl()
 
 int comm_allgather_inplace(const l2z_comm *c, float *buf, size_t count_per_rank, hipStream_t st)
 {
-    if (c == nullptr || c->world == 1) return L2Z_OK;
+    if (c == nullptr || c->nccl == nullptr) return L2Z_OK;  // single GPU without a communicator
     // in-place form: sendbuff == recvbuff + rank * count
     ncclResult_t r = g_api.AllGather(buf + (size_t)c->rank * count_per_rank, buf, count_per_rank,
                                      ncclFloat, static_cast<ncclComm_t>(c->nccl), st);
@@ -86,7 +86,9 @@ extern "C" int l2z_comm_init(int rank, int world, const void *id, int device, l2
     c->world = world;
     c->device = device;
     c->nccl = nullptr;
-    if (world > 1) {
+    // world == 1 with an id still builds a 1-rank RCCL communicator: the same call path as
+    // N > 1 (dlopen, ncclCommInitRank, ncclAllGather on the stream), testable on one GPU
+    if (world > 1 || id != nullptr) {
         if (id == nullptr) {
             delete c;
             set_error("l2z_comm_init: id required when world > 1");
@@ -108,6 +110,20 @@ extern "C" int l2z_comm_init(int rank, int world, const void *id, int device, l2
         }
         c->nccl = comm;
     }
+    *out = c;
+    return L2Z_OK;
+}
+
+// A rank descriptor without a communicator: for l2z_emu_transformer (one process, one GPU).
+extern "C" int l2z_comm_init_emulated(int rank, int world, int device, l2z_comm **out)
+{
+    L2Z_CHECK(out != nullptr && world >= 1 && rank >= 0 && rank < world, L2Z_ERR_INVALID,
+              "l2z_comm_init_emulated: bad rank/world %d/%d", rank, world);
+    l2z_comm *c = new l2z_comm();
+    c->rank = rank;
+    c->world = world;
+    c->device = device;
+    c->nccl = nullptr;
     *out = c;
     return L2Z_OK;
 }
