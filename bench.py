@@ -133,14 +133,13 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     comm, barrier, dist = None, None, None
-    # Load libllama2_hip.so (and with it the system HIP runtime) BEFORE torch, so that both
-    # share one libamdhip64 -- the one the kernels were built against.
-    B.lib()
     force_dist = os.environ.get("L2Z_BENCH_FORCE_DIST") == "1"  # 1-rank RCCL + gloo, for testing
     if args.gpus > 1 or world > 1 or force_dist:
         if world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with "
                              "python -m torch.distributed.run --nproc-per-node N ...)")
+        # torch is imported BEFORE libllama2_hip.so is loaded: the other order leaves HIP
+        # without a visible device on this image (measured on the MI355X box)
         import torch
         import torch.distributed as dist
         # control plane only (barrier, id broadcast, max-reduce of the clock): gloo on CPU.
