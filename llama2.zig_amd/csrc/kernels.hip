@@ -16,6 +16,8 @@
 //    add, SiLU*mul (epilogues).  5 launches per layer.
 //  * token and position live in device memory so one captured hipGraph per
 //    step can be replayed without host involvement.
+#include <cstdlib>
+
 #include "l2z_internal.h"
 
 namespace l2z {
@@ -534,14 +536,14 @@ struct AttnGeom {
     int G;    // groups per block
 };
 
-__host__ __device__ inline AttnGeom attn_geom(int head_size, bool vec)
+__host__ __device__ inline AttnGeom attn_geom(int head_size, bool vec, int block = kBlock)
 {
     AttnGeom g;
     g.E = vec ? head_size >> 2 : head_size;
     int t = 1;
     while (t < g.E && t < 64) t <<= 1;
     g.TPR = t;
-    g.G = kBlock / t;
+    g.G = block / t;
     return g;
 }
 
@@ -702,12 +704,16 @@ __device__ __forceinline__ void wave_softmax(float *att, int T)
 // summation order as attn_scores / attn_weighted_sum.  Kept compact on purpose: at
 // stories15M sizes this kernel's time is launch + instruction fetch, not data.
 constexpr int kFastUB = 8;
+constexpr int kAttnFastBlock = 1024;  // long contexts: 16 waves per head (32 groups at head_size 128)
 
-__global__ __launch_bounds__(kBlock) void attention_fast_kernel(const AttnArgs a)
+// NT = 256 for short contexts (seq_len <= 512: launch latency matters most),
+// NT = 1024 for long ones (more rows in flight per head).
+template <int NT>
+__global__ __launch_bounds__(NT) void attention_fast_kernel(const AttnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int hs = a.head_size;
-    const AttnGeom ge = attn_geom(hs, true);
+    const AttnGeom ge = attn_geom(hs, true, NT);
     float *att = lds;                                  // seq_len
     float *part = att + ((a.seq_len + 3) & ~3);        // G*hs
     const int h = blockIdx.x;
@@ -1029,8 +1035,13 @@ size_t matvec_lds_bytes(int n) { return (size_t)(4 * ((n >> 2) + 384) + kScratch
 size_t attention_lds_bytes(int head_size, int seq_len, bool vec)
 {
     const AttnGeom ge = attn_geom(head_size, vec);
-    return (size_t)(((head_size + 3) & ~3) + ((seq_len + 3) & ~3) + ge.G * head_size + kScratch) *
-           sizeof(float);
+    size_t fl = (size_t)((head_size + 3) & ~3) + ((seq_len + 3) & ~3) + (size_t)ge.G * head_size + kScratch;
+    if (vec && head_size <= 256) {  // fast kernel geometry
+        const AttnGeom gf = attn_geom(head_size, true, kAttnFastBlock);
+        const size_t f2 = (size_t)((seq_len + 3) & ~3) + (size_t)gf.G * head_size;
+        if (f2 > fl) fl = f2;
+    }
+    return fl * sizeof(float);
 }
 
 int matvec_max_grid(int n_cus) { return n_cus * 8; }
@@ -1093,9 +1104,21 @@ hipError_t launch_attention(const AttnArgs &a, int n_heads_local, hipStream_t st
                      aligned16(a.kcache) && aligned16(a.vcache);
     const size_t lds = attention_lds_bytes(a.head_size, a.seq_len, vec);
     if (vec && a.head_size <= 256) {
-        hipError_t e = ensure_lds(attention_fast_kernel, lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(attention_fast_kernel, dim3(n_heads_local), dim3(kBlock), lds, st, a);
+        static const int forced = getenv("L2Z_ATTN_BLOCK") ? atoi(getenv("L2Z_ATTN_BLOCK")) : 0;
+        const int nt = forced ? forced : (a.seq_len > 512 ? kAttnFastBlock : kBlock);
+        const AttnGeom gf = attn_geom(a.head_size, true, nt);
+        const size_t lds_fast = (size_t)(((a.seq_len + 3) & ~3) + gf.G * a.head_size) * sizeof(float);
+        if (nt == kAttnFastBlock) {
+            hipError_t e = ensure_lds(attention_fast_kernel<kAttnFastBlock>, lds_fast);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((attention_fast_kernel<kAttnFastBlock>), dim3(n_heads_local),
+                               dim3(kAttnFastBlock), lds_fast, st, a);
+        } else {
+            hipError_t e = ensure_lds(attention_fast_kernel<kBlock>, lds_fast);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((attention_fast_kernel<kBlock>), dim3(n_heads_local), dim3(kBlock),
+                               lds_fast, st, a);
+        }
         return hipGetLastError();
     }
     if (vec) {

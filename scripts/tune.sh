@@ -2,7 +2,7 @@
 # usage: scripts/tune.sh "<env assignments>" ...   -> tokens/s of the 7B shape per setting
 for e in "$@"; do
   echo "== $e"
-  env $e timeout 200 python bench.py --steps 48 --no-cpu-baseline --no-extra 2>&1 | python -c "
+  env $e timeout 200 python bench.py --steps ${STEPS:-255} --no-cpu-baseline --no-extra 2>&1 | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
