@@ -300,9 +300,40 @@ __device__ __forceinline__ void pair_rows(const MvLocals &m, int p, const float 
     }
 }
 
+// What the epilogue of pair p reads from memory (residual values, RoPE cos/sin).  Loaded by
+// the writer lane when the pair's weight loads are issued, so the epilogue itself never
+// waits on memory (a dependent L2 round trip per unit otherwise: ~1 us, serialised).
+struct EpiIn {
+    float ra, rb;
+    float2 cs;
+};
+
+template <int EPI>
+__device__ __forceinline__ EpiIn epi_prefetch(const MvLocals &m, int p, bool writer)
+{
+    EpiIn e;
+    e.ra = 0.0f; e.rb = 0.0f; e.cs = make_float2(1.0f, 0.0f);
+    if (!writer || p >= m.n_pairs) return e;
+    if (EPI == EPI_RESID) {  // single segment: rows 2p, 2p+1
+        const int ga = 2 * p, gb = ga + 1;
+        e.ra = m.resid[ga];
+        if (gb < m.total_rows) e.rb = m.resid[gb];
+    } else if (EPI == EPI_ROPE) {
+        const int ga = 2 * p;
+        const bool a1 = ga >= m.rows0, a2 = ga >= m.r01;
+        const int seg_a = a2 ? 2 : (a1 ? 1 : 0);
+        const int row_a = ga - (a2 ? m.r01 : (a1 ? m.rows0 : 0));
+        if (seg_a < m.rope_segs) {
+            const int hs = m.head_size;
+            e.cs = m.rope[(size_t)m.pos * (size_t)(hs >> 1) + (size_t)((row_a % hs) >> 1)];
+        }
+    }
+    return e;
+}
+
 template <int EPI>
 __device__ __forceinline__ void pair_epilogue(const MvLocals &m, int p, float sa, float sb,
-                                              bool writer)
+                                              bool writer, const EpiIn &in)
 {
     const bool valid_a = p < m.n_pairs;
     if (EPI == EPI_SWIGLU) {
@@ -327,8 +358,7 @@ __device__ __forceinline__ void pair_epilogue(const MvLocals &m, int p, float sa
         float o0 = sa, o1 = sb;
         const int seg_a = a2 ? 2 : (a1 ? 1 : 0);
         if (seg_a < m.rope_segs) {
-            const int hs = m.head_size;
-            const float2 cs = m.rope[(size_t)m.pos * (size_t)(hs >> 1) + (size_t)((row_a % hs) >> 1)];
+            const float2 cs = in.cs;     // rope[pos][(row_a % head_size)/2], prefetched
             o0 = sa * cs.x - sb * cs.y;  // :348
             o1 = sa * cs.y + sb * cs.x;  // :349
         }
@@ -338,8 +368,8 @@ __device__ __forceinline__ void pair_epilogue(const MvLocals &m, int p, float sa
         }
     } else if (EPI == EPI_RESID) {
         if (writer && valid_a) {
-            oa[row_a] = m.resid[row_a] + sa;  // :711 a[i] += b[i]
-            if (valid_b) ob[row_b] = m.resid[row_b] + sb;
+            oa[row_a] = in.ra + sa;  // :711 a[i] += b[i]  (resid[row] prefetched)
+            if (valid_b) ob[row_b] = in.rb + sb;
         }
     } else {
         if (writer && valid_a) {
@@ -433,6 +463,8 @@ __global__ __launch_bounds__(kBlock) void matvec_kernel(const MatvecArgs a)
     const float *pa, *pb;
     pair_rows<EPI>(m, (has_unit ? u : 0) * RW + grp, pa, pb);
     v4f wa[U], wb[U];
+    EpiIn ein = epi_prefetch<EPI>(m, (has_unit ? u : 0) * RW + grp, cl == 0 && has_unit);
+    EpiIn ein_next = ein;
     mv_load<LPR>(pa, pb, cl, 0, n4, wa, wb);
     xstage_finish<PRO, XC>(a.x, a.rms_w, m.n, n4_pad, xr, gr, xs, scratch);
     if (EPI != EPI_ARGMAX && !has_unit) return;
@@ -450,13 +482,17 @@ __global__ __launch_bounds__(kBlock) void matvec_kernel(const MatvecArgs a)
         const int b_next = unit_done ? 0 : b + 1;
         const bool more = u_next < n_units;
         if (more) {
-            if (unit_done) pair_rows<EPI>(m, u_next * RW + grp, pa, pb);
+            if (unit_done) {
+                pair_rows<EPI>(m, u_next * RW + grp, pa, pb);
+                ein_next = epi_prefetch<EPI>(m, u_next * RW + grp, cl == 0);
+            }
             mv_load<LPR>(pa, pb, cl + b_next * (LPR * U), b_next * (LPR * U), n4, wa, wb);
         }
         if (unit_done) {
             const float sa = group_sum<LPR>(hsum4(acc_a));
             const float sb = group_sum<LPR>(hsum4(acc_b));
-            pair_epilogue<EPI>(m, u * RW + grp, sa, sb, cl == 0);
+            pair_epilogue<EPI>(m, u * RW + grp, sa, sb, cl == 0, ein);
+            ein = ein_next;
             if (EPI == EPI_ARGMAX) {  // single segment: pair p = rows 2p, 2p+1
                 const int ra_ = 2 * (u * RW + grp), rb_ = ra_ + 1;
                 if (ra_ < m.total_rows && (sa > best_v || best_i == 0x7fffffff)) {
@@ -505,6 +541,115 @@ __global__ __launch_bounds__(kBlock) void matvec_kernel(const MatvecArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------
+// Wide rows (n >= 4096, n/4 a multiple of 64: the 7B shapes): the WHOLE BLOCK works on
+// one pair.  Rows 2p and 2p+1 are adjacent in memory, so a block reads one contiguous
+// 8n-byte run per unit and consecutive blocks read consecutive runs -- the chip sweeps
+// the matrix linearly, like a plain streaming read (DRAM page locality: +10 % over
+// giving every wave its own row pair, measured).  Thread t takes float4 columns
+// t, t+256, ...; per-thread component accumulators, (x+y)+(z+w), wave xor-shuffle,
+// then the 4 wave partials are added in wave order.  Still a function of n only.
+// ---------------------------------------------------------------------------
+template <int PRO, int EPI, int XC>
+__global__ __launch_bounds__(kBlock) void matvec_row_kernel(const MatvecArgs a)
+{
+    constexpr int U = 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const MvLocals m = mv_locals<EPI>(a);
+    const int n4 = m.n >> 2;
+    const int n_batches = (n4 + kBlock * U - 1) / (kBlock * U);
+    const int n4_pad = n_batches * (kBlock * U);
+    float *xs = lds;
+    float *scratch = lds + 4 * n4_pad;            // kScratch floats
+    float *part = scratch + kScratch;             // [2][kWaves][2] wave partials
+    const v4f *xs4 = (const v4f *)xs;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_units = m.n_pairs;
+    const int ustride = gridDim.x;
+
+    v4f xr[XC], gr[XC];
+    xload_issue<PRO, XC>(a.x, a.rms_w, n4, xr, gr);
+    int u = blockIdx.x;  // grid <= n_units
+    const float *pa, *pb;
+    pair_rows<EPI>(m, u, pa, pb);
+    v4f wa[U], wb[U];
+    auto load = [&](int cb) {  // columns cb + tid + 256k; validity is wave-uniform (n4 % 64 == 0)
+        const v4f *a4 = (const v4f *)pa + cb + tid, *b4 = (const v4f *)pb + cb + tid;
+        const int wbase = cb + (tid & ~63);
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const int off = (wbase + kBlock * k < n4) ? kBlock * k : -(cb + (tid & ~63));
+            wa[k] = ldg_nt(a4 + off);  // out-of-row steps re-read the row start; their x is 0
+            wb[k] = ldg_nt(b4 + off);
+        }
+    };
+    EpiIn ein = epi_prefetch<EPI>(m, u, tid == 0);
+    EpiIn ein_next = ein;
+    load(0);
+    xstage_finish<PRO, XC>(a.x, a.rms_w, m.n, n4_pad, xr, gr, xs, scratch);
+
+    v4f acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
+    float best_v = -INFINITY;
+    int best_i = 0x7fffffff;
+    int b = 0, parity = 0;
+    while (true) {
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const v4f xv = xs4[b * (kBlock * U) + tid + kBlock * k];
+            acc_a = fma4(wa[k], xv, acc_a);
+            acc_b = fma4(wb[k], xv, acc_b);
+        }
+        const bool unit_done = (b + 1 == n_batches);
+        const int u_next = unit_done ? u + ustride : u;
+        const int b_next = unit_done ? 0 : b + 1;
+        const bool more = u_next < n_units;
+        if (more) {
+            if (unit_done) {
+                pair_rows<EPI>(m, u_next, pa, pb);
+                ein_next = epi_prefetch<EPI>(m, u_next, tid == 0);
+            }
+            load(b_next * (kBlock * U));
+        }
+        if (unit_done) {
+#ifdef L2Z_DBG_NOREDUCE
+            const float sa = hsum4(acc_a), sb = hsum4(acc_b);
+#else
+            const float sa = wave_sum(hsum4(acc_a));
+            const float sb = wave_sum(hsum4(acc_b));
+#endif
+            float *pp = part + parity * (2 * kWaves);
+            if (lane == 0) {
+                pp[wave] = sa;
+                pp[kWaves + wave] = sb;
+            }
+#ifndef L2Z_DBG_NOBARRIER
+            __syncthreads();
+#endif
+            if (tid == 0) {
+                const float ta = ((pp[0] + pp[1]) + pp[2]) + pp[3];
+                const float tb = ((pp[kWaves] + pp[kWaves + 1]) + pp[kWaves + 2]) + pp[kWaves + 3];
+                pair_epilogue<EPI>(m, u, ta, tb, true, ein);
+                if (EPI == EPI_ARGMAX) {
+                    const int ra_ = 2 * u, rb_ = ra_ + 1;
+                    if (ta > best_v || best_i == 0x7fffffff) { best_v = ta; best_i = ra_ + a.row_offset; }
+                    if (rb_ < m.total_rows && tb > best_v) { best_v = tb; best_i = rb_ + a.row_offset; }
+                }
+            }
+            ein = ein_next;
+            parity ^= 1;
+            acc_a = v4f{0.f, 0.f, 0.f, 0.f};
+            acc_b = v4f{0.f, 0.f, 0.f, 0.f};
+        }
+        if (!more) break;
+        u = u_next;
+        b = b_next;
+    }
+    if (EPI == EPI_ARGMAX && tid == 0) {  // units ascend within a block: first index kept
+        a.part_val[blockIdx.x] = best_v;
+        a.part_idx[blockIdx.x] = best_i;
+    }
+}
+
 // Generic form: any n, any alignment (the reference's 3x3 / 2x12 known-answer
 // tests land here).  One pair per wave, scalar loads.
 template <int PRO, int EPI>
@@ -521,7 +666,7 @@ __global__ __launch_bounds__(kBlock) void matvec_scalar_kernel(const MatvecArgs 
         pair_rows<EPI>(m, u, pa, pb);
         float sa, sb;
         dot2_scalar(pa, pb, xs, m.n, sa, sb);
-        pair_epilogue<EPI>(m, u, sa, sb, lane == 0);
+        pair_epilogue<EPI>(m, u, sa, sb, lane == 0, epi_prefetch<EPI>(m, u, lane == 0));
     }
 }
 
@@ -1011,6 +1156,26 @@ MvLaunch mv_pick(int lpr, bool big_x)
     return big_x ? mv_entry<PRO, EPI, 64, 12>() : mv_entry<PRO, EPI, 64, 4>();
 }
 
+template <int PRO, int EPI>
+const void *mv_row_fn(bool big_x)
+{
+    return big_x ? reinterpret_cast<const void *>(&matvec_row_kernel<PRO, EPI, 12>)
+                 : reinterpret_cast<const void *>(&matvec_row_kernel<PRO, EPI, 4>);
+}
+
+const void *mv_row_pick(int pro, int epi, bool big_x)
+{
+#define L2Z_MVR(P, E) if (pro == P && epi == E) return mv_row_fn<P, E>(big_x);
+    L2Z_MVR(PRO_NONE, EPI_STORE)
+    L2Z_MVR(PRO_NONE, EPI_RESID)
+    L2Z_MVR(PRO_RMS, EPI_STORE)
+    L2Z_MVR(PRO_RMS, EPI_ROPE)
+    L2Z_MVR(PRO_RMS, EPI_SWIGLU)
+    L2Z_MVR(PRO_RMS, EPI_ARGMAX)
+#undef L2Z_MVR
+    return nullptr;
+}
+
 MvLaunch mv_pick_pe(int pro, int epi, int lpr, bool big_x, bool vec)
 {
 #define L2Z_MV(P, E)                                                                      \
@@ -1030,7 +1195,7 @@ MvLaunch mv_pick_pe(int pro, int epi, int lpr, bool big_x, bool vec)
 }  // namespace
 
 // upper bound over every instantiation (n4 padded to whole batches of <= 384 float4)
-size_t matvec_lds_bytes(int n) { return (size_t)(4 * ((n >> 2) + 384) + kScratch + 4) * sizeof(float); }
+size_t matvec_lds_bytes(int n) { return (size_t)(4 * ((n >> 2) + 1024) + kScratch + 4 * kWaves + 4) * sizeof(float); }
 
 size_t attention_lds_bytes(int head_size, int seq_len, bool vec)
 {
@@ -1062,11 +1227,19 @@ hipError_t launch_matvec(const MatvecArgs &a, int pro, int epi, int max_blocks_p
     const int lpr = lpr_for(n4);
     if (lpr == 64 && (n4 % 64) != 0) vec = false;  // rare odd widths: generic scalar kernel
     if (epi == EPI_ARGMAX && (!vec || a.rows1 != 0 || a.rows2 != 0)) return hipErrorNotSupported;
-    const MvLaunch k = mv_pick_pe(pro, epi, lpr, a.n > 4096, vec);
+    static const int row_mode = getenv("L2Z_ROW_KERNEL") ? atoi(getenv("L2Z_ROW_KERNEL")) : 1;
+    const bool use_row = vec && row_mode && n4 >= 1024 && (n4 % 64) == 0;
+    MvLaunch k = mv_pick_pe(pro, epi, lpr, a.n > 4096, vec);
+    if (use_row) k.fn = mv_row_pick(pro, epi, a.n > 4096);
     if (k.fn == nullptr) return hipErrorInvalidValue;
     size_t lds;
     int n_units;
-    if (vec) {
+    if (use_row) {
+        const int batch = kBlock * 4;
+        const int n4_pad = ((n4 + batch - 1) / batch) * batch;
+        lds = (size_t)(4 * n4_pad + kScratch + 4 * kWaves) * sizeof(float);
+        n_units = n_pairs;
+    } else if (vec) {
         const int batch = k.lpr * k.u;
         const int n4_pad = ((n4 + batch - 1) / batch) * batch;
         lds = (size_t)(4 * n4_pad + kScratch) * sizeof(float);
@@ -1086,12 +1259,30 @@ hipError_t launch_matvec(const MatvecArgs &a, int pro, int epi, int max_blocks_p
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k.fn, kBlock, lds) != hipSuccess || occ < 1)
         occ = 1;
     if (occ > max_blocks_per_cu) occ = max_blocks_per_cu;
+    // The row kernel streams best with few blocks per CU in lock step (fewer concurrent DRAM
+    // streams).  Measured at 7B: 1 block/CU 6.6-6.8 TB/s on the long launches (ffn13, cls:
+    // >= 32 units per CU) but a slow start on the short ones; 2 blocks/CU 5.6-5.9 TB/s there;
+    // 4-8 blocks/CU 6.05 TB/s overall.  L2Z_ROW_BLOCKS overrides.
+    static const int row_blocks_env = getenv("L2Z_ROW_BLOCKS") ? atoi(getenv("L2Z_ROW_BLOCKS")) : 0;
+    if (use_row) {
+        const int row_blocks = row_blocks_env ? row_blocks_env : (n_units >= 32 * n_cus ? 1 : 2);
+        if (occ > row_blocks) occ = row_blocks;
+    }
     const int resident = occ * n_cus;
-    const int blocks_needed = (n_units + kWaves - 1) / kWaves;
-    int grid = blocks_needed;
-    if (grid > resident) {
-        const int per_wave = (n_units + resident * kWaves - 1) / (resident * kWaves);
-        grid = (n_units + per_wave * kWaves - 1) / (per_wave * kWaves);
+    int grid;
+    if (use_row) {  // a unit per block at a time
+        grid = n_units;
+        if (grid > resident) {
+            const int per_block = (n_units + resident - 1) / resident;
+            grid = (n_units + per_block - 1) / per_block;
+        }
+    } else {
+        const int blocks_needed = (n_units + kWaves - 1) / kWaves;
+        grid = blocks_needed;
+        if (grid > resident) {
+            const int per_wave = (n_units + resident * kWaves - 1) / (resident * kWaves);
+            grid = (n_units + per_wave * kWaves - 1) / (per_wave * kWaves);
+        }
     }
     if (out_grid) *out_grid = grid;
     void *args[] = {const_cast<MatvecArgs *>(&a)};
