@@ -1260,14 +1260,11 @@ hipError_t launch_matvec(const MatvecArgs &a, int pro, int epi, int max_blocks_p
         occ = 1;
     if (occ > max_blocks_per_cu) occ = max_blocks_per_cu;
     // The row kernel streams best with few blocks per CU in lock step (fewer concurrent DRAM
-    // streams).  Measured at 7B: 1 block/CU 6.6-6.8 TB/s on the long launches (ffn13, cls:
-    // >= 32 units per CU) but a slow start on the short ones; 2 blocks/CU 5.6-5.9 TB/s there;
-    // 4-8 blocks/CU 6.05 TB/s overall.  L2Z_ROW_BLOCKS overrides.
-    static const int row_blocks_env = getenv("L2Z_ROW_BLOCKS") ? atoi(getenv("L2Z_ROW_BLOCKS")) : 0;
-    if (use_row) {
-        const int row_blocks = row_blocks_env ? row_blocks_env : (n_units >= 32 * n_cus ? 1 : 2);
-        if (occ > row_blocks) occ = row_blocks;
-    }
+    // streams).  Measured at 7B, whole-token rate: 2 blocks/CU 219 tok/s, 1 -> 208, 3 -> 213,
+    // 4-8 -> 208-211 (single launches shift against each other under the power cap, so the
+    // choice is made on the whole-token rate).  L2Z_ROW_BLOCKS overrides.
+    static const int row_blocks = getenv("L2Z_ROW_BLOCKS") ? atoi(getenv("L2Z_ROW_BLOCKS")) : 2;
+    if (use_row && occ > row_blocks) occ = row_blocks;
     const int resident = occ * n_cus;
     int grid;
     if (use_row) {  // a unit per block at a time
