@@ -419,7 +419,15 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
         if (v > 0) s->max_blocks = v;
     }
     if (const char *e = getenv("L2Z_NO_GRAPH")) s->use_graphs = atoi(e) == 0;
-    if (comm && (comm->nccl || comm->world > 1)) s->use_graphs = false;  // collectives are launched eagerly
+    // With a communicator the launches and RCCL calls go out eagerly by default: at N > 1 a
+    // step is bound by the ~130 small collectives on the GPU, not by host launch cost, and
+    // multi-rank capture could not be exercised on the 1-GPU dev box.  L2Z_COMM_GRAPH=1
+    // captures the collectives into the step graph (works with a 1-rank communicator).
+    if (comm && comm->world > 1 && !comm->nccl) s->use_graphs = false;  // emulated ranks
+    if (comm && comm->nccl) {
+        const char *e = getenv("L2Z_COMM_GRAPH");
+        s->use_graphs = e && atoi(e) == 1;
+    }
 
     const size_t kv = (size_t)c.n_layers * c.seq_len * sh.kvd_loc;
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
