@@ -191,9 +191,12 @@ struct l2z_runstate {
     float *d_part_val = nullptr;  // classifier launch's per-block argmax candidates
     int *d_part_idx = nullptr;
     int n_part = 0;               // 0: argmax scans the logits instead
+    float *d_attn_part = nullptr; // split attention: per (head, chunk) partials
+    int attn_nch = 0;             // 0: one block per head at every position
+    int attn_split_pos = 0;       // positions >= this use the split form (host picks the graph)
     // graphs, keyed by the weights they were captured with
     const l2z_weights *graph_w = nullptr;
-    hipGraphExec_t g_forward = nullptr, g_step = nullptr;
+    hipGraphExec_t g_forward[2] = {nullptr, nullptr}, g_step[2] = {nullptr, nullptr};  // [split?]
     bool use_graphs = true;
     int host_pos = 0;   // next position the greedy loop will run
     bool done = false;  // greedy loop saw BOS
@@ -451,6 +454,23 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
     alloc((void **)&s->d_out_tokens, (size_t)c.seq_len * 4);
     alloc((void **)&s->d_part_val, (size_t)matvec_max_grid(g_cus) * 4);
     alloc((void **)&s->d_part_idx, (size_t)matvec_max_grid(g_cus) * 4);
+    {   // Attention form by position.  One block per head is fastest while the
+        // context is short; from pos 256 on, the split form (nch blocks per head + combine)
+        // wins and keeps winning (2.4x at pos 2047 on the 7B shape).  The host knows pos, so it
+        // replays one of two captured graphs.  L2Z_ATTN_SPLIT: 0 = never, n = n chunks at every
+        // position (tests); L2Z_ATTN_SPLIT_POS moves the switch-over.
+        const char *ev = getenv("L2Z_ATTN_SPLIT");
+        const int mode = ev ? atoi(ev) : -1;
+        int nch = mode > 0 ? mode : attention_split_chunks(sh.heads_loc, g_cus);
+        if (nch > 16) nch = 16;
+        s->attn_split_pos = mode > 0 ? 0 : 256;
+        if (const char *ep = getenv("L2Z_ATTN_SPLIT_POS")) s->attn_split_pos = atoi(ep);
+        if (mode == 0 || c.seq_len <= s->attn_split_pos) nch = 0;
+        if (nch > 1) {
+            s->attn_nch = nch;
+            alloc((void **)&s->d_attn_part, attention_split_part_floats(sh.heads_loc, sh.hs, nch) * 4);
+        }
+    }
     if (e != hipSuccess) {
         set_error("RunState allocation failed: %s", hipGetErrorString(e));
         l2z_runstate_free(s);
@@ -487,11 +507,13 @@ extern "C" void l2z_runstate_free(l2z_runstate *s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    if (s->g_forward) (void)hipGraphExecDestroy(s->g_forward);
-    if (s->g_step) (void)hipGraphExecDestroy(s->g_step);
+    for (int v = 0; v < 2; v++) {
+        if (s->g_forward[v]) (void)hipGraphExecDestroy(s->g_forward[v]);
+        if (s->g_step[v]) (void)hipGraphExecDestroy(s->g_step[v]);
+    }
     void *ptrs[] = {s->x, s->xb, s->hb, s->q, s->logits, s->key_cache, s->value_cache, s->rope,
                     s->d_token, s->d_pos, s->d_prompt, s->d_n_prompt, s->d_out_tokens, s->d_argmax,
-                    s->d_part_val, s->d_part_idx};
+                    s->d_part_val, s->d_part_idx, s->d_attn_part};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -541,7 +563,7 @@ int check_pair(const l2z_config *config, const l2z_runstate *s, const l2z_weight
 // stage by stage and performs the gathers itself.  Stages: 4 per layer (after attention,
 // wo, ffn13, ffn2), then the classifier, then argmax.
 int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof *prof,
-                    int only_stage = -1)
+                    int only_stage, bool split)
 {
     const l2z_config &c = s->cfg;
     const Shard &sh = s->sh;
@@ -575,7 +597,11 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.q = s->q; a.kcache = kc; a.vcache = vc; a.xb = s->xb + sh.dim0;
             a.pos_ptr = s->d_pos; a.head_size = sh.hs; a.kv_dim = sh.kvd_loc;
             a.kv_mul = c.n_heads / c.n_kv_heads; a.seq_len = c.seq_len;
-            L2Z_LAUNCH(KIND_ATTN, launch_attention(a, sh.heads_loc, st));
+            if (split && s->attn_nch > 1 && attention_split_supported(a))
+                L2Z_LAUNCH(KIND_ATTN, launch_attention_split(a, sh.heads_loc, s->attn_nch,
+                                                             s->d_attn_part, st));
+            else
+                L2Z_LAUNCH(KIND_ATTN, launch_attention(a, sh.heads_loc, st));
         }
         L2Z_TRY(gather(s->xb, sh.dim_loc));
         if (want()) {   // wo (:392) + residual (:395)
@@ -630,11 +656,14 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
     return L2Z_OK;
 }
 
-int build_graph(l2z_runstate *s, const l2z_weights *w, bool with_step, hipGraphExec_t *out)
+bool use_split(const l2z_runstate *s, int pos) { return s->attn_nch > 1 && pos >= s->attn_split_pos; }
+
+int build_graph(l2z_runstate *s, const l2z_weights *w, bool with_step, bool split,
+                hipGraphExec_t *out)
 {
     hipGraph_t graph = nullptr;
     L2Z_HIP(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-    int rc = enqueue_forward(s, w, with_step, nullptr);
+    int rc = enqueue_forward(s, w, with_step, nullptr, -1, split);
     hipError_t e = hipStreamEndCapture(s->stream, &graph);
     if (rc != L2Z_OK) {
         if (graph) (void)hipGraphDestroy(graph);
@@ -647,19 +676,30 @@ int build_graph(l2z_runstate *s, const l2z_weights *w, bool with_step, hipGraphE
     return L2Z_OK;
 }
 
+void drop_graphs(l2z_runstate *s)
+{
+    for (int v = 0; v < 2; v++) {
+        if (s->g_forward[v]) { (void)hipGraphExecDestroy(s->g_forward[v]); s->g_forward[v] = nullptr; }
+        if (s->g_step[v]) { (void)hipGraphExecDestroy(s->g_step[v]); s->g_step[v] = nullptr; }
+    }
+    s->graph_w = nullptr;
+}
+
 int ensure_graphs(l2z_runstate *s, const l2z_weights *w)
 {
     if (!s->use_graphs) return L2Z_OK;
-    if (s->graph_w == w && s->g_forward && s->g_step) return L2Z_OK;
-    if (s->g_forward) { (void)hipGraphExecDestroy(s->g_forward); s->g_forward = nullptr; }
-    if (s->g_step) { (void)hipGraphExecDestroy(s->g_step); s->g_step = nullptr; }
-    s->graph_w = nullptr;
-    int rc = build_graph(s, w, false, &s->g_forward);
-    if (rc == L2Z_OK) rc = build_graph(s, w, true, &s->g_step);
+    if (s->graph_w == w && s->g_forward[0] && s->g_step[0]) return L2Z_OK;
+    drop_graphs(s);
+    const int n_var = s->attn_nch > 1 ? 2 : 1;
+    int rc = L2Z_OK;
+    for (int v = 0; v < n_var && rc == L2Z_OK; v++) {
+        rc = build_graph(s, w, false, v == 1, &s->g_forward[v]);
+        if (rc == L2Z_OK) rc = build_graph(s, w, true, v == 1, &s->g_step[v]);
+    }
     if (rc != L2Z_OK) {
         // capture is an optimisation, not a requirement: run the same launches eagerly
         fprintf(stderr, "llama2_hip: hipGraph capture failed (%s); launching eagerly\n", g_err);
-        if (s->g_forward) { (void)hipGraphExecDestroy(s->g_forward); s->g_forward = nullptr; }
+        drop_graphs(s);
         s->use_graphs = false;
         (void)hipGetLastError();
         return L2Z_OK;
@@ -668,14 +708,17 @@ int ensure_graphs(l2z_runstate *s, const l2z_weights *w)
     return L2Z_OK;
 }
 
-int run_forward(l2z_runstate *s, const l2z_weights *w, bool with_step)
+// one forward pass at position `pos` (the host mirrors the device-side pos)
+int run_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, int pos)
 {
+    const bool split = use_split(s, pos);
     L2Z_TRY(ensure_graphs(s, w));
     if (s->use_graphs) {
-        L2Z_HIP(hipGraphLaunch(with_step ? s->g_step : s->g_forward, s->stream));
+        const int v = split ? 1 : 0;
+        L2Z_HIP(hipGraphLaunch(with_step ? s->g_step[v] : s->g_forward[v], s->stream));
         return L2Z_OK;
     }
-    return enqueue_forward(s, w, with_step, nullptr);
+    return enqueue_forward(s, w, with_step, nullptr, -1, split);
 }
 
 }  // namespace
@@ -691,7 +734,7 @@ extern "C" int l2z_transformer(int token, int pos, const l2z_config *config, l2z
     L2Z_HIP(hipSetDevice(s->device));
     L2Z_HIP(launch_set_state(token, pos, s->d_token, s->d_pos, w->tok_emb, s->x, config->dim,
                              s->stream));
-    L2Z_TRY(run_forward(s, w, false));
+    L2Z_TRY(run_forward(s, w, false, pos));
     s->host_pos = pos + 1;
     return L2Z_OK;
 }
@@ -792,7 +835,7 @@ extern "C" int l2z_greedy_run(const l2z_config *config, l2z_runstate *s, const l
     int produced = 0;
     while (remaining > 0 && !s->done) {
         const int n = remaining < kChunk ? remaining : kChunk;
-        for (int i = 0; i < n; i++) L2Z_TRY(run_forward(s, w, true));
+        for (int i = 0; i < n; i++) L2Z_TRY(run_forward(s, w, true, s->host_pos + i));
         L2Z_HIP(hipMemcpyAsync(out_tokens + produced, s->d_out_tokens + s->host_pos,
                                (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s->stream));
         L2Z_HIP(hipStreamSynchronize(s->stream));
@@ -828,7 +871,7 @@ extern "C" int l2z_profile_forward(int token, int pos, const l2z_config *config,
     L2Z_HIP(launch_set_state(token, pos, s->d_token, s->d_pos, w->tok_emb, s->x, config->dim,
                              s->stream));
     Prof prof;
-    int rc = enqueue_forward(s, w, true, &prof);
+    int rc = enqueue_forward(s, w, true, &prof, -1, use_split(s, pos));
     hipError_t e = hipStreamSynchronize(s->stream);
     for (int k = 0; k < n_kinds; k++) { ms_by_kind[k] = 0.0; launches_by_kind[k] = 0; }
     if (rc == L2Z_OK && e == hipSuccess) {
@@ -867,7 +910,8 @@ extern "C" int l2z_emu_transformer(int n_ranks, l2z_runstate *const *ss,
     }
     const int n_stages = 4 * c.n_layers + 1;
     for (int stage = 0; stage < n_stages; stage++) {
-        for (int r = 0; r < n_ranks; r++) L2Z_TRY(enqueue_forward(ss[r], ws[r], false, nullptr, stage));
+        for (int r = 0; r < n_ranks; r++)
+            L2Z_TRY(enqueue_forward(ss[r], ws[r], false, nullptr, stage, use_split(ss[r], pos)));
         for (int r = 0; r < n_ranks; r++) L2Z_HIP(hipStreamSynchronize(ss[r]->stream));
         // which buffer this stage produced, and the per-rank slice length
         const Shard &sh0 = ss[0]->sh;
@@ -1020,3 +1064,8 @@ extern "C" int l2z_argmax_host(const float *x, size_t n, size_t *out_index)
     *out_index = (size_t)idx;
     return L2Z_OK;
 }
+
+#ifdef L2Z_DBG_TS
+namespace l2z { hipError_t dbg_ts_read(long long *out); }
+extern "C" int l2z_dbg_ts(long long *out) { return l2z::dbg_ts_read(out) == hipSuccess ? 0 : -3; }
+#endif

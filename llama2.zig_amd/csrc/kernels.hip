@@ -34,17 +34,42 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ v4f ldg_nt(const v4f *p) { return __builtin_nontemporal_load(p); }
 
-__device__ __forceinline__ float wave_sum(float v)
+// Cross-lane reductions.  Inside a 16-lane row the exchange is a DPP modifier on a VALU op
+// (a few cycles); ds_bpermute-based __shfl_xor (~100 cycles each, and the five steps of one
+// sum are a dependent chain) is kept only for the 16- and 32-lane hops.  s_memtime showed the
+// shuffle chains were ~2 us of the 8 us attention kernel.  Every lane of the group ends with
+// the same value; the order of additions is fixed:
+//   xor 1 (quad_perm [1,0,3,2]), xor 2 (quad_perm [2,3,0,1]), 7-i (row_half_mirror),
+//   15-i (row_mirror), then xor 16, xor 32.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+
+// sum over aligned groups of n lanes (n a power of two, 1..64); all lanes get the result
+__device__ __forceinline__ float lanes_sum(float v, int n)
+{
+    if (n >= 2) v += dpp_mov<kDppXor1>(v);
+    if (n >= 4) v += dpp_mov<kDppXor2>(v);
+    if (n >= 8) v += dpp_mov<kDppHalfMirror>(v);
+    if (n >= 16) v += dpp_mov<kDppMirror>(v);
+    if (n >= 32) v += __shfl_xor(v, 16, 64);
+    if (n >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
 
+__device__ __forceinline__ float wave_sum(float v) { return lanes_sum(v, 64); }
+
 __device__ __forceinline__ float wave_max(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = fmaxf(v, dpp_mov<kDppXor1>(v));
+    v = fmaxf(v, dpp_mov<kDppXor2>(v));
+    v = fmaxf(v, dpp_mov<kDppHalfMirror>(v));
+    v = fmaxf(v, dpp_mov<kDppMirror>(v));
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
 }
 
@@ -431,9 +456,7 @@ __device__ __forceinline__ void mv_consume(const v4f *xs4, int c0, const v4f (&w
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v)
 {
-#pragma unroll
-    for (int o = LPR >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    return lanes_sum(v, LPR);
 }
 
 template <int PRO, int EPI, int LPR, int XC>
@@ -741,7 +764,7 @@ __device__ __forceinline__ void attn_scores(const float *qs, const float *__rest
 #pragma unroll
         for (int i = 0; i < kAttnUB; i++) {
             float v = p[i];
-            for (int o = ge.TPR >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            v = lanes_sum(v, ge.TPR);
             const int t = t0 + ge.G * i;
             if (c0 == 0 && t < T) att[t] = v / div;  // :372 divide, not multiply by reciprocal
         }
@@ -827,7 +850,8 @@ __device__ __forceinline__ void attn_weighted_sum(const float *att, const float 
 // each wave reduces max and sum over ALL T with the same instruction sequence, so
 // all waves hold bit-identical (max, sum) without any cross-wave barrier -- and
 // wave w normalises the entries t = w*64 + lane, + blockDim, ...
-__device__ __forceinline__ void wave_softmax(float *att, int T)
+// The normalised weights go to a second buffer, so no wave overwrites what another still reads.
+__device__ __forceinline__ void wave_softmax(const float *att, float *prob, int T)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     float m = -INFINITY;
@@ -836,9 +860,23 @@ __device__ __forceinline__ void wave_softmax(float *att, int T)
     float s = 0.0f;
     for (int t = lane; t < T; t += kWave) s += expf(att[t] - m);  // :699
     s = wave_sum(s);
-    __syncthreads();  // every wave has read the raw scores before any is overwritten
-    for (int t = wave * kWave + lane; t < T; t += nw * kWave) att[t] = expf(att[t] - m) / s;  // :704
+    for (int t = wave * kWave + lane; t < T; t += nw * kWave) prob[t] = expf(att[t] - m) / s;  // :704
     __syncthreads();
+}
+
+// out[i] = part[0][i] + part[1][i] + ... + part[G-1][i], i < hs.  R = 1..16 adjacent lanes
+// share one output: lane r adds partials r, r+R, ... (increasing), then a DPP sum over the R
+// lanes.  R depends only on (G, hs, blockDim) -- fixed per model.
+__device__ __forceinline__ void reduce_partials(const float *part, int G, int hs, float *out)
+{
+    int R = 1;
+    while (R * 2 <= G && R * 2 * hs <= (int)blockDim.x && R < 16) R <<= 1;
+    const int i = threadIdx.x / R, r = threadIdx.x % R;
+    float s = 0.0f;
+    if (i < hs)
+        for (int gg = r; gg < G; gg += R) s += part[(size_t)gg * hs + i];
+    s = lanes_sum(s, R);
+    if (i < hs && r == 0) out[i] = s;
 }
 
 // Fast path (head_size % 4 == 0, head_size <= 256).  The first kFastUB timesteps of
@@ -853,14 +891,21 @@ constexpr int kAttnFastBlock = 1024;  // long contexts: 16 waves per head (32 gr
 
 // NT = 256 for short contexts (seq_len <= 512: launch latency matters most),
 // NT = 1024 for long ones (more rows in flight per head).
-template <int NT>
+#ifdef L2Z_DBG_TS
+__device__ long long g_dbg_ts[16];
+#define L2Z_TS(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dbg_ts[i] = clock64(); } while (0)
+#else
+#define L2Z_TS(i) do { } while (0)
+#endif
+template <int NT, bool SPEC>
 __global__ __launch_bounds__(NT) void attention_fast_kernel(const AttnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int hs = a.head_size;
     const AttnGeom ge = attn_geom(hs, true, NT);
-    float *att = lds;                                  // seq_len
-    float *part = att + ((a.seq_len + 3) & ~3);        // G*hs
+    float *att = lds;                                  // seq_len raw scores
+    float *prob = att + ((a.seq_len + 3) & ~3);        // seq_len softmax weights
+    float *part = prob + ((a.seq_len + 3) & ~3);       // G*hs
     const int h = blockIdx.x;
     const int kvh = h / a.kv_mul;                      // :369 (h / kv_mul) * head_size
     const float *kbase = a.kcache + (size_t)kvh * hs;
@@ -872,27 +917,34 @@ __global__ __launch_bounds__(NT) void attention_fast_kernel(const AttnArgs a)
     const int step = ge.G * kFastUB;
     const v4f zero = {0.f, 0.f, 0.f, 0.f};
 
-    const int T = *a.pos_ptr + 1;  // timesteps 0..pos inclusive (:367); first used after the loads
+    L2Z_TS(0);
+    // SPEC (small models, latency-bound): the first round is requested without waiting for
+    // pos -- rows past pos exist and are masked -- so pos, q, K and V travel in one round trip.
+    // !SPEC (large heads): one CU pulls only ~45 GB/s, speculative rows would cost more than the
+    // extra dependent read of pos, so rows are clamped to pos (duplicates hit the L1).
+    const int T = *a.pos_ptr + 1;  // timesteps 0..pos inclusive (:367)
+    const int lim = SPEC ? a.seq_len : T;
     const v4f qv = active ? ((const v4f *)(a.q + (size_t)h * hs))[cc] : zero;
     v4f kr[kFastUB], vr[kFastUB];
 #pragma unroll
     for (int i = 0; i < kFastUB; i++) {
         int t = g + ge.G * i;
-        t = t < a.seq_len ? t : a.seq_len - 1;
+        t = t < lim ? t : lim - 1;
         kr[i] = ((const v4f *)(kbase + (size_t)t * stride))[cc];
     }
 #pragma unroll
     for (int i = 0; i < kFastUB; i++) {
         int t = g + ge.G * i;
-        t = t < a.seq_len ? t : a.seq_len - 1;
+        t = t < lim ? t : lim - 1;
         vr[i] = ((const v4f *)(vbase + (size_t)t * stride))[cc];
     }
+    L2Z_TS(1);
     const float div = sqrtf((float)hs);
     for (int t0 = g;;) {  // scores (:367-375)
 #pragma unroll
         for (int i = 0; i < kFastUB; i++) {
             float p = hsum4(fma4(qv, kr[i], zero));
-            for (int o = ge.TPR >> 1; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
+            p = lanes_sum(p, ge.TPR);
             const int t = t0 + ge.G * i;
             if (c0 == 0 && t < T) att[t] = p / div;  // :372 divide
         }
@@ -905,14 +957,17 @@ __global__ __launch_bounds__(NT) void attention_fast_kernel(const AttnArgs a)
             kr[i] = ((const v4f *)(kbase + (size_t)t * stride))[cc];
         }
     }
+    L2Z_TS(2);
     __syncthreads();
-    wave_softmax(att, T);  // :378
+    L2Z_TS(3);
+    wave_softmax(att, prob, T);  // :378
+    L2Z_TS(4);
     v4f acc = zero;
     for (int t0 = g;;) {  // att . V (:381-388), increasing t within the group
 #pragma unroll
         for (int i = 0; i < kFastUB; i++) {
             const int t = t0 + ge.G * i;
-            const float w = t < T ? att[t] : 0.0f;
+            const float w = t < T ? prob[t] : 0.0f;
             acc.x = fmaf(vr[i].x, w, acc.x);
             acc.y = fmaf(vr[i].y, w, acc.y);
             acc.z = fmaf(vr[i].z, w, acc.z);
@@ -927,13 +982,155 @@ __global__ __launch_bounds__(NT) void attention_fast_kernel(const AttnArgs a)
             vr[i] = ((const v4f *)(vbase + (size_t)t * stride))[cc];
         }
     }
+    L2Z_TS(5);
     if (active) ((v4f *)(part + (size_t)g * hs))[cc] = acc;
     __syncthreads();
-    float *out = a.xb + (size_t)h * hs;
+    L2Z_TS(6);
+    reduce_partials(part, ge.G, hs, a.xb + (size_t)h * hs);
+    L2Z_TS(7);
+}
+
+// ---------------------------------------------------------------------------
+// Split attention (flash-decoding form).  One CU pulls only ~45 GB/s, so one block per
+// head (attention_fast_kernel) leaves 7/8 of a 256-CU chip idle at 32 heads and spends its
+// time waiting for its own K/V rows (measured with s_memtime: 6 of 10 us).  Here head h is
+// shared by `nch` blocks; block (h, c) owns timesteps t = c, c+nch, c+2*nch, ... and writes
+//     m_c = max score,  l_c = sum exp(score - m_c),  o_c[i] = sum exp(score - m_c) * V[t][i]
+// attention_combine_kernel then forms  out[i] = (sum_c o_c[i] e^(m_c-M)) / (sum_c l_c e^(m_c-M)),
+// M = max_c m_c.  Mathematically main.zig:361-389; in floating point the weights are
+// e^(s-m_c) * e^(m_c-M) / L instead of e^(s-M) / L (a few ulp), well inside the logit
+// tolerance, and independent of GPU count (attention is head-local).
+// part layout: [head][chunk][head_size + 4] floats = o_c[head_size], m_c, l_c, pad, pad
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void attention_split_kernel(const AttnArgs a, int nch,
+                                                                 float *__restrict__ part_out)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int hs = a.head_size;
+    const AttnGeom ge = attn_geom(hs, true, kBlock);
+    const int max_local = (a.seq_len + nch - 1) / nch;
+    float *sc = lds;                                   // local scores
+    float *wt = sc + ((max_local + 3) & ~3);           // local unnormalised weights
+    float *part = wt + ((max_local + 3) & ~3);         // G*hs
+    const int h = blockIdx.x / nch, c = blockIdx.x % nch;
+    const int kvh = h / a.kv_mul;                      // :369
+    const float *kbase = a.kcache + (size_t)kvh * hs;
+    const float *vbase = a.vcache + (size_t)kvh * hs;
+    const size_t stride = (size_t)a.kv_dim;
+    const int g = threadIdx.x / ge.TPR, c0 = threadIdx.x % ge.TPR;
+    const bool active = c0 < ge.E;
+    const int cc = active ? c0 : 0;
+    const int step = ge.G * kFastUB;
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+
+    const int T = *a.pos_ptr + 1;                      // :367
+    const int Tc = T > c ? (T - c + nch - 1) / nch : 0;  // timesteps owned by this block
+    float *po = part_out + ((size_t)h * nch + c) * (size_t)(hs + 4);
+    if (Tc == 0) {  // pos < c: empty chunk (uniform branch)
+        for (int i = threadIdx.x; i < hs; i += blockDim.x) po[i] = 0.0f;
+        if (threadIdx.x == 0) { po[hs] = -INFINITY; po[hs + 1] = 0.0f; }
+        return;
+    }
+    const v4f qv = active ? ((const v4f *)(a.q + (size_t)h * hs))[cc] : zero;
+    v4f kr[kFastUB], vr[kFastUB];
+#pragma unroll
+    for (int i = 0; i < kFastUB; i++) {  // rows clamped to the chunk's last one (duplicates hit L1)
+        int j = g + ge.G * i;
+        j = j < Tc ? j : Tc - 1;
+        kr[i] = ((const v4f *)(kbase + (size_t)(c + nch * j) * stride))[cc];
+    }
+#pragma unroll
+    for (int i = 0; i < kFastUB; i++) {
+        int j = g + ge.G * i;
+        j = j < Tc ? j : Tc - 1;
+        vr[i] = ((const v4f *)(vbase + (size_t)(c + nch * j) * stride))[cc];
+    }
+    const float div = sqrtf((float)hs);
+    for (int j0 = g;;) {  // scores (:367-375), local index j <-> t = c + nch*j
+#pragma unroll
+        for (int i = 0; i < kFastUB; i++) {
+            float p = hsum4(fma4(qv, kr[i], zero));
+            p = lanes_sum(p, ge.TPR);
+            const int j = j0 + ge.G * i;
+            if (c0 == 0 && j < Tc) sc[j] = p / div;  // :372
+        }
+        j0 += step;
+        if (j0 >= Tc) break;
+#pragma unroll
+        for (int i = 0; i < kFastUB; i++) {
+            int j = j0 + ge.G * i;
+            j = j < Tc ? j : Tc - 1;
+            kr[i] = ((const v4f *)(kbase + (size_t)(c + nch * j) * stride))[cc];
+        }
+    }
+    __syncthreads();
+    // chunk-local max and sum of exponentials, redundantly per wave (identical in every wave)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float m = -INFINITY;
+    for (int j = lane; j < Tc; j += kWave) m = fmaxf(m, sc[j]);
+    m = wave_max(m);
+    float l = 0.0f;
+    for (int j = lane; j < Tc; j += kWave) l += expf(sc[j] - m);
+    l = wave_sum(l);
+    for (int j = wave * kWave + lane; j < Tc; j += kBlock) wt[j] = expf(sc[j] - m);  // unnormalised
+    __syncthreads();
+    v4f acc = zero;
+    for (int j0 = g;;) {  // weighted V (:381-388), increasing t within the group
+#pragma unroll
+        for (int i = 0; i < kFastUB; i++) {
+            const int j = j0 + ge.G * i;
+            const float w = j < Tc ? wt[j] : 0.0f;
+            acc.x = fmaf(vr[i].x, w, acc.x);
+            acc.y = fmaf(vr[i].y, w, acc.y);
+            acc.z = fmaf(vr[i].z, w, acc.z);
+            acc.w = fmaf(vr[i].w, w, acc.w);
+        }
+        j0 += step;
+        if (j0 >= Tc) break;
+#pragma unroll
+        for (int i = 0; i < kFastUB; i++) {
+            int j = j0 + ge.G * i;
+            j = j < Tc ? j : Tc - 1;
+            vr[i] = ((const v4f *)(vbase + (size_t)(c + nch * j) * stride))[cc];
+        }
+    }
+    if (active) ((v4f *)(part + (size_t)g * hs))[cc] = acc;
+    __syncthreads();
+    reduce_partials(part, ge.G, hs, po);
+    if (threadIdx.x == 0) { po[hs] = m; po[hs + 1] = l; }
+}
+
+__global__ void attention_combine_kernel(const float *__restrict__ part_in, int nch, int hs,
+                                         float *__restrict__ xb)
+{
+    constexpr int kMaxCh = 16;
+    const int h = blockIdx.x;
+    const float *p = part_in + (size_t)h * nch * (size_t)(hs + 4);
+    float mc[kMaxCh], lc[kMaxCh];
+#pragma unroll
+    for (int c = 0; c < kMaxCh; c++) {  // all chunk statistics in one round trip
+        const int cc = c < nch ? c : 0;
+        mc[c] = p[(size_t)cc * (hs + 4) + hs];
+        lc[c] = p[(size_t)cc * (hs + 4) + hs + 1];
+    }
+    float M = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < kMaxCh; c++)
+        if (c < nch) M = fmaxf(M, mc[c]);
+    float den = 0.0f;
+#pragma unroll
+    for (int c = 0; c < kMaxCh; c++) {
+        mc[c] = c < nch ? expf(mc[c] - M) : 0.0f;  // scale of chunk c; empty chunk: e^(-inf) = 0
+        den = fmaf(lc[c], mc[c], den);
+    }
     for (int i = threadIdx.x; i < hs; i += blockDim.x) {
-        float s = part[i];
-        for (int gg = 1; gg < ge.G; gg++) s += part[(size_t)gg * hs + i];
-        out[i] = s;
+        float oc[kMaxCh];
+#pragma unroll
+        for (int c = 0; c < kMaxCh; c++) oc[c] = p[(size_t)(c < nch ? c : 0) * (hs + 4) + i];
+        float num = 0.0f;
+#pragma unroll
+        for (int c = 0; c < kMaxCh; c++) num = fmaf(oc[c], mc[c], num);
+        xb[(size_t)h * hs + i] = num / den;
     }
 }
 
@@ -1203,7 +1400,7 @@ size_t attention_lds_bytes(int head_size, int seq_len, bool vec)
     size_t fl = (size_t)((head_size + 3) & ~3) + ((seq_len + 3) & ~3) + (size_t)ge.G * head_size + kScratch;
     if (vec && head_size <= 256) {  // fast kernel geometry
         const AttnGeom gf = attn_geom(head_size, true, kAttnFastBlock);
-        const size_t f2 = (size_t)((seq_len + 3) & ~3) + (size_t)gf.G * head_size;
+        const size_t f2 = 2 * (size_t)((seq_len + 3) & ~3) + (size_t)gf.G * head_size;
         if (f2 > fl) fl = f2;
     }
     return fl * sizeof(float);
@@ -1286,6 +1483,44 @@ hipError_t launch_matvec(const MatvecArgs &a, int pro, int epi, int max_blocks_p
     return hipLaunchKernel(k.fn, dim3(grid), dim3(kBlock), args, lds, st);
 }
 
+int attention_split_chunks(int n_heads_local, int n_cus)
+{
+    int nch = n_cus / (n_heads_local > 0 ? n_heads_local : 1);
+    if (nch > 16) nch = 16;
+    if (nch < 1) nch = 1;
+    return nch;
+}
+
+size_t attention_split_part_floats(int n_heads_local, int head_size, int nch)
+{
+    return (size_t)n_heads_local * nch * (size_t)(head_size + 4);
+}
+
+hipError_t launch_attention_split(const AttnArgs &a, int n_heads_local, int nch, float *part,
+                                  hipStream_t st)
+{
+    const AttnGeom ge = attn_geom(a.head_size, true, kBlock);
+    const int max_local = (a.seq_len + nch - 1) / nch;
+    const size_t lds = (size_t)(2 * ((max_local + 3) & ~3) + ge.G * a.head_size) * sizeof(float);
+    hipError_t e = ensure_lds(attention_split_kernel, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(attention_split_kernel, dim3(n_heads_local * nch), dim3(kBlock), lds, st, a,
+                       nch, part);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    int ct = (a.head_size + 63) & ~63;
+    if (ct > 1024) ct = 1024;
+    hipLaunchKernelGGL(attention_combine_kernel, dim3(n_heads_local), dim3(ct), 0, st, part, nch,
+                       a.head_size, a.xb);
+    return hipGetLastError();
+}
+
+bool attention_split_supported(const AttnArgs &a)
+{
+    return (a.head_size % 4) == 0 && a.head_size <= 256 && (a.kv_dim % 4) == 0 && aligned16(a.q) &&
+           aligned16(a.kcache) && aligned16(a.vcache);
+}
+
 hipError_t launch_attention(const AttnArgs &a, int n_heads_local, hipStream_t st)
 {
     const bool vec = (a.head_size % 4) == 0 && (a.kv_dim % 4) == 0 && aligned16(a.q) &&
@@ -1295,17 +1530,17 @@ hipError_t launch_attention(const AttnArgs &a, int n_heads_local, hipStream_t st
         static const int forced = getenv("L2Z_ATTN_BLOCK") ? atoi(getenv("L2Z_ATTN_BLOCK")) : 0;
         const int nt = forced ? forced : (a.seq_len > 512 ? kAttnFastBlock : kBlock);
         const AttnGeom gf = attn_geom(a.head_size, true, nt);
-        const size_t lds_fast = (size_t)(((a.seq_len + 3) & ~3) + gf.G * a.head_size) * sizeof(float);
+        const size_t lds_fast = (size_t)(2 * ((a.seq_len + 3) & ~3) + gf.G * a.head_size) * sizeof(float);
         if (nt == kAttnFastBlock) {
-            hipError_t e = ensure_lds(attention_fast_kernel<kAttnFastBlock>, lds_fast);
+            hipError_t e = ensure_lds(attention_fast_kernel<kAttnFastBlock, false>, lds_fast);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((attention_fast_kernel<kAttnFastBlock>), dim3(n_heads_local),
+            hipLaunchKernelGGL((attention_fast_kernel<kAttnFastBlock, false>), dim3(n_heads_local),
                                dim3(kAttnFastBlock), lds_fast, st, a);
         } else {
-            hipError_t e = ensure_lds(attention_fast_kernel<kBlock>, lds_fast);
+            hipError_t e = ensure_lds(attention_fast_kernel<kBlock, true>, lds_fast);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((attention_fast_kernel<kBlock>), dim3(n_heads_local), dim3(kBlock),
-                               lds_fast, st, a);
+            hipLaunchKernelGGL((attention_fast_kernel<kBlock, true>), dim3(n_heads_local),
+                               dim3(kBlock), lds_fast, st, a);
         }
         return hipGetLastError();
     }
@@ -1398,5 +1633,12 @@ hipError_t launch_synth_fill(float *dst, uint64_t base_idx, uint64_t count, uint
                        count, seed, scale, bias);
     return hipGetLastError();
 }
+
+#ifdef L2Z_DBG_TS
+hipError_t dbg_ts_read(long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_ts), 16 * sizeof(long long));
+}
+#endif
 
 }  // namespace l2z

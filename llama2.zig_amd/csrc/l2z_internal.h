@@ -114,6 +114,12 @@ hipError_t launch_matvec(const MatvecArgs &a, int pro, int epi, int max_blocks_p
                          hipStream_t st, int *out_grid = nullptr);
 int matvec_max_grid(int n_cus);  // upper bound of the grid launch_matvec picks
 hipError_t launch_attention(const AttnArgs &a, int n_heads_local, hipStream_t st);
+// flash-decoding form: `nch` blocks per head + a combine launch (kernels.hip)
+int attention_split_chunks(int n_heads_local, int n_cus);
+size_t attention_split_part_floats(int n_heads_local, int head_size, int nch);
+bool attention_split_supported(const AttnArgs &a);
+hipError_t launch_attention_split(const AttnArgs &a, int n_heads_local, int nch, float *part,
+                                  hipStream_t st);
 hipError_t launch_argmax(const ArgmaxArgs &a, hipStream_t st);
 hipError_t launch_set_state(int token, int pos, int *token_ptr, int *pos_ptr, const float *tok_emb,
                             float *x, int dim, hipStream_t st);

@@ -162,3 +162,33 @@ def test_stories110M_full_shape_logits_tolerance(gpu, ck, orc):
         assert s.argmax() == int(np.argmax(ref)) or np.sort(ref)[-1] - np.sort(ref)[-2] < 1e-4
     print(f"stories110M shape: max |logit diff| over {len(toks)} positions = {worst:.3e}")
     s.close(); w.close(); m.close()
+
+
+def test_stories110M_across_the_attention_switch_over(gpu, ck, orc):
+    """Positions 0..270 of the 110M shape: the device switches from one block per head to the
+    split (flash-decoding) attention at pos 256; logits stay within tolerance across it and
+    the device greedy loop equals the host loop."""
+    cfg = ck.STORIES110M
+    blob = ck.synth_blob(cfg, True, 111)
+    w, s = gpu.Weights(cfg, blob, True), gpu.RunState(cfg)
+    m = orc.Model(cfg.as_i32(), blob, True)
+    rng = np.random.default_rng(5)
+    toks = [1] + rng.integers(0, cfg.vocab_size, 270).tolist()
+    worst = 0.0
+    for pos, t in enumerate(toks):
+        ref = m.transformer(t, pos)
+        s.transformer(t, pos, w)
+        if pos >= 250 or pos % 50 == 0:
+            got = s.logits()
+            worst = max(worst, float(np.abs(got - ref).max()))
+            np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4, err_msg=f"pos {pos}")
+    print(f"110M shape across pos 256: max |logit diff| {worst:.3e}")
+    s.greedy_begin(toks[1:260])
+    dev = s.greedy_run(w, 275)
+    tok, host = 1, []
+    for pos in range(len(dev)):
+        s.transformer(tok, pos, w)
+        tok = toks[1 + pos] if pos < 259 else s.argmax()
+        host.append(tok)
+    assert host == dev.tolist()
+    s.close(); w.close(); m.close()

@@ -359,3 +359,27 @@ def test_sharded_hip_path_emulated_ranks(gpu, ck, world, from_blob):
         o.close()
     for c in comms:
         c.close()
+
+
+@pytest.mark.parametrize("nch", [2, 3, 16])
+def test_split_attention_matches_oracle(gpu, ck, orc, nch, monkeypatch):
+    """The flash-decoding attention (nch blocks per head + combine) is forced on for toy
+    models (it is auto-enabled only for seq_len > 256): logits within tolerance at every
+    position, greedy tokens identical, including positions < nch (empty chunks)."""
+    monkeypatch.setenv("L2Z_ATTN_SPLIT", str(nch))
+    for name, kw, shared in CONFIGS[:3]:
+        cfg = ck.Config(**kw)
+        blob = ck.synth_blob(cfg, shared, seed=61)
+        w, s = gpu.Weights(cfg, blob, shared), gpu.RunState(cfg)
+        m = orc.Model(cfg.as_i32(), blob, shared)
+        ref_toks, _ = m.generate_greedy([2, 3], cfg.seq_len)
+        s.greedy_begin([2, 3])
+        assert np.array_equal(s.greedy_run(w, cfg.seq_len), ref_toks), name
+        m2 = orc.Model(cfg.as_i32(), blob, shared)
+        tok = 1
+        for pos in range(cfg.seq_len):
+            ref = m2.transformer(tok, pos)
+            s.transformer(tok, pos, w)
+            np.testing.assert_allclose(s.logits(), ref, rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
+            tok = int(ref_toks[pos])
+        s.close(); w.close(); m.close(); m2.close()
