@@ -383,3 +383,30 @@ def test_split_attention_matches_oracle(gpu, ck, orc, nch, monkeypatch):
             np.testing.assert_allclose(s.logits(), ref, rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
             tok = int(ref_toks[pos])
         s.close(); w.close(); m.close(); m2.close()
+
+
+def test_greedy_loop_edges(gpu, ck, orc):
+    """main.zig:1017 (a BOS -- even one forced by the prompt -- ends the sequence), :992-993
+    (steps clamp to seq_len), chunked calls, restart."""
+    cfg = ck.Config(**TOY)
+    blob = ck.synth_blob(cfg, False, 77)
+    w, s = gpu.Weights(cfg, blob, False), gpu.RunState(cfg)
+    m = orc.Model(cfg.as_i32(), blob, False)
+    # BOS inside the prompt: the loop stops right there, on both sides
+    ref, _ = m.generate_greedy([5, 1, 7], cfg.seq_len)
+    assert ref.tolist() == [5, 1]
+    s.greedy_begin([5, 1, 7])
+    assert s.greedy_run(w, cfg.seq_len).tolist() == [5, 1]
+    assert s.greedy_run(w, 4).size == 0            # the sequence is over until the next begin
+    # more steps than seq_len: clamped (main.zig:993)
+    ref, _ = m.generate_greedy([], cfg.seq_len)
+    s.greedy_begin([])
+    got = s.greedy_run(w, 10 * cfg.seq_len)
+    assert np.array_equal(got, ref) and len(got) <= cfg.seq_len
+    assert s.greedy_run(w, 1).size == 0            # pos == seq_len: nothing left
+    # one token at a time == all at once
+    s.greedy_begin([])
+    one = [int(s.greedy_run(w, 1)[0]) for _ in range(len(ref))]
+    assert one == ref.tolist()
+    assert s.greedy_run(w, 0).size == 0
+    s.close(); w.close(); m.close()
