@@ -135,6 +135,22 @@ int l2z_greedy_begin(l2z_runstate *s, const int32_t *prompt, int n_prompt);
 int l2z_greedy_run(const l2z_config *config, l2z_runstate *s, const l2z_weights *w, int n_steps,
                    int32_t *out_tokens, int *out_n);
 
+/* ---- batched prefill (no reference equivalent: src/main.zig:999-1000
+ * feeds the prompt one token at a time) ----
+ * Same state change as l2z_transformer(tokens[i], pos0 + i) for i = 0 .. n_tokens-1 -- the
+ * KV-cache rows pos0 .. pos0+n_tokens-1 of every layer are written and the logits of the LAST
+ * position are left in the runstate (l2z_argmax / l2z_logits_read) -- but each weight matrix is
+ * streamed once per chunk of up to 256 tokens and multiplied as a dense GEMM on the fp32 matrix
+ * cores (v_mfma_f32_32x32x2_f32).  Values agree with the token-by-token path up to summation
+ * order.  Single-GPU runstates only; dims must be multiples of 4 (else L2Z_ERR_INVALID, and the
+ * caller loops over l2z_transformer).
+ * l2z_greedy_run uses the same pass for the prompt positions when its first call after
+ * l2z_greedy_begin asks for at least n_prompt steps, n_prompt >= L2Z_PREFILL_MIN_PROMPT and no
+ * prompt token is BOS; L2Z_PREFILL=0 in the environment keeps the stepped loop. */
+#define L2Z_PREFILL_MIN_PROMPT 4
+int l2z_prefill(const int32_t *tokens, int n_tokens, int pos0, const l2z_config *config,
+                l2z_runstate *s, const l2z_weights *w);
+
 /* ---- measurement support ----
  * l2z_profile_forward runs ONE forward pass (+ argmax/hand-over) eagerly with
  * a HIP event pair around every kernel launch, recorded on the runstate's own

@@ -73,6 +73,7 @@ def lib():
     L.l2z_argmax.argtypes = [vp, ip]
     L.l2z_logits_read.argtypes = [vp, fp]
     L.l2z_runstate_read.argtypes = [vp, C.c_char_p, sz, sz, fp]
+    L.l2z_prefill.argtypes = [i32p, C.c_int, C.c_int, cfgp, vp, vp]
     L.l2z_greedy_begin.argtypes = [vp, i32p, C.c_int]
     L.l2z_greedy_run.argtypes = [cfgp, vp, vp, C.c_int, i32p, ip]
     L.l2z_profile_forward.argtypes = [C.c_int, C.c_int, cfgp, vp, vp, C.POINTER(C.c_double), ip,
@@ -209,6 +210,12 @@ class RunState:
     def transformer(self, token: int, pos: int, w: Weights) -> None:
         """src/main.zig:285"""
         _chk(lib().l2z_transformer(token, pos, C.byref(self.cfg), self.h, w.h))
+
+    def prefill(self, tokens, pos0: int, w: Weights) -> None:
+        """l2z_prefill: the state change of transformer(tokens[i], pos0+i) for all i, batched."""
+        t = np.ascontiguousarray(tokens, np.int32)
+        _chk(lib().l2z_prefill(t.ctypes.data_as(C.POINTER(C.c_int32)), t.size, pos0,
+                               C.byref(self.cfg), self.h, w.h))
 
     def argmax(self) -> int:
         t = C.c_int(0)

@@ -4,6 +4,7 @@
 //
 // Product code.  No CPU fallback anywhere: without a HIP device every compute
 // entry point returns L2Z_ERR_NO_DEVICE.  Nothing under oracle/ is referenced.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -188,6 +189,10 @@ struct l2z_runstate {
     // loop state on the device
     int *d_token = nullptr, *d_pos = nullptr, *d_prompt = nullptr, *d_n_prompt = nullptr;
     int *d_out_tokens = nullptr, *d_argmax = nullptr;
+    // batched prefill scratch (allocated on first l2z_prefill): [kPrefillChunk, dim|hidden]
+    float *pf_x = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_att = nullptr;
+    float *pf_h1 = nullptr, *pf_h3 = nullptr;
+    int *pf_tokens = nullptr;
     float *d_part_val = nullptr;  // classifier launch's per-block argmax candidates
     int *d_part_idx = nullptr;
     int n_part = 0;               // 0: argmax scans the logits instead
@@ -200,6 +205,7 @@ struct l2z_runstate {
     bool use_graphs = true;
     int host_pos = 0;   // next position the greedy loop will run
     bool done = false;  // greedy loop saw BOS
+    std::vector<int32_t> h_prompt;  // host copy of the greedy loop's prompt (prefill path)
     int max_blocks = 0;
 };
 
@@ -513,7 +519,8 @@ extern "C" void l2z_runstate_free(l2z_runstate *s)
     }
     void *ptrs[] = {s->x, s->xb, s->hb, s->q, s->logits, s->key_cache, s->value_cache, s->rope,
                     s->d_token, s->d_pos, s->d_prompt, s->d_n_prompt, s->d_out_tokens, s->d_argmax,
-                    s->d_part_val, s->d_part_idx, s->d_attn_part};
+                    s->d_part_val, s->d_part_idx, s->d_attn_part, s->pf_x, s->pf_xn, s->pf_q,
+                    s->pf_att, s->pf_h1, s->pf_h3, s->pf_tokens};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -795,6 +802,137 @@ extern "C" int l2z_synchronize(l2z_runstate *s)
 }
 
 // ---------------------------------------------------------------------------
+// Batched prefill: the same state change as calling
+// l2z_transformer(tokens[i], pos0 + i) for i = 0..n-1 -- KV-cache rows pos0..pos0+n-1 written in
+// every layer, logits of the LAST position left in the runstate -- but every weight matrix is
+// streamed once per chunk of up to kPrefillChunk tokens and multiplied on the fp32 matrix cores.
+namespace {
+constexpr int kPrefillChunk = 256;
+
+int prefill_alloc(l2z_runstate *s)
+{
+    if (s->pf_x) return L2Z_OK;
+    const l2z_config &c = s->cfg;
+    const size_t P = kPrefillChunk;
+    L2Z_HIP(hipMalloc(&s->pf_x, P * c.dim * 4));
+    L2Z_HIP(hipMalloc(&s->pf_xn, P * c.dim * 4));
+    L2Z_HIP(hipMalloc(&s->pf_q, P * c.dim * 4));
+    L2Z_HIP(hipMalloc(&s->pf_att, P * c.dim * 4));
+    L2Z_HIP(hipMalloc(&s->pf_h1, P * c.hidden_dim * 4));
+    L2Z_HIP(hipMalloc(&s->pf_h3, P * c.hidden_dim * 4));
+    L2Z_HIP(hipMalloc(&s->pf_tokens, P * 4));
+    return L2Z_OK;
+}
+
+int prefill_chunk(l2z_runstate *s, const l2z_weights *w, const int32_t *tokens, int P, int pos0)
+{
+    const l2z_config &c = s->cfg;
+    const Shard &sh = s->sh;
+    hipStream_t st = s->stream;
+    const int dim = c.dim, hid = c.hidden_dim, kvd = sh.kvd_loc, hs = sh.hs;
+    L2Z_HIP(hipMemcpyAsync(s->pf_tokens, tokens, (size_t)P * 4, hipMemcpyHostToDevice, st));
+    L2Z_HIP(launch_prefill_embed(s->pf_x, w->tok_emb, s->pf_tokens, dim, P, st));  // :295
+    for (int l = 0; l < c.n_layers; l++) {
+        float *kc = s->key_cache + (size_t)l * c.seq_len * kvd;
+        float *vc = s->value_cache + (size_t)l * c.seq_len * kvd;
+        L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, s->pf_x, w->rms_att + (size_t)l * dim, dim, P, st));  // :305
+        L2Z_HIP(launch_prefill_gemm(PG_ROPE, s->pf_xn, dim, w->wq + (size_t)l * dim * dim, s->pf_q, dim,
+                                    P, dim, dim, pos0, s->rope, hs, st));                   // :308-351
+        L2Z_HIP(launch_prefill_gemm(PG_ROPE_CACHE, s->pf_xn, dim, w->wk + (size_t)l * kvd * dim, kc, kvd,
+                                    P, kvd, dim, pos0, s->rope, hs, st));                   // :354-357
+        L2Z_HIP(launch_prefill_gemm(PG_CACHE, s->pf_xn, dim, w->wv + (size_t)l * kvd * dim, vc, kvd, P,
+                                    kvd, dim, pos0, s->rope, hs, st));                      // :358
+        L2Z_HIP(launch_prefill_attention(s->pf_q, dim, kc, vc, s->pf_att, dim, pos0, P, c.n_heads, hs,
+                                         kvd, c.n_heads / c.n_kv_heads, c.seq_len, st));    // :361-389
+        L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_att, dim, w->wo + (size_t)l * dim * dim, s->pf_x, dim,
+                                    P, dim, dim, pos0, s->rope, hs, st));                   // :392-395
+        L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, s->pf_x, w->rms_ffn + (size_t)l * dim, dim, P, st));  // :398
+        L2Z_HIP(launch_prefill_gemm(PG_STORE, s->pf_xn, dim, w->w1 + (size_t)l * hid * dim, s->pf_h1, hid,
+                                    P, hid, dim, pos0, s->rope, hs, st));                   // :405
+        L2Z_HIP(launch_prefill_gemm(PG_STORE, s->pf_xn, dim, w->w3 + (size_t)l * hid * dim, s->pf_h3, hid,
+                                    P, hid, dim, pos0, s->rope, hs, st));
+        L2Z_HIP(launch_prefill_swiglu(s->pf_h1, s->pf_h1, s->pf_h3, (size_t)P * hid, st));   // :411-416
+        L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_h1, hid, w->w2 + (size_t)l * dim * hid, s->pf_x, dim,
+                                    P, dim, hid, pos0, s->rope, hs, st));                   // :419-422
+    }
+    return L2Z_OK;
+}
+}  // namespace
+
+constexpr int kPrefillMinPrompt = L2Z_PREFILL_MIN_PROMPT;  // shorter prompts: the stepped loop is as fast
+
+static bool prefill_enabled()
+{
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("L2Z_PREFILL");
+        on = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return on == 1;
+}
+
+static int prefill_check(const l2z_config *config, const l2z_runstate *s)
+{
+    L2Z_CHECK(s->sh.world == 1, L2Z_ERR_INVALID, "l2z_prefill: not available on a sharded runstate");
+    L2Z_CHECK(config->dim % 4 == 0 && config->hidden_dim % 4 == 0 && s->sh.hs % 4 == 0 &&
+                  s->sh.hs <= 256, L2Z_ERR_INVALID,
+              "l2z_prefill: needs dim, hidden_dim, head_size multiples of 4 and head_size <= 256");
+    return L2Z_OK;
+}
+
+// positions pos0 .. pos0+n-1 in chunks; leaves the last position's residual row in RunState.x
+static int prefill_tokens(l2z_runstate *s, const l2z_weights *w, const int32_t *tokens, int n_tokens,
+                          int pos0)
+{
+    const l2z_config *config = &s->cfg;
+    L2Z_TRY(prefill_alloc(s));
+    int done = 0;
+    while (done < n_tokens) {
+        const int P = n_tokens - done < kPrefillChunk ? n_tokens - done : kPrefillChunk;
+        L2Z_TRY(prefill_chunk(s, w, tokens + done, P, pos0 + done));
+        if (done + P == n_tokens)
+            L2Z_HIP(hipMemcpyAsync(s->x, s->pf_x + (size_t)(P - 1) * config->dim, (size_t)config->dim * 4,
+                                   hipMemcpyDeviceToDevice, s->stream));
+        L2Z_HIP(hipStreamSynchronize(s->stream));  // the host token buffer may now be reused
+        done += P;
+    }
+    return L2Z_OK;
+}
+
+extern "C" int l2z_prefill(const int32_t *tokens, int n_tokens, int pos0, const l2z_config *config,
+                           l2z_runstate *s, const l2z_weights *w)
+{
+    L2Z_TRY(check_pair(config, s, w));
+    L2Z_CHECK(tokens != nullptr && n_tokens >= 1, L2Z_ERR_INVALID, "l2z_prefill: no tokens");
+    L2Z_CHECK(pos0 >= 0 && pos0 + n_tokens <= config->seq_len, L2Z_ERR_STATE,
+              "l2z_prefill: positions %d..%d outside [0,%d)", pos0, pos0 + n_tokens - 1, config->seq_len);
+    for (int i = 0; i < n_tokens; i++)
+        L2Z_CHECK(tokens[i] >= 0 && tokens[i] < config->vocab_size, L2Z_ERR_STATE,
+                  "l2z_prefill: tokens[%d] = %d out of vocabulary", i, tokens[i]);
+    L2Z_TRY(prefill_check(config, s));
+    L2Z_HIP(hipSetDevice(s->device));
+    L2Z_TRY(prefill_tokens(s, w, tokens, n_tokens, pos0));
+    // the last position's residual row is RunState.x: the usual final rmsnorm + classifier
+    // launch (:426-429) leaves the logits in place
+    const int last_pos = pos0 + n_tokens - 1;
+    L2Z_HIP(hipMemcpyAsync(s->d_pos, &last_pos, sizeof(int), hipMemcpyHostToDevice, s->stream));
+    L2Z_HIP(hipMemcpyAsync(s->d_token, &tokens[n_tokens - 1], sizeof(int), hipMemcpyHostToDevice, s->stream));
+    {
+        const l2z_config &c = s->cfg;
+        MatvecArgs a = {};
+        a.w0 = w->wcls; a.out0 = s->logits; a.rows0 = c.vocab_size; a.n = c.dim; a.x = s->x;
+        a.rms_w = w->rms_final;
+        a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.row_offset = 0;
+        int grid = 0;
+        L2Z_HIP(launch_matvec(a, PRO_RMS, EPI_ARGMAX, s->max_blocks, g_cus, s->stream, &grid));
+        s->n_part = grid;
+    }
+    L2Z_HIP(hipStreamSynchronize(s->stream));
+    s->host_pos = pos0 + n_tokens;
+    return L2Z_OK;
+}
+
+// ---------------------------------------------------------------------------
 // src/main.zig:987-1042 at temperature 0
 extern "C" int l2z_greedy_begin(l2z_runstate *s, const int32_t *prompt, int n_prompt)
 {
@@ -809,6 +947,7 @@ extern "C" int l2z_greedy_begin(l2z_runstate *s, const int32_t *prompt, int n_pr
     if (n_prompt)
         L2Z_HIP(hipMemcpy(s->d_prompt, prompt, (size_t)n_prompt * sizeof(int), hipMemcpyHostToDevice));
     L2Z_HIP(hipMemcpy(s->d_n_prompt, &n_prompt, sizeof(int), hipMemcpyHostToDevice));
+    s->h_prompt.assign(prompt, prompt + n_prompt);
     s->host_pos = 0;
     s->done = false;
     s->graph_w = s->graph_w;  // graphs stay valid: all loop state is in device memory
@@ -833,6 +972,28 @@ extern "C" int l2z_greedy_run(const l2z_config *config, l2z_runstate *s, const l
     }
     const int kChunk = 64;  // host looks for BOS (main.zig:1017) once per chunk
     int produced = 0;
+    // Prompt positions (main.zig:999-1000 forces next = prompt[pos], the logits there are never
+    // looked at) run as one batched pass: inputs BOS, prompt[0..n-2] at positions 0..n-1, then
+    // the loop resumes at pos = n with token = prompt[n-1].  Only when this call covers the whole
+    // prompt, no prompt token is BOS (the loop would stop there, :1017) and L2Z_PREFILL != 0.
+    const int np = (int)s->h_prompt.size();
+    if (s->host_pos == 0 && np >= kPrefillMinPrompt && remaining >= np && prefill_enabled() &&
+        s->sh.world == 1 && config->dim % 4 == 0 && config->hidden_dim % 4 == 0 &&
+        s->sh.hs % 4 == 0 && s->sh.hs <= 256 &&
+        std::find(s->h_prompt.begin(), s->h_prompt.end(), 1) == s->h_prompt.end()) {
+        std::vector<int32_t> in((size_t)np);
+        in[0] = 1;
+        for (int i = 1; i < np; i++) in[(size_t)i] = s->h_prompt[(size_t)i - 1];
+        L2Z_TRY(prefill_tokens(s, w, in.data(), np, 0));
+        L2Z_HIP(hipMemcpyAsync(s->d_out_tokens, s->d_prompt, (size_t)np * sizeof(int),
+                               hipMemcpyDeviceToDevice, s->stream));
+        L2Z_HIP(launch_set_state(s->h_prompt[(size_t)np - 1], np, s->d_token, s->d_pos, w->tok_emb,
+                                 s->x, config->dim, s->stream));
+        for (int i = 0; i < np; i++) out_tokens[i] = s->h_prompt[(size_t)i];
+        produced = np;
+        s->host_pos = np;
+        remaining -= np;
+    }
     while (remaining > 0 && !s->done) {
         const int n = remaining < kChunk ? remaining : kChunk;
         for (int i = 0; i < n; i++) L2Z_TRY(run_forward(s, w, true, s->host_pos + i));

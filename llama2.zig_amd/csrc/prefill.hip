@@ -1,0 +1,464 @@
+// prefill.hip -- batched prompt processing.
+//
+// The reference feeds the prompt one token at a time through transformer()
+// (src/main.zig:999-1000): every matrix op is a mat-vec and the logits of
+// prompt positions are thrown away.  Here P prompt tokens go through a layer
+// together, so each weight matrix is streamed once per chunk instead of once
+// per token and the matrix work is a true dense GEMM:
+//     C[P, N] = X[P, K] . W[N, K]^T        (W row-major as in the checkpoint)
+// on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate,
+// bit-for-bit a k-ordered fmaf chain, 157 TFLOP/s peak = the f32 vector rate).
+// Results equal the token-by-token path up to summation order (tested within
+// the same logit tolerance); the KV cache and RunState end in the same state.
+//
+// Kernels: prefill_gemm (LDS-tiled MFMA GEMM with fused epilogues), batched
+// rmsnorm, SwiGLU, embedding gather, causal attention for a chunk (one block
+// per (head, token), the decode kernel's arithmetic).
+#include <cstdlib>
+
+#include "l2z_internal.h"
+
+namespace l2z {
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int kPfBlock = 256;
+
+enum GemmEpi { G_STORE = 0, G_RESID = 1, G_ROPE = 2, G_ROPE_CACHE = 3, G_CACHE = 4 };
+
+struct GemmArgs {
+    const float *x;      // [P, K] row-major (ldx floats per row)
+    const float *w;      // [N, K] row-major
+    float *out;          // [P, ldo]; G_*CACHE: cache base, row = pos0 + token
+    int P, N, K, ldx, ldo;
+    int pos0;            // position of token 0 (RoPE angle, cache row)
+    const float2 *rope;  // (seq_len, head_size/2) {cos, sin}
+    int head_size;
+};
+
+// Block tile (64 TM tokens) x (64 TN features), 4 waves as 2 x 2, each wave TM x TN MFMA tiles of
+// 32 x 32.  MFMA 32x32x2 f32: D[i][j] += A[i][k] B[k][j] with
+//   A operand: lane l holds A[i = l & 31][k = l >> 5]      -> X[token i][k]
+//   B operand: lane l holds B[k = l >> 5][j = l & 31]      -> W[feature j][k]
+//   D: lane l, reg r holds D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31]
+// Global loads of stage s+1 are issued before the MFMAs of stage s (register staged), weights
+// non-temporal.  (TM,TN) = (2,2): 128 x 128 tile, 32 flop per byte staged -- for long prompts;
+// (1,1): 64 x 64, twice the blocks -- for short ones, which are bound by weight streaming.
+template <int EPI, int TM, int TN, int BK>
+__global__ __launch_bounds__(kPfBlock) void prefill_gemm(const GemmArgs a)
+{
+    constexpr int LDK = BK + 1;  // padded row: 32 rows hit 32 distinct banks
+    constexpr int RF = BK / 4;   // float4 per tile row
+    constexpr int BMt = 64 * TM, BNt = 64 * TN;
+    constexpr int XL = BMt * BK / 4 / kPfBlock, WL = BNt * BK / 4 / kPfBlock;  // float4 per thread
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *xs = smem, *ws = smem + BMt * LDK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * BNt, m0 = blockIdx.y * BMt;
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+    // float4 slot f of a tile: row f / 8, columns 4 (f % 8)
+    v4f xv[XL], wv[WL];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < XL; i++) {
+            const int f = tid + kPfBlock * i, r = f / RF, c = (f % RF) * 4;
+            const bool ok = m0 + r < a.P && k0 + c < a.K;  // K % 4 == 0: a float4 is all in or out
+            xv[i] = ok ? *(const v4f *)(a.x + (size_t)(m0 + r) * a.ldx + k0 + c) : zero;
+        }
+#pragma unroll
+        for (int i = 0; i < WL; i++) {
+            const int f = tid + kPfBlock * i, r = f / RF, c = (f % RF) * 4;
+            const bool ok = n0 + r < a.N && k0 + c < a.K;
+            wv[i] = ok ? __builtin_nontemporal_load((const v4f *)(a.w + (size_t)(n0 + r) * a.K + k0 + c))
+                       : zero;
+        }
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < XL; i++) {
+            const int f = tid + kPfBlock * i;
+            float *d = xs + (f / RF) * LDK + (f % RF) * 4;
+            d[0] = xv[i].x; d[1] = xv[i].y; d[2] = xv[i].z; d[3] = xv[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < WL; i++) {
+            const int f = tid + kPfBlock * i;
+            float *d = ws + (f / RF) * LDK + (f % RF) * 4;
+            d[0] = wv[i].x; d[1] = wv[i].y; d[2] = wv[i].z; d[3] = wv[i].w;
+        }
+    };
+    v16f acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+    const int arow = (wm * 32 * TM + (lane & 31)) * LDK + (lane >> 5);
+    const int brow = (wn * 32 * TN + (lane & 31)) * LDK + (lane >> 5);
+    gload(0);
+    for (int k0 = 0; k0 < a.K; k0 += BK) {
+        __syncthreads();  // previous stage fully consumed
+        sstore();
+        __syncthreads();
+        if (k0 + BK < a.K) gload(k0 + BK);  // flies while this stage is multiplied
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) av[i] = xs[arow + i * 32 * LDK + kk];
+#pragma unroll
+            for (int j = 0; j < TN; j++) bv[j] = ws[brow + j * 32 * LDK + kk];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // epilogue: per MFMA tile this lane owns one feature and 16 tokens
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int jt = 0; jt < TN; jt++) {
+            const int j = n0 + (wn * TN + jt) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int tok = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float v = acc[i][jt][r];
+                if (EPI == G_ROPE || EPI == G_ROPE_CACHE) {
+                    // RoPE pair (j, j+1) sits in adjacent lanes (main.zig:346-349)
+                    const float partner = __shfl_xor(v, 1, 64);
+                    const int hs = a.head_size;
+                    const int pos = a.pos0 + (tok < a.P ? tok : 0);
+                    const float2 cs = a.rope[(size_t)pos * (size_t)(hs >> 1) +
+                                             (size_t)(((j < a.N ? j : 0) % hs) >> 1)];
+                    v = (j & 1) ? partner * cs.y + v * cs.x    // v0*fci + v1*fcr
+                                : v * cs.x - partner * cs.y;   // v0*fcr - v1*fci
+                }
+                if (tok < a.P && j < a.N) {
+                    if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + j] = v;
+                    else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + j] += v;        // main.zig:711
+                    else a.out[(size_t)(a.pos0 + tok) * a.ldo + j] = v;                  // main.zig:354-358
+                }
+            }
+        }
+}
+
+// Short prompts (P <= 64): the product is bound by streaming W once, like the decode mat-vec, and
+// a 64 x 64 tile leaves most CUs without a block (N / 64 blocks).  Here a block owns 16 features
+// and 16 TMS tokens; its 8 waves split K in chunks of 64 and every lane feeds MFMA 16x16x4 straight
+// from global memory -- no LDS staging: each W element is loaded by exactly one lane, X (P x K,
+// L2 resident) by one lane per block.  MFMA 16x16x4 f32 operands:
+//   A: lane l holds A[i = l & 15][k = l >> 4]   B: lane l holds B[k = l >> 4][j = l & 15]
+//   D: lane l, reg r holds D[i = 4 (l >> 4) + r][j = l & 15]
+// Lane (., q) loads the float4 at k = 64 c + 16 u + 4 q; component t of it is "k = q" of MFMA
+// (c, u, t) for both operands, which is all the instruction needs (a sum over k is unordered in
+// exact arithmetic; the fp32 order is fixed by (c, u, t), then waves 0..7: deterministic).
+constexpr int kSkWaves = 8;
+
+template <int EPI, int TMS>
+__global__ __launch_bounds__(64 * kSkWaves) void prefill_skinny(const GemmArgs a)
+{
+    __shared__ float red[kSkWaves][TMS][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * TMS;
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+    const bool fok = n0 + j < a.N;
+    const float *wrow = a.w + (size_t)(fok ? n0 + j : 0) * a.K + 4 * q;
+    const float *xrow[TMS];
+    bool tok_ok[TMS];
+#pragma unroll
+    for (int tm = 0; tm < TMS; tm++) {
+        const int tok = m0 + 16 * tm + j;
+        tok_ok[tm] = tok < a.P;
+        xrow[tm] = a.x + (size_t)(tok_ok[tm] ? tok : 0) * a.ldx + 4 * q;
+    }
+    v4f acc[TMS];
+#pragma unroll
+    for (int tm = 0; tm < TMS; tm++) acc[tm] = zero;
+    const int nchunk = (a.K + 63) >> 6;
+    v4f wc[4], wn[4], xc[TMS][4], xn[TMS][4];
+    auto load = [&](int c, v4f (&wv)[4], v4f (&xv)[TMS][4]) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int k = 64 * c + 16 * u;
+            const bool kok = k + 4 * q < a.K;  // K % 4 == 0
+            wv[u] = (kok && fok) ? __builtin_nontemporal_load((const v4f *)(wrow + k)) : zero;
+#pragma unroll
+            for (int tm = 0; tm < TMS; tm++)
+                xv[tm][u] = (kok && tok_ok[tm]) ? *(const v4f *)(xrow[tm] + k) : zero;
+        }
+    };
+    int c = wave;
+    if (c < nchunk) load(c, wc, xc);
+    for (; c < nchunk; c += kSkWaves) {
+        if (c + kSkWaves < nchunk) load(c + kSkWaves, wn, xn);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int tm = 0; tm < TMS; tm++)
+                    acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[tm][u][t], wc[u][t], acc[tm], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            wc[u] = wn[u];
+#pragma unroll
+            for (int tm = 0; tm < TMS; tm++) xc[tm][u] = xn[tm][u];
+        }
+    }
+#pragma unroll
+    for (int tm = 0; tm < TMS; tm++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[wave][tm][r][lane] = acc[tm][r];
+    __syncthreads();
+    // TMS * 4 * 64 results; a wave of threads shares (tm, r), lanes are the MFMA lanes
+    for (int idx = tid; idx < TMS * 256; idx += 64 * kSkWaves) {
+        const int tm = idx >> 8, r = (idx >> 6) & 3, l = idx & 63;
+        float v = red[0][tm][r][l];
+#pragma unroll
+        for (int w = 1; w < kSkWaves; w++) v += red[w][tm][r][l];
+        const int tok = m0 + 16 * tm + 4 * (l >> 4) + r;
+        const int f = n0 + (l & 15);
+        if (EPI == G_ROPE || EPI == G_ROPE_CACHE) {
+            const float partner = __shfl_xor(v, 1, 64);  // feature f ^ 1, same token (main.zig:346-349)
+            const int hs = a.head_size;
+            const int pos = a.pos0 + (tok < a.P ? tok : 0);
+            const float2 cs = a.rope[(size_t)pos * (size_t)(hs >> 1) + (size_t)(((f < a.N ? f : 0) % hs) >> 1)];
+            v = (f & 1) ? partner * cs.y + v * cs.x : v * cs.x - partner * cs.y;
+        }
+        if (tok < a.P && f < a.N) {
+            if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + f] = v;
+            else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + f] += v;
+            else a.out[(size_t)(a.pos0 + tok) * a.ldo + f] = v;
+        }
+    }
+}
+
+// rows of x -> rmsnorm rows (main.zig:432-468), one block per token
+__global__ __launch_bounds__(kPfBlock) void prefill_rmsnorm(float *o, const float *x, const float *w,
+                                                            int n, int P)
+{
+    __shared__ float red[8];
+    const int t = blockIdx.x;
+    const float *xr = x + (size_t)t * n;
+    float ss = 0.0f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) ss = fmaf(xr[i], xr[i], ss);
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    float tot = red[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); i++) tot += red[i];
+    float s = tot / (float)n;
+    s += 1e-5f;
+    s = 1.0f / sqrtf(s);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) o[(size_t)t * n + i] = (xr[i] * s) * w[i];
+}
+
+// hb = silu(h1) * h3   (main.zig:411-416)
+__global__ void prefill_swiglu(float *hb, const float *h1, const float *h3, size_t count)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (size_t)gridDim.x * blockDim.x) {
+        float v = h1[i];
+        v = v * (1.0f / (1.0f + expf(-v)));
+        hb[i] = v * h3[i];
+    }
+}
+
+// x[t] = embedding row of tokens[t]   (main.zig:295-296)
+__global__ void prefill_embed(float *x, const float *tok_emb, const int *tokens, int dim)
+{
+    const float *row = tok_emb + (size_t)tokens[blockIdx.x] * dim;
+    for (int i = threadIdx.x; i < dim; i += blockDim.x) x[(size_t)blockIdx.x * dim + i] = row[i];
+}
+
+// Causal attention for a chunk (main.zig:361-389): block (h, t) is query token t of head h and
+// attends to cache rows 0..pos0+t.  256 threads = G groups of TPR lanes, as in the decode kernel.
+__global__ __launch_bounds__(kPfBlock) void prefill_attention(const float *q, int ldq,
+                                                              const float *kcache, const float *vcache,
+                                                              float *out, int ldo, int pos0,
+                                                              int head_size, int kv_dim, int kv_mul,
+                                                              int seq_len)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int hs = head_size, E = hs >> 2;
+    int TPR = 1;
+    while (TPR < E && TPR < 64) TPR <<= 1;
+    const int G = kPfBlock / TPR;
+    float *att = lds;                                   // seq_len
+    float *part = att + ((seq_len + 3) & ~3);           // G*hs
+    float *red = part + (size_t)G * hs;                 // 8
+    const int h = blockIdx.x, tok = blockIdx.y;
+    const int T = pos0 + tok + 1;
+    const int kvh = h / kv_mul;
+    const float *kbase = kcache + (size_t)kvh * hs, *vbase = vcache + (size_t)kvh * hs;
+    const int g = threadIdx.x / TPR, c0 = threadIdx.x % TPR;
+    const bool active = c0 < E;
+    const int cc = active ? c0 : 0;
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+    const v4f qv = active ? ((const v4f *)(q + (size_t)tok * ldq + (size_t)h * hs))[cc] : zero;
+    const float div = sqrtf((float)hs);
+    for (int t = g; t < T; t += G) {
+        const v4f kv = ((const v4f *)(kbase + (size_t)t * kv_dim))[cc];
+        float p = fmaf(qv.x, kv.x, 0.0f);
+        p = fmaf(qv.y, kv.y, p); p = fmaf(qv.z, kv.z, p); p = fmaf(qv.w, kv.w, p);
+        for (int o = TPR >> 1; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
+        if (c0 == 0) att[t] = p / div;
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) m = fmaxf(m, att[t]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.0f;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        const float e = expf(att[t] - m);
+        att[t] = e;
+        s += e;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = s;
+    __syncthreads();
+    s = ((red[4] + red[5]) + red[6]) + red[7];
+    v4f acc = zero;
+    for (int t = g; t < T; t += G) {
+        const v4f vv = ((const v4f *)(vbase + (size_t)t * kv_dim))[cc];
+        const float w = att[t] / s;  // main.zig:704
+        acc.x = fmaf(vv.x, w, acc.x); acc.y = fmaf(vv.y, w, acc.y);
+        acc.z = fmaf(vv.z, w, acc.z); acc.w = fmaf(vv.w, w, acc.w);
+    }
+    if (active) ((v4f *)(part + (size_t)g * hs))[cc] = acc;
+    __syncthreads();
+    for (int i = threadIdx.x; i < hs; i += blockDim.x) {
+        float r = part[i];
+        for (int gg = 1; gg < G; gg++) r += part[(size_t)gg * hs + i];
+        out[(size_t)tok * ldo + (size_t)h * hs + i] = r;
+    }
+}
+
+template <int EPI, int TM, int TN, int BK>
+hipError_t gemm_launch_t(const GemmArgs &a, hipStream_t st)
+{
+    constexpr int BMt = 64 * TM, BNt = 64 * TN;
+    const size_t lds = (size_t)(BMt + BNt) * (BK + 1) * sizeof(float);
+    static bool attr = false;
+    if (!attr && lds > 48 * 1024) {
+        (void)hipFuncSetAttribute((const void *)prefill_gemm<EPI, TM, TN, BK>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    dim3 grid((a.N + BNt - 1) / BNt, (a.P + BMt - 1) / BMt);
+    hipLaunchKernelGGL((prefill_gemm<EPI, TM, TN, BK>), grid, dim3(kPfBlock), lds, st, a);
+    return hipGetLastError();
+}
+
+template <int EPI, int TMS>
+hipError_t skinny_launch_t(const GemmArgs &a, hipStream_t st)
+{
+    dim3 grid((a.N + 15) / 16, (a.P + 16 * TMS - 1) / (16 * TMS));
+    hipLaunchKernelGGL((prefill_skinny<EPI, TMS>), grid, dim3(64 * kSkWaves), 0, st, a);
+    return hipGetLastError();
+}
+
+template <int EPI>
+hipError_t gemm_launch(const GemmArgs &a, hipStream_t st)
+{
+    static int tile = -1, skinny_max = 64, skinny_tms = 4;
+    if (tile < 0) {
+        const char *e = getenv("L2Z_PF_TILE");
+        tile = e ? atoi(e) : 1;
+        if (const char *m = getenv("L2Z_PF_SKINNY_MAX")) skinny_max = atoi(m);
+        if (const char *m = getenv("L2Z_PF_SKINNY_TMS")) skinny_tms = atoi(m);
+    }
+    if (a.P <= skinny_max) {
+        // a matrix that stays in the on-die caches is cheapest re-read per 16 tokens (more blocks,
+        // more waves per CU); one that streams from HBM is read once, tokens tiled in registers
+        const bool cached = (size_t)a.N * (size_t)a.K * sizeof(float) <= ((size_t)16 << 20);
+        if (a.P <= 16 || skinny_tms == 1 || cached) return skinny_launch_t<EPI, 1>(a, st);
+        if (a.P <= 32 || skinny_tms == 2) return skinny_launch_t<EPI, 2>(a, st);
+        return skinny_launch_t<EPI, 4>(a, st);  // more than 64 tokens: grid.y tiles of 64
+    }
+    switch (tile) {
+    case 1: return gemm_launch_t<EPI, 1, 1, 64>(a, st);
+    case 2: return gemm_launch_t<EPI, 1, 1, 128>(a, st);
+    case 3: return gemm_launch_t<EPI, 2, 1, 32>(a, st);
+    case 4: return gemm_launch_t<EPI, 2, 1, 64>(a, st);
+    case 5: return gemm_launch_t<EPI, 1, 2, 32>(a, st);
+    case 6: return gemm_launch_t<EPI, 1, 2, 64>(a, st);
+    case 7: return gemm_launch_t<EPI, 2, 2, 32>(a, st);
+    case 8: return gemm_launch_t<EPI, 1, 1, 16>(a, st);
+    default: return gemm_launch_t<EPI, 1, 1, 32>(a, st);
+    }
+}
+
+}  // namespace
+
+// C[P,N] (+)= X[P,K] W[N,K]^T with the chosen epilogue; K % 4 == 0, 16-byte aligned rows
+hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w, float *out, int ldo,
+                               int P, int N, int K, int pos0, const float2 *rope, int head_size,
+                               hipStream_t st)
+{
+    if (P <= 0 || N <= 0 || K <= 0 || (K % 4) != 0 || (ldx % 4) != 0) return hipErrorInvalidValue;
+    if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return hipErrorInvalidValue;
+    GemmArgs a = {x, w, out, P, N, K, ldx, ldo, pos0, rope, head_size};
+    switch (epi) {
+        case G_STORE: return gemm_launch<G_STORE>(a, st);
+        case G_RESID: return gemm_launch<G_RESID>(a, st);
+        case G_ROPE: return gemm_launch<G_ROPE>(a, st);
+        case G_ROPE_CACHE: return gemm_launch<G_ROPE_CACHE>(a, st);
+        case G_CACHE: return gemm_launch<G_CACHE>(a, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_prefill_rmsnorm(float *o, const float *x, const float *w, int n, int P,
+                                  hipStream_t st)
+{
+    hipLaunchKernelGGL(prefill_rmsnorm, dim3(P), dim3(kPfBlock), 0, st, o, x, w, n, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_prefill_swiglu(float *hb, const float *h1, const float *h3, size_t count,
+                                 hipStream_t st)
+{
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(prefill_swiglu, dim3((unsigned)blocks), dim3(256), 0, st, hb, h1, h3, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_prefill_embed(float *x, const float *tok_emb, const int *tokens, int dim, int P,
+                                hipStream_t st)
+{
+    hipLaunchKernelGGL(prefill_embed, dim3(P), dim3(256), 0, st, x, tok_emb, tokens, dim);
+    return hipGetLastError();
+}
+
+hipError_t launch_prefill_attention(const float *q, int ldq, const float *kcache, const float *vcache,
+                                    float *out, int ldo, int pos0, int P, int n_heads, int head_size,
+                                    int kv_dim, int kv_mul, int seq_len, hipStream_t st)
+{
+    int E = head_size >> 2, TPR = 1;
+    while (TPR < E && TPR < 64) TPR <<= 1;
+    const int G = kPfBlock / TPR;
+    const size_t lds = (size_t)(((seq_len + 3) & ~3) + G * head_size + 8) * sizeof(float);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(prefill_attention),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(prefill_attention, dim3(n_heads, P), dim3(kPfBlock), lds, st, q, ldq, kcache,
+                       vcache, out, ldo, pos0, head_size, kv_dim, kv_mul, seq_len);
+    return hipGetLastError();
+}
+
+}  // namespace l2z

@@ -233,8 +233,14 @@ int main(int argc, char **argv)
         std::vector<int32_t> chunk(64);
         bool alive = true;
         while (alive && pos < seq_len) {
-            // first token alone so the clock starts where the reference starts it
-            const int want = pos == 0 ? 1 : (int)std::min<size_t>(chunk.size(), seq_len - pos);
+            // first token alone so the clock starts where the reference starts it; a prompt of
+            // L2Z_PREFILL_MIN_PROMPT tokens or more is asked for in one call so that the library
+            // runs its positions as one batched pass (they then print in a burst)
+            int want = pos == 0 ? 1 : (int)std::min<size_t>(chunk.size(), seq_len - pos);
+            if (pos == 0 && prompt_len >= L2Z_PREFILL_MIN_PROMPT && prompt_len <= seq_len) {
+                want = (int)prompt_len;
+                chunk.resize(std::max(chunk.size(), prompt_len));
+            }
             int got = 0;
             if (l2z_greedy_run(&cfg, s, w, want, chunk.data(), &got) != L2Z_OK) return die("greedy_run");
             if (got == 0) break;

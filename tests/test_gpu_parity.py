@@ -410,3 +410,107 @@ def test_greedy_loop_edges(gpu, ck, orc):
     assert one == ref.tolist()
     assert s.greedy_run(w, 0).size == 0
     s.close(); w.close(); m.close()
+
+
+# ---------------------------------------------------------------- batched prefill (MFMA GEMM)
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_prompt", [3, 4, 21, 70])
+def test_greedy_prompt_through_prefill(gpu, ck, n_prompt):
+    """l2z_greedy_run with a prompt (batched pass over the prompt positions when it has >= 4
+    tokens) produces the tokens of the stepped loop: prompt echoed, then argmax (main.zig:995-1036).
+    A differing token is accepted only at a near tie of the stepped path's top two logits."""
+    cfg = ck.Config(dim=64, hidden_dim=172, n_layers=3, n_heads=4, n_kv_heads=2, vocab_size=512, seq_len=128)
+    blob = ck.synth_blob(cfg, False, seed=17)
+    w = gpu.Weights(cfg, blob, False)
+    s1, s2 = gpu.RunState(cfg), gpu.RunState(cfg)
+    prompt = np.random.default_rng(3).integers(2, cfg.vocab_size, n_prompt).tolist()
+    n_steps = 100
+    s2.greedy_begin(prompt)
+    got = s2.greedy_run(w, n_steps).tolist()
+    token, want = 1, []
+    for pos in range(n_steps):
+        s1.transformer(token, pos, w)
+        if pos < n_prompt:
+            nxt = prompt[pos]
+        else:
+            nxt = s1.argmax()
+            if len(got) > pos and got[pos] != nxt:
+                lg = np.sort(s1.logits())
+                assert lg[-1] - lg[-2] < 1e-4, f"pos {pos}: {got[pos]} vs {nxt}, margin {lg[-1]-lg[-2]}"
+                break
+        want.append(nxt)
+        if nxt == 1:
+            break
+        token = nxt
+    assert got[: len(want)] == want
+    assert got[:n_prompt] == prompt
+    # a first call shorter than the prompt keeps the stepped loop and gives the same tokens
+    s2.greedy_begin(prompt)
+    a = s2.greedy_run(w, 2).tolist() + s2.greedy_run(w, n_steps - 2).tolist()
+    assert a[: len(want)] == want
+    for o in (s1, s2, w):
+        o.close()
+
+
+
+PREFILL_CONFIGS = [
+    ("toy-gqa", dict(dim=64, hidden_dim=172, n_layers=2, n_heads=4, n_kv_heads=2, vocab_size=512, seq_len=96), False),
+    ("toy-mqa", dict(dim=96, hidden_dim=256, n_layers=2, n_heads=6, n_kv_heads=1, vocab_size=1000, seq_len=80), True),
+    ("stories15M-shape-2layers", dict(dim=288, hidden_dim=768, n_layers=2, n_heads=6, n_kv_heads=6, vocab_size=32000, seq_len=300), True),
+]
+
+
+@pytest.mark.parametrize("name,kw,shared", PREFILL_CONFIGS, ids=[c[0] for c in PREFILL_CONFIGS])
+def test_prefill_equals_token_by_token(gpu, ck, orc, name, kw, shared):
+    """l2z_prefill(tokens, pos0) leaves the KV cache and the last position's logits as n calls
+    of l2z_transformer do (within the logit tolerance: the GEMM sums in MFMA k-order), also
+    when it continues an existing context (pos0 > 0) and spans more than one 256-token chunk."""
+    cfg = ck.Config(**kw)
+    blob = ck.synth_blob(cfg, shared, seed=91)
+    w = gpu.Weights(cfg, blob, shared)
+    s1, s2 = gpu.RunState(cfg), gpu.RunState(cfg)
+    rng = np.random.default_rng(9)
+    n_total = min(cfg.seq_len - 4, 290)
+    toks = [1] + rng.integers(2, cfg.vocab_size, n_total - 1).tolist()
+    for pos, t in enumerate(toks):
+        s1.transformer(t, pos, w)
+    ref_logits = s1.logits()
+    split = 7  # first 7 tokens one call, the rest a second call (pos0 > 0)
+    s2.prefill(toks[:split], 0, w)
+    s2.prefill(toks[split:], split, w)
+    got = s2.logits()
+    np.testing.assert_allclose(got, ref_logits, rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
+    assert s2.argmax() == s1.argmax()
+    kvd, S = cfg.kv_dim, cfg.seq_len
+    for l in range(cfg.n_layers):
+        for name_ in ("key_cache", "value_cache"):
+            a = s1.read(name_, l * S * kvd, n_total * kvd)
+            b = s2.read(name_, l * S * kvd, n_total * kvd)
+            np.testing.assert_allclose(b, a, rtol=2e-4, atol=2e-4)
+    # decoding continues from the prefilled state exactly like from the stepped one
+    nxt = s1.argmax()
+    s1.transformer(nxt, n_total, w); s2.transformer(nxt, n_total, w)
+    np.testing.assert_allclose(s2.logits(), s1.logits(), rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
+    # and against the CPU oracle
+    m = orc.Model(cfg.as_i32(), blob, shared)
+    for pos, t in enumerate(toks[:24]):
+        ref = m.transformer(t, pos)
+    s3 = gpu.RunState(cfg)
+    s3.prefill(toks[:24], 0, w)
+    np.testing.assert_allclose(s3.logits(), ref, rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
+    m.close()
+    # every tile path: 16x16x4 skinny kernel with 1, 2, 4 token tiles (n <= 16, 32, 64), the
+    # 64x64 LDS-tiled GEMM beyond, partial tiles on both sides of each boundary
+    for n in (1, 2, 15, 16, 17, 32, 33, 50, 64, 65, min(79, n_total)):
+        for pos, t in enumerate(toks[:n]):
+            s1.transformer(t, pos, w)
+        s3.prefill(toks[:n], 0, w)
+        np.testing.assert_allclose(s3.logits(), s1.logits(), rtol=LOGIT_RTOL, atol=LOGIT_ATOL,
+                                   err_msg=f"n={n}")
+        for l in range(cfg.n_layers):
+            for name_ in ("key_cache", "value_cache"):
+                a = s1.read(name_, l * S * kvd, n * kvd)
+                b = s3.read(name_, l * S * kvd, n * kvd)
+                np.testing.assert_allclose(b, a, rtol=2e-4, atol=2e-4, err_msg=f"n={n} {name_} l={l}")
+    for o in (s1, s2, s3, w):
+        o.close()
