@@ -140,7 +140,7 @@ int l2z_greedy_run(const l2z_config *config, l2z_runstate *s, const l2z_weights 
  * Same state change as l2z_transformer(tokens[i], pos0 + i) for i = 0 .. n_tokens-1 -- the
  * KV-cache rows pos0 .. pos0+n_tokens-1 of every layer are written and the logits of the LAST
  * position are left in the runstate (l2z_argmax / l2z_logits_read) -- but each weight matrix is
- * streamed once per chunk of up to 256 tokens and multiplied as a dense GEMM on the fp32 matrix
+ * streamed once per chunk of up to 512 tokens and multiplied as a dense GEMM on the fp32 matrix
  * cores (v_mfma_f32_32x32x2_f32).  Values agree with the token-by-token path up to summation
  * order.  Single-GPU runstates only; dims must be multiples of 4 (else L2Z_ERR_INVALID, and the
  * caller loops over l2z_transformer).

@@ -807,7 +807,18 @@ extern "C" int l2z_synchronize(l2z_runstate *s)
 // every layer, logits of the LAST position left in the runstate -- but every weight matrix is
 // streamed once per chunk of up to kPrefillChunk tokens and multiplied on the fp32 matrix cores.
 namespace {
-constexpr int kPrefillChunk = 256;
+static int prefill_chunk_tokens()
+{
+    static int n = 0;
+    if (n == 0) {
+        const char *e = getenv("L2Z_PF_CHUNK");
+        n = e ? atoi(e) : 512;
+        if (n < 16) n = 16;
+        if (n > 2048) n = 2048;
+    }
+    return n;
+}
+#define kPrefillChunk prefill_chunk_tokens()
 
 int prefill_alloc(l2z_runstate *s)
 {

@@ -24,6 +24,9 @@ namespace {
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
+#ifndef L2Z_DBG_GEMM
+#define L2Z_DBG_GEMM 0  // timing experiments only: 1 no global loads, 2 no LDS writes, 4 no LDS reads, 8 no barrier
+#endif
 constexpr int kPfBlock = 256;
 
 enum GemmEpi { G_STORE = 0, G_RESID = 1, G_ROPE = 2, G_ROPE_CACHE = 3, G_CACHE = 4 };
@@ -43,52 +46,59 @@ struct GemmArgs {
 //   A operand: lane l holds A[i = l & 31][k = l >> 5]      -> X[token i][k]
 //   B operand: lane l holds B[k = l >> 5][j = l & 31]      -> W[feature j][k]
 //   D: lane l, reg r holds D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31]
-// Global loads of stage s+1 are issued before the MFMAs of stage s (register staged), weights
-// non-temporal.  (TM,TN) = (2,2): 128 x 128 tile, 32 flop per byte staged -- for long prompts;
-// (1,1): 64 x 64, twice the blocks -- for short ones, which are bound by weight streaming.
-template <int EPI, int TM, int TN, int BK>
-__global__ __launch_bounds__(kPfBlock) void prefill_gemm(const GemmArgs a)
+// KS groups of 4 waves split each stage's k range (two waves per SIMD at KS = 2) and are summed
+// through LDS at the end.  Stages are double buffered in LDS (see the loop), weights non-temporal.
+template <int EPI, int TM, int TN, int BK, int KS>
+__global__ __launch_bounds__(256 * KS) void prefill_gemm(const GemmArgs a)
 {
     constexpr int LDK = BK + 1;  // padded row: 32 rows hit 32 distinct banks
     constexpr int RF = BK / 4;   // float4 per tile row
     constexpr int BMt = 64 * TM, BNt = 64 * TN;
-    constexpr int XL = BMt * BK / 4 / kPfBlock, WL = BNt * BK / 4 / kPfBlock;  // float4 per thread
+    constexpr int NT = 256 * KS;  // KS groups of 4 waves; group g multiplies its 1/KS of each stage's k
+    constexpr int XL = BMt * BK / 4 / NT, WL = BNt * BK / 4 / NT;  // float4 per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *xs = smem, *ws = smem + BMt * LDK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = (wave >> 1) & 1, wn = wave & 1, kg = wave >> 2;
     const int n0 = blockIdx.x * BNt, m0 = blockIdx.y * BMt;
     const v4f zero = {0.f, 0.f, 0.f, 0.f};
     // float4 slot f of a tile: row f / 8, columns 4 (f % 8)
     v4f xv[XL], wv[WL];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < XL; i++) {
-            const int f = tid + kPfBlock * i, r = f / RF, c = (f % RF) * 4;
-            const bool ok = m0 + r < a.P && k0 + c < a.K;  // K % 4 == 0: a float4 is all in or out
-            xv[i] = ok ? *(const v4f *)(a.x + (size_t)(m0 + r) * a.ldx + k0 + c) : zero;
-        }
-#pragma unroll
-        for (int i = 0; i < WL; i++) {
-            const int f = tid + kPfBlock * i, r = f / RF, c = (f % RF) * 4;
-            const bool ok = n0 + r < a.N && k0 + c < a.K;
-            wv[i] = ok ? __builtin_nontemporal_load((const v4f *)(a.w + (size_t)(n0 + r) * a.K + k0 + c))
-                       : zero;
+    // clamped addresses: every load is legal, out-of-range values are zeroed when the stage is
+    // written to LDS (a select right after the load would wait for it)
+    // piece p < XL: float4 p of the X tile; p >= XL: float4 p - XL of the W tile
+    auto gload_piece = [&](int p, int k0) {
+        if (p < XL) {
+            const int f = tid + NT * p, r = f / RF, c = (f % RF) * 4;
+            xv[p] = *(const v4f *)(a.x + (size_t)min(m0 + r, a.P - 1) * a.ldx + min(k0 + c, a.K - 4));
+        } else {
+            const int f = tid + NT * (p - XL), r = f / RF, c = (f % RF) * 4;
+            wv[p - XL] = __builtin_nontemporal_load(
+                (const v4f *)(a.w + (size_t)min(n0 + r, a.N - 1) * a.K + min(k0 + c, a.K - 4)));
         }
     };
-    auto sstore = [&]() {
-#pragma unroll
-        for (int i = 0; i < XL; i++) {
-            const int f = tid + kPfBlock * i;
-            float *d = xs + (f / RF) * LDK + (f % RF) * 4;
-            d[0] = xv[i].x; d[1] = xv[i].y; d[2] = xv[i].z; d[3] = xv[i].w;
+    auto sstore_piece = [&](int p, int k0) {
+        if (p < XL) {
+            const int f = tid + NT * p, r = f / RF, c = (f % RF) * 4;
+            const bool ok = m0 + r < a.P && k0 + c < a.K;  // K % 4 == 0: a float4 is all in or out
+            const v4f v = ok ? xv[p] : zero;
+            float *d = xs + r * LDK + c;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        } else {
+            const int f = tid + NT * (p - XL), r = f / RF, c = (f % RF) * 4;
+            const bool ok = n0 + r < a.N && k0 + c < a.K;
+            const v4f v = ok ? wv[p - XL] : zero;
+            float *d = ws + r * LDK + c;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
+    };
+    auto gload = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < WL; i++) {
-            const int f = tid + kPfBlock * i;
-            float *d = ws + (f / RF) * LDK + (f % RF) * 4;
-            d[0] = wv[i].x; d[1] = wv[i].y; d[2] = wv[i].z; d[3] = wv[i].w;
-        }
+        for (int p = 0; p < XL + WL; p++) gload_piece(p, k0);
+    };
+    auto sstore = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < XL + WL; p++) sstore_piece(p, k0);
     };
     v16f acc[TM][TN];
 #pragma unroll
@@ -97,27 +107,89 @@ __global__ __launch_bounds__(kPfBlock) void prefill_gemm(const GemmArgs a)
         for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
-    const int arow = (wm * 32 * TM + (lane & 31)) * LDK + (lane >> 5);
-    const int brow = (wn * 32 * TN + (lane & 31)) * LDK + (lane >> 5);
+    // MFMA step t of a stage multiplies the k pair (t, t + BK/2): lanes 32..63 then read LDS banks
+    // 32 away from lanes 0..31 (row stride BK+1 words), conflict-free; (t, t+1) collides 2-way
+    const int arow = (wm * 32 * TM + (lane & 31)) * LDK + (lane >> 5) * (BK / 2);
+    const int brow = (wn * 32 * TN + (lane & 31)) * LDK + (lane >> 5) * (BK / 2);
+    // two LDS buffers: stage s+1 is written (from registers) and stage s+2 requested from HBM
+    // before stage s is multiplied; one barrier per stage
+    constexpr int STAGE = (BMt + BNt) * LDK;
     gload(0);
+    sstore(0);
+    if (BK < a.K) gload(BK);
+    __syncthreads();
+    int buf = 0;
+    constexpr int STEPS = BK / 2 / KS;  // MFMA steps of this wave group per stage
+    constexpr int PIECES = XL + WL;     // float4 per thread per stage
+    constexpr int AH = 3;               // LDS operand reads run this many MFMA steps ahead
     for (int k0 = 0; k0 < a.K; k0 += BK) {
-        __syncthreads();  // previous stage fully consumed
-        sstore();
-        __syncthreads();
-        if (k0 + BK < a.K) gload(k0 + BK);  // flies while this stage is multiplied
+        // Stage s is multiplied while stage s+1 goes from registers into the other LDS buffer and
+        // stage s+2 is requested from HBM into the registers just freed -- piece by piece between
+        // the MFMA steps: LDS operations keep their program order, so the interleaving has to be
+        // in the source.  (Copy first, then all MFMAs, costs a fifth of the run time: one wave per
+        // SIMD, and the barrier puts all waves in the same phase.)  No branch in the body: the
+        // last stages store / load clamped data nobody reads.
+        xs = smem + (buf ^ 1) * STAGE; ws = xs + BMt * LDK;
+        const float *xr = smem + buf * STAGE, *wr = xr + BMt * LDK;
+        float av[STEPS][TM], bv[STEPS][TN];
+        auto lds_read = [&](int t) {
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float av[TM], bv[TN];
+            for (int i = 0; i < TM; i++) av[t][i] = xr[arow + i * 32 * LDK + kg * STEPS + t];
 #pragma unroll
-            for (int i = 0; i < TM; i++) av[i] = xs[arow + i * 32 * LDK + kk];
+            for (int j = 0; j < TN; j++) bv[t][j] = wr[brow + j * 32 * LDK + kg * STEPS + t];
+        };
 #pragma unroll
-            for (int j = 0; j < TN; j++) bv[j] = ws[brow + j * 32 * LDK + kk];
+        for (int t = 0; t < AH && t < STEPS; t++) lds_read(t);
+#pragma unroll
+        for (int t = 0; t < STEPS; t++) {
+            if (t + AH < STEPS) lds_read(t + AH);
+#pragma unroll
+            for (int p = (t * PIECES) / STEPS; p < ((t + 1) * PIECES) / STEPS; p++) {
+#if !(L2Z_DBG_GEMM & 2)
+                sstore_piece(p, k0 + BK);
+#endif
+#if !(L2Z_DBG_GEMM & 1)
+                gload_piece(p, k0 + 2 * BK);
+#endif
+            }
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][i], bv[t][j], acc[i][j], 0, 0, 0);
+            // pin the step: the scheduler otherwise gathers all selects (and their vmcnt waits) at
+            // the top of the stage and sinks the global loads to its end
+            __builtin_amdgcn_sched_barrier(0);
         }
+#if !(L2Z_DBG_GEMM & 8)
+        __syncthreads();
+#endif
+        buf ^= 1;
+    }
+    if (KS > 1) {
+        // partial sums of wave groups 1.. -> LDS -> added by group 0 in group order (the last
+        // barrier of the loop has already retired every read of the stage buffers)
+        float *red = smem;  // [KS-1][4 waves][TM*TN*16][64 lanes]
+        if (kg > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        red[((((kg - 1) * 4 + (wave & 3)) * TM * TN + i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (kg > 0) return;
+#pragma unroll
+        for (int g = 1; g < KS; g++)
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        acc[i][j][r] += red[((((g - 1) * 4 + wave) * TM * TN + i * TN + j) * 16 + r) * 64 + lane];
     }
     // epilogue: per MFMA tile this lane owns one feature and 16 tokens
 #pragma unroll
@@ -345,19 +417,23 @@ __global__ __launch_bounds__(kPfBlock) void prefill_attention(const float *q, in
     }
 }
 
-template <int EPI, int TM, int TN, int BK>
+template <int EPI, int TM, int TN, int BK, int KS>
 hipError_t gemm_launch_t(const GemmArgs &a, hipStream_t st)
 {
     constexpr int BMt = 64 * TM, BNt = 64 * TN;
-    const size_t lds = (size_t)(BMt + BNt) * (BK + 1) * sizeof(float);
+    static_assert((BMt * BK / 4) % (256 * KS) == 0 && (BNt * BK / 4) % (256 * KS) == 0, "tile copy");
+    static_assert((BK / 2) % KS == 0 && ((BK / 2 / KS) % 8 == 0 || BK / 2 / KS < 8), "k steps");
+    size_t lds = 2 * (size_t)(BMt + BNt) * (BK + 1) * sizeof(float);
+    const size_t red = (size_t)(KS - 1) * 4 * TM * TN * 16 * 64 * sizeof(float);
+    if (red > lds) lds = red;
     static bool attr = false;
     if (!attr && lds > 48 * 1024) {
-        (void)hipFuncSetAttribute((const void *)prefill_gemm<EPI, TM, TN, BK>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)prefill_gemm<EPI, TM, TN, BK, KS>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     dim3 grid((a.N + BNt - 1) / BNt, (a.P + BMt - 1) / BMt);
-    hipLaunchKernelGGL((prefill_gemm<EPI, TM, TN, BK>), grid, dim3(kPfBlock), lds, st, a);
+    hipLaunchKernelGGL((prefill_gemm<EPI, TM, TN, BK, KS>), grid, dim3(256 * KS), lds, st, a);
     return hipGetLastError();
 }
 
@@ -375,7 +451,7 @@ hipError_t gemm_launch(const GemmArgs &a, hipStream_t st)
     static int tile = -1, skinny_max = 64, skinny_tms = 4;
     if (tile < 0) {
         const char *e = getenv("L2Z_PF_TILE");
-        tile = e ? atoi(e) : 1;
+        tile = e ? atoi(e) : 0;
         if (const char *m = getenv("L2Z_PF_SKINNY_MAX")) skinny_max = atoi(m);
         if (const char *m = getenv("L2Z_PF_SKINNY_TMS")) skinny_tms = atoi(m);
     }
@@ -387,17 +463,19 @@ hipError_t gemm_launch(const GemmArgs &a, hipStream_t st)
         if (a.P <= 32 || skinny_tms == 2) return skinny_launch_t<EPI, 2>(a, st);
         return skinny_launch_t<EPI, 4>(a, st);  // more than 64 tokens: grid.y tiles of 64
     }
-    switch (tile) {
-    case 1: return gemm_launch_t<EPI, 1, 1, 64>(a, st);
-    case 2: return gemm_launch_t<EPI, 1, 1, 128>(a, st);
-    case 3: return gemm_launch_t<EPI, 2, 1, 32>(a, st);
-    case 4: return gemm_launch_t<EPI, 2, 1, 64>(a, st);
-    case 5: return gemm_launch_t<EPI, 1, 2, 32>(a, st);
-    case 6: return gemm_launch_t<EPI, 1, 2, 64>(a, st);
-    case 7: return gemm_launch_t<EPI, 2, 2, 32>(a, st);
-    case 8: return gemm_launch_t<EPI, 1, 1, 16>(a, st);
-    default: return gemm_launch_t<EPI, 1, 1, 32>(a, st);
+    switch (tile) {  // L2Z_PF_TILE: experiments
+    case 1: return gemm_launch_t<EPI, 1, 1, 64, 1>(a, st);
+    case 2: return gemm_launch_t<EPI, 1, 1, 64, 2>(a, st);
+    case 3: return gemm_launch_t<EPI, 1, 1, 64, 4>(a, st);
+    case 6: return gemm_launch_t<EPI, 1, 2, 64, 2>(a, st);
+    case 7: return gemm_launch_t<EPI, 2, 2, 32, 2>(a, st);
+    case 8: return gemm_launch_t<EPI, 2, 1, 64, 2>(a, st);
+    default: break;
     }
+    // 64 x 64 tiles fill the 256 CUs from N = 4096 at 256 tokens; beyond that 128 x 64 halves
+    // the LDS operand reads per MFMA (measured on the 7B shape: 94.7 vs 89.5 TFLOP/s at 512)
+    if (a.P > 256) return gemm_launch_t<EPI, 2, 1, 64, 2>(a, st);
+    return gemm_launch_t<EPI, 1, 1, 64, 2>(a, st);
 }
 
 }  // namespace

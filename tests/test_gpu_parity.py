@@ -456,7 +456,7 @@ def test_greedy_prompt_through_prefill(gpu, ck, n_prompt):
 PREFILL_CONFIGS = [
     ("toy-gqa", dict(dim=64, hidden_dim=172, n_layers=2, n_heads=4, n_kv_heads=2, vocab_size=512, seq_len=96), False),
     ("toy-mqa", dict(dim=96, hidden_dim=256, n_layers=2, n_heads=6, n_kv_heads=1, vocab_size=1000, seq_len=80), True),
-    ("stories15M-shape-2layers", dict(dim=288, hidden_dim=768, n_layers=2, n_heads=6, n_kv_heads=6, vocab_size=32000, seq_len=300), True),
+    ("stories15M-shape-2layers", dict(dim=288, hidden_dim=768, n_layers=2, n_heads=6, n_kv_heads=6, vocab_size=32000, seq_len=560), True),
 ]
 
 
@@ -464,13 +464,13 @@ PREFILL_CONFIGS = [
 def test_prefill_equals_token_by_token(gpu, ck, orc, name, kw, shared):
     """l2z_prefill(tokens, pos0) leaves the KV cache and the last position's logits as n calls
     of l2z_transformer do (within the logit tolerance: the GEMM sums in MFMA k-order), also
-    when it continues an existing context (pos0 > 0) and spans more than one 256-token chunk."""
+    when it continues an existing context (pos0 > 0) and spans more than one 512-token chunk."""
     cfg = ck.Config(**kw)
     blob = ck.synth_blob(cfg, shared, seed=91)
     w = gpu.Weights(cfg, blob, shared)
     s1, s2 = gpu.RunState(cfg), gpu.RunState(cfg)
     rng = np.random.default_rng(9)
-    n_total = min(cfg.seq_len - 4, 290)
+    n_total = min(cfg.seq_len - 4, 530)
     toks = [1] + rng.integers(2, cfg.vocab_size, n_total - 1).tolist()
     for pos, t in enumerate(toks):
         s1.transformer(t, pos, w)
