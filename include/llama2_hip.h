@@ -152,6 +152,10 @@ int l2z_prefill(const int32_t *tokens, int n_tokens, int pos0, const l2z_config 
                 l2z_runstate *s, const l2z_weights *w);
 
 /* ---- measurement support ----
+ * l2z_stream_read_probe streams `slice_bytes` pieces of the resident weight blob (0 = all of it)
+ * through a pure read kernel `reps` times, a different piece per launch, and returns the average
+ * and best read rate in GB/s: the measured ceiling bench.py quotes beside the 8 TB/s HBM3E spec
+ * (SURVEY.md 8d "also report against a measured ... on the same box").
  * l2z_profile_forward runs ONE forward pass (+ argmax/hand-over) eagerly with
  * a HIP event pair around every kernel launch, recorded on the runstate's own
  * stream, and returns per-kind total device time (ms) and launch count.
@@ -161,6 +165,8 @@ int l2z_prefill(const int32_t *tokens, int n_tokens, int pos0, const l2z_config 
  * its own weights, so nothing is re-read from cache between launches.  The
  * numbers must agree with rocprofv3 --kernel-trace --stats (profiles/). */
 #define L2Z_N_KINDS 7
+int l2z_stream_read_probe(l2z_runstate *s, const l2z_weights *w, size_t slice_bytes, int reps,
+                          double *avg_gbps, double *best_gbps);
 int l2z_profile_forward(int token, int pos, const l2z_config *config, l2z_runstate *s,
                         const l2z_weights *w, double *ms_by_kind, int *launches_by_kind,
                         int n_kinds);

@@ -78,6 +78,7 @@ def lib():
     L.l2z_greedy_run.argtypes = [cfgp, vp, vp, C.c_int, i32p, ip]
     L.l2z_profile_forward.argtypes = [C.c_int, C.c_int, cfgp, vp, vp, C.POINTER(C.c_double), ip,
                                       C.c_int]
+    L.l2z_stream_read_probe.argtypes = [vp, vp, sz, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.l2z_kind_name.argtypes = [C.c_int, C.c_char_p, sz]
     L.l2z_synchronize.argtypes = [vp]
     L.l2z_matmul.argtypes = [fp, fp, fp, sz, sz]
@@ -249,6 +250,12 @@ class RunState:
         _chk(lib().l2z_profile_forward(token, pos, C.byref(self.cfg), self.h, w.h, ms, cnt,
                                        len(KINDS)))
         return {k: (ms[i], cnt[i]) for i, k in enumerate(KINDS)}
+
+    def stream_read_probe(self, w: Weights, slice_bytes: int = 0, reps: int = 8):
+        """(average, best) GB/s of a pure streaming-read kernel over the resident weight blob."""
+        avg, best = C.c_double(0), C.c_double(0)
+        _chk(lib().l2z_stream_read_probe(self.h, w.h, slice_bytes, reps, C.byref(avg), C.byref(best)))
+        return avg.value, best.value
 
     def synchronize(self) -> None:
         _chk(lib().l2z_synchronize(self.h))

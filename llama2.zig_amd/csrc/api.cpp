@@ -793,6 +793,52 @@ extern "C" int l2z_runstate_read(l2z_runstate *s, const char *name, size_t offse
     return L2Z_OK;
 }
 
+// Measured ceiling for the roofline: stream `slice_bytes`-sized pieces of the resident weight
+// blob through a pure read kernel, a different piece every launch (nothing is re-read from the
+// on-die caches unless the blob itself is that small), HIP events on the runstate's stream.
+extern "C" int l2z_stream_read_probe(l2z_runstate *s, const l2z_weights *w, size_t slice_bytes, int reps,
+                                     double *avg_gbps, double *best_gbps)
+{
+    L2Z_CHECK(s && w && avg_gbps && best_gbps && reps >= 1, L2Z_ERR_INVALID,
+              "l2z_stream_read_probe: bad arguments");
+    L2Z_HIP(hipSetDevice(s->device));
+    const size_t blob_bytes = w->blob_floats * sizeof(float);
+    if (slice_bytes == 0 || slice_bytes > blob_bytes) slice_bytes = blob_bytes;
+    slice_bytes &= ~(size_t)4095;
+    L2Z_CHECK(slice_bytes >= (1u << 20), L2Z_ERR_INVALID, "l2z_stream_read_probe: blob too small");
+    const size_t n_slices = blob_bytes / slice_bytes;
+    hipEvent_t e0, e1;
+    L2Z_HIP(hipEventCreate(&e0));
+    L2Z_HIP(hipEventCreate(&e1));
+    double tot = 0.0, best = 1e30;
+    int rc = L2Z_OK;
+    for (int r = 0; r < reps + 2 && rc == L2Z_OK; r++) {  // two untimed warm-ups
+        const float *p = w->blob + (size_t)(r % n_slices) * (slice_bytes / sizeof(float));
+        hipError_t e = hipEventRecord(e0, s->stream);
+        // d_part_val has one float per possible mat-vec block (8 per CU): the probe's scratch
+        if (e == hipSuccess) e = launch_stream_read(p, slice_bytes / sizeof(float), s->d_part_val, g_cus, s->stream);
+        if (e == hipSuccess) e = hipEventRecord(e1, s->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) {
+            set_error("l2z_stream_read_probe: %s", hipGetErrorString(e));
+            rc = L2Z_ERR_HIP;
+            break;
+        }
+        if (r >= 2) {
+            tot += ms;
+            if (ms < best) best = ms;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != L2Z_OK) return rc;
+    *avg_gbps = (double)slice_bytes / (tot / reps * 1e-3) / 1e9;
+    *best_gbps = (double)slice_bytes / (best * 1e-3) / 1e9;
+    return L2Z_OK;
+}
+
 extern "C" int l2z_synchronize(l2z_runstate *s)
 {
     L2Z_CHECK(s != nullptr, L2Z_ERR_INVALID, "l2z_synchronize: null runstate");

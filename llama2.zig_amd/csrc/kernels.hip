@@ -1389,6 +1389,26 @@ MvLaunch mv_pick_pe(int pro, int epi, int lpr, bool big_x, bool vec)
     return {nullptr, 0, 0};
 }
 
+// Pure streaming read (non-temporal float4 loads, 8 in flight per lane, sum kept out of DCE's
+// reach): the rate the memory system gives a kernel that does nothing else -- the measured
+// ceiling the mat-vec GB/s are quoted against beside the 8 TB/s spec (bench.py roofline).
+__global__ __launch_bounds__(256) void stream_read_kernel(const v4f *__restrict__ p, size_t n4, float *out)
+{
+    constexpr int U = 8;
+    size_t i = (size_t)blockIdx.x * 256 * U + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256 * U;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (; i + 256 * (U - 1) < n4; i += stride) {
+        v4f r[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) r[k] = ldg_nt(p + i + 256 * k);
+#pragma unroll
+        for (int k = 0; k < U; k++) acc += r[k];
+    }
+    const float s = (acc.x + acc.y) + (acc.z + acc.w);
+    if (s == 123.456f) out[blockIdx.x] = s;
+}
+
 }  // namespace
 
 // upper bound over every instantiation (n4 padded to whole batches of <= 384 float4)
@@ -1407,6 +1427,12 @@ size_t attention_lds_bytes(int head_size, int seq_len, bool vec)
 }
 
 int matvec_max_grid(int n_cus) { return n_cus * 8; }
+
+hipError_t launch_stream_read(const float *p, size_t n_floats, float *out, int n_cus, hipStream_t st)
+{
+    hipLaunchKernelGGL(stream_read_kernel, dim3(n_cus * 8), dim3(256), 0, st, (const v4f *)p, n_floats / 4, out);
+    return hipGetLastError();
+}
 
 hipError_t launch_matvec(const MatvecArgs &a, int pro, int epi, int max_blocks_per_cu, int n_cus,
                          hipStream_t st, int *out_grid)

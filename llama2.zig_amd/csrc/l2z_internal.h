@@ -112,7 +112,9 @@ struct ArgmaxArgs {
 // Launchers (kernels.hip).  All return a hipError_t from the launch.
 hipError_t launch_matvec(const MatvecArgs &a, int pro, int epi, int max_blocks_per_cu, int n_cus,
                          hipStream_t st, int *out_grid = nullptr);
-int matvec_max_grid(int n_cus);  // upper bound of the grid launch_matvec picks
+int matvec_max_grid(int n_cus);
+// out: >= 8 * n_cus floats of scratch (never written in practice)
+hipError_t launch_stream_read(const float *p, size_t n_floats, float *out, int n_cus, hipStream_t st);  // upper bound of the grid launch_matvec picks
 hipError_t launch_attention(const AttnArgs &a, int n_heads_local, hipStream_t st);
 // flash-decoding form: `nch` blocks per head + a combine launch (kernels.hip)
 int attention_split_chunks(int n_heads_local, int n_cus);
