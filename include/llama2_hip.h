@@ -185,14 +185,24 @@ int l2z_vector_weighted_sum_rows(float *xout, size_t xout_len, const float *rows
                                  size_t row_stride, const float *weights, size_t n_weights); /* :657 */
 int l2z_argmax_host(const float *x, size_t n, size_t *out_index);                      /* :715 */
 
-/* ---- multi-GPU shard group: one process per GPU, RCCL over xGMI ----
+/* ---- multi-GPU shard group: one process per GPU, xGMI ----
  * The reference is single-threaded and single-device; this is what the build
- * adds.  id is an opaque 128-byte ncclUniqueId made on rank 0
- * and distributed by the launcher (bench.py uses torch.distributed for that).
+ * adds.  Two transports for the per-layer all-gathers:
+ *  - RCCL: id is an opaque 128-byte ncclUniqueId made on rank 0 and distributed by the launcher
+ *    (bench.py uses torch.distributed/gloo for that);
+ *  - peer writes: l2z_comm_init(rank, world, NULL, device, &c), then every rank exports the IPC
+ *    handle of its landing arena (l2z_comm_p2p_export), the launcher all-gathers the 64-byte
+ *    handles in rank order, and l2z_comm_p2p_connect maps the peers.  A gather is then one small
+ *    kernel of direct stores into the peers' memory plus flags -- no collective library, and it
+ *    can be captured in the step graph.  Preferred when both are set up (L2Z_COMM=rccl overrides).
  */
 #define L2Z_COMM_ID_BYTES 128
 int l2z_comm_unique_id(void *out_id);
 int l2z_comm_init(int rank, int world, const void *id, int device, l2z_comm **out);
+#define L2Z_COMM_IPC_BYTES 64
+/* max_vector_floats: the longest vector that will be gathered = max(dim, hidden_dim, vocab_size) */
+int l2z_comm_p2p_export(l2z_comm *c, size_t max_vector_floats, void *handle_out);
+int l2z_comm_p2p_connect(l2z_comm *c, const void *handles /* world x L2Z_COMM_IPC_BYTES */);
 int l2z_comm_rank(const l2z_comm *c, int *rank, int *world);
 void l2z_comm_free(l2z_comm *c);
 /* Testing support: N emulated ranks in ONE process on ONE GPU (RCCL refuses two ranks on

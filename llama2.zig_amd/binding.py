@@ -19,6 +19,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "llama2_hip.h")
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_COMM, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
 COMM_ID_BYTES = 128
+COMM_IPC_BYTES = 64
 KINDS = ["qkv", "attn", "wo", "ffn13", "ffn2", "cls", "argmax"]
 
 
@@ -90,6 +91,8 @@ def lib():
     L.l2z_argmax_host.argtypes = [fp, sz, C.POINTER(sz)]
     L.l2z_comm_unique_id.argtypes = [vp]
     L.l2z_comm_init.argtypes = [C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp)]
+    L.l2z_comm_p2p_export.argtypes = [vp, sz, vp]
+    L.l2z_comm_p2p_connect.argtypes = [vp, vp]
     L.l2z_comm_rank.argtypes = [vp, ip, ip]
     L.l2z_comm_free.argtypes = [vp]
     L.l2z_comm_free.restype = None
@@ -152,6 +155,18 @@ class Comm:
             buf = C.create_string_buffer(uid, COMM_ID_BYTES) if uid is not None else None
             _chk(lib().l2z_comm_init(rank, world, buf, device, C.byref(self.h)))
         self.rank, self.world = rank, world
+
+    def p2p_export(self, max_vector_floats: int) -> bytes:
+        """Allocate this rank's landing arena; returns its 64-byte IPC handle (to be all-gathered)."""
+        buf = C.create_string_buffer(COMM_IPC_BYTES)
+        _chk(lib().l2z_comm_p2p_export(self.h, max_vector_floats, buf))
+        return buf.raw
+
+    def p2p_connect(self, handles: bytes) -> None:
+        """handles: every rank's p2p_export() result concatenated in rank order."""
+        assert len(handles) == COMM_IPC_BYTES * self.world
+        buf = C.create_string_buffer(handles, len(handles))
+        _chk(lib().l2z_comm_p2p_connect(self.h, buf))
 
     @staticmethod
     def unique_id() -> bytes:

@@ -428,12 +428,12 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
         if (v > 0) s->max_blocks = v;
     }
     if (const char *e = getenv("L2Z_NO_GRAPH")) s->use_graphs = atoi(e) == 0;
-    // With a communicator the launches and RCCL calls go out eagerly by default: at N > 1 a
-    // step is bound by the ~130 small collectives on the GPU, not by host launch cost, and
-    // multi-rank capture could not be exercised on the 1-GPU dev box.  L2Z_COMM_GRAPH=1
-    // captures the collectives into the step graph (works with a 1-rank communicator).
-    if (comm && comm->world > 1 && !comm->nccl) s->use_graphs = false;  // emulated ranks
-    if (comm && comm->nccl) {
+    // Peer-write gathers are plain kernels: captured with the rest of the step.  With RCCL only,
+    // the launches and collectives go out eagerly by default (multi-rank capture of RCCL calls
+    // could not be exercised on the 1-GPU dev box); L2Z_COMM_GRAPH=1 captures them too (works
+    // with a 1-rank communicator).  Emulated ranks are driven stage by stage, never captured.
+    if (comm && comm->world > 1 && !comm->nccl && !comm->p2p) s->use_graphs = false;
+    if (comm && comm->nccl && !comm->p2p) {
         const char *e = getenv("L2Z_COMM_GRAPH");
         s->use_graphs = e && atoi(e) == 1;
     }
@@ -719,6 +719,10 @@ int ensure_graphs(l2z_runstate *s, const l2z_weights *w)
 int run_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, int pos)
 {
     const bool split = use_split(s, pos);
+    L2Z_CHECK(s->sh.world == 1 || (s->comm && (s->comm->nccl || s->comm->p2p)), L2Z_ERR_STATE,
+              "sharded runstate without a transport: connect the group (RCCL id or "
+              "l2z_comm_p2p_export/_connect), or drive emulated ranks with l2z_emu_transformer");
+    L2Z_TRY(comm_check(s->comm));
     L2Z_TRY(ensure_graphs(s, w));
     if (s->use_graphs) {
         const int v = split ? 1 : 0;
@@ -766,6 +770,7 @@ extern "C" int l2z_logits_read(l2z_runstate *s, float *out_logits)
     L2Z_HIP(hipMemcpyAsync(out_logits, s->logits, (size_t)s->cfg.vocab_size * sizeof(float),
                            hipMemcpyDeviceToHost, s->stream));
     L2Z_HIP(hipStreamSynchronize(s->stream));
+    L2Z_TRY(comm_check(s->comm));
     return L2Z_OK;
 }
 
@@ -844,6 +849,7 @@ extern "C" int l2z_synchronize(l2z_runstate *s)
     L2Z_CHECK(s != nullptr, L2Z_ERR_INVALID, "l2z_synchronize: null runstate");
     L2Z_HIP(hipSetDevice(s->device));
     L2Z_HIP(hipStreamSynchronize(s->stream));
+    L2Z_TRY(comm_check(s->comm));
     return L2Z_OK;
 }
 
@@ -1057,6 +1063,7 @@ extern "C" int l2z_greedy_run(const l2z_config *config, l2z_runstate *s, const l
         L2Z_HIP(hipMemcpyAsync(out_tokens + produced, s->d_out_tokens + s->host_pos,
                                (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s->stream));
         L2Z_HIP(hipStreamSynchronize(s->stream));
+        L2Z_TRY(comm_check(s->comm));
         int got = n;
         for (int i = 0; i < n; i++) {
             if (out_tokens[produced + i] == 1) {  // BOS ends the sequence

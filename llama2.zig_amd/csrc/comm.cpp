@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "l2z_comm.h"
@@ -50,8 +51,34 @@ int load_rccl()
 }
 }  // namespace
 
+int comm_check(const l2z_comm *c)
+{
+    if (c && c->h_err && *(volatile int *)c->h_err != 0) {
+        set_error("peer-write all-gather timed out waiting for rank %d (peer gone or call sequences differ)",
+                  *(volatile int *)c->h_err - 1);
+        return L2Z_ERR_COMM;
+    }
+    return L2Z_OK;
+}
+
 int comm_allgather_inplace(const l2z_comm *c, float *buf, size_t count_per_rank, hipStream_t st)
 {
+    static const bool prefer_rccl = getenv("L2Z_COMM") && std::strcmp(getenv("L2Z_COMM"), "rccl") == 0;
+    if (c != nullptr && c->p2p && c->world > 1 && !(prefer_rccl && c->nccl)) {
+        L2Z_CHECK(count_per_rank * (size_t)c->world <= c->slot_floats, L2Z_ERR_COMM,
+                  "peer-write gather of %zu floats exceeds the landing slot (%zu)",
+                  count_per_rank * (size_t)c->world, c->slot_floats);
+        P2pArgs a = {};
+        a.buf = buf; a.count = count_per_rank; a.rank = c->rank; a.world = c->world;
+        a.slot_floats = c->slot_floats;
+        for (int r = 0; r < c->world; r++) a.peer_arena[r] = c->peer_arena[r];
+        a.epoch = c->d_epoch; a.err = c->h_err;
+        static const long long timeout_s = getenv("L2Z_P2P_TIMEOUT_S") ? atoll(getenv("L2Z_P2P_TIMEOUT_S")) : 20;
+        a.timeout_ticks = timeout_s * 100000000LL;
+        hipError_t e = launch_p2p_allgather(a, st);
+        L2Z_CHECK(e == hipSuccess, L2Z_ERR_HIP, "peer-write gather launch failed: %s", hipGetErrorString(e));
+        return L2Z_OK;
+    }
     if (c == nullptr || c->nccl == nullptr) return L2Z_OK;  // single GPU without a communicator
     // in-place form: sendbuff == recvbuff + rank * count
     ncclResult_t r = g_api.AllGather(buf + (size_t)c->rank * count_per_rank, buf, count_per_rank,
@@ -88,12 +115,9 @@ extern "C" int l2z_comm_init(int rank, int world, const void *id, int device, l2
     c->nccl = nullptr;
     // world == 1 with an id still builds a 1-rank RCCL communicator: the same call path as
     // N > 1 (dlopen, ncclCommInitRank, ncclAllGather on the stream), testable on one GPU
-    if (world > 1 || id != nullptr) {
-        if (id == nullptr) {
-            delete c;
-            set_error("l2z_comm_init: id required when world > 1");
-            return L2Z_ERR_INVALID;
-        }
+    // id == NULL with world > 1: no RCCL communicator; the group must then be connected for
+    // peer-write gathers (l2z_comm_p2p_export / _connect) before it is used
+    if (id != nullptr) {
         int s = load_rccl();
         if (s != L2Z_OK) {
             delete c;
@@ -128,6 +152,55 @@ extern "C" int l2z_comm_init_emulated(int rank, int world, int device, l2z_comm 
     return L2Z_OK;
 }
 
+// ---- peer-write all-gather: arena export / connect (protocol in p2p.hip) ----
+extern "C" int l2z_comm_p2p_export(l2z_comm *c, size_t max_vector_floats, void *handle_out)
+{
+    L2Z_CHECK(c != nullptr && handle_out != nullptr && max_vector_floats > 0, L2Z_ERR_INVALID,
+              "l2z_comm_p2p_export: bad arguments");
+    L2Z_CHECK(c->world <= kMaxWorld, L2Z_ERR_INVALID, "peer-write gathers support up to %d ranks", kMaxWorld);
+    L2Z_CHECK(c->arena == nullptr, L2Z_ERR_STATE, "l2z_comm_p2p_export: called twice");
+    static_assert(sizeof(hipIpcMemHandle_t) == L2Z_COMM_IPC_BYTES, "hipIpcMemHandle_t size");
+    L2Z_HIP(hipSetDevice(c->device));
+    c->slot_floats = (max_vector_floats + 1023) & ~(size_t)1023;
+    const size_t bytes = kP2pFlagBytes + 2 * c->slot_floats * sizeof(float);
+    // fine-grained: peers' stores and this rank's flag polls / landing reads are coherent inside
+    // a running kernel (ordinary hipMalloc memory is only coherent at kernel boundaries)
+    L2Z_HIP(hipExtMallocWithFlags((void **)&c->arena, bytes, hipDeviceMallocFinegrained));
+    L2Z_HIP(hipMemset(c->arena, 0, bytes));
+    L2Z_HIP(hipMalloc((void **)&c->d_epoch, kMaxWorld * sizeof(int)));
+    L2Z_HIP(hipMemset(c->d_epoch, 0, kMaxWorld * sizeof(int)));
+    L2Z_HIP(hipHostMalloc((void **)&c->h_err, sizeof(int), hipHostMallocDefault));
+    *c->h_err = 0;
+    L2Z_HIP(hipDeviceSynchronize());
+    hipIpcMemHandle_t h;
+    L2Z_HIP(hipIpcGetMemHandle(&h, c->arena));
+    std::memcpy(handle_out, &h, sizeof h);
+    return L2Z_OK;
+}
+
+extern "C" int l2z_comm_p2p_connect(l2z_comm *c, const void *handles)
+{
+    L2Z_CHECK(c != nullptr && handles != nullptr, L2Z_ERR_INVALID, "l2z_comm_p2p_connect: bad arguments");
+    L2Z_CHECK(c->arena != nullptr && !c->p2p, L2Z_ERR_STATE,
+              "l2z_comm_p2p_connect: call l2z_comm_p2p_export first (once)");
+    L2Z_HIP(hipSetDevice(c->device));
+    for (int r = 0; r < c->world; r++) {
+        if (r == c->rank) {
+            c->peer_arena[r] = c->arena;
+            continue;
+        }
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, static_cast<const char *>(handles) + (size_t)r * L2Z_COMM_IPC_BYTES, sizeof h);
+        void *p = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        L2Z_CHECK(e == hipSuccess, L2Z_ERR_COMM, "hipIpcOpenMemHandle(rank %d) failed: %s", r,
+                  hipGetErrorString(e));
+        c->peer_arena[r] = static_cast<char *>(p);
+    }
+    c->p2p = true;
+    return L2Z_OK;
+}
+
 extern "C" int l2z_comm_rank(const l2z_comm *c, int *rank, int *world)
 {
     L2Z_CHECK(c != nullptr, L2Z_ERR_INVALID, "l2z_comm_rank: null comm");
@@ -139,6 +212,11 @@ extern "C" int l2z_comm_rank(const l2z_comm *c, int *rank, int *world)
 extern "C" void l2z_comm_free(l2z_comm *c)
 {
     if (!c) return;
+    for (int r = 0; r < c->world && r < kMaxWorld; r++)
+        if (r != c->rank && c->peer_arena[r]) (void)hipIpcCloseMemHandle(c->peer_arena[r]);
+    if (c->arena) (void)hipFree(c->arena);
+    if (c->d_epoch) (void)hipFree(c->d_epoch);
+    if (c->h_err) (void)hipHostFree(c->h_err);
     if (c->nccl && g_api.CommDestroy) g_api.CommDestroy(static_cast<ncclComm_t>(c->nccl));
     delete c;
 }

@@ -5,7 +5,7 @@ pkg = ge.load_package(); B, ck = pkg.binding, pkg.checkpoint
 cfg = ck.LLAMA2_7B
 w = B.Weights(cfg, None, False, seed=1)
 res = {}
-for split in ("0", "8", "16"):
+for split in os.environ.get("SPLITS", "0,8,16").split(","):
     os.environ["L2Z_ATTN_SPLIT"] = split
     s = B.RunState(cfg)
     for pos in (0, 31, 63, 127, 255, 383, 511, 767, 1023, 1535, 2047):

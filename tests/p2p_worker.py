@@ -1,0 +1,54 @@
+"""One rank of a multi-PROCESS sharded run on one GPU (tests/test_gpu_p2p.py spawns these).
+
+usage: p2p_worker.py <rank> <world> <dir> <model.json>
+The ranks exchange the IPC handles of their landing arenas through files in <dir>, connect the
+peer-write all-gather (l2z_comm_p2p_*), run the greedy loop on a sharded toy checkpoint and write
+tokens + final logits to <dir>/out_<rank>.npz.  No RCCL, no torch.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+
+def main() -> None:
+    rank, world, d, spec = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], json.load(open(sys.argv[4]))
+    pkg = ge.load_package()
+    B, ck = pkg.binding, pkg.checkpoint
+    cfg = ck.Config(**spec["cfg"])
+    shared, seed = spec["shared"], spec["seed"]
+    comm = B.Comm(rank, world, None, 0)  # every rank on device 0: this is a one-GPU test
+    h = comm.p2p_export(max(cfg.dim, cfg.hidden_dim, cfg.vocab_size))
+    with open(os.path.join(d, f"h_{rank}.tmp"), "wb") as f:
+        f.write(h)
+    os.rename(os.path.join(d, f"h_{rank}.tmp"), os.path.join(d, f"h_{rank}.bin"))
+    handles, t0 = [], time.time()
+    for r in range(world):
+        p = os.path.join(d, f"h_{r}.bin")
+        while not os.path.exists(p):
+            if time.time() - t0 > 120:
+                raise SystemExit(f"rank {rank}: no handle from rank {r}")
+            time.sleep(0.01)
+        handles.append(open(p, "rb").read())
+    comm.p2p_connect(b"".join(handles))
+    blob = ck.synth_blob(cfg, shared, seed) if spec.get("blob", True) else None
+    w = B.Weights(cfg, blob, shared, seed=seed, comm=comm)
+    s = B.RunState(cfg, comm=comm)
+    s.greedy_begin(spec["prompt"])
+    toks = s.greedy_run(w, spec["steps"])
+    logits = s.logits()
+    # the stepped API on top of the same state
+    s.transformer(int(toks[-1]), len(toks) % cfg.seq_len, w)
+    logits2, am = s.logits(), s.argmax()
+    np.savez(os.path.join(d, f"out_{rank}.npz"), toks=toks, logits=logits, logits2=logits2, am=am)
+    s.close(); w.close(); comm.close()
+
+
+if __name__ == "__main__":
+    main()
