@@ -92,22 +92,41 @@ def cpu_baseline(ck, cfg, shared, name: str) -> dict:
                       f"extrapolated to {cfg.n_layers} layers"}
 
 
-def run_once(B, cfg, shared, seed, steps, warmup, comm=None, barrier=None):
-    """Returns (tokens produced in the timed region, elapsed seconds, runstate, weights)."""
-    w = B.Weights(cfg, None, shared, seed=seed, comm=comm)
-    s = B.RunState(cfg, comm=comm)
-    s.greedy_begin([])
-    if warmup > 0:
-        s.greedy_run(w, warmup)
-    s.synchronize()
-    if barrier:
-        barrier()
+def run_once(B, cfg, shared, seed, steps, warmup, comm=None, sync_ok=None):
+    """Returns (tokens produced in the timed region, elapsed seconds, runstate, weights).
+
+    sync_ok(ok) -> bool is the multi-rank barrier: every rank reports whether its phase worked and
+    learns whether all did, so that a failure on one rank makes ALL ranks raise here instead of
+    leaving the others waiting in a barrier."""
+    sync_ok = sync_ok or (lambda ok: ok)
+    s = w = None
+    err = None
+    try:
+        w = B.Weights(cfg, None, shared, seed=seed, comm=comm)
+        s = B.RunState(cfg, comm=comm)
+        s.greedy_begin([])
+        if warmup > 0:
+            s.greedy_run(w, warmup)
+        s.synchronize()
+    except Exception as e:  # noqa: BLE001
+        err = e
+    if not sync_ok(err is None):
+        for o in (s, w):
+            if o is not None:
+                o.close()
+        raise RuntimeError(f"set-up / warm-up failed on some rank ({err})")
     t0 = time.perf_counter()
-    toks = s.greedy_run(w, steps)  # synchronises before returning the tokens
-    s.synchronize()
-    if barrier:
-        barrier()
+    toks = ()
+    try:
+        toks = s.greedy_run(w, steps)  # synchronises before returning the tokens
+        s.synchronize()
+    except Exception as e:  # noqa: BLE001
+        err = e
+    ok = sync_ok(err is None)
     dt = time.perf_counter() - t0
+    if not ok:
+        s.close(); w.close()
+        raise RuntimeError(f"timed region failed on some rank ({err})")
     return len(toks), dt, s, w
 
 
@@ -132,7 +151,8 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    comm, barrier, dist = None, None, None
+    comm, dist = None, None
+    transport = None
     force_dist = os.environ.get("L2Z_BENCH_FORCE_DIST") == "1"  # 1-rank RCCL + gloo, for testing
     if args.gpus > 1 or world > 1 or force_dist:
         if world != args.gpus:
@@ -142,23 +162,87 @@ def main() -> None:
         # without a visible device on this image (measured on the MI355X box)
         import torch
         import torch.distributed as dist
-        # control plane only (barrier, id broadcast, max-reduce of the clock): gloo on CPU.
-        # The data path's collectives are RCCL calls made by libllama2_hip.so itself.
+        # control plane only (barrier, handle/id exchange, max-reduce of the clock): gloo on CPU.
+        # The data path's all-gathers are issued by libllama2_hip.so itself.
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        uid = [B.Comm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        comm = B.Comm(rank, world, uid[0], local_rank)
-        barrier = dist.barrier
 
     if B.device_count() < 1:
         raise SystemExit("bench.py: no HIP device visible (the HIP path has no CPU fallback)")
+    device = local_rank % B.device_count()  # several ranks on one GPU only happens in tests
 
-    n_tok, dt, s, w = run_once(B, cfg, shared, args.seed, steps, args.warmup, comm, barrier)
+    def all_ok(ok: bool) -> bool:
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(ok))
+        return all(flags)
+
+    def make_comm(kind: str):
+        """'p2p': peer-write gathers over IPC-mapped arenas (xGMI between GPUs); 'rccl': RCCL."""
+        if kind == "p2p":
+            c, h = None, b""
+            try:
+                c = B.Comm(rank, world, None, device)
+                h = c.p2p_export(max(cfg.dim, cfg.hidden_dim, cfg.vocab_size))
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank {rank}] peer-write export failed: {e}", file=sys.stderr)
+            hs = [None] * world
+            dist.all_gather_object(hs, h)
+            ok = c is not None and all(len(x) == B.COMM_IPC_BYTES for x in hs)
+            if ok:
+                try:
+                    c.p2p_connect(b"".join(hs))
+                except Exception as e:  # noqa: BLE001
+                    print(f"[rank {rank}] peer-write connect failed: {e}", file=sys.stderr)
+                    ok = False
+            if all_ok(ok):
+                return c
+            if c is not None:
+                c.close()
+            return None
+        uid = [B.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        return B.Comm(rank, world, uid[0], device)
+
+    def ranks_agree(s) -> bool:
+        """Every rank must hold the same logits after the same steps (bit for bit)."""
+        lg = s.logits()
+        sig = (int(np.argmax(lg)), float(lg.astype(np.float64).sum()), float(np.abs(lg).max()))
+        sigs = [None] * world
+        dist.all_gather_object(sigs, sig)
+        return all(x == sigs[0] for x in sigs) and bool(np.isfinite(lg).all())
+
+    agree = None
     if dist is not None:
-        import torch
+        want = os.environ.get("L2Z_COMM", "p2p")
+        for kind in ([want] if want == "rccl" or force_dist else ["p2p", "rccl"]):
+            comm = make_comm("rccl" if force_dist else kind)
+            if comm is None:
+                continue
+            transport = "rccl" if force_dist else kind
+            s = w = None
+            try:
+                n_tok, dt, s, w = run_once(B, cfg, shared, args.seed, steps, args.warmup, comm, all_ok)
+                ran = True
+            except Exception as e:  # noqa: BLE001  (a gather timed out, a launch failed, ...)
+                print(f"[rank {rank}] run with transport {transport} failed: {e}", file=sys.stderr)
+                ran = False
+            agree = ranks_agree(s) if all_ok(ran) else False
+            if agree or transport == "rccl":
+                if not agree and not ran:
+                    raise SystemExit("bench.py: the sharded run failed with RCCL as well")
+                break
+            print(f"[rank {rank}] transport {transport} unusable here (ran={ran}); retrying with RCCL",
+                  file=sys.stderr)
+            for o in (s, w, comm):
+                if o is not None:
+                    o.close()
+            comm = None
+        if comm is None:
+            raise SystemExit("bench.py: no working transport for the shard group")
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    else:
+        n_tok, dt, s, w = run_once(B, cfg, shared, args.seed, steps, args.warmup, None, None)
 
     # ---- roofline of the dominant kernel, HIP events in situ ----
     by_kind = {k: [0.0, 0] for k in B.KINDS}
@@ -175,7 +259,7 @@ def main() -> None:
     achieved = wb[dom] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and world == 1:  # the PMC passes were taken unsharded
         try:
             traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
         except Exception:
@@ -211,7 +295,10 @@ def main() -> None:
                                f"(dim {cfg.dim}, hidden {cfg.hidden_dim}, L {cfg.n_layers}, "
                                f"H {cfg.n_heads}, kv {cfg.n_kv_heads}, V {cfg.vocab_size}, "
                                f"S {cfg.seq_len}), greedy from BOS, seeded synthetic weights",
-                   "parallelism": f"rows/heads sharded x{args.gpus}" if args.gpus > 1 else "1 GPU",
+                   "parallelism": (f"rows/heads sharded x{args.gpus}, all-gathers by "
+                                   + ("peer writes over IPC-mapped memory (xGMI)" if transport == "p2p"
+                                      else "RCCL")) if transport else "1 GPU",
+                   "ranks_agree": agree,
                    "weight_bytes_per_token": sum(
                        wb[k] * (1 if k == "cls" else cfg.n_layers) for k in wb) * world},
         "roofline": roofline,
