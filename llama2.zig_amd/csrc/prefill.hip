@@ -417,6 +417,133 @@ __global__ __launch_bounds__(kPfBlock) void prefill_attention(const float *q, in
     }
 }
 
+// Tiled causal attention for a chunk (flash form): block (h, 64 query tokens) walks the cache in
+// tiles of 64 timesteps; S = Q K^T and O += P V run on the fp32 matrix cores, the softmax is the
+// running-max form (m, l per query row, O rescaled by e^(m_old - m_new)), so a K/V tile is read
+// once per 64 queries instead of once per query.  Mathematically main.zig:361-389; in floating
+// point the weights are e^(s-m)/l applied after the sum instead of before (a few ulp, same as the
+// decode path's split attention).  LDS: Q, K, V tiles 64 x (hs+1), P tile 64 x 65.
+//   S: wave (wm, wn) owns S[32 wm.., 32 wn..];  O: 32 x 32 tiles (row half, column tile) dealt to
+//   the waves round-robin, TPW per wave.
+template <int TPW>
+__global__ __launch_bounds__(kPfBlock) void prefill_attention_tiled(const float *q, int ldq,
+                                                                    const float *kcache, const float *vcache,
+                                                                    float *out, int ldo, int pos0, int P,
+                                                                    int hs, int kv_dim, int kv_mul, int seq_len)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int LD = hs + 1;
+    float *qs = lds, *ks = qs + 64 * LD, *vs = ks + 64 * LD, *ps = vs + 64 * LD;
+    float *row_m = ps + 64 * 65, *row_l = row_m + 64, *row_a = row_l + 64;
+    const int h = blockIdx.x, q0 = blockIdx.y * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int kvh = h / kv_mul;  // :369
+    const float *kbase = kcache + (size_t)kvh * hs, *vbase = vcache + (size_t)kvh * hs;
+    const int E = hs >> 2;
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+    for (int f = tid; f < 64 * E; f += kPfBlock) {
+        const int r = f / E, c = (f % E) * 4;
+        const v4f v = q0 + r < P ? *(const v4f *)(q + (size_t)(q0 + r) * ldq + (size_t)h * hs + c) : zero;
+        float *d = qs + r * LD + c;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    if (tid < 64) { row_m[tid] = -INFINITY; row_l[tid] = 0.0f; }
+    v16f acc[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[j][r] = 0.0f;
+    const int last_q = (q0 + 63 < P ? q0 + 63 : P - 1);
+    const int n_kt = (pos0 + last_q) / 64 + 1;  // key tiles 0 .. the one holding the last query's own position
+    const float div = sqrtf((float)hs);
+    // k order of the S product: pairs 32 apart inside chunks of 64 when hs allows (lanes 32..63 then
+    // hit LDS banks 32 away from lanes 0..31), else pairs hs/2 apart
+    const bool chunked = (hs & 63) == 0;
+    const int half = hs >> 1;
+    for (int kt = 0; kt < n_kt; kt++) {
+        const int t0 = kt * 64;
+        __syncthreads();  // the previous tile's P V product is done with ks / vs / ps
+        for (int f = tid; f < 64 * E; f += kPfBlock) {
+            const int r = f / E, c = (f % E) * 4;
+            int t = t0 + r;
+            t = t < seq_len ? t : seq_len - 1;  // rows past the context are masked below
+            const v4f kv = *(const v4f *)(kbase + (size_t)t * kv_dim + c);
+            const v4f vv = *(const v4f *)(vbase + (size_t)t * kv_dim + c);
+            float *dk = ks + r * LD + c, *dv = vs + r * LD + c;
+            dk[0] = kv.x; dk[1] = kv.y; dk[2] = kv.z; dk[3] = kv.w;
+            dv[0] = vv.x; dv[1] = vv.y; dv[2] = vv.z; dv[3] = vv.w;
+        }
+        __syncthreads();
+        {   // S = Q K^T for this wave's 32 x 32 tile (:367-371)
+            v16f sacc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) sacc[r] = 0.0f;
+            const float *qa = qs + (32 * wm + li) * LD, *kb = ks + (32 * wn + li) * LD;
+            for (int st = 0; st < half; st++) {
+                const int k = chunked ? ((st >> 5) << 6) + (st & 31) + 32 * lh : st + half * lh;
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[k], kb[k], sacc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * lh, col = 32 * wn + li;
+                const bool live = t0 + col <= pos0 + q0 + row;  // causal: t <= pos of the query
+                ps[row * 65 + col] = live ? sacc[r] / div : -INFINITY;  // :372
+            }
+        }
+        __syncthreads();
+        {   // running softmax, 4 lanes per query row (:687-706 in running-max form)
+            const int row = tid >> 2, q4 = tid & 3;
+            float *pr = ps + row * 65;
+            float mx = -INFINITY;
+            for (int c = q4; c < 64; c += 4) mx = fmaxf(mx, pr[c]);
+            mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+            const float m_old = row_m[row];
+            const float m_new = fmaxf(m_old, mx);  // finite: key 0 is live for every query
+            float sum = 0.0f;
+            for (int c = q4; c < 64; c += 4) {
+                const float e = expf(pr[c] - m_new);
+                pr[c] = e;
+                sum += e;
+            }
+            sum += __shfl_xor(sum, 1, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            if (q4 == 0) {
+                const float alpha = expf(m_old - m_new);
+                row_a[row] = alpha;
+                row_l[row] = row_l[row] * alpha + sum;
+                row_m[row] = m_new;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TPW; j++) {  // O = O e^(m_old - m_new) + P V  (:381-388)
+            const int ti = wave + 4 * j, rt = ti & 1, ct = ti >> 1;
+            if (ct * 32 < hs) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[j][r] *= row_a[32 * rt + (r & 3) + 8 * (r >> 2) + 4 * lh];
+                const float *pa = ps + (32 * rt + li) * 65 + 32 * lh;
+                const float *vb = vs + (32 * lh) * LD + 32 * ct + li;  // columns >= hs: finite junk, dropped
+#pragma unroll 8
+                for (int st = 0; st < 32; st++)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[st], vb[st * LD], acc[j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TPW; j++) {
+        const int ti = wave + 4 * j, rt = ti & 1, ct = ti >> 1;
+        const int col = 32 * ct + li;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (col < hs && q0 + row < P)
+                out[(size_t)(q0 + row) * ldo + (size_t)h * hs + col] = acc[j][r] / row_l[row];  // :704
+        }
+    }
+}
+
 template <int EPI, int TM, int TN, int BK, int KS>
 hipError_t gemm_launch_t(const GemmArgs &a, hipStream_t st)
 {
@@ -525,6 +652,33 @@ hipError_t launch_prefill_attention(const float *q, int ldq, const float *kcache
                                     float *out, int ldo, int pos0, int P, int n_heads, int head_size,
                                     int kv_dim, int kv_mul, int seq_len, hipStream_t st)
 {
+    static const bool naive = getenv("L2Z_PF_ATTN") && atoi(getenv("L2Z_PF_ATTN")) == 0;
+    const size_t lds_t = (size_t)(3 * 64 * (head_size + 1) + 64 * 65 + 3 * 64) * sizeof(float);
+    const int n_ct = (head_size + 31) / 32;  // O column tiles; 2 n_ct tiles over 4 waves
+    // one block per (head, 64 queries): worth it once that fills half the CUs (7B: from 256 tokens);
+    // below, and for models with few heads, the block-per-(head, query) kernel has more parallelism
+    const bool enough_blocks = n_heads * ((P + 63) / 64) >= 128;
+    if (!naive && enough_blocks && lds_t <= 160 * 1024 && n_ct <= 8 && (head_size % 4) == 0 && (kv_dim % 4) == 0) {
+        const int tpw = (2 * n_ct + 3) / 4;
+        const void *fn = tpw <= 1 ? (const void *)prefill_attention_tiled<1>
+                       : tpw == 2 ? (const void *)prefill_attention_tiled<2>
+                                  : (const void *)prefill_attention_tiled<4>;
+        if (lds_t > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
+            if (e != hipSuccess) return e;
+        }
+        const dim3 grid(n_heads, (P + 63) / 64);
+        if (tpw <= 1)
+            hipLaunchKernelGGL(prefill_attention_tiled<1>, grid, dim3(kPfBlock), lds_t, st, q, ldq, kcache, vcache,
+                               out, ldo, pos0, P, head_size, kv_dim, kv_mul, seq_len);
+        else if (tpw == 2)
+            hipLaunchKernelGGL(prefill_attention_tiled<2>, grid, dim3(kPfBlock), lds_t, st, q, ldq, kcache, vcache,
+                               out, ldo, pos0, P, head_size, kv_dim, kv_mul, seq_len);
+        else
+            hipLaunchKernelGGL(prefill_attention_tiled<4>, grid, dim3(kPfBlock), lds_t, st, q, ldq, kcache, vcache,
+                               out, ldo, pos0, P, head_size, kv_dim, kv_mul, seq_len);
+        return hipGetLastError();
+    }
     int E = head_size >> 2, TPR = 1;
     while (TPR < E && TPR < 64) TPR <<= 1;
     const int G = kPfBlock / TPR;

@@ -457,6 +457,10 @@ PREFILL_CONFIGS = [
     ("toy-gqa", dict(dim=64, hidden_dim=172, n_layers=2, n_heads=4, n_kv_heads=2, vocab_size=512, seq_len=96), False),
     ("toy-mqa", dict(dim=96, hidden_dim=256, n_layers=2, n_heads=6, n_kv_heads=1, vocab_size=1000, seq_len=80), True),
     ("stories15M-shape-2layers", dict(dim=288, hidden_dim=768, n_layers=2, n_heads=6, n_kv_heads=6, vocab_size=32000, seq_len=560), True),
+    # many heads: the tiled (flash-form) prefill attention runs from n_heads * ceil(P/64) >= 128
+    ("32-heads-hs16-gqa", dict(dim=512, hidden_dim=1024, n_layers=2, n_heads=32, n_kv_heads=8, vocab_size=1024, seq_len=560), False),
+    ("16-heads-hs48", dict(dim=768, hidden_dim=1024, n_layers=2, n_heads=16, n_kv_heads=16, vocab_size=1024, seq_len=560), True),
+    ("16-heads-hs64-gqa", dict(dim=1024, hidden_dim=1536, n_layers=2, n_heads=16, n_kv_heads=4, vocab_size=1024, seq_len=560), False),
 ]
 
 
