@@ -227,43 +227,40 @@ __global__ __launch_bounds__(256 * KS) void prefill_gemm(const GemmArgs a)
 // L2 resident) by one lane per block.  MFMA 16x16x4 f32 operands:
 //   A: lane l holds A[i = l & 15][k = l >> 4]   B: lane l holds B[k = l >> 4][j = l & 15]
 //   D: lane l, reg r holds D[i = 4 (l >> 4) + r][j = l & 15]
-// Lane (., q) loads the float4 at k = 64 c + 16 u + 4 q; component t of it is "k = q" of MFMA
+// Lane (., q) loads the float4 at k = chunk base + 16 u + 4 q; component t of it is "k = q" of MFMA
 // (c, u, t) for both operands, which is all the instruction needs (a sum over k is unordered in
-// exact arithmetic; the fp32 order is fixed by (c, u, t), then waves 0..7: deterministic).
-constexpr int kSkWaves = 8;
+// exact arithmetic; the fp32 order is fixed by (c, u, t), then the waves in order: deterministic).
 
-template <int EPI, int TMS>
+template <int EPI, int TMS, int kSkWaves, int CU, bool KTAIL>
 __global__ __launch_bounds__(64 * kSkWaves) void prefill_skinny(const GemmArgs a)
 {
+    // CU float4 loads per lane and chunk (a chunk is 16 CU values of k); KTAIL: K % (16 CU) != 0
     __shared__ float red[kSkWaves][TMS][4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
     const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * TMS;
     const v4f zero = {0.f, 0.f, 0.f, 0.f};
-    const bool fok = n0 + j < a.N;
-    const float *wrow = a.w + (size_t)(fok ? n0 + j : 0) * a.K + 4 * q;
+    // rows / tokens past the end are clamped: their products land in outputs nobody stores.
+    // No branch and no select around the loads (either would make the loop wait for them early).
+    const float *wrow = a.w + (size_t)min(n0 + j, a.N - 1) * a.K + 4 * q;
     const float *xrow[TMS];
-    bool tok_ok[TMS];
 #pragma unroll
-    for (int tm = 0; tm < TMS; tm++) {
-        const int tok = m0 + 16 * tm + j;
-        tok_ok[tm] = tok < a.P;
-        xrow[tm] = a.x + (size_t)(tok_ok[tm] ? tok : 0) * a.ldx + 4 * q;
-    }
+    for (int tm = 0; tm < TMS; tm++) xrow[tm] = a.x + (size_t)min(m0 + 16 * tm + j, a.P - 1) * a.ldx + 4 * q;
     v4f acc[TMS];
 #pragma unroll
     for (int tm = 0; tm < TMS; tm++) acc[tm] = zero;
-    const int nchunk = (a.K + 63) >> 6;
-    v4f wc[4], wn[4], xc[TMS][4], xn[TMS][4];
-    auto load = [&](int c, v4f (&wv)[4], v4f (&xv)[TMS][4]) {
+    constexpr int CK = 16 * CU;
+    const int nchunk = (a.K + CK - 1) / CK;
+    v4f wc[CU], wn[CU], xc[TMS][CU], xn[TMS][CU];
+    auto load = [&](int c, v4f (&wv)[CU], v4f (&xv)[TMS][CU]) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int k = 64 * c + 16 * u;
-            const bool kok = k + 4 * q < a.K;  // K % 4 == 0
-            wv[u] = (kok && fok) ? __builtin_nontemporal_load((const v4f *)(wrow + k)) : zero;
+        for (int u = 0; u < CU; u++) {
+            int k = CK * c + 16 * u;
+            if (KTAIL && k + 4 * q >= a.K) k = a.K - 4 - 4 * q;  // a lane past the row end re-reads the
+                                                                 // row's last float4; zeroed at use
+            wv[u] = __builtin_nontemporal_load((const v4f *)(wrow + k));
 #pragma unroll
-            for (int tm = 0; tm < TMS; tm++)
-                xv[tm][u] = (kok && tok_ok[tm]) ? *(const v4f *)(xrow[tm] + k) : zero;
+            for (int tm = 0; tm < TMS; tm++) xv[tm][u] = *(const v4f *)(xrow[tm] + k);
         }
     };
     int c = wave;
@@ -271,14 +268,16 @@ __global__ __launch_bounds__(64 * kSkWaves) void prefill_skinny(const GemmArgs a
     for (; c < nchunk; c += kSkWaves) {
         if (c + kSkWaves < nchunk) load(c + kSkWaves, wn, xn);
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int u = 0; u < CU; u++) {
+            const bool dead = KTAIL && CK * c + 16 * u + 4 * q >= a.K;  // K % 4 == 0
 #pragma unroll
             for (int t = 0; t < 4; t++)
 #pragma unroll
                 for (int tm = 0; tm < TMS; tm++)
-                    acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[tm][u][t], wc[u][t], acc[tm], 0, 0, 0);
+                    acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(dead ? 0.0f : xc[tm][u][t], wc[u][t], acc[tm], 0, 0, 0);
+        }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < CU; u++) {
             wc[u] = wn[u];
 #pragma unroll
             for (int tm = 0; tm < TMS; tm++) xc[tm][u] = xn[tm][u];
@@ -568,7 +567,10 @@ template <int EPI, int TMS>
 hipError_t skinny_launch_t(const GemmArgs &a, hipStream_t st)
 {
     dim3 grid((a.N + 15) / 16, (a.P + 16 * TMS - 1) / (16 * TMS));
-    hipLaunchKernelGGL((prefill_skinny<EPI, TMS>), grid, dim3(64 * kSkWaves), 0, st, a);
+    if (a.K % 64 == 0)
+        hipLaunchKernelGGL((prefill_skinny<EPI, TMS, 8, 4, false>), grid, dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL((prefill_skinny<EPI, TMS, 8, 4, true>), grid, dim3(512), 0, st, a);
     return hipGetLastError();
 }
 
