@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E vendor peak (MI355X_MICROARCH.md); ~6300 measured copy
+MFMA_F32_PEAK_TF = 157.3  # dense fp32 matrix peak (256 CUs x 256 flop/clk x 2.4 GHz)
 
 
 def weight_bytes_by_kind(cfg, world: int = 1) -> dict:
@@ -283,6 +284,28 @@ def main() -> None:
                                          "frac_of_measured": (achieved / rd_avg) if rd_avg else None,
                                          "note": "pure nt-load kernel over the resident weights, "
                                                  "slices of the dominant launch's size"}}
+    # ---- batched prompt prefill: the MFMA-bound part, reported beside the
+    # decode figure, never folded into `value`
+    prefill = None
+    if rank == 0 and world == 1 and not args.no_extra:
+        try:
+            n_p = min(512, cfg.seq_len - 1)
+            toks = [1] + np.random.default_rng(args.seed).integers(2, cfg.vocab_size, n_p - 1).tolist()
+            s.prefill(toks, 0, w)  # allocations, first-touch
+            t0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                s.prefill(toks, 0, w)  # synchronises
+            dtp = (time.perf_counter() - t0) / reps
+            flops = 2.0 * n_p * (cfg.n_layers * (2 * cfg.dim * cfg.dim + 2 * cfg.dim * cfg.kv_dim
+                                                 + 3 * cfg.dim * cfg.hidden_dim))
+            prefill = {"prompt_tokens": n_p, "ms": dtp * 1e3, "tokens_per_s": n_p / dtp,
+                       "roofline": {"bound": "mfma", "achieved": flops / dtp / 1e12, "peak": MFMA_F32_PEAK_TF,
+                                    "unit": "TFLOP/s", "frac": flops / dtp / 1e12 / MFMA_F32_PEAK_TF,
+                                    "note": "whole prefill (GEMMs + attention + norms), GEMM flops only "
+                                            "in the numerator; v_mfma_f32_32x32x2_f32"}}
+        except Exception as e:  # noqa: BLE001
+            prefill = {"error": str(e)}
     s.close()
     w.close()
 
@@ -308,7 +331,8 @@ def main() -> None:
             c15, sh15 = shapes["stories15M"]
             n15, dt15, s15, w15 = run_once(B, c15, sh15, args.seed, 255, 1)
             s15.close(); w15.close()
-            out["extra"] = {"stories15M_tokens_per_s": n15 / dt15, "stories15M_steps": n15,
+            out["extra"] = {"prefill": prefill,
+                            "stories15M_tokens_per_s": n15 / dt15, "stories15M_steps": n15,
                             "note": "stories15M shape, -t 0 -n 256; weights fit the on-die "
                                     "cache, launch/latency bound, no HBM fraction quoted"}
         if not args.no_cpu_baseline:
