@@ -874,16 +874,23 @@ static int prefill_chunk_tokens()
 
 int prefill_alloc(l2z_runstate *s)
 {
-    if (s->pf_x) return L2Z_OK;
+    if (s->pf_tokens) return L2Z_OK;  // the last one allocated: all of them exist
     const l2z_config &c = s->cfg;
     const size_t P = kPrefillChunk;
-    L2Z_HIP(hipMalloc(&s->pf_x, P * c.dim * 4));
-    L2Z_HIP(hipMalloc(&s->pf_xn, P * c.dim * 4));
-    L2Z_HIP(hipMalloc(&s->pf_q, P * c.dim * 4));
-    L2Z_HIP(hipMalloc(&s->pf_att, P * c.dim * 4));
-    L2Z_HIP(hipMalloc(&s->pf_h1, P * c.hidden_dim * 4));
-    L2Z_HIP(hipMalloc(&s->pf_h3, P * c.hidden_dim * 4));
-    L2Z_HIP(hipMalloc(&s->pf_tokens, P * 4));
+    struct { void **p; size_t bytes; } want[] = {
+        {(void **)&s->pf_x, P * c.dim * 4},   {(void **)&s->pf_xn, P * c.dim * 4},
+        {(void **)&s->pf_q, P * c.dim * 4},   {(void **)&s->pf_att, P * c.dim * 4},
+        {(void **)&s->pf_h1, P * c.hidden_dim * 4}, {(void **)&s->pf_h3, P * c.hidden_dim * 4},
+        {(void **)&s->pf_tokens, P * 4}};
+    for (auto &b : want) {
+        if (*b.p) continue;  // kept from an earlier, partly failed attempt
+        hipError_t e = hipMalloc(b.p, b.bytes);
+        if (e != hipSuccess) {
+            *b.p = nullptr;
+            set_error("prefill scratch allocation (%zu bytes) failed: %s", b.bytes, hipGetErrorString(e));
+            return e == hipErrorOutOfMemory ? L2Z_ERR_OOM : L2Z_ERR_HIP;
+        }
+    }
     return L2Z_OK;
 }
 
@@ -1013,7 +1020,6 @@ extern "C" int l2z_greedy_begin(l2z_runstate *s, const int32_t *prompt, int n_pr
     s->h_prompt.assign(prompt, prompt + n_prompt);
     s->host_pos = 0;
     s->done = false;
-    s->graph_w = s->graph_w;  // graphs stay valid: all loop state is in device memory
     return L2Z_OK;
 }
 
