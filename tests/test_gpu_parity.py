@@ -448,6 +448,17 @@ def test_greedy_prompt_through_prefill(gpu, ck, n_prompt):
     s2.greedy_begin(prompt)
     a = s2.greedy_run(w, 2).tolist() + s2.greedy_run(w, n_steps - 2).tolist()
     assert a[: len(want)] == want
+    # a BOS inside a long prompt: no batched pass, the loop ends on it (main.zig:1017)
+    if n_prompt >= 8:
+        p2 = list(prompt)
+        p2[6] = 1
+        s2.greedy_begin(p2)
+        assert s2.greedy_run(w, n_steps).tolist() == p2[:7]
+    # a prompt that fills the whole context: every position is forced, nothing is generated
+    full = np.random.default_rng(4).integers(2, cfg.vocab_size, cfg.seq_len).tolist()
+    s2.greedy_begin(full)
+    assert s2.greedy_run(w, 10 * cfg.seq_len).tolist() == full
+    assert s2.greedy_run(w, 1).size == 0
     for o in (s1, s2, w):
         o.close()
 
