@@ -239,3 +239,40 @@ def test_stories110M_prefill_two_chunks_then_decode(gpu, ck):
         np.testing.assert_allclose(lg2, lg1, rtol=2e-4, atol=2e-4)
     for o in (s1, s2, w):
         o.close()
+
+
+def test_7b_full_forward_logits_vs_oracle(gpu, ck, orc, model7b):
+    """The whole Llama-2-7B-shape forward pass against the CPU oracle: the same 27 GB of seeded
+    weights are generated on the host (oracle's generator, bit-identical to the device's), three
+    positions are run on both sides, logits compared at the stated tolerance.  Needs ~30 GB of
+    host memory and a few seconds of all host cores for the fill; skipped on small hosts."""
+    psutil = pytest.importorskip("psutil")
+    if psutil.virtual_memory().available < 64 * (1 << 30):
+        pytest.skip("needs 64 GB of free host memory")
+    import os
+    cfg, w, s = model7b
+    blob = orc.synth_fill(cfg.as_i32(), False, 2024, os.cpu_count() or 1)
+    # spot-check that host and device hold the same weights
+    for off in (0, 123456789, ck.weights_count(cfg, False) - 4096):
+        assert np.array_equal(w.read(off, 4096), blob[off:off + 4096])
+    m = orc.Model(cfg.as_i32(), blob, False)
+    worst = 0.0
+    for pos, tok in enumerate([1, 9038, 2501]):
+        ref = m.transformer(tok, pos)
+        s.transformer(tok, pos, w)
+        got = s.logits()
+        worst = max(worst, float(np.abs(got - ref).max()))
+        np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4, err_msg=f"pos {pos}")
+        srt = np.sort(ref)
+        assert s.argmax() == int(np.argmax(ref)) or srt[-1] - srt[-2] < 1e-4
+    print(f"7B shape, full forward vs oracle: max |logit diff| = {worst:.3e}")
+    # and the -t 0 loop: token ids identical to the CPU path (main.zig:995-1036)
+    ref_toks, margins = m.generate_greedy([], 6)
+    s.greedy_begin([])
+    dev = s.greedy_run(w, 6)
+    n = min(len(dev), len(ref_toks))
+    same = next((i for i in range(n) if dev[i] != ref_toks[i]), n)
+    assert same == n or margins[same] < 1e-4, (dev.tolist(), ref_toks.tolist(), margins.tolist())
+    print(f"7B shape, greedy: {same} of {n} token ids identical to the oracle, min top-2 margin {float(np.min(margins[:n])):.3e}")
+    m.close()
+    del blob
