@@ -1,5 +1,5 @@
-"""BASELINE.json's full sizes on the GPU, checked through size-independent properties
-and row-sampled oracle parity (the CPU oracle cannot run a full 7B pass in test time):
+"""BASELINE.json's full sizes on the GPU, checked through size-independent properties,
+row-sampled oracle parity and -- where the host has the memory -- the full 7B pass on the oracle:
 
   * every mat-vec shape of the 7B / 110M / 15M configs at full size: 96 sampled output
     rows per shape against the oracle's dot product of the same row;
@@ -7,7 +7,9 @@ and row-sampled oracle parity (the CPU oracle cannot run a full 7B pass in test 
     device greedy loop == host loop (l2z_transformer + l2z_argmax), run-to-run
     determinism, logits finite, classifier rows re-derived by the oracle from the
     device's own final activations;
-  * the 7B shape sharded over 8 emulated ranks == unsharded, bit for bit.
+  * the 7B shape sharded over 8 emulated ranks == unsharded, bit for bit;
+  * the full 7B forward pass and the first greedy tokens against the CPU oracle (27 GB host blob);
+  * batched prefill at the 7B and 110M shapes against the stepped loop.
 """
 import numpy as np
 import pytest
