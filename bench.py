@@ -161,6 +161,9 @@ def main() -> None:
                              "python -m torch.distributed.run --nproc-per-node N ...)")
         # torch is imported BEFORE libllama2_hip.so is loaded: the other order leaves HIP
         # without a visible device on this image (measured on the MI355X box)
+        # a peer that never shows up must fail the peer-write attempt quickly, so that the RCCL
+        # fallback still fits the run (ranks are within a second of each other after the handshake)
+        os.environ.setdefault("L2Z_P2P_TIMEOUT_S", "8")
         import torch
         import torch.distributed as dist
         # control plane only (barrier, handle/id exchange, max-reduce of the clock): gloo on CPU.
