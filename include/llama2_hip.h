@@ -193,8 +193,8 @@ int l2z_argmax_host(const float *x, size_t n, size_t *out_index);               
  *  - peer writes: l2z_comm_init(rank, world, NULL, device, &c), then every rank exports the IPC
  *    handle of its landing arena (l2z_comm_p2p_export), the launcher all-gathers the 64-byte
  *    handles in rank order, and l2z_comm_p2p_connect maps the peers.  A gather is then one small
- *    kernel of direct stores into the peers' memory plus flags -- no collective library, and it
- *    can be captured in the step graph.  Preferred when both are set up (L2Z_COMM=rccl overrides).
+ *    kernel of direct 8-byte {value, epoch} stores into the peers' memory, polled by the receiver --
+ *    no fences, no collective library, and it can be captured in the step graph.  Preferred when both are set up (L2Z_COMM=rccl overrides).
  */
 #define L2Z_COMM_ID_BYTES 128
 int l2z_comm_unique_id(void *out_id);

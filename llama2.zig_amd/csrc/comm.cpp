@@ -162,7 +162,7 @@ extern "C" int l2z_comm_p2p_export(l2z_comm *c, size_t max_vector_floats, void *
     static_assert(sizeof(hipIpcMemHandle_t) == L2Z_COMM_IPC_BYTES, "hipIpcMemHandle_t size");
     L2Z_HIP(hipSetDevice(c->device));
     c->slot_floats = (max_vector_floats + 1023) & ~(size_t)1023;
-    const size_t bytes = kP2pFlagBytes + 2 * c->slot_floats * sizeof(float);
+    const size_t bytes = kP2pFlagBytes + 2 * c->slot_floats * 8;  // 8-byte {value, epoch} words
     // fine-grained: peers' stores and this rank's flag polls / landing reads are coherent inside
     // a running kernel (ordinary hipMalloc memory is only coherent at kernel boundaries)
     L2Z_HIP(hipExtMallocWithFlags((void **)&c->arena, bytes, hipDeviceMallocFinegrained));

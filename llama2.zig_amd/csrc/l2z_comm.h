@@ -3,7 +3,7 @@
 #include "l2z_internal.h"
 
 constexpr int kMaxWorld = 16;
-constexpr size_t kP2pFlagBytes = 4096;  // int flag[kMaxWorld] at the start of every arena
+constexpr size_t kP2pFlagBytes = 4096;  // reserved head of every arena
 
 struct l2z_comm {
     int rank;
@@ -12,8 +12,8 @@ struct l2z_comm {
     void *nccl;  // ncclComm_t, null when world == 1 / peer-write only / emulated
     // ---- peer-write all-gather (comm.cpp, p2p.hip) ----
     bool p2p = false;                 // connected: gathers go through peer stores + flags
-    char *arena = nullptr;            // this rank's arena: flags | landing slot 0 | landing slot 1
-    size_t slot_floats = 0;           // floats per landing slot (>= the longest gathered vector)
+    char *arena = nullptr;            // this rank's arena: reserved | landing slot 0 | landing slot 1
+    size_t slot_floats = 0;           // 8-byte words per landing slot (>= the longest gathered vector)
     char *peer_arena[kMaxWorld] = {}; // every rank's arena mapped here ([rank] == arena)
     int *d_epoch = nullptr;           // [kMaxWorld] gathers completed with peer p (device)
     int *h_err = nullptr;             // pinned host int: a wait timed out (peer died / desync)
