@@ -311,6 +311,97 @@ __global__ __launch_bounds__(64 * kSkWaves) void prefill_skinny(const GemmArgs a
     }
 }
 
+// The same 16-feature x 16 TMS-token block as prefill_skinny, but W and X are staged through LDS
+// in chunks of 256 k: every wave-wide global load then reads 1 KB of ONE row instead of 16 rows x
+// 64 bytes, and the MFMA operands come from LDS rows of 260 floats (bank = 4 j + q: conflict-free).
+// Both forms stream W at ~3.4 TB/s, half the decode kernel's rate: N/16 blocks x 16 rows are
+// thousands of concurrent DRAM row streams, where the decode kernel sweeps 2 rows per block in
+// 16-KB bursts -- the price of having 16 features in flight per MFMA.
+// Stage s+1 travels global -> registers while stage s is multiplied; the 4 waves split each
+// stage's 64 k-steps and are summed through LDS at the end (order fixed: deterministic).
+constexpr int kSkBK = 256, kSkLD = kSkBK + 4;
+
+template <int EPI, int TMS>
+__global__ __launch_bounds__(kPfBlock) void prefill_skinny_lds(const GemmArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *ws = smem;                    // 16 x kSkLD
+    float *xs = smem + 16 * kSkLD;       // 16 TMS x kSkLD
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * TMS;
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+    // float4 slot f = tid + 256 i of a tile: row f / 64, k = 4 (f % 64): a wave reads 1 KB of a row
+    v4f wv[4], xv[TMS][4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int f = tid + kPfBlock * i, r = f >> 6, k = k0 + 4 * (f & 63);
+            const int kc = min(k, a.K - 4);  // clamped: legal address, zeroed at the LDS store
+            wv[i] = __builtin_nontemporal_load((const v4f *)(a.w + (size_t)min(n0 + r, a.N - 1) * a.K + kc));
+#pragma unroll
+            for (int tm = 0; tm < TMS; tm++)
+                xv[tm][i] = *(const v4f *)(a.x + (size_t)min(m0 + 16 * tm + r, a.P - 1) * a.ldx + kc);
+        }
+    };
+    auto sstore = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int f = tid + kPfBlock * i, r = f >> 6, c = 4 * (f & 63);
+            const bool ok = k0 + c < a.K;  // K % 4 == 0; rows / tokens past the end: junk nobody stores
+            *(v4f *)(ws + r * kSkLD + c) = ok ? wv[i] : zero;
+#pragma unroll
+            for (int tm = 0; tm < TMS; tm++) *(v4f *)(xs + (16 * tm + r) * kSkLD + c) = ok ? xv[tm][i] : zero;
+        }
+    };
+    v4f acc[TMS];
+#pragma unroll
+    for (int tm = 0; tm < TMS; tm++) acc[tm] = zero;
+    gload(0);
+    for (int k0 = 0; k0 < a.K; k0 += kSkBK) {
+        __syncthreads();  // the previous stage has been multiplied
+        sstore(k0);
+        __syncthreads();
+        if (k0 + kSkBK < a.K) gload(k0 + kSkBK);  // flies while this stage is multiplied
+        const float *wr = ws + j * kSkLD + 64 * wave + q;
+        const float *xr = xs + j * kSkLD + 64 * wave + q;
+#pragma unroll
+        for (int st = 0; st < 16; st++) {  // this wave's quarter of the stage: k = 64 wave + 4 st + q
+            const float b = wr[4 * st];
+#pragma unroll
+            for (int tm = 0; tm < TMS; tm++)
+                acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[16 * tm * kSkLD + 4 * st], b, acc[tm], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    float *red = smem;  // [4 waves][TMS][4][64]
+#pragma unroll
+    for (int tm = 0; tm < TMS; tm++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[((wave * TMS + tm) * 4 + r) * 64 + lane] = acc[tm][r];
+    __syncthreads();
+    for (int idx = tid; idx < TMS * 256; idx += kPfBlock) {
+        const int tm = idx >> 8, r = (idx >> 6) & 3, l = idx & 63;
+        float v = red[((0 * TMS + tm) * 4 + r) * 64 + l];
+#pragma unroll
+        for (int w = 1; w < 4; w++) v += red[((w * TMS + tm) * 4 + r) * 64 + l];
+        const int tok = m0 + 16 * tm + 4 * (l >> 4) + r;
+        const int f = n0 + (l & 15);
+        if (EPI == G_ROPE || EPI == G_ROPE_CACHE) {
+            const float partner = __shfl_xor(v, 1, 64);  // feature f ^ 1, same token (main.zig:346-349)
+            const int hs = a.head_size;
+            const int pos = a.pos0 + (tok < a.P ? tok : 0);
+            const float2 cs = a.rope[(size_t)pos * (size_t)(hs >> 1) + (size_t)(((f < a.N ? f : 0) % hs) >> 1)];
+            v = (f & 1) ? partner * cs.y + v * cs.x : v * cs.x - partner * cs.y;
+        }
+        if (tok < a.P && f < a.N) {
+            if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + f] = v;
+            else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + f] += v;
+            else a.out[(size_t)(a.pos0 + tok) * a.ldo + f] = v;
+        }
+    }
+}
+
 // rows of x -> rmsnorm rows (main.zig:432-468), one block per token
 __global__ __launch_bounds__(kPfBlock) void prefill_rmsnorm(float *o, const float *x, const float *w,
                                                             int n, int P)
@@ -566,11 +657,26 @@ hipError_t gemm_launch_t(const GemmArgs &a, hipStream_t st)
 template <int EPI, int TMS>
 hipError_t skinny_launch_t(const GemmArgs &a, hipStream_t st)
 {
+    static const int form = getenv("L2Z_PF_SKINNY_FORM") ? atoi(getenv("L2Z_PF_SKINNY_FORM")) : 1;
     dim3 grid((a.N + 15) / 16, (a.P + 16 * TMS - 1) / (16 * TMS));
-    if (a.K % 64 == 0)
+    // LDS-staged form (1-KB row reads): 5-8 % ahead at 16-32 tokens on the 7B shape, level at 8,
+    // behind at 64 (83 KB of LDS, one block per CU) -- so only up to two token tiles
+    if (form == 1 && a.K >= kSkBK && TMS <= 2) {
+        const size_t stage = (size_t)(16 + 16 * TMS) * kSkLD * sizeof(float);
+        const size_t red = (size_t)4 * TMS * 4 * 64 * sizeof(float);
+        const size_t lds = stage > red ? stage : red;
+        static bool attr = false;
+        if (!attr && lds > 48 * 1024) {
+            (void)hipFuncSetAttribute((const void *)prefill_skinny_lds<EPI, TMS>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        hipLaunchKernelGGL((prefill_skinny_lds<EPI, TMS>), grid, dim3(kPfBlock), lds, st, a);
+    } else if (a.K % 64 == 0) {
         hipLaunchKernelGGL((prefill_skinny<EPI, TMS, 8, 4, false>), grid, dim3(512), 0, st, a);
-    else
+    } else {
         hipLaunchKernelGGL((prefill_skinny<EPI, TMS, 8, 4, true>), grid, dim3(512), 0, st, a);
+    }
     return hipGetLastError();
 }
 
