@@ -409,20 +409,49 @@ __global__ __launch_bounds__(kPfBlock) void prefill_rmsnorm(float *o, const floa
     __shared__ float red[8];
     const int t = blockIdx.x;
     const float *xr = x + (size_t)t * n;
+    const int n4 = n >> 2;  // n % 4 == 0 on this path
+    constexpr int R = 8;    // float4 kept in registers per lane: one round trip up to n = 8192
+    const bool in_regs = n4 <= R * kPfBlock;
+    v4f xv[R];
     float ss = 0.0f;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) ss = fmaf(xr[i], xr[i], ss);
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const int i = threadIdx.x + kPfBlock * k;
+            xv[k] = i < n4 ? ((const v4f *)xr)[i] : v4f{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            ss = fmaf(xv[k].x, xv[k].x, ss); ss = fmaf(xv[k].y, xv[k].y, ss);
+            ss = fmaf(xv[k].z, xv[k].z, ss); ss = fmaf(xv[k].w, xv[k].w, ss);
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) ss = fmaf(xr[i], xr[i], ss);
+    }
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
     __syncthreads();
     float tot = red[0];
     for (int i = 1; i < (int)(blockDim.x >> 6); i++) tot += red[i];
-    float s = tot / (float)n;
+    float s = tot / (float)n;  // main.zig:452-455
     s += 1e-5f;
     s = 1.0f / sqrtf(s);
-    for (int i = threadIdx.x; i < n; i += blockDim.x) o[(size_t)t * n + i] = (xr[i] * s) * w[i];
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const int i = threadIdx.x + kPfBlock * k;
+            if (i < n4) {
+                const v4f wv = ((const v4f *)w)[i];
+                v4f r;
+                r.x = (xv[k].x * s) * wv.x; r.y = (xv[k].y * s) * wv.y;
+                r.z = (xv[k].z * s) * wv.z; r.w = (xv[k].w * s) * wv.w;
+                ((v4f *)(o + (size_t)t * n))[i] = r;
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) o[(size_t)t * n + i] = (xr[i] * s) * w[i];
+    }
 }
-
-// hb = silu(h1) * h3   (main.zig:411-416)
 __global__ void prefill_swiglu(float *hb, const float *h1, const float *h3, size_t count)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
