@@ -191,7 +191,7 @@ struct l2z_runstate {
     int *d_out_tokens = nullptr, *d_argmax = nullptr;
     // batched prefill scratch (allocated on first l2z_prefill): [kPrefillChunk, dim|hidden]
     float *pf_x = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_att = nullptr;
-    float *pf_h1 = nullptr, *pf_h3 = nullptr;
+    float *pf_h1 = nullptr;
     int *pf_tokens = nullptr;
     float *d_part_val = nullptr;  // classifier launch's per-block argmax candidates
     int *d_part_idx = nullptr;
@@ -520,7 +520,7 @@ extern "C" void l2z_runstate_free(l2z_runstate *s)
     void *ptrs[] = {s->x, s->xb, s->hb, s->q, s->logits, s->key_cache, s->value_cache, s->rope,
                     s->d_token, s->d_pos, s->d_prompt, s->d_n_prompt, s->d_out_tokens, s->d_argmax,
                     s->d_part_val, s->d_part_idx, s->d_attn_part, s->pf_x, s->pf_xn, s->pf_q,
-                    s->pf_att, s->pf_h1, s->pf_h3, s->pf_tokens};
+                    s->pf_att, s->pf_h1, s->pf_tokens};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -880,7 +880,7 @@ int prefill_alloc(l2z_runstate *s)
     struct { void **p; size_t bytes; } want[] = {
         {(void **)&s->pf_x, P * c.dim * 4},   {(void **)&s->pf_xn, P * c.dim * 4},
         {(void **)&s->pf_q, P * c.dim * 4},   {(void **)&s->pf_att, P * c.dim * 4},
-        {(void **)&s->pf_h1, P * c.hidden_dim * 4}, {(void **)&s->pf_h3, P * c.hidden_dim * 4},
+        {(void **)&s->pf_h1, P * c.hidden_dim * 4},
         {(void **)&s->pf_tokens, P * 4}};
     for (auto &b : want) {
         if (*b.p) continue;  // kept from an earlier, partly failed attempt
@@ -919,9 +919,8 @@ int prefill_chunk(l2z_runstate *s, const l2z_weights *w, const int32_t *tokens, 
         L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, s->pf_x, w->rms_ffn + (size_t)l * dim, dim, P, st));  // :398
         L2Z_HIP(launch_prefill_gemm(PG_STORE, s->pf_xn, dim, w->w1 + (size_t)l * hid * dim, s->pf_h1, hid,
                                     P, hid, dim, pos0, s->rope, hs, st));                   // :405
-        L2Z_HIP(launch_prefill_gemm(PG_STORE, s->pf_xn, dim, w->w3 + (size_t)l * hid * dim, s->pf_h3, hid,
-                                    P, hid, dim, pos0, s->rope, hs, st));
-        L2Z_HIP(launch_prefill_swiglu(s->pf_h1, s->pf_h1, s->pf_h3, (size_t)P * hid, st));   // :411-416
+        L2Z_HIP(launch_prefill_gemm(PG_SWIGLU, s->pf_xn, dim, w->w3 + (size_t)l * hid * dim, s->pf_h1, hid,
+                                    P, hid, dim, pos0, s->rope, hs, st));   // :408 + :411-416 in the epilogue
         L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_h1, hid, w->w2 + (size_t)l * dim * hid, s->pf_x, dim,
                                     P, dim, hid, pos0, s->rope, hs, st));                   // :419-422
     }

@@ -135,14 +135,13 @@ hipError_t launch_synth_fill(float *dst, uint64_t base_idx, uint64_t count, uint
 size_t attention_lds_bytes(int head_size, int seq_len, bool vec);
 
 // ---- batched prefill (prefill.hip) ----
-enum PrefillGemmEpi { PG_STORE = 0, PG_RESID = 1, PG_ROPE = 2, PG_ROPE_CACHE = 3, PG_CACHE = 4 };
+enum PrefillGemmEpi { PG_STORE = 0, PG_RESID = 1, PG_ROPE = 2, PG_ROPE_CACHE = 3, PG_CACHE = 4,
+                      PG_SWIGLU = 5 };  // out = silu(out) * (X W^T): the W3 product merged into W1's
 hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w, float *out, int ldo,
                                int P, int N, int K, int pos0, const float2 *rope, int head_size,
                                hipStream_t st);
 hipError_t launch_prefill_rmsnorm(float *o, const float *x, const float *w, int n, int P,
                                   hipStream_t st);
-hipError_t launch_prefill_swiglu(float *hb, const float *h1, const float *h3, size_t count,
-                                 hipStream_t st);
 hipError_t launch_prefill_embed(float *x, const float *tok_emb, const int *tokens, int dim, int P,
                                 hipStream_t st);
 hipError_t launch_prefill_attention(const float *q, int ldq, const float *kcache, const float *vcache,

@@ -29,7 +29,14 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 #endif
 constexpr int kPfBlock = 256;
 
-enum GemmEpi { G_STORE = 0, G_RESID = 1, G_ROPE = 2, G_ROPE_CACHE = 3, G_CACHE = 4 };
+enum GemmEpi { G_STORE = 0, G_RESID = 1, G_ROPE = 2, G_ROPE_CACHE = 3, G_CACHE = 4, G_SWIGLU = 5 };
+
+// main.zig:411-416 on the W3 product: out holds W1 x, becomes silu(W1 x) * (W3 x)
+__device__ __forceinline__ float swiglu_merge(float h1, float h3)
+{
+    const float v = h1 * (1.0f / (1.0f + expf(-h1)));
+    return v * h3;
+}
 
 struct GemmArgs {
     const float *x;      // [P, K] row-major (ldx floats per row)
@@ -214,6 +221,8 @@ __global__ __launch_bounds__(256 * KS) void prefill_gemm(const GemmArgs a)
                 if (tok < a.P && j < a.N) {
                     if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + j] = v;
                     else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + j] += v;        // main.zig:711
+                    else if (EPI == G_SWIGLU)
+                        a.out[(size_t)tok * a.ldo + j] = swiglu_merge(a.out[(size_t)tok * a.ldo + j], v);
                     else a.out[(size_t)(a.pos0 + tok) * a.ldo + j] = v;                  // main.zig:354-358
                 }
             }
@@ -306,6 +315,7 @@ __global__ __launch_bounds__(64 * kSkWaves) void prefill_skinny(const GemmArgs a
         if (tok < a.P && f < a.N) {
             if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + f] = v;
             else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + f] += v;
+            else if (EPI == G_SWIGLU) a.out[(size_t)tok * a.ldo + f] = swiglu_merge(a.out[(size_t)tok * a.ldo + f], v);
             else a.out[(size_t)(a.pos0 + tok) * a.ldo + f] = v;
         }
     }
@@ -397,6 +407,7 @@ __global__ __launch_bounds__(kPfBlock) void prefill_skinny_lds(const GemmArgs a)
         if (tok < a.P && f < a.N) {
             if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + f] = v;
             else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + f] += v;
+            else if (EPI == G_SWIGLU) a.out[(size_t)tok * a.ldo + f] = swiglu_merge(a.out[(size_t)tok * a.ldo + f], v);
             else a.out[(size_t)(a.pos0 + tok) * a.ldo + f] = v;
         }
     }
@@ -450,15 +461,6 @@ __global__ __launch_bounds__(kPfBlock) void prefill_rmsnorm(float *o, const floa
         }
     } else {
         for (int i = threadIdx.x; i < n; i += blockDim.x) o[(size_t)t * n + i] = (xr[i] * s) * w[i];
-    }
-}
-__global__ void prefill_swiglu(float *hb, const float *h1, const float *h3, size_t count)
-{
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
-         i += (size_t)gridDim.x * blockDim.x) {
-        float v = h1[i];
-        v = v * (1.0f / (1.0f + expf(-v)));
-        hb[i] = v * h3[i];
     }
 }
 
@@ -758,6 +760,7 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
         case G_ROPE: return gemm_launch<G_ROPE>(a, st);
         case G_ROPE_CACHE: return gemm_launch<G_ROPE_CACHE>(a, st);
         case G_CACHE: return gemm_launch<G_CACHE>(a, st);
+        case G_SWIGLU: return gemm_launch<G_SWIGLU>(a, st);
     }
     return hipErrorInvalidValue;
 }
@@ -766,15 +769,6 @@ hipError_t launch_prefill_rmsnorm(float *o, const float *x, const float *w, int 
                                   hipStream_t st)
 {
     hipLaunchKernelGGL(prefill_rmsnorm, dim3(P), dim3(kPfBlock), 0, st, o, x, w, n, P);
-    return hipGetLastError();
-}
-
-hipError_t launch_prefill_swiglu(float *hb, const float *h1, const float *h3, size_t count,
-                                 hipStream_t st)
-{
-    size_t blocks = (count + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(prefill_swiglu, dim3((unsigned)blocks), dim3(256), 0, st, hb, h1, h3, count);
     return hipGetLastError();
 }
 
