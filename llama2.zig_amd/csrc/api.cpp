@@ -299,7 +299,8 @@ extern "C" int l2z_device_info(int dev, char *name, size_t cap, int *out_cus, ui
     L2Z_TRY(ensure_device(dev));
     hipDeviceProp_t p;
     L2Z_HIP(hipGetDeviceProperties(&p, dev));
-    if (name && cap) snprintf(name, cap, "%s (%s)", p.name, p.gcnArchName);
+    // some boxes report an empty marketing name
+    if (name && cap) snprintf(name, cap, "%s (%s)", p.name[0] ? p.name : "AMD GPU", p.gcnArchName);
     if (out_cus) *out_cus = p.multiProcessorCount;
     if (out_hbm) *out_hbm = (uint64_t)p.totalGlobalMem;
     return L2Z_OK;
