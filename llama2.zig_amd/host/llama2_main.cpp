@@ -250,6 +250,23 @@ int main(int argc, char **argv)
             }
         }
     } else {
+        // The prompt positions (:999-1000: next = prompt[pos], their logits are never sampled) as
+        // one batched pass when the prompt is long enough; the tokens print in a burst, then the
+        // loop continues at pos = prompt_len.  Any refusal (odd dims, L2Z_PREFILL=0, a BOS inside
+        // the prompt, which would end the loop at :1017) leaves the stepped loop below to do it.
+        const char *pf_env = getenv("L2Z_PREFILL");
+        bool has_bos = false;
+        for (int32_t t : prompt) has_bos = has_bos || t == 1;
+        if (prompt_len >= L2Z_PREFILL_MIN_PROMPT && prompt_len <= seq_len && !has_bos &&
+            !(pf_env && atoi(pf_env) == 0)) {
+            std::vector<int32_t> in(prompt_len);
+            in[0] = 1;
+            for (size_t i = 1; i < prompt_len; i++) in[i] = prompt[i - 1];
+            if (l2z_prefill(in.data(), (int)prompt_len, 0, &cfg, s, w) == L2Z_OK) {
+                for (size_t i = 0; i < prompt_len; i++) emit((size_t)prompt[i]);
+                pos = prompt_len;
+            }
+        }
         for (; pos < seq_len; pos++) {
             if (l2z_transformer((int)token, (int)pos, &cfg, s, w) != L2Z_OK) return die("transformer");  // :996
             size_t next;

@@ -199,3 +199,33 @@ def test_cli_sampling_runs(gpu):
         assert r.returncode == 0, r.stderr.decode(errors="replace")
         outs.append([l for l in r.stderr.decode().splitlines() if l.startswith("tokens:")][0])
     assert outs[0] == outs[1] and len(outs[0].split()) > 2
+
+
+@pytest.mark.gpu
+def test_cli_sampling_with_long_prompt_uses_batched_prefill(gpu, ck):
+    """-t 1.0 with a prompt of >= 4 tokens: the prompt positions go through l2z_prefill, the
+    output starts with the prompt's tokens, and the run is seed-deterministic; with L2Z_PREFILL=0
+    (stepped prompt) the echoed prompt is the same."""
+    exe = os.path.join(HOST, "llama2")
+    ckpt = os.path.join(GOLDEN, "toy_mha_shared.bin")
+    c, _, _ = ck.read_checkpoint(ckpt, mmap=False)
+    text = "a b c d e f g h"
+    H = C.CDLL(os.path.join(HOST, "libllama2_host.so"))
+    err = C.create_string_buffer(64)
+    H.l2zh_tokenizer_open.restype = C.c_void_p
+    tk = H.l2zh_tokenizer_open(TOK.encode(), c.vocab_size, err, 64)
+    out = (C.c_int32 * 64)()
+    H.l2zh_tokenizer_encode.restype = C.c_long
+    n = H.l2zh_tokenizer_encode(C.c_void_p(tk), text.encode(), len(text), out, 64)
+    prompt = list(out[:n])
+    assert n >= 4 and 1 not in prompt
+
+    def run(env_extra):
+        r = subprocess.run([exe, ckpt, "-t", "1.0", "-p", "0.9", "-n", "28", "-s", "7", "-z", TOK, "-i", text,
+                            "--tokens"], capture_output=True, timeout=120, env=dict(os.environ, **env_extra))
+        assert r.returncode == 0, r.stderr.decode(errors="replace")
+        line = [l for l in r.stderr.decode().splitlines() if l.startswith("tokens:")][0]
+        return [int(v) for v in line.split()[1:]]
+
+    a, b, stepped = run({}), run({}), run({"L2Z_PREFILL": "0"})
+    assert a == b and a[:n] == prompt and stepped[:n] == prompt and len(a) > n
