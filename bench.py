@@ -336,6 +336,9 @@ def main() -> None:
             s15.close(); w15.close()
             out["extra"] = {"prefill": prefill,
                             "stories15M_tokens_per_s": n15 / dt15, "stories15M_steps": n15,
+                            # the only figure the reference publishes: 660 tok/s, -t 0,
+                            # stories15M, one Ryzen 9 5900X core, Zig 0.11 -- other hardware, indicative
+                            "stories15M_vs_reference_readme_660": (n15 / dt15) / 660.0,
                             "note": "stories15M shape, -t 0 -n 256; weights fit the on-die "
                                     "cache, launch/latency bound, no HBM fraction quoted"}
         if not args.no_cpu_baseline:
