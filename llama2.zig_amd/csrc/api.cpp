@@ -206,6 +206,9 @@ struct l2z_runstate {
     int host_pos = 0;   // next position the greedy loop will run
     bool done = false;  // greedy loop saw BOS
     std::vector<int32_t> h_prompt;  // host copy of the greedy loop's prompt (prefill path)
+    // peer-write transport: device copies of the four gathers' descriptions (xb, x, hb, logits) for
+    // the kernels that push their outputs to the peers themselves (MatvecArgs::push)
+    P2pArgs *d_push = nullptr;
     int max_blocks = 0;
 };
 
@@ -468,7 +471,10 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
         // position (tests); L2Z_ATTN_SPLIT_POS moves the switch-over.
         const char *ev = getenv("L2Z_ATTN_SPLIT");
         const int mode = ev ? atoi(ev) : -1;
-        int nch = mode > 0 ? mode : attention_split_chunks(sh.heads_loc, g_cus);
+        // The chunk count is part of the arithmetic (the combine rounds per chunk), so it is taken
+        // from the model's TOTAL head count, not this rank's share: sharded and unsharded runs then
+        // use the same chunks and stay bit-identical beyond pos 256 as well.
+        int nch = mode > 0 ? mode : attention_split_chunks(c.n_heads, g_cus);
         if (nch > 16) nch = 16;
         s->attn_split_pos = mode > 0 ? 0 : 256;
         if (const char *ep = getenv("L2Z_ATTN_SPLIT_POS")) s->attn_split_pos = atoi(ep);
@@ -477,6 +483,15 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
             s->attn_nch = nch;
             alloc((void **)&s->d_attn_part, attention_split_part_floats(sh.heads_loc, sh.hs, nch) * 4);
         }
+    }
+    if (comm && comm->p2p && comm->world > 1) {
+        P2pArgs t[4];
+        comm_p2p_args(comm, s->xb, (size_t)sh.dim_loc, &t[0]);
+        comm_p2p_args(comm, s->x, (size_t)sh.dim_loc, &t[1]);
+        comm_p2p_args(comm, s->hb, (size_t)sh.hid_loc, &t[2]);
+        comm_p2p_args(comm, s->logits, (size_t)sh.v_loc, &t[3]);
+        alloc((void **)&s->d_push, sizeof t);
+        if (e == hipSuccess) e = hipMemcpy(s->d_push, t, sizeof t, hipMemcpyHostToDevice);
     }
     if (e != hipSuccess) {
         set_error("RunState allocation failed: %s", hipGetErrorString(e));
@@ -521,7 +536,7 @@ extern "C" void l2z_runstate_free(l2z_runstate *s)
     void *ptrs[] = {s->x, s->xb, s->hb, s->q, s->logits, s->key_cache, s->value_cache, s->rope,
                     s->d_token, s->d_pos, s->d_prompt, s->d_n_prompt, s->d_out_tokens, s->d_argmax,
                     s->d_part_val, s->d_part_idx, s->d_attn_part, s->pf_x, s->pf_xn, s->pf_q,
-                    s->pf_att, s->pf_h1, s->pf_tokens};
+                    s->pf_att, s->pf_h1, s->pf_tokens, s->d_push};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -580,9 +595,21 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
     const int mb = s->max_blocks;
     int stage = 0;
     auto want = [&]() { return only_stage < 0 || only_stage == stage; };
+    // Peer-write transport: kernels that can, store their outputs as LL words straight into the
+    // peers' slots (the values travel while the launch still runs); the gather that follows then
+    // only collects.  `pushed` = the launch just made did.  Not while profiling (the gather's
+    // share would be hidden in the kernel's time), not for emulated ranks, not with L2Z_COMM=rccl.
+    static const bool push_env = !(getenv("L2Z_P2P_PUSH") && atoi(getenv("L2Z_P2P_PUSH")) == 0) &&
+                                 !(getenv("L2Z_COMM") && strcmp(getenv("L2Z_COMM"), "rccl") == 0);
+    const bool can_push = push_env && s->d_push != nullptr && prof == nullptr && only_stage < 0;
+    bool pushed = false;
     auto gather = [&](float *buf, size_t count_per_rank) -> int {
         stage++;
         if (only_stage >= 0) return L2Z_OK;
+        if (pushed) {
+            pushed = false;
+            return comm_allgather_inplace_pushed(s->comm, buf, count_per_rank, st);
+        }
         return comm_allgather_inplace(s->comm, buf, count_per_rank, st);
     };
     for (int l = 0; l < c.n_layers; l++) {
@@ -605,6 +632,10 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.q = s->q; a.kcache = kc; a.vcache = vc; a.xb = s->xb + sh.dim0;
             a.pos_ptr = s->d_pos; a.head_size = sh.hs; a.kv_dim = sh.kvd_loc;
             a.kv_mul = c.n_heads / c.n_kv_heads; a.seq_len = c.seq_len;
+            if (can_push && attention_push_supported(a)) {
+                a.push = s->d_push + 0;
+                pushed = true;
+            }
             if (split && s->attn_nch > 1 && attention_split_supported(a))
                 L2Z_LAUNCH(KIND_ATTN, launch_attention_split(a, sh.heads_loc, s->attn_nch,
                                                              s->d_attn_part, st));
@@ -617,7 +648,8 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.w0 = w->wo + (size_t)l * sh.dim_loc * dim;
             a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0;
             a.rows0 = sh.dim_loc; a.n = c.dim; a.x = s->xb;
-            L2Z_LAUNCH(KIND_WO, launch_matvec(a, PRO_NONE, EPI_RESID, mb, g_cus, st));
+            if (can_push) a.push = s->d_push + 1;
+            L2Z_LAUNCH(KIND_WO, launch_matvec(a, PRO_NONE, EPI_RESID, mb, g_cus, st, nullptr, &pushed));
         }
         L2Z_TRY(gather(s->x, sh.dim_loc));
         if (want()) {   // rmsnorm (:398) + w1,w3 (:405-408) + SiLU*mul (:411-416)
@@ -627,7 +659,8 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.out0 = s->hb + sh.hid0;
             a.rows0 = sh.hid_loc; a.rows1 = sh.hid_loc; a.n = c.dim;
             a.x = s->x; a.rms_w = w->rms_ffn + (size_t)l * dim;
-            L2Z_LAUNCH(KIND_FFN13, launch_matvec(a, PRO_RMS, EPI_SWIGLU, mb, g_cus, st));
+            if (can_push) a.push = s->d_push + 2;
+            L2Z_LAUNCH(KIND_FFN13, launch_matvec(a, PRO_RMS, EPI_SWIGLU, mb, g_cus, st, nullptr, &pushed));
         }
         L2Z_TRY(gather(s->hb, sh.hid_loc));
         if (want()) {   // w2 (:419) + residual (:422)
@@ -635,7 +668,8 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.w0 = w->w2 + (size_t)l * sh.dim_loc * hid;
             a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0;
             a.rows0 = sh.dim_loc; a.n = c.hidden_dim; a.x = s->hb;
-            L2Z_LAUNCH(KIND_FFN2, launch_matvec(a, PRO_NONE, EPI_RESID, mb, g_cus, st));
+            if (can_push) a.push = s->d_push + 1;
+            L2Z_LAUNCH(KIND_FFN2, launch_matvec(a, PRO_NONE, EPI_RESID, mb, g_cus, st, nullptr, &pushed));
         }
         L2Z_TRY(gather(s->x, sh.dim_loc));
     }
@@ -647,8 +681,9 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         // single GPU, vector path: the launch also leaves one argmax candidate per block
         const bool fuse = sh.world == 1 && c.dim % 4 == 0;
         int grid = 0;
+        if (can_push) a.push = s->d_push + 3;
         L2Z_LAUNCH(KIND_CLS, launch_matvec(a, PRO_RMS, fuse ? EPI_ARGMAX : EPI_STORE, mb, g_cus, st,
-                                           &grid));
+                                           &grid, &pushed));
         s->n_part = fuse ? grid : 0;
     }
     L2Z_TRY(gather(s->logits, sh.v_loc));

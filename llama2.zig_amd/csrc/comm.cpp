@@ -61,6 +61,30 @@ int comm_check(const l2z_comm *c)
     return L2Z_OK;
 }
 
+bool comm_p2p_args(const l2z_comm *c, float *buf, size_t count_per_rank, P2pArgs *out)
+{
+    if (c == nullptr || !c->p2p || c->world <= 1) return false;
+    static const long long timeout_s = getenv("L2Z_P2P_TIMEOUT_S") ? atoll(getenv("L2Z_P2P_TIMEOUT_S")) : 20;
+    P2pArgs a = {};
+    a.buf = buf; a.count = count_per_rank; a.rank = c->rank; a.world = c->world;
+    a.slot_floats = c->slot_floats;
+    for (int r = 0; r < c->world; r++) a.peer_arena[r] = c->peer_arena[r];
+    a.epoch = c->d_epoch; a.err = c->h_err;
+    a.timeout_ticks = timeout_s * 100000000LL;
+    *out = a;
+    return true;
+}
+
+// the gather after a launch that pushed its own LL words: collect only
+int comm_allgather_inplace_pushed(const l2z_comm *c, float *buf, size_t count_per_rank, hipStream_t st)
+{
+    P2pArgs a = {};
+    L2Z_CHECK(comm_p2p_args(c, buf, count_per_rank, &a), L2Z_ERR_STATE, "pushed gather without peer-write transport");
+    hipError_t e = launch_p2p_allgather(a, st, true);
+    L2Z_CHECK(e == hipSuccess, L2Z_ERR_HIP, "peer-write gather launch failed: %s", hipGetErrorString(e));
+    return L2Z_OK;
+}
+
 int comm_allgather_inplace(const l2z_comm *c, float *buf, size_t count_per_rank, hipStream_t st)
 {
     static const bool prefer_rccl = getenv("L2Z_COMM") && std::strcmp(getenv("L2Z_COMM"), "rccl") == 0;
@@ -69,12 +93,7 @@ int comm_allgather_inplace(const l2z_comm *c, float *buf, size_t count_per_rank,
                   "peer-write gather of %zu floats exceeds the landing slot (%zu)",
                   count_per_rank * (size_t)c->world, c->slot_floats);
         P2pArgs a = {};
-        a.buf = buf; a.count = count_per_rank; a.rank = c->rank; a.world = c->world;
-        a.slot_floats = c->slot_floats;
-        for (int r = 0; r < c->world; r++) a.peer_arena[r] = c->peer_arena[r];
-        a.epoch = c->d_epoch; a.err = c->h_err;
-        static const long long timeout_s = getenv("L2Z_P2P_TIMEOUT_S") ? atoll(getenv("L2Z_P2P_TIMEOUT_S")) : 20;
-        a.timeout_ticks = timeout_s * 100000000LL;
+        comm_p2p_args(c, buf, count_per_rank, &a);
         hipError_t e = launch_p2p_allgather(a, st);
         L2Z_CHECK(e == hipSuccess, L2Z_ERR_HIP, "peer-write gather launch failed: %s", hipGetErrorString(e));
         return L2Z_OK;

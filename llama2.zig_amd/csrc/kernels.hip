@@ -18,6 +18,7 @@
 //    step can be replayed without host involvement.
 #include <cstdlib>
 
+#include "l2z_comm.h"
 #include "l2z_internal.h"
 
 namespace l2z {
@@ -282,6 +283,9 @@ struct MvLocals {
     const float2 *rope;
     int rows0, r01, total_rows, n_pairs, n, head_size, rope_segs, pos;
     size_t ps1, ps2;
+    const P2pArgs *push;  // sharded: LL words of the outputs go straight to the peers
+    int push_e;
+    size_t push_base;     // index of out0[0] in the gathered vector
 };
 
 template <int EPI>
@@ -297,6 +301,9 @@ __device__ __forceinline__ MvLocals mv_locals(const MatvecArgs &a)
     m.pos = (EPI == EPI_ROPE) ? *a.pos_ptr : 0;
     m.ps1 = (size_t)m.pos * (size_t)a.pos_stride1;
     m.ps2 = (size_t)m.pos * (size_t)a.pos_stride2;
+    m.push = a.push;
+    m.push_e = m.push ? p2p_ll_epoch(m.push) : 0;
+    m.push_base = m.push ? (size_t)m.push->rank * m.push->count : 0;
     return m;
 }
 
@@ -365,7 +372,10 @@ __device__ __forceinline__ void pair_epilogue(const MvLocals &m, int p, float sa
         float v = sa;
         v = v * (1.0f / (1.0f + expf(-v)));  // :412
         v = v * sb;                          // :416
-        if (writer && valid_a) m.out0[p] = v;
+        if (writer && valid_a) {
+            m.out0[p] = v;
+            if (m.push) p2p_ll_push(m.push, m.push_e, m.push_base + (size_t)p, v);
+        }
         return;
     }
     const int ga = 2 * p, gb = ga + 1;
@@ -393,13 +403,22 @@ __device__ __forceinline__ void pair_epilogue(const MvLocals &m, int p, float sa
         }
     } else if (EPI == EPI_RESID) {
         if (writer && valid_a) {
-            oa[row_a] = in.ra + sa;  // :711 a[i] += b[i]  (resid[row] prefetched)
-            if (valid_b) ob[row_b] = in.rb + sb;
+            const float va = in.ra + sa, vb = in.rb + sb;  // :711 a[i] += b[i]  (resid[row] prefetched)
+            oa[row_a] = va;
+            if (valid_b) ob[row_b] = vb;
+            if (m.push) {  // single segment on this path: row == index in the slice
+                p2p_ll_push(m.push, m.push_e, m.push_base + (size_t)row_a, va);
+                if (valid_b) p2p_ll_push(m.push, m.push_e, m.push_base + (size_t)row_b, vb);
+            }
         }
     } else {
         if (writer && valid_a) {
             oa[row_a] = sa;
             if (valid_b) ob[row_b] = sb;
+            if (m.push) {
+                p2p_ll_push(m.push, m.push_e, m.push_base + (size_t)row_a, sa);
+                if (valid_b) p2p_ll_push(m.push, m.push_e, m.push_base + (size_t)row_b, sb);
+            }
         }
     }
 }
@@ -867,7 +886,8 @@ __device__ __forceinline__ void wave_softmax(const float *att, float *prob, int 
 // out[i] = part[0][i] + part[1][i] + ... + part[G-1][i], i < hs.  R = 1..16 adjacent lanes
 // share one output: lane r adds partials r, r+R, ... (increasing), then a DPP sum over the R
 // lanes.  R depends only on (G, hs, blockDim) -- fixed per model.
-__device__ __forceinline__ void reduce_partials(const float *part, int G, int hs, float *out)
+__device__ __forceinline__ void reduce_partials(const float *part, int G, int hs, float *out,
+                                                const P2pArgs *push = nullptr, size_t push_idx0 = 0)
 {
     int R = 1;
     while (R * 2 <= G && R * 2 * hs <= (int)blockDim.x && R < 16) R <<= 1;
@@ -876,7 +896,10 @@ __device__ __forceinline__ void reduce_partials(const float *part, int G, int hs
     if (i < hs)
         for (int gg = r; gg < G; gg += R) s += part[(size_t)gg * hs + i];
     s = lanes_sum(s, R);
-    if (i < hs && r == 0) out[i] = s;
+    if (i < hs && r == 0) {
+        out[i] = s;
+        if (push) p2p_ll_push(push, p2p_ll_epoch(push), push_idx0 + (size_t)i, s);
+    }
 }
 
 // Fast path (head_size % 4 == 0, head_size <= 256).  The first kFastUB timesteps of
@@ -986,7 +1009,9 @@ __global__ __launch_bounds__(NT) void attention_fast_kernel(const AttnArgs a)
     if (active) ((v4f *)(part + (size_t)g * hs))[cc] = acc;
     __syncthreads();
     L2Z_TS(6);
-    reduce_partials(part, ge.G, hs, a.xb + (size_t)h * hs);
+    // sharded: a.xb already points at this rank's slice, head h of it starts at h * hs
+    reduce_partials(part, ge.G, hs, a.xb + (size_t)h * hs, a.push,
+                    a.push ? (size_t)a.push->rank * a.push->count + (size_t)h * hs : 0);
     L2Z_TS(7);
 }
 
@@ -1101,7 +1126,7 @@ __global__ __launch_bounds__(kBlock) void attention_split_kernel(const AttnArgs 
 }
 
 __global__ void attention_combine_kernel(const float *__restrict__ part_in, int nch, int hs,
-                                         float *__restrict__ xb)
+                                         float *__restrict__ xb, const P2pArgs *push)
 {
     constexpr int kMaxCh = 16;
     const int h = blockIdx.x;
@@ -1130,7 +1155,10 @@ __global__ void attention_combine_kernel(const float *__restrict__ part_in, int 
         float num = 0.0f;
 #pragma unroll
         for (int c = 0; c < kMaxCh; c++) num = fmaf(oc[c], mc[c], num);
-        xb[(size_t)h * hs + i] = num / den;
+        const float v = num / den;
+        xb[(size_t)h * hs + i] = v;
+        if (push)
+            p2p_ll_push(push, p2p_ll_epoch(push), (size_t)push->rank * push->count + (size_t)h * hs + i, v);
     }
 }
 
@@ -1434,9 +1462,10 @@ hipError_t launch_stream_read(const float *p, size_t n_floats, float *out, int n
     return hipGetLastError();
 }
 
-hipError_t launch_matvec(const MatvecArgs &a, int pro, int epi, int max_blocks_per_cu, int n_cus,
-                         hipStream_t st, int *out_grid)
+hipError_t launch_matvec(const MatvecArgs &a_in, int pro, int epi, int max_blocks_per_cu, int n_cus,
+                         hipStream_t st, int *out_grid, bool *pushed)
 {
+    MatvecArgs a = a_in;
     if (max_blocks_per_cu > 8) max_blocks_per_cu = 8;
     bool vec = (a.n % 4) == 0 && aligned16(a.x) && aligned16(a.w0);
     if (a.rows1 > 0) vec = vec && aligned16(a.w1);
@@ -1505,7 +1534,10 @@ hipError_t launch_matvec(const MatvecArgs &a, int pro, int epi, int max_blocks_p
         }
     }
     if (out_grid) *out_grid = grid;
-    void *args[] = {const_cast<MatvecArgs *>(&a)};
+    // only the row kernel's single-segment epilogues push (wo, ffn13, ffn2, classifier)
+    if (!use_row || epi == EPI_ROPE || a.rows2 != 0 || (epi != EPI_SWIGLU && a.rows1 != 0)) a.push = nullptr;
+    if (pushed) *pushed = a.push != nullptr;
+    void *args[] = {&a};
     return hipLaunchKernel(k.fn, dim3(grid), dim3(kBlock), args, lds, st);
 }
 
@@ -1537,8 +1569,14 @@ hipError_t launch_attention_split(const AttnArgs &a, int n_heads_local, int nch,
     int ct = (a.head_size + 63) & ~63;
     if (ct > 1024) ct = 1024;
     hipLaunchKernelGGL(attention_combine_kernel, dim3(n_heads_local), dim3(ct), 0, st, part, nch,
-                       a.head_size, a.xb);
+                       a.head_size, a.xb, a.push);
     return hipGetLastError();
+}
+
+bool attention_push_supported(const AttnArgs &a)
+{
+    return (a.head_size % 4) == 0 && (a.kv_dim % 4) == 0 && a.head_size <= 256 && aligned16(a.q) &&
+           aligned16(a.kcache) && aligned16(a.vcache);  // the fast / split kernels, not the generic one
 }
 
 bool attention_split_supported(const AttnArgs &a)

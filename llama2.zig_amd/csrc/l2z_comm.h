@@ -36,5 +36,25 @@ struct P2pArgs {
     int *err;
     long long timeout_ticks;  // wall_clock64 ticks (100 MHz)
 };
-hipError_t launch_p2p_allgather(const P2pArgs &a, hipStream_t st);
+// pushed: the producing kernel has already written this rank's words (MatvecArgs::push)
+hipError_t launch_p2p_allgather(const P2pArgs &a, hipStream_t st, bool pushed = false);
+bool comm_p2p_args(const l2z_comm *c, float *buf, size_t count_per_rank, P2pArgs *out);
+int comm_allgather_inplace_pushed(const l2z_comm *c, float *buf, size_t count_per_rank, hipStream_t st);
+
+#ifdef __HIPCC__
+// LL word of gather `e` for element `idx` of the gathered vector, to every peer (one lane)
+__device__ __forceinline__ void p2p_ll_push(const P2pArgs *a, int e, size_t idx, float v)
+{
+    const unsigned long long w = ((unsigned long long)(unsigned)e << 32) | (unsigned long long)__float_as_uint(v);
+    const int world = a->world, rank = a->rank;
+    const size_t off = (size_t)(e & 1) * a->slot_floats + idx;
+    for (int p = 0; p < world; p++) {
+        if (p == rank) continue;
+        unsigned long long *dst = (unsigned long long *)(a->peer_arena[p] + kP2pFlagBytes) + off;
+        __hip_atomic_store(dst, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// number of the gather this launch feeds (all peers are at the same count)
+__device__ __forceinline__ int p2p_ll_epoch(const P2pArgs *a) { return a->epoch[a->rank == 0 ? 1 : 0] + 1; }
+#endif
 }  // namespace l2z

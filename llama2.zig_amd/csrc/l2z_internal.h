@@ -14,6 +14,8 @@
 
 namespace l2z {
 
+struct P2pArgs;  // l2z_comm.h: device-side description of one peer-write gather
+
 void set_error(const char *fmt, ...);
 
 #define L2Z_HIP(expr)                                                                    \
@@ -75,6 +77,11 @@ struct MatvecArgs {
     float *part_val;
     int *part_idx;
     int row_offset;           // global index of row 0 (vocab shard offset)
+    // Sharded runs, peer-write transport: the writer lane also stores every output value as an LL
+    // word {value, epoch} straight into the peers' landing slots (p2p.hip), so the values travel
+    // while the rest of the launch still runs and the gather that follows only has to collect.
+    // Row kernel only (launch_matvec reports whether it was honoured).  Device memory; may be null.
+    const P2pArgs *push;
 };
 
 // main.zig:361-389: scores, softmax, att.V for the local heads of one layer
@@ -88,6 +95,7 @@ struct AttnArgs {
     int kv_dim;            // local row stride of the caches
     int kv_mul;
     int seq_len;
+    const P2pArgs *push;   // as in MatvecArgs, for xb (fast / split-combine kernels); may be null
 };
 
 // main.zig:715 argmax + main.zig:999-1000,1036 hand-over to the next step
@@ -110,8 +118,11 @@ struct ArgmaxArgs {
 };
 
 // Launchers (kernels.hip).  All return a hipError_t from the launch.
+// pushed: set to whether a.push was honoured (row kernel only)
 hipError_t launch_matvec(const MatvecArgs &a, int pro, int epi, int max_blocks_per_cu, int n_cus,
-                         hipStream_t st, int *out_grid = nullptr);
+                         hipStream_t st, int *out_grid = nullptr, bool *pushed = nullptr);
+// true if launch_attention / launch_attention_split will honour a.push (vector kernels only)
+bool attention_push_supported(const AttnArgs &a);
 int matvec_max_grid(int n_cus);
 // out: >= 8 * n_cus floats of scratch (never written in practice)
 hipError_t launch_stream_read(const float *p, size_t n_floats, float *out, int n_cus, hipStream_t st);  // upper bound of the grid launch_matvec picks

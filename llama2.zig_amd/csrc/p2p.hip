@@ -32,7 +32,7 @@ __device__ __forceinline__ u64 *slot_words(char *arena, int e, size_t slot_float
     return (u64 *)(arena + kP2pFlagBytes) + (size_t)(e & 1) * slot_floats;
 }
 
-__global__ __launch_bounds__(256) void p2p_allgather_kernel(const P2pArgs a)
+__global__ __launch_bounds__(256) void p2p_allgather_kernel(const P2pArgs a, int pushed)
 {
     const int p = blockIdx.x;
     if (p == a.rank) return;  // own slice is already in place
@@ -44,8 +44,8 @@ __global__ __launch_bounds__(256) void p2p_allgather_kernel(const P2pArgs a)
     __syncthreads();
     const int e = s_epoch;
     const u64 tag = (u64)(unsigned)e << 32;
-    // 1. my slice -> peer p's slot
-    {
+    // 1. my slice -> peer p's slot (unless the producing kernel wrote the words itself)
+    if (!pushed) {
         u64 *dst = slot_words(a.peer_arena[p], e, a.slot_floats) + (size_t)a.rank * a.count;
         const float *src = a.buf + (size_t)a.rank * a.count;
         for (size_t i = threadIdx.x; i < a.count; i += blockDim.x)
@@ -91,9 +91,9 @@ __global__ __launch_bounds__(256) void p2p_allgather_kernel(const P2pArgs a)
 
 }  // namespace
 
-hipError_t launch_p2p_allgather(const P2pArgs &a, hipStream_t st)
+hipError_t launch_p2p_allgather(const P2pArgs &a, hipStream_t st, bool pushed)
 {
-    hipLaunchKernelGGL(p2p_allgather_kernel, dim3(a.world), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(p2p_allgather_kernel, dim3(a.world), dim3(256), 0, st, a, pushed ? 1 : 0);
     return hipGetLastError();
 }
 

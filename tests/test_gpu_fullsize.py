@@ -115,12 +115,15 @@ def test_7b_sharded_over_8_emulated_ranks_is_bit_identical(gpu, ck, model7b):
     comms = [gpu.Comm(r, world, None, 0, emulated=True) for r in range(world)]
     ws = [gpu.Weights(cfg, None, False, seed=2024, comm=c) for c in comms]
     ss = [gpu.RunState(cfg, comm=c) for c in comms]
-    for pos, tok in enumerate([1, 31999]):
+    # positions 0, 1 (one block per head) and 300, 2047 (split attention: its chunk count is
+    # taken from the model's total head count so that it does not change with the shard count;
+    # the cache rows in between are still zero on both sides, which is a valid context)
+    for pos, tok in ((0, 1), (1, 31999), (300, 17), (2047, 4242)):
         s0.transformer(tok, pos, w0)
         ref = s0.logits()
         gpu.emu_transformer(ss, ws, tok, pos)
         for r in (0, 3, 7):
-            assert np.array_equal(ss[r].logits(), ref)
+            assert np.array_equal(ss[r].logits(), ref), f"pos {pos} rank {r}"
     for o in ss + ws:
         o.close()
     for c in comms:

@@ -18,6 +18,9 @@ MODELS = [
     ("toy-gqa", dict(dim=64, hidden_dim=176, n_layers=3, n_heads=8, n_kv_heads=4, vocab_size=512, seq_len=96), False, 4),
     ("stories15M-shape-2layers", dict(dim=288, hidden_dim=768, n_layers=2, n_heads=6, n_kv_heads=6, vocab_size=32000, seq_len=256), True, 2),
     ("wide-rows", dict(dim=1024, hidden_dim=4096, n_layers=2, n_heads=8, n_kv_heads=8, vocab_size=4096, seq_len=320), False, 4),
+    # n = 4096: the row kernel, whose writer lanes push their outputs to the peers themselves
+    ("row-kernel-7B-width", dict(dim=4096, hidden_dim=8192, n_layers=2, n_heads=32, n_kv_heads=8, vocab_size=8192, seq_len=320), False, 4),
+    ("row-kernel-7B-width", dict(dim=4096, hidden_dim=8192, n_layers=2, n_heads=32, n_kv_heads=8, vocab_size=8192, seq_len=320), False, 2),
 ]
 
 
@@ -25,7 +28,8 @@ MODELS = [
 def test_multiprocess_peer_write_gather_is_bit_identical(gpu, ck, tmp_path, name, kw, shared, world):
     cfg = ck.Config(**kw)
     steps = min(cfg.seq_len - 2, 300)
-    spec = dict(cfg=kw, shared=shared, seed=33, prompt=[5, 9, 11], steps=steps)
+    on_device = cfg.dim >= 4096  # big shapes: seeded weights generated on the device by every rank
+    spec = dict(cfg=kw, shared=shared, seed=33, prompt=[5, 9, 11], steps=steps, blob=not on_device)
     (tmp_path / "model.json").write_text(json.dumps(spec))
     env = dict(os.environ, L2Z_P2P_TIMEOUT_S="60")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "p2p_worker.py"), str(r), str(world),
@@ -43,8 +47,8 @@ def test_multiprocess_peer_write_gather_is_bit_identical(gpu, ck, tmp_path, name
     for r, p in enumerate(procs):
         assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-2000:]}"
     # unsharded reference in this process
-    blob = ck.synth_blob(cfg, shared, 33)
-    w, s = gpu.Weights(cfg, blob, shared), gpu.RunState(cfg)
+    blob = None if on_device else ck.synth_blob(cfg, shared, 33)
+    w, s = gpu.Weights(cfg, blob, shared, seed=33), gpu.RunState(cfg)
     s.greedy_begin(spec["prompt"])
     toks = s.greedy_run(w, steps)
     logits = s.logits()
