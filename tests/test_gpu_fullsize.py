@@ -110,7 +110,8 @@ def test_7b_layer0_qkv_rows_vs_oracle(gpu, ck, orc, model7b):
 
 
 def test_7b_sharded_over_8_emulated_ranks_is_bit_identical(gpu, ck, model7b):
-    cfg, w0, s0 = model7b
+    cfg, w0, _ = model7b
+    s0 = gpu.RunState(cfg)  # fresh (zero) KV cache, like the emulated ranks' caches
     world = 8
     comms = [gpu.Comm(r, world, None, 0, emulated=True) for r in range(world)]
     ws = [gpu.Weights(cfg, None, False, seed=2024, comm=c) for c in comms]
@@ -124,7 +125,7 @@ def test_7b_sharded_over_8_emulated_ranks_is_bit_identical(gpu, ck, model7b):
         gpu.emu_transformer(ss, ws, tok, pos)
         for r in (0, 3, 7):
             assert np.array_equal(ss[r].logits(), ref), f"pos {pos} rank {r}"
-    for o in ss + ws:
+    for o in ss + ws + [s0]:
         o.close()
     for c in comms:
         c.close()
