@@ -21,6 +21,7 @@ MODELS = [
     # n = 4096: the row kernel, whose writer lanes push their outputs to the peers themselves
     ("row-kernel-7B-width", dict(dim=4096, hidden_dim=8192, n_layers=2, n_heads=32, n_kv_heads=8, vocab_size=8192, seq_len=320), False, 4),
     ("row-kernel-7B-width", dict(dim=4096, hidden_dim=8192, n_layers=2, n_heads=32, n_kv_heads=8, vocab_size=8192, seq_len=320), False, 2),
+    ("row-kernel-7B-width", dict(dim=4096, hidden_dim=8192, n_layers=2, n_heads=32, n_kv_heads=8, vocab_size=8192, seq_len=320), False, 8),
 ]
 
 
