@@ -679,7 +679,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         a.rows0 = sh.v_loc; a.n = c.dim; a.x = s->x; a.rms_w = w->rms_final;
         a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.row_offset = sh.v0;
         // single GPU, vector path: the launch also leaves one argmax candidate per block
-        const bool fuse = sh.world == 1 && c.dim % 4 == 0;
+        const bool fuse = sh.world == 1 && matvec_vector_width(c.dim);
         int grid = 0;
         if (can_push) a.push = s->d_push + 3;
         L2Z_LAUNCH(KIND_CLS, launch_matvec(a, PRO_RMS, fuse ? EPI_ARGMAX : EPI_STORE, mb, g_cus, st,
@@ -1029,8 +1029,10 @@ extern "C" int l2z_prefill(const int32_t *tokens, int n_tokens, int pos0, const 
         a.rms_w = w->rms_final;
         a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.row_offset = 0;
         int grid = 0;
-        L2Z_HIP(launch_matvec(a, PRO_RMS, EPI_ARGMAX, s->max_blocks, g_cus, s->stream, &grid));
-        s->n_part = grid;
+        const bool fuse = matvec_vector_width(c.dim);  // as in enqueue_forward
+        L2Z_HIP(launch_matvec(a, PRO_RMS, fuse ? EPI_ARGMAX : EPI_STORE, s->max_blocks, g_cus, s->stream,
+                              &grid));
+        s->n_part = fuse ? grid : 0;
     }
     L2Z_HIP(hipStreamSynchronize(s->stream));
     s->host_pos = pos0 + n_tokens;

@@ -1456,6 +1456,15 @@ size_t attention_lds_bytes(int head_size, int seq_len, bool vec)
 
 int matvec_max_grid(int n_cus) { return n_cus * 8; }
 
+// widths the vector kernels take (16-byte aligned operands assumed); the rest goes to the generic
+// scalar kernel, which has no fused-argmax epilogue
+bool matvec_vector_width(int n)
+{
+    if (n <= 0 || (n % 4) != 0) return false;
+    const int n4 = n >> 2;
+    return !(lpr_for(n4) == 64 && (n4 % 64) != 0);
+}
+
 hipError_t launch_stream_read(const float *p, size_t n_floats, float *out, int n_cus, hipStream_t st)
 {
     hipLaunchKernelGGL(stream_read_kernel, dim3(n_cus * 8), dim3(256), 0, st, (const v4f *)p, n_floats / 4, out);

@@ -124,6 +124,7 @@ hipError_t launch_matvec(const MatvecArgs &a, int pro, int epi, int max_blocks_p
 // true if launch_attention / launch_attention_split will honour a.push (vector kernels only)
 bool attention_push_supported(const AttnArgs &a);
 int matvec_max_grid(int n_cus);
+bool matvec_vector_width(int n);
 // out: >= 8 * n_cus floats of scratch (never written in practice)
 hipError_t launch_stream_read(const float *p, size_t n_floats, float *out, int n_cus, hipStream_t st);  // upper bound of the grid launch_matvec picks
 hipError_t launch_attention(const AttnArgs &a, int n_heads_local, hipStream_t st);

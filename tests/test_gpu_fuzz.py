@@ -1,0 +1,34 @@
+"""Seeded random model shapes (head sizes 2..128, GQA ratios, odd hidden sizes, tiny and odd
+vocabularies, contexts across the pos-256 attention switch) through the C ABI against the CPU
+oracle -- the sweep that found the classifier path refusing widths like dim 1152 (scripts/
+fuzz_shapes.py; run it with more configs by hand)."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _fuzz():
+    spec = importlib.util.spec_from_file_location("fuzz_shapes", os.path.join(ROOT, "scripts", "fuzz_shapes.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_random_shapes_against_oracle(gpu, ck, orc):
+    lines = []
+    bad = _fuzz().run(24, 20260926, lines.append)
+    assert bad == 0, "\n".join(l for l in lines if not l.startswith("ok "))
+
+
+def test_width_that_takes_the_scalar_kernel_with_classifier(gpu, ck, orc):
+    """dim 1152: (dim/4) % 64 != 0 above the narrow-row range -> generic scalar mat-vec kernel,
+    which has no fused-argmax epilogue; the classifier launch must fall back, not fail."""
+    f = _fuzz()
+    cfg = ck.Config(1152, 2304, 1, 12, 3, 1000, 96)
+    lines = []
+    assert f.check_config(gpu, ck, orc, np.random.default_rng(5), cfg, False, 77, lines.append), lines
