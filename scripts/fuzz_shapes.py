@@ -55,13 +55,28 @@ def random_config(ck, rng):
     return ck.Config(dim, hidden, L, n_heads, n_kv, vocab, seq), bool(rng.integers(0, 2))
 
 
-def run(n_cfg, seed, log=print):
+def random_wide_config(ck, rng):
+    """Row-kernel and 64-lane widths: dim 1024..8192, head sizes 64..256, hidden up to 11008."""
+    hs = int(rng.choice([64, 128, 256]))
+    dim = int(rng.choice([1024, 1536, 2048, 2304, 3072, 4096, 4352, 5120, 8192]))
+    if dim % hs:
+        hs = 64
+    n_heads = dim // hs
+    divs = [d for d in (1, 2, 4, 8) if n_heads % d == 0]
+    n_kv = n_heads // int(rng.choice(divs))
+    hidden = int(rng.choice([dim, 2 * dim + 256, 11008, 4096 + 4 * int(rng.integers(0, 512))]))
+    vocab = int(rng.choice([100, 4000]))
+    seq = int(rng.choice([24, 300]))
+    return ck.Config(dim, hidden, 1, n_heads, n_kv, vocab, seq), bool(rng.integers(0, 2))
+
+
+def run(n_cfg, seed, log=print, wide=False):
     pkg = ge.load_package(); B, ck = pkg.binding, pkg.checkpoint
     orc = ge.load_oracle()
     rng = np.random.default_rng(seed)
     bad = 0
     for it in range(n_cfg):
-        cfg, shared = random_config(ck, rng)
+        cfg, shared = random_wide_config(ck, rng) if wide else random_config(ck, rng)
         try:
             bad += not check_config(B, ck, orc, rng, cfg, shared, 1000 + it, log)
         except Exception as e:  # noqa: BLE001
@@ -73,4 +88,4 @@ def run(n_cfg, seed, log=print):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     sd = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    print("bad:", run(n, sd))
+    print("bad:", run(n, sd, wide=len(sys.argv) > 3 and sys.argv[3] == "wide"))
