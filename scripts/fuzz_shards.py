@@ -1,0 +1,49 @@
+"""Random shapes x random world sizes with emulated ranks (one process, one GPU): every rank's logits
+must equal the unsharded pass bit for bit, at short positions and beyond the pos-256 attention switch.
+usage: fuzz_shards.py [n_configs] [seed]"""
+import os, sys
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, __graft_entry__ as ge
+
+
+def run(n_cfg, seed, log=print):
+    pkg = ge.load_package(); B, ck = pkg.binding, pkg.checkpoint
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for it in range(n_cfg):
+        world = int(rng.choice([2, 3, 4, 6, 8]))
+        hs = int(rng.choice([4, 8, 16, 48, 64, 128]))
+        n_kv = world * int(rng.choice([1, 2]))
+        n_heads = n_kv * int(rng.choice([1, 2, 4]))
+        dim = hs * n_heads
+        hidden = world * int(rng.integers(4, 600)) * 2
+        vocab = world * int(rng.integers(5, 700))
+        seq = int(rng.choice([40, 320]))
+        cfg = ck.Config(dim, hidden, int(rng.integers(1, 3)), n_heads, n_kv, vocab, seq)
+        shared = bool(rng.integers(0, 2))
+        try:
+            w0 = B.Weights(cfg, None, shared, seed=50 + it); s0 = B.RunState(cfg)
+            comms = [B.Comm(r, world, None, 0, emulated=True) for r in range(world)]
+            ws = [B.Weights(cfg, None, shared, seed=50 + it, comm=c) for c in comms]
+            ss = [B.RunState(cfg, comm=c) for c in comms]
+            ok = True
+            for pos in ([0, 1, 2, 17] + ([300] if seq > 300 else [])):
+                tok = int(rng.integers(0, vocab))
+                s0.transformer(tok, pos, w0)
+                B.emu_transformer(ss, ws, tok, pos)
+                ref = s0.logits()
+                ok = ok and all(np.array_equal(x.logits(), ref) for x in ss) and bool(np.isfinite(ref).all())
+            log(f"{'ok ' if ok else 'BAD'} world {world} dim {dim} hs {hs} H {n_heads} kv {n_kv} hid {hidden} V {vocab} S {seq} L {cfg.n_layers} shared {int(shared)}")
+            bad += not ok
+            for o in ss + ws + [s0, w0]:
+                o.close()
+            for c in comms:
+                c.close()
+        except Exception as e:  # noqa: BLE001
+            log(f"ERR world {world} {cfg}: {e}")
+            bad += 1
+    return bad
+
+
+if __name__ == "__main__":
+    print("bad:", run(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 0))

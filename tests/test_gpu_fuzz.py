@@ -12,8 +12,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _fuzz():
-    spec = importlib.util.spec_from_file_location("fuzz_shapes", os.path.join(ROOT, "scripts", "fuzz_shapes.py"))
+def _fuzz(name="fuzz_shapes"):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "scripts", name + ".py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
@@ -32,3 +32,11 @@ def test_width_that_takes_the_scalar_kernel_with_classifier(gpu, ck, orc):
     cfg = ck.Config(1152, 2304, 1, 12, 3, 1000, 96)
     lines = []
     assert f.check_config(gpu, ck, orc, np.random.default_rng(5), cfg, False, 77, lines.append), lines
+
+
+def test_random_shapes_and_world_sizes_sharded_bit_identical(gpu):
+    """Emulated ranks (world 2, 3, 4, 6, 8) on random shapes: every rank's logits equal the
+    unsharded pass bit for bit, also beyond the pos-256 attention switch (scripts/fuzz_shards.py)."""
+    lines = []
+    bad = _fuzz("fuzz_shards").run(16, 20260926, lines.append)
+    assert bad == 0, "\n".join(l for l in lines if not l.startswith("ok "))
