@@ -1,0 +1,38 @@
+"""Random shapes x world sizes with REAL processes on one GPU through the peer-write transport
+(tests/p2p_worker.py): tokens and logits of every rank must equal the unsharded run bit for bit.
+usage: fuzz_p2p.py [n_configs] [seed]"""
+import json, os, subprocess, sys, tempfile
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np, __graft_entry__ as ge
+pkg = ge.load_package(); B, ck = pkg.binding, pkg.checkpoint
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 8):
+    world = int(rng.choice([2, 3, 4, 5, 8]))
+    hs = int(rng.choice([2, 6, 16, 64, 128]))
+    n_kv = world * int(rng.choice([1, 2])); n_heads = n_kv * int(rng.choice([1, 2]))
+    dim = hs * n_heads
+    kw = dict(dim=dim, hidden_dim=world * int(rng.integers(3, 500)), n_layers=int(rng.integers(1, 3)), n_heads=n_heads,
+              n_kv_heads=n_kv, vocab_size=world * int(rng.integers(3, 400)), seq_len=int(rng.choice([48, 300])))
+    cfg = ck.Config(**kw); shared = bool(rng.integers(0, 2))
+    steps = cfg.seq_len - 2
+    with tempfile.TemporaryDirectory() as d:
+        spec = dict(cfg=kw, shared=shared, seed=it, prompt=[2, 3], steps=steps, blob=True)
+        json.dump(spec, open(os.path.join(d, "m.json"), "w"))
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "p2p_worker.py"), str(r), str(world), d,
+                                   os.path.join(d, "m.json")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                  env=dict(os.environ, L2Z_P2P_TIMEOUT_S="60")) for r in range(world)]
+        outs = [p.communicate(timeout=300)[0].decode(errors="replace") for p in procs]
+        ok = all(p.returncode == 0 for p in procs)
+        if ok:
+            w, s = B.Weights(cfg, ck.synth_blob(cfg, shared, it), shared), B.RunState(cfg)
+            s.greedy_begin([2, 3]); toks = s.greedy_run(w, steps); lg = s.logits()
+            for r in range(world):
+                o = np.load(os.path.join(d, f"out_{r}.npz"))
+                ok = ok and np.array_equal(o["toks"], toks) and np.array_equal(o["logits"], lg)
+            s.close(); w.close()
+        else:
+            print("\n".join(x[-400:] for x in outs))
+    print(("ok " if ok else "BAD"), "world", world, kw, "shared", int(shared)); bad += not ok
+print("bad:", bad)
