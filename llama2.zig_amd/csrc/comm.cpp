@@ -203,6 +203,18 @@ extern "C" int l2z_comm_p2p_connect(l2z_comm *c, const void *handles)
     L2Z_CHECK(c->arena != nullptr && !c->p2p, L2Z_ERR_STATE,
               "l2z_comm_p2p_connect: call l2z_comm_p2p_export first (once)");
     L2Z_HIP(hipSetDevice(c->device));
+    {   // best effort: kernels here store straight into the peers' memory, so make sure peer access
+        // is on for every other visible GPU (hipIpcOpenMemHandle's lazy flag covers copies; errors
+        // such as "already enabled" or "not supported" are not fatal -- the open below decides)
+        int n_dev = 0;
+        if (hipGetDeviceCount(&n_dev) == hipSuccess)
+            for (int d = 0; d < n_dev; d++) {
+                int can = 0;
+                if (d != c->device && hipDeviceCanAccessPeer(&can, c->device, d) == hipSuccess && can)
+                    (void)hipDeviceEnablePeerAccess(d, 0);
+            }
+        (void)hipGetLastError();  // clear a sticky "peer access already enabled"
+    }
     for (int r = 0; r < c->world; r++) {
         if (r == c->rank) {
             c->peer_arena[r] = c->arena;
