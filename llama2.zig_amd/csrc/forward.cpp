@@ -1,0 +1,454 @@
+// forward.cpp -- transformer() (main.zig:285-430) as a chain of fused launches, its hipGraph
+// capture, the on-device greedy loop (main.zig:987-1042 at temperature 0), per-kind profiling and
+// the emulated-rank driver.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "l2z_state.h"
+
+namespace l2z {
+
+struct Prof {
+    std::vector<hipEvent_t> ev;   // pairs
+    std::vector<int> kind;
+};
+
+#define L2Z_LAUNCH(kind_id, expr)                                                         \
+    do {                                                                                  \
+        hipEvent_t _a = nullptr, _b = nullptr;                                            \
+        if (prof) {                                                                       \
+            L2Z_HIP(hipEventCreate(&_a));                                                 \
+            L2Z_HIP(hipEventCreate(&_b));                                                 \
+            L2Z_HIP(hipEventRecord(_a, st));                                              \
+        }                                                                                 \
+        L2Z_HIP(expr);                                                                    \
+        if (prof) {                                                                       \
+            L2Z_HIP(hipEventRecord(_b, st));                                              \
+            prof->ev.push_back(_a);                                                       \
+            prof->ev.push_back(_b);                                                       \
+            prof->kind.push_back(kind_id);                                                \
+        }                                                                                 \
+    } while (0)
+
+int check_pair(const l2z_config *config, const l2z_runstate *s, const l2z_weights *w)
+{
+    L2Z_CHECK(config && s && w, L2Z_ERR_INVALID, "null config / runstate / weights");
+    L2Z_CHECK(memcmp(config, &s->cfg, sizeof *config) == 0 &&
+                  memcmp(config, &w->cfg, sizeof *config) == 0,
+              L2Z_ERR_INVALID, "config does not match the one RunState / Weights were built with");
+    L2Z_CHECK(s->device == w->device && s->sh.rank == w->sh.rank && s->sh.world == w->sh.world,
+              L2Z_ERR_INVALID, "RunState and Weights live on different devices / shards");
+    return L2Z_OK;
+}
+
+// The forward pass (main.zig:285-430) as 5 launches per layer + classifier
+// (+ argmax/hand-over).  Token and pos are read from device memory.
+// `only_stage` >= 0 runs just the launches between two gather points (and no collective):
+// the single-process multi-rank emulation (l2z_emu_transformer) interleaves the ranks
+// stage by stage and performs the gathers itself.  Stages: 4 per layer (after attention,
+// wo, ffn13, ffn2), then the classifier, then argmax.
+int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof *prof,
+                    int only_stage, bool split)
+{
+    const l2z_config &c = s->cfg;
+    const Shard &sh = s->sh;
+    hipStream_t st = s->stream;
+    const size_t dim = c.dim, hid = c.hidden_dim;
+    const int mb = s->max_blocks;
+    int stage = 0;
+    auto want = [&]() { return only_stage < 0 || only_stage == stage; };
+    // Peer-write transport: kernels that can, store their outputs as LL words straight into the
+    // peers' slots (the values travel while the launch still runs); the gather that follows then
+    // only collects.  `pushed` = the launch just made did.  Not while profiling (the gather's
+    // share would be hidden in the kernel's time), not for emulated ranks, not with L2Z_COMM=rccl.
+    static const bool push_env = !(getenv("L2Z_P2P_PUSH") && atoi(getenv("L2Z_P2P_PUSH")) == 0) &&
+                                 !(getenv("L2Z_COMM") && strcmp(getenv("L2Z_COMM"), "rccl") == 0);
+    const bool can_push = push_env && s->d_push != nullptr && prof == nullptr && only_stage < 0;
+    bool pushed = false;
+    auto gather = [&](float *buf, size_t count_per_rank) -> int {
+        stage++;
+        if (only_stage >= 0) return L2Z_OK;
+        if (pushed) {
+            pushed = false;
+            return comm_allgather_inplace_pushed(s->comm, buf, count_per_rank, st);
+        }
+        return comm_allgather_inplace(s->comm, buf, count_per_rank, st);
+    };
+    for (int l = 0; l < c.n_layers; l++) {
+        float *kc = s->key_cache + (size_t)l * c.seq_len * sh.kvd_loc;  // :354 loff
+        float *vc = s->value_cache + (size_t)l * c.seq_len * sh.kvd_loc;
+        if (want()) {   // rmsnorm (:305) + q,k,v (:308-320) + RoPE (:336-351) + KV write (:354-358)
+            MatvecArgs a = {};
+            a.w0 = w->wq + (size_t)l * sh.dim_loc * dim;
+            a.w1 = w->wk + (size_t)l * sh.kvd_loc * dim;
+            a.w2 = w->wv + (size_t)l * sh.kvd_loc * dim;
+            a.out0 = s->q; a.out1 = kc; a.out2 = vc;
+            a.rows0 = sh.dim_loc; a.rows1 = sh.kvd_loc; a.rows2 = sh.kvd_loc;
+            a.pos_stride1 = sh.kvd_loc; a.pos_stride2 = sh.kvd_loc;
+            a.n = c.dim; a.x = s->x; a.rms_w = w->rms_att + (size_t)l * dim;
+            a.pos_ptr = s->d_pos; a.rope = s->rope; a.head_size = sh.hs; a.rope_segs = 2;
+            L2Z_LAUNCH(KIND_QKV, launch_matvec(a, PRO_RMS, EPI_ROPE, mb, g_cus, st));
+        }
+        if (want()) {   // attention (:361-389) over the local heads
+            AttnArgs a = {};
+            a.q = s->q; a.kcache = kc; a.vcache = vc; a.xb = s->xb + sh.dim0;
+            a.pos_ptr = s->d_pos; a.head_size = sh.hs; a.kv_dim = sh.kvd_loc;
+            a.kv_mul = c.n_heads / c.n_kv_heads; a.seq_len = c.seq_len;
+            if (can_push && attention_push_supported(a)) {
+                a.push = s->d_push + 0;
+                pushed = true;
+            }
+            if (split && s->attn_nch > 1 && attention_split_supported(a))
+                L2Z_LAUNCH(KIND_ATTN, launch_attention_split(a, sh.heads_loc, s->attn_nch,
+                                                             s->d_attn_part, st));
+            else
+                L2Z_LAUNCH(KIND_ATTN, launch_attention(a, sh.heads_loc, st));
+        }
+        L2Z_TRY(gather(s->xb, sh.dim_loc));
+        if (want()) {   // wo (:392) + residual (:395)
+            MatvecArgs a = {};
+            a.w0 = w->wo + (size_t)l * sh.dim_loc * dim;
+            a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0;
+            a.rows0 = sh.dim_loc; a.n = c.dim; a.x = s->xb;
+            if (can_push) a.push = s->d_push + 1;
+            L2Z_LAUNCH(KIND_WO, launch_matvec(a, PRO_NONE, EPI_RESID, mb, g_cus, st, nullptr, &pushed));
+        }
+        L2Z_TRY(gather(s->x, sh.dim_loc));
+        if (want()) {   // rmsnorm (:398) + w1,w3 (:405-408) + SiLU*mul (:411-416)
+            MatvecArgs a = {};
+            a.w0 = w->w1 + (size_t)l * sh.hid_loc * dim;
+            a.w1 = w->w3 + (size_t)l * sh.hid_loc * dim;
+            a.out0 = s->hb + sh.hid0;
+            a.rows0 = sh.hid_loc; a.rows1 = sh.hid_loc; a.n = c.dim;
+            a.x = s->x; a.rms_w = w->rms_ffn + (size_t)l * dim;
+            if (can_push) a.push = s->d_push + 2;
+            L2Z_LAUNCH(KIND_FFN13, launch_matvec(a, PRO_RMS, EPI_SWIGLU, mb, g_cus, st, nullptr, &pushed));
+        }
+        L2Z_TRY(gather(s->hb, sh.hid_loc));
+        if (want()) {   // w2 (:419) + residual (:422)
+            MatvecArgs a = {};
+            a.w0 = w->w2 + (size_t)l * sh.dim_loc * hid;
+            a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0;
+            a.rows0 = sh.dim_loc; a.n = c.hidden_dim; a.x = s->hb;
+            if (can_push) a.push = s->d_push + 1;
+            L2Z_LAUNCH(KIND_FFN2, launch_matvec(a, PRO_NONE, EPI_RESID, mb, g_cus, st, nullptr, &pushed));
+        }
+        L2Z_TRY(gather(s->x, sh.dim_loc));
+    }
+    if (want()) {   // final rmsnorm (:426) + classifier (:429)
+        MatvecArgs a = {};
+        a.w0 = w->wcls; a.out0 = s->logits + sh.v0;
+        a.rows0 = sh.v_loc; a.n = c.dim; a.x = s->x; a.rms_w = w->rms_final;
+        a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.row_offset = sh.v0;
+        // single GPU, vector path: the launch also leaves one argmax candidate per block
+        const bool fuse = sh.world == 1 && matvec_vector_width(c.dim);
+        int grid = 0;
+        if (can_push) a.push = s->d_push + 3;
+        L2Z_LAUNCH(KIND_CLS, launch_matvec(a, PRO_RMS, fuse ? EPI_ARGMAX : EPI_STORE, mb, g_cus, st,
+                                           &grid, &pushed));
+        s->n_part = fuse ? grid : 0;
+    }
+    L2Z_TRY(gather(s->logits, sh.v_loc));
+    if (with_step && want()) {
+        ArgmaxArgs a = {};
+        a.logits = s->logits; a.vocab = c.vocab_size; a.token_ptr = s->d_token;
+        if (s->n_part > 0) { a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.n_part = s->n_part; }
+        a.pos_ptr = s->d_pos; a.prompt = s->d_prompt; a.n_prompt_ptr = s->d_n_prompt;
+        a.out_tokens = s->d_out_tokens; a.argmax_out = s->d_argmax; a.tok_emb = w->tok_emb;
+        a.x = s->x; a.dim = c.dim; a.advance = 1;
+        L2Z_LAUNCH(KIND_ARGMAX, launch_argmax(a, st));
+    }
+    return L2Z_OK;
+}
+
+bool use_split(const l2z_runstate *s, int pos) { return s->attn_nch > 1 && pos >= s->attn_split_pos; }
+
+int build_graph(l2z_runstate *s, const l2z_weights *w, bool with_step, bool split,
+                hipGraphExec_t *out)
+{
+    hipGraph_t graph = nullptr;
+    L2Z_HIP(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+    int rc = enqueue_forward(s, w, with_step, nullptr, -1, split);
+    hipError_t e = hipStreamEndCapture(s->stream, &graph);
+    if (rc != L2Z_OK) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+    }
+    L2Z_HIP(e);
+    e = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    L2Z_HIP(e);
+    return L2Z_OK;
+}
+
+void drop_graphs(l2z_runstate *s)
+{
+    for (int v = 0; v < 2; v++) {
+        if (s->g_forward[v]) { (void)hipGraphExecDestroy(s->g_forward[v]); s->g_forward[v] = nullptr; }
+        if (s->g_step[v]) { (void)hipGraphExecDestroy(s->g_step[v]); s->g_step[v] = nullptr; }
+    }
+    s->graph_w = nullptr;
+}
+
+int ensure_graphs(l2z_runstate *s, const l2z_weights *w)
+{
+    if (!s->use_graphs) return L2Z_OK;
+    if (s->graph_w == w && s->g_forward[0] && s->g_step[0]) return L2Z_OK;
+    drop_graphs(s);
+    const int n_var = s->attn_nch > 1 ? 2 : 1;
+    int rc = L2Z_OK;
+    for (int v = 0; v < n_var && rc == L2Z_OK; v++) {
+        rc = build_graph(s, w, false, v == 1, &s->g_forward[v]);
+        if (rc == L2Z_OK) rc = build_graph(s, w, true, v == 1, &s->g_step[v]);
+    }
+    if (rc != L2Z_OK) {
+        // capture is an optimisation, not a requirement: run the same launches eagerly
+        fprintf(stderr, "llama2_hip: hipGraph capture failed (%s); launching eagerly\n", l2z_last_error());
+        drop_graphs(s);
+        s->use_graphs = false;
+        (void)hipGetLastError();
+        return L2Z_OK;
+    }
+    s->graph_w = w;
+    return L2Z_OK;
+}
+
+// one forward pass at position `pos` (the host mirrors the device-side pos)
+int run_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, int pos)
+{
+    const bool split = use_split(s, pos);
+    L2Z_CHECK(s->sh.world == 1 || (s->comm && (s->comm->nccl || s->comm->p2p)), L2Z_ERR_STATE,
+              "sharded runstate without a transport: connect the group (RCCL id or "
+              "l2z_comm_p2p_export/_connect), or drive emulated ranks with l2z_emu_transformer");
+    L2Z_TRY(comm_check(s->comm));
+    L2Z_TRY(ensure_graphs(s, w));
+    if (s->use_graphs) {
+        const int v = split ? 1 : 0;
+        L2Z_HIP(hipGraphLaunch(with_step ? s->g_step[v] : s->g_forward[v], s->stream));
+        return L2Z_OK;
+    }
+    return enqueue_forward(s, w, with_step, nullptr, -1, split);
+}
+
+
+}  // namespace l2z
+
+using namespace l2z;
+
+// src/main.zig:285 transformer(token, pos, config, s, w)
+extern "C" int l2z_transformer(int token, int pos, const l2z_config *config, l2z_runstate *s,
+                               const l2z_weights *w)
+{
+    L2Z_TRY(check_pair(config, s, w));
+    L2Z_CHECK(token >= 0 && token < config->vocab_size, L2Z_ERR_STATE, "token %d out of range", token);
+    L2Z_CHECK(pos >= 0 && pos < config->seq_len, L2Z_ERR_STATE, "pos %d out of range [0,%d)", pos,
+              config->seq_len);
+    L2Z_HIP(hipSetDevice(s->device));
+    L2Z_HIP(launch_set_state(token, pos, s->d_token, s->d_pos, w->tok_emb, s->x, config->dim,
+                             s->stream));
+    L2Z_TRY(run_forward(s, w, false, pos));
+    s->host_pos = pos + 1;
+    return L2Z_OK;
+}
+
+extern "C" int l2z_argmax(l2z_runstate *s, int *out_token)
+{
+    L2Z_CHECK(s && out_token, L2Z_ERR_INVALID, "l2z_argmax: null argument");
+    L2Z_HIP(hipSetDevice(s->device));
+    ArgmaxArgs a = {};
+    a.logits = s->logits; a.vocab = s->cfg.vocab_size; a.argmax_out = s->d_argmax; a.advance = 0;
+    if (s->n_part > 0) { a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.n_part = s->n_part; }
+    L2Z_HIP(launch_argmax(a, s->stream));
+    L2Z_HIP(hipMemcpyAsync(out_token, s->d_argmax, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    L2Z_HIP(hipStreamSynchronize(s->stream));
+    return L2Z_OK;
+}
+
+extern "C" int l2z_logits_read(l2z_runstate *s, float *out_logits)
+{
+    L2Z_CHECK(s && out_logits, L2Z_ERR_INVALID, "l2z_logits_read: null argument");
+    L2Z_HIP(hipSetDevice(s->device));
+    L2Z_HIP(hipMemcpyAsync(out_logits, s->logits, (size_t)s->cfg.vocab_size * sizeof(float),
+                           hipMemcpyDeviceToHost, s->stream));
+    L2Z_HIP(hipStreamSynchronize(s->stream));
+    L2Z_TRY(comm_check(s->comm));
+    return L2Z_OK;
+}
+
+// ---------------------------------------------------------------------------
+// src/main.zig:987-1042 at temperature 0
+extern "C" int l2z_greedy_begin(l2z_runstate *s, const int32_t *prompt, int n_prompt)
+{
+    L2Z_CHECK(s != nullptr && n_prompt >= 0 && (n_prompt == 0 || prompt != nullptr),
+              L2Z_ERR_INVALID, "l2z_greedy_begin: bad arguments");
+    L2Z_CHECK(n_prompt <= s->cfg.seq_len, L2Z_ERR_INVALID, "prompt longer than seq_len");
+    for (int i = 0; i < n_prompt; i++)
+        L2Z_CHECK(prompt[i] >= 0 && prompt[i] < s->cfg.vocab_size, L2Z_ERR_INVALID,
+                  "prompt[%d] = %d out of vocabulary", i, prompt[i]);
+    L2Z_HIP(hipSetDevice(s->device));
+    L2Z_HIP(hipStreamSynchronize(s->stream));
+    if (n_prompt)
+        L2Z_HIP(hipMemcpy(s->d_prompt, prompt, (size_t)n_prompt * sizeof(int), hipMemcpyHostToDevice));
+    L2Z_HIP(hipMemcpy(s->d_n_prompt, &n_prompt, sizeof(int), hipMemcpyHostToDevice));
+    s->h_prompt.assign(prompt, prompt + n_prompt);
+    s->host_pos = 0;
+    s->done = false;
+    return L2Z_OK;
+}
+
+extern "C" int l2z_greedy_run(const l2z_config *config, l2z_runstate *s, const l2z_weights *w,
+                              int n_steps, int32_t *out_tokens, int *out_n)
+{
+    L2Z_TRY(check_pair(config, s, w));
+    L2Z_CHECK(out_tokens && out_n && n_steps >= 0, L2Z_ERR_INVALID, "l2z_greedy_run: bad arguments");
+    *out_n = 0;
+    L2Z_HIP(hipSetDevice(s->device));
+    if (s->done) return L2Z_OK;
+    int remaining = n_steps;
+    if (remaining > config->seq_len - s->host_pos) remaining = config->seq_len - s->host_pos;
+    if (remaining <= 0) return L2Z_OK;
+    if (s->host_pos == 0) {
+        // token = 1 (BOS, main.zig:988), pos = 0, x = embedding row of BOS
+        L2Z_HIP(launch_set_state(1, 0, s->d_token, s->d_pos, w->tok_emb, s->x, config->dim,
+                                 s->stream));
+    }
+    const int kChunk = 64;  // host looks for BOS (main.zig:1017) once per chunk
+    int produced = 0;
+    // Prompt positions (main.zig:999-1000 forces next = prompt[pos], the logits there are never
+    // looked at) run as one batched pass: inputs BOS, prompt[0..n-2] at positions 0..n-1, then
+    // the loop resumes at pos = n with token = prompt[n-1].  Only when this call covers the whole
+    // prompt, no prompt token is BOS (the loop would stop there, :1017) and L2Z_PREFILL != 0.
+    const int np = (int)s->h_prompt.size();
+    if (s->host_pos == 0 && np >= kPrefillMinPrompt && remaining >= np && prefill_enabled() &&
+        s->sh.world == 1 && config->dim % 4 == 0 && config->hidden_dim % 4 == 0 &&
+        s->sh.hs % 4 == 0 && s->sh.hs <= 256 &&
+        std::find(s->h_prompt.begin(), s->h_prompt.end(), 1) == s->h_prompt.end()) {
+        std::vector<int32_t> in((size_t)np);
+        in[0] = 1;
+        for (int i = 1; i < np; i++) in[(size_t)i] = s->h_prompt[(size_t)i - 1];
+        L2Z_TRY(prefill_tokens(s, w, in.data(), np, 0));
+        L2Z_HIP(hipMemcpyAsync(s->d_out_tokens, s->d_prompt, (size_t)np * sizeof(int),
+                               hipMemcpyDeviceToDevice, s->stream));
+        L2Z_HIP(launch_set_state(s->h_prompt[(size_t)np - 1], np, s->d_token, s->d_pos, w->tok_emb,
+                                 s->x, config->dim, s->stream));
+        for (int i = 0; i < np; i++) out_tokens[i] = s->h_prompt[(size_t)i];
+        produced = np;
+        s->host_pos = np;
+        remaining -= np;
+    }
+    while (remaining > 0 && !s->done) {
+        const int n = remaining < kChunk ? remaining : kChunk;
+        for (int i = 0; i < n; i++) L2Z_TRY(run_forward(s, w, true, s->host_pos + i));
+        L2Z_HIP(hipMemcpyAsync(out_tokens + produced, s->d_out_tokens + s->host_pos,
+                               (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        L2Z_HIP(hipStreamSynchronize(s->stream));
+        L2Z_TRY(comm_check(s->comm));
+        int got = n;
+        for (int i = 0; i < n; i++) {
+            if (out_tokens[produced + i] == 1) {  // BOS ends the sequence
+                got = i + 1;
+                s->done = true;
+                break;
+            }
+        }
+        produced += got;
+        s->host_pos += got;
+        remaining -= n;
+    }
+    *out_n = produced;
+    return L2Z_OK;
+}
+
+// ---------------------------------------------------------------------------
+// One forward pass launched eagerly with a HIP event pair around every kernel:
+// per-kind device time, measured live on the stream the kernels run on.
+extern "C" int l2z_profile_forward(int token, int pos, const l2z_config *config, l2z_runstate *s,
+                                   const l2z_weights *w, double *ms_by_kind, int *launches_by_kind,
+                                   int n_kinds)
+{
+    L2Z_TRY(check_pair(config, s, w));
+    L2Z_CHECK(ms_by_kind && launches_by_kind && n_kinds >= KIND_COUNT, L2Z_ERR_INVALID,
+              "l2z_profile_forward: need %d kind slots", (int)KIND_COUNT);
+    L2Z_CHECK(token >= 0 && token < config->vocab_size && pos >= 0 && pos < config->seq_len,
+              L2Z_ERR_STATE, "token/pos out of range");
+    L2Z_HIP(hipSetDevice(s->device));
+    L2Z_HIP(launch_set_state(token, pos, s->d_token, s->d_pos, w->tok_emb, s->x, config->dim,
+                             s->stream));
+    Prof prof;
+    int rc = enqueue_forward(s, w, true, &prof, -1, use_split(s, pos));
+    hipError_t e = hipStreamSynchronize(s->stream);
+    for (int k = 0; k < n_kinds; k++) { ms_by_kind[k] = 0.0; launches_by_kind[k] = 0; }
+    if (rc == L2Z_OK && e == hipSuccess) {
+        for (size_t i = 0; i < prof.kind.size(); i++) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, prof.ev[2 * i], prof.ev[2 * i + 1]) == hipSuccess) {
+                ms_by_kind[prof.kind[i]] += ms;
+                launches_by_kind[prof.kind[i]] += 1;
+            }
+        }
+    }
+    for (hipEvent_t ev : prof.ev) (void)hipEventDestroy(ev);
+    s->host_pos = pos + 1;
+    if (rc != L2Z_OK) return rc;
+    L2Z_HIP(e);
+    return L2Z_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Single-process emulation of an N-rank shard group on ONE GPU (testing support): the
+// dev box has one GPU and RCCL refuses two ranks on one device, so this runs the exact
+// per-rank launches of enqueue_forward for every emulated rank, stage by stage, and does
+// each all-gather as device-to-device copies.  Validates sharded upload, shard offsets,
+// KV-cache sharding and GQA head mapping of the real HIP code without a second GPU.
+extern "C" int l2z_emu_transformer(int n_ranks, l2z_runstate *const *ss,
+                                   const l2z_weights *const *ws, int token, int pos)
+{
+    L2Z_CHECK(n_ranks >= 1 && ss && ws, L2Z_ERR_INVALID, "l2z_emu_transformer: bad arguments");
+    const l2z_config &c = ss[0]->cfg;
+    for (int r = 0; r < n_ranks; r++) {
+        L2Z_TRY(check_pair(&c, ss[r], ws[r]));
+        L2Z_CHECK(ss[r]->sh.world == n_ranks && ss[r]->sh.rank == r, L2Z_ERR_INVALID,
+                  "l2z_emu_transformer: runstate %d is not rank %d of %d", r, r, n_ranks);
+        L2Z_HIP(launch_set_state(token, pos, ss[r]->d_token, ss[r]->d_pos, ws[r]->tok_emb, ss[r]->x,
+                                 c.dim, ss[r]->stream));
+    }
+    const int n_stages = 4 * c.n_layers + 1;
+    for (int stage = 0; stage < n_stages; stage++) {
+        for (int r = 0; r < n_ranks; r++)
+            L2Z_TRY(enqueue_forward(ss[r], ws[r], false, nullptr, stage, use_split(ss[r], pos)));
+        for (int r = 0; r < n_ranks; r++) L2Z_HIP(hipStreamSynchronize(ss[r]->stream));
+        // which buffer this stage produced, and the per-rank slice length
+        const Shard &sh0 = ss[0]->sh;
+        size_t count;
+        int which;  // 0 xb, 1 x, 2 hb, 3 logits
+        if (stage == n_stages - 1) { which = 3; count = sh0.v_loc; }
+        else if (stage % 4 == 0) { which = 0; count = sh0.dim_loc; }
+        else if (stage % 4 == 2) { which = 2; count = sh0.hid_loc; }
+        else { which = 1; count = sh0.dim_loc; }
+        auto buf = [&](l2z_runstate *s) {
+            return which == 0 ? s->xb : which == 1 ? s->x : which == 2 ? s->hb : s->logits;
+        };
+        for (int src = 0; src < n_ranks; src++)
+            for (int dst = 0; dst < n_ranks; dst++)
+                if (dst != src)
+                    L2Z_HIP(hipMemcpy(buf(ss[dst]) + (size_t)src * count,
+                                      buf(ss[src]) + (size_t)src * count, count * sizeof(float),
+                                      hipMemcpyDeviceToDevice));
+        // D2D hipMemcpy runs on the null stream and may return early; the ranks' streams are
+        // non-blocking, so order the next stage behind the copies explicitly
+        L2Z_HIP(hipDeviceSynchronize());
+    }
+    for (int r = 0; r < n_ranks; r++) ss[r]->host_pos = pos + 1;
+    return L2Z_OK;
+}
+
+extern "C" int l2z_kind_name(int kind, char *out, size_t cap)
+{
+    L2Z_CHECK(kind >= 0 && kind < KIND_COUNT && out && cap, L2Z_ERR_INVALID, "l2z_kind_name: bad kind");
+    snprintf(out, cap, "%s", kKindNames[kind]);
+    return L2Z_OK;
+}
+

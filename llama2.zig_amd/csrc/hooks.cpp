@@ -1,0 +1,136 @@
+// hooks.cpp -- kernel-level entry points of the C ABI (tests, and the reference's own unit-test shapes).
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "l2z_state.h"
+
+using namespace l2z;
+
+// ---------------------------------------------------------------------------
+// Kernel-level test hooks: upload, run the SAME device code the forward pass
+// uses, download.
+namespace {
+struct DevBuf {
+    float *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) { L2Z_HIP(hipMalloc(&p, (n ? n : 1) * sizeof(float))); return L2Z_OK; }
+    int up(const float *h, size_t n) { L2Z_HIP(hipMemcpy(p, h, n * sizeof(float), hipMemcpyHostToDevice)); return L2Z_OK; }
+    int down(float *h, size_t n) { L2Z_HIP(hipMemcpy(h, p, n * sizeof(float), hipMemcpyDeviceToHost)); return L2Z_OK; }
+};
+}  // namespace
+
+extern "C" int l2z_matmul_fused(int N, float *const *outs, const float *x, const float *const *ws,
+                                size_t n, size_t d)
+{
+    L2Z_CHECK(N >= 1 && N <= kMaxSeg && outs && x && ws && n > 0 && d > 0, L2Z_ERR_INVALID,
+              "l2z_matmul_fused: bad arguments");
+    L2Z_CHECK(n < (1u << 30) && d < (1u << 30), L2Z_ERR_INVALID, "l2z_matmul_fused: too large");
+    L2Z_TRY(ensure_device(current_device_for(nullptr)));
+    DevBuf dx, dw[kMaxSeg], dout[kMaxSeg];
+    L2Z_TRY(dx.alloc(n));
+    L2Z_TRY(dx.up(x, n));
+    MatvecArgs a = {};
+    a.n = (int)n; a.x = dx.p;
+    for (int j = 0; j < N; j++) {
+        L2Z_TRY(dw[j].alloc(n * d));
+        L2Z_TRY(dw[j].up(ws[j], n * d));
+        L2Z_TRY(dout[j].alloc(d));
+    }
+    a.w0 = dw[0].p; a.out0 = dout[0].p; a.rows0 = (int)d;
+    if (N > 1) { a.w1 = dw[1].p; a.out1 = dout[1].p; a.rows1 = (int)d; }
+    if (N > 2) { a.w2 = dw[2].p; a.out2 = dout[2].p; a.rows2 = (int)d; }
+    L2Z_HIP(launch_matvec(a, PRO_NONE, EPI_STORE, 8, g_cus, nullptr));
+    L2Z_HIP(hipDeviceSynchronize());
+    for (int j = 0; j < N; j++) L2Z_TRY(dout[j].down(outs[j], d));
+    return L2Z_OK;
+}
+
+extern "C" int l2z_matmul(float *xout, const float *x, const float *w, size_t n, size_t d)
+{
+    float *outs[1] = {xout};
+    const float *ws[1] = {w};
+    return l2z_matmul_fused(1, outs, x, ws, n, d);
+}
+
+extern "C" int l2z_rmsnorm(float *o, const float *x, const float *w, size_t n)
+{
+    L2Z_CHECK(o && x && w && n > 0 && n < (1u << 30), L2Z_ERR_INVALID, "l2z_rmsnorm: bad arguments");
+    L2Z_CHECK(matvec_lds_bytes((int)n) <= 160 * 1024, L2Z_ERR_INVALID, "l2z_rmsnorm: n too large for LDS");
+    L2Z_TRY(ensure_device(current_device_for(nullptr)));
+    DevBuf dx, dw, dout;
+    L2Z_TRY(dx.alloc(n)); L2Z_TRY(dw.alloc(n)); L2Z_TRY(dout.alloc(n));
+    L2Z_TRY(dx.up(x, n)); L2Z_TRY(dw.up(w, n));
+    L2Z_HIP(launch_rmsnorm(dout.p, dx.p, dw.p, (int)n, nullptr));
+    L2Z_HIP(hipDeviceSynchronize());
+    return dout.down(o, n);
+}
+
+extern "C" int l2z_softmax(float *x, size_t n)
+{
+    L2Z_CHECK(x && n > 0 && n < (1u << 30), L2Z_ERR_INVALID, "l2z_softmax: bad arguments");
+    L2Z_TRY(ensure_device(current_device_for(nullptr)));
+    DevBuf dx;
+    L2Z_TRY(dx.alloc(n)); L2Z_TRY(dx.up(x, n));
+    L2Z_HIP(launch_softmax(dx.p, (int)n, nullptr));
+    L2Z_HIP(hipDeviceSynchronize());
+    return dx.down(x, n);
+}
+
+extern "C" int l2z_vector_dot_product(float *out, const float *x, const float *y, size_t n)
+{
+    L2Z_CHECK(out && x && y && n > 0 && n < (1u << 30), L2Z_ERR_INVALID, "l2z_vector_dot_product: bad arguments");
+    L2Z_TRY(ensure_device(current_device_for(nullptr)));
+    DevBuf dx, dy, dout;
+    L2Z_TRY(dx.alloc(n)); L2Z_TRY(dy.alloc(n)); L2Z_TRY(dout.alloc(1));
+    L2Z_TRY(dx.up(x, n)); L2Z_TRY(dy.up(y, n));
+    L2Z_HIP(launch_dot(dout.p, dx.p, dy.p, (int)n, nullptr));
+    L2Z_HIP(hipDeviceSynchronize());
+    return dout.down(out, 1);
+}
+
+extern "C" int l2z_vector_weighted_sum_rows(float *xout, size_t xout_len, const float *rows,
+                                            size_t rows_len, size_t row_stride,
+                                            const float *weights, size_t n_weights)
+{
+    L2Z_CHECK(xout && rows && weights && xout_len > 0 && n_weights > 0, L2Z_ERR_INVALID,
+              "l2z_vector_weighted_sum_rows: bad arguments");
+    // main.zig:660-661 asserts
+    L2Z_CHECK(row_stride >= xout_len && rows_len >= (n_weights - 1) * row_stride + xout_len,
+              L2Z_ERR_INVALID, "l2z_vector_weighted_sum_rows: stride/length contract violated");
+    L2Z_TRY(ensure_device(current_device_for(nullptr)));
+    DevBuf dr, dw, dout;
+    L2Z_TRY(dr.alloc(rows_len)); L2Z_TRY(dw.alloc(n_weights)); L2Z_TRY(dout.alloc(xout_len));
+    L2Z_TRY(dr.up(rows, rows_len)); L2Z_TRY(dw.up(weights, n_weights));
+    L2Z_HIP(launch_weighted_sum_rows(dout.p, (int)xout_len, dr.p, (int)row_stride, dw.p,
+                                     (int)n_weights, nullptr));
+    L2Z_HIP(hipDeviceSynchronize());
+    return dout.down(xout, xout_len);
+}
+
+extern "C" int l2z_argmax_host(const float *x, size_t n, size_t *out_index)
+{
+    L2Z_CHECK(x && out_index && n > 0 && n < (1u << 30), L2Z_ERR_INVALID, "l2z_argmax_host: bad arguments");
+    L2Z_TRY(ensure_device(current_device_for(nullptr)));
+    DevBuf dx;
+    int *didx = nullptr;
+    L2Z_TRY(dx.alloc(n)); L2Z_TRY(dx.up(x, n));
+    L2Z_HIP(hipMalloc(&didx, sizeof(int)));
+    ArgmaxArgs a = {};
+    a.logits = dx.p; a.vocab = (int)n; a.argmax_out = didx; a.advance = 0;
+    hipError_t e = launch_argmax(a, nullptr);
+    int idx = 0;
+    if (e == hipSuccess) e = hipMemcpy(&idx, didx, sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipFree(didx);
+    L2Z_HIP(e);
+    *out_index = (size_t)idx;
+    return L2Z_OK;
+}
+
+#ifdef L2Z_DBG_TS
+namespace l2z { hipError_t dbg_ts_read(long long *out); }
+extern "C" int l2z_dbg_ts(long long *out) { return l2z::dbg_ts_read(out) == hipSuccess ? 0 : -3; }
+#endif
+

@@ -1,4 +1,4 @@
-// l2z_comm.h -- shard group object shared by comm.cpp and api.cpp
+// l2z_comm.h -- shard group object shared by comm.cpp and the host sources (l2z_state.h)
 #pragma once
 #include "l2z_internal.h"
 

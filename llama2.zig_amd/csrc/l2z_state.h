@@ -1,0 +1,116 @@
+// l2z_state.h -- the device-resident Weights / RunState objects behind the C ABI and the internal
+// functions the translation units share (weights.cpp, runstate.cpp, forward.cpp, prefill_host.cpp,
+// hooks.cpp).  Product code; nothing under oracle/ is referenced.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "l2z_comm.h"
+#include "l2z_internal.h"
+
+namespace l2z {
+
+// ----- shard geometry (DESIGN.md "Sharding"; world == 1 -> everything local) -----
+struct Shard {
+    int rank = 0, world = 1;
+    int hs = 0;        // head_size
+    int dim0 = 0, dim_loc = 0;   // rows of q / wo / w2 and slice of x, xb owned here
+    int kvd_loc = 0;             // local kv_dim (whole kv heads)
+    int heads_loc = 0;
+    int hid0 = 0, hid_loc = 0;   // rows of w1/w3, slice of hb
+    int v0 = 0, v_loc = 0;       // rows of wcls, slice of logits
+};
+int make_shard(const l2z_config &c, const l2z_comm *comm, Shard *out);
+
+// ----- the Weights.init pointer walk (main.zig:85-112) as a table -----
+enum ShardKind { REPL, BY_Q_HEADS, BY_KV_HEADS, BY_HIDDEN, BY_DIM_ROWS, BY_VOCAB, SKIP };
+
+struct TensorDesc {
+    const char *name;
+    size_t offset;  // f32 index in the file blob
+    size_t layers, rows, cols;
+    ShardKind kind;
+    float scale, bias;  // synthetic generator
+    size_t count() const { return layers * rows * cols; }
+};
+std::vector<TensorDesc> tensor_table(const l2z_config &c, bool shared);
+void shard_rows(const TensorDesc &d, const Shard &s, size_t *r0, size_t *r1);
+
+extern int g_cus;  // compute units of the device in use (set by ensure_device)
+int ensure_device(int device);
+int current_device_for(const l2z_comm *comm);
+
+}  // namespace l2z
+
+struct l2z_weights {
+    l2z_config cfg;
+    int shared;
+    int device;
+    l2z::Shard sh;
+    float *blob = nullptr;       // one allocation; world==1: identical to the file blob
+    size_t blob_floats = 0;
+    bool file_layout = false;
+    // carved device pointers (local shards when world > 1)
+    const float *tok_emb = nullptr, *rms_att = nullptr, *rms_ffn = nullptr, *rms_final = nullptr;
+    const float *wq = nullptr, *wk = nullptr, *wv = nullptr, *wo = nullptr;
+    const float *w1 = nullptr, *w2 = nullptr, *w3 = nullptr, *wcls = nullptr;
+};
+
+enum { KIND_QKV = 0, KIND_ATTN, KIND_WO, KIND_FFN13, KIND_FFN2, KIND_CLS, KIND_ARGMAX, KIND_COUNT };
+static const char *const kKindNames[KIND_COUNT] = {"qkv", "attn", "wo", "ffn13", "ffn2", "cls", "argmax"};
+
+struct l2z_runstate {
+    l2z_config cfg;
+    int device;
+    l2z::Shard sh;
+    const l2z_comm *comm = nullptr;
+    hipStream_t stream = nullptr;
+    // main.zig:119-135 (k, v, xb2, hb2, logits_indexed have no device twin:
+    // k/v go straight into the cache rows, xb2/hb2 are fused away)
+    float *x = nullptr, *xb = nullptr, *hb = nullptr, *q = nullptr, *logits = nullptr;
+    float *key_cache = nullptr, *value_cache = nullptr;
+    float2 *rope = nullptr;  // (seq_len, head_size/2) {cos, sin}
+    // loop state on the device
+    int *d_token = nullptr, *d_pos = nullptr, *d_prompt = nullptr, *d_n_prompt = nullptr;
+    int *d_out_tokens = nullptr, *d_argmax = nullptr;
+    // batched prefill scratch (allocated on first l2z_prefill): [kPrefillChunk, dim|hidden]
+    float *pf_x = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_att = nullptr;
+    float *pf_h1 = nullptr;
+    int *pf_tokens = nullptr;
+    float *d_part_val = nullptr;  // classifier launch's per-block argmax candidates
+    int *d_part_idx = nullptr;
+    int n_part = 0;               // 0: argmax scans the logits instead
+    float *d_attn_part = nullptr; // split attention: per (head, chunk) partials
+    int attn_nch = 0;             // 0: one block per head at every position
+    int attn_split_pos = 0;       // positions >= this use the split form (host picks the graph)
+    // graphs, keyed by the weights they were captured with
+    const l2z_weights *graph_w = nullptr;
+    hipGraphExec_t g_forward[2] = {nullptr, nullptr}, g_step[2] = {nullptr, nullptr};  // [split?]
+    bool use_graphs = true;
+    int host_pos = 0;   // next position the greedy loop will run
+    bool done = false;  // greedy loop saw BOS
+    std::vector<int32_t> h_prompt;  // host copy of the greedy loop's prompt (prefill path)
+    // peer-write transport: device copies of the four gathers' descriptions (xb, x, hb, logits) for
+    // the kernels that push their outputs to the peers themselves (MatvecArgs::push)
+    l2z::P2pArgs *d_push = nullptr;
+    int max_blocks = 0;
+};
+
+namespace l2z {
+
+// forward.cpp
+struct Prof;
+int check_pair(const l2z_config *config, const l2z_runstate *s, const l2z_weights *w);
+int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof *prof, int only_stage,
+                    bool split);
+bool use_split(const l2z_runstate *s, int pos);
+int run_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, int pos);
+void drop_graphs(l2z_runstate *s);
+
+// prefill_host.cpp
+constexpr int kPrefillMinPrompt = L2Z_PREFILL_MIN_PROMPT;  // shorter prompts: the stepped loop is as fast
+bool prefill_enabled();
+int prefill_check(const l2z_config *config, const l2z_runstate *s);
+int prefill_tokens(l2z_runstate *s, const l2z_weights *w, const int32_t *tokens, int n_tokens, int pos0);
+
+}  // namespace l2z

@@ -1,0 +1,321 @@
+// weights.cpp -- shard geometry, the llama2.c-v0 tensor table (main.zig:85-112) and the device
+// resident Weights object of the C ABI (include/llama2_hip.h).
+//
+// Product code.  No CPU fallback anywhere: without a HIP device every compute entry point returns
+// L2Z_ERR_NO_DEVICE.  Nothing under oracle/ is referenced.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "l2z_state.h"
+
+namespace l2z {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+int make_shard(const l2z_config &c, const l2z_comm *comm, Shard *out)
+{
+    Shard s;
+    s.rank = comm ? comm->rank : 0;
+    s.world = comm ? comm->world : 1;
+    L2Z_CHECK(c.dim > 0 && c.hidden_dim > 0 && c.n_layers > 0 && c.n_heads > 0 &&
+                  c.n_kv_heads > 0 && c.vocab_size > 0 && c.seq_len > 0,
+              L2Z_ERR_INVALID, "config: all seven fields must be positive");
+    L2Z_CHECK(c.dim % c.n_heads == 0, L2Z_ERR_INVALID, "config: dim %% n_heads != 0");
+    L2Z_CHECK(c.n_heads % c.n_kv_heads == 0, L2Z_ERR_INVALID, "config: n_heads %% n_kv_heads != 0");
+    s.hs = c.dim / c.n_heads;
+    L2Z_CHECK(s.hs % 2 == 0, L2Z_ERR_INVALID, "config: head_size must be even (RoPE pairs)");
+    const int kv_dim = (int)(((int64_t)c.dim * c.n_kv_heads) / c.n_heads);
+    int64_t a, b;
+    L2Z_TRY(l2z_shard_range(c.dim, s.hs, s.rank, s.world, &a, &b));
+    s.dim0 = (int)a;
+    s.dim_loc = (int)(b - a);
+    s.heads_loc = s.dim_loc / s.hs;
+    L2Z_TRY(l2z_shard_range(kv_dim, s.hs, s.rank, s.world, &a, &b));
+    s.kvd_loc = (int)(b - a);
+    L2Z_TRY(l2z_shard_range(c.hidden_dim, 1, s.rank, s.world, &a, &b));
+    s.hid0 = (int)a;
+    s.hid_loc = (int)(b - a);
+    L2Z_TRY(l2z_shard_range(c.vocab_size, 1, s.rank, s.world, &a, &b));
+    s.v0 = (int)a;
+    s.v_loc = (int)(b - a);
+    *out = s;
+    return L2Z_OK;
+}
+
+std::vector<TensorDesc> tensor_table(const l2z_config &c, bool shared)
+{
+    const size_t V = c.vocab_size, dim = c.dim, hid = c.hidden_dim, L = c.n_layers;
+    const size_t S = c.seq_len, hs = dim / c.n_heads, kvd = (dim * c.n_kv_heads) / c.n_heads;
+    const float s_dim = sqrtf(3.0f / (float)dim), s_hid = sqrtf(3.0f / (float)hid);
+    const float s_emb = 2.0f * s_dim;
+    std::vector<TensorDesc> t = {
+        {"token_embedding_table", 0, 1, V, dim, REPL, s_emb, 0.0f},   // :86
+        {"rms_att_weight", 0, L, 1, dim, REPL, 0.1f, 1.0f},           // :88
+        {"wq", 0, L, dim, dim, BY_Q_HEADS, s_dim, 0.0f},              // :90
+        {"wk", 0, L, kvd, dim, BY_KV_HEADS, s_dim, 0.0f},             // :92
+        {"wv", 0, L, kvd, dim, BY_KV_HEADS, s_dim, 0.0f},             // :94
+        {"wo", 0, L, dim, dim, BY_DIM_ROWS, s_dim, 0.0f},             // :96
+        {"rms_ffn_weight", 0, L, 1, dim, REPL, 0.1f, 1.0f},           // :98
+        {"w1", 0, L, hid, dim, BY_HIDDEN, s_dim, 0.0f},               // :100
+        {"w2", 0, L, dim, hid, BY_DIM_ROWS, s_hid, 0.0f},             // :102
+        {"w3", 0, L, hid, dim, BY_HIDDEN, s_dim, 0.0f},               // :104
+        {"rms_final_weight", 0, 1, 1, dim, REPL, 0.1f, 1.0f},         // :106
+        {"freq_cis_real", 0, 1, 1, S * hs / 2, SKIP, 1.0f, 0.0f},     // :108 (never read)
+        {"freq_cis_imag", 0, 1, 1, S * hs / 2, SKIP, 1.0f, 0.0f},     // :110
+    };
+    if (!shared) t.push_back({"wcls", 0, 1, V, dim, BY_VOCAB, s_emb, 0.0f});  // :112
+    size_t off = 0;
+    for (auto &d : t) {
+        d.offset = off;
+        off += d.count();
+    }
+    return t;
+}
+
+void shard_rows(const TensorDesc &d, const Shard &s, size_t *r0, size_t *r1)
+{
+    switch (d.kind) {
+        case BY_Q_HEADS:
+        case BY_DIM_ROWS: *r0 = s.dim0; *r1 = (size_t)s.dim0 + s.dim_loc; break;
+        case BY_KV_HEADS: *r0 = (size_t)s.rank * s.kvd_loc; *r1 = *r0 + s.kvd_loc; break;
+        case BY_HIDDEN: *r0 = s.hid0; *r1 = (size_t)s.hid0 + s.hid_loc; break;
+        case BY_VOCAB: *r0 = s.v0; *r1 = (size_t)s.v0 + s.v_loc; break;
+        default: *r0 = 0; *r1 = d.rows; break;
+    }
+}
+
+int g_cus = 0;
+
+int ensure_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device available (%s); this library has no CPU fallback",
+                  e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return L2Z_ERR_NO_DEVICE;
+    }
+    L2Z_CHECK(device >= 0 && device < n, L2Z_ERR_NO_DEVICE, "device %d out of range (%d present)",
+              device, n);
+    L2Z_HIP(hipSetDevice(device));
+    if (g_cus == 0) {
+        hipDeviceProp_t p;
+        L2Z_HIP(hipGetDeviceProperties(&p, device));
+        g_cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    }
+    return L2Z_OK;
+}
+
+int current_device_for(const l2z_comm *comm)
+{
+    if (comm) return comm->device;
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) d = 0;
+    return d;
+}
+
+}  // namespace l2z
+
+using namespace l2z;
+
+namespace {
+
+void carve_local(l2z_weights *w, const std::vector<TensorDesc> &tt)
+{
+    // local layout: same tensor order, each tensor (layers, rows_loc, cols); SKIP kept only
+    // in file layout
+    size_t off = 0;
+    const float *base = w->blob;
+    for (const auto &d : tt) {
+        size_t r0, r1;
+        shard_rows(d, w->sh, &r0, &r1);
+        const bool present = w->file_layout || d.kind != SKIP;
+        const float *p = base + off;
+        const std::string n = d.name;
+        if (n == "token_embedding_table") w->tok_emb = p;
+        else if (n == "rms_att_weight") w->rms_att = p;
+        else if (n == "wq") w->wq = p;
+        else if (n == "wk") w->wk = p;
+        else if (n == "wv") w->wv = p;
+        else if (n == "wo") w->wo = p;
+        else if (n == "rms_ffn_weight") w->rms_ffn = p;
+        else if (n == "w1") w->w1 = p;
+        else if (n == "w2") w->w2 = p;
+        else if (n == "w3") w->w3 = p;
+        else if (n == "rms_final_weight") w->rms_final = p;
+        else if (n == "wcls") w->wcls = p;
+        if (present) off += d.layers * (r1 - r0) * d.cols;
+    }
+    if (w->shared) w->wcls = w->tok_emb + (size_t)w->sh.v0 * w->cfg.dim;  // main.zig:112
+}
+
+size_t local_floats(const l2z_weights *w, const std::vector<TensorDesc> &tt)
+{
+    size_t off = 0;
+    for (const auto &d : tt) {
+        size_t r0, r1;
+        shard_rows(d, w->sh, &r0, &r1);
+        if (w->file_layout || d.kind != SKIP) off += d.layers * (r1 - r0) * d.cols;
+    }
+    return off;
+}
+
+int weights_alloc(const l2z_config *config, int shared_weights, const l2z_comm *comm,
+                  l2z_weights **out, std::vector<TensorDesc> *tt_out)
+{
+    L2Z_CHECK(config != nullptr && out != nullptr, L2Z_ERR_INVALID, "weights_init: null argument");
+    const int dev = current_device_for(comm);
+    L2Z_TRY(ensure_device(dev));
+    Shard sh;
+    L2Z_TRY(make_shard(*config, comm, &sh));
+    l2z_weights *w = new l2z_weights();
+    w->cfg = *config;
+    w->shared = shared_weights ? 1 : 0;
+    w->device = dev;
+    w->sh = sh;
+    w->file_layout = sh.world == 1;
+    *tt_out = tensor_table(*config, w->shared != 0);
+    w->blob_floats = local_floats(w, *tt_out);
+    hipError_t e = hipMalloc(&w->blob, w->blob_floats * sizeof(float));
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) for weights failed: %s", w->blob_floats * sizeof(float),
+                  hipGetErrorString(e));
+        delete w;
+        return e == hipErrorOutOfMemory ? L2Z_ERR_OOM : L2Z_ERR_HIP;
+    }
+    carve_local(w, *tt_out);
+    *out = w;
+    return L2Z_OK;
+}
+
+}  // namespace
+
+extern "C" int l2z_abi_version(void) { return L2Z_ABI_VERSION; }
+extern "C" const char *l2z_last_error(void) { return l2z::g_err; }
+
+extern "C" int l2z_device_count(int *out_n)
+{
+    L2Z_CHECK(out_n != nullptr, L2Z_ERR_INVALID, "l2z_device_count: null out");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) n = 0;
+    *out_n = n;
+    return L2Z_OK;
+}
+
+extern "C" int l2z_device_info(int dev, char *name, size_t cap, int *out_cus, uint64_t *out_hbm)
+{
+    L2Z_TRY(ensure_device(dev));
+    hipDeviceProp_t p;
+    L2Z_HIP(hipGetDeviceProperties(&p, dev));
+    // some boxes report an empty marketing name
+    if (name && cap) snprintf(name, cap, "%s (%s)", p.name[0] ? p.name : "AMD GPU", p.gcnArchName);
+    if (out_cus) *out_cus = p.multiProcessorCount;
+    if (out_hbm) *out_hbm = (uint64_t)p.totalGlobalMem;
+    return L2Z_OK;
+}
+
+// src/main.zig:73 Weights.init
+extern "C" int l2z_weights_init(const l2z_config *config, const float *data, size_t n_floats,
+                                int shared_weights, const l2z_comm *comm, l2z_weights **out)
+{
+    L2Z_CHECK(data != nullptr, L2Z_ERR_INVALID, "l2z_weights_init: null data");
+    std::vector<TensorDesc> tt;
+    l2z_weights *w = nullptr;
+    L2Z_TRY(weights_alloc(config, shared_weights, comm, &w, &tt));
+    const size_t need = tt.back().offset + tt.back().count();
+    if (n_floats < need) {
+        set_error("l2z_weights_init: blob has %zu f32, config needs %zu", n_floats, need);
+        l2z_weights_free(w);
+        return L2Z_ERR_INVALID;
+    }
+    hipError_t e = hipSuccess;
+    if (w->file_layout) {
+        // one allocation, byte-identical to the file blob; copy in 256 MiB pieces
+        const size_t piece = (size_t)64 << 20;
+        for (size_t o = 0; o < need && e == hipSuccess; o += piece) {
+            const size_t n = need - o < piece ? need - o : piece;
+            e = hipMemcpy(w->blob + o, data + o, n * sizeof(float), hipMemcpyHostToDevice);
+        }
+    } else {
+        // sharded direct upload: only this rank's rows are read from the host blob
+        size_t off = 0;
+        for (const auto &d : tt) {
+            if (d.kind == SKIP) continue;
+            size_t r0, r1;
+            shard_rows(d, w->sh, &r0, &r1);
+            const size_t rl = r1 - r0;
+            for (size_t l = 0; l < d.layers && e == hipSuccess; l++) {
+                const float *src = data + d.offset + (l * d.rows + r0) * d.cols;
+                e = hipMemcpy(w->blob + off + l * rl * d.cols, src, rl * d.cols * sizeof(float),
+                              hipMemcpyHostToDevice);
+            }
+            off += d.layers * rl * d.cols;
+        }
+    }
+    if (e != hipSuccess) {
+        set_error("weight upload failed: %s", hipGetErrorString(e));
+        l2z_weights_free(w);
+        return L2Z_ERR_HIP;
+    }
+    *out = w;
+    return L2Z_OK;
+}
+
+extern "C" int l2z_weights_init_synthetic(const l2z_config *config, int shared_weights,
+                                          uint64_t seed, const l2z_comm *comm, l2z_weights **out)
+{
+    std::vector<TensorDesc> tt;
+    l2z_weights *w = nullptr;
+    L2Z_TRY(weights_alloc(config, shared_weights, comm, &w, &tt));
+    hipError_t e = hipSuccess;
+    size_t off = 0;
+    for (const auto &d : tt) {
+        if (d.kind == SKIP && !w->file_layout) continue;
+        size_t r0, r1;
+        shard_rows(d, w->sh, &r0, &r1);
+        const size_t rl = r1 - r0;
+        for (size_t l = 0; l < d.layers && e == hipSuccess; l++) {
+            const uint64_t base = d.offset + (l * d.rows + r0) * d.cols;
+            e = launch_synth_fill(w->blob + off + l * rl * d.cols, base, rl * d.cols, seed, d.scale,
+                                  d.bias, nullptr);
+        }
+        off += d.layers * rl * d.cols;
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        set_error("synthetic weight fill failed: %s", hipGetErrorString(e));
+        l2z_weights_free(w);
+        return L2Z_ERR_HIP;
+    }
+    *out = w;
+    return L2Z_OK;
+}
+
+extern "C" int l2z_weights_read(const l2z_weights *w, size_t offset, size_t count, float *out)
+{
+    L2Z_CHECK(w != nullptr && out != nullptr, L2Z_ERR_INVALID, "l2z_weights_read: null argument");
+    L2Z_CHECK(w->file_layout, L2Z_ERR_INVALID, "l2z_weights_read: only for unsharded weights");
+    L2Z_CHECK(offset + count <= w->blob_floats, L2Z_ERR_INVALID, "l2z_weights_read: out of range");
+    L2Z_HIP(hipSetDevice(w->device));
+    L2Z_HIP(hipMemcpy(out, w->blob + offset, count * sizeof(float), hipMemcpyDeviceToHost));
+    return L2Z_OK;
+}
+
+extern "C" void l2z_weights_free(l2z_weights *w)
+{
+    if (!w) return;
+    if (w->blob) (void)hipFree(w->blob);
+    delete w;
+}

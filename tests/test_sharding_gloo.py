@@ -1,6 +1,6 @@
 """World-size-2 (and 4) CPU test of the multi-GPU shard plan, over gloo.
 
-What runs on the GPUs at N>1 (csrc/api.cpp enqueue_forward, DESIGN.md
+What runs on the GPUs at N>1 (csrc/forward.cpp enqueue_forward, DESIGN.md
 "Sharding") is: every rank owns whole heads of q/k/v, rows of wo / w1 / w3 / w2
 and rows of the classifier, given by l2z_shard_range; after attention, after
 each residual update, after the SwiGLU and after the classifier the owned
