@@ -1,0 +1,618 @@
+// attention.hip -- decode attention for gfx950 (main.zig:361-389): one block per head (fast and generic
+// forms) and the split / combine (flash-decoding) form.  See kernels' comments and DESIGN.md 4.2.
+#include "kernel_common.h"
+
+namespace l2z {
+namespace {
+
+// ---------------------------------------------------------------------------
+// Attention for one head per block (main.zig:361-389).
+// Thread (g, c): group g of TPR lanes walks timesteps t = g, g+G, ...; lane c
+// owns float4 column(s) c of the head.
+// ---------------------------------------------------------------------------
+struct AttnGeom {
+    int E;    // elements per head row in load units (head_size/4 if VEC else head_size)
+    int TPR;  // lanes per row: power of two, <= 64
+    int G;    // groups per block
+};
+
+__host__ __device__ inline AttnGeom attn_geom(int head_size, bool vec, int block = kBlock)
+{
+    AttnGeom g;
+    g.E = vec ? head_size >> 2 : head_size;
+    int t = 1;
+    while (t < g.E && t < 64) t <<= 1;
+    g.TPR = t;
+    g.G = block / t;
+    return g;
+}
+
+// scores for timesteps t < T: att[t] = dot(q, K[t]) / div   (:367-375).
+// Group g walks t = g, g+G, ...; kAttnUB timesteps are loaded before any is
+// used so kAttnUB K rows are in flight per lane (the first build did one
+// dependent load per step: 16 serial round trips at pos 255).
+constexpr int kAttnUB = 4;
+
+template <bool VEC>
+__device__ __forceinline__ void attn_scores(const float *qs, const float *__restrict__ kbase,
+                                            int kv_stride, int head_size, int T, float div,
+                                            float *att)
+{
+    const AttnGeom ge = attn_geom(head_size, VEC);
+    const int g = threadIdx.x / ge.TPR, c0 = threadIdx.x % ge.TPR;
+    for (int t0 = g; t0 < T; t0 += ge.G * kAttnUB) {
+        float p[kAttnUB];
+#pragma unroll
+        for (int i = 0; i < kAttnUB; i++) p[i] = 0.0f;
+        for (int c = c0; c < ge.E; c += ge.TPR) {  // one trip unless head_size > 256
+            if (VEC) {
+                v4f kv[kAttnUB];
+#pragma unroll
+                for (int i = 0; i < kAttnUB; i++) {
+                    int t = t0 + ge.G * i;
+                    t = t < T ? t : T - 1;  // clamped: result discarded below
+                    kv[i] = ((const v4f *)(kbase + (size_t)t * (size_t)kv_stride))[c];
+                }
+                const v4f qv = ((const v4f *)qs)[c];
+#pragma unroll
+                for (int i = 0; i < kAttnUB; i++) {
+                    v4f acc = {0.f, 0.f, 0.f, 0.f};
+                    acc = fma4(qv, kv[i], acc);
+                    p[i] += hsum4(acc);
+                }
+            } else {
+                float kv[kAttnUB];
+#pragma unroll
+                for (int i = 0; i < kAttnUB; i++) {
+                    int t = t0 + ge.G * i;
+                    t = t < T ? t : T - 1;
+                    kv[i] = kbase[(size_t)t * (size_t)kv_stride + c];
+                }
+                const float qv = qs[c];
+#pragma unroll
+                for (int i = 0; i < kAttnUB; i++) p[i] = fmaf(qv, kv[i], p[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kAttnUB; i++) {
+            float v = p[i];
+            v = lanes_sum(v, ge.TPR);
+            const int t = t0 + ge.G * i;
+            if (c0 == 0 && t < T) att[t] = v / div;  // :372 divide, not multiply by reciprocal
+        }
+    }
+}
+
+
+// out[i] = sum_t att[t] * V[t][i]   (main.zig:657-685): G interleaved partial
+// sums per column (t = g, g+G, ... in increasing t), combined in g order.
+// kAttnUB V rows are loaded ahead of their use.
+template <bool VEC>
+__device__ __forceinline__ void attn_weighted_sum(const float *att, const float *__restrict__ vbase,
+                                                  int kv_stride, int head_size, int T, float *part,
+                                                  float *out)
+{
+    const AttnGeom ge = attn_geom(head_size, VEC);
+    const int g = threadIdx.x / ge.TPR, c0 = threadIdx.x % ge.TPR;
+    for (int c = c0; c < ge.E; c += ge.TPR) {
+        if (VEC) {
+            v4f acc = {0.f, 0.f, 0.f, 0.f};
+            for (int t0 = g; t0 < T; t0 += ge.G * kAttnUB) {
+                v4f vv[kAttnUB];
+                float w[kAttnUB];
+#pragma unroll
+                for (int i = 0; i < kAttnUB; i++) {
+                    const int t = t0 + ge.G * i;
+                    const int tc = t < T ? t : T - 1;
+                    vv[i] = ((const v4f *)(vbase + (size_t)tc * (size_t)kv_stride))[c];
+                    w[i] = t < T ? att[tc] : 0.0f;
+                }
+#pragma unroll
+                for (int i = 0; i < kAttnUB; i++) {  // increasing t
+                    acc.x = fmaf(vv[i].x, w[i], acc.x);
+                    acc.y = fmaf(vv[i].y, w[i], acc.y);
+                    acc.z = fmaf(vv[i].z, w[i], acc.z);
+                    acc.w = fmaf(vv[i].w, w[i], acc.w);
+                }
+            }
+            ((v4f *)(part + (size_t)g * head_size))[c] = acc;
+        } else {
+            float acc = 0.0f;
+            for (int t0 = g; t0 < T; t0 += ge.G * kAttnUB) {
+                float vv[kAttnUB], w[kAttnUB];
+#pragma unroll
+                for (int i = 0; i < kAttnUB; i++) {
+                    const int t = t0 + ge.G * i;
+                    const int tc = t < T ? t : T - 1;
+                    vv[i] = vbase[(size_t)tc * (size_t)kv_stride + c];
+                    w[i] = t < T ? att[tc] : 0.0f;
+                }
+#pragma unroll
+                for (int i = 0; i < kAttnUB; i++) acc = fmaf(vv[i], w[i], acc);
+            }
+            part[(size_t)g * head_size + c] = acc;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < head_size; i += blockDim.x) {
+        float s = part[i];
+        for (int gg = 1; gg < ge.G; gg++) s += part[(size_t)gg * head_size + i];
+        out[i] = s;
+    }
+}
+
+// Softmax over att[0..T) (main.zig:687-706) computed redundantly by every wave --
+// each wave reduces max and sum over ALL T with the same instruction sequence, so
+// all waves hold bit-identical (max, sum) without any cross-wave barrier -- and
+// wave w normalises the entries t = w*64 + lane, + blockDim, ...
+// The normalised weights go to a second buffer, so no wave overwrites what another still reads.
+__device__ __forceinline__ void wave_softmax(const float *att, float *prob, int T)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    float m = -INFINITY;
+    for (int t = lane; t < T; t += kWave) m = fmaxf(m, att[t]);
+    m = wave_max(m);
+    float s = 0.0f;
+    for (int t = lane; t < T; t += kWave) s += expf(att[t] - m);  // :699
+    s = wave_sum(s);
+    for (int t = wave * kWave + lane; t < T; t += nw * kWave) prob[t] = expf(att[t] - m) / s;  // :704
+    __syncthreads();
+}
+
+// out[i] = part[0][i] + part[1][i] + ... + part[G-1][i], i < hs.  R = 1..16 adjacent lanes
+// share one output: lane r adds partials r, r+R, ... (increasing), then a DPP sum over the R
+// lanes.  R depends only on (G, hs, blockDim) -- fixed per model.
+__device__ __forceinline__ void reduce_partials(const float *part, int G, int hs, float *out,
+                                                const P2pArgs *push = nullptr, size_t push_idx0 = 0)
+{
+    int R = 1;
+    while (R * 2 <= G && R * 2 * hs <= (int)blockDim.x && R < 16) R <<= 1;
+    const int i = threadIdx.x / R, r = threadIdx.x % R;
+    float s = 0.0f;
+    if (i < hs)
+        for (int gg = r; gg < G; gg += R) s += part[(size_t)gg * hs + i];
+    s = lanes_sum(s, R);
+    if (i < hs && r == 0) {
+        out[i] = s;
+        if (push) p2p_ll_push(push, p2p_ll_epoch(push), push_idx0 + (size_t)i, s);
+    }
+}
+
+// Fast path (head_size % 4 == 0, head_size <= 256).  The first kFastUB timesteps of
+// every group -- K rows AND V rows -- are requested up front, WITHOUT waiting for pos:
+// rows past pos exist (the cache has seq_len rows, zero-initialised or holding finite
+// values of an earlier sequence) and are masked, so pos, q, K and V travel in one
+// round trip and the V rows arrive while the softmax runs.  Same arithmetic and
+// summation order as attn_scores / attn_weighted_sum.  Kept compact on purpose: at
+// stories15M sizes this kernel's time is launch + instruction fetch, not data.
+constexpr int kFastUB = 8;
+constexpr int kAttnFastBlock = 1024;  // long contexts: 16 waves per head (32 groups at head_size 128)
+
+// NT = 256 for short contexts (seq_len <= 512: launch latency matters most),
+// NT = 1024 for long ones (more rows in flight per head).
+#ifdef L2Z_DBG_TS
+__device__ long long g_dbg_ts[16];
+#define L2Z_TS(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dbg_ts[i] = clock64(); } while (0)
+#else
+#define L2Z_TS(i) do { } while (0)
+#endif
+template <int NT, bool SPEC>
+__global__ __launch_bounds__(NT) void attention_fast_kernel(const AttnArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int hs = a.head_size;
+    const AttnGeom ge = attn_geom(hs, true, NT);
+    float *att = lds;                                  // seq_len raw scores
+    float *prob = att + ((a.seq_len + 3) & ~3);        // seq_len softmax weights
+    float *part = prob + ((a.seq_len + 3) & ~3);       // G*hs
+    const int h = blockIdx.x;
+    const int kvh = h / a.kv_mul;                      // :369 (h / kv_mul) * head_size
+    const float *kbase = a.kcache + (size_t)kvh * hs;
+    const float *vbase = a.vcache + (size_t)kvh * hs;
+    const size_t stride = (size_t)a.kv_dim;
+    const int g = threadIdx.x / ge.TPR, c0 = threadIdx.x % ge.TPR;
+    const bool active = c0 < ge.E;
+    const int cc = active ? c0 : 0;
+    const int step = ge.G * kFastUB;
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+
+    L2Z_TS(0);
+    // SPEC (small models, latency-bound): the first round is requested without waiting for
+    // pos -- rows past pos exist and are masked -- so pos, q, K and V travel in one round trip.
+    // !SPEC (large heads): one CU pulls only ~45 GB/s, speculative rows would cost more than the
+    // extra dependent read of pos, so rows are clamped to pos (duplicates hit the L1).
+    const int T = *a.pos_ptr + 1;  // timesteps 0..pos inclusive (:367)
+    const int lim = SPEC ? a.seq_len : T;
+    const v4f qv = active ? ((const v4f *)(a.q + (size_t)h * hs))[cc] : zero;
+    v4f kr[kFastUB], vr[kFastUB];
+#pragma unroll
+    for (int i = 0; i < kFastUB; i++) {
+        int t = g + ge.G * i;
+        t = t < lim ? t : lim - 1;
+        kr[i] = ((const v4f *)(kbase + (size_t)t * stride))[cc];
+    }
+#pragma unroll
+    for (int i = 0; i < kFastUB; i++) {
+        int t = g + ge.G * i;
+        t = t < lim ? t : lim - 1;
+        vr[i] = ((const v4f *)(vbase + (size_t)t * stride))[cc];
+    }
+    L2Z_TS(1);
+    const float div = sqrtf((float)hs);
+    for (int t0 = g;;) {  // scores (:367-375)
+#pragma unroll
+        for (int i = 0; i < kFastUB; i++) {
+            float p = hsum4(fma4(qv, kr[i], zero));
+            p = lanes_sum(p, ge.TPR);
+            const int t = t0 + ge.G * i;
+            if (c0 == 0 && t < T) att[t] = p / div;  // :372 divide
+        }
+        t0 += step;
+        if (t0 >= T) break;
+#pragma unroll
+        for (int i = 0; i < kFastUB; i++) {
+            int t = t0 + ge.G * i;
+            t = t < T ? t : T - 1;
+            kr[i] = ((const v4f *)(kbase + (size_t)t * stride))[cc];
+        }
+    }
+    L2Z_TS(2);
+    __syncthreads();
+    L2Z_TS(3);
+    wave_softmax(att, prob, T);  // :378
+    L2Z_TS(4);
+    v4f acc = zero;
+    for (int t0 = g;;) {  // att . V (:381-388), increasing t within the group
+#pragma unroll
+        for (int i = 0; i < kFastUB; i++) {
+            const int t = t0 + ge.G * i;
+            const float w = t < T ? prob[t] : 0.0f;
+            acc.x = fmaf(vr[i].x, w, acc.x);
+            acc.y = fmaf(vr[i].y, w, acc.y);
+            acc.z = fmaf(vr[i].z, w, acc.z);
+            acc.w = fmaf(vr[i].w, w, acc.w);
+        }
+        t0 += step;
+        if (t0 >= T) break;
+#pragma unroll
+        for (int i = 0; i < kFastUB; i++) {
+            int t = t0 + ge.G * i;
+            t = t < T ? t : T - 1;
+            vr[i] = ((const v4f *)(vbase + (size_t)t * stride))[cc];
+        }
+    }
+    L2Z_TS(5);
+    if (active) ((v4f *)(part + (size_t)g * hs))[cc] = acc;
+    __syncthreads();
+    L2Z_TS(6);
+    // sharded: a.xb already points at this rank's slice, head h of it starts at h * hs
+    reduce_partials(part, ge.G, hs, a.xb + (size_t)h * hs, a.push,
+                    a.push ? (size_t)a.push->rank * a.push->count + (size_t)h * hs : 0);
+    L2Z_TS(7);
+}
+
+// ---------------------------------------------------------------------------
+// Split attention (flash-decoding form).  One CU pulls only ~45 GB/s, so one block per
+// head (attention_fast_kernel) leaves 7/8 of a 256-CU chip idle at 32 heads and spends its
+// time waiting for its own K/V rows (measured with s_memtime: 6 of 10 us).  Here head h is
+// shared by `nch` blocks; block (h, c) owns timesteps t = c, c+nch, c+2*nch, ... and writes
+//     m_c = max score,  l_c = sum exp(score - m_c),  o_c[i] = sum exp(score - m_c) * V[t][i]
+// attention_combine_kernel then forms  out[i] = (sum_c o_c[i] e^(m_c-M)) / (sum_c l_c e^(m_c-M)),
+// M = max_c m_c.  Mathematically main.zig:361-389; in floating point the weights are
+// e^(s-m_c) * e^(m_c-M) / L instead of e^(s-M) / L (a few ulp), well inside the logit
+// tolerance, and independent of GPU count (attention is head-local).
+// part layout: [head][chunk][head_size + 4] floats = o_c[head_size], m_c, l_c, pad, pad
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void attention_split_kernel(const AttnArgs a, int nch,
+                                                                 float *__restrict__ part_out)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int hs = a.head_size;
+    const AttnGeom ge = attn_geom(hs, true, kBlock);
+    const int max_local = (a.seq_len + nch - 1) / nch;
+    float *sc = lds;                                   // local scores
+    float *wt = sc + ((max_local + 3) & ~3);           // local unnormalised weights
+    float *part = wt + ((max_local + 3) & ~3);         // G*hs
+    const int h = blockIdx.x / nch, c = blockIdx.x % nch;
+    const int kvh = h / a.kv_mul;                      // :369
+    const float *kbase = a.kcache + (size_t)kvh * hs;
+    const float *vbase = a.vcache + (size_t)kvh * hs;
+    const size_t stride = (size_t)a.kv_dim;
+    const int g = threadIdx.x / ge.TPR, c0 = threadIdx.x % ge.TPR;
+    const bool active = c0 < ge.E;
+    const int cc = active ? c0 : 0;
+    const int step = ge.G * kFastUB;
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+
+    const int T = *a.pos_ptr + 1;                      // :367
+    const int Tc = T > c ? (T - c + nch - 1) / nch : 0;  // timesteps owned by this block
+    float *po = part_out + ((size_t)h * nch + c) * (size_t)(hs + 4);
+    if (Tc == 0) {  // pos < c: empty chunk (uniform branch)
+        for (int i = threadIdx.x; i < hs; i += blockDim.x) po[i] = 0.0f;
+        if (threadIdx.x == 0) { po[hs] = -INFINITY; po[hs + 1] = 0.0f; }
+        return;
+    }
+    const v4f qv = active ? ((const v4f *)(a.q + (size_t)h * hs))[cc] : zero;
+    v4f kr[kFastUB], vr[kFastUB];
+#pragma unroll
+    for (int i = 0; i < kFastUB; i++) {  // rows clamped to the chunk's last one (duplicates hit L1)
+        int j = g + ge.G * i;
+        j = j < Tc ? j : Tc - 1;
+        kr[i] = ((const v4f *)(kbase + (size_t)(c + nch * j) * stride))[cc];
+    }
+#pragma unroll
+    for (int i = 0; i < kFastUB; i++) {
+        int j = g + ge.G * i;
+        j = j < Tc ? j : Tc - 1;
+        vr[i] = ((const v4f *)(vbase + (size_t)(c + nch * j) * stride))[cc];
+    }
+    const float div = sqrtf((float)hs);
+    for (int j0 = g;;) {  // scores (:367-375), local index j <-> t = c + nch*j
+#pragma unroll
+        for (int i = 0; i < kFastUB; i++) {
+            float p = hsum4(fma4(qv, kr[i], zero));
+            p = lanes_sum(p, ge.TPR);
+            const int j = j0 + ge.G * i;
+            if (c0 == 0 && j < Tc) sc[j] = p / div;  // :372
+        }
+        j0 += step;
+        if (j0 >= Tc) break;
+#pragma unroll
+        for (int i = 0; i < kFastUB; i++) {
+            int j = j0 + ge.G * i;
+            j = j < Tc ? j : Tc - 1;
+            kr[i] = ((const v4f *)(kbase + (size_t)(c + nch * j) * stride))[cc];
+        }
+    }
+    __syncthreads();
+    // chunk-local max and sum of exponentials, redundantly per wave (identical in every wave)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float m = -INFINITY;
+    for (int j = lane; j < Tc; j += kWave) m = fmaxf(m, sc[j]);
+    m = wave_max(m);
+    float l = 0.0f;
+    for (int j = lane; j < Tc; j += kWave) l += expf(sc[j] - m);
+    l = wave_sum(l);
+    for (int j = wave * kWave + lane; j < Tc; j += kBlock) wt[j] = expf(sc[j] - m);  // unnormalised
+    __syncthreads();
+    v4f acc = zero;
+    for (int j0 = g;;) {  // weighted V (:381-388), increasing t within the group
+#pragma unroll
+        for (int i = 0; i < kFastUB; i++) {
+            const int j = j0 + ge.G * i;
+            const float w = j < Tc ? wt[j] : 0.0f;
+            acc.x = fmaf(vr[i].x, w, acc.x);
+            acc.y = fmaf(vr[i].y, w, acc.y);
+            acc.z = fmaf(vr[i].z, w, acc.z);
+            acc.w = fmaf(vr[i].w, w, acc.w);
+        }
+        j0 += step;
+        if (j0 >= Tc) break;
+#pragma unroll
+        for (int i = 0; i < kFastUB; i++) {
+            int j = j0 + ge.G * i;
+            j = j < Tc ? j : Tc - 1;
+            vr[i] = ((const v4f *)(vbase + (size_t)(c + nch * j) * stride))[cc];
+        }
+    }
+    if (active) ((v4f *)(part + (size_t)g * hs))[cc] = acc;
+    __syncthreads();
+    reduce_partials(part, ge.G, hs, po);
+    if (threadIdx.x == 0) { po[hs] = m; po[hs + 1] = l; }
+}
+
+__global__ void attention_combine_kernel(const float *__restrict__ part_in, int nch, int hs,
+                                         float *__restrict__ xb, const P2pArgs *push)
+{
+    constexpr int kMaxCh = 16;
+    const int h = blockIdx.x;
+    const float *p = part_in + (size_t)h * nch * (size_t)(hs + 4);
+    float mc[kMaxCh], lc[kMaxCh];
+#pragma unroll
+    for (int c = 0; c < kMaxCh; c++) {  // all chunk statistics in one round trip
+        const int cc = c < nch ? c : 0;
+        mc[c] = p[(size_t)cc * (hs + 4) + hs];
+        lc[c] = p[(size_t)cc * (hs + 4) + hs + 1];
+    }
+    float M = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < kMaxCh; c++)
+        if (c < nch) M = fmaxf(M, mc[c]);
+    float den = 0.0f;
+#pragma unroll
+    for (int c = 0; c < kMaxCh; c++) {
+        mc[c] = c < nch ? expf(mc[c] - M) : 0.0f;  // scale of chunk c; empty chunk: e^(-inf) = 0
+        den = fmaf(lc[c], mc[c], den);
+    }
+    for (int i = threadIdx.x; i < hs; i += blockDim.x) {
+        float oc[kMaxCh];
+#pragma unroll
+        for (int c = 0; c < kMaxCh; c++) oc[c] = p[(size_t)(c < nch ? c : 0) * (hs + 4) + i];
+        float num = 0.0f;
+#pragma unroll
+        for (int c = 0; c < kMaxCh; c++) num = fmaf(oc[c], mc[c], num);
+        const float v = num / den;
+        xb[(size_t)h * hs + i] = v;
+        if (push)
+            p2p_ll_push(push, p2p_ll_epoch(push), (size_t)push->rank * push->count + (size_t)h * hs + i, v);
+    }
+}
+
+// Generic path: any head_size / alignment.
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void attention_kernel(const AttnArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int hs = a.head_size;
+    const AttnGeom ge = attn_geom(hs, VEC);
+    float *qs = lds;                                  // hs
+    float *att = qs + ((hs + 3) & ~3);                // seq_len
+    float *part = att + ((a.seq_len + 3) & ~3);       // G*hs
+    float *scratch = part + (size_t)ge.G * hs;        // kScratch
+
+    const int h = blockIdx.x;
+    const int kvh = h / a.kv_mul;                     // :369 (h / kv_mul) * head_size
+    const int T = *a.pos_ptr + 1;                     // timesteps 0..pos inclusive (:367)
+    for (int i = threadIdx.x; i < hs; i += blockDim.x) qs[i] = a.q[(size_t)h * hs + i];
+    __syncthreads();
+    attn_scores<VEC>(qs, a.kcache + (size_t)kvh * hs, a.kv_dim, hs, T, sqrtf((float)hs), att);
+    __syncthreads();
+    block_softmax(att, T, scratch);                   // :378
+    attn_weighted_sum<VEC>(att, a.vcache + (size_t)kvh * hs, a.kv_dim, hs, T, part,
+                           a.xb + (size_t)h * hs);    // :381-388
+}
+
+// Stand-alone wrappers for the test hooks: the same device functions as the attention kernels.
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void dot_kernel(float *out, const float *x, const float *y,
+                                                     int n)
+{
+    // one "timestep" with head_size = n and divisor 1 (x/1 is exact)
+    __shared__ float r;
+    attn_scores<VEC>(x, y, 0, n, 1, 1.0f, &r);
+    __syncthreads();
+    if (threadIdx.x == 0) *out = r;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void wsum_rows_kernel(float *xout, int xout_len,
+                                                           const float *rows, int row_stride,
+                                                           const float *weights, int n_weights,
+                                                           float *part)
+{
+    attn_weighted_sum<VEC>(weights, rows, row_stride, xout_len, n_weights, part, xout);
+}
+
+
+}  // namespace
+
+size_t attention_lds_bytes(int head_size, int seq_len, bool vec)
+{
+    const AttnGeom ge = attn_geom(head_size, vec);
+    size_t fl = (size_t)((head_size + 3) & ~3) + ((seq_len + 3) & ~3) + (size_t)ge.G * head_size + kScratch;
+    if (vec && head_size <= 256) {  // fast kernel geometry
+        const AttnGeom gf = attn_geom(head_size, true, kAttnFastBlock);
+        const size_t f2 = 2 * (size_t)((seq_len + 3) & ~3) + (size_t)gf.G * head_size;
+        if (f2 > fl) fl = f2;
+    }
+    return fl * sizeof(float);
+}
+
+int attention_split_chunks(int n_heads_local, int n_cus)
+{
+    int nch = n_cus / (n_heads_local > 0 ? n_heads_local : 1);
+    if (nch > 16) nch = 16;
+    if (nch < 1) nch = 1;
+    return nch;
+}
+
+size_t attention_split_part_floats(int n_heads_local, int head_size, int nch)
+{
+    return (size_t)n_heads_local * nch * (size_t)(head_size + 4);
+}
+
+hipError_t launch_attention_split(const AttnArgs &a, int n_heads_local, int nch, float *part,
+                                  hipStream_t st)
+{
+    const AttnGeom ge = attn_geom(a.head_size, true, kBlock);
+    const int max_local = (a.seq_len + nch - 1) / nch;
+    const size_t lds = (size_t)(2 * ((max_local + 3) & ~3) + ge.G * a.head_size) * sizeof(float);
+    hipError_t e = ensure_lds(attention_split_kernel, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(attention_split_kernel, dim3(n_heads_local * nch), dim3(kBlock), lds, st, a,
+                       nch, part);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    int ct = (a.head_size + 63) & ~63;
+    if (ct > 1024) ct = 1024;
+    hipLaunchKernelGGL(attention_combine_kernel, dim3(n_heads_local), dim3(ct), 0, st, part, nch,
+                       a.head_size, a.xb, a.push);
+    return hipGetLastError();
+}
+
+bool attention_push_supported(const AttnArgs &a)
+{
+    return (a.head_size % 4) == 0 && (a.kv_dim % 4) == 0 && a.head_size <= 256 && aligned16(a.q) &&
+           aligned16(a.kcache) && aligned16(a.vcache);  // the fast / split kernels, not the generic one
+}
+
+bool attention_split_supported(const AttnArgs &a)
+{
+    return (a.head_size % 4) == 0 && a.head_size <= 256 && (a.kv_dim % 4) == 0 && aligned16(a.q) &&
+           aligned16(a.kcache) && aligned16(a.vcache);
+}
+
+hipError_t launch_attention(const AttnArgs &a, int n_heads_local, hipStream_t st)
+{
+    const bool vec = (a.head_size % 4) == 0 && (a.kv_dim % 4) == 0 && aligned16(a.q) &&
+                     aligned16(a.kcache) && aligned16(a.vcache);
+    const size_t lds = attention_lds_bytes(a.head_size, a.seq_len, vec);
+    if (vec && a.head_size <= 256) {
+        static const int forced = getenv("L2Z_ATTN_BLOCK") ? atoi(getenv("L2Z_ATTN_BLOCK")) : 0;
+        const int nt = forced ? forced : (a.seq_len > 512 ? kAttnFastBlock : kBlock);
+        const AttnGeom gf = attn_geom(a.head_size, true, nt);
+        const size_t lds_fast = (size_t)(2 * ((a.seq_len + 3) & ~3) + gf.G * a.head_size) * sizeof(float);
+        if (nt == kAttnFastBlock) {
+            hipError_t e = ensure_lds(attention_fast_kernel<kAttnFastBlock, false>, lds_fast);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((attention_fast_kernel<kAttnFastBlock, false>), dim3(n_heads_local),
+                               dim3(kAttnFastBlock), lds_fast, st, a);
+        } else {
+            hipError_t e = ensure_lds(attention_fast_kernel<kBlock, true>, lds_fast);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((attention_fast_kernel<kBlock, true>), dim3(n_heads_local),
+                               dim3(kBlock), lds_fast, st, a);
+        }
+        return hipGetLastError();
+    }
+    if (vec) {
+        hipError_t e = ensure_lds(attention_kernel<true>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((attention_kernel<true>), dim3(n_heads_local), dim3(kBlock), lds, st, a);
+    } else {
+        hipError_t e = ensure_lds(attention_kernel<false>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((attention_kernel<false>), dim3(n_heads_local), dim3(kBlock), lds, st, a);
+    }
+    return hipGetLastError();
+}
+
+#ifdef L2Z_DBG_TS
+hipError_t dbg_ts_read(long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_ts), 16 * sizeof(long long));
+}
+#endif
+
+hipError_t launch_dot(float *out, const float *x, const float *y, int n, hipStream_t st)
+{
+    const bool vec = (n % 4) == 0 && aligned16(x) && aligned16(y);
+    if (vec)
+        hipLaunchKernelGGL((dot_kernel<true>), dim3(1), dim3(kBlock), 0, st, out, x, y, n);
+    else
+        hipLaunchKernelGGL((dot_kernel<false>), dim3(1), dim3(kBlock), 0, st, out, x, y, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_weighted_sum_rows(float *xout, int xout_len, const float *rows, int row_stride,
+                                    const float *weights, int n_weights, hipStream_t st)
+{
+    const bool vec = (xout_len % 4) == 0 && (row_stride % 4) == 0 && aligned16(rows) &&
+                     aligned16(xout);
+    float *part = nullptr;
+    hipError_t e = hipMalloc(&part, (size_t)kBlock * xout_len * sizeof(float));
+    if (e != hipSuccess) return e;
+    if (vec)
+        hipLaunchKernelGGL((wsum_rows_kernel<true>), dim3(1), dim3(kBlock), 0, st, xout, xout_len,
+                           rows, row_stride, weights, n_weights, part);
+    else
+        hipLaunchKernelGGL((wsum_rows_kernel<false>), dim3(1), dim3(kBlock), 0, st, xout, xout_len,
+                           rows, row_stride, weights, n_weights, part);
+    e = hipGetLastError();
+    hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(part);
+    return e != hipSuccess ? e : e2;
+}
+
+
+}  // namespace l2z

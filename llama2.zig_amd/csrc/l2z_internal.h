@@ -117,7 +117,7 @@ struct ArgmaxArgs {
     int advance;             // 1: greedy step (write token/pos/x), 0: argmax only
 };
 
-// Launchers (kernels.hip).  All return a hipError_t from the launch.
+// Launchers (matvec.hip, attention.hip, misc_kernels.hip).  All return a hipError_t from the launch.
 // pushed: set to whether a.push was honoured (row kernel only)
 hipError_t launch_matvec(const MatvecArgs &a, int pro, int epi, int max_blocks_per_cu, int n_cus,
                          hipStream_t st, int *out_grid = nullptr, bool *pushed = nullptr);
@@ -128,7 +128,7 @@ bool matvec_vector_width(int n);
 // out: >= 8 * n_cus floats of scratch (never written in practice)
 hipError_t launch_stream_read(const float *p, size_t n_floats, float *out, int n_cus, hipStream_t st);  // upper bound of the grid launch_matvec picks
 hipError_t launch_attention(const AttnArgs &a, int n_heads_local, hipStream_t st);
-// flash-decoding form: `nch` blocks per head + a combine launch (kernels.hip)
+// flash-decoding form: `nch` blocks per head + a combine launch (attention.hip)
 int attention_split_chunks(int n_heads_local, int n_cus);
 size_t attention_split_part_floats(int n_heads_local, int head_size, int nch);
 bool attention_split_supported(const AttnArgs &a);

@@ -1,0 +1,691 @@
+// matvec.hip (with attention.hip, misc_kernels.hip, kernel_common.h) -- hand-written gfx950
+// (CDNA4, wave64) kernels for the llama2.zig forward pass.  Every kernel cites the reference lines (src/main.zig) whose
+// arithmetic it performs.  Compiled with -ffp-contract=off: every fused
+// multiply-add below is an explicit fmaf(), everything else rounds once per
+// operation exactly like the reference's scalar code.
+//
+// Design (DESIGN.md has the numbers):
+//  * mat-vec is pure HBM streaming (0.5 flop/byte): one wave owns two weight
+//    rows at a time, each lane issues 16-byte non-temporal loads (1 KiB per
+//    wave-instruction, 8 in flight per lane), x is staged once per block in
+//    LDS, dot products finish with a wave-wide xor-shuffle reduction.  One
+//    fixed summation order per output row => results do not depend on grid
+//    size or on how rows are sharded over GPUs.
+//  * what the reference does immediately before / after each matmul is fused
+//    into that launch: rmsnorm (prologue), RoPE + KV-cache write, residual
+//    add, SiLU*mul (epilogues).  5 launches per layer.
+//  * token and position live in device memory so one captured hipGraph per
+//    step can be replayed without host involvement.
+// matvec.hip: the fused mat-vec kernels (narrow rows, wide rows, generic scalar) and their launcher.
+#include "kernel_common.h"
+
+namespace l2z {
+namespace {
+
+// Two dot products against the staged x, generic scalar form (any n / alignment).
+__device__ __forceinline__ void dot2_scalar(const float *__restrict__ pa,
+                                            const float *__restrict__ pb, const float *xs, int n,
+                                            float &ra, float &rb)
+{
+    const int lane = threadIdx.x & 63;
+    float sa = 0.0f, sb = 0.0f;
+    for (int j = lane; j < n; j += kWave) {
+        const float xv = xs[j];
+        sa = fmaf(pa[j], xv, sa);
+        sb = fmaf(pb[j], xv, sb);
+    }
+    ra = wave_sum(sa);
+    rb = wave_sum(sb);
+}
+
+// ---------------------------------------------------------------------------
+// The fused mat-vec.  main.zig:530-605 matmul_fused with its neighbours:
+//   PRO_RMS    rmsnorm before it                   :305 / :398 / :426
+//   EPI_ROPE   RoPE on q,k + KV-cache row write    :336-358
+//   EPI_RESID  accum into the residual stream      :395 / :422
+//   EPI_SWIGLU silu(w1.x) * (w3.x)                 :411-416
+//
+// Work decomposition.  A "pair" is two weight rows that share x reads (rows
+// 2p,2p+1 of the concatenated row space -- exactly the RoPE pair (i,i+1) -- or
+// row p of w1 and of w3 for SwiGLU).  LPR lanes cooperate on one pair, so a
+// wave works on 64/LPR pairs at once:
+//   LPR = 64 : large n (7B shapes): one pair per wave, 1 KiB per load instruction
+//   LPR < 64 : small n (stories15M/110M): several pairs per wave so that all 64
+//              lanes load 16 B and a whole row is in flight at once
+// Lane cl of a group takes float4 columns cl, cl+LPR, ... in increasing order
+// into 4 component accumulators, then (x+y)+(z+w), then an xor-shuffle over the
+// group.  LPR is a function of n only, so a row's summation order never
+// depends on the grid, the row count or how rows are sharded over GPUs.
+//
+// Latency.  Each wave issues the loads of its first weight batch BEFORE the
+// block stages x (x's own loads are issued first and return first), so HBM
+// latency overlaps the rmsnorm prologue instead of following it.
+//
+// All kernel arguments are read into scalars and selected with arithmetic:
+// indexing the by-value argument block dynamically pushes it into scratch.
+// ---------------------------------------------------------------------------
+// Kernel arguments copied into plain locals once (keeps them out of scratch).
+struct MvLocals {
+    const float *w0, *w1, *w2;
+    float *out0, *out1, *out2;
+    const float *resid;
+    const float2 *rope;
+    int rows0, r01, total_rows, n_pairs, n, head_size, rope_segs, pos;
+    size_t ps1, ps2;
+    const P2pArgs *push;  // sharded: LL words of the outputs go straight to the peers
+    int push_e;
+    size_t push_base;     // index of out0[0] in the gathered vector
+};
+
+template <int EPI>
+__device__ __forceinline__ MvLocals mv_locals(const MatvecArgs &a)
+{
+    MvLocals m;
+    m.w0 = a.w0; m.w1 = a.w1; m.w2 = a.w2;
+    m.out0 = a.out0; m.out1 = a.out1; m.out2 = a.out2;
+    m.resid = a.resid; m.rope = a.rope;
+    m.rows0 = a.rows0; m.r01 = a.rows0 + a.rows1; m.total_rows = a.rows0 + a.rows1 + a.rows2;
+    m.n_pairs = (EPI == EPI_SWIGLU) ? a.rows0 : (m.total_rows + 1) >> 1;
+    m.n = a.n; m.head_size = a.head_size; m.rope_segs = a.rope_segs;
+    m.pos = (EPI == EPI_ROPE) ? *a.pos_ptr : 0;
+    m.ps1 = (size_t)m.pos * (size_t)a.pos_stride1;
+    m.ps2 = (size_t)m.pos * (size_t)a.pos_stride2;
+    m.push = a.push;
+    m.push_e = m.push ? p2p_ll_epoch(m.push) : 0;
+    m.push_base = m.push ? (size_t)m.push->rank * m.push->count : 0;
+    return m;
+}
+
+// the two weight rows of pair p (clamped to the last pair for idle lane groups)
+template <int EPI>
+__device__ __forceinline__ void pair_rows(const MvLocals &m, int p, const float *&pa,
+                                          const float *&pb)
+{
+    if (p >= m.n_pairs) p = m.n_pairs - 1;
+    if (EPI == EPI_SWIGLU) {
+        pa = m.w0 + (size_t)p * (size_t)m.n;
+        pb = m.w1 + (size_t)p * (size_t)m.n;
+    } else {
+        const int ga = 2 * p;
+        const int gb = (ga + 1 < m.total_rows) ? ga + 1 : ga;
+        const bool a1 = ga >= m.rows0, a2 = ga >= m.r01;
+        const bool b1 = gb >= m.rows0, b2 = gb >= m.r01;
+        const int row_a = ga - (a2 ? m.r01 : (a1 ? m.rows0 : 0));
+        const int row_b = gb - (b2 ? m.r01 : (b1 ? m.rows0 : 0));
+        const float *wa = a1 ? m.w1 : m.w0;
+        wa = a2 ? m.w2 : wa;
+        const float *wb = b1 ? m.w1 : m.w0;
+        wb = b2 ? m.w2 : wb;
+        pa = wa + (size_t)row_a * (size_t)m.n;
+        pb = wb + (size_t)row_b * (size_t)m.n;
+    }
+}
+
+// What the epilogue of pair p reads from memory (residual values, RoPE cos/sin).  Loaded by
+// the writer lane when the pair's weight loads are issued, so the epilogue itself never
+// waits on memory (a dependent L2 round trip per unit otherwise: ~1 us, serialised).
+struct EpiIn {
+    float ra, rb;
+    float2 cs;
+};
+
+template <int EPI>
+__device__ __forceinline__ EpiIn epi_prefetch(const MvLocals &m, int p, bool writer)
+{
+    EpiIn e;
+    e.ra = 0.0f; e.rb = 0.0f; e.cs = make_float2(1.0f, 0.0f);
+    if (!writer || p >= m.n_pairs) return e;
+    if (EPI == EPI_RESID) {  // single segment: rows 2p, 2p+1
+        const int ga = 2 * p, gb = ga + 1;
+        e.ra = m.resid[ga];
+        if (gb < m.total_rows) e.rb = m.resid[gb];
+    } else if (EPI == EPI_ROPE) {
+        const int ga = 2 * p;
+        const bool a1 = ga >= m.rows0, a2 = ga >= m.r01;
+        const int seg_a = a2 ? 2 : (a1 ? 1 : 0);
+        const int row_a = ga - (a2 ? m.r01 : (a1 ? m.rows0 : 0));
+        if (seg_a < m.rope_segs) {
+            const int hs = m.head_size;
+            e.cs = m.rope[(size_t)m.pos * (size_t)(hs >> 1) + (size_t)((row_a % hs) >> 1)];
+        }
+    }
+    return e;
+}
+
+template <int EPI>
+__device__ __forceinline__ void pair_epilogue(const MvLocals &m, int p, float sa, float sb,
+                                              bool writer, const EpiIn &in)
+{
+    const bool valid_a = p < m.n_pairs;
+    if (EPI == EPI_SWIGLU) {
+        float v = sa;
+        v = v * (1.0f / (1.0f + expf(-v)));  // :412
+        v = v * sb;                          // :416
+        if (writer && valid_a) {
+            m.out0[p] = v;
+            if (m.push) p2p_ll_push(m.push, m.push_e, m.push_base + (size_t)p, v);
+        }
+        return;
+    }
+    const int ga = 2 * p, gb = ga + 1;
+    const bool valid_b = valid_a && gb < m.total_rows;
+    const bool a1 = ga >= m.rows0, a2 = ga >= m.r01;
+    const bool b1 = gb >= m.rows0, b2 = gb >= m.r01;
+    const int row_a = ga - (a2 ? m.r01 : (a1 ? m.rows0 : 0));
+    const int row_b = gb - (b2 ? m.r01 : (b1 ? m.rows0 : 0));
+    float *oa = a1 ? m.out1 + m.ps1 : m.out0;
+    oa = a2 ? m.out2 + m.ps2 : oa;
+    float *ob = b1 ? m.out1 + m.ps1 : m.out0;
+    ob = b2 ? m.out2 + m.ps2 : ob;
+    if (EPI == EPI_ROPE) {
+        // rows (row_a, row_a+1) of one segment: the pair (i, i+1) of :346-349
+        float o0 = sa, o1 = sb;
+        const int seg_a = a2 ? 2 : (a1 ? 1 : 0);
+        if (seg_a < m.rope_segs) {
+            const float2 cs = in.cs;     // rope[pos][(row_a % head_size)/2], prefetched
+            o0 = sa * cs.x - sb * cs.y;  // :348
+            o1 = sa * cs.y + sb * cs.x;  // :349
+        }
+        if (writer && valid_a) {  // q, or the pos row of the K / V cache (:354-358)
+            oa[row_a] = o0;
+            if (valid_b) ob[row_b] = o1;
+        }
+    } else if (EPI == EPI_RESID) {
+        if (writer && valid_a) {
+            const float va = in.ra + sa, vb = in.rb + sb;  // :711 a[i] += b[i]  (resid[row] prefetched)
+            oa[row_a] = va;
+            if (valid_b) ob[row_b] = vb;
+            if (m.push) {  // single segment on this path: row == index in the slice
+                p2p_ll_push(m.push, m.push_e, m.push_base + (size_t)row_a, va);
+                if (valid_b) p2p_ll_push(m.push, m.push_e, m.push_base + (size_t)row_b, vb);
+            }
+        }
+    } else {
+        if (writer && valid_a) {
+            oa[row_a] = sa;
+            if (valid_b) ob[row_b] = sb;
+            if (m.push) {
+                p2p_ll_push(m.push, m.push_e, m.push_base + (size_t)row_a, sa);
+                if (valid_b) p2p_ll_push(m.push, m.push_e, m.push_base + (size_t)row_b, sb);
+            }
+        }
+    }
+}
+
+template <int LPR>
+struct MvGeom {
+    static constexpr int RW = kWave / LPR;          // pairs per wave
+    static constexpr int U = (LPR == 64) ? 4 : 6;   // float4 per row per lane per batch
+};
+
+// Issue one batch: U float4 of row a and of row b at columns c0 + k*LPR.  Columns past
+// the row end are clamped to its last float4: the matching x entries in LDS are the
+// zero padding, so they add exactly 0 (weights are finite) -- no predicated loads.
+template <int LPR>
+__device__ __forceinline__ void mv_load(const float *pa, const float *pb, int c0, int cb, int n4,
+                                        v4f (&wa)[MvGeom<LPR>::U], v4f (&wb)[MvGeom<LPR>::U])
+{
+    constexpr int U = MvGeom<LPR>::U;
+    const v4f *a4 = (const v4f *)pa, *b4 = (const v4f *)pb;
+    if (LPR == 64) {
+        // n4 % 64 == 0 (checked by the launcher): whether step k of the batch that starts
+        // at column cb is inside the row is the same for every lane.  Out-of-row steps
+        // re-read step 0 (their x entries are the zero padding).
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const int off = (cb + 64 * k < n4) ? 64 * k : 0;  // wave-uniform
+            wa[k] = ldg_nt(a4 + c0 + off);
+            wb[k] = ldg_nt(b4 + c0 + off);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            int c = c0 + LPR * k;
+            c = c < n4 ? c : n4 - 1;
+            wa[k] = ldg_nt(a4 + c);
+            wb[k] = ldg_nt(b4 + c);
+        }
+    }
+}
+
+template <int LPR>
+__device__ __forceinline__ void mv_consume(const v4f *xs4, int c0, const v4f (&wa)[MvGeom<LPR>::U],
+                                           const v4f (&wb)[MvGeom<LPR>::U], v4f &acc_a, v4f &acc_b)
+{
+    constexpr int U = MvGeom<LPR>::U;
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+        const v4f xv = xs4[c0 + LPR * k];  // zero padded to whole batches
+        acc_a = fma4(wa[k], xv, acc_a);
+        acc_b = fma4(wb[k], xv, acc_b);
+    }
+}
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v)
+{
+    return lanes_sum(v, LPR);
+}
+
+template <int PRO, int EPI, int LPR, int XC>
+__global__ __launch_bounds__(kBlock) void matvec_kernel(const MatvecArgs a)
+{
+    using G = MvGeom<LPR>;
+    constexpr int U = G::U, RW = G::RW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const MvLocals m = mv_locals<EPI>(a);
+    const int n4 = m.n >> 2;
+    const int n_batches = (n4 + LPR * U - 1) / (LPR * U);
+    const int n4_pad = n_batches * (LPR * U);
+    float *xs = lds;
+    float *scratch = lds + 4 * n4_pad;
+    const v4f *xs4 = (const v4f *)xs;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / LPR, cl = lane % LPR;
+    const int n_units = (m.n_pairs + RW - 1) / RW;
+    const int ustride = gridDim.x * kWaves;
+
+    // 1. issue x loads (they return first), 2. issue the first weight batch, 3. stage x
+    v4f xr[XC], gr[XC];
+    xload_issue<PRO, XC>(a.x, a.rms_w, n4, xr, gr);
+    int u = blockIdx.x * kWaves + wave;
+    const bool has_unit = u < n_units;
+    const float *pa, *pb;
+    pair_rows<EPI>(m, (has_unit ? u : 0) * RW + grp, pa, pb);
+    v4f wa[U], wb[U];
+    EpiIn ein = epi_prefetch<EPI>(m, (has_unit ? u : 0) * RW + grp, cl == 0 && has_unit);
+    EpiIn ein_next = ein;
+    mv_load<LPR>(pa, pb, cl, 0, n4, wa, wb);
+    xstage_finish<PRO, XC>(a.x, a.rms_w, m.n, n4_pad, xr, gr, xs, scratch);
+    if (EPI != EPI_ARGMAX && !has_unit) return;
+
+    // flat loop over (unit, batch): consume the batch in registers, then immediately
+    // issue the next one -- the next unit's first batch included -- before reducing
+    v4f acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
+    float best_v = -INFINITY;  // EPI_ARGMAX: running (max, first index) of this lane's rows
+    int best_i = 0x7fffffff;
+    int b = 0;
+    while (has_unit) {
+        mv_consume<LPR>(xs4, cl + b * (LPR * U), wa, wb, acc_a, acc_b);
+        const bool unit_done = (b + 1 == n_batches);
+        const int u_next = unit_done ? u + ustride : u;
+        const int b_next = unit_done ? 0 : b + 1;
+        const bool more = u_next < n_units;
+        if (more) {
+            if (unit_done) {
+                pair_rows<EPI>(m, u_next * RW + grp, pa, pb);
+                ein_next = epi_prefetch<EPI>(m, u_next * RW + grp, cl == 0);
+            }
+            mv_load<LPR>(pa, pb, cl + b_next * (LPR * U), b_next * (LPR * U), n4, wa, wb);
+        }
+        if (unit_done) {
+            const float sa = group_sum<LPR>(hsum4(acc_a));
+            const float sb = group_sum<LPR>(hsum4(acc_b));
+            pair_epilogue<EPI>(m, u * RW + grp, sa, sb, cl == 0, ein);
+            ein = ein_next;
+            if (EPI == EPI_ARGMAX) {  // single segment: pair p = rows 2p, 2p+1
+                const int ra_ = 2 * (u * RW + grp), rb_ = ra_ + 1;
+                if (ra_ < m.total_rows && (sa > best_v || best_i == 0x7fffffff)) {
+                    best_v = sa; best_i = ra_ + a.row_offset;
+                }
+                if (rb_ < m.total_rows && sb > best_v) {  // strict '>' : first index wins ties
+                    best_v = sb; best_i = rb_ + a.row_offset;
+                }
+            }
+            acc_a = v4f{0.f, 0.f, 0.f, 0.f};
+            acc_b = v4f{0.f, 0.f, 0.f, 0.f};
+        }
+        if (!more) break;
+        u = u_next;
+        b = b_next;
+    }
+    if (EPI == EPI_ARGMAX) {
+        // block candidate: larger value wins, equal values -> lower index (main.zig:720)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best_v, o, 64);
+            const int oi = __shfl_xor(best_i, o, 64);
+            if (oi != 0x7fffffff && (best_i == 0x7fffffff || ov > best_v || (ov == best_v && oi < best_i))) {
+                best_v = ov; best_i = oi;
+            }
+        }
+        __syncthreads();
+        if (lane == 0) {
+            scratch[wave] = best_v;
+            scratch[kWaves + wave] = __int_as_float(best_i);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float bv = scratch[0];
+            int bi = __float_as_int(scratch[kWaves]);
+            for (int w = 1; w < kWaves; w++) {
+                const float ov = scratch[w];
+                const int oi = __float_as_int(scratch[kWaves + w]);
+                if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) {
+                    bv = ov; bi = oi;
+                }
+            }
+            a.part_val[blockIdx.x] = bv;
+            a.part_idx[blockIdx.x] = bi;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Wide rows (n >= 4096, n/4 a multiple of 64: the 7B shapes): the WHOLE BLOCK works on
+// one pair.  Rows 2p and 2p+1 are adjacent in memory, so a block reads one contiguous
+// 8n-byte run per unit and consecutive blocks read consecutive runs -- the chip sweeps
+// the matrix linearly, like a plain streaming read (DRAM page locality: +10 % over
+// giving every wave its own row pair, measured).  Thread t takes float4 columns
+// t, t+256, ...; per-thread component accumulators, (x+y)+(z+w), wave xor-shuffle,
+// then the 4 wave partials are added in wave order.  Still a function of n only.
+// ---------------------------------------------------------------------------
+template <int PRO, int EPI, int XC>
+__global__ __launch_bounds__(kBlock) void matvec_row_kernel(const MatvecArgs a)
+{
+    constexpr int U = 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const MvLocals m = mv_locals<EPI>(a);
+    const int n4 = m.n >> 2;
+    const int n_batches = (n4 + kBlock * U - 1) / (kBlock * U);
+    const int n4_pad = n_batches * (kBlock * U);
+    float *xs = lds;
+    float *scratch = lds + 4 * n4_pad;            // kScratch floats
+    float *part = scratch + kScratch;             // [2][kWaves][2] wave partials
+    const v4f *xs4 = (const v4f *)xs;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_units = m.n_pairs;
+    const int ustride = gridDim.x;
+
+    v4f xr[XC], gr[XC];
+    xload_issue<PRO, XC>(a.x, a.rms_w, n4, xr, gr);
+    int u = blockIdx.x;  // grid <= n_units
+    const float *pa, *pb;
+    pair_rows<EPI>(m, u, pa, pb);
+    v4f wa[U], wb[U];
+    auto load = [&](int cb) {  // columns cb + tid + 256k; validity is wave-uniform (n4 % 64 == 0)
+        const v4f *a4 = (const v4f *)pa + cb + tid, *b4 = (const v4f *)pb + cb + tid;
+        const int wbase = cb + (tid & ~63);
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const int off = (wbase + kBlock * k < n4) ? kBlock * k : -(cb + (tid & ~63));
+            wa[k] = ldg_nt(a4 + off);  // out-of-row steps re-read the row start; their x is 0
+            wb[k] = ldg_nt(b4 + off);
+        }
+    };
+    EpiIn ein = epi_prefetch<EPI>(m, u, tid == 0);
+    EpiIn ein_next = ein;
+    load(0);
+    xstage_finish<PRO, XC>(a.x, a.rms_w, m.n, n4_pad, xr, gr, xs, scratch);
+
+    v4f acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
+    float best_v = -INFINITY;
+    int best_i = 0x7fffffff;
+    int b = 0, parity = 0;
+    while (true) {
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const v4f xv = xs4[b * (kBlock * U) + tid + kBlock * k];
+            acc_a = fma4(wa[k], xv, acc_a);
+            acc_b = fma4(wb[k], xv, acc_b);
+        }
+        const bool unit_done = (b + 1 == n_batches);
+        const int u_next = unit_done ? u + ustride : u;
+        const int b_next = unit_done ? 0 : b + 1;
+        const bool more = u_next < n_units;
+        if (more) {
+            if (unit_done) {
+                pair_rows<EPI>(m, u_next, pa, pb);
+                ein_next = epi_prefetch<EPI>(m, u_next, tid == 0);
+            }
+            load(b_next * (kBlock * U));
+        }
+        if (unit_done) {
+#ifdef L2Z_DBG_NOREDUCE
+            const float sa = hsum4(acc_a), sb = hsum4(acc_b);
+#else
+            const float sa = wave_sum(hsum4(acc_a));
+            const float sb = wave_sum(hsum4(acc_b));
+#endif
+            float *pp = part + parity * (2 * kWaves);
+            if (lane == 0) {
+                pp[wave] = sa;
+                pp[kWaves + wave] = sb;
+            }
+#ifndef L2Z_DBG_NOBARRIER
+            __syncthreads();
+#endif
+            if (tid == 0) {
+                const float ta = ((pp[0] + pp[1]) + pp[2]) + pp[3];
+                const float tb = ((pp[kWaves] + pp[kWaves + 1]) + pp[kWaves + 2]) + pp[kWaves + 3];
+                pair_epilogue<EPI>(m, u, ta, tb, true, ein);
+                if (EPI == EPI_ARGMAX) {
+                    const int ra_ = 2 * u, rb_ = ra_ + 1;
+                    if (ta > best_v || best_i == 0x7fffffff) { best_v = ta; best_i = ra_ + a.row_offset; }
+                    if (rb_ < m.total_rows && tb > best_v) { best_v = tb; best_i = rb_ + a.row_offset; }
+                }
+            }
+            ein = ein_next;
+            parity ^= 1;
+            acc_a = v4f{0.f, 0.f, 0.f, 0.f};
+            acc_b = v4f{0.f, 0.f, 0.f, 0.f};
+        }
+        if (!more) break;
+        u = u_next;
+        b = b_next;
+    }
+    if (EPI == EPI_ARGMAX && tid == 0) {  // units ascend within a block: first index kept
+        a.part_val[blockIdx.x] = best_v;
+        a.part_idx[blockIdx.x] = best_i;
+    }
+}
+
+// Generic form: any n, any alignment (the reference's 3x3 / 2x12 known-answer
+// tests land here).  One pair per wave, scalar loads.
+template <int PRO, int EPI>
+__global__ __launch_bounds__(kBlock) void matvec_scalar_kernel(const MatvecArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const MvLocals m = mv_locals<EPI>(a);
+    float *xs = lds;
+    float *scratch = lds + ((m.n + 3) & ~3);
+    stage_x_scalar<PRO>(a.x, a.rms_w, m.n, xs, scratch);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int u = blockIdx.x * kWaves + wave; u < m.n_pairs; u += gridDim.x * kWaves) {
+        const float *pa, *pb;
+        pair_rows<EPI>(m, u, pa, pb);
+        float sa, sb;
+        dot2_scalar(pa, pb, xs, m.n, sa, sb);
+        pair_epilogue<EPI>(m, u, sa, sb, lane == 0, epi_prefetch<EPI>(m, u, lane == 0));
+    }
+}
+
+// lanes per pair for a row of n4 float4: the smallest power of two that puts a
+// whole row in one batch of 6 loads per lane, clamped to [8, 64].  A function of
+// n only (see the kernel header).
+int lpr_for(int n4)
+{
+    int l = 8;
+    while (l < 64 && l * 6 < n4) l <<= 1;
+    return l;
+}
+
+struct MvLaunch {
+    const void *fn;
+    int lpr, u;
+};
+
+template <int PRO, int EPI, int LPR, int XC>
+MvLaunch mv_entry()
+{
+    return {reinterpret_cast<const void *>(&matvec_kernel<PRO, EPI, LPR, XC>), LPR, MvGeom<LPR>::U};
+}
+
+template <int PRO, int EPI>
+MvLaunch mv_pick(int lpr, bool big_x)
+{
+    if (lpr == 8) return mv_entry<PRO, EPI, 8, 4>();
+    if (lpr == 16) return mv_entry<PRO, EPI, 16, 4>();
+    if (lpr == 32) return mv_entry<PRO, EPI, 32, 4>();
+    return big_x ? mv_entry<PRO, EPI, 64, 12>() : mv_entry<PRO, EPI, 64, 4>();
+}
+
+template <int PRO, int EPI>
+const void *mv_row_fn(bool big_x)
+{
+    return big_x ? reinterpret_cast<const void *>(&matvec_row_kernel<PRO, EPI, 12>)
+                 : reinterpret_cast<const void *>(&matvec_row_kernel<PRO, EPI, 4>);
+}
+
+const void *mv_row_pick(int pro, int epi, bool big_x)
+{
+#define L2Z_MVR(P, E) if (pro == P && epi == E) return mv_row_fn<P, E>(big_x);
+    L2Z_MVR(PRO_NONE, EPI_STORE)
+    L2Z_MVR(PRO_NONE, EPI_RESID)
+    L2Z_MVR(PRO_RMS, EPI_STORE)
+    L2Z_MVR(PRO_RMS, EPI_ROPE)
+    L2Z_MVR(PRO_RMS, EPI_SWIGLU)
+    L2Z_MVR(PRO_RMS, EPI_ARGMAX)
+#undef L2Z_MVR
+    return nullptr;
+}
+
+MvLaunch mv_pick_pe(int pro, int epi, int lpr, bool big_x, bool vec)
+{
+#define L2Z_MV(P, E)                                                                      \
+    if (pro == P && epi == E)                                                             \
+        return vec ? mv_pick<P, E>(lpr, big_x)                                            \
+                   : MvLaunch{reinterpret_cast<const void *>(&matvec_scalar_kernel<P, E>), 0, 0};
+    L2Z_MV(PRO_NONE, EPI_STORE)
+    L2Z_MV(PRO_NONE, EPI_RESID)
+    L2Z_MV(PRO_RMS, EPI_STORE)
+    L2Z_MV(PRO_RMS, EPI_ROPE)
+    L2Z_MV(PRO_RMS, EPI_SWIGLU)
+#undef L2Z_MV
+    if (pro == PRO_RMS && epi == EPI_ARGMAX && vec) return mv_pick<PRO_RMS, EPI_ARGMAX>(lpr, big_x);
+    return {nullptr, 0, 0};
+}
+
+// Pure streaming read (non-temporal float4 loads, 8 in flight per lane, sum kept out of DCE's
+// reach): the rate the memory system gives a kernel that does nothing else -- the measured
+// ceiling the mat-vec GB/s are quoted against beside the 8 TB/s spec (bench.py roofline).
+__global__ __launch_bounds__(256) void stream_read_kernel(const v4f *__restrict__ p, size_t n4, float *out)
+{
+    constexpr int U = 8;
+    size_t i = (size_t)blockIdx.x * 256 * U + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256 * U;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (; i + 256 * (U - 1) < n4; i += stride) {
+        v4f r[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) r[k] = ldg_nt(p + i + 256 * k);
+#pragma unroll
+        for (int k = 0; k < U; k++) acc += r[k];
+    }
+    const float s = (acc.x + acc.y) + (acc.z + acc.w);
+    if (s == 123.456f) out[blockIdx.x] = s;
+}
+
+}  // namespace
+
+// upper bound over every instantiation (n4 padded to whole batches of <= 384 float4)
+size_t matvec_lds_bytes(int n) { return (size_t)(4 * ((n >> 2) + 1024) + kScratch + 4 * kWaves + 4) * sizeof(float); }
+
+int matvec_max_grid(int n_cus) { return n_cus * 8; }
+
+// widths the vector kernels take (16-byte aligned operands assumed); the rest goes to the generic
+// scalar kernel, which has no fused-argmax epilogue
+bool matvec_vector_width(int n)
+{
+    if (n <= 0 || (n % 4) != 0) return false;
+    const int n4 = n >> 2;
+    return !(lpr_for(n4) == 64 && (n4 % 64) != 0);
+}
+
+hipError_t launch_stream_read(const float *p, size_t n_floats, float *out, int n_cus, hipStream_t st)
+{
+    hipLaunchKernelGGL(stream_read_kernel, dim3(n_cus * 8), dim3(256), 0, st, (const v4f *)p, n_floats / 4, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_matvec(const MatvecArgs &a_in, int pro, int epi, int max_blocks_per_cu, int n_cus,
+                         hipStream_t st, int *out_grid, bool *pushed)
+{
+    MatvecArgs a = a_in;
+    if (max_blocks_per_cu > 8) max_blocks_per_cu = 8;
+    bool vec = (a.n % 4) == 0 && aligned16(a.x) && aligned16(a.w0);
+    if (a.rows1 > 0) vec = vec && aligned16(a.w1);
+    if (a.rows2 > 0) vec = vec && aligned16(a.w2);
+    if (pro == PRO_RMS) vec = vec && aligned16(a.rms_w);
+    if (epi == EPI_SWIGLU && a.rows1 != a.rows0) return hipErrorInvalidValue;
+    const int total_rows = a.rows0 + a.rows1 + a.rows2;
+    const int n_pairs = (epi == EPI_SWIGLU) ? a.rows0 : (total_rows + 1) / 2;
+    if (n_pairs <= 0 || a.n <= 0) return hipErrorInvalidValue;
+    const int n4 = a.n >> 2;
+    const int lpr = lpr_for(n4);
+    if (lpr == 64 && (n4 % 64) != 0) vec = false;  // rare odd widths: generic scalar kernel
+    if (epi == EPI_ARGMAX && (!vec || a.rows1 != 0 || a.rows2 != 0)) return hipErrorNotSupported;
+    static const int row_mode = getenv("L2Z_ROW_KERNEL") ? atoi(getenv("L2Z_ROW_KERNEL")) : 1;
+    const bool use_row = vec && row_mode && n4 >= 1024 && (n4 % 64) == 0;
+    MvLaunch k = mv_pick_pe(pro, epi, lpr, a.n > 4096, vec);
+    if (use_row) k.fn = mv_row_pick(pro, epi, a.n > 4096);
+    if (k.fn == nullptr) return hipErrorInvalidValue;
+    size_t lds;
+    int n_units;
+    if (use_row) {
+        const int batch = kBlock * 4;
+        const int n4_pad = ((n4 + batch - 1) / batch) * batch;
+        lds = (size_t)(4 * n4_pad + kScratch + 4 * kWaves) * sizeof(float);
+        n_units = n_pairs;
+    } else if (vec) {
+        const int batch = k.lpr * k.u;
+        const int n4_pad = ((n4 + batch - 1) / batch) * batch;
+        lds = (size_t)(4 * n4_pad + kScratch) * sizeof(float);
+        const int rw = kWave / k.lpr;
+        n_units = (n_pairs + rw - 1) / rw;
+    } else {
+        lds = (size_t)(((a.n + 3) & ~3) + kScratch) * sizeof(float);
+        n_units = n_pairs;
+    }
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    // Grid: at most what is resident at once (so every wave's prologue is paid
+    // once), units dealt round-robin so every wave gets the same count +-1.
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k.fn, kBlock, lds) != hipSuccess || occ < 1)
+        occ = 1;
+    if (occ > max_blocks_per_cu) occ = max_blocks_per_cu;
+    // The row kernel streams best with few blocks per CU in lock step (fewer concurrent DRAM
+    // streams).  Measured at 7B, whole-token rate: 2 blocks/CU 219 tok/s, 1 -> 208, 3 -> 213,
+    // 4-8 -> 208-211 (single launches shift against each other under the power cap, so the
+    // choice is made on the whole-token rate).  L2Z_ROW_BLOCKS overrides.
+    static const int row_blocks = getenv("L2Z_ROW_BLOCKS") ? atoi(getenv("L2Z_ROW_BLOCKS")) : 2;
+    if (use_row && occ > row_blocks) occ = row_blocks;
+    const int resident = occ * n_cus;
+    int grid;
+    if (use_row) {  // a unit per block at a time
+        grid = n_units;
+        if (grid > resident) {
+            const int per_block = (n_units + resident - 1) / resident;
+            grid = (n_units + per_block - 1) / per_block;
+        }
+    } else {
+        const int blocks_needed = (n_units + kWaves - 1) / kWaves;
+        grid = blocks_needed;
+        if (grid > resident) {
+            const int per_wave = (n_units + resident * kWaves - 1) / (resident * kWaves);
+            grid = (n_units + per_wave * kWaves - 1) / (per_wave * kWaves);
+        }
+    }
+    if (out_grid) *out_grid = grid;
+    // only the row kernel's single-segment epilogues push (wo, ffn13, ffn2, classifier)
+    if (!use_row || epi == EPI_ROPE || a.rows2 != 0 || (epi != EPI_SWIGLU && a.rows1 != 0)) a.push = nullptr;
+    if (pushed) *pushed = a.push != nullptr;
+    void *args[] = {&a};
+    return hipLaunchKernel(k.fn, dim3(grid), dim3(kBlock), args, lds, st);
+}
+
+}  // namespace l2z

@@ -1,0 +1,190 @@
+// misc_kernels.hip -- argmax + loop hand-over, state set-up, the stand-alone kernels behind the
+// test hooks (rmsnorm, softmax, dot, weighted row sum) and the synthetic-checkpoint generator.
+#include "kernel_common.h"
+
+namespace l2z {
+namespace {
+
+// ---------------------------------------------------------------------------
+// argmax (main.zig:715-726) + the loop's hand-over (main.zig:999-1003, :1036)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void argmax_kernel(const ArgmaxArgs a)
+{
+    __shared__ float s_val[16];
+    __shared__ int s_idx[16];
+    __shared__ int s_next;
+    const int tid = threadIdx.x;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    if (a.part_val != nullptr) {  // per-block candidates left by the classifier launch
+        for (int i = tid; i < a.n_part; i += blockDim.x) {
+            const float v = a.part_val[i];
+            const int id = a.part_idx[i];
+            if (id != 0x7fffffff && (bi == 0x7fffffff || v > best || (v == best && id < bi))) {
+                best = v;
+                bi = id;
+            }
+        }
+    } else {
+        for (int i = tid; i < a.vocab; i += blockDim.x) {
+            const float v = a.logits[i];
+            if (v > best || bi == 0x7fffffff) {  // strict '>' keeps the lowest index (:720)
+                best = v;
+                bi = i;
+            }
+        }
+    }
+    // wave reduce: larger value wins, equal values -> lower index
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) {
+            best = ov;
+            bi = oi;
+        }
+    }
+    if ((tid & 63) == 0) {
+        s_val[tid >> 6] = best;
+        s_idx[tid >> 6] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int nw = blockDim.x >> 6;
+        for (int w = 1; w < nw; w++) {
+            if (s_idx[w] != 0x7fffffff &&
+                (bi == 0x7fffffff || s_val[w] > best || (s_val[w] == best && s_idx[w] < bi))) {
+                best = s_val[w];
+                bi = s_idx[w];
+            }
+        }
+        if (bi == 0x7fffffff) bi = 0;
+        if (a.argmax_out) *a.argmax_out = bi;
+        int next = bi;
+        if (a.advance) {
+            const int pos = *a.pos_ptr;
+            if (pos < *a.n_prompt_ptr) next = a.prompt[pos];  // :999-1000
+            a.out_tokens[pos] = next;
+            *a.token_ptr = next;                              // :1036
+            *a.pos_ptr = pos + 1;                             // :995
+        }
+        s_next = next;
+    }
+    __syncthreads();
+    if (a.advance) {
+        // next step's embedding row -> x (main.zig:295-296), saves a launch
+        const float *row = a.tok_emb + (size_t)s_next * (size_t)a.dim;
+        for (int i = tid; i < a.dim; i += blockDim.x) a.x[i] = row[i];
+    }
+}
+
+// token/pos from the host + embedding copy (main.zig:295-296)
+__global__ void set_state_kernel(int token, int pos, int *token_ptr, int *pos_ptr,
+                                 const float *tok_emb, float *x, int dim)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *token_ptr = token;
+        *pos_ptr = pos;
+    }
+    const float *row = tok_emb + (size_t)token * (size_t)dim;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < dim; i += gridDim.x * blockDim.x)
+        x[i] = row[i];
+}
+
+// ---------------------------------------------------------------------------
+// Stand-alone wrappers for the test hooks: same device functions as above.
+// ---------------------------------------------------------------------------
+// VEC: the vector staging path the fused mat-vec uses (XC = 4, zero padded)
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void rmsnorm_kernel(float *o, const float *x, const float *w,
+                                                         int n)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (VEC) {
+        const int n4 = n >> 2, n4_pad = (n4 + 255) & ~255;
+        float *xs = lds, *scratch = lds + 4 * n4_pad;
+        v4f xr[4], gr[4];
+        xload_issue<PRO_RMS, 4>(x, w, n4, xr, gr);
+        xstage_finish<PRO_RMS, 4>(x, w, n, n4_pad, xr, gr, xs, scratch);
+        for (int j = threadIdx.x; j < n; j += blockDim.x) o[j] = xs[j];
+    } else {
+        float *xs = lds, *scratch = lds + ((n + 3) & ~3);
+        stage_x_scalar<PRO_RMS>(x, w, n, xs, scratch);
+        for (int j = threadIdx.x; j < n; j += blockDim.x) o[j] = xs[j];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void softmax_kernel(float *x, int n)
+{
+    __shared__ float scratch[kScratch];
+    block_softmax(x, n, scratch);
+}
+
+// Seeded synthetic weights: value(idx) = bias + scale*r(idx,seed); must match
+// oracle/llama2_oracle.c orc_synth_value and checkpoint.py synth_values bit for bit.
+__global__ void synth_fill_kernel(float *dst, uint64_t base_idx, uint64_t count, uint64_t seed,
+                                  float scale, float bias)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        uint64_t z = (base_idx + i) + seed * 0x9E3779B97F4A7C15ULL;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        z = z ^ (z >> 31);
+        const uint32_t u = (uint32_t)(z >> 41);
+        const float r = __fsub_rn(__fmul_rn((float)u, 0x1p-22f), 1.0f);
+        dst[i] = __fadd_rn(bias, __fmul_rn(scale, r));
+    }
+}
+
+}  // namespace
+
+hipError_t launch_argmax(const ArgmaxArgs &a, hipStream_t st)
+{
+    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_set_state(int token, int pos, int *token_ptr, int *pos_ptr, const float *tok_emb,
+                            float *x, int dim, hipStream_t st)
+{
+    const int grid = (dim + 255) / 256 > 64 ? 64 : (dim + 255) / 256;
+    hipLaunchKernelGGL(set_state_kernel, dim3(grid), dim3(256), 0, st, token, pos, token_ptr,
+                       pos_ptr, tok_emb, x, dim);
+    return hipGetLastError();
+}
+
+hipError_t launch_rmsnorm(float *o, const float *x, const float *w, int n, hipStream_t st)
+{
+    const bool vec = (n % 4) == 0 && aligned16(x) && aligned16(w);
+    const size_t lds = matvec_lds_bytes(n);
+    if (vec) {
+        hipError_t e = ensure_lds(rmsnorm_kernel<true>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((rmsnorm_kernel<true>), dim3(1), dim3(kBlock), lds, st, o, x, w, n);
+    } else {
+        hipError_t e = ensure_lds(rmsnorm_kernel<false>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((rmsnorm_kernel<false>), dim3(1), dim3(kBlock), lds, st, o, x, w, n);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_softmax(float *x, int n, hipStream_t st)
+{
+    hipLaunchKernelGGL(softmax_kernel, dim3(1), dim3(kBlock), 0, st, x, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth_fill(float *dst, uint64_t base_idx, uint64_t count, uint64_t seed,
+                             float scale, float bias, hipStream_t st)
+{
+    if (count == 0) return hipSuccess;
+    uint64_t blocks = (count + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(synth_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dst, base_idx,
+                       count, seed, scale, bias);
+    return hipGetLastError();
+}
+
+}  // namespace l2z
