@@ -185,6 +185,7 @@ def main() -> None:
         # a peer that never shows up must fail the peer-write attempt quickly, so that the RCCL
         # fallback still fits the run (ranks are within a second of each other after the handshake)
         os.environ.setdefault("L2Z_P2P_TIMEOUT_S", "8")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (the only kind the host driver has)
         import torch
         import torch.distributed as dist
         # control plane only (barrier, handle/id exchange, max-reduce of the clock): gloo on CPU.
@@ -193,7 +194,12 @@ def main() -> None:
 
     if B.device_count() < 1:
         raise SystemExit("bench.py: no HIP device visible (the HIP path has no CPU fallback)")
-    device = local_rank % B.device_count()  # several ranks on one GPU only happens in tests
+    n_dev = B.device_count()
+    device = local_rank % n_dev  # several ranks on one GPU only happens in tests
+    if world > n_dev:
+        # ranks share a chip: a mat-vec launch that may be polling for a peer's words must leave the
+        # peer's kernels room to run (never needed with a GPU per rank)
+        B.option_set("L2Z_GRID_CAP", max(32, 512 // ((world + n_dev - 1) // n_dev)))
 
     def all_ok(ok: bool) -> bool:
         flags = [None] * world
@@ -223,9 +229,23 @@ def main() -> None:
             if c is not None:
                 c.close()
             return None
-        uid = [B.Comm.unique_id() if rank == 0 else None]
+        c = None
+        try:
+            uid = [B.Comm.unique_id() if rank == 0 else None]
+        except Exception as e:  # noqa: BLE001
+            print(f"[rank {rank}] ncclGetUniqueId failed: {e}", file=sys.stderr)
+            uid = [None]
         dist.broadcast_object_list(uid, src=0)
-        return B.Comm(rank, world, uid[0], device)
+        if uid[0] is not None:
+            try:
+                c = B.Comm(rank, world, uid[0], device)
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank {rank}] RCCL communicator failed: {e}", file=sys.stderr)
+        if all_ok(c is not None):
+            return c
+        if c is not None:
+            c.close()
+        return None
 
     def ranks_agree(s) -> bool:
         """Every rank must hold the same logits after the same steps (bit for bit)."""
@@ -236,13 +256,27 @@ def main() -> None:
         return all(x == sigs[0] for x in sigs) and bool(np.isfinite(lg).all())
 
     agree = None
+    attempts = []
     if dist is not None:
-        want = os.environ.get("L2Z_COMM", "p2p")
-        for kind in ([want] if want == "rccl" or force_dist else ["p2p", "rccl"]):
-            comm = make_comm("rccl" if force_dist else kind)
+        # Transports for the per-layer gathers, best first.  A form that cannot be set
+        # up, times out, or leaves the ranks with different logits is dropped for the next one.
+        #   p2p-consume  producers store LL words into every rank's landing slot, consumers poll
+        #                them while staging x: 5 graph nodes per layer, one gather launch per token
+        #   p2p-gather   the same stores, collected by a gather launch per vector (9 nodes per layer)
+        #   rccl         ncclAllGather per vector, captured into the step graph when that works
+        want = os.environ.get("L2Z_COMM", "")
+        order = {"": ["p2p-consume", "p2p-gather", "rccl"], "p2p": ["p2p-consume", "p2p-gather", "rccl"],
+                 "p2p-consume": ["p2p-consume"], "p2p-gather": ["p2p-gather"], "rccl": ["rccl"]}[want]
+        if force_dist:
+            order = ["rccl"]
+        for kind in order:
+            B.option_set("L2Z_P2P_CONSUME", 1 if kind == "p2p-consume" else 0)
+            B.option_set("L2Z_COMM_RCCL", 1 if kind == "rccl" else 0)
+            comm = make_comm("rccl" if kind == "rccl" else "p2p")
             if comm is None:
+                attempts.append({"transport": kind, "ok": False, "why": "set-up failed"})
                 continue
-            transport = "rccl" if force_dist else kind
+            transport = kind
             s = w = None
             try:
                 n_tok, dt, s, w = run_once(B, cfg, shared, args.seed, steps, args.warmup, comm, all_ok)
@@ -251,18 +285,18 @@ def main() -> None:
                 print(f"[rank {rank}] run with transport {transport} failed: {e}", file=sys.stderr)
                 ran = False
             agree = ranks_agree(s) if all_ok(ran) else False
-            if agree or transport == "rccl":
-                if not agree and not ran:
-                    raise SystemExit("bench.py: the sharded run failed with RCCL as well")
+            attempts.append({"transport": kind, "ok": bool(agree), "why": None if agree else
+                             ("ranks disagree" if ran else "run failed")})
+            if agree:
                 break
-            print(f"[rank {rank}] transport {transport} unusable here (ran={ran}); retrying with RCCL",
+            print(f"[rank {rank}] transport {transport} unusable here (ran={ran}); trying the next one",
                   file=sys.stderr)
             for o in (s, w, comm):
                 if o is not None:
                     o.close()
             comm = None
         if comm is None:
-            raise SystemExit("bench.py: no working transport for the shard group")
+            raise SystemExit(f"bench.py: no working transport for the shard group: {attempts}")
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -343,13 +377,33 @@ def main() -> None:
                                f"H {cfg.n_heads}, kv {cfg.n_kv_heads}, V {cfg.vocab_size}, "
                                f"S {cfg.seq_len}), greedy from BOS, seeded synthetic weights",
                    "parallelism": (f"rows/heads sharded x{args.gpus}, all-gathers by "
-                                   + ("peer writes over IPC-mapped memory (xGMI)" if transport == "p2p"
-                                      else "RCCL")) if transport else "1 GPU",
+                                   + {"p2p-consume": "peer writes of LL words over IPC-mapped memory (xGMI), "
+                                                     "polled by the consuming mat-vec (no gather launch)",
+                                      "p2p-gather": "peer writes over IPC-mapped memory (xGMI) + a gather "
+                                                    "launch per vector",
+                                      "rccl": "RCCL ncclAllGather"}[transport]) if transport else "1 GPU",
                    "ranks_agree": agree,
                    "weight_bytes_per_token": sum(
                        wb[k] * (1 if k == "cls" else cfg.n_layers) for k in wb) * world},
         "roofline": roofline,
     }
+    if transport:
+        n_g = 4 * cfg.n_layers + 1
+        launches = by_kind["gather"][1] // n_prof
+        ideal_ms = (sum(wb[k] * (1 if k == "cls" else cfg.n_layers) for k in wb) / (rd_avg * 1e9) * 1e3
+                    if rd_avg else None)
+        out["comm"] = {
+            "transport": transport, "attempts": attempts, "gathers_per_token": n_g,
+            "gather_launches_per_token": launches,
+            "us_per_gather_launch": (by_kind["gather"][0] / max(by_kind["gather"][1], 1) * 1e3) if launches else None,
+            "graph_nodes_per_layer": 5 + (4 if launches > 1 else 0),
+            # this rank's weight bytes at the streaming-read rate measured on this box: what a step
+            # would take with free gathers; the rest of ms_per_step is gather + launch overhead
+            "ideal_ms_per_step_at_measured_stream_rate": ideal_ms,
+            "overhead_ms_per_step": (dt / n_tok * 1e3 - ideal_ms) if ideal_ms else None,
+            "note": "kernel times in roofline.by_kind include the consumer-side polling of the gathered "
+                    "input (p2p-consume) -- compare with the N=1 line",
+        }
     if rank == 0 and args.gpus == 1:
         if not args.no_extra and args.workload != "stories15M":
             c15, sh15 = shapes["stories15M"]

@@ -18,11 +18,8 @@
  *   argmax(state.logits)         :715,:1003  l2z_argmax            (on device)
  *   state.logits after return    :1005-1012  l2z_logits_read       (D2H, for samplers)
  *   while (pos < seq_len) loop at -t 0 :995  l2z_greedy_begin / l2z_greedy_run
- *   matmul / matmul_fused        :485,:530   l2z_matmul / l2z_matmul_fused   (test hooks)
- *   rmsnorm                      :432        l2z_rmsnorm                     (test hook)
- *   softmax                      :687        l2z_softmax                     (test hook)
- *   vector_dot_product           :503        l2z_vector_dot_product          (test hook)
- *   vector_weighted_sum_rows     :657        l2z_vector_weighted_sum_rows    (test hook)
+ *   matmul, rmsnorm, softmax, ... :432-726   kernel-level hooks of the same names, for tests only:
+ *                                            include/llama2_hip_test.h
  *
  * Ownership: the caller owns config; weights and runstate handles own their
  * device memory.  The host blob passed to l2z_weights_init may be freed (or
@@ -47,7 +44,7 @@
 extern "C" {
 #endif
 
-#define L2Z_ABI_VERSION 1
+#define L2Z_ABI_VERSION 2
 
 typedef enum l2z_status {
     L2Z_OK = 0,
@@ -91,14 +88,6 @@ int l2z_device_info(int dev, char *name, size_t cap, int *out_cus, uint64_t *out
  * every matrix are uploaded (heads / output rows, DESIGN.md "Sharding"). */
 int l2z_weights_init(const l2z_config *config, const float *data, size_t n_floats,
                      int shared_weights, const l2z_comm *comm, l2z_weights **out);
-/* Same layout, filled ON DEVICE by the seeded generator of DESIGN.md
- * "Synthetic checkpoints" (no checkpoint exists in the build image, and a 27 GB
- * PCIe upload is not part of the measured path). */
-int l2z_weights_init_synthetic(const l2z_config *config, int shared_weights, uint64_t seed,
-                               const l2z_comm *comm, l2z_weights **out);
-/* Copy `count` floats starting at blob index `offset` back to the host
- * (single-GPU weights only; used by tests to check uploads / the generator). */
-int l2z_weights_read(const l2z_weights *w, size_t offset, size_t count, float *out);
 void l2z_weights_free(l2z_weights *w);
 
 /* ---- RunState: src/main.zig:137 RunState.init / :156 deinit ----
@@ -118,10 +107,6 @@ int l2z_transformer(int token, int pos, const l2z_config *config, l2z_runstate *
 int l2z_argmax(l2z_runstate *s, int *out_token);
 /* copy s.logits (vocab_size floats) to the host */
 int l2z_logits_read(l2z_runstate *s, float *out_logits);
-/* copy a named RunState buffer to the host: "x","xb","hb","q","att","logits",
- * "key_cache","value_cache" (tests only) */
-int l2z_runstate_read(l2z_runstate *s, const char *name, size_t offset, size_t count, float *out);
-
 /* ---- src/main.zig:987-1042, the generation loop at temperature 0 ----
  * Runs entirely on the device: the forward pass, argmax, the prompt override
  * (main.zig:999-1000) and the token/pos hand-over to the next step are one
@@ -151,39 +136,8 @@ int l2z_greedy_run(const l2z_config *config, l2z_runstate *s, const l2z_weights 
 int l2z_prefill(const int32_t *tokens, int n_tokens, int pos0, const l2z_config *config,
                 l2z_runstate *s, const l2z_weights *w);
 
-/* ---- measurement support ----
- * l2z_stream_read_probe streams `slice_bytes` pieces of the resident weight blob (0 = all of it)
- * through a pure read kernel `reps` times, a different piece per launch, and returns the average
- * and best read rate in GB/s: the measured ceiling bench.py quotes beside the 8 TB/s HBM3E spec
- * (SURVEY.md 8d "also report against a measured ... on the same box").
- * l2z_profile_forward runs ONE forward pass (+ argmax/hand-over) eagerly with
- * a HIP event pair around every kernel launch, recorded on the runstate's own
- * stream, and returns per-kind total device time (ms) and launch count.
- * Kinds, in slot order (l2z_kind_name): 0 "qkv", 1 "attn", 2 "wo", 3 "ffn13",
- * 4 "ffn2", 5 "cls", 6 "argmax"; n_kinds must be >= 7.  bench.py derives the
- * roofline of the dominant kernel from this, in situ: every layer streams
- * its own weights, so nothing is re-read from cache between launches.  The
- * numbers must agree with rocprofv3 --kernel-trace --stats (profiles/). */
-#define L2Z_N_KINDS 7
-int l2z_stream_read_probe(l2z_runstate *s, const l2z_weights *w, size_t slice_bytes, int reps,
-                          double *avg_gbps, double *best_gbps);
-int l2z_profile_forward(int token, int pos, const l2z_config *config, l2z_runstate *s,
-                        const l2z_weights *w, double *ms_by_kind, int *launches_by_kind,
-                        int n_kinds);
-int l2z_kind_name(int kind, char *out, size_t cap);
+/* wait for everything queued on the runstate's stream */
 int l2z_synchronize(l2z_runstate *s);
-
-/* ---- kernel-level test hooks (host pointers in and out; same device code
- *      the forward pass runs).  Names follow src/main.zig. ---- */
-int l2z_matmul(float *xout, const float *x, const float *w, size_t n, size_t d);      /* :485 */
-int l2z_matmul_fused(int N, float *const *outs, const float *x, const float *const *ws, size_t n,
-                     size_t d);                                                        /* :530 */
-int l2z_rmsnorm(float *o, const float *x, const float *w, size_t n);                   /* :432 */
-int l2z_softmax(float *x, size_t n);                                                   /* :687 */
-int l2z_vector_dot_product(float *out, const float *x, const float *y, size_t n);      /* :503 */
-int l2z_vector_weighted_sum_rows(float *xout, size_t xout_len, const float *rows, size_t rows_len,
-                                 size_t row_stride, const float *weights, size_t n_weights); /* :657 */
-int l2z_argmax_host(const float *x, size_t n, size_t *out_index);                      /* :715 */
 
 /* ---- multi-GPU shard group: one process per GPU, xGMI ----
  * The reference is single-threaded and single-device; this is what the build
@@ -195,6 +149,8 @@ int l2z_argmax_host(const float *x, size_t n, size_t *out_index);               
  *    handles in rank order, and l2z_comm_p2p_connect maps the peers.  A gather is then one small
  *    kernel of direct 8-byte {value, epoch} stores into the peers' memory, polled by the receiver --
  *    no fences, no collective library, and it can be captured in the step graph.  Preferred when both are set up (L2Z_COMM=rccl overrides).
+ *    max_vector_floats must be >= max(dim, hidden_dim, vocab_size) of every config used with the
+ *    group: l2z_runstate_init refuses (L2Z_ERR_COMM) a config the landing slots cannot hold.
  */
 #define L2Z_COMM_ID_BYTES 128
 int l2z_comm_unique_id(void *out_id);
@@ -205,14 +161,6 @@ int l2z_comm_p2p_export(l2z_comm *c, size_t max_vector_floats, void *handle_out)
 int l2z_comm_p2p_connect(l2z_comm *c, const void *handles /* world x L2Z_COMM_IPC_BYTES */);
 int l2z_comm_rank(const l2z_comm *c, int *rank, int *world);
 void l2z_comm_free(l2z_comm *c);
-/* Testing support: N emulated ranks in ONE process on ONE GPU (RCCL refuses two ranks on
- * one device).  l2z_comm_init_emulated makes a rank descriptor without a communicator;
- * weights / runstates built with it hold exactly rank r's shard; l2z_emu_transformer runs
- * one forward pass for all ranks, interleaved stage by stage, doing each all-gather as
- * device-to-device copies.  Afterwards every rank's logits must equal the unsharded pass. */
-int l2z_comm_init_emulated(int rank, int world, int device, l2z_comm **out);
-int l2z_emu_transformer(int n_ranks, l2z_runstate *const *ss, const l2z_weights *const *ws,
-                        int token, int pos);
 /* Pure host logic, no GPU needed: the row range [*r0,*r1) of a `rows`-row
  * tensor owned by `rank` of `world`, in units of `granule` rows (head_size for
  * q/k/v so shards are whole heads, 1 otherwise).  Fails if not divisible. */

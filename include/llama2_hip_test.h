@@ -1,0 +1,99 @@
+/*
+ * llama2_hip_test.h -- entry points of libllama2_hip.so that exist for TESTS and MEASUREMENT only.
+ *
+ * Nothing here is part of the drop-in boundary (include/llama2_hip.h): a host that replaces
+ * src/main.zig's transformer() never calls these.  tests/, bench.py and scripts/ do:
+ *   - kernel-level hooks named after the reference's math functions (src/main.zig:432-726), so the
+ *     reference's own unit-test vectors (main.zig:1078-1150) can be run against the device code;
+ *   - l2z_attention_decode: the decode attention kernels the forward pass launches, driven directly;
+ *   - read-back of device state, the seeded synthetic-checkpoint generator, emulated ranks;
+ *   - per-kernel timing and the streaming-read probe behind bench.py's roofline;
+ *   - l2z_option_set: the tuning knobs of csrc/tunables.h from inside a process.
+ */
+#ifndef LLAMA2_HIP_TEST_H
+#define LLAMA2_HIP_TEST_H
+
+#include "llama2_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- synthetic checkpoints / state read-back ---- */
+/* Same layout, filled ON DEVICE by the seeded generator of DESIGN.md
+ * "Synthetic checkpoints" (no checkpoint exists in the build image, and a 27 GB
+ * PCIe upload is not part of the measured path). */
+int l2z_weights_init_synthetic(const l2z_config *config, int shared_weights, uint64_t seed,
+                               const l2z_comm *comm, l2z_weights **out);
+/* Copy `count` floats starting at blob index `offset` back to the host
+ * (single-GPU weights only; used by tests to check uploads / the generator). */
+int l2z_weights_read(const l2z_weights *w, size_t offset, size_t count, float *out);
+
+/* copy a named RunState buffer to the host: "x","xb","hb","q","att","logits",
+ * "key_cache","value_cache" (tests only) */
+int l2z_runstate_read(l2z_runstate *s, const char *name, size_t offset, size_t count, float *out);
+
+
+/* ---- measurement support ----
+ * l2z_stream_read_probe streams `slice_bytes` pieces of the resident weight blob (0 = all of it)
+ * through a pure read kernel `reps` times, a different piece per launch, and returns the average
+ * and best read rate in GB/s: the measured ceiling bench.py quotes beside the 8 TB/s HBM3E spec
+ * (SURVEY.md 8d "also report against a measured ... on the same box").
+ * l2z_profile_forward runs ONE forward pass (+ argmax/hand-over) eagerly with
+ * a HIP event pair around every kernel launch, recorded on the runstate's own
+ * stream, and returns per-kind total device time (ms) and launch count.
+ * Kinds, in slot order (l2z_kind_name): 0 "qkv", 1 "attn", 2 "wo", 3 "ffn13",
+ * 4 "ffn2", 5 "cls", 6 "argmax" (0 launches when the classifier's last block hands the loop over
+ * itself), 7 "gather" (sharded runs: gather launches); n_kinds must be >= 8.  bench.py derives the
+ * roofline of the dominant kernel from this, in situ: every layer streams
+ * its own weights, so nothing is re-read from cache between launches.  The
+ * numbers must agree with rocprofv3 --kernel-trace --stats (profiles/). */
+#define L2Z_N_KINDS 8
+int l2z_stream_read_probe(l2z_runstate *s, const l2z_weights *w, size_t slice_bytes, int reps,
+                          double *avg_gbps, double *best_gbps);
+int l2z_profile_forward(int token, int pos, const l2z_config *config, l2z_runstate *s,
+                        const l2z_weights *w, double *ms_by_kind, int *launches_by_kind,
+                        int n_kinds);
+int l2z_kind_name(int kind, char *out, size_t cap);
+
+/* ---- kernel-level test hooks (host pointers in and out; same device code
+ *      the forward pass runs).  Names follow src/main.zig. ---- */
+int l2z_matmul(float *xout, const float *x, const float *w, size_t n, size_t d);      /* :485 */
+int l2z_matmul_fused(int N, float *const *outs, const float *x, const float *const *ws, size_t n,
+                     size_t d);                                                        /* :530 */
+int l2z_rmsnorm(float *o, const float *x, const float *w, size_t n);                   /* :432 */
+int l2z_softmax(float *x, size_t n);                                                   /* :687 */
+int l2z_vector_dot_product(float *out, const float *x, const float *y, size_t n);      /* :503 */
+int l2z_vector_weighted_sum_rows(float *xout, size_t xout_len, const float *rows, size_t rows_len,
+                                 size_t row_stride, const float *weights, size_t n_weights); /* :657 */
+int l2z_argmax_host(const float *x, size_t n, size_t *out_index);                      /* :715 */
+
+/* The decode attention of ONE layer (src/main.zig:361-389: scores :367-375, softmax :378 / :687-706,
+ * weighted sum of V rows :381-388 / :657-685) through the kernels the forward pass launches.
+ *   q [n_heads*head_size]; kcache, vcache [seq_len * kv_dim] (rows 0..pos are read);
+ *   out [n_heads*head_size].   form: 0 = what the forward pass would pick at `pos`,
+ *   1 = one block per head, 256 threads (speculative first round: seq_len <= 512 models),
+ *   2 = one block per head, 1024 threads, 3 = split over `nch` blocks per head + combine
+ *   (nch 0: the runstate default for n_heads), 4 = generic kernel. */
+int l2z_attention_decode(int form, int nch, float *out, const float *q, const float *kcache,
+                         const float *vcache, int pos, int n_heads, int n_kv_heads, int head_size,
+                         int seq_len);
+
+/* ---- emulated ranks ---- */
+/* Testing support: N emulated ranks in ONE process on ONE GPU (RCCL refuses two ranks on
+ * one device).  l2z_comm_init_emulated makes a rank descriptor without a communicator;
+ * weights / runstates built with it hold exactly rank r's shard; l2z_emu_transformer runs
+ * one forward pass for all ranks, interleaved stage by stage, doing each all-gather as
+ * device-to-device copies.  Afterwards every rank's logits must equal the unsharded pass. */
+int l2z_comm_init_emulated(int rank, int world, int device, l2z_comm **out);
+int l2z_emu_transformer(int n_ranks, l2z_runstate *const *ss, const l2z_weights *const *ws,
+                        int token, int pos);
+
+/* Set one tuning knob by its environment-variable name (csrc/tunables.h), e.g. ("L2Z_P2P_CONSUME", 0).
+ * Applies to objects created afterwards.  L2Z_ERR_INVALID for an unknown name. */
+int l2z_option_set(const char *env_name, long long value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LLAMA2_HIP_TEST_H */

@@ -16,11 +16,12 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("L2Z_LIB") or os.path.join(_HERE, "libllama2_hip.so")  # L2Z_LIB: A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "llama2_hip.h")
+TEST_HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "llama2_hip_test.h")
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_COMM, ERR_STATE = 0, -1, -2, -3, -4, -5, -6
 COMM_ID_BYTES = 128
 COMM_IPC_BYTES = 64
-KINDS = ["qkv", "attn", "wo", "ffn13", "ffn2", "cls", "argmax"]
+KINDS = ["qkv", "attn", "wo", "ffn13", "ffn2", "cls", "argmax", "gather"]
 
 
 class L2ZError(RuntimeError):
@@ -36,11 +37,17 @@ class L2ZConfig(C.Structure):
                 ("dim", "hidden_dim", "n_layers", "n_heads", "n_kv_heads", "vocab_size", "seq_len")]
 
 
-def declared_symbols() -> list[str]:
-    """Every function include/llama2_hip.h declares (for the export check)."""
-    txt = open(HEADER_PATH).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(l2z_[a-z0-9_]+)\s*\(", txt)))
+def declared_symbols(which: str = "all") -> list[str]:
+    """Every function the headers declare (for the export check): the drop-in boundary
+    include/llama2_hip.h ("product"), the test / measurement entry points of
+    include/llama2_hip_test.h ("test"), or both."""
+    paths = {"product": [HEADER_PATH], "test": [TEST_HEADER_PATH],
+             "all": [HEADER_PATH, TEST_HEADER_PATH]}[which]
+    out = set()
+    for path in paths:
+        txt = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+        out |= set(re.findall(r"\b(l2z_[a-z0-9_]+)\s*\(", txt))
+    return sorted(out)
 
 
 _lib = None
@@ -89,6 +96,8 @@ def lib():
     L.l2z_vector_dot_product.argtypes = [fp, fp, fp, sz]
     L.l2z_vector_weighted_sum_rows.argtypes = [fp, sz, fp, sz, sz, fp, sz]
     L.l2z_argmax_host.argtypes = [fp, sz, C.POINTER(sz)]
+    L.l2z_attention_decode.argtypes = [C.c_int, C.c_int, fp, fp, fp, fp] + [C.c_int] * 5
+    L.l2z_option_set.argtypes = [C.c_char_p, C.c_longlong]
     L.l2z_comm_unique_id.argtypes = [vp]
     L.l2z_comm_init.argtypes = [C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp)]
     L.l2z_comm_p2p_export.argtypes = [vp, sz, vp]
@@ -342,6 +351,25 @@ def vector_weighted_sum_rows(xout_len: int, rows, row_stride: int, weights) -> n
     _chk(lib().l2z_vector_weighted_sum_rows(_fp(o), xout_len, _fp(rows), rows.size, row_stride,
                                             _fp(weights), weights.size))
     return o
+
+
+ATTN_FORMS = {"auto": 0, "fast256": 1, "fast1024": 2, "split": 3, "generic": 4}
+
+
+def attention_decode(q, kcache, vcache, pos: int, n_heads: int, n_kv_heads: int, head_size: int,
+                     seq_len: int, form: str = "auto", nch: int = 0) -> np.ndarray:
+    """One layer's decode attention (src/main.zig:361-389) through the forward pass's kernels."""
+    q, kcache, vcache = _f32(q), _f32(kcache), _f32(vcache)
+    assert q.size == n_heads * head_size and kcache.size == seq_len * n_kv_heads * head_size
+    out = np.empty(n_heads * head_size, np.float32)
+    _chk(lib().l2z_attention_decode(ATTN_FORMS[form], nch, _fp(out), _fp(q), _fp(kcache), _fp(vcache),
+                                    pos, n_heads, n_kv_heads, head_size, seq_len))
+    return out
+
+
+def option_set(name: str, value: int) -> None:
+    """A tuning knob of csrc/tunables.h by its environment name; applies to objects created afterwards."""
+    _chk(lib().l2z_option_set(name.encode(), int(value)))
 
 
 def argmax(x) -> int:

@@ -163,7 +163,8 @@ __device__ __forceinline__ void wave_softmax(const float *att, float *prob, int 
 // share one output: lane r adds partials r, r+R, ... (increasing), then a DPP sum over the R
 // lanes.  R depends only on (G, hs, blockDim) -- fixed per model.
 __device__ __forceinline__ void reduce_partials(const float *part, int G, int hs, float *out,
-                                                const P2pArgs *push = nullptr, size_t push_idx0 = 0)
+                                                const P2pArgs *push = nullptr, int push_e = 0,
+                                                size_t push_idx0 = 0)
 {
     int R = 1;
     while (R * 2 <= G && R * 2 * hs <= (int)blockDim.x && R < 16) R <<= 1;
@@ -174,8 +175,21 @@ __device__ __forceinline__ void reduce_partials(const float *part, int G, int hs
     s = lanes_sum(s, R);
     if (i < hs && r == 0) {
         out[i] = s;
-        if (push) p2p_ll_push(push, p2p_ll_epoch(push), push_idx0 + (size_t)i, s);
+        if (push) p2p_ll_push(push, push_e, push_idx0 + (size_t)i, s);
     }
+}
+
+// the same sum, stored write-through (one agent-scope store per value): a hand-off to another block
+__device__ __forceinline__ void reduce_partials_wt(const float *part, int G, int hs, float *out)
+{
+    int R = 1;
+    while (R * 2 <= G && R * 2 * hs <= (int)blockDim.x && R < 16) R <<= 1;
+    const int i = threadIdx.x / R, r = threadIdx.x % R;
+    float s = 0.0f;
+    if (i < hs)
+        for (int gg = r; gg < G; gg += R) s += part[(size_t)gg * hs + i];
+    s = lanes_sum(s, R);
+    if (i < hs && r == 0) __hip_atomic_store(out + i, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Fast path (head_size % 4 == 0, head_size <= 256).  The first kFastUB timesteps of
@@ -196,10 +210,42 @@ __device__ long long g_dbg_ts[16];
 #else
 #define L2Z_TS(i) do { } while (0)
 #endif
+// Blocks past the heads (short contexts on a big chip: 32 heads occupy 32 of 256 CUs for a
+// latency chain that moves almost no bytes) pull the weights of the NEXT launch -- this layer's
+// wo rows -- through the cache hierarchy with plain loads, so that launch finds them in the
+// on-die Infinity Cache instead of HBM.  Values are discarded; nothing depends on it.
+template <int NT>
+__device__ __forceinline__ void prefetch_block(const AttnArgs &a, int b)
+{
+    const v4f *p = (const v4f *)a.pf_ptr;
+    const size_t n4 = a.pf_floats >> 2;
+    const size_t per = (n4 + a.pf_blocks - 1) / a.pf_blocks;
+    const size_t lo = per * (size_t)b;
+    size_t hi = lo + per;
+    if (hi > n4) hi = n4;
+    constexpr int U = 8;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    size_t i = lo + threadIdx.x;
+    for (; i + (size_t)NT * (U - 1) < hi; i += (size_t)NT * U) {
+        v4f r[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) r[k] = p[i + (size_t)NT * k];
+#pragma unroll
+        for (int k = 0; k < U; k++) acc += r[k];
+    }
+    for (; i < hi; i += NT) acc += p[i];
+    const float sum = (acc.x + acc.y) + (acc.z + acc.w);
+    if (sum == 123.456f) a.pf_sink[b] = sum;  // keeps the loads alive; never true in practice
+}
+
 template <int NT, bool SPEC>
 __global__ __launch_bounds__(NT) void attention_fast_kernel(const AttnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if ((int)blockIdx.x >= a.n_head_blocks) {
+        prefetch_block<NT>(a, (int)blockIdx.x - a.n_head_blocks);
+        return;
+    }
     const int hs = a.head_size;
     const AttnGeom ge = attn_geom(hs, true, NT);
     float *att = lds;                                  // seq_len raw scores
@@ -287,6 +333,7 @@ __global__ __launch_bounds__(NT) void attention_fast_kernel(const AttnArgs a)
     L2Z_TS(6);
     // sharded: a.xb already points at this rank's slice, head h of it starts at h * hs
     reduce_partials(part, ge.G, hs, a.xb + (size_t)h * hs, a.push,
+                    a.push ? a.push_ctl[kCtlEpoch] + a.push_gi : 0,
                     a.push ? (size_t)a.push->rank * a.push->count + (size_t)h * hs : 0);
     L2Z_TS(7);
 }
@@ -297,116 +344,17 @@ __global__ __launch_bounds__(NT) void attention_fast_kernel(const AttnArgs a)
 // time waiting for its own K/V rows (measured with s_memtime: 6 of 10 us).  Here head h is
 // shared by `nch` blocks; block (h, c) owns timesteps t = c, c+nch, c+2*nch, ... and writes
 //     m_c = max score,  l_c = sum exp(score - m_c),  o_c[i] = sum exp(score - m_c) * V[t][i]
-// attention_combine_kernel then forms  out[i] = (sum_c o_c[i] e^(m_c-M)) / (sum_c l_c e^(m_c-M)),
+// the combine then forms  out[i] = (sum_c o_c[i] e^(m_c-M)) / (sum_c l_c e^(m_c-M)),
 // M = max_c m_c.  Mathematically main.zig:361-389; in floating point the weights are
 // e^(s-m_c) * e^(m_c-M) / L instead of e^(s-M) / L (a few ulp), well inside the logit
 // tolerance, and independent of GPU count (attention is head-local).
 // part layout: [head][chunk][head_size + 4] floats = o_c[head_size], m_c, l_c, pad, pad
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void attention_split_kernel(const AttnArgs a, int nch,
-                                                                 float *__restrict__ part_out)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int hs = a.head_size;
-    const AttnGeom ge = attn_geom(hs, true, kBlock);
-    const int max_local = (a.seq_len + nch - 1) / nch;
-    float *sc = lds;                                   // local scores
-    float *wt = sc + ((max_local + 3) & ~3);           // local unnormalised weights
-    float *part = wt + ((max_local + 3) & ~3);         // G*hs
-    const int h = blockIdx.x / nch, c = blockIdx.x % nch;
-    const int kvh = h / a.kv_mul;                      // :369
-    const float *kbase = a.kcache + (size_t)kvh * hs;
-    const float *vbase = a.vcache + (size_t)kvh * hs;
-    const size_t stride = (size_t)a.kv_dim;
-    const int g = threadIdx.x / ge.TPR, c0 = threadIdx.x % ge.TPR;
-    const bool active = c0 < ge.E;
-    const int cc = active ? c0 : 0;
-    const int step = ge.G * kFastUB;
-    const v4f zero = {0.f, 0.f, 0.f, 0.f};
-
-    const int T = *a.pos_ptr + 1;                      // :367
-    const int Tc = T > c ? (T - c + nch - 1) / nch : 0;  // timesteps owned by this block
-    float *po = part_out + ((size_t)h * nch + c) * (size_t)(hs + 4);
-    if (Tc == 0) {  // pos < c: empty chunk (uniform branch)
-        for (int i = threadIdx.x; i < hs; i += blockDim.x) po[i] = 0.0f;
-        if (threadIdx.x == 0) { po[hs] = -INFINITY; po[hs + 1] = 0.0f; }
-        return;
-    }
-    const v4f qv = active ? ((const v4f *)(a.q + (size_t)h * hs))[cc] : zero;
-    v4f kr[kFastUB], vr[kFastUB];
-#pragma unroll
-    for (int i = 0; i < kFastUB; i++) {  // rows clamped to the chunk's last one (duplicates hit L1)
-        int j = g + ge.G * i;
-        j = j < Tc ? j : Tc - 1;
-        kr[i] = ((const v4f *)(kbase + (size_t)(c + nch * j) * stride))[cc];
-    }
-#pragma unroll
-    for (int i = 0; i < kFastUB; i++) {
-        int j = g + ge.G * i;
-        j = j < Tc ? j : Tc - 1;
-        vr[i] = ((const v4f *)(vbase + (size_t)(c + nch * j) * stride))[cc];
-    }
-    const float div = sqrtf((float)hs);
-    for (int j0 = g;;) {  // scores (:367-375), local index j <-> t = c + nch*j
-#pragma unroll
-        for (int i = 0; i < kFastUB; i++) {
-            float p = hsum4(fma4(qv, kr[i], zero));
-            p = lanes_sum(p, ge.TPR);
-            const int j = j0 + ge.G * i;
-            if (c0 == 0 && j < Tc) sc[j] = p / div;  // :372
-        }
-        j0 += step;
-        if (j0 >= Tc) break;
-#pragma unroll
-        for (int i = 0; i < kFastUB; i++) {
-            int j = j0 + ge.G * i;
-            j = j < Tc ? j : Tc - 1;
-            kr[i] = ((const v4f *)(kbase + (size_t)(c + nch * j) * stride))[cc];
-        }
-    }
-    __syncthreads();
-    // chunk-local max and sum of exponentials, redundantly per wave (identical in every wave)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float m = -INFINITY;
-    for (int j = lane; j < Tc; j += kWave) m = fmaxf(m, sc[j]);
-    m = wave_max(m);
-    float l = 0.0f;
-    for (int j = lane; j < Tc; j += kWave) l += expf(sc[j] - m);
-    l = wave_sum(l);
-    for (int j = wave * kWave + lane; j < Tc; j += kBlock) wt[j] = expf(sc[j] - m);  // unnormalised
-    __syncthreads();
-    v4f acc = zero;
-    for (int j0 = g;;) {  // weighted V (:381-388), increasing t within the group
-#pragma unroll
-        for (int i = 0; i < kFastUB; i++) {
-            const int j = j0 + ge.G * i;
-            const float w = j < Tc ? wt[j] : 0.0f;
-            acc.x = fmaf(vr[i].x, w, acc.x);
-            acc.y = fmaf(vr[i].y, w, acc.y);
-            acc.z = fmaf(vr[i].z, w, acc.z);
-            acc.w = fmaf(vr[i].w, w, acc.w);
-        }
-        j0 += step;
-        if (j0 >= Tc) break;
-#pragma unroll
-        for (int i = 0; i < kFastUB; i++) {
-            int j = j0 + ge.G * i;
-            j = j < Tc ? j : Tc - 1;
-            vr[i] = ((const v4f *)(vbase + (size_t)(c + nch * j) * stride))[cc];
-        }
-    }
-    if (active) ((v4f *)(part + (size_t)g * hs))[cc] = acc;
-    __syncthreads();
-    reduce_partials(part, ge.G, hs, po);
-    if (threadIdx.x == 0) { po[hs] = m; po[hs + 1] = l; }
-}
-
-__global__ void attention_combine_kernel(const float *__restrict__ part_in, int nch, int hs,
-                                         float *__restrict__ xb, const P2pArgs *push)
+// Combine of one head's chunk partials (see above); nt threads of one block, i < hs.
+__device__ __forceinline__ void combine_chunks(const float *p, int nch, int hs, float *xb_h,
+                                               const P2pArgs *push, int push_e, size_t push_idx0)
 {
     constexpr int kMaxCh = 16;
-    const int h = blockIdx.x;
-    const float *p = part_in + (size_t)h * nch * (size_t)(hs + 4);
     float mc[kMaxCh], lc[kMaxCh];
 #pragma unroll
     for (int c = 0; c < kMaxCh; c++) {  // all chunk statistics in one round trip
@@ -432,10 +380,134 @@ __global__ void attention_combine_kernel(const float *__restrict__ part_in, int 
 #pragma unroll
         for (int c = 0; c < kMaxCh; c++) num = fmaf(oc[c], mc[c], num);
         const float v = num / den;
-        xb[(size_t)h * hs + i] = v;
-        if (push)
-            p2p_ll_push(push, p2p_ll_epoch(push), (size_t)push->rank * push->count + (size_t)h * hs + i, v);
+        xb_h[i] = v;
+        if (push) p2p_ll_push(push, push_e, push_idx0 + (size_t)i, v);
     }
+}
+
+// One launch: block (h, c) leaves its partial in global memory with write-through stores, drains
+// them, and bumps head h's arrival counter; the block that arrives last (whichever it is) drops its
+// stale cache lines once and combines the nch partials (the hand-off recipe of the CDNA4 guide:
+// write-through payload -> drain -> counter, consumer one agent-scope acquire -> plain loads).
+// No block ever waits for another.  The counter is left at 0 for the next launch.
+__global__ __launch_bounds__(kBlock) void attention_split_kernel(const AttnArgs a, int nch,
+                                                                 float *__restrict__ part_out,
+                                                                 int *__restrict__ arrivals)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int hs = a.head_size;
+    const AttnGeom ge = attn_geom(hs, true, kBlock);
+    const int max_local = (a.seq_len + nch - 1) / nch;
+    float *sc = lds;                                   // local scores
+    float *wt = sc + ((max_local + 3) & ~3);           // local unnormalised weights
+    float *part = wt + ((max_local + 3) & ~3);         // G*hs
+    const int h = blockIdx.x / nch, c = blockIdx.x % nch;
+    const int kvh = h / a.kv_mul;                      // :369
+    const float *kbase = a.kcache + (size_t)kvh * hs;
+    const float *vbase = a.vcache + (size_t)kvh * hs;
+    const size_t stride = (size_t)a.kv_dim;
+    const int g = threadIdx.x / ge.TPR, c0 = threadIdx.x % ge.TPR;
+    const bool active = c0 < ge.E;
+    const int cc = active ? c0 : 0;
+    const int step = ge.G * kFastUB;
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+
+    const int T = *a.pos_ptr + 1;                      // :367
+    const int Tc = T > c ? (T - c + nch - 1) / nch : 0;  // timesteps owned by this block
+    float *po = part_out + ((size_t)h * nch + c) * (size_t)(hs + 4);
+    float m = -INFINITY, l = 0.0f;
+    if (Tc == 0) {  // pos < c: empty chunk (uniform branch)
+        for (int i = threadIdx.x; i < hs; i += blockDim.x)
+            __hip_atomic_store(po + i, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        const v4f qv = active ? ((const v4f *)(a.q + (size_t)h * hs))[cc] : zero;
+        v4f kr[kFastUB], vr[kFastUB];
+        // K and V rows are read once per token and the long-context cache does not fit the on-die
+        // caches: non-temporal, like the weight stream
+#pragma unroll
+        for (int i = 0; i < kFastUB; i++) {  // rows clamped to the chunk's last one (duplicates hit L1)
+            int j = g + ge.G * i;
+            j = j < Tc ? j : Tc - 1;
+            kr[i] = ldg_nt((const v4f *)(kbase + (size_t)(c + nch * j) * stride) + cc);
+        }
+#pragma unroll
+        for (int i = 0; i < kFastUB; i++) {
+            int j = g + ge.G * i;
+            j = j < Tc ? j : Tc - 1;
+            vr[i] = ldg_nt((const v4f *)(vbase + (size_t)(c + nch * j) * stride) + cc);
+        }
+        const float div = sqrtf((float)hs);
+        for (int j0 = g;;) {  // scores (:367-375), local index j <-> t = c + nch*j
+#pragma unroll
+            for (int i = 0; i < kFastUB; i++) {
+                float p = hsum4(fma4(qv, kr[i], zero));
+                p = lanes_sum(p, ge.TPR);
+                const int j = j0 + ge.G * i;
+                if (c0 == 0 && j < Tc) sc[j] = p / div;  // :372
+            }
+            j0 += step;
+            if (j0 >= Tc) break;
+#pragma unroll
+            for (int i = 0; i < kFastUB; i++) {
+                int j = j0 + ge.G * i;
+                j = j < Tc ? j : Tc - 1;
+                kr[i] = ldg_nt((const v4f *)(kbase + (size_t)(c + nch * j) * stride) + cc);
+            }
+        }
+        __syncthreads();
+        // chunk-local max and sum of exponentials, redundantly per wave (identical in every wave)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int j = lane; j < Tc; j += kWave) m = fmaxf(m, sc[j]);
+        m = wave_max(m);
+        for (int j = lane; j < Tc; j += kWave) l += expf(sc[j] - m);
+        l = wave_sum(l);
+        for (int j = wave * kWave + lane; j < Tc; j += kBlock) wt[j] = expf(sc[j] - m);  // unnormalised
+        __syncthreads();
+        v4f acc = zero;
+        for (int j0 = g;;) {  // weighted V (:381-388), increasing t within the group
+#pragma unroll
+            for (int i = 0; i < kFastUB; i++) {
+                const int j = j0 + ge.G * i;
+                const float w = j < Tc ? wt[j] : 0.0f;
+                acc.x = fmaf(vr[i].x, w, acc.x);
+                acc.y = fmaf(vr[i].y, w, acc.y);
+                acc.z = fmaf(vr[i].z, w, acc.z);
+                acc.w = fmaf(vr[i].w, w, acc.w);
+            }
+            j0 += step;
+            if (j0 >= Tc) break;
+#pragma unroll
+            for (int i = 0; i < kFastUB; i++) {
+                int j = j0 + ge.G * i;
+                j = j < Tc ? j : Tc - 1;
+                vr[i] = ldg_nt((const v4f *)(vbase + (size_t)(c + nch * j) * stride) + cc);
+            }
+        }
+        if (active) ((v4f *)(part + (size_t)g * hs))[cc] = acc;
+        __syncthreads();
+        reduce_partials_wt(part, ge.G, hs, po);
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(po + hs, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(po + hs + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its partial
+    __syncthreads();
+    int *flag = (int *)sc;  // scores are dead: reuse their first word
+    if (threadIdx.x == 0) {
+        const int prev = __hip_atomic_fetch_add(arrivals + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = prev == nch - 1;
+        if (last) {
+            __hip_atomic_store(arrivals + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this CU's stale lines of the partials
+        }
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    combine_chunks(part_out + (size_t)h * nch * (size_t)(hs + 4), nch, hs, a.xb + (size_t)h * hs, a.push,
+                   a.push ? a.push_ctl[kCtlEpoch] + a.push_gi : 0,
+                   a.push ? (size_t)a.push->rank * a.push->count + (size_t)h * hs : 0);
 }
 
 // Generic path: any head_size / alignment.
@@ -511,22 +583,18 @@ size_t attention_split_part_floats(int n_heads_local, int head_size, int nch)
     return (size_t)n_heads_local * nch * (size_t)(head_size + 4);
 }
 
-hipError_t launch_attention_split(const AttnArgs &a, int n_heads_local, int nch, float *part,
-                                  hipStream_t st)
+hipError_t launch_attention_split(const AttnArgs &a_in, int n_heads_local, int nch, float *part,
+                                  int *arrivals, hipStream_t st)
 {
+    AttnArgs a = a_in;
+    a.n_head_blocks = n_heads_local * nch;  // every block works on a head: no prefetch blocks here
     const AttnGeom ge = attn_geom(a.head_size, true, kBlock);
     const int max_local = (a.seq_len + nch - 1) / nch;
     const size_t lds = (size_t)(2 * ((max_local + 3) & ~3) + ge.G * a.head_size) * sizeof(float);
     hipError_t e = ensure_lds(attention_split_kernel, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(attention_split_kernel, dim3(n_heads_local * nch), dim3(kBlock), lds, st, a,
-                       nch, part);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    int ct = (a.head_size + 63) & ~63;
-    if (ct > 1024) ct = 1024;
-    hipLaunchKernelGGL(attention_combine_kernel, dim3(n_heads_local), dim3(ct), 0, st, part, nch,
-                       a.head_size, a.xb, a.push);
+                       nch, part, arrivals);
     return hipGetLastError();
 }
 
@@ -542,25 +610,35 @@ bool attention_split_supported(const AttnArgs &a)
            aligned16(a.kcache) && aligned16(a.vcache);
 }
 
-hipError_t launch_attention(const AttnArgs &a, int n_heads_local, hipStream_t st)
+// form: 0 = by shape (1024 threads per head for seq_len > 512, else 256 speculative), 1 / 2 force the
+// 256- / 1024-thread fast kernel, 4 forces the generic kernel (tests drive every form directly)
+hipError_t launch_attention(const AttnArgs &a_in, int n_heads_local, hipStream_t st, int form)
 {
+    AttnArgs a = a_in;
+    a.n_head_blocks = n_heads_local;
     const bool vec = (a.head_size % 4) == 0 && (a.kv_dim % 4) == 0 && aligned16(a.q) &&
                      aligned16(a.kcache) && aligned16(a.vcache);
     const size_t lds = attention_lds_bytes(a.head_size, a.seq_len, vec);
-    if (vec && a.head_size <= 256) {
-        static const int forced = getenv("L2Z_ATTN_BLOCK") ? atoi(getenv("L2Z_ATTN_BLOCK")) : 0;
+    if (vec && a.head_size <= 256 && form != 4) {
+        const int forced = form == 1 ? kBlock : form == 2 ? kAttnFastBlock : tunables().attn_block;
         const int nt = forced ? forced : (a.seq_len > 512 ? kAttnFastBlock : kBlock);
         const AttnGeom gf = attn_geom(a.head_size, true, nt);
         const size_t lds_fast = (size_t)(2 * ((a.seq_len + 3) & ~3) + gf.G * a.head_size) * sizeof(float);
+        // idle CUs pull the next launch's weights (prefetch_block); only worth a block per spare CU
+        int extra = 0;
+        if (a.pf_ptr != nullptr && a.pf_floats >= 1024 && aligned16(a.pf_ptr) && a.pf_blocks > 0)
+            extra = a.pf_blocks;
+        else
+            a.pf_ptr = nullptr;
         if (nt == kAttnFastBlock) {
             hipError_t e = ensure_lds(attention_fast_kernel<kAttnFastBlock, false>, lds_fast);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((attention_fast_kernel<kAttnFastBlock, false>), dim3(n_heads_local),
+            hipLaunchKernelGGL((attention_fast_kernel<kAttnFastBlock, false>), dim3(n_heads_local + extra),
                                dim3(kAttnFastBlock), lds_fast, st, a);
         } else {
             hipError_t e = ensure_lds(attention_fast_kernel<kBlock, true>, lds_fast);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((attention_fast_kernel<kBlock, true>), dim3(n_heads_local),
+            hipLaunchKernelGGL((attention_fast_kernel<kBlock, true>), dim3(n_heads_local + extra),
                                dim3(kBlock), lds_fast, st, a);
         }
         return hipGetLastError();

@@ -11,6 +11,7 @@
 #include <cstring>
 
 #include "l2z_comm.h"
+#include "tunables.h"
 
 namespace l2z {
 
@@ -61,43 +62,53 @@ int comm_check(const l2z_comm *c)
     return L2Z_OK;
 }
 
-bool comm_p2p_args(const l2z_comm *c, float *buf, size_t count_per_rank, P2pArgs *out)
+bool comm_p2p_args(const l2z_comm *c, float *buf, size_t count_per_rank, bool self, P2pArgs *out)
 {
     if (c == nullptr || !c->p2p || c->world <= 1) return false;
-    static const long long timeout_s = getenv("L2Z_P2P_TIMEOUT_S") ? atoll(getenv("L2Z_P2P_TIMEOUT_S")) : 20;
     P2pArgs a = {};
     a.buf = buf; a.count = count_per_rank; a.rank = c->rank; a.world = c->world;
     a.slot_floats = c->slot_floats;
     for (int r = 0; r < c->world; r++) a.peer_arena[r] = c->peer_arena[r];
-    a.epoch = c->d_epoch; a.err = c->h_err;
-    a.timeout_ticks = timeout_s * 100000000LL;
+    a.ctl = c->d_ctl; a.err = c->h_err;
+    a.timeout_ticks = tunables().p2p_timeout_s * 100000000LL;
+    a.self = self ? 1 : 0;
     *out = a;
     return true;
 }
 
-// the gather after a launch that pushed its own LL words: collect only
-int comm_allgather_inplace_pushed(const l2z_comm *c, float *buf, size_t count_per_rank, hipStream_t st)
+// where a consumer finds gathered vector `gi` as LL words: this rank's own landing slots
+LLIn comm_ll_in(const l2z_comm *c, int gi, size_t count_per_rank)
 {
-    P2pArgs a = {};
-    L2Z_CHECK(comm_p2p_args(c, buf, count_per_rank, &a), L2Z_ERR_STATE, "pushed gather without peer-write transport");
-    hipError_t e = launch_p2p_allgather(a, st, true);
-    L2Z_CHECK(e == hipSuccess, L2Z_ERR_HIP, "peer-write gather launch failed: %s", hipGetErrorString(e));
-    return L2Z_OK;
+    LLIn in = {};
+    in.slots = reinterpret_cast<const unsigned long long *>(c->arena + kP2pFlagBytes);
+    in.slot_floats = (unsigned)c->slot_floats;
+    in.count = (unsigned)count_per_rank;
+    in.gi = gi;
+    in.ctl = c->d_ctl;
+    in.h_err = c->h_err;
+    in.timeout_ticks = tunables().p2p_timeout_s * 100000000LL;
+    return in;
 }
 
-int comm_allgather_inplace(const l2z_comm *c, float *buf, size_t count_per_rank, hipStream_t st)
+bool comm_uses_p2p(const l2z_comm *c)
 {
-    static const bool prefer_rccl = getenv("L2Z_COMM") && std::strcmp(getenv("L2Z_COMM"), "rccl") == 0;
-    if (c != nullptr && c->p2p && c->world > 1 && !(prefer_rccl && c->nccl)) {
+    return c != nullptr && c->p2p && c->world > 1 && !(tunables().prefer_rccl && c->nccl);
+}
+
+int comm_allgather_inplace(const l2z_comm *c, float *buf, size_t count_per_rank, int gi, int n_gathers,
+                           bool pushed, hipStream_t st)
+{
+    if (comm_uses_p2p(c)) {
         L2Z_CHECK(count_per_rank * (size_t)c->world <= c->slot_floats, L2Z_ERR_COMM,
                   "peer-write gather of %zu floats exceeds the landing slot (%zu)",
                   count_per_rank * (size_t)c->world, c->slot_floats);
         P2pArgs a = {};
-        comm_p2p_args(c, buf, count_per_rank, &a);
-        hipError_t e = launch_p2p_allgather(a, st);
+        comm_p2p_args(c, buf, count_per_rank, false, &a);
+        hipError_t e = launch_p2p_allgather(a, gi, n_gathers, pushed, st);
         L2Z_CHECK(e == hipSuccess, L2Z_ERR_HIP, "peer-write gather launch failed: %s", hipGetErrorString(e));
         return L2Z_OK;
     }
+    L2Z_CHECK(!pushed, L2Z_ERR_STATE, "pushed gather without the peer-write transport");
     if (c == nullptr || c->nccl == nullptr) return L2Z_OK;  // single GPU without a communicator
     // in-place form: sendbuff == recvbuff + rank * count
     ncclResult_t r = g_api.AllGather(buf + (size_t)c->rank * count_per_rank, buf, count_per_rank,
@@ -186,8 +197,8 @@ extern "C" int l2z_comm_p2p_export(l2z_comm *c, size_t max_vector_floats, void *
     // a running kernel (ordinary hipMalloc memory is only coherent at kernel boundaries)
     L2Z_HIP(hipExtMallocWithFlags((void **)&c->arena, bytes, hipDeviceMallocFinegrained));
     L2Z_HIP(hipMemset(c->arena, 0, bytes));
-    L2Z_HIP(hipMalloc((void **)&c->d_epoch, kMaxWorld * sizeof(int)));
-    L2Z_HIP(hipMemset(c->d_epoch, 0, kMaxWorld * sizeof(int)));
+    L2Z_HIP(hipMalloc((void **)&c->d_ctl, kCtlInts * sizeof(int)));
+    L2Z_HIP(hipMemset(c->d_ctl, 0, kCtlInts * sizeof(int)));
     L2Z_HIP(hipHostMalloc((void **)&c->h_err, sizeof(int), hipHostMallocDefault));
     *c->h_err = 0;
     L2Z_HIP(hipDeviceSynchronize());
@@ -246,7 +257,7 @@ extern "C" void l2z_comm_free(l2z_comm *c)
     for (int r = 0; r < c->world && r < kMaxWorld; r++)
         if (r != c->rank && c->peer_arena[r]) (void)hipIpcCloseMemHandle(c->peer_arena[r]);
     if (c->arena) (void)hipFree(c->arena);
-    if (c->d_epoch) (void)hipFree(c->d_epoch);
+    if (c->d_ctl) (void)hipFree(c->d_ctl);
     if (c->h_err) (void)hipHostFree(c->h_err);
     if (c->nccl && g_api.CommDestroy) g_api.CommDestroy(static_cast<ncclComm_t>(c->nccl));
     delete c;

@@ -50,6 +50,12 @@ int check_pair(const l2z_config *config, const l2z_runstate *s, const l2z_weight
 // the single-process multi-rank emulation (l2z_emu_transformer) interleaves the ranks
 // stage by stage and performs the gathers itself.  Stages: 4 per layer (after attention,
 // wo, ffn13, ffn2), then the classifier, then argmax.
+//
+// Sharded runs (world > 1) gather xb, x, hb, x per layer and the logits at the end; gather gi
+// (1-based) of the pass is vector (gi-1) % 4 of layer (gi-1) / 4.  Three forms (p2p.hip):
+//   ll_consume  producers push LL words to every rank, consumers read them from their own landing
+//               slot while staging x: no launch per gather, 5 nodes per layer as at world == 1;
+//   gather launch after every producer (peer writes without consumer polling, or RCCL).
 int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof *prof,
                     int only_stage, bool split)
 {
@@ -60,22 +66,53 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
     const int mb = s->max_blocks;
     int stage = 0;
     auto want = [&]() { return only_stage < 0 || only_stage == stage; };
-    // Peer-write transport: kernels that can, store their outputs as LL words straight into the
-    // peers' slots (the values travel while the launch still runs); the gather that follows then
-    // only collects.  `pushed` = the launch just made did.  Not while profiling (the gather's
-    // share would be hidden in the kernel's time), not for emulated ranks, not with L2Z_COMM=rccl.
-    static const bool push_env = !(getenv("L2Z_P2P_PUSH") && atoi(getenv("L2Z_P2P_PUSH")) == 0) &&
-                                 !(getenv("L2Z_COMM") && strcmp(getenv("L2Z_COMM"), "rccl") == 0);
-    const bool can_push = push_env && s->d_push != nullptr && prof == nullptr && only_stage < 0;
-    bool pushed = false;
+    const bool p2p = s->d_push != nullptr && only_stage < 0;
+    const bool consume = p2p && s->ll_consume;
+    // Producers push their outputs as LL words straight into the peers' slots (the values travel
+    // while the launch still runs).  With gather launches, not while profiling: the gather's share
+    // would be hidden in the producer's time.
+    const bool can_push = p2p && tunables().p2p_push && (consume || prof == nullptr);
+    const int n_g = s->n_gathers;
+    bool handed_over = false;  // the classifier launch did argmax + hand-over itself
+    int gi = 0;           // gathers issued so far in this pass
+    bool pushed = false;  // the launch just made pushed its outputs itself
+    const int *ctl = s->comm ? s->comm->d_ctl : nullptr;
     auto gather = [&](float *buf, size_t count_per_rank) -> int {
         stage++;
+        gi++;
         if (only_stage >= 0) return L2Z_OK;
-        if (pushed) {
-            pushed = false;
-            return comm_allgather_inplace_pushed(s->comm, buf, count_per_rank, st);
+        const bool was_pushed = pushed;
+        pushed = false;
+        if (consume) {
+            L2Z_CHECK(was_pushed, L2Z_ERR_STATE, "consumer-side gather %d: the producer did not push", gi);
+            if (gi < n_g) return L2Z_OK;  // the consumer collects; only the logits get a launch
         }
-        return comm_allgather_inplace(s->comm, buf, count_per_rank, st);
+        hipEvent_t ea = nullptr, eb = nullptr;
+        const bool timed = prof != nullptr && s->comm != nullptr && s->comm->world > 1;
+        if (timed) {
+            L2Z_HIP(hipEventCreate(&ea));
+            L2Z_HIP(hipEventCreate(&eb));
+            L2Z_HIP(hipEventRecord(ea, st));
+        }
+        L2Z_TRY(comm_allgather_inplace(s->comm, buf, count_per_rank, gi, n_g, was_pushed, st));
+        if (timed) {
+            L2Z_HIP(hipEventRecord(eb, st));
+            prof->ev.push_back(ea);
+            prof->ev.push_back(eb);
+            prof->kind.push_back(KIND_GATHER);
+        }
+        return L2Z_OK;
+    };
+    // input of a consumer: the vector gathered as number g (consumer-side form), else the plain buffer
+    auto x_in = [&](MatvecArgs &a, const float *plain, int g, size_t count_per_rank) {
+        a.x = plain;
+        if (consume && g >= 1) a.xin = comm_ll_in(s->comm, g, count_per_rank);
+    };
+    auto push_to = [&](MatvecArgs &a, int which) {
+        if (!can_push) return;
+        a.push = s->d_push + which;
+        a.push_ctl = ctl;
+        a.push_gi = gi + 1;
     };
     for (int l = 0; l < c.n_layers; l++) {
         float *kc = s->key_cache + (size_t)l * c.seq_len * sh.kvd_loc;  // :354 loff
@@ -88,7 +125,8 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.out0 = s->q; a.out1 = kc; a.out2 = vc;
             a.rows0 = sh.dim_loc; a.rows1 = sh.kvd_loc; a.rows2 = sh.kvd_loc;
             a.pos_stride1 = sh.kvd_loc; a.pos_stride2 = sh.kvd_loc;
-            a.n = c.dim; a.x = s->x; a.rms_w = w->rms_att + (size_t)l * dim;
+            a.n = c.dim; a.rms_w = w->rms_att + (size_t)l * dim;
+            x_in(a, s->x, gi, sh.dim_loc);  // layer 0: the embedding row, a plain buffer (gi == 0)
             a.pos_ptr = s->d_pos; a.rope = s->rope; a.head_size = sh.hs; a.rope_segs = 2;
             L2Z_LAUNCH(KIND_QKV, launch_matvec(a, PRO_RMS, EPI_ROPE, mb, g_cus, st));
         }
@@ -99,21 +137,37 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.kv_mul = c.n_heads / c.n_kv_heads; a.seq_len = c.seq_len;
             if (can_push && attention_push_supported(a)) {
                 a.push = s->d_push + 0;
+                a.push_ctl = ctl;
+                a.push_gi = gi + 1;
                 pushed = true;
             }
-            if (split && s->attn_nch > 1 && attention_split_supported(a))
+            if (split && s->attn_nch > 1 && attention_split_supported(a)) {
                 L2Z_LAUNCH(KIND_ATTN, launch_attention_split(a, sh.heads_loc, s->attn_nch,
-                                                             s->d_attn_part, st));
-            else
+                                                             s->d_attn_part, s->d_attn_cnt, st));
+            } else {
+                // short context: one block per head leaves most CUs idle for a latency chain that
+                // moves almost no bytes -- they pull this layer's wo rows (the next launch's
+                // stream) into the on-die cache meanwhile.  Only for matrices far larger than the
+                // L2s (the small models are cache resident anyway).
+                const size_t wo_floats = (size_t)sh.dim_loc * dim;
+                const int pct = tunables().attn_prefetch;
+                if (pct > 0 && g_cus > sh.heads_loc && wo_floats * 4 >= ((size_t)8 << 20)) {
+                    a.pf_ptr = w->wo + (size_t)l * wo_floats;
+                    a.pf_floats = (wo_floats / 100 * (size_t)(pct > 100 ? 100 : pct)) & ~(size_t)3;
+                    a.pf_blocks = g_cus - sh.heads_loc;
+                    a.pf_sink = s->d_pf_sink;
+                }
                 L2Z_LAUNCH(KIND_ATTN, launch_attention(a, sh.heads_loc, st));
+            }
         }
         L2Z_TRY(gather(s->xb, sh.dim_loc));
         if (want()) {   // wo (:392) + residual (:395)
             MatvecArgs a = {};
             a.w0 = w->wo + (size_t)l * sh.dim_loc * dim;
             a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0;
-            a.rows0 = sh.dim_loc; a.n = c.dim; a.x = s->xb;
-            if (can_push) a.push = s->d_push + 1;
+            a.rows0 = sh.dim_loc; a.n = c.dim;
+            x_in(a, s->xb, gi, sh.dim_loc);
+            push_to(a, 1);
             L2Z_LAUNCH(KIND_WO, launch_matvec(a, PRO_NONE, EPI_RESID, mb, g_cus, st, nullptr, &pushed));
         }
         L2Z_TRY(gather(s->x, sh.dim_loc));
@@ -123,8 +177,9 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.w1 = w->w3 + (size_t)l * sh.hid_loc * dim;
             a.out0 = s->hb + sh.hid0;
             a.rows0 = sh.hid_loc; a.rows1 = sh.hid_loc; a.n = c.dim;
-            a.x = s->x; a.rms_w = w->rms_ffn + (size_t)l * dim;
-            if (can_push) a.push = s->d_push + 2;
+            a.rms_w = w->rms_ffn + (size_t)l * dim;
+            x_in(a, s->x, gi, sh.dim_loc);
+            push_to(a, 2);
             L2Z_LAUNCH(KIND_FFN13, launch_matvec(a, PRO_RMS, EPI_SWIGLU, mb, g_cus, st, nullptr, &pushed));
         }
         L2Z_TRY(gather(s->hb, sh.hid_loc));
@@ -132,8 +187,9 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             MatvecArgs a = {};
             a.w0 = w->w2 + (size_t)l * sh.dim_loc * hid;
             a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0;
-            a.rows0 = sh.dim_loc; a.n = c.hidden_dim; a.x = s->hb;
-            if (can_push) a.push = s->d_push + 1;
+            a.rows0 = sh.dim_loc; a.n = c.hidden_dim;
+            x_in(a, s->hb, gi, sh.hid_loc);
+            push_to(a, 1);
             L2Z_LAUNCH(KIND_FFN2, launch_matvec(a, PRO_NONE, EPI_RESID, mb, g_cus, st, nullptr, &pushed));
         }
         L2Z_TRY(gather(s->x, sh.dim_loc));
@@ -141,18 +197,28 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
     if (want()) {   // final rmsnorm (:426) + classifier (:429)
         MatvecArgs a = {};
         a.w0 = w->wcls; a.out0 = s->logits + sh.v0;
-        a.rows0 = sh.v_loc; a.n = c.dim; a.x = s->x; a.rms_w = w->rms_final;
+        a.rows0 = sh.v_loc; a.n = c.dim; a.rms_w = w->rms_final;
+        x_in(a, s->x, gi, sh.dim_loc);
         a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.row_offset = sh.v0;
         // single GPU, vector path: the launch also leaves one argmax candidate per block
         const bool fuse = sh.world == 1 && matvec_vector_width(c.dim);
         int grid = 0;
-        if (can_push) a.push = s->d_push + 3;
+        push_to(a, 3);
+        // greedy step: the classifier's last block also does argmax + hand-over (cls_finish)
+        handed_over = fuse && with_step && tunables().cls_handover != 0;
+        if (handed_over) {
+            ArgmaxArgs &f = a.fin;
+            f.token_ptr = s->d_token; f.pos_ptr = s->d_pos; f.prompt = s->d_prompt;
+            f.n_prompt_ptr = s->d_n_prompt; f.out_tokens = s->d_out_tokens; f.argmax_out = s->d_argmax;
+            f.tok_emb = w->tok_emb; f.x = s->x; f.dim = c.dim; f.advance = 1;
+            a.fin_counter = s->d_fin_cnt;
+        }
         L2Z_LAUNCH(KIND_CLS, launch_matvec(a, PRO_RMS, fuse ? EPI_ARGMAX : EPI_STORE, mb, g_cus, st,
                                            &grid, &pushed));
         s->n_part = fuse ? grid : 0;
     }
     L2Z_TRY(gather(s->logits, sh.v_loc));
-    if (with_step && want()) {
+    if (with_step && want() && !handed_over) {
         ArgmaxArgs a = {};
         a.logits = s->logits; a.vocab = c.vocab_size; a.token_ptr = s->d_token;
         if (s->n_part > 0) { a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.n_part = s->n_part; }
@@ -190,13 +256,13 @@ void drop_graphs(l2z_runstate *s)
         if (s->g_forward[v]) { (void)hipGraphExecDestroy(s->g_forward[v]); s->g_forward[v] = nullptr; }
         if (s->g_step[v]) { (void)hipGraphExecDestroy(s->g_step[v]); s->g_step[v] = nullptr; }
     }
-    s->graph_w = nullptr;
+    s->graph_w_uid = 0;
 }
 
 int ensure_graphs(l2z_runstate *s, const l2z_weights *w)
 {
     if (!s->use_graphs) return L2Z_OK;
-    if (s->graph_w == w && s->g_forward[0] && s->g_step[0]) return L2Z_OK;
+    if (s->graph_w_uid == w->uid && s->g_forward[0] && s->g_step[0]) return L2Z_OK;
     drop_graphs(s);
     const int n_var = s->attn_nch > 1 ? 2 : 1;
     int rc = L2Z_OK;
@@ -212,7 +278,7 @@ int ensure_graphs(l2z_runstate *s, const l2z_weights *w)
         (void)hipGetLastError();
         return L2Z_OK;
     }
-    s->graph_w = w;
+    s->graph_w_uid = w->uid;
     return L2Z_OK;
 }
 

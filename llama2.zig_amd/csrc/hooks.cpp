@@ -1,4 +1,12 @@
-// hooks.cpp -- kernel-level entry points of the C ABI (tests, and the reference's own unit-test shapes).
+// hooks.cpp -- kernel-level entry points of include/llama2_hip_test.h (tests, and the reference's own
+// unit-test shapes).  What runs behind each hook:
+//   l2z_matmul / l2z_matmul_fused   launch_matvec: the forward pass's own kernels for that width
+//   l2z_rmsnorm                     the mat-vec prologue's staging code (xload_issue / xstage_finish)
+//   l2z_attention_decode            the forward pass's attention kernels, every form selectable
+//   l2z_softmax, l2z_vector_dot_product, l2z_vector_weighted_sum_rows
+//                                   the GENERIC attention kernel's device functions (block_softmax,
+//                                   attn_scores, attn_weighted_sum) -- the forms the stories / 7B
+//                                   shapes run are covered by l2z_attention_decode instead
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -10,8 +18,7 @@
 using namespace l2z;
 
 // ---------------------------------------------------------------------------
-// Kernel-level test hooks: upload, run the SAME device code the forward pass
-// uses, download.
+// Kernel-level test hooks: upload, launch, download.
 namespace {
 struct DevBuf {
     float *p = nullptr;
@@ -126,6 +133,64 @@ extern "C" int l2z_argmax_host(const float *x, size_t n, size_t *out_index)
     (void)hipFree(didx);
     L2Z_HIP(e);
     *out_index = (size_t)idx;
+    return L2Z_OK;
+}
+
+// src/main.zig:361-389 for one layer, through the forward pass's attention kernels
+extern "C" int l2z_attention_decode(int form, int nch, float *out, const float *q, const float *kcache,
+                                    const float *vcache, int pos, int n_heads, int n_kv_heads,
+                                    int head_size, int seq_len)
+{
+    L2Z_CHECK(out && q && kcache && vcache && n_heads > 0 && n_kv_heads > 0 && head_size > 0 &&
+                  n_heads % n_kv_heads == 0 && seq_len > 0 && pos >= 0 && pos < seq_len,
+              L2Z_ERR_INVALID, "l2z_attention_decode: bad arguments");
+    L2Z_CHECK(form >= 0 && form <= 4, L2Z_ERR_INVALID, "l2z_attention_decode: form %d", form);
+    L2Z_TRY(ensure_device(current_device_for(nullptr)));
+    const size_t dim = (size_t)n_heads * head_size, kvd = (size_t)n_kv_heads * head_size;
+    const size_t kvn = (size_t)seq_len * kvd;
+    DevBuf dq, dk, dv, dout, dpart;
+    int *dpos = nullptr, *dcnt = nullptr;
+    L2Z_TRY(dq.alloc(dim)); L2Z_TRY(dk.alloc(kvn)); L2Z_TRY(dv.alloc(kvn)); L2Z_TRY(dout.alloc(dim));
+    L2Z_TRY(dq.up(q, dim)); L2Z_TRY(dk.up(kcache, kvn)); L2Z_TRY(dv.up(vcache, kvn));
+    AttnArgs a = {};
+    a.q = dq.p; a.kcache = dk.p; a.vcache = dv.p; a.xb = dout.p;
+    a.head_size = head_size; a.kv_dim = (int)kvd; a.kv_mul = n_heads / n_kv_heads; a.seq_len = seq_len;
+    const bool fast_ok = attention_split_supported(a);  // same conditions as the fast kernels
+    L2Z_CHECK(form == 0 || form == 4 || fast_ok, L2Z_ERR_INVALID,
+              "l2z_attention_decode: form %d needs head_size %% 4 == 0 and <= 256", form);
+    const size_t att_lds = attention_lds_bytes(head_size, seq_len, fast_ok);
+    L2Z_CHECK(att_lds <= 160 * 1024, L2Z_ERR_INVALID, "l2z_attention_decode: seq_len too long for LDS");
+    hipError_t e = hipMalloc(&dpos, sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(dpos, &pos, sizeof(int), hipMemcpyHostToDevice);
+    a.pos_ptr = dpos;
+    int use_nch = 0;
+    if (e == hipSuccess && (form == 3 || (form == 0 && fast_ok && pos >= 256 && seq_len > 256))) {
+        use_nch = nch > 0 ? nch : attention_split_chunks(n_heads, g_cus);
+        if (use_nch > 16) use_nch = 16;
+        if (use_nch < 2) use_nch = form == 3 ? 2 : 0;
+    }
+    if (e == hipSuccess && use_nch > 1) {
+        int rc = dpart.alloc(attention_split_part_floats(n_heads, head_size, use_nch));
+        if (rc != L2Z_OK) { (void)hipFree(dpos); return rc; }
+        e = hipMalloc(&dcnt, (size_t)n_heads * sizeof(int));
+        if (e == hipSuccess) e = hipMemset(dcnt, 0, (size_t)n_heads * sizeof(int));
+        // twice: the second launch finds the counters as the first one left them
+        if (e == hipSuccess) e = launch_attention_split(a, n_heads, use_nch, dpart.p, dcnt, nullptr);
+        if (e == hipSuccess) e = launch_attention_split(a, n_heads, use_nch, dpart.p, dcnt, nullptr);
+    } else if (e == hipSuccess) {
+        e = launch_attention(a, n_heads, nullptr, form == 3 ? 0 : form);
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(dpos);
+    if (dcnt) (void)hipFree(dcnt);
+    L2Z_HIP(e);
+    return dout.down(out, dim);
+}
+
+extern "C" int l2z_option_set(const char *env_name, long long value)
+{
+    L2Z_CHECK(env_name != nullptr && tunables_set(env_name, value), L2Z_ERR_INVALID,
+              "l2z_option_set: unknown option '%s'", env_name ? env_name : "(null)");
     return L2Z_OK;
 }
 

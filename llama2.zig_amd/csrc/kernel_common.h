@@ -7,6 +7,7 @@
 
 #include "l2z_comm.h"
 #include "l2z_internal.h"
+#include "tunables.h"
 
 namespace l2z {
 namespace {
@@ -151,15 +152,15 @@ __device__ __forceinline__ void xload_issue(const float *__restrict__ x,
     }
 }
 
-template <int PRO, int XC>
-__device__ __forceinline__ void xstage_finish(const float *__restrict__ x,
-                                              const float *__restrict__ rms_w, int n, int n4_pad,
-                                              v4f (&xr)[XC], v4f (&gr)[XC], float *xs,
-                                              float *scratch)
+// Tail of the staging shared by the plain and the LL form: xr[] holds this thread's first XC
+// float4 of x; `loadx(j)` fetches float4 j of x for the part of a long x that is not in registers.
+template <int PRO, int XC, typename LoadX>
+__device__ __forceinline__ void xstage_tail(const float *__restrict__ rms_w, int n, int n4_pad,
+                                            v4f (&xr)[XC], v4f (&gr)[XC], float *xs, float *scratch,
+                                            LoadX loadx)
 {
     const int tid = threadIdx.x;
     const int n4 = n >> 2;
-    const v4f *x4 = (const v4f *)x;
     v4f *xs4 = (v4f *)xs;
     float ss = 0.0f;
 #pragma unroll
@@ -174,7 +175,7 @@ __device__ __forceinline__ void xstage_finish(const float *__restrict__ x,
         }
     }
     for (int j = tid + kBlock * XC; j < n4_pad; j += kBlock) {  // n > XC*1024 floats
-        const v4f v = (j < n4) ? x4[j] : v4f{0.f, 0.f, 0.f, 0.f};
+        const v4f v = (j < n4) ? loadx(j) : v4f{0.f, 0.f, 0.f, 0.f};
         xs4[j] = v;
         if (PRO == PRO_RMS) {
             ss = fmaf(v.x, v.x, ss);
@@ -218,6 +219,111 @@ __device__ __forceinline__ void xstage_finish(const float *__restrict__ x,
         }
     }
     __syncthreads();
+}
+
+template <int PRO, int XC>
+__device__ __forceinline__ void xstage_finish(const float *__restrict__ x,
+                                              const float *__restrict__ rms_w, int n, int n4_pad,
+                                              v4f (&xr)[XC], v4f (&gr)[XC], float *xs,
+                                              float *scratch)
+{
+    const v4f *x4 = (const v4f *)x;
+    xstage_tail<PRO, XC>(rms_w, n, n4_pad, xr, gr, xs, scratch, [&](int j) { return x4[j]; });
+}
+
+// ---------------------------------------------------------------------------
+// The same staging when x is a GATHERED vector of a sharded run (peer-write transport, p2p.hip):
+// instead of a separate gather launch copying the peers' slices into a plain buffer, the consumer
+// reads the LL words {value, epoch} straight out of this rank's own landing slot -- every rank,
+// this one included, stored its slice there -- and re-reads until every word carries the epoch of
+// the gather.  Four words (two 16-byte system-scope loads) make one float4 of x.
+// ---------------------------------------------------------------------------
+struct LLPoll {
+    const unsigned long long *slot;  // landing slot of this gather
+    unsigned e;
+    unsigned count;
+    int *ctl;
+    int *h_err;
+    long long timeout_ticks;
+};
+
+__device__ __forceinline__ LLPoll ll_poll_init(const LLIn &in)
+{
+    LLPoll p;
+    const int e = in.ctl[kCtlEpoch] + in.gi;
+    p.e = (unsigned)e;
+    p.slot = in.slots + (size_t)(e & 1) * in.slot_floats;
+    p.count = in.count;
+    p.ctl = in.ctl;
+    p.h_err = in.h_err;
+    p.timeout_ticks = in.timeout_ticks;
+    return p;
+}
+
+// float4 j of the gathered vector; a, b = the two loads already made (re-made until ready)
+__device__ __forceinline__ v4f ll_wait4(const LLPoll &p, int j, v4u a, v4u b)
+{
+    if (!(ll_ready2(a, p.e) && ll_ready2(b, p.e))) {
+        // slow path: a peer (or this rank's own producer on another stream: never) is behind
+        bool give_up = __hip_atomic_load(p.ctl + kCtlErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        const long long t0 = wall_clock64();
+        while (!give_up) {
+            __builtin_amdgcn_s_sleep(4);
+            a = ll_load2(p.slot, (size_t)4 * j);
+            b = ll_load2(p.slot, (size_t)4 * j + 2);
+            if (ll_ready2(a, p.e) && ll_ready2(b, p.e)) break;
+            if (wall_clock64() - t0 > p.timeout_ticks) {
+                give_up = true;
+                __hip_atomic_store(p.ctl + kCtlErr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *p.h_err = 1 + (int)((unsigned)(4 * j) / (p.count ? p.count : 1u));
+            }
+        }
+    }
+    v4f v;
+    v.x = __uint_as_float(a.x);
+    v.y = __uint_as_float(a.z);
+    v.z = __uint_as_float(b.x);
+    v.w = __uint_as_float(b.z);
+    return v;
+}
+
+template <int PRO, int XC>
+__device__ __forceinline__ void xload_issue_ll(const LLPoll &p, const float *__restrict__ rms_w,
+                                               int n4, v4u (&xl)[2 * XC], v4f (&gr)[XC])
+{
+    const v4f *g4 = (const v4f *)rms_w;
+#pragma unroll
+    for (int k = 0; k < XC; k++) {
+        const int j = threadIdx.x + kBlock * k;
+        const int jc = j < n4 ? j : 0;  // past the end: any valid words, the value is dropped below
+        xl[2 * k] = ll_load2(p.slot, (size_t)4 * jc);
+        xl[2 * k + 1] = ll_load2(p.slot, (size_t)4 * jc + 2);
+    }
+    if (PRO == PRO_RMS) {
+#pragma unroll
+        for (int k = 0; k < XC; k++) {
+            const int j = threadIdx.x + kBlock * k;
+            gr[k] = (j < n4) ? g4[j] : v4f{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+
+template <int PRO, int XC>
+__device__ __forceinline__ void xstage_finish_ll(const LLPoll &p, const float *__restrict__ rms_w,
+                                                 int n, int n4_pad, v4u (&xl)[2 * XC],
+                                                 v4f (&gr)[XC], float *xs, float *scratch)
+{
+    const int n4 = n >> 2;
+    v4f xr[XC];
+#pragma unroll
+    for (int k = 0; k < XC; k++) {
+        const int j = threadIdx.x + kBlock * k;
+        const v4f v = ll_wait4(p, j < n4 ? j : 0, xl[2 * k], xl[2 * k + 1]);
+        xr[k] = (j < n4) ? v : v4f{0.f, 0.f, 0.f, 0.f};
+    }
+    xstage_tail<PRO, XC>(rms_w, n, n4_pad, xr, gr, xs, scratch, [&](int j) {
+        return ll_wait4(p, j, ll_load2(p.slot, (size_t)4 * j), ll_load2(p.slot, (size_t)4 * j + 2));
+    });
 }
 
 // in-place softmax over att[0..T)  (main.zig:687-706)

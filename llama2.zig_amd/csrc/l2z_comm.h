@@ -1,9 +1,16 @@
-// l2z_comm.h -- shard group object shared by comm.cpp and the host sources (l2z_state.h)
+// l2z_comm.h -- shard group object shared by comm.cpp and the host sources (l2z_state.h), and the
+// device side of the peer-write ("LL") all-gather: protocol in p2p.hip.
 #pragma once
 #include "l2z_internal.h"
 
 constexpr int kMaxWorld = 16;
 constexpr size_t kP2pFlagBytes = 4096;  // reserved head of every arena
+
+// ints of l2z_comm::d_ctl (device memory, shared by every runstate of the group)
+constexpr int kCtlEpoch = 0;  // epochs used up by completed passes: gather gi of the running pass is ctl[0] + gi
+constexpr int kCtlDone = 1;   // blocks of the pass-closing gather that have finished
+constexpr int kCtlErr = 2;    // != 0 once a wait has timed out: later waits give up at once
+constexpr int kCtlInts = 8;
 
 struct l2z_comm {
     int rank;
@@ -11,50 +18,72 @@ struct l2z_comm {
     int device;
     void *nccl;  // ncclComm_t, null when world == 1 / peer-write only / emulated
     // ---- peer-write all-gather (comm.cpp, p2p.hip) ----
-    bool p2p = false;                 // connected: gathers go through peer stores + flags
+    bool p2p = false;                 // connected: gathers go through peer stores of LL words
     char *arena = nullptr;            // this rank's arena: reserved | landing slot 0 | landing slot 1
     size_t slot_floats = 0;           // 8-byte words per landing slot (>= the longest gathered vector)
     char *peer_arena[kMaxWorld] = {}; // every rank's arena mapped here ([rank] == arena)
-    int *d_epoch = nullptr;           // [kMaxWorld] gathers completed with peer p (device)
+    int *d_ctl = nullptr;             // [kCtlInts] epoch counter, arrival counter, error latch (device)
     int *h_err = nullptr;             // pinned host int: a wait timed out (peer died / desync)
 };
 
 namespace l2z {
-// In-place all-gather of `count_per_rank` floats per rank over buf[0 .. world*count).
+// In-place all-gather of `count_per_rank` floats per rank over buf[0 .. world*count) as its own
+// launch (RCCL, or the peer-write gather kernel).  gi = 1-based index of this gather in the
+// forward pass, n_gathers = gathers per pass; the peer-write form derives its epoch from them
+// and the pass-closing gather (gi == n_gathers) advances the group's epoch counter.
 // No-op for a null comm or world == 1.
-int comm_allgather_inplace(const l2z_comm *c, float *buf, size_t count_per_rank, hipStream_t st);
-// 0, or L2Z_ERR_COMM once a peer-write gather has timed out (checked after synchronising)
+int comm_allgather_inplace(const l2z_comm *c, float *buf, size_t count_per_rank, int gi, int n_gathers,
+                           bool pushed, hipStream_t st);
+// 0, or L2Z_ERR_COMM once a peer-write wait has timed out (checked after synchronising)
 int comm_check(const l2z_comm *c);
 
+// device-side description of one gathered vector (lives in device memory: l2z_runstate::d_push)
 struct P2pArgs {
     float *buf;
     size_t count;        // floats per rank
     int rank, world;
     size_t slot_floats;
     char *peer_arena[kMaxWorld];
-    int *epoch;
-    int *err;
+    int *ctl;            // l2z_comm::d_ctl
+    int *err;            // l2z_comm::h_err
     long long timeout_ticks;  // wall_clock64 ticks (100 MHz)
+    int self;            // 1: producers also write this rank's own landing slot (consumers read LL words)
 };
+
 // pushed: the producing kernel has already written this rank's words (MatvecArgs::push)
-hipError_t launch_p2p_allgather(const P2pArgs &a, hipStream_t st, bool pushed = false);
-bool comm_p2p_args(const l2z_comm *c, float *buf, size_t count_per_rank, P2pArgs *out);
-int comm_allgather_inplace_pushed(const l2z_comm *c, float *buf, size_t count_per_rank, hipStream_t st);
+hipError_t launch_p2p_allgather(const P2pArgs &a, int gi, int n_gathers, bool pushed, hipStream_t st);
+bool comm_p2p_args(const l2z_comm *c, float *buf, size_t count_per_rank, bool self, P2pArgs *out);
+LLIn comm_ll_in(const l2z_comm *c, int gi, size_t count_per_rank);
+// the peer-write transport is connected and not overridden by L2Z_COMM=rccl
+bool comm_uses_p2p(const l2z_comm *c);
 
 #ifdef __HIPCC__
-// LL word of gather `e` for element `idx` of the gathered vector, to every peer (one lane)
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+
+// LL word of gather epoch `e` for element `idx` of the gathered vector, to every peer (one lane);
+// with a->self also into this rank's own slot
 __device__ __forceinline__ void p2p_ll_push(const P2pArgs *a, int e, size_t idx, float v)
 {
     const unsigned long long w = ((unsigned long long)(unsigned)e << 32) | (unsigned long long)__float_as_uint(v);
-    const int world = a->world, rank = a->rank;
+    const int world = a->world, rank = a->rank, self = a->self;
     const size_t off = (size_t)(e & 1) * a->slot_floats + idx;
     for (int p = 0; p < world; p++) {
-        if (p == rank) continue;
+        if (p == rank && !self) continue;
         unsigned long long *dst = (unsigned long long *)(a->peer_arena[p] + kP2pFlagBytes) + off;
         __hip_atomic_store(dst, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
-// number of the gather this launch feeds (all peers are at the same count)
-__device__ __forceinline__ int p2p_ll_epoch(const P2pArgs *a) { return a->epoch[a->rank == 0 ? 1 : 0] + 1; }
+// epoch of gather `gi` of the pass that is running (every rank counts the same gathers)
+__device__ __forceinline__ int p2p_ll_epoch(const P2pArgs *a, int gi) { return a->ctl[kCtlEpoch] + gi; }
+
+// Two adjacent LL words (16 bytes) in one system-scope load.  Each 8-byte half validates itself
+// through its own epoch, so nothing is assumed about the two halves having been written together.
+__device__ __forceinline__ v4u ll_load2(const unsigned long long *slot_base, size_t word_idx)
+{
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned long long *>(slot_base), 0, 0x7ffffff0, 0x00020000);
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(word_idx * 8), 0, 17 /* sc0 sc1 */);
+}
+__device__ __forceinline__ bool ll_ready2(v4u w, unsigned e) { return w.y == e && w.w == e; }
 #endif
 }  // namespace l2z

@@ -11,10 +11,24 @@
 #include <vector>
 
 #include "../../include/llama2_hip.h"
+#include "../../include/llama2_hip_test.h"
 
 namespace l2z {
 
 struct P2pArgs;  // l2z_comm.h: device-side description of one peer-write gather
+
+// By value in a consumer's arguments (sharded runs, peer-write transport): where it finds its input
+// vector as LL words {value, epoch} -- this rank's own landing slots, filled by every rank's
+// producers (p2p.hip) -- instead of a plain buffer.  slots == null: plain buffer.
+struct LLIn {
+    const unsigned long long *slots;  // own arena + reserved head
+    unsigned slot_floats;
+    unsigned count;       // floats per rank (names the late peer when a wait times out)
+    int gi;               // index of the gather that fills it (epoch = ctl[0] + gi)
+    int *ctl;             // l2z_comm::d_ctl
+    int *h_err;           // l2z_comm::h_err
+    long long timeout_ticks;
+};
 
 void set_error(const char *fmt, ...);
 
@@ -54,6 +68,25 @@ enum Epilogue { EPI_STORE = 0, EPI_ROPE = 1, EPI_RESID = 2, EPI_SWIGLU = 3, EPI_
 
 constexpr int kMaxSeg = 3;
 
+// main.zig:715 argmax + main.zig:999-1000,1036 hand-over to the next step
+struct ArgmaxArgs {
+    const float *logits;
+    int vocab;
+    const float *part_val;   // if non-null: scan n_part (value, index) candidates instead
+    const int *part_idx;
+    int n_part;
+    int *token_ptr;          // in/out: current token
+    int *pos_ptr;            // in/out
+    const int *prompt;       // forced tokens (n_prompt)
+    const int *n_prompt_ptr;
+    int *out_tokens;         // out_tokens[pos] = next
+    int *argmax_out;         // plain argmax result
+    const float *tok_emb;    // (vocab, dim): next step's embedding row -> x
+    float *x;
+    int dim;
+    int advance;             // 1: greedy step (write token/pos/x), 0: argmax only
+};
+
 // One fused mat-vec launch: up to 3 row-major (rowsJ, n) matrices sharing x.
 // main.zig:530 matmul_fused(N) -- plus what the reference does right before
 // (rmsnorm, :305/:398/:426) and right after (RoPE+KV write :336-358, accum
@@ -80,8 +113,17 @@ struct MatvecArgs {
     // Sharded runs, peer-write transport: the writer lane also stores every output value as an LL
     // word {value, epoch} straight into the peers' landing slots (p2p.hip), so the values travel
     // while the rest of the launch still runs and the gather that follows only has to collect.
-    // Row kernel only (launch_matvec reports whether it was honoured).  Device memory; may be null.
+    // Vector kernels only (launch_matvec reports whether it was honoured).  Device memory; may be null.
     const P2pArgs *push;
+    const int *push_ctl;      // l2z_comm::d_ctl by value (saves a dependent load)
+    int push_gi;              // index of the gather the outputs belong to
+    // x is a gathered vector that is read as LL words from this rank's landing slot (xin.slots != null)
+    LLIn xin;
+    // EPI_ARGMAX, greedy step on one GPU: the block that finishes LAST reduces the per-block
+    // candidates and performs the loop hand-over itself (what argmax_kernel does as a separate
+    // launch otherwise).  fin_counter: one int, zero between launches.  null: no hand-over.
+    int *fin_counter;
+    ArgmaxArgs fin;
 };
 
 // main.zig:361-389: scores, softmax, att.V for the local heads of one layer
@@ -96,44 +138,40 @@ struct AttnArgs {
     int kv_mul;
     int seq_len;
     const P2pArgs *push;   // as in MatvecArgs, for xb (fast / split-combine kernels); may be null
+    const int *push_ctl;
+    int push_gi;
+    // one-block-per-head kernels: blocks past n_head_blocks (set by the launcher) read
+    // pf_floats floats at pf_ptr and drop them -- the next launch's weights, pulled into the
+    // on-die cache by CUs that would otherwise idle.  pf_ptr null / pf_blocks 0: none.
+    const float *pf_ptr;
+    size_t pf_floats;
+    int pf_blocks;
+    float *pf_sink;        // >= pf_blocks floats (never written in practice)
+    int n_head_blocks;
 };
 
-// main.zig:715 argmax + main.zig:999-1000,1036 hand-over to the next step
-struct ArgmaxArgs {
-    const float *logits;
-    int vocab;
-    const float *part_val;   // if non-null: scan n_part (value, index) candidates instead
-    const int *part_idx;
-    int n_part;
-    int *token_ptr;          // in/out: current token
-    int *pos_ptr;            // in/out
-    const int *prompt;       // forced tokens (n_prompt)
-    const int *n_prompt_ptr;
-    int *out_tokens;         // out_tokens[pos] = next
-    int *argmax_out;         // plain argmax result
-    const float *tok_emb;    // (vocab, dim): next step's embedding row -> x
-    float *x;
-    int dim;
-    int advance;             // 1: greedy step (write token/pos/x), 0: argmax only
-};
 
 // Launchers (matvec.hip, attention.hip, misc_kernels.hip).  All return a hipError_t from the launch.
 // pushed: set to whether a.push was honoured (row kernel only)
+// (a.push / a.xin are all-or-nothing: matvec_ll_supported tells beforehand whether they will be)
 hipError_t launch_matvec(const MatvecArgs &a, int pro, int epi, int max_blocks_per_cu, int n_cus,
                          hipStream_t st, int *out_grid = nullptr, bool *pushed = nullptr);
+// true if a launch with this width takes the vector kernels, which honour push and xin
+bool matvec_ll_supported(int n);
 // true if launch_attention / launch_attention_split will honour a.push (vector kernels only)
 bool attention_push_supported(const AttnArgs &a);
 int matvec_max_grid(int n_cus);
 bool matvec_vector_width(int n);
 // out: >= 8 * n_cus floats of scratch (never written in practice)
 hipError_t launch_stream_read(const float *p, size_t n_floats, float *out, int n_cus, hipStream_t st);  // upper bound of the grid launch_matvec picks
-hipError_t launch_attention(const AttnArgs &a, int n_heads_local, hipStream_t st);
+hipError_t launch_attention(const AttnArgs &a, int n_heads_local, hipStream_t st, int form = 0);
 // flash-decoding form: `nch` blocks per head + a combine launch (attention.hip)
 int attention_split_chunks(int n_heads_local, int n_cus);
 size_t attention_split_part_floats(int n_heads_local, int head_size, int nch);
 bool attention_split_supported(const AttnArgs &a);
+// arrivals: one int per local head, zero before the first launch (the kernel leaves them at zero)
 hipError_t launch_attention_split(const AttnArgs &a, int n_heads_local, int nch, float *part,
-                                  hipStream_t st);
+                                  int *arrivals, hipStream_t st);
 hipError_t launch_argmax(const ArgmaxArgs &a, hipStream_t st);
 hipError_t launch_set_state(int token, int pos, int *token_ptr, int *pos_ptr, const float *tok_emb,
                             float *x, int dim, hipStream_t st);

@@ -7,6 +7,7 @@
 
 #include "l2z_comm.h"
 #include "l2z_internal.h"
+#include "tunables.h"
 
 namespace l2z {
 
@@ -43,6 +44,7 @@ int current_device_for(const l2z_comm *comm);
 }  // namespace l2z
 
 struct l2z_weights {
+    uint64_t uid = 0;  // unique per object for the life of the process: keys a runstate's captured graphs
     l2z_config cfg;
     int shared;
     int device;
@@ -56,8 +58,9 @@ struct l2z_weights {
     const float *w1 = nullptr, *w2 = nullptr, *w3 = nullptr, *wcls = nullptr;
 };
 
-enum { KIND_QKV = 0, KIND_ATTN, KIND_WO, KIND_FFN13, KIND_FFN2, KIND_CLS, KIND_ARGMAX, KIND_COUNT };
-static const char *const kKindNames[KIND_COUNT] = {"qkv", "attn", "wo", "ffn13", "ffn2", "cls", "argmax"};
+enum { KIND_QKV = 0, KIND_ATTN, KIND_WO, KIND_FFN13, KIND_FFN2, KIND_CLS, KIND_ARGMAX, KIND_GATHER, KIND_COUNT };
+static const char *const kKindNames[KIND_COUNT] = {"qkv", "attn", "wo", "ffn13", "ffn2", "cls", "argmax", "gather"};
+static_assert(KIND_COUNT == L2Z_N_KINDS, "include/llama2_hip_test.h L2Z_N_KINDS");
 
 struct l2z_runstate {
     l2z_config cfg;
@@ -81,10 +84,14 @@ struct l2z_runstate {
     int *d_part_idx = nullptr;
     int n_part = 0;               // 0: argmax scans the logits instead
     float *d_attn_part = nullptr; // split attention: per (head, chunk) partials
+    int *d_fin_cnt = nullptr;     // classifier launch: blocks finished (zero between launches)
+    int *d_attn_cnt = nullptr;    // split attention: arrivals per local head (zero between launches)
+    float *d_pf_sink = nullptr;   // prefetch blocks' never-written sink (one float per CU)
     int attn_nch = 0;             // 0: one block per head at every position
     int attn_split_pos = 0;       // positions >= this use the split form (host picks the graph)
-    // graphs, keyed by the weights they were captured with
-    const l2z_weights *graph_w = nullptr;
+    // graphs, keyed by the uid of the weights they were captured with (a freed object's address
+    // is commonly handed to the next one)
+    uint64_t graph_w_uid = 0;
     hipGraphExec_t g_forward[2] = {nullptr, nullptr}, g_step[2] = {nullptr, nullptr};  // [split?]
     bool use_graphs = true;
     int host_pos = 0;   // next position the greedy loop will run
@@ -93,6 +100,10 @@ struct l2z_runstate {
     // peer-write transport: device copies of the four gathers' descriptions (xb, x, hb, logits) for
     // the kernels that push their outputs to the peers themselves (MatvecArgs::push)
     l2z::P2pArgs *d_push = nullptr;
+    int n_gathers = 0;        // gathers per forward pass at world > 1: 4 per layer + logits
+    bool ll_consume = false;  // peer-write transport, consumer side: mat-vecs read their gathered input
+                              // as LL words from the landing slot; no gather launch except the logits
+    bool fused_qkv_attn = false;  // small models: qkv + RoPE + KV write + attention in one launch
     int max_blocks = 0;
 };
 

@@ -91,7 +91,7 @@ __device__ __forceinline__ MvLocals mv_locals(const MatvecArgs &a)
     m.ps1 = (size_t)m.pos * (size_t)a.pos_stride1;
     m.ps2 = (size_t)m.pos * (size_t)a.pos_stride2;
     m.push = a.push;
-    m.push_e = m.push ? p2p_ll_epoch(m.push) : 0;
+    m.push_e = m.push ? a.push_ctl[kCtlEpoch] + a.push_gi : 0;
     m.push_base = m.push ? (size_t)m.push->rank * m.push->count : 0;
     return m;
 }
@@ -261,13 +261,91 @@ __device__ __forceinline__ void mv_consume(const v4f *xs4, int c0, const v4f (&w
     }
 }
 
+// EPI_ARGMAX tail, all threads of the block: thread 0 holds the block's candidate (bv, bi).  It is
+// published write-through; with a.fin_counter set, the block that arrives last (every other block
+// has then staged x and stored its logits and candidate) reduces the gridDim.x candidates with the
+// strict '>' / lowest-index rule of main.zig:715-726 and hands the loop over to the next step
+// (main.zig:999-1003, :1036, :295-296) -- the separate argmax launch of the step is gone.
+__device__ __forceinline__ void cls_finish(const MatvecArgs &a, float bv, int bi, float *scratch)
+{
+    int *flag = (int *)scratch + 16;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(a.part_val + blockIdx.x, bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.part_idx + blockIdx.x, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int last = 0;
+        if (a.fin_counter != nullptr) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // candidate (and this wave's logits) out
+            last = __hip_atomic_fetch_add(a.fin_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                   (int)gridDim.x - 1;
+            if (last) {
+                __hip_atomic_store(a.fin_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+        }
+        *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    const int tid = threadIdx.x;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = tid; i < (int)gridDim.x; i += kBlock) {
+        const float v = a.part_val[i];
+        const int id = a.part_idx[i];
+        if (id != 0x7fffffff && (idx == 0x7fffffff || v > best || (v == best && id < idx))) {
+            best = v;
+            idx = id;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (oi != 0x7fffffff && (idx == 0x7fffffff || ov > best || (ov == best && oi < idx))) {
+            best = ov;
+            idx = oi;
+        }
+    }
+    if ((tid & 63) == 0) {
+        scratch[tid >> 6] = best;
+        scratch[kWaves + (tid >> 6)] = __int_as_float(idx);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < kWaves; w++) {
+            const float ov = scratch[w];
+            const int oi = __float_as_int(scratch[kWaves + w]);
+            if (oi != 0x7fffffff && (idx == 0x7fffffff || ov > best || (ov == best && oi < idx))) {
+                best = ov;
+                idx = oi;
+            }
+        }
+        if (idx == 0x7fffffff) idx = 0;
+        const ArgmaxArgs &f = a.fin;
+        if (f.argmax_out) *f.argmax_out = idx;
+        int next = idx;
+        const int pos = *f.pos_ptr;
+        if (pos < *f.n_prompt_ptr) next = f.prompt[pos];  // :999-1000
+        f.out_tokens[pos] = next;
+        *f.token_ptr = next;                              // :1036
+        *f.pos_ptr = pos + 1;                             // :995
+        ((int *)scratch)[17] = next;
+    }
+    __syncthreads();
+    {   // next step's embedding row -> x (main.zig:295-296)
+        const int next = ((int *)scratch)[17];
+        const float *row = a.fin.tok_emb + (size_t)next * (size_t)a.fin.dim;
+        for (int i = tid; i < a.fin.dim; i += kBlock) a.fin.x[i] = row[i];
+    }
+}
+
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v)
 {
     return lanes_sum(v, LPR);
 }
 
-template <int PRO, int EPI, int LPR, int XC>
+template <int PRO, int EPI, int LPR, int XC, bool LL>
 __global__ __launch_bounds__(kBlock) void matvec_kernel(const MatvecArgs a)
 {
     using G = MvGeom<LPR>;
@@ -287,8 +365,15 @@ __global__ __launch_bounds__(kBlock) void matvec_kernel(const MatvecArgs a)
     const int ustride = gridDim.x * kWaves;
 
     // 1. issue x loads (they return first), 2. issue the first weight batch, 3. stage x
-    v4f xr[XC], gr[XC];
-    xload_issue<PRO, XC>(a.x, a.rms_w, n4, xr, gr);
+    v4f xr[LL ? 1 : XC], gr[XC];
+    v4u xl[LL ? 2 * XC : 2];
+    LLPoll poll;
+    if constexpr (LL) {
+        poll = ll_poll_init(a.xin);
+        xload_issue_ll<PRO, XC>(poll, a.rms_w, n4, xl, gr);
+    } else {
+        xload_issue<PRO, XC>(a.x, a.rms_w, n4, xr, gr);
+    }
     int u = blockIdx.x * kWaves + wave;
     const bool has_unit = u < n_units;
     const float *pa, *pb;
@@ -297,7 +382,10 @@ __global__ __launch_bounds__(kBlock) void matvec_kernel(const MatvecArgs a)
     EpiIn ein = epi_prefetch<EPI>(m, (has_unit ? u : 0) * RW + grp, cl == 0 && has_unit);
     EpiIn ein_next = ein;
     mv_load<LPR>(pa, pb, cl, 0, n4, wa, wb);
-    xstage_finish<PRO, XC>(a.x, a.rms_w, m.n, n4_pad, xr, gr, xs, scratch);
+    if constexpr (LL)
+        xstage_finish_ll<PRO, XC>(poll, a.rms_w, m.n, n4_pad, xl, gr, xs, scratch);
+    else
+        xstage_finish<PRO, XC>(a.x, a.rms_w, m.n, n4_pad, xr, gr, xs, scratch);
     if (EPI != EPI_ARGMAX && !has_unit) return;
 
     // flat loop over (unit, batch): consume the batch in registers, then immediately
@@ -356,9 +444,11 @@ __global__ __launch_bounds__(kBlock) void matvec_kernel(const MatvecArgs a)
             scratch[kWaves + wave] = __int_as_float(best_i);
         }
         __syncthreads();
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
         if (threadIdx.x == 0) {
-            float bv = scratch[0];
-            int bi = __float_as_int(scratch[kWaves]);
+            bv = scratch[0];
+            bi = __float_as_int(scratch[kWaves]);
             for (int w = 1; w < kWaves; w++) {
                 const float ov = scratch[w];
                 const int oi = __float_as_int(scratch[kWaves + w]);
@@ -366,9 +456,9 @@ __global__ __launch_bounds__(kBlock) void matvec_kernel(const MatvecArgs a)
                     bv = ov; bi = oi;
                 }
             }
-            a.part_val[blockIdx.x] = bv;
-            a.part_idx[blockIdx.x] = bi;
         }
+        __syncthreads();  // scratch is reused below
+        cls_finish(a, bv, bi, scratch);
     }
 }
 
@@ -381,7 +471,7 @@ __global__ __launch_bounds__(kBlock) void matvec_kernel(const MatvecArgs a)
 // t, t+256, ...; per-thread component accumulators, (x+y)+(z+w), wave xor-shuffle,
 // then the 4 wave partials are added in wave order.  Still a function of n only.
 // ---------------------------------------------------------------------------
-template <int PRO, int EPI, int XC>
+template <int PRO, int EPI, int XC, bool LL>
 __global__ __launch_bounds__(kBlock) void matvec_row_kernel(const MatvecArgs a)
 {
     constexpr int U = 4;
@@ -398,8 +488,15 @@ __global__ __launch_bounds__(kBlock) void matvec_row_kernel(const MatvecArgs a)
     const int n_units = m.n_pairs;
     const int ustride = gridDim.x;
 
-    v4f xr[XC], gr[XC];
-    xload_issue<PRO, XC>(a.x, a.rms_w, n4, xr, gr);
+    v4f xr[LL ? 1 : XC], gr[XC];
+    v4u xl[LL ? 2 * XC : 2];
+    LLPoll poll;
+    if constexpr (LL) {
+        poll = ll_poll_init(a.xin);
+        xload_issue_ll<PRO, XC>(poll, a.rms_w, n4, xl, gr);
+    } else {
+        xload_issue<PRO, XC>(a.x, a.rms_w, n4, xr, gr);
+    }
     int u = blockIdx.x;  // grid <= n_units
     const float *pa, *pb;
     pair_rows<EPI>(m, u, pa, pb);
@@ -417,7 +514,10 @@ __global__ __launch_bounds__(kBlock) void matvec_row_kernel(const MatvecArgs a)
     EpiIn ein = epi_prefetch<EPI>(m, u, tid == 0);
     EpiIn ein_next = ein;
     load(0);
-    xstage_finish<PRO, XC>(a.x, a.rms_w, m.n, n4_pad, xr, gr, xs, scratch);
+    if constexpr (LL)
+        xstage_finish_ll<PRO, XC>(poll, a.rms_w, m.n, n4_pad, xl, gr, xs, scratch);
+    else
+        xstage_finish<PRO, XC>(a.x, a.rms_w, m.n, n4_pad, xr, gr, xs, scratch);
 
     v4f acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
     float best_v = -INFINITY;
@@ -475,9 +575,9 @@ __global__ __launch_bounds__(kBlock) void matvec_row_kernel(const MatvecArgs a)
         u = u_next;
         b = b_next;
     }
-    if (EPI == EPI_ARGMAX && tid == 0) {  // units ascend within a block: first index kept
-        a.part_val[blockIdx.x] = best_v;
-        a.part_idx[blockIdx.x] = best_i;
+    if (EPI == EPI_ARGMAX) {  // units ascend within a block: thread 0 kept the first index
+        __syncthreads();
+        cls_finish(a, best_v, best_i, scratch);
     }
 }
 
@@ -516,54 +616,68 @@ struct MvLaunch {
     int lpr, u;
 };
 
-template <int PRO, int EPI, int LPR, int XC>
+template <int PRO, int EPI, int LPR, int XC, bool LL>
 MvLaunch mv_entry()
 {
-    return {reinterpret_cast<const void *>(&matvec_kernel<PRO, EPI, LPR, XC>), LPR, MvGeom<LPR>::U};
+    return {reinterpret_cast<const void *>(&matvec_kernel<PRO, EPI, LPR, XC, LL>), LPR, MvGeom<LPR>::U};
 }
 
-template <int PRO, int EPI>
+template <int PRO, int EPI, bool LL>
 MvLaunch mv_pick(int lpr, bool big_x)
 {
-    if (lpr == 8) return mv_entry<PRO, EPI, 8, 4>();
-    if (lpr == 16) return mv_entry<PRO, EPI, 16, 4>();
-    if (lpr == 32) return mv_entry<PRO, EPI, 32, 4>();
-    return big_x ? mv_entry<PRO, EPI, 64, 12>() : mv_entry<PRO, EPI, 64, 4>();
+    if (lpr == 8) return mv_entry<PRO, EPI, 8, 4, LL>();
+    if (lpr == 16) return mv_entry<PRO, EPI, 16, 4, LL>();
+    if (lpr == 32) return mv_entry<PRO, EPI, 32, 4, LL>();
+    return big_x ? mv_entry<PRO, EPI, 64, 12, LL>() : mv_entry<PRO, EPI, 64, 4, LL>();
 }
 
-template <int PRO, int EPI>
+template <int PRO, int EPI, bool LL>
 const void *mv_row_fn(bool big_x)
 {
-    return big_x ? reinterpret_cast<const void *>(&matvec_row_kernel<PRO, EPI, 12>)
-                 : reinterpret_cast<const void *>(&matvec_row_kernel<PRO, EPI, 4>);
+    return big_x ? reinterpret_cast<const void *>(&matvec_row_kernel<PRO, EPI, 12, LL>)
+                 : reinterpret_cast<const void *>(&matvec_row_kernel<PRO, EPI, 4, LL>);
 }
 
-const void *mv_row_pick(int pro, int epi, bool big_x)
+// ll: x is read as LL words from the landing slot (sharded runs).  Only the (prologue, epilogue)
+// pairs the forward pass launches on a gathered vector exist in that form.
+const void *mv_row_pick(int pro, int epi, bool big_x, bool ll)
 {
-#define L2Z_MVR(P, E) if (pro == P && epi == E) return mv_row_fn<P, E>(big_x);
+#define L2Z_MVR(P, E) if (pro == P && epi == E && !ll) return mv_row_fn<P, E, false>(big_x);
+#define L2Z_MVR_LL(P, E) if (pro == P && epi == E && ll) return mv_row_fn<P, E, true>(big_x);
     L2Z_MVR(PRO_NONE, EPI_STORE)
     L2Z_MVR(PRO_NONE, EPI_RESID)
     L2Z_MVR(PRO_RMS, EPI_STORE)
     L2Z_MVR(PRO_RMS, EPI_ROPE)
     L2Z_MVR(PRO_RMS, EPI_SWIGLU)
     L2Z_MVR(PRO_RMS, EPI_ARGMAX)
+    L2Z_MVR_LL(PRO_NONE, EPI_RESID)
+    L2Z_MVR_LL(PRO_RMS, EPI_STORE)
+    L2Z_MVR_LL(PRO_RMS, EPI_ROPE)
+    L2Z_MVR_LL(PRO_RMS, EPI_SWIGLU)
 #undef L2Z_MVR
+#undef L2Z_MVR_LL
     return nullptr;
 }
 
-MvLaunch mv_pick_pe(int pro, int epi, int lpr, bool big_x, bool vec)
+MvLaunch mv_pick_pe(int pro, int epi, int lpr, bool big_x, bool vec, bool ll)
 {
 #define L2Z_MV(P, E)                                                                      \
-    if (pro == P && epi == E)                                                             \
-        return vec ? mv_pick<P, E>(lpr, big_x)                                            \
+    if (pro == P && epi == E && !ll)                                                      \
+        return vec ? mv_pick<P, E, false>(lpr, big_x)                                     \
                    : MvLaunch{reinterpret_cast<const void *>(&matvec_scalar_kernel<P, E>), 0, 0};
+#define L2Z_MV_LL(P, E) if (pro == P && epi == E && ll && vec) return mv_pick<P, E, true>(lpr, big_x);
     L2Z_MV(PRO_NONE, EPI_STORE)
     L2Z_MV(PRO_NONE, EPI_RESID)
     L2Z_MV(PRO_RMS, EPI_STORE)
     L2Z_MV(PRO_RMS, EPI_ROPE)
     L2Z_MV(PRO_RMS, EPI_SWIGLU)
+    L2Z_MV_LL(PRO_NONE, EPI_RESID)
+    L2Z_MV_LL(PRO_RMS, EPI_STORE)
+    L2Z_MV_LL(PRO_RMS, EPI_ROPE)
+    L2Z_MV_LL(PRO_RMS, EPI_SWIGLU)
 #undef L2Z_MV
-    if (pro == PRO_RMS && epi == EPI_ARGMAX && vec) return mv_pick<PRO_RMS, EPI_ARGMAX>(lpr, big_x);
+#undef L2Z_MV_LL
+    if (pro == PRO_RMS && epi == EPI_ARGMAX && vec && !ll) return mv_pick<PRO_RMS, EPI_ARGMAX, false>(lpr, big_x);
     return {nullptr, 0, 0};
 }
 
@@ -603,6 +717,9 @@ bool matvec_vector_width(int n)
     return !(lpr_for(n4) == 64 && (n4 % 64) != 0);
 }
 
+// vector kernels (16-byte aligned operands assumed: every buffer here is a hipMalloc or a row of one)
+bool matvec_ll_supported(int n) { return matvec_vector_width(n); }
+
 hipError_t launch_stream_read(const float *p, size_t n_floats, float *out, int n_cus, hipStream_t st)
 {
     hipLaunchKernelGGL(stream_read_kernel, dim3(n_cus * 8), dim3(256), 0, st, (const v4f *)p, n_floats / 4, out);
@@ -626,10 +743,12 @@ hipError_t launch_matvec(const MatvecArgs &a_in, int pro, int epi, int max_block
     const int lpr = lpr_for(n4);
     if (lpr == 64 && (n4 % 64) != 0) vec = false;  // rare odd widths: generic scalar kernel
     if (epi == EPI_ARGMAX && (!vec || a.rows1 != 0 || a.rows2 != 0)) return hipErrorNotSupported;
-    static const int row_mode = getenv("L2Z_ROW_KERNEL") ? atoi(getenv("L2Z_ROW_KERNEL")) : 1;
-    const bool use_row = vec && row_mode && n4 >= 1024 && (n4 % 64) == 0;
-    MvLaunch k = mv_pick_pe(pro, epi, lpr, a.n > 4096, vec);
-    if (use_row) k.fn = mv_row_pick(pro, epi, a.n > 4096);
+    const Tunables &tn = tunables();
+    const bool use_row = vec && tn.row_kernel && n4 >= 1024 && (n4 % 64) == 0;
+    const bool ll = a.xin.slots != nullptr;
+    if (ll && !vec) return hipErrorNotSupported;  // callers ask matvec_ll_supported() first
+    MvLaunch k = mv_pick_pe(pro, epi, lpr, a.n > 4096, vec, ll);
+    if (use_row) k.fn = mv_row_pick(pro, epi, a.n > 4096, ll);
     if (k.fn == nullptr) return hipErrorInvalidValue;
     size_t lds;
     int n_units;
@@ -662,9 +781,11 @@ hipError_t launch_matvec(const MatvecArgs &a_in, int pro, int epi, int max_block
     // streams).  Measured at 7B, whole-token rate: 2 blocks/CU 219 tok/s, 1 -> 208, 3 -> 213,
     // 4-8 -> 208-211 (single launches shift against each other under the power cap, so the
     // choice is made on the whole-token rate).  L2Z_ROW_BLOCKS overrides.
-    static const int row_blocks = getenv("L2Z_ROW_BLOCKS") ? atoi(getenv("L2Z_ROW_BLOCKS")) : 2;
-    if (use_row && occ > row_blocks) occ = row_blocks;
-    const int resident = occ * n_cus;
+    if (use_row && occ > tn.row_blocks) occ = tn.row_blocks;
+    int resident = occ * n_cus;
+    // several ranks sharing ONE GPU (tests): a launch must leave room for the peers' kernels it
+    // may be waiting for
+    if (tn.grid_cap > 0 && resident > tn.grid_cap) resident = tn.grid_cap;
     int grid;
     if (use_row) {  // a unit per block at a time
         grid = n_units;
@@ -681,8 +802,8 @@ hipError_t launch_matvec(const MatvecArgs &a_in, int pro, int epi, int max_block
         }
     }
     if (out_grid) *out_grid = grid;
-    // only the row kernel's single-segment epilogues push (wo, ffn13, ffn2, classifier)
-    if (!use_row || epi == EPI_ROPE || a.rows2 != 0 || (epi != EPI_SWIGLU && a.rows1 != 0)) a.push = nullptr;
+    // only single-segment epilogues of the vector kernels push (wo, ffn13, ffn2, classifier)
+    if (!vec || epi == EPI_ROPE || a.rows2 != 0 || (epi != EPI_SWIGLU && a.rows1 != 0)) a.push = nullptr;
     if (pushed) *pushed = a.push != nullptr;
     void *args[] = {&a};
     return hipLaunchKernel(k.fn, dim3(grid), dim3(kBlock), args, lds, st);

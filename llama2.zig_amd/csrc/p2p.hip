@@ -4,19 +4,36 @@
 //   (4 KB reserved) | landing slot 0 | landing slot 1     slot = 8 bytes per float of the longest
 //                                                          gathered vector
 // "LL" form: a float travels as ONE 8-byte word {value bits, epoch}, written with a single relaxed
-// system-scope atomic store and read with a relaxed system-scope atomic load.  An 8-byte access is
-// atomic, so the receiver either sees the old word or the complete new one: no fence, no separate
-// flag, no assumption about the order in which different stores arrive -- and none of the L2
-// write-backs / invalidates a release / acquire pair costs on this part (per-XCD L2s).
-// One launch gathers one vector.  Block p of rank r talks to peer p only:
-//   1. writes {slice[i], e} for r's slice into p's slot (at r's offset), e = number of this gather
-//      between r and p;
-//   2. polls p's slice in its OWN slot until every word carries e, copying the values into the
-//      ordinary (cached) activation buffer.
-// No block waits for another block of the same launch, so nothing here can deadlock on
-// scheduling; a peer that never arrives trips the timeout, sets *err and lets the kernel end.
-// Slots alternate with e: a rank can only be writing gather g+2 (same slot as g) after it has
-// received every peer's words of g+1, which a peer writes only after it finished reading gather g.
+// system-scope atomic store and read with a system-scope load.  An 8-byte access is atomic, so the
+// receiver either sees the old word or the complete new one: no fence, no separate flag, no
+// assumption about the order in which different stores arrive -- and none of the L2 write-backs /
+// invalidates a release / acquire pair costs on this part (per-XCD L2s).
+//
+// Epochs.  Every rank runs the same sequence of forward passes, each with the same n gathers, so
+// gather gi (1-based) of the running pass has epoch  ctl[kCtlEpoch] + gi  on every rank; the
+// pass-closing gather (gi == n: the logits) adds n to the counter once all its blocks are done.
+// Epochs are consecutive, and a gather lands in slot (epoch & 1).
+//
+// Who writes: the PRODUCING kernel -- the writer lane of a mat-vec epilogue or of the attention
+// output stage stores {value, epoch} for each of its outputs straight into every peer's slot
+// (p2p_ll_push), so the values travel while the launch is still running.  (A producer that cannot
+// push leaves it to the gather launch below.)
+// Who reads, two forms:
+//   * consumer-side (default, P2pArgs::self = 1): the producers also store into their OWN slot, and
+//     the next mat-vec reads its whole input vector as LL words out of this rank's slot while it
+//     stages x in LDS (kernel_common.h xload_issue_ll / xstage_finish_ll), re-reading until every
+//     word carries the epoch.  No gather launch at all: a layer stays 5 graph nodes at any N.  Only
+//     the logits are collected by a launch (the host and argmax read them as a plain buffer).
+//   * gather launch (L2Z_P2P_CONSUME=0, or shapes only the scalar kernels take): one launch per
+//     gathered vector; block p polls peer p's slice in this rank's slot and copies the values into
+//     the ordinary (cached) activation buffer the consumer then reads.
+// Slot reuse is safe with two slots in both forms: a rank writes gather g+2 (same slot as g) only
+// from a kernel that has read ALL of gather g+1, and a peer's g+1 words are all there only after
+// every block of the peer's kernel that read g has finished reading it (each consumer block is
+// also a producer of the next gather, and it produces after it has staged its input).
+// No block waits for another block of the same launch, so nothing here can deadlock on scheduling;
+// a peer that never arrives trips the timeout, latches ctl[kCtlErr] (every later wait gives up at
+// once), sets *err for the host and lets the kernel end.
 // The gathered values are bit copies -- results stay identical to the unsharded pass.
 #include <hip/hip_runtime.h>
 
@@ -32,31 +49,30 @@ __device__ __forceinline__ u64 *slot_words(char *arena, int e, size_t slot_float
     return (u64 *)(arena + kP2pFlagBytes) + (size_t)(e & 1) * slot_floats;
 }
 
-__global__ __launch_bounds__(256) void p2p_allgather_kernel(const P2pArgs a, int pushed)
+__global__ __launch_bounds__(256) void p2p_allgather_kernel(const P2pArgs a, int gi, int n_gathers,
+                                                            int pushed)
 {
     const int p = blockIdx.x;
-    if (p == a.rank) return;  // own slice is already in place
-    __shared__ int s_epoch, s_timeout;
-    if (threadIdx.x == 0) {
-        s_epoch = a.epoch[p] + 1;
-        s_timeout = 0;
-    }
+    __shared__ int s_timeout;
+    if (threadIdx.x == 0) s_timeout = 0;
+    const int e = a.ctl[kCtlEpoch] + gi;
+    const bool dead = __hip_atomic_load(a.ctl + kCtlErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     __syncthreads();
-    const int e = s_epoch;
     const u64 tag = (u64)(unsigned)e << 32;
-    // 1. my slice -> peer p's slot (unless the producing kernel wrote the words itself)
-    if (!pushed) {
-        u64 *dst = slot_words(a.peer_arena[p], e, a.slot_floats) + (size_t)a.rank * a.count;
-        const float *src = a.buf + (size_t)a.rank * a.count;
-        for (size_t i = threadIdx.x; i < a.count; i += blockDim.x)
-            __hip_atomic_store(dst + i, tag | (u64)__float_as_uint(src[i]), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    // 2. peer p's slice <- my slot: up to 4 words per lane in flight, re-polled until all carry e
-    {
+    if (p != a.rank && !dead) {  // own slice is already in place
+        // 1. my slice -> peer p's slot (unless the producing kernel wrote the words itself)
+        if (!pushed) {
+            u64 *dst = slot_words(a.peer_arena[p], e, a.slot_floats) + (size_t)a.rank * a.count;
+            const float *src = a.buf + (size_t)a.rank * a.count;
+            for (size_t i = threadIdx.x; i < a.count; i += blockDim.x)
+                __hip_atomic_store(dst + i, tag | (u64)__float_as_uint(src[i]), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        // 2. peer p's slice <- my slot: up to 4 words per lane in flight, re-polled until all carry e
         const u64 *src = slot_words(a.peer_arena[a.rank], e, a.slot_floats) + (size_t)p * a.count;
         float *dst = a.buf + (size_t)p * a.count;
         const long long t0 = wall_clock64();
+        bool give_up = false;
         for (size_t base = threadIdx.x; base < a.count; base += 4 * (size_t)blockDim.x) {
             u64 w[4];
             bool ready;
@@ -70,7 +86,8 @@ __global__ __launch_bounds__(256) void p2p_allgather_kernel(const P2pArgs a, int
                 }
 #pragma unroll
                 for (int k = 0; k < 4; k++) ready = ready && (unsigned)(w[k] >> 32) == (unsigned)e;
-                if (!ready && wall_clock64() - t0 > a.timeout_ticks) {
+                if (!ready && (give_up || wall_clock64() - t0 > a.timeout_ticks)) {
+                    give_up = true;
                     s_timeout = 1;
                     break;
                 }
@@ -84,16 +101,26 @@ __global__ __launch_bounds__(256) void p2p_allgather_kernel(const P2pArgs a, int
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        a.epoch[p] = e;
-        if (s_timeout) *a.err = 1 + p;
+        if (s_timeout) {
+            __hip_atomic_store(a.ctl + kCtlErr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *a.err = 1 + p;
+        }
+        // the pass-closing gather advances the epoch counter once every block has read it
+        if (gi == n_gathers &&
+            __hip_atomic_fetch_add(a.ctl + kCtlDone, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                (int)gridDim.x - 1) {
+            __hip_atomic_store(a.ctl + kCtlDone, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.ctl + kCtlEpoch, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
 }  // namespace
 
-hipError_t launch_p2p_allgather(const P2pArgs &a, hipStream_t st, bool pushed)
+hipError_t launch_p2p_allgather(const P2pArgs &a, int gi, int n_gathers, bool pushed, hipStream_t st)
 {
-    hipLaunchKernelGGL(p2p_allgather_kernel, dim3(a.world), dim3(256), 0, st, a, pushed ? 1 : 0);
+    hipLaunchKernelGGL(p2p_allgather_kernel, dim3(a.world), dim3(256), 0, st, a, gi, n_gathers,
+                       pushed ? 1 : 0);
     return hipGetLastError();
 }
 

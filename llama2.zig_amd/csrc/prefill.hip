@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "l2z_internal.h"
+#include "tunables.h"
 
 namespace l2z {
 namespace {
@@ -688,7 +689,7 @@ hipError_t gemm_launch_t(const GemmArgs &a, hipStream_t st)
 template <int EPI, int TMS>
 hipError_t skinny_launch_t(const GemmArgs &a, hipStream_t st)
 {
-    static const int form = getenv("L2Z_PF_SKINNY_FORM") ? atoi(getenv("L2Z_PF_SKINNY_FORM")) : 1;
+    const int form = tunables().pf_skinny_form;
     dim3 grid((a.N + 15) / 16, (a.P + 16 * TMS - 1) / (16 * TMS));
     // LDS-staged form (1-KB row reads): 5-8 % ahead at 16-32 tokens on the 7B shape, level at 8,
     // behind at 64 (83 KB of LDS, one block per CU) -- so only up to two token tiles
@@ -714,13 +715,10 @@ hipError_t skinny_launch_t(const GemmArgs &a, hipStream_t st)
 template <int EPI>
 hipError_t gemm_launch(const GemmArgs &a, hipStream_t st)
 {
-    static int tile = -1, skinny_max = 64, skinny_tms = 4;
-    if (tile < 0) {
-        const char *e = getenv("L2Z_PF_TILE");
-        tile = e ? atoi(e) : 0;
-        if (const char *m = getenv("L2Z_PF_SKINNY_MAX")) skinny_max = atoi(m);
-        if (const char *m = getenv("L2Z_PF_SKINNY_TMS")) skinny_tms = atoi(m);
-    }
+    const Tunables &tn = tunables();
+    const int tile = tn.pf_tile;
+    const int skinny_max = tn.pf_skinny_max >= 0 ? tn.pf_skinny_max : 64;
+    const int skinny_tms = tn.pf_skinny_tms > 0 ? tn.pf_skinny_tms : 4;
     if (a.P <= skinny_max) {
         // a matrix that stays in the on-die caches is cheapest re-read per 16 tokens (more blocks,
         // more waves per CU); one that streams from HBM is read once, tokens tiled in registers
@@ -783,7 +781,7 @@ hipError_t launch_prefill_attention(const float *q, int ldq, const float *kcache
                                     float *out, int ldo, int pos0, int P, int n_heads, int head_size,
                                     int kv_dim, int kv_mul, int seq_len, hipStream_t st)
 {
-    static const bool naive = getenv("L2Z_PF_ATTN") && atoi(getenv("L2Z_PF_ATTN")) == 0;
+    const bool naive = tunables().pf_attn == 0;
     const size_t lds_t = (size_t)(3 * 64 * (head_size + 1) + 64 * 65 + 3 * 64) * sizeof(float);
     const int n_ct = (head_size + 31) / 32;  // O column tiles; 2 n_ct tiles over 4 waves
     // one block per (head, 64 queries): worth it once that fills half the CUs (7B: from 256 tokens);

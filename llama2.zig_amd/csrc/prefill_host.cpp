@@ -17,13 +17,9 @@ using namespace l2z;
 namespace {
 static int prefill_chunk_tokens()
 {
-    static int n = 0;
-    if (n == 0) {
-        const char *e = getenv("L2Z_PF_CHUNK");
-        n = e ? atoi(e) : 512;
-        if (n < 16) n = 16;
-        if (n > 2048) n = 2048;
-    }
+    int n = tunables().pf_chunk > 0 ? tunables().pf_chunk : 512;
+    if (n < 16) n = 16;
+    if (n > 2048) n = 2048;
     return n;
 }
 #define kPrefillChunk prefill_chunk_tokens()
@@ -88,12 +84,7 @@ namespace l2z {
 
 bool prefill_enabled()
 {
-    static int on = -1;
-    if (on < 0) {
-        const char *e = getenv("L2Z_PREFILL");
-        on = (e && atoi(e) == 0) ? 0 : 1;
-    }
-    return on == 1;
+    return tunables().prefill != 0;
 }
 
 int prefill_check(const l2z_config *config, const l2z_runstate *s)

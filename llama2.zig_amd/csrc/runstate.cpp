@@ -33,20 +33,25 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
     s->device = dev;
     s->sh = sh;
     s->comm = comm;
-    s->max_blocks = 8;  // per CU; the launcher also caps at the occupancy query
-    if (const char *e = getenv("L2Z_MAX_BLOCKS_PER_CU")) {
-        const int v = atoi(e);
-        if (v > 0) s->max_blocks = v;
-    }
-    if (const char *e = getenv("L2Z_NO_GRAPH")) s->use_graphs = atoi(e) == 0;
-    // Peer-write gathers are plain kernels: captured with the rest of the step.  With RCCL only,
-    // the launches and collectives go out eagerly by default (multi-rank capture of RCCL calls
-    // could not be exercised on the 1-GPU dev box); L2Z_COMM_GRAPH=1 captures them too (works
-    // with a 1-rank communicator).  Emulated ranks are driven stage by stage, never captured.
+    const Tunables &tn = tunables();
+    s->max_blocks = tn.max_blocks_per_cu;  // per CU; the launcher also caps at the occupancy query
+    s->use_graphs = tn.no_graph == 0;
+    // Peer-write gathers are plain kernels (or no launch at all): captured with the rest of the
+    // step.  RCCL collectives are captured too (stream capture of ncclAllGather; if the capture
+    // fails the step is launched eagerly, ensure_graphs); L2Z_COMM_GRAPH=0 keeps them eager.
+    // Emulated ranks are driven stage by stage, never captured.
     if (comm && comm->world > 1 && !comm->nccl && !comm->p2p) s->use_graphs = false;
-    if (comm && comm->nccl && !comm->p2p) {
-        const char *e = getenv("L2Z_COMM_GRAPH");
-        s->use_graphs = e && atoi(e) == 1;
+    if (comm && comm->nccl && !comm_uses_p2p(comm) && tn.comm_graph == 0) s->use_graphs = false;
+    s->n_gathers = 4 * c.n_layers + 1;
+    if (comm_uses_p2p(comm)) {
+        // the producers store straight into the peers' landing slots: they must hold the longest vector
+        const size_t longest = (size_t)std::max(std::max(c.dim, c.hidden_dim), c.vocab_size);
+        if (comm->slot_floats < longest) {
+            set_error("peer-write landing slots hold %zu floats, this config gathers up to %zu: pass "
+                      "max(dim, hidden_dim, vocab_size) to l2z_comm_p2p_export", comm->slot_floats, longest);
+            delete s;
+            return L2Z_ERR_COMM;
+        }
     }
 
     const size_t kv = (size_t)c.n_layers * c.seq_len * sh.kvd_loc;
@@ -71,32 +76,41 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
     alloc((void **)&s->d_out_tokens, (size_t)c.seq_len * 4);
     alloc((void **)&s->d_part_val, (size_t)matvec_max_grid(g_cus) * 4);
     alloc((void **)&s->d_part_idx, (size_t)matvec_max_grid(g_cus) * 4);
+    alloc((void **)&s->d_fin_cnt, 4);
     {   // Attention form by position.  One block per head is fastest while the
         // context is short; from pos 256 on, the split form (nch blocks per head + combine)
         // wins and keeps winning (2.4x at pos 2047 on the 7B shape).  The host knows pos, so it
-        // replays one of two captured graphs.  L2Z_ATTN_SPLIT: 0 = never, n = n chunks at every
-        // position (tests); L2Z_ATTN_SPLIT_POS moves the switch-over.
-        const char *ev = getenv("L2Z_ATTN_SPLIT");
-        const int mode = ev ? atoi(ev) : -1;
+        // replays one of two captured graphs.  Tunables attn_split: 0 = never, n = n chunks at every
+        // position (tests); attn_split_pos moves the switch-over.
+        const int mode = tn.attn_split;
         // The chunk count is part of the arithmetic (the combine rounds per chunk), so it is taken
         // from the model's TOTAL head count, not this rank's share: sharded and unsharded runs then
         // use the same chunks and stay bit-identical beyond pos 256 as well.
         int nch = mode > 0 ? mode : attention_split_chunks(c.n_heads, g_cus);
         if (nch > 16) nch = 16;
         s->attn_split_pos = mode > 0 ? 0 : 256;
-        if (const char *ep = getenv("L2Z_ATTN_SPLIT_POS")) s->attn_split_pos = atoi(ep);
+        if (tn.attn_split_pos >= 0) s->attn_split_pos = tn.attn_split_pos;
         if (mode == 0 || c.seq_len <= s->attn_split_pos) nch = 0;
         if (nch > 1) {
             s->attn_nch = nch;
             alloc((void **)&s->d_attn_part, attention_split_part_floats(sh.heads_loc, sh.hs, nch) * 4);
+            alloc((void **)&s->d_attn_cnt, (size_t)sh.heads_loc * 4);
         }
+        alloc((void **)&s->d_pf_sink, (size_t)(g_cus > 0 ? g_cus : 256) * 4);
     }
-    if (comm && comm->p2p && comm->world > 1) {
+    if (comm_uses_p2p(comm) && e == hipSuccess) {
+        // consumer-side gathers need every producer to push and every consumer to read LL words:
+        // the vector mat-vec kernels and the vector attention kernels
+        AttnArgs aa = {};
+        aa.q = s->q; aa.kcache = s->key_cache; aa.vcache = s->value_cache;
+        aa.head_size = sh.hs; aa.kv_dim = sh.kvd_loc;
+        s->ll_consume = tn.p2p_push && tn.p2p_consume && matvec_ll_supported(c.dim) &&
+                        matvec_ll_supported(c.hidden_dim) && attention_push_supported(aa);
         P2pArgs t[4];
-        comm_p2p_args(comm, s->xb, (size_t)sh.dim_loc, &t[0]);
-        comm_p2p_args(comm, s->x, (size_t)sh.dim_loc, &t[1]);
-        comm_p2p_args(comm, s->hb, (size_t)sh.hid_loc, &t[2]);
-        comm_p2p_args(comm, s->logits, (size_t)sh.v_loc, &t[3]);
+        comm_p2p_args(comm, s->xb, (size_t)sh.dim_loc, s->ll_consume, &t[0]);
+        comm_p2p_args(comm, s->x, (size_t)sh.dim_loc, s->ll_consume, &t[1]);
+        comm_p2p_args(comm, s->hb, (size_t)sh.hid_loc, s->ll_consume, &t[2]);
+        comm_p2p_args(comm, s->logits, (size_t)sh.v_loc, false, &t[3]);
         alloc((void **)&s->d_push, sizeof t);
         if (e == hipSuccess) e = hipMemcpy(s->d_push, t, sizeof t, hipMemcpyHostToDevice);
     }
@@ -142,7 +156,7 @@ extern "C" void l2z_runstate_free(l2z_runstate *s)
     }
     void *ptrs[] = {s->x, s->xb, s->hb, s->q, s->logits, s->key_cache, s->value_cache, s->rope,
                     s->d_token, s->d_pos, s->d_prompt, s->d_n_prompt, s->d_out_tokens, s->d_argmax,
-                    s->d_part_val, s->d_part_idx, s->d_attn_part, s->pf_x, s->pf_xn, s->pf_q,
+                    s->d_part_val, s->d_part_idx, s->d_fin_cnt, s->d_attn_part, s->d_attn_cnt, s->d_pf_sink, s->pf_x, s->pf_xn, s->pf_q,
                     s->pf_att, s->pf_h1, s->pf_tokens, s->d_push};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);

@@ -1,0 +1,90 @@
+// tunables.cpp -- the one place the environment is read (see tunables.h).
+#include "tunables.h"
+
+#include <cstdlib>
+#include <cstring>
+
+namespace l2z {
+namespace {
+
+void env_int(const char *name, int *v)
+{
+    if (const char *e = getenv(name))
+        if (*e) *v = atoi(e);
+}
+
+Tunables read_env()
+{
+    Tunables t;
+    env_int("L2Z_ROW_KERNEL", &t.row_kernel);
+    env_int("L2Z_ROW_BLOCKS", &t.row_blocks);
+    env_int("L2Z_MAX_BLOCKS_PER_CU", &t.max_blocks_per_cu);
+    env_int("L2Z_GRID_CAP", &t.grid_cap);
+    env_int("L2Z_ATTN_BLOCK", &t.attn_block);
+    env_int("L2Z_ATTN_SPLIT", &t.attn_split);
+    env_int("L2Z_ATTN_SPLIT_POS", &t.attn_split_pos);
+    env_int("L2Z_ATTN_PREFETCH", &t.attn_prefetch);
+    env_int("L2Z_FUSE_SMALL", &t.fuse_small);
+    env_int("L2Z_CLS_HANDOVER", &t.cls_handover);
+    env_int("L2Z_NO_GRAPH", &t.no_graph);
+    env_int("L2Z_COMM_GRAPH", &t.comm_graph);
+    if (const char *e = getenv("L2Z_COMM")) t.prefer_rccl = strcmp(e, "rccl") == 0;
+    env_int("L2Z_P2P_PUSH", &t.p2p_push);
+    env_int("L2Z_P2P_CONSUME", &t.p2p_consume);
+    if (const char *e = getenv("L2Z_P2P_TIMEOUT_S"))
+        if (*e) t.p2p_timeout_s = atoll(e);
+    env_int("L2Z_PREFILL", &t.prefill);
+    env_int("L2Z_PF_CHUNK", &t.pf_chunk);
+    env_int("L2Z_PF_SKINNY_FORM", &t.pf_skinny_form);
+    env_int("L2Z_PF_TILE", &t.pf_tile);
+    env_int("L2Z_PF_SKINNY_MAX", &t.pf_skinny_max);
+    env_int("L2Z_PF_SKINNY_TMS", &t.pf_skinny_tms);
+    env_int("L2Z_PF_ATTN", &t.pf_attn);
+    env_int("L2Z_PF_FUSE", &t.pf_fuse);
+    env_int("L2Z_UPLOAD_PINNED", &t.upload_pinned);
+    if (t.row_blocks < 1) t.row_blocks = 1;
+    if (t.max_blocks_per_cu < 1) t.max_blocks_per_cu = 8;
+    return t;
+}
+
+}  // namespace
+
+namespace {
+Tunables &mutable_tunables()
+{
+    static Tunables t = read_env();
+    return t;
+}
+}  // namespace
+
+const Tunables &tunables() { return mutable_tunables(); }
+
+bool tunables_set(const char *name, long long v)
+{
+    Tunables &t = mutable_tunables();
+    struct { const char *n; int *p; } ints[] = {
+        {"L2Z_ROW_KERNEL", &t.row_kernel}, {"L2Z_ROW_BLOCKS", &t.row_blocks},
+        {"L2Z_MAX_BLOCKS_PER_CU", &t.max_blocks_per_cu}, {"L2Z_GRID_CAP", &t.grid_cap},
+        {"L2Z_ATTN_BLOCK", &t.attn_block}, {"L2Z_ATTN_SPLIT", &t.attn_split},
+        {"L2Z_ATTN_SPLIT_POS", &t.attn_split_pos}, {"L2Z_ATTN_PREFETCH", &t.attn_prefetch},
+        {"L2Z_FUSE_SMALL", &t.fuse_small}, {"L2Z_CLS_HANDOVER", &t.cls_handover}, {"L2Z_NO_GRAPH", &t.no_graph},
+        {"L2Z_COMM_GRAPH", &t.comm_graph}, {"L2Z_COMM_RCCL", &t.prefer_rccl},
+        {"L2Z_P2P_PUSH", &t.p2p_push}, {"L2Z_P2P_CONSUME", &t.p2p_consume},
+        {"L2Z_PREFILL", &t.prefill}, {"L2Z_PF_CHUNK", &t.pf_chunk},
+        {"L2Z_PF_SKINNY_FORM", &t.pf_skinny_form}, {"L2Z_PF_TILE", &t.pf_tile},
+        {"L2Z_PF_SKINNY_MAX", &t.pf_skinny_max}, {"L2Z_PF_SKINNY_TMS", &t.pf_skinny_tms},
+        {"L2Z_PF_ATTN", &t.pf_attn}, {"L2Z_PF_FUSE", &t.pf_fuse},
+        {"L2Z_UPLOAD_PINNED", &t.upload_pinned}};
+    for (auto &e : ints)
+        if (strcmp(e.n, name) == 0) {
+            *e.p = (int)v;
+            return true;
+        }
+    if (strcmp(name, "L2Z_P2P_TIMEOUT_S") == 0) {
+        t.p2p_timeout_s = v;
+        return true;
+    }
+    return false;
+}
+
+}  // namespace l2z

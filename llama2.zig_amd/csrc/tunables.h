@@ -1,0 +1,52 @@
+// tunables.h -- every environment knob of the library, read ONCE (first use) in one place.
+// None of them changes results except where noted; they exist for A/B measurements on the GPU box
+// (scripts/) and for the tests that put several ranks on one GPU.  Launch paths only
+// ever see this struct.
+#pragma once
+
+namespace l2z {
+
+struct Tunables {
+    // --- decode mat-vec (matvec.hip) ---
+    int row_kernel = 1;        // L2Z_ROW_KERNEL      0: wide rows take the per-wave kernel too
+    int row_blocks = 2;        // L2Z_ROW_BLOCKS      resident row-kernel blocks per CU
+    int max_blocks_per_cu = 8; // L2Z_MAX_BLOCKS_PER_CU
+    int grid_cap = 0;          // L2Z_GRID_CAP        max blocks of one mat-vec launch (0: none); set when
+                               //                     several ranks share one GPU so that a kernel
+                               //                     waiting for a peer leaves the peer room to run
+    // --- decode attention (attention.hip, runstate.cpp) ---
+    int attn_block = 0;        // L2Z_ATTN_BLOCK      force the one-block-per-head kernel's block size
+    int attn_split = -1;       // L2Z_ATTN_SPLIT      0: never split; n > 0: n chunks at every position
+                               //                     (changes rounding: chunk count is part of the arithmetic)
+    int attn_split_pos = -1;   // L2Z_ATTN_SPLIT_POS  first position that uses the split form (default 256)
+    int attn_prefetch = 100;   // L2Z_ATTN_PREFETCH   % of wo the idle CUs of the short-context attention launch
+                               //                     pull into the on-die cache (0: none)
+    int cls_handover = 1;      // L2Z_CLS_HANDOVER    0: argmax + loop hand-over stay a separate launch
+    int fuse_small = 1;        // L2Z_FUSE_SMALL      0: small models keep separate qkv / attention launches
+    // --- graphs / transport (runstate.cpp, comm.cpp, forward.cpp) ---
+    int no_graph = 0;          // L2Z_NO_GRAPH        1: launch eagerly
+    int comm_graph = 1;        // L2Z_COMM_GRAPH      0: RCCL collectives are launched eagerly, not captured
+    int prefer_rccl = 0;       // L2Z_COMM=rccl       use RCCL even when the peer-write transport is connected
+    int p2p_push = 1;          // L2Z_P2P_PUSH        0: producers do not push, the gather launch sends
+    int p2p_consume = 1;       // L2Z_P2P_CONSUME     0: keep a gather launch per gathered vector (consumers
+                               //                     read plain buffers)
+    long long p2p_timeout_s = 20;  // L2Z_P2P_TIMEOUT_S
+    // --- batched prefill (prefill_host.cpp, prefill.hip) ---
+    int prefill = 1;           // L2Z_PREFILL         0: prompts are stepped token by token
+    int pf_chunk = 0;          // L2Z_PF_CHUNK        tokens per chunk (0: default)
+    int pf_skinny_form = 1;    // L2Z_PF_SKINNY_FORM
+    int pf_tile = 0;           // L2Z_PF_TILE
+    int pf_skinny_max = -1;    // L2Z_PF_SKINNY_MAX
+    int pf_skinny_tms = 0;     // L2Z_PF_SKINNY_TMS
+    int pf_attn = 1;           // L2Z_PF_ATTN         0: per-query prefill attention only
+    int pf_fuse = 1;           // L2Z_PF_FUSE         0: separate Q / K / V and W1 / W3 GEMMs
+    // --- loader (weights.cpp) ---
+    int upload_pinned = 1;     // L2Z_UPLOAD_PINNED   0: plain hipMemcpy from the caller's buffer
+};
+
+const Tunables &tunables();
+// Override one knob by its environment name after start-up (measurement harnesses that try several
+// settings in one process: include/llama2_hip_test.h l2z_option_set).  False: unknown name.
+bool tunables_set(const char *env_name, long long value);
+
+}  // namespace l2z

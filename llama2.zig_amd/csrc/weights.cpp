@@ -4,6 +4,7 @@
 // Product code.  No CPU fallback anywhere: without a HIP device every compute entry point returns
 // L2Z_ERR_NO_DEVICE.  Nothing under oracle/ is referenced.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -179,7 +180,9 @@ int weights_alloc(const l2z_config *config, int shared_weights, const l2z_comm *
     L2Z_TRY(ensure_device(dev));
     Shard sh;
     L2Z_TRY(make_shard(*config, comm, &sh));
+    static std::atomic<uint64_t> next_uid{1};
     l2z_weights *w = new l2z_weights();
+    w->uid = next_uid.fetch_add(1);
     w->cfg = *config;
     w->shared = shared_weights ? 1 : 0;
     w->device = dev;

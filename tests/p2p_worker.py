@@ -23,8 +23,10 @@ def main() -> None:
     B, ck = pkg.binding, pkg.checkpoint
     cfg = ck.Config(**spec["cfg"])
     shared, seed = spec["shared"], spec["seed"]
+    expect = spec.get("expect", "ok")
     comm = B.Comm(rank, world, None, 0)  # every rank on device 0: this is a one-GPU test
-    h = comm.p2p_export(max(cfg.dim, cfg.hidden_dim, cfg.vocab_size))
+    longest = max(cfg.dim, cfg.hidden_dim, cfg.vocab_size)
+    h = comm.p2p_export(longest // 2 if expect == "slot_error" else longest)
     with open(os.path.join(d, f"h_{rank}.tmp"), "wb") as f:
         f.write(h)
     os.rename(os.path.join(d, f"h_{rank}.tmp"), os.path.join(d, f"h_{rank}.bin"))
@@ -37,10 +39,38 @@ def main() -> None:
             time.sleep(0.01)
         handles.append(open(p, "rb").read())
     comm.p2p_connect(b"".join(handles))
+    if expect == "slot_error":
+        # landing slots shorter than the longest gathered vector: producers would store past the
+        # end of the peers' arenas, so the runstate must be refused (L2Z_ERR_COMM), not built
+        try:
+            B.RunState(cfg, comm=comm)
+        except B.L2ZError as e:
+            assert e.code == B.ERR_COMM, e
+            open(os.path.join(d, f"ok_{rank}"), "w").write(str(e))
+            comm.close()
+            return
+        raise SystemExit("runstate_init accepted landing slots that are too small")
+    if expect == "peer_dies" and rank != 0:
+        # this rank never runs: rank 0's first wait must time out ONCE and every later wait give up
+        # at once, so that L2Z_ERR_COMM reaches its host quickly instead of after steps x gathers x timeout
+        t0 = time.time()  # keep the arena mapped until rank 0 has reported
+        while not os.path.exists(os.path.join(d, "ok_0")) and time.time() - t0 < 100:
+            time.sleep(0.05)
+        comm.close()
+        return
     blob = ck.synth_blob(cfg, shared, seed) if spec.get("blob", True) else None
     w = B.Weights(cfg, blob, shared, seed=seed, comm=comm)
     s = B.RunState(cfg, comm=comm)
     s.greedy_begin(spec["prompt"])
+    if expect == "peer_dies":
+        t0 = time.time()
+        try:
+            s.greedy_run(w, spec["steps"])
+        except B.L2ZError as e:
+            assert e.code == B.ERR_COMM, e
+            open(os.path.join(d, f"ok_{rank}"), "w").write(f"{time.time() - t0:.2f} {e}")
+            return  # no clean-up: the group is dead
+        raise SystemExit("greedy_run succeeded although the peer never ran")
     toks = s.greedy_run(w, spec["steps"])
     logits = s.logits()
     # the stepped API on top of the same state

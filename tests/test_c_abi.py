@@ -1,0 +1,64 @@
+"""The drop-in boundary from plain C: include/llama2_hip.h must compile as strict C99 and a C host
+must be able to run the whole hot path through it ("nothing proves the header is valid
+C").  The reference's only caller is Zig (src/main.zig:996); Zig's `extern fn` binds the same C
+symbols this program links against."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "c_abi", "abi_smoke.c")
+GOLD = os.path.join(HERE, "golden")
+
+
+def build_smoke(tmp_path, B):
+    exe = str(tmp_path / "abi_smoke")
+    lib_dir = os.path.dirname(B.LIB_PATH)
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+           SRC, "-o", exe, "-L", lib_dir, "-lllama2_hip", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    return exe
+
+
+def test_header_is_strict_c99_and_config_layout_matches_the_reference(B, tmp_path):
+    """sizeof(l2z_config) == 28, fields at 0,4,...,24: src/main.zig:17-25 ConfigReader."""
+    # the header alone, as a translation unit
+    tu = tmp_path / "hdr.c"
+    tu.write_text('#include "llama2_hip.h"\n#include "llama2_hip_test.h"\nint main(void) { return 0; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-I",
+                    os.path.join(ROOT, "include"), str(tu)], check=True, capture_output=True, text=True)
+    out = subprocess.run([build_smoke(tmp_path, B), "layout"], check=True, capture_output=True, text=True).stdout
+    got = dict(line.split() for line in out.strip().splitlines())
+    assert got.pop("abi") == str(B.lib().l2z_abi_version())
+    assert {k: int(v) for k, v in got.items()} == {
+        "sizeof": 28, "dim": 0, "hidden_dim": 4, "n_layers": 8, "n_heads": 12, "n_kv_heads": 16,
+        "vocab_size": 20, "seq_len": 24}
+
+
+def test_product_and_test_headers_do_not_overlap(B):
+    prod, test = set(B.declared_symbols("product")), set(B.declared_symbols("test"))
+    assert not (prod & test)
+    # nothing a drop-in host needs lives in the test header, and vice versa
+    assert {"l2z_weights_init", "l2z_runstate_init", "l2z_transformer", "l2z_argmax", "l2z_logits_read",
+            "l2z_greedy_run", "l2z_prefill", "l2z_comm_init"} <= prod
+    assert {"l2z_emu_transformer", "l2z_comm_init_emulated", "l2z_weights_read", "l2z_runstate_read",
+            "l2z_matmul", "l2z_option_set"} <= test
+
+
+@pytest.mark.gpu
+def test_c_host_runs_the_golden_toy_checkpoints(gpu, tmp_path):
+    """init -> l2z_transformer -> l2z_argmax -> free from C on the committed toy checkpoints:
+    the printed token ids equal the golden greedy tokens (tests/golden/*.npz)."""
+    exe = build_smoke(tmp_path, gpu)
+    meta = json.load(open(os.path.join(GOLD, "toy_models.json")))
+    for m in meta["models"]:
+        exp = np.load(os.path.join(GOLD, m["expected"]))["tokens"]
+        n = m["config"]["seq_len"]
+        out = subprocess.run([exe, "run", os.path.join(GOLD, m["checkpoint"]), str(n)] +
+                             [str(t) for t in m["prompt"]], check=True, capture_output=True, text=True).stdout
+        got = np.array([int(x) for x in out.split()], np.int32)
+        assert np.array_equal(got, exp[:len(got)]) and len(got) == len(exp), (m["checkpoint"], got, exp)

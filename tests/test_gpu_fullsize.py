@@ -149,6 +149,25 @@ def test_stories15M_full_shape_greedy_tokens_identical(gpu, ck, orc):
     s.close(); w.close(); m.close()
 
 
+def test_real_stories15M_checkpoint_if_supplied(gpu, ck, orc):
+    """BASELINE.json configs[0]/[1] on the REAL file: if $L2Z_STORIES15M names a stories15M.bin
+    (none ships with the image: /root/reference/.gitignore:1), 256 greedy token ids from BOS must be
+    identical to the CPU path's.  Still "vs the C restatement": there is no Zig compiler here."""
+    import os
+    path = os.environ.get("L2Z_STORIES15M")
+    if not path or not os.path.exists(path):
+        pytest.skip("no real stories15M.bin supplied ($L2Z_STORIES15M)")
+    cfg, shared, blob = ck.read_checkpoint(path)
+    w, s = gpu.Weights(cfg, np.ascontiguousarray(blob), shared), gpu.RunState(cfg)
+    m = orc.Model(cfg.as_i32(), np.ascontiguousarray(blob), shared)
+    ref, margins = m.generate_greedy([], 256)
+    s.greedy_begin([])
+    got = s.greedy_run(w, 256)
+    print(f"real stories15M: min top1-top2 margin {margins.min():.3e}")
+    assert np.array_equal(got, ref)
+    s.close(); w.close(); m.close()
+
+
 def test_stories110M_full_shape_logits_tolerance(gpu, ck, orc):
     """configs[2]: stories110M shape, logits within the stated fp32 tolerance (the sampled
     token ids at -t 1.0 -p 0.9 depend on Zig's PRNG stream, so logits are compared)."""
@@ -164,8 +183,8 @@ def test_stories110M_full_shape_logits_tolerance(gpu, ck, orc):
         s.transformer(t, pos, w)
         got = s.logits()
         worst = max(worst, float(np.abs(got - ref).max()))
-        np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4)
-        assert s.argmax() == int(np.argmax(ref)) or np.sort(ref)[-1] - np.sort(ref)[-2] < 1e-4
+        np.testing.assert_allclose(got, ref, rtol=5e-5, atol=5e-5)
+        assert s.argmax() == int(np.argmax(ref)) or np.sort(ref)[-1] - np.sort(ref)[-2] < 1e-5
     print(f"stories110M shape: max |logit diff| over {len(toks)} positions = {worst:.3e}")
     s.close(); w.close(); m.close()
 
@@ -187,7 +206,7 @@ def test_stories110M_across_the_attention_switch_over(gpu, ck, orc):
         if pos >= 250 or pos % 50 == 0:
             got = s.logits()
             worst = max(worst, float(np.abs(got - ref).max()))
-            np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4, err_msg=f"pos {pos}")
+            np.testing.assert_allclose(got, ref, rtol=5e-5, atol=5e-5, err_msg=f"pos {pos}")
     print(f"110M shape across pos 256: max |logit diff| {worst:.3e}")
     s.greedy_begin(toks[1:260])
     dev = s.greedy_run(w, 275)
@@ -268,17 +287,19 @@ def test_7b_full_forward_logits_vs_oracle(gpu, ck, orc, model7b):
         s.transformer(tok, pos, w)
         got = s.logits()
         worst = max(worst, float(np.abs(got - ref).max()))
-        np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4, err_msg=f"pos {pos}")
-        srt = np.sort(ref)
-        assert s.argmax() == int(np.argmax(ref)) or srt[-1] - srt[-2] < 1e-4
+        np.testing.assert_allclose(got, ref, rtol=5e-5, atol=5e-5, err_msg=f"pos {pos}")
+        assert s.argmax() == int(np.argmax(ref))
     print(f"7B shape, full forward vs oracle: max |logit diff| = {worst:.3e}")
-    # and the -t 0 loop: token ids identical to the CPU path (main.zig:995-1036)
-    ref_toks, margins = m.generate_greedy([], 6)
+    # and the -t 0 loop: token ids identical to the CPU path (main.zig:995-1036), 32 positions,
+    # no near-tie escape: the margin is reported, a mismatch fails
+    n_greedy = 32
+    ref_toks, margins = m.generate_greedy([], n_greedy)
     s.greedy_begin([])
-    dev = s.greedy_run(w, 6)
+    dev = s.greedy_run(w, n_greedy)
     n = min(len(dev), len(ref_toks))
     same = next((i for i in range(n) if dev[i] != ref_toks[i]), n)
-    assert same == n or margins[same] < 1e-4, (dev.tolist(), ref_toks.tolist(), margins.tolist())
-    print(f"7B shape, greedy: {same} of {n} token ids identical to the oracle, min top-2 margin {float(np.min(margins[:n])):.3e}")
+    print(f"7B shape, greedy: {same} of {n} token ids identical to the oracle, min top-2 margin "
+          f"{float(np.min(margins[:n])):.3e}")
+    assert len(dev) == len(ref_toks) and same == n, (dev.tolist(), ref_toks.tolist(), margins.tolist())
     m.close()
     del blob

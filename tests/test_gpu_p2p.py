@@ -25,21 +25,23 @@ MODELS = [
 ]
 
 
-@pytest.mark.parametrize("name,kw,shared,world", MODELS, ids=[f"{m[0]}-x{m[3]}" for m in MODELS])
-def test_multiprocess_peer_write_gather_is_bit_identical(gpu, ck, tmp_path, name, kw, shared, world):
-    cfg = ck.Config(**kw)
-    steps = min(cfg.seq_len - 2, 300)
-    on_device = cfg.dim >= 4096  # big shapes: seeded weights generated on the device by every rank
-    spec = dict(cfg=kw, shared=shared, seed=33, prompt=[5, 9, 11], steps=steps, blob=not on_device)
+def grid_cap(world: int) -> str:
+    """All ranks share ONE GPU here: a mat-vec launch that may be waiting for a peer's kernel must
+    leave that kernel room to run (on real multi-GPU nodes every rank has its own chip)."""
+    return str(max(32, 512 // world))
+
+
+def run_ranks(tmp_path, world, spec, env_extra=None, timeout=300):
     (tmp_path / "model.json").write_text(json.dumps(spec))
-    env = dict(os.environ, L2Z_P2P_TIMEOUT_S="60")
+    env = dict(os.environ, L2Z_P2P_TIMEOUT_S="60", L2Z_GRID_CAP=grid_cap(world))
+    env.update(env_extra or {})
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "p2p_worker.py"), str(r), str(world),
                                str(tmp_path), str(tmp_path / "model.json")], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = []
     for p in procs:
         try:
-            out, _ = p.communicate(timeout=300)
+            out, _ = p.communicate(timeout=timeout)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
@@ -47,6 +49,23 @@ def test_multiprocess_peer_write_gather_is_bit_identical(gpu, ck, tmp_path, name
         outs.append(out.decode(errors="replace"))
     for r, p in enumerate(procs):
         assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-2000:]}"
+    return outs
+
+
+# consume: consumers read the LL words from their own landing slot (no gather launches, default);
+# gather: one gather launch per gathered vector (L2Z_P2P_CONSUME=0); nopush: the gather launch also sends
+CASES = [(m, "consume") for m in MODELS] + [(MODELS[0], "gather"), (MODELS[4], "gather"), (MODELS[3], "nopush")]
+MODE_ENV = {"consume": {}, "gather": {"L2Z_P2P_CONSUME": "0"}, "nopush": {"L2Z_P2P_PUSH": "0"}}
+
+
+@pytest.mark.parametrize("model,mode", CASES, ids=[f"{m[0]}-x{m[3]}-{mode}" for m, mode in CASES])
+def test_multiprocess_peer_write_gather_is_bit_identical(gpu, ck, tmp_path, model, mode):
+    name, kw, shared, world = model
+    cfg = ck.Config(**kw)
+    steps = min(cfg.seq_len - 2, 300)
+    on_device = cfg.dim >= 4096  # big shapes: seeded weights generated on the device by every rank
+    spec = dict(cfg=kw, shared=shared, seed=33, prompt=[5, 9, 11], steps=steps, blob=not on_device)
+    run_ranks(tmp_path, world, spec, MODE_ENV[mode])
     # unsharded reference in this process
     blob = None if on_device else ck.synth_blob(cfg, shared, 33)
     w, s = gpu.Weights(cfg, blob, shared, seed=33), gpu.RunState(cfg)
@@ -61,3 +80,21 @@ def test_multiprocess_peer_write_gather_is_bit_identical(gpu, ck, tmp_path, name
         assert np.array_equal(o["logits"], logits), f"rank {r} logits"
         assert np.array_equal(o["logits2"], logits2) and int(o["am"]) == am, f"rank {r} stepped call"
     s.close(); w.close()
+
+
+def test_landing_slots_too_small_are_refused(gpu, tmp_path):
+    kw = MODELS[0][1]
+    spec = dict(cfg=kw, shared=False, seed=1, prompt=[], steps=4, expect="slot_error")
+    run_ranks(tmp_path, 2, spec)
+    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
+
+
+@pytest.mark.parametrize("mode", ["consume", "gather"])
+def test_dead_peer_fails_fast(gpu, tmp_path, mode):
+    """One timeout, not steps x gathers timeouts: after the first wait gives up, every later wait
+    sees the latched error and returns at once (2 s timeout, 64 queued steps x 13 gathers)."""
+    kw = MODELS[0][1]
+    spec = dict(cfg=kw, shared=False, seed=1, prompt=[], steps=80, expect="peer_dies")
+    run_ranks(tmp_path, 2, spec, dict(MODE_ENV[mode], L2Z_P2P_TIMEOUT_S="2"), timeout=120)
+    took = float((tmp_path / "ok_0").read_text().split()[0])
+    assert took < 20.0, f"rank 0 needed {took:.1f} s to report the dead peer"

@@ -18,8 +18,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 # |gpu - oracle| <= LOGIT_ATOL + LOGIT_RTOL * |oracle|, logits are O(1..10)
-LOGIT_RTOL = 2e-4
-LOGIT_ATOL = 2e-4
+LOGIT_RTOL = 5e-5   # observed on MI355X: max |diff| 3e-6 on toy models, 1.05e-5 on the 7B shape
+LOGIT_ATOL = 5e-5
 # single kernels (one dot product deep): relative to sum |a_i b_i|
 KERNEL_RTOL = 4e-6
 
@@ -143,6 +143,83 @@ def test_weighted_sum_rows_vs_oracle(gpu, orc, hs, stride, T):
     got = gpu.vector_weighted_sum_rows(hs, rows, stride, wts)
     ref = orc.vector_weighted_sum_rows(hs, rows, stride, wts)
     np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5 * np.sqrt(T))
+
+
+def attention_ref(orc, q, kc, vc, pos, n_heads, n_kv_heads, hs):
+    """src/main.zig:361-389 for one layer out of the oracle's own kernels (:503 dot, :687 softmax,
+    :657 weighted row sum)."""
+    kv_dim, kv_mul = n_kv_heads * hs, n_heads // n_kv_heads
+    K, V = kc.reshape(-1, kv_dim), vc.reshape(-1)
+    out = np.empty(n_heads * hs, np.float32)
+    div = np.float32(np.sqrt(np.float32(hs)))
+    for h in range(n_heads):
+        o = (h // kv_mul) * hs                                               # :369
+        att = np.array([orc.vector_dot_product(q[h * hs:(h + 1) * hs], K[t, o:o + hs]) for t in range(pos + 1)],
+                       np.float32) / div                                    # :372
+        att = orc.softmax(att)                                              # :378
+        out[h * hs:(h + 1) * hs] = orc.vector_weighted_sum_rows(hs, V[o:], kv_dim, att)   # :381-388
+    return out
+
+
+ATTN_SHAPES = {  # n_heads, n_kv_heads, head_size, seq_len
+    "stories15M": (6, 6, 48, 256), "stories110M": (12, 12, 64, 1024), "llama2-7b": (32, 32, 128, 2048),
+    "gqa": (8, 2, 32, 64), "mqa-wide-head": (4, 1, 256, 96),
+}
+# (shape, form, nch, positions): every kernel the forward pass can pick for these models, driven
+# directly -- attention_fast_kernel<256, speculative>, <1024>, the single-launch split form -- plus
+# the generic kernel; positions cover pos 0, fewer timesteps than groups / chunks, the last row
+ATTN_CASES = [
+    ("stories15M", "fast256", 0, (0, 1, 31, 255)),
+    ("stories15M", "generic", 0, (0, 255)),
+    ("stories15M", "split", 3, (0, 1, 2, 255)),
+    ("stories110M", "fast1024", 0, (0, 5, 255, 1023)),
+    ("stories110M", "fast256", 0, (300,)),
+    ("stories110M", "split", 0, (256, 1023)),
+    ("llama2-7b", "fast1024", 0, (0, 100, 255)),
+    ("llama2-7b", "split", 0, (0, 3, 300, 2047)),
+    ("llama2-7b", "split", 16, (2047,)),
+    ("gqa", "fast256", 0, (0, 63)),
+    ("gqa", "split", 2, (0, 1, 63)),
+    ("gqa", "generic", 0, (63,)),
+    ("mqa-wide-head", "fast256", 0, (95,)),
+    ("mqa-wide-head", "split", 4, (2, 95)),
+]
+
+
+@pytest.mark.parametrize("shape,form,nch,positions", ATTN_CASES,
+                         ids=[f"{c[0]}-{c[1]}{c[2] or ''}" for c in ATTN_CASES])
+def test_attention_kernels_vs_oracle(gpu, orc, shape, form, nch, positions):
+    """The decode attention kernels the forward pass launches, one layer at a time, against the
+    oracle's dot / softmax / weighted-row-sum (main.zig:361-389).  Outputs are convex combinations
+    of V entries (|v| <= 2 here), observed max |diff| ~1e-6; bound 1e-5."""
+    H, KV, hs, S = ATTN_SHAPES[shape]
+    rng = np.random.default_rng(H * 1000 + hs)
+    q = rng.standard_normal(H * hs, dtype=np.float32)
+    kc = rng.standard_normal(S * KV * hs, dtype=np.float32)
+    vc = rng.uniform(-2, 2, S * KV * hs).astype(np.float32)
+    worst = 0.0
+    for pos in positions:
+        got = gpu.attention_decode(q, kc, vc, pos, H, KV, hs, S, form=form, nch=nch)
+        ref = attention_ref(orc, q, kc, vc, pos, H, KV, hs)
+        worst = max(worst, float(np.abs(got - ref).max()))
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5, err_msg=f"{shape} {form} pos {pos}")
+    print(f"attention {shape} {form}{nch or ''}: max |diff| {worst:.2e}")
+
+
+def test_attention_auto_picks_the_documented_form(gpu):
+    """form 'auto' is what enqueue_forward launches: 256 threads per head (speculative first round)
+    for seq_len <= 512, 1024 threads beyond, the split form from pos 256 on -- bit-identical to the
+    same form asked for by name."""
+    rng = np.random.default_rng(5)
+    for shape, pos, want, nch in (("stories15M", 200, "fast256", 0), ("stories110M", 200, "fast1024", 0),
+                                  ("stories110M", 700, "split", 0), ("llama2-7b", 2047, "split", 0)):
+        H, KV, hs, S = ATTN_SHAPES[shape]
+        q = rng.standard_normal(H * hs, dtype=np.float32)
+        kc = rng.standard_normal(S * KV * hs, dtype=np.float32)
+        vc = rng.standard_normal(S * KV * hs, dtype=np.float32)
+        a = gpu.attention_decode(q, kc, vc, pos, H, KV, hs, S, form="auto")
+        b = gpu.attention_decode(q, kc, vc, pos, H, KV, hs, S, form=want, nch=nch)
+        assert np.array_equal(a, b), (shape, pos, want)
 
 
 def test_argmax_tie_rule(gpu, orc):
@@ -362,11 +439,11 @@ def test_sharded_hip_path_emulated_ranks(gpu, ck, world, from_blob):
 
 
 @pytest.mark.parametrize("nch", [2, 3, 16])
-def test_split_attention_matches_oracle(gpu, ck, orc, nch, monkeypatch):
-    """The flash-decoding attention (nch blocks per head + combine) is forced on for toy
-    models (it is auto-enabled only for seq_len > 256): logits within tolerance at every
+def test_split_attention_matches_oracle(gpu, ck, orc, nch, options):
+    """The flash-decoding attention (nch blocks per head, the last arriver combines) is forced on
+    for toy models (it is auto-enabled only for seq_len > 256): logits within tolerance at every
     position, greedy tokens identical, including positions < nch (empty chunks)."""
-    monkeypatch.setenv("L2Z_ATTN_SPLIT", str(nch))
+    options(L2Z_ATTN_SPLIT=nch)
     for name, kw, shared in CONFIGS[:3]:
         cfg = ck.Config(**kw)
         blob = ck.synth_blob(cfg, shared, seed=61)
