@@ -33,7 +33,7 @@ def grid_cap(world: int) -> str:
 
 def run_ranks(tmp_path, world, spec, env_extra=None, timeout=300):
     (tmp_path / "model.json").write_text(json.dumps(spec))
-    env = dict(os.environ, L2Z_P2P_TIMEOUT_S="60", L2Z_GRID_CAP=grid_cap(world))
+    env = dict(os.environ, L2Z_P2P_TIMEOUT_S="30", L2Z_GRID_CAP=grid_cap(world))
     env.update(env_extra or {})
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "p2p_worker.py"), str(r), str(world),
                                str(tmp_path), str(tmp_path / "model.json")], env=env,
@@ -83,8 +83,8 @@ def test_multiprocess_peer_write_gather_is_bit_identical(gpu, ck, tmp_path, mode
 
 
 def test_landing_slots_too_small_are_refused(gpu, tmp_path):
-    kw = MODELS[0][1]
-    spec = dict(cfg=kw, shared=False, seed=1, prompt=[], steps=4, expect="slot_error")
+    kw = MODELS[2][1]  # vocab 32000: half of it rounds up to 16384 words, too few
+    spec = dict(cfg=kw, shared=True, seed=1, prompt=[], steps=4, expect="slot_error")
     run_ranks(tmp_path, 2, spec)
     assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
 
