@@ -5,28 +5,6 @@
 namespace l2z {
 namespace {
 
-// ---------------------------------------------------------------------------
-// Attention for one head per block (main.zig:361-389).
-// Thread (g, c): group g of TPR lanes walks timesteps t = g, g+G, ...; lane c
-// owns float4 column(s) c of the head.
-// ---------------------------------------------------------------------------
-struct AttnGeom {
-    int E;    // elements per head row in load units (head_size/4 if VEC else head_size)
-    int TPR;  // lanes per row: power of two, <= 64
-    int G;    // groups per block
-};
-
-__host__ __device__ inline AttnGeom attn_geom(int head_size, bool vec, int block = kBlock)
-{
-    AttnGeom g;
-    g.E = vec ? head_size >> 2 : head_size;
-    int t = 1;
-    while (t < g.E && t < 64) t <<= 1;
-    g.TPR = t;
-    g.G = block / t;
-    return g;
-}
-
 // scores for timesteps t < T: att[t] = dot(q, K[t]) / div   (:367-375).
 // Group g walks t = g, g+G, ...; kAttnUB timesteps are loaded before any is
 // used so kAttnUB K rows are in flight per lane (the first build did one
@@ -141,24 +119,6 @@ __device__ __forceinline__ void attn_weighted_sum(const float *att, const float 
     }
 }
 
-// Softmax over att[0..T) (main.zig:687-706) computed redundantly by every wave --
-// each wave reduces max and sum over ALL T with the same instruction sequence, so
-// all waves hold bit-identical (max, sum) without any cross-wave barrier -- and
-// wave w normalises the entries t = w*64 + lane, + blockDim, ...
-// The normalised weights go to a second buffer, so no wave overwrites what another still reads.
-__device__ __forceinline__ void wave_softmax(const float *att, float *prob, int T)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    float m = -INFINITY;
-    for (int t = lane; t < T; t += kWave) m = fmaxf(m, att[t]);
-    m = wave_max(m);
-    float s = 0.0f;
-    for (int t = lane; t < T; t += kWave) s += expf(att[t] - m);  // :699
-    s = wave_sum(s);
-    for (int t = wave * kWave + lane; t < T; t += nw * kWave) prob[t] = expf(att[t] - m) / s;  // :704
-    __syncthreads();
-}
-
 // out[i] = part[0][i] + part[1][i] + ... + part[G-1][i], i < hs.  R = 1..16 adjacent lanes
 // share one output: lane r adds partials r, r+R, ... (increasing), then a DPP sum over the R
 // lanes.  R depends only on (G, hs, blockDim) -- fixed per model.
@@ -210,42 +170,10 @@ __device__ long long g_dbg_ts[16];
 #else
 #define L2Z_TS(i) do { } while (0)
 #endif
-// Blocks past the heads (short contexts on a big chip: 32 heads occupy 32 of 256 CUs for a
-// latency chain that moves almost no bytes) pull the weights of the NEXT launch -- this layer's
-// wo rows -- through the cache hierarchy with plain loads, so that launch finds them in the
-// on-die Infinity Cache instead of HBM.  Values are discarded; nothing depends on it.
-template <int NT>
-__device__ __forceinline__ void prefetch_block(const AttnArgs &a, int b)
-{
-    const v4f *p = (const v4f *)a.pf_ptr;
-    const size_t n4 = a.pf_floats >> 2;
-    const size_t per = (n4 + a.pf_blocks - 1) / a.pf_blocks;
-    const size_t lo = per * (size_t)b;
-    size_t hi = lo + per;
-    if (hi > n4) hi = n4;
-    constexpr int U = 8;
-    v4f acc = {0.f, 0.f, 0.f, 0.f};
-    size_t i = lo + threadIdx.x;
-    for (; i + (size_t)NT * (U - 1) < hi; i += (size_t)NT * U) {
-        v4f r[U];
-#pragma unroll
-        for (int k = 0; k < U; k++) r[k] = p[i + (size_t)NT * k];
-#pragma unroll
-        for (int k = 0; k < U; k++) acc += r[k];
-    }
-    for (; i < hi; i += NT) acc += p[i];
-    const float sum = (acc.x + acc.y) + (acc.z + acc.w);
-    if (sum == 123.456f) a.pf_sink[b] = sum;  // keeps the loads alive; never true in practice
-}
-
 template <int NT, bool SPEC>
 __global__ __launch_bounds__(NT) void attention_fast_kernel(const AttnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    if ((int)blockIdx.x >= a.n_head_blocks) {
-        prefetch_block<NT>(a, (int)blockIdx.x - a.n_head_blocks);
-        return;
-    }
     const int hs = a.head_size;
     const AttnGeom ge = attn_geom(hs, true, NT);
     float *att = lds;                                  // seq_len raw scores
@@ -390,13 +318,18 @@ __device__ __forceinline__ void combine_chunks(const float *p, int nch, int hs, 
 // stale cache lines once and combines the nch partials (the hand-off recipe of the CDNA4 guide:
 // write-through payload -> drain -> counter, consumer one agent-scope acquire -> plain loads).
 // No block ever waits for another.  The counter is left at 0 for the next launch.
-__global__ __launch_bounds__(kBlock) void attention_split_kernel(const AttnArgs a, int nch,
-                                                                 float *__restrict__ part_out,
-                                                                 int *__restrict__ arrivals)
+// NT = 1024 for long contexts: 32 groups of lanes (head_size 128) x 8 rows each put a whole
+// 256-timestep chunk -- K rows and V rows -- in flight in ONE round trip; with 256 threads the same
+// chunk took four dependent rounds of K loads and four of V (measured 21 us per layer at pos 2047
+// for 67 MB: latency-, not bandwidth-bound).
+template <int NT>
+__global__ __launch_bounds__(NT) void attention_split_kernel(const AttnArgs a, int nch,
+                                                             float *__restrict__ part_out,
+                                                             int *__restrict__ arrivals)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int hs = a.head_size;
-    const AttnGeom ge = attn_geom(hs, true, kBlock);
+    const AttnGeom ge = attn_geom(hs, true, NT);
     const int max_local = (a.seq_len + nch - 1) / nch;
     float *sc = lds;                                   // local scores
     float *wt = sc + ((max_local + 3) & ~3);           // local unnormalised weights
@@ -461,7 +394,7 @@ __global__ __launch_bounds__(kBlock) void attention_split_kernel(const AttnArgs 
         m = wave_max(m);
         for (int j = lane; j < Tc; j += kWave) l += expf(sc[j] - m);
         l = wave_sum(l);
-        for (int j = wave * kWave + lane; j < Tc; j += kBlock) wt[j] = expf(sc[j] - m);  // unnormalised
+        for (int j = wave * kWave + lane; j < Tc; j += NT) wt[j] = expf(sc[j] - m);  // unnormalised
         __syncthreads();
         v4f acc = zero;
         for (int j0 = g;;) {  // weighted V (:381-388), increasing t within the group
@@ -586,15 +519,23 @@ size_t attention_split_part_floats(int n_heads_local, int head_size, int nch)
 hipError_t launch_attention_split(const AttnArgs &a_in, int n_heads_local, int nch, float *part,
                                   int *arrivals, hipStream_t st)
 {
-    AttnArgs a = a_in;
-    a.n_head_blocks = n_heads_local * nch;  // every block works on a head: no prefetch blocks here
-    const AttnGeom ge = attn_geom(a.head_size, true, kBlock);
+    const AttnArgs &a = a_in;
+    const int forced = tunables().attn_block;
+    const int nt = forced ? forced : (a.seq_len > 512 ? kAttnFastBlock : kBlock);
+    const AttnGeom ge = attn_geom(a.head_size, true, nt);
     const int max_local = (a.seq_len + nch - 1) / nch;
     const size_t lds = (size_t)(2 * ((max_local + 3) & ~3) + ge.G * a.head_size) * sizeof(float);
-    hipError_t e = ensure_lds(attention_split_kernel, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(attention_split_kernel, dim3(n_heads_local * nch), dim3(kBlock), lds, st, a,
-                       nch, part, arrivals);
+    if (nt == kAttnFastBlock) {
+        hipError_t e = ensure_lds(attention_split_kernel<kAttnFastBlock>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(attention_split_kernel<kAttnFastBlock>, dim3(n_heads_local * nch),
+                           dim3(kAttnFastBlock), lds, st, a, nch, part, arrivals);
+    } else {
+        hipError_t e = ensure_lds(attention_split_kernel<kBlock>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(attention_split_kernel<kBlock>, dim3(n_heads_local * nch), dim3(kBlock), lds,
+                           st, a, nch, part, arrivals);
+    }
     return hipGetLastError();
 }
 
@@ -614,8 +555,7 @@ bool attention_split_supported(const AttnArgs &a)
 // 256- / 1024-thread fast kernel, 4 forces the generic kernel (tests drive every form directly)
 hipError_t launch_attention(const AttnArgs &a_in, int n_heads_local, hipStream_t st, int form)
 {
-    AttnArgs a = a_in;
-    a.n_head_blocks = n_heads_local;
+    const AttnArgs &a = a_in;
     const bool vec = (a.head_size % 4) == 0 && (a.kv_dim % 4) == 0 && aligned16(a.q) &&
                      aligned16(a.kcache) && aligned16(a.vcache);
     const size_t lds = attention_lds_bytes(a.head_size, a.seq_len, vec);
@@ -624,21 +564,15 @@ hipError_t launch_attention(const AttnArgs &a_in, int n_heads_local, hipStream_t
         const int nt = forced ? forced : (a.seq_len > 512 ? kAttnFastBlock : kBlock);
         const AttnGeom gf = attn_geom(a.head_size, true, nt);
         const size_t lds_fast = (size_t)(2 * ((a.seq_len + 3) & ~3) + gf.G * a.head_size) * sizeof(float);
-        // idle CUs pull the next launch's weights (prefetch_block); only worth a block per spare CU
-        int extra = 0;
-        if (a.pf_ptr != nullptr && a.pf_floats >= 1024 && aligned16(a.pf_ptr) && a.pf_blocks > 0)
-            extra = a.pf_blocks;
-        else
-            a.pf_ptr = nullptr;
         if (nt == kAttnFastBlock) {
             hipError_t e = ensure_lds(attention_fast_kernel<kAttnFastBlock, false>, lds_fast);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((attention_fast_kernel<kAttnFastBlock, false>), dim3(n_heads_local + extra),
+            hipLaunchKernelGGL((attention_fast_kernel<kAttnFastBlock, false>), dim3(n_heads_local),
                                dim3(kAttnFastBlock), lds_fast, st, a);
         } else {
             hipError_t e = ensure_lds(attention_fast_kernel<kBlock, true>, lds_fast);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((attention_fast_kernel<kBlock, true>), dim3(n_heads_local + extra),
+            hipLaunchKernelGGL((attention_fast_kernel<kBlock, true>), dim3(n_heads_local),
                                dim3(kBlock), lds_fast, st, a);
         }
         return hipGetLastError();

@@ -73,7 +73,6 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
     // would be hidden in the producer's time.
     const bool can_push = p2p && tunables().p2p_push && (consume || prof == nullptr);
     const int n_g = s->n_gathers;
-    bool handed_over = false;  // the classifier launch did argmax + hand-over itself
     int gi = 0;           // gathers issued so far in this pass
     bool pushed = false;  // the launch just made pushed its outputs itself
     const int *ctl = s->comm ? s->comm->d_ctl : nullptr;
@@ -117,7 +116,18 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
     for (int l = 0; l < c.n_layers; l++) {
         float *kc = s->key_cache + (size_t)l * c.seq_len * sh.kvd_loc;  // :354 loff
         float *vc = s->value_cache + (size_t)l * c.seq_len * sh.kvd_loc;
-        if (want()) {   // rmsnorm (:305) + q,k,v (:308-320) + RoPE (:336-351) + KV write (:354-358)
+        const bool fused = s->fused_qkv_attn && !split && only_stage < 0;
+        if (fused) {    // small models: :305-389 in one launch, one block per head (fused_small.hip)
+            FusedQkvAttnArgs a = {};
+            a.wq = w->wq + (size_t)l * dim * dim;
+            a.wk = w->wk + (size_t)l * dim * dim;
+            a.wv = w->wv + (size_t)l * dim * dim;
+            a.rms_w = w->rms_att + (size_t)l * dim; a.x = s->x; a.q_out = s->q;
+            a.kcache = kc; a.vcache = vc; a.xb = s->xb; a.pos_ptr = s->d_pos; a.rope = s->rope;
+            a.n = c.dim; a.head_size = sh.hs; a.seq_len = c.seq_len; a.kv_dim = sh.kvd_loc;
+            L2Z_LAUNCH(KIND_QKV, launch_fused_qkv_attn(a, c.n_heads, st));
+        }
+        if (!fused && want()) {   // rmsnorm (:305) + q,k,v (:308-320) + RoPE (:336-351) + KV write (:354-358)
             MatvecArgs a = {};
             a.w0 = w->wq + (size_t)l * sh.dim_loc * dim;
             a.w1 = w->wk + (size_t)l * sh.kvd_loc * dim;
@@ -128,9 +138,10 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.n = c.dim; a.rms_w = w->rms_att + (size_t)l * dim;
             x_in(a, s->x, gi, sh.dim_loc);  // layer 0: the embedding row, a plain buffer (gi == 0)
             a.pos_ptr = s->d_pos; a.rope = s->rope; a.head_size = sh.hs; a.rope_segs = 2;
+            a.plain_loads = s->plain_layer_loads;
             L2Z_LAUNCH(KIND_QKV, launch_matvec(a, PRO_RMS, EPI_ROPE, mb, g_cus, st));
         }
-        if (want()) {   // attention (:361-389) over the local heads
+        if (!fused && want()) {   // attention (:361-389) over the local heads
             AttnArgs a = {};
             a.q = s->q; a.kcache = kc; a.vcache = vc; a.xb = s->xb + sh.dim0;
             a.pos_ptr = s->d_pos; a.head_size = sh.hs; a.kv_dim = sh.kvd_loc;
@@ -141,24 +152,11 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
                 a.push_gi = gi + 1;
                 pushed = true;
             }
-            if (split && s->attn_nch > 1 && attention_split_supported(a)) {
+            if (split && s->attn_nch > 1 && attention_split_supported(a))
                 L2Z_LAUNCH(KIND_ATTN, launch_attention_split(a, sh.heads_loc, s->attn_nch,
                                                              s->d_attn_part, s->d_attn_cnt, st));
-            } else {
-                // short context: one block per head leaves most CUs idle for a latency chain that
-                // moves almost no bytes -- they pull this layer's wo rows (the next launch's
-                // stream) into the on-die cache meanwhile.  Only for matrices far larger than the
-                // L2s (the small models are cache resident anyway).
-                const size_t wo_floats = (size_t)sh.dim_loc * dim;
-                const int pct = tunables().attn_prefetch;
-                if (pct > 0 && g_cus > sh.heads_loc && wo_floats * 4 >= ((size_t)8 << 20)) {
-                    a.pf_ptr = w->wo + (size_t)l * wo_floats;
-                    a.pf_floats = (wo_floats / 100 * (size_t)(pct > 100 ? 100 : pct)) & ~(size_t)3;
-                    a.pf_blocks = g_cus - sh.heads_loc;
-                    a.pf_sink = s->d_pf_sink;
-                }
+            else
                 L2Z_LAUNCH(KIND_ATTN, launch_attention(a, sh.heads_loc, st));
-            }
         }
         L2Z_TRY(gather(s->xb, sh.dim_loc));
         if (want()) {   // wo (:392) + residual (:395)
@@ -167,6 +165,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0;
             a.rows0 = sh.dim_loc; a.n = c.dim;
             x_in(a, s->xb, gi, sh.dim_loc);
+            a.plain_loads = s->plain_layer_loads;
             push_to(a, 1);
             L2Z_LAUNCH(KIND_WO, launch_matvec(a, PRO_NONE, EPI_RESID, mb, g_cus, st, nullptr, &pushed));
         }
@@ -179,6 +178,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.rows0 = sh.hid_loc; a.rows1 = sh.hid_loc; a.n = c.dim;
             a.rms_w = w->rms_ffn + (size_t)l * dim;
             x_in(a, s->x, gi, sh.dim_loc);
+            a.plain_loads = s->plain_layer_loads;
             push_to(a, 2);
             L2Z_LAUNCH(KIND_FFN13, launch_matvec(a, PRO_RMS, EPI_SWIGLU, mb, g_cus, st, nullptr, &pushed));
         }
@@ -189,6 +189,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0;
             a.rows0 = sh.dim_loc; a.n = c.hidden_dim;
             x_in(a, s->hb, gi, sh.hid_loc);
+            a.plain_loads = s->plain_layer_loads;
             push_to(a, 1);
             L2Z_LAUNCH(KIND_FFN2, launch_matvec(a, PRO_NONE, EPI_RESID, mb, g_cus, st, nullptr, &pushed));
         }
@@ -204,21 +205,12 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         const bool fuse = sh.world == 1 && matvec_vector_width(c.dim);
         int grid = 0;
         push_to(a, 3);
-        // greedy step: the classifier's last block also does argmax + hand-over (cls_finish)
-        handed_over = fuse && with_step && tunables().cls_handover != 0;
-        if (handed_over) {
-            ArgmaxArgs &f = a.fin;
-            f.token_ptr = s->d_token; f.pos_ptr = s->d_pos; f.prompt = s->d_prompt;
-            f.n_prompt_ptr = s->d_n_prompt; f.out_tokens = s->d_out_tokens; f.argmax_out = s->d_argmax;
-            f.tok_emb = w->tok_emb; f.x = s->x; f.dim = c.dim; f.advance = 1;
-            a.fin_counter = s->d_fin_cnt;
-        }
         L2Z_LAUNCH(KIND_CLS, launch_matvec(a, PRO_RMS, fuse ? EPI_ARGMAX : EPI_STORE, mb, g_cus, st,
                                            &grid, &pushed));
         s->n_part = fuse ? grid : 0;
     }
     L2Z_TRY(gather(s->logits, sh.v_loc));
-    if (with_step && want() && !handed_over) {
+    if (with_step && want()) {
         ArgmaxArgs a = {};
         a.logits = s->logits; a.vocab = c.vocab_size; a.token_ptr = s->d_token;
         if (s->n_part > 0) { a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.n_part = s->n_part; }

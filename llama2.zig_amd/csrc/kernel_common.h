@@ -344,6 +344,46 @@ __device__ __forceinline__ void block_softmax(float *att, int T, float *scratch)
     __syncthreads();
 }
 
+// ---------------------------------------------------------------------------
+// Attention for one head per block (main.zig:361-389).
+// Thread (g, c): group g of TPR lanes walks timesteps t = g, g+G, ...; lane c
+// owns float4 column(s) c of the head.
+// ---------------------------------------------------------------------------
+struct AttnGeom {
+    int E;    // elements per head row in load units (head_size/4 if VEC else head_size)
+    int TPR;  // lanes per row: power of two, <= 64
+    int G;    // groups per block
+};
+
+__host__ __device__ inline AttnGeom attn_geom(int head_size, bool vec, int block = kBlock)
+{
+    AttnGeom g;
+    g.E = vec ? head_size >> 2 : head_size;
+    int t = 1;
+    while (t < g.E && t < 64) t <<= 1;
+    g.TPR = t;
+    g.G = block / t;
+    return g;
+}
+
+// Softmax over att[0..T) (main.zig:687-706) computed redundantly by every wave --
+// each wave reduces max and sum over ALL T with the same instruction sequence, so
+// all waves hold bit-identical (max, sum) without any cross-wave barrier -- and
+// wave w normalises the entries t = w*64 + lane, + blockDim, ...
+// The normalised weights go to a second buffer, so no wave overwrites what another still reads.
+__device__ __forceinline__ void wave_softmax(const float *att, float *prob, int T)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    float m = -INFINITY;
+    for (int t = lane; t < T; t += kWave) m = fmaxf(m, att[t]);
+    m = wave_max(m);
+    float s = 0.0f;
+    for (int t = lane; t < T; t += kWave) s += expf(att[t] - m);  // :699
+    s = wave_sum(s);
+    for (int t = wave * kWave + lane; t < T; t += nw * kWave) prob[t] = expf(att[t] - m) / s;  // :704
+    __syncthreads();
+}
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <typename K>

@@ -119,11 +119,9 @@ struct MatvecArgs {
     int push_gi;              // index of the gather the outputs belong to
     // x is a gathered vector that is read as LL words from this rank's landing slot (xin.slots != null)
     LLIn xin;
-    // EPI_ARGMAX, greedy step on one GPU: the block that finishes LAST reduces the per-block
-    // candidates and performs the loop hand-over itself (what argmax_kernel does as a separate
-    // launch otherwise).  fin_counter: one int, zero between launches.  null: no hand-over.
-    int *fin_counter;
-    ArgmaxArgs fin;
+    // narrow-row kernels: cacheable instead of non-temporal weight loads -- for models whose layer
+    // weights fit the L2s and are found there again by the next token (runstate decides)
+    int plain_loads;
 };
 
 // main.zig:361-389: scores, softmax, att.V for the local heads of one layer
@@ -140,16 +138,24 @@ struct AttnArgs {
     const P2pArgs *push;   // as in MatvecArgs, for xb (fast / split-combine kernels); may be null
     const int *push_ctl;
     int push_gi;
-    // one-block-per-head kernels: blocks past n_head_blocks (set by the launcher) read
-    // pf_floats floats at pf_ptr and drop them -- the next launch's weights, pulled into the
-    // on-die cache by CUs that would otherwise idle.  pf_ptr null / pf_blocks 0: none.
-    const float *pf_ptr;
-    size_t pf_floats;
-    int pf_blocks;
-    float *pf_sink;        // >= pf_blocks floats (never written in practice)
-    int n_head_blocks;
 };
 
+
+// fused_small.hip: rmsnorm + q/k/v rows + RoPE + KV write + attention of one head per block
+// (main.zig:305-389) for small cache-resident MHA models; one launch instead of two
+struct FusedQkvAttnArgs {
+    const float *wq, *wk, *wv;   // this layer: (dim, dim) each (MHA: kv_dim == dim)
+    const float *rms_w, *x;      // (dim)
+    float *q_out;                // RunState.q (dim)
+    float *kcache, *vcache;      // this layer: (seq_len, kv_dim); row pos is written
+    float *xb;                   // (dim) attention output
+    const int *pos_ptr;
+    const float2 *rope;
+    int n;                       // dim
+    int head_size, seq_len, kv_dim;
+};
+bool fused_qkv_attn_supported(int dim, int n_heads, int n_kv_heads, int seq_len, int n_cus);
+hipError_t launch_fused_qkv_attn(const FusedQkvAttnArgs &a, int n_heads, hipStream_t st);
 
 // Launchers (matvec.hip, attention.hip, misc_kernels.hip).  All return a hipError_t from the launch.
 // pushed: set to whether a.push was honoured (row kernel only)

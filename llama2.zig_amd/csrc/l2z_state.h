@@ -84,9 +84,7 @@ struct l2z_runstate {
     int *d_part_idx = nullptr;
     int n_part = 0;               // 0: argmax scans the logits instead
     float *d_attn_part = nullptr; // split attention: per (head, chunk) partials
-    int *d_fin_cnt = nullptr;     // classifier launch: blocks finished (zero between launches)
     int *d_attn_cnt = nullptr;    // split attention: arrivals per local head (zero between launches)
-    float *d_pf_sink = nullptr;   // prefetch blocks' never-written sink (one float per CU)
     int attn_nch = 0;             // 0: one block per head at every position
     int attn_split_pos = 0;       // positions >= this use the split form (host picks the graph)
     // graphs, keyed by the uid of the weights they were captured with (a freed object's address
@@ -103,6 +101,7 @@ struct l2z_runstate {
     int n_gathers = 0;        // gathers per forward pass at world > 1: 4 per layer + logits
     bool ll_consume = false;  // peer-write transport, consumer side: mat-vecs read their gathered input
                               // as LL words from the landing slot; no gather launch except the logits
+    bool plain_layer_loads = false;  // layer weights are L2 resident from token to token: cacheable loads
     bool fused_qkv_attn = false;  // small models: qkv + RoPE + KV write + attention in one launch
     int max_blocks = 0;
 };

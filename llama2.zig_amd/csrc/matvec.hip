@@ -221,7 +221,12 @@ struct MvGeom {
 // Issue one batch: U float4 of row a and of row b at columns c0 + k*LPR.  Columns past
 // the row end are clamped to its last float4: the matching x entries in LDS are the
 // zero padding, so they add exactly 0 (weights are finite) -- no predicated loads.
-template <int LPR>
+// NTL: non-temporal loads (weights that stream from HBM once per token); plain loads for models
+// whose per-layer weights stay in the L2s from one token to the next (launch_matvec decides)
+template <bool NTL>
+__device__ __forceinline__ v4f ldg_w(const v4f *p) { return NTL ? ldg_nt(p) : *p; }
+
+template <int LPR, bool NTL>
 __device__ __forceinline__ void mv_load(const float *pa, const float *pb, int c0, int cb, int n4,
                                         v4f (&wa)[MvGeom<LPR>::U], v4f (&wb)[MvGeom<LPR>::U])
 {
@@ -234,16 +239,16 @@ __device__ __forceinline__ void mv_load(const float *pa, const float *pb, int c0
 #pragma unroll
         for (int k = 0; k < U; k++) {
             const int off = (cb + 64 * k < n4) ? 64 * k : 0;  // wave-uniform
-            wa[k] = ldg_nt(a4 + c0 + off);
-            wb[k] = ldg_nt(b4 + c0 + off);
+            wa[k] = ldg_w<NTL>(a4 + c0 + off);
+            wb[k] = ldg_w<NTL>(b4 + c0 + off);
         }
     } else {
 #pragma unroll
         for (int k = 0; k < U; k++) {
             int c = c0 + LPR * k;
             c = c < n4 ? c : n4 - 1;
-            wa[k] = ldg_nt(a4 + c);
-            wb[k] = ldg_nt(b4 + c);
+            wa[k] = ldg_w<NTL>(a4 + c);
+            wb[k] = ldg_w<NTL>(b4 + c);
         }
     }
 }
@@ -261,91 +266,13 @@ __device__ __forceinline__ void mv_consume(const v4f *xs4, int c0, const v4f (&w
     }
 }
 
-// EPI_ARGMAX tail, all threads of the block: thread 0 holds the block's candidate (bv, bi).  It is
-// published write-through; with a.fin_counter set, the block that arrives last (every other block
-// has then staged x and stored its logits and candidate) reduces the gridDim.x candidates with the
-// strict '>' / lowest-index rule of main.zig:715-726 and hands the loop over to the next step
-// (main.zig:999-1003, :1036, :295-296) -- the separate argmax launch of the step is gone.
-__device__ __forceinline__ void cls_finish(const MatvecArgs &a, float bv, int bi, float *scratch)
-{
-    int *flag = (int *)scratch + 16;
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(a.part_val + blockIdx.x, bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.part_idx + blockIdx.x, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int last = 0;
-        if (a.fin_counter != nullptr) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // candidate (and this wave's logits) out
-            last = __hip_atomic_fetch_add(a.fin_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-                   (int)gridDim.x - 1;
-            if (last) {
-                __hip_atomic_store(a.fin_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-        }
-        *flag = last;
-    }
-    __syncthreads();
-    if (!*flag) return;
-    const int tid = threadIdx.x;
-    float best = -INFINITY;
-    int idx = 0x7fffffff;
-    for (int i = tid; i < (int)gridDim.x; i += kBlock) {
-        const float v = a.part_val[i];
-        const int id = a.part_idx[i];
-        if (id != 0x7fffffff && (idx == 0x7fffffff || v > best || (v == best && id < idx))) {
-            best = v;
-            idx = id;
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(idx, o, 64);
-        if (oi != 0x7fffffff && (idx == 0x7fffffff || ov > best || (ov == best && oi < idx))) {
-            best = ov;
-            idx = oi;
-        }
-    }
-    if ((tid & 63) == 0) {
-        scratch[tid >> 6] = best;
-        scratch[kWaves + (tid >> 6)] = __int_as_float(idx);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < kWaves; w++) {
-            const float ov = scratch[w];
-            const int oi = __float_as_int(scratch[kWaves + w]);
-            if (oi != 0x7fffffff && (idx == 0x7fffffff || ov > best || (ov == best && oi < idx))) {
-                best = ov;
-                idx = oi;
-            }
-        }
-        if (idx == 0x7fffffff) idx = 0;
-        const ArgmaxArgs &f = a.fin;
-        if (f.argmax_out) *f.argmax_out = idx;
-        int next = idx;
-        const int pos = *f.pos_ptr;
-        if (pos < *f.n_prompt_ptr) next = f.prompt[pos];  // :999-1000
-        f.out_tokens[pos] = next;
-        *f.token_ptr = next;                              // :1036
-        *f.pos_ptr = pos + 1;                             // :995
-        ((int *)scratch)[17] = next;
-    }
-    __syncthreads();
-    {   // next step's embedding row -> x (main.zig:295-296)
-        const int next = ((int *)scratch)[17];
-        const float *row = a.fin.tok_emb + (size_t)next * (size_t)a.fin.dim;
-        for (int i = tid; i < a.fin.dim; i += kBlock) a.fin.x[i] = row[i];
-    }
-}
-
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v)
 {
     return lanes_sum(v, LPR);
 }
 
-template <int PRO, int EPI, int LPR, int XC, bool LL>
+template <int PRO, int EPI, int LPR, int XC, bool LL, bool NTL>
 __global__ __launch_bounds__(kBlock) void matvec_kernel(const MatvecArgs a)
 {
     using G = MvGeom<LPR>;
@@ -381,7 +308,7 @@ __global__ __launch_bounds__(kBlock) void matvec_kernel(const MatvecArgs a)
     v4f wa[U], wb[U];
     EpiIn ein = epi_prefetch<EPI>(m, (has_unit ? u : 0) * RW + grp, cl == 0 && has_unit);
     EpiIn ein_next = ein;
-    mv_load<LPR>(pa, pb, cl, 0, n4, wa, wb);
+    mv_load<LPR, NTL>(pa, pb, cl, 0, n4, wa, wb);
     if constexpr (LL)
         xstage_finish_ll<PRO, XC>(poll, a.rms_w, m.n, n4_pad, xl, gr, xs, scratch);
     else
@@ -405,7 +332,7 @@ __global__ __launch_bounds__(kBlock) void matvec_kernel(const MatvecArgs a)
                 pair_rows<EPI>(m, u_next * RW + grp, pa, pb);
                 ein_next = epi_prefetch<EPI>(m, u_next * RW + grp, cl == 0);
             }
-            mv_load<LPR>(pa, pb, cl + b_next * (LPR * U), b_next * (LPR * U), n4, wa, wb);
+            mv_load<LPR, NTL>(pa, pb, cl + b_next * (LPR * U), b_next * (LPR * U), n4, wa, wb);
         }
         if (unit_done) {
             const float sa = group_sum<LPR>(hsum4(acc_a));
@@ -444,11 +371,9 @@ __global__ __launch_bounds__(kBlock) void matvec_kernel(const MatvecArgs a)
             scratch[kWaves + wave] = __int_as_float(best_i);
         }
         __syncthreads();
-        float bv = -INFINITY;
-        int bi = 0x7fffffff;
         if (threadIdx.x == 0) {
-            bv = scratch[0];
-            bi = __float_as_int(scratch[kWaves]);
+            float bv = scratch[0];
+            int bi = __float_as_int(scratch[kWaves]);
             for (int w = 1; w < kWaves; w++) {
                 const float ov = scratch[w];
                 const int oi = __float_as_int(scratch[kWaves + w]);
@@ -456,9 +381,9 @@ __global__ __launch_bounds__(kBlock) void matvec_kernel(const MatvecArgs a)
                     bv = ov; bi = oi;
                 }
             }
+            a.part_val[blockIdx.x] = bv;
+            a.part_idx[blockIdx.x] = bi;
         }
-        __syncthreads();  // scratch is reused below
-        cls_finish(a, bv, bi, scratch);
     }
 }
 
@@ -575,9 +500,9 @@ __global__ __launch_bounds__(kBlock) void matvec_row_kernel(const MatvecArgs a)
         u = u_next;
         b = b_next;
     }
-    if (EPI == EPI_ARGMAX) {  // units ascend within a block: thread 0 kept the first index
-        __syncthreads();
-        cls_finish(a, best_v, best_i, scratch);
+    if (EPI == EPI_ARGMAX && tid == 0) {  // units ascend within a block: first index kept
+        a.part_val[blockIdx.x] = best_v;
+        a.part_idx[blockIdx.x] = best_i;
     }
 }
 
@@ -616,19 +541,25 @@ struct MvLaunch {
     int lpr, u;
 };
 
-template <int PRO, int EPI, int LPR, int XC, bool LL>
+template <int PRO, int EPI, int LPR, int XC, bool LL, bool NTL>
 MvLaunch mv_entry()
 {
-    return {reinterpret_cast<const void *>(&matvec_kernel<PRO, EPI, LPR, XC, LL>), LPR, MvGeom<LPR>::U};
+    return {reinterpret_cast<const void *>(&matvec_kernel<PRO, EPI, LPR, XC, LL, NTL>), LPR, MvGeom<LPR>::U};
 }
 
+// plain: cacheable weight loads (small rows only: LPR < 64, unsharded)
 template <int PRO, int EPI, bool LL>
-MvLaunch mv_pick(int lpr, bool big_x)
+MvLaunch mv_pick(int lpr, bool big_x, bool plain)
 {
-    if (lpr == 8) return mv_entry<PRO, EPI, 8, 4, LL>();
-    if (lpr == 16) return mv_entry<PRO, EPI, 16, 4, LL>();
-    if (lpr == 32) return mv_entry<PRO, EPI, 32, 4, LL>();
-    return big_x ? mv_entry<PRO, EPI, 64, 12, LL>() : mv_entry<PRO, EPI, 64, 4, LL>();
+    if constexpr (!LL) {
+        if (plain && lpr == 8) return mv_entry<PRO, EPI, 8, 4, false, false>();
+        if (plain && lpr == 16) return mv_entry<PRO, EPI, 16, 4, false, false>();
+        if (plain && lpr == 32) return mv_entry<PRO, EPI, 32, 4, false, false>();
+    }
+    if (lpr == 8) return mv_entry<PRO, EPI, 8, 4, LL, true>();
+    if (lpr == 16) return mv_entry<PRO, EPI, 16, 4, LL, true>();
+    if (lpr == 32) return mv_entry<PRO, EPI, 32, 4, LL, true>();
+    return big_x ? mv_entry<PRO, EPI, 64, 12, LL, true>() : mv_entry<PRO, EPI, 64, 4, LL, true>();
 }
 
 template <int PRO, int EPI, bool LL>
@@ -659,13 +590,13 @@ const void *mv_row_pick(int pro, int epi, bool big_x, bool ll)
     return nullptr;
 }
 
-MvLaunch mv_pick_pe(int pro, int epi, int lpr, bool big_x, bool vec, bool ll)
+MvLaunch mv_pick_pe(int pro, int epi, int lpr, bool big_x, bool vec, bool ll, bool plain)
 {
 #define L2Z_MV(P, E)                                                                      \
     if (pro == P && epi == E && !ll)                                                      \
-        return vec ? mv_pick<P, E, false>(lpr, big_x)                                     \
+        return vec ? mv_pick<P, E, false>(lpr, big_x, plain)                              \
                    : MvLaunch{reinterpret_cast<const void *>(&matvec_scalar_kernel<P, E>), 0, 0};
-#define L2Z_MV_LL(P, E) if (pro == P && epi == E && ll && vec) return mv_pick<P, E, true>(lpr, big_x);
+#define L2Z_MV_LL(P, E) if (pro == P && epi == E && ll && vec) return mv_pick<P, E, true>(lpr, big_x, false);
     L2Z_MV(PRO_NONE, EPI_STORE)
     L2Z_MV(PRO_NONE, EPI_RESID)
     L2Z_MV(PRO_RMS, EPI_STORE)
@@ -677,7 +608,7 @@ MvLaunch mv_pick_pe(int pro, int epi, int lpr, bool big_x, bool vec, bool ll)
     L2Z_MV_LL(PRO_RMS, EPI_SWIGLU)
 #undef L2Z_MV
 #undef L2Z_MV_LL
-    if (pro == PRO_RMS && epi == EPI_ARGMAX && vec && !ll) return mv_pick<PRO_RMS, EPI_ARGMAX, false>(lpr, big_x);
+    if (pro == PRO_RMS && epi == EPI_ARGMAX && vec && !ll) return mv_pick<PRO_RMS, EPI_ARGMAX, false>(lpr, big_x, plain);
     return {nullptr, 0, 0};
 }
 
@@ -747,7 +678,7 @@ hipError_t launch_matvec(const MatvecArgs &a_in, int pro, int epi, int max_block
     const bool use_row = vec && tn.row_kernel && n4 >= 1024 && (n4 % 64) == 0;
     const bool ll = a.xin.slots != nullptr;
     if (ll && !vec) return hipErrorNotSupported;  // callers ask matvec_ll_supported() first
-    MvLaunch k = mv_pick_pe(pro, epi, lpr, a.n > 4096, vec, ll);
+    MvLaunch k = mv_pick_pe(pro, epi, lpr, a.n > 4096, vec, ll, a.plain_loads != 0);
     if (use_row) k.fn = mv_row_pick(pro, epi, a.n > 4096, ll);
     if (k.fn == nullptr) return hipErrorInvalidValue;
     size_t lds;

@@ -42,6 +42,17 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
     // Emulated ranks are driven stage by stage, never captured.
     if (comm && comm->world > 1 && !comm->nccl && !comm->p2p) s->use_graphs = false;
     if (comm && comm->nccl && !comm_uses_p2p(comm) && tn.comm_graph == 0) s->use_graphs = false;
+    {   // Cacheable weight loads for models whose per-layer matrices stay in the L2s between tokens:
+        // block b runs on XCD b % 8 and reads the same rows every token, so each 4 MiB L2 sees 1/8 of
+        // the layer weights (stories15M: 26 MB of layers -> 3.2 MB per XCD).  The classifier
+        // (V x dim, 37 MB there) keeps streaming non-temporally so that it does not evict them.
+        const size_t layer_bytes = (size_t)c.n_layers * 4 * ((size_t)2 * c.dim * c.dim + (size_t)2 * c.dim * sh.kvd_loc * sh.world +
+                                                              (size_t)3 * c.dim * c.hidden_dim);
+        const bool fits = layer_bytes / 8 <= ((size_t)7 << 19);  // 3.5 MiB of each XCD's 4
+        s->plain_layer_loads = sh.world == 1 && (tn.nt_small == 0 || (tn.nt_small < 0 && fits));
+    }
+    s->fused_qkv_attn = sh.world == 1 && tn.fuse_small != 0 &&
+                        fused_qkv_attn_supported(c.dim, c.n_heads, c.n_kv_heads, c.seq_len, g_cus);
     s->n_gathers = 4 * c.n_layers + 1;
     if (comm_uses_p2p(comm)) {
         // the producers store straight into the peers' landing slots: they must hold the longest vector
@@ -76,7 +87,6 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
     alloc((void **)&s->d_out_tokens, (size_t)c.seq_len * 4);
     alloc((void **)&s->d_part_val, (size_t)matvec_max_grid(g_cus) * 4);
     alloc((void **)&s->d_part_idx, (size_t)matvec_max_grid(g_cus) * 4);
-    alloc((void **)&s->d_fin_cnt, 4);
     {   // Attention form by position.  One block per head is fastest while the
         // context is short; from pos 256 on, the split form (nch blocks per head + combine)
         // wins and keeps winning (2.4x at pos 2047 on the 7B shape).  The host knows pos, so it
@@ -96,7 +106,6 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
             alloc((void **)&s->d_attn_part, attention_split_part_floats(sh.heads_loc, sh.hs, nch) * 4);
             alloc((void **)&s->d_attn_cnt, (size_t)sh.heads_loc * 4);
         }
-        alloc((void **)&s->d_pf_sink, (size_t)(g_cus > 0 ? g_cus : 256) * 4);
     }
     if (comm_uses_p2p(comm) && e == hipSuccess) {
         // consumer-side gathers need every producer to push and every consumer to read LL words:
@@ -156,7 +165,7 @@ extern "C" void l2z_runstate_free(l2z_runstate *s)
     }
     void *ptrs[] = {s->x, s->xb, s->hb, s->q, s->logits, s->key_cache, s->value_cache, s->rope,
                     s->d_token, s->d_pos, s->d_prompt, s->d_n_prompt, s->d_out_tokens, s->d_argmax,
-                    s->d_part_val, s->d_part_idx, s->d_fin_cnt, s->d_attn_part, s->d_attn_cnt, s->d_pf_sink, s->pf_x, s->pf_xn, s->pf_q,
+                    s->d_part_val, s->d_part_idx, s->d_attn_part, s->d_attn_cnt, s->pf_x, s->pf_xn, s->pf_q,
                     s->pf_att, s->pf_h1, s->pf_tokens, s->d_push};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);

@@ -20,12 +20,11 @@ Tunables read_env()
     env_int("L2Z_ROW_BLOCKS", &t.row_blocks);
     env_int("L2Z_MAX_BLOCKS_PER_CU", &t.max_blocks_per_cu);
     env_int("L2Z_GRID_CAP", &t.grid_cap);
+    env_int("L2Z_NT_SMALL", &t.nt_small);
     env_int("L2Z_ATTN_BLOCK", &t.attn_block);
     env_int("L2Z_ATTN_SPLIT", &t.attn_split);
     env_int("L2Z_ATTN_SPLIT_POS", &t.attn_split_pos);
-    env_int("L2Z_ATTN_PREFETCH", &t.attn_prefetch);
     env_int("L2Z_FUSE_SMALL", &t.fuse_small);
-    env_int("L2Z_CLS_HANDOVER", &t.cls_handover);
     env_int("L2Z_NO_GRAPH", &t.no_graph);
     env_int("L2Z_COMM_GRAPH", &t.comm_graph);
     if (const char *e = getenv("L2Z_COMM")) t.prefer_rccl = strcmp(e, "rccl") == 0;
@@ -64,10 +63,10 @@ bool tunables_set(const char *name, long long v)
     Tunables &t = mutable_tunables();
     struct { const char *n; int *p; } ints[] = {
         {"L2Z_ROW_KERNEL", &t.row_kernel}, {"L2Z_ROW_BLOCKS", &t.row_blocks},
-        {"L2Z_MAX_BLOCKS_PER_CU", &t.max_blocks_per_cu}, {"L2Z_GRID_CAP", &t.grid_cap},
+        {"L2Z_MAX_BLOCKS_PER_CU", &t.max_blocks_per_cu}, {"L2Z_GRID_CAP", &t.grid_cap}, {"L2Z_NT_SMALL", &t.nt_small},
         {"L2Z_ATTN_BLOCK", &t.attn_block}, {"L2Z_ATTN_SPLIT", &t.attn_split},
-        {"L2Z_ATTN_SPLIT_POS", &t.attn_split_pos}, {"L2Z_ATTN_PREFETCH", &t.attn_prefetch},
-        {"L2Z_FUSE_SMALL", &t.fuse_small}, {"L2Z_CLS_HANDOVER", &t.cls_handover}, {"L2Z_NO_GRAPH", &t.no_graph},
+        {"L2Z_ATTN_SPLIT_POS", &t.attn_split_pos}, 
+        {"L2Z_FUSE_SMALL", &t.fuse_small}, {"L2Z_NO_GRAPH", &t.no_graph},
         {"L2Z_COMM_GRAPH", &t.comm_graph}, {"L2Z_COMM_RCCL", &t.prefer_rccl},
         {"L2Z_P2P_PUSH", &t.p2p_push}, {"L2Z_P2P_CONSUME", &t.p2p_consume},
         {"L2Z_PREFILL", &t.prefill}, {"L2Z_PF_CHUNK", &t.pf_chunk},

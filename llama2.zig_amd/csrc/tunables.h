@@ -11,6 +11,8 @@ struct Tunables {
     int row_kernel = 1;        // L2Z_ROW_KERNEL      0: wide rows take the per-wave kernel too
     int row_blocks = 2;        // L2Z_ROW_BLOCKS      resident row-kernel blocks per CU
     int max_blocks_per_cu = 8; // L2Z_MAX_BLOCKS_PER_CU
+    int nt_small = -1;         // L2Z_NT_SMALL        1: always non-temporal weight loads, 0: cacheable loads in the
+                               //                     narrow-row kernels, -1: cacheable when a layer fits the L2s
     int grid_cap = 0;          // L2Z_GRID_CAP        max blocks of one mat-vec launch (0: none); set when
                                //                     several ranks share one GPU so that a kernel
                                //                     waiting for a peer leaves the peer room to run
@@ -19,9 +21,6 @@ struct Tunables {
     int attn_split = -1;       // L2Z_ATTN_SPLIT      0: never split; n > 0: n chunks at every position
                                //                     (changes rounding: chunk count is part of the arithmetic)
     int attn_split_pos = -1;   // L2Z_ATTN_SPLIT_POS  first position that uses the split form (default 256)
-    int attn_prefetch = 100;   // L2Z_ATTN_PREFETCH   % of wo the idle CUs of the short-context attention launch
-                               //                     pull into the on-die cache (0: none)
-    int cls_handover = 1;      // L2Z_CLS_HANDOVER    0: argmax + loop hand-over stay a separate launch
     int fuse_small = 1;        // L2Z_FUSE_SMALL      0: small models keep separate qkv / attention launches
     // --- graphs / transport (runstate.cpp, comm.cpp, forward.cpp) ---
     int no_graph = 0;          // L2Z_NO_GRAPH        1: launch eagerly

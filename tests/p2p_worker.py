@@ -47,6 +47,9 @@ def main() -> None:
         except B.L2ZError as e:
             assert e.code == B.ERR_COMM, e
             open(os.path.join(d, f"ok_{rank}"), "w").write(str(e))
+            t0 = time.time()  # keep the arena alive until every rank has mapped it and reported
+            while not all(os.path.exists(os.path.join(d, f"ok_{r}")) for r in range(world)) and time.time() - t0 < 60:
+                time.sleep(0.02)
             comm.close()
             return
         raise SystemExit("runstate_init accepted landing slots that are too small")

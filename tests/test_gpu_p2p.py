@@ -59,8 +59,9 @@ MODE_ENV = {"consume": {}, "gather": {"L2Z_P2P_CONSUME": "0"}, "nopush": {"L2Z_P
 
 
 @pytest.mark.parametrize("model,mode", CASES, ids=[f"{m[0]}-x{m[3]}-{mode}" for m, mode in CASES])
-def test_multiprocess_peer_write_gather_is_bit_identical(gpu, ck, tmp_path, model, mode):
+def test_multiprocess_peer_write_gather_is_bit_identical(gpu, ck, tmp_path, model, mode, options):
     name, kw, shared, world = model
+    options(L2Z_FUSE_SMALL=0)  # the unsharded reference runs the launches the shards run
     cfg = ck.Config(**kw)
     steps = min(cfg.seq_len - 2, 300)
     on_device = cfg.dim >= 4096  # big shapes: seeded weights generated on the device by every rank

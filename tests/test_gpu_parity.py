@@ -388,6 +388,60 @@ def test_golden_toy_checkpoints_on_gpu(gpu, ck):
         s.close(); w.close()
 
 
+FUSED_SHAPES = [  # MHA shapes the fused qkv+attention launch takes (fused_small.hip)
+    ("stories15M-3layers", dict(dim=288, hidden_dim=768, n_layers=3, n_heads=6, n_kv_heads=6, vocab_size=4096, seq_len=256)),
+    ("hs12", dict(dim=48, hidden_dim=128, n_layers=2, n_heads=4, n_kv_heads=4, vocab_size=300, seq_len=24)),
+    ("hs64-one-head", dict(dim=64, hidden_dim=160, n_layers=2, n_heads=1, n_kv_heads=1, vocab_size=200, seq_len=64)),
+    ("hs128-one-head", dict(dim=128, hidden_dim=256, n_layers=1, n_heads=1, n_kv_heads=1, vocab_size=300, seq_len=128)),
+]
+
+
+@pytest.mark.parametrize("name,kw", FUSED_SHAPES, ids=[c[0] for c in FUSED_SHAPES])
+def test_fused_qkv_attention_launch_vs_oracle_and_unfused(gpu, ck, orc, name, kw, options):
+    """Small MHA models run rmsnorm + q/k/v + RoPE + KV write + attention of a head as ONE launch
+    (main.zig:305-389).  Against the oracle at every position of a full context (logits, K/V cache
+    rows, q), and against the separate launches (L2Z_FUSE_SMALL=0): same tokens, logits within the
+    tolerance (the summation orders differ, the values do not)."""
+    cfg = ck.Config(**kw)
+    blob = ck.synth_blob(cfg, True, seed=88)
+    w = gpu.Weights(cfg, blob, True)
+    s_f = gpu.RunState(cfg)
+    options(L2Z_FUSE_SMALL=0)
+    s_u = gpu.RunState(cfg)
+    options(L2Z_FUSE_SMALL=1)
+    m = orc.Model(cfg.as_i32(), blob, True)
+    ref_toks, margins = m.generate_greedy([4, 5], cfg.seq_len)
+    for s in (s_f, s_u):
+        s.greedy_begin([4, 5])
+        assert np.array_equal(s.greedy_run(w, cfg.seq_len), ref_toks), (name, margins.min())
+    m2 = orc.Model(cfg.as_i32(), blob, True)
+    tok, worst = 1, 0.0
+    kvd = cfg.kv_dim
+    for pos in range(cfg.seq_len):
+        ref = m2.transformer(tok, pos)
+        s_f.transformer(tok, pos, w)
+        got = s_f.logits()
+        worst = max(worst, float(np.abs(got - ref).max()))
+        np.testing.assert_allclose(got, ref, rtol=LOGIT_RTOL, atol=LOGIT_ATOL, err_msg=f"{name} pos {pos}")
+        if pos in (0, 1, cfg.seq_len // 2, cfg.seq_len - 1):
+            s_u.transformer(tok, pos, w)
+            np.testing.assert_allclose(got, s_u.logits(), rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
+            L = cfg.n_layers - 1  # the last layer's cache row and q of this position
+            np.testing.assert_allclose(s_f.read("key_cache", (L * cfg.seq_len + pos) * kvd, kvd),
+                                       m2.state("key_cache", cfg.n_layers * cfg.seq_len * kvd)[(L * cfg.seq_len + pos) * kvd:][:kvd],
+                                       rtol=2e-5, atol=2e-5)
+            np.testing.assert_allclose(s_f.read("value_cache", (L * cfg.seq_len + pos) * kvd, kvd),
+                                       m2.state("value_cache", cfg.n_layers * cfg.seq_len * kvd)[(L * cfg.seq_len + pos) * kvd:][:kvd],
+                                       rtol=2e-5, atol=2e-5)
+            np.testing.assert_allclose(s_f.read("q", 0, cfg.dim), m2.state("q", cfg.dim), rtol=2e-5, atol=2e-5)
+        else:
+            s_u.transformer(tok, pos, w)  # keep its cache in step
+        tok = int(ref_toks[pos])
+    print(f"fused qkv+attention {name}: max |logit diff| vs oracle {worst:.2e}")
+    for o in (s_f, s_u, w, m, m2):
+        o.close()
+
+
 def test_rccl_call_path_world1(gpu, ck):
     """A 1-rank RCCL communicator exercises the N>1 code path on one GPU: dlopen of
     librccl, ncclCommInitRank, the in-place ncclAllGather after every shard step, eager
@@ -412,11 +466,12 @@ def test_rccl_call_path_world1(gpu, ck):
 
 @pytest.mark.parametrize("world", [2, 4, 8])
 @pytest.mark.parametrize("from_blob", [True, False], ids=["uploaded", "synthetic"])
-def test_sharded_hip_path_emulated_ranks(gpu, ck, world, from_blob):
+def test_sharded_hip_path_emulated_ranks(gpu, ck, world, from_blob, options):
     """The real HIP shard path (sharded upload / on-device generation, shard offsets, sharded
     KV cache, GQA head mapping) for N = 2, 4, 8 emulated ranks on one GPU: every rank's
     logits must be BIT-IDENTICAL to the unsharded pass (scheme A: a row's dot product does
     not depend on which rank owns it)."""
+    options(L2Z_FUSE_SMALL=0)  # the unsharded reference runs the launches the shards run
     cfg = ck.Config(dim=128, hidden_dim=352, n_layers=2, n_heads=16, n_kv_heads=8, vocab_size=512, seq_len=16)
     seed, shared = 17, False
     blob = ck.synth_blob(cfg, shared, seed)
