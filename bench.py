@@ -199,7 +199,7 @@ def main() -> None:
     if world > n_dev:
         # ranks share a chip: a mat-vec launch that may be polling for a peer's words must leave the
         # peer's kernels room to run (never needed with a GPU per rank)
-        B.option_set("L2Z_GRID_CAP", max(32, 512 // ((world + n_dev - 1) // n_dev)))
+        B.option_set("L2Z_GRID_CAP", max(64, 1024 // ((world + n_dev - 1) // n_dev)))
 
     def all_ok(ok: bool) -> bool:
         flags = [None] * world
@@ -409,7 +409,45 @@ def main() -> None:
             c15, sh15 = shapes["stories15M"]
             n15, dt15, s15, w15 = run_once(B, c15, sh15, args.seed, 255, 1)
             s15.close(); w15.close()
+            # stories110M (BASELINE config 3's shape): 438 MB of weights per token do not fit the
+            # 256 MB Infinity Cache, so an HBM fraction is meaningful, though launch latency dominates
+            c110, sh110 = shapes["stories110M"]
+            n110, dt110, s110, w110 = run_once(B, c110, sh110, args.seed, 255, 1)
+            s110.close(); w110.close()
+            wb110 = weight_bytes_by_kind(c110)
+            bytes110 = sum(wb110[k] * (1 if k == "cls" else c110.n_layers) for k in wb110)
+            # long context on the headline shape: the prompt fills the cache through the batched
+            # prefill, then 32 greedy positions near the end of the 2048-token context are timed
+            long_ctx = None
+            if args.workload == "llama2-7b":
+                try:
+                    w7 = B.Weights(cfg, None, shared, seed=args.seed)
+                    s7 = B.RunState(cfg)
+                    n_p = cfg.seq_len - 48
+                    prompt = np.random.default_rng(1).integers(2, cfg.vocab_size, n_p).tolist()
+                    s7.greedy_begin(prompt)
+                    s7.greedy_run(w7, n_p + 8)  # prefill + 8 warm-up positions
+                    s7.synchronize()
+                    t0 = time.perf_counter()
+                    n_l = len(s7.greedy_run(w7, 32))
+                    s7.synchronize()
+                    dtl = time.perf_counter() - t0
+                    pr = s7.profile_forward(1, cfg.seq_len - 1, w7)
+                    kv_bytes = 8 * cfg.n_layers * (cfg.seq_len - 24) * cfg.kv_dim
+                    long_ctx = {"positions": [n_p + 8, n_p + 8 + n_l - 1], "tokens_per_s": n_l / dtl,
+                                "ms_per_token": dtl / n_l * 1e3,
+                                "attention_us_per_layer_at_last_pos": pr["attn"][0] / max(pr["attn"][1], 1) * 1e3,
+                                "kv_bytes_per_token": kv_bytes,
+                                "hbm_frac_incl_kv": (out["config"]["weight_bytes_per_token"] + kv_bytes)
+                                                    / (dtl / n_l) / 1e9 / HBM_PEAK_GBS}
+                    s7.close(); w7.close()
+                except Exception as e:  # noqa: BLE001
+                    long_ctx = {"error": str(e)}
             out["extra"] = {"prefill": prefill,
+                            "stories110M": {"tokens_per_s": n110 / dt110, "steps": n110,
+                                            "weight_bytes_per_token": bytes110,
+                                            "hbm_frac": bytes110 / (dt110 / n110) / 1e9 / HBM_PEAK_GBS},
+                            "long_context": long_ctx,
                             "stories15M_tokens_per_s": n15 / dt15, "stories15M_steps": n15,
                             # the only figure the reference publishes: 660 tok/s, -t 0,
                             # stories15M, one Ryzen 9 5900X core, Zig 0.11 -- other hardware, indicative

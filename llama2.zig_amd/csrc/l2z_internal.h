@@ -119,9 +119,6 @@ struct MatvecArgs {
     int push_gi;              // index of the gather the outputs belong to
     // x is a gathered vector that is read as LL words from this rank's landing slot (xin.slots != null)
     LLIn xin;
-    // narrow-row kernels: cacheable instead of non-temporal weight loads -- for models whose layer
-    // weights fit the L2s and are found there again by the next token (runstate decides)
-    int plain_loads;
 };
 
 // main.zig:361-389: scores, softmax, att.V for the local heads of one layer

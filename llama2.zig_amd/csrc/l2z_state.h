@@ -101,7 +101,6 @@ struct l2z_runstate {
     int n_gathers = 0;        // gathers per forward pass at world > 1: 4 per layer + logits
     bool ll_consume = false;  // peer-write transport, consumer side: mat-vecs read their gathered input
                               // as LL words from the landing slot; no gather launch except the logits
-    bool plain_layer_loads = false;  // layer weights are L2 resident from token to token: cacheable loads
     bool fused_qkv_attn = false;  // small models: qkv + RoPE + KV write + attention in one launch
     int max_blocks = 0;
 };

@@ -221,12 +221,7 @@ struct MvGeom {
 // Issue one batch: U float4 of row a and of row b at columns c0 + k*LPR.  Columns past
 // the row end are clamped to its last float4: the matching x entries in LDS are the
 // zero padding, so they add exactly 0 (weights are finite) -- no predicated loads.
-// NTL: non-temporal loads (weights that stream from HBM once per token); plain loads for models
-// whose per-layer weights stay in the L2s from one token to the next (launch_matvec decides)
-template <bool NTL>
-__device__ __forceinline__ v4f ldg_w(const v4f *p) { return NTL ? ldg_nt(p) : *p; }
-
-template <int LPR, bool NTL>
+template <int LPR>
 __device__ __forceinline__ void mv_load(const float *pa, const float *pb, int c0, int cb, int n4,
                                         v4f (&wa)[MvGeom<LPR>::U], v4f (&wb)[MvGeom<LPR>::U])
 {
@@ -239,16 +234,16 @@ __device__ __forceinline__ void mv_load(const float *pa, const float *pb, int c0
 #pragma unroll
         for (int k = 0; k < U; k++) {
             const int off = (cb + 64 * k < n4) ? 64 * k : 0;  // wave-uniform
-            wa[k] = ldg_w<NTL>(a4 + c0 + off);
-            wb[k] = ldg_w<NTL>(b4 + c0 + off);
+            wa[k] = ldg_nt(a4 + c0 + off);
+            wb[k] = ldg_nt(b4 + c0 + off);
         }
     } else {
 #pragma unroll
         for (int k = 0; k < U; k++) {
             int c = c0 + LPR * k;
             c = c < n4 ? c : n4 - 1;
-            wa[k] = ldg_w<NTL>(a4 + c);
-            wb[k] = ldg_w<NTL>(b4 + c);
+            wa[k] = ldg_nt(a4 + c);
+            wb[k] = ldg_nt(b4 + c);
         }
     }
 }
@@ -272,7 +267,7 @@ __device__ __forceinline__ float group_sum(float v)
     return lanes_sum(v, LPR);
 }
 
-template <int PRO, int EPI, int LPR, int XC, bool LL, bool NTL>
+template <int PRO, int EPI, int LPR, int XC, bool LL>
 __global__ __launch_bounds__(kBlock) void matvec_kernel(const MatvecArgs a)
 {
     using G = MvGeom<LPR>;
@@ -308,7 +303,7 @@ __global__ __launch_bounds__(kBlock) void matvec_kernel(const MatvecArgs a)
     v4f wa[U], wb[U];
     EpiIn ein = epi_prefetch<EPI>(m, (has_unit ? u : 0) * RW + grp, cl == 0 && has_unit);
     EpiIn ein_next = ein;
-    mv_load<LPR, NTL>(pa, pb, cl, 0, n4, wa, wb);
+    mv_load<LPR>(pa, pb, cl, 0, n4, wa, wb);
     if constexpr (LL)
         xstage_finish_ll<PRO, XC>(poll, a.rms_w, m.n, n4_pad, xl, gr, xs, scratch);
     else
@@ -332,7 +327,7 @@ __global__ __launch_bounds__(kBlock) void matvec_kernel(const MatvecArgs a)
                 pair_rows<EPI>(m, u_next * RW + grp, pa, pb);
                 ein_next = epi_prefetch<EPI>(m, u_next * RW + grp, cl == 0);
             }
-            mv_load<LPR, NTL>(pa, pb, cl + b_next * (LPR * U), b_next * (LPR * U), n4, wa, wb);
+            mv_load<LPR>(pa, pb, cl + b_next * (LPR * U), b_next * (LPR * U), n4, wa, wb);
         }
         if (unit_done) {
             const float sa = group_sum<LPR>(hsum4(acc_a));
@@ -541,25 +536,19 @@ struct MvLaunch {
     int lpr, u;
 };
 
-template <int PRO, int EPI, int LPR, int XC, bool LL, bool NTL>
+template <int PRO, int EPI, int LPR, int XC, bool LL>
 MvLaunch mv_entry()
 {
-    return {reinterpret_cast<const void *>(&matvec_kernel<PRO, EPI, LPR, XC, LL, NTL>), LPR, MvGeom<LPR>::U};
+    return {reinterpret_cast<const void *>(&matvec_kernel<PRO, EPI, LPR, XC, LL>), LPR, MvGeom<LPR>::U};
 }
 
-// plain: cacheable weight loads (small rows only: LPR < 64, unsharded)
 template <int PRO, int EPI, bool LL>
-MvLaunch mv_pick(int lpr, bool big_x, bool plain)
+MvLaunch mv_pick(int lpr, bool big_x)
 {
-    if constexpr (!LL) {
-        if (plain && lpr == 8) return mv_entry<PRO, EPI, 8, 4, false, false>();
-        if (plain && lpr == 16) return mv_entry<PRO, EPI, 16, 4, false, false>();
-        if (plain && lpr == 32) return mv_entry<PRO, EPI, 32, 4, false, false>();
-    }
-    if (lpr == 8) return mv_entry<PRO, EPI, 8, 4, LL, true>();
-    if (lpr == 16) return mv_entry<PRO, EPI, 16, 4, LL, true>();
-    if (lpr == 32) return mv_entry<PRO, EPI, 32, 4, LL, true>();
-    return big_x ? mv_entry<PRO, EPI, 64, 12, LL, true>() : mv_entry<PRO, EPI, 64, 4, LL, true>();
+    if (lpr == 8) return mv_entry<PRO, EPI, 8, 4, LL>();
+    if (lpr == 16) return mv_entry<PRO, EPI, 16, 4, LL>();
+    if (lpr == 32) return mv_entry<PRO, EPI, 32, 4, LL>();
+    return big_x ? mv_entry<PRO, EPI, 64, 12, LL>() : mv_entry<PRO, EPI, 64, 4, LL>();
 }
 
 template <int PRO, int EPI, bool LL>
@@ -590,13 +579,13 @@ const void *mv_row_pick(int pro, int epi, bool big_x, bool ll)
     return nullptr;
 }
 
-MvLaunch mv_pick_pe(int pro, int epi, int lpr, bool big_x, bool vec, bool ll, bool plain)
+MvLaunch mv_pick_pe(int pro, int epi, int lpr, bool big_x, bool vec, bool ll)
 {
 #define L2Z_MV(P, E)                                                                      \
     if (pro == P && epi == E && !ll)                                                      \
-        return vec ? mv_pick<P, E, false>(lpr, big_x, plain)                              \
+        return vec ? mv_pick<P, E, false>(lpr, big_x)                                     \
                    : MvLaunch{reinterpret_cast<const void *>(&matvec_scalar_kernel<P, E>), 0, 0};
-#define L2Z_MV_LL(P, E) if (pro == P && epi == E && ll && vec) return mv_pick<P, E, true>(lpr, big_x, false);
+#define L2Z_MV_LL(P, E) if (pro == P && epi == E && ll && vec) return mv_pick<P, E, true>(lpr, big_x);
     L2Z_MV(PRO_NONE, EPI_STORE)
     L2Z_MV(PRO_NONE, EPI_RESID)
     L2Z_MV(PRO_RMS, EPI_STORE)
@@ -608,7 +597,7 @@ MvLaunch mv_pick_pe(int pro, int epi, int lpr, bool big_x, bool vec, bool ll, bo
     L2Z_MV_LL(PRO_RMS, EPI_SWIGLU)
 #undef L2Z_MV
 #undef L2Z_MV_LL
-    if (pro == PRO_RMS && epi == EPI_ARGMAX && vec && !ll) return mv_pick<PRO_RMS, EPI_ARGMAX, false>(lpr, big_x, plain);
+    if (pro == PRO_RMS && epi == EPI_ARGMAX && vec && !ll) return mv_pick<PRO_RMS, EPI_ARGMAX, false>(lpr, big_x);
     return {nullptr, 0, 0};
 }
 
@@ -678,7 +667,7 @@ hipError_t launch_matvec(const MatvecArgs &a_in, int pro, int epi, int max_block
     const bool use_row = vec && tn.row_kernel && n4 >= 1024 && (n4 % 64) == 0;
     const bool ll = a.xin.slots != nullptr;
     if (ll && !vec) return hipErrorNotSupported;  // callers ask matvec_ll_supported() first
-    MvLaunch k = mv_pick_pe(pro, epi, lpr, a.n > 4096, vec, ll, a.plain_loads != 0);
+    MvLaunch k = mv_pick_pe(pro, epi, lpr, a.n > 4096, vec, ll);
     if (use_row) k.fn = mv_row_pick(pro, epi, a.n > 4096, ll);
     if (k.fn == nullptr) return hipErrorInvalidValue;
     size_t lds;

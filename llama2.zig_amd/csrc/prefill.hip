@@ -49,6 +49,41 @@ struct GemmArgs {
     int head_size;
 };
 
+// epilogue shared by the two tile kernels: per MFMA tile a lane owns one feature and 16 tokens
+template <int EPI, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, v16f (&acc)[TM][TN], int n0, int m0, int wm,
+                                              int wn, int lane)
+{
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int jt = 0; jt < TN; jt++) {
+            const int j = n0 + (wn * TN + jt) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int tok = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float v = acc[i][jt][r];
+                if (EPI == G_ROPE || EPI == G_ROPE_CACHE) {
+                    // RoPE pair (j, j+1) sits in adjacent lanes (main.zig:346-349)
+                    const float partner = __shfl_xor(v, 1, 64);
+                    const int hs = a.head_size;
+                    const int pos = a.pos0 + (tok < a.P ? tok : 0);
+                    const float2 cs = a.rope[(size_t)pos * (size_t)(hs >> 1) +
+                                             (size_t)(((j < a.N ? j : 0) % hs) >> 1)];
+                    v = (j & 1) ? partner * cs.y + v * cs.x    // v0*fci + v1*fcr
+                                : v * cs.x - partner * cs.y;   // v0*fcr - v1*fci
+                }
+                if (tok < a.P && j < a.N) {
+                    if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + j] = v;
+                    else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + j] += v;        // main.zig:711
+                    else if (EPI == G_SWIGLU)
+                        a.out[(size_t)tok * a.ldo + j] = swiglu_merge(a.out[(size_t)tok * a.ldo + j], v);
+                    else a.out[(size_t)(a.pos0 + tok) * a.ldo + j] = v;                  // main.zig:354-358
+                }
+            }
+        }
+}
+
 // Block tile (64 TM tokens) x (64 TN features), 4 waves as 2 x 2, each wave TM x TN MFMA tiles of
 // 32 x 32.  MFMA 32x32x2 f32: D[i][j] += A[i][k] B[k][j] with
 //   A operand: lane l holds A[i = l & 31][k = l >> 5]      -> X[token i][k]
@@ -199,35 +234,149 @@ __global__ __launch_bounds__(256 * KS) void prefill_gemm(const GemmArgs a)
                     for (int r = 0; r < 16; r++)
                         acc[i][j][r] += red[((((g - 1) * 4 + wave) * TM * TN + i * TN + j) * 16 + r) * 64 + lane];
     }
-    // epilogue: per MFMA tile this lane owns one feature and 16 tokens
+    gemm_epilogue<EPI, TM, TN>(a, acc, n0, m0, wm, wn, lane);
+}
+
+// One direct-to-LDS load: 16 bytes per lane from `g` (per lane) to lds + 16 * lane (`lds` wave-uniform).
+// A plain __device__ function: called from the kernel TEMPLATE directly, the builtin makes the
+// host-side instantiation fail silently (no launch stub is emitted, the library then does not link).
+__device__ __forceinline__ void lds_dma16(const float *g, float *lds)
+{
+    __builtin_amdgcn_global_load_lds(g, lds, 16, 0, 0);
+}
+
+// The same tile product with the operands brought in by DIRECT-TO-LDS loads
+// (global_load_lds_dwordx4, gfx950): no VGPR round trip and no LDS-write instructions -- in the
+// register-staged kernel above the copy (6 float4 loads -> 24 ds_write_b32 per thread and stage,
+// the row padding forbids wider writes) costs 13 % of the run time (ablation).
+//  * LDS tile rows are unpadded (BK = 64 floats = 256 B = 16 float4 slots); a wave-wide load writes
+//    1 KB = 4 whole rows, lane L -> row L / 16, physical slot L % 16.
+//  * Operands are read with ds_read_b128: lane l of an MFMA 32x32x2 operand holds row l & 31 and
+//    k-half l >> 5; it reads the float4 of logical slot 2 s + (l >> 5) of its wave group's 8 slots
+//    and feeds components 0..3 to four consecutive MFMAs, i.e. MFMA (s, t) multiplies the k pair
+//    (8 s + t, 8 s + 4 + t).  A and B use the same pairing, and a sum over k has no order in exact
+//    arithmetic (the fp32 order is fixed by (stage, s, t), then the wave groups: deterministic).
+//  * 16 lanes that read the same slot of 16 consecutive rows would hit the same 4 banks (row pitch
+//    256 B): the physical slot is  logical ^ (row & 15), applied on the SOURCE address of the
+//    load (the LDS side of a direct load is lane-linear), so every 16-lane phase of a b128 read
+//    touches 16 different slots.
+//  * Two stage buffers; the loads of stage s+1 are issued before stage s is multiplied and waited for
+//    (vmcnt(0)) before the barrier that ends it.  Requires K % 64 == 0 (no zero fill on this path);
+//    rows past P / N are clamped to the last one and feed outputs nobody stores.
+template <int EPI, int TM, int TN, int KS>
+__global__ __launch_bounds__(256 * KS) void prefill_gemm_dma(const GemmArgs a)
+{
+    constexpr int BK = 64, SLOTS = BK / 4;
+    constexpr int BMt = 64 * TM, BNt = 64 * TN;
+    constexpr int NW = 4 * KS;                       // waves
+    constexpr int XI = BMt / 4 / NW, WI = BNt / 4 / NW;  // 1-KB loads per wave and stage
+    static_assert(BMt % (4 * NW) == 0 && BNt % (4 * NW) == 0, "tile rows per wave");
+    constexpr int STAGE = (BMt + BNt) * BK;          // floats
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) & 1, wn = wave & 1, kg = wave >> 2;
+    const int n0 = blockIdx.x * BNt, m0 = blockIdx.y * BMt;
+
+    // this lane's part of every load: row (within the 4-row group) lane / 16, physical slot lane % 16
+    const int lrow = lane >> 4, pslot = lane & 15;
+    const float *xsrc[XI], *wsrc[WI];
+#pragma unroll
+    for (int j = 0; j < XI; j++) {
+        const int r = (wave * XI + j) * 4 + lrow;                 // tile row
+        xsrc[j] = a.x + (size_t)min(m0 + r, a.P - 1) * a.ldx + 4 * (pslot ^ (r & 15));
+    }
+#pragma unroll
+    for (int j = 0; j < WI; j++) {
+        const int r = (wave * WI + j) * 4 + lrow;
+        wsrc[j] = a.w + (size_t)min(n0 + r, a.N - 1) * a.K + 4 * (pslot ^ (r & 15));
+    }
+#define L2Z_DMA_ISSUE(k0_, buf_)                                                                          \
+    do {                                                                                                  \
+        float *xs_ = smem + (buf_) * STAGE, *ws_ = xs_ + BMt * BK;                                        \
+        _Pragma("unroll") for (int j = 0; j < XI; j++)                                                    \
+            lds_dma16(xsrc[j] + (k0_), xs_ + (wave * XI + j) * 4 * BK);                                    \
+        _Pragma("unroll") for (int j = 0; j < WI; j++)                                                    \
+            lds_dma16(wsrc[j] + (k0_), ws_ + (wave * WI + j) * 4 * BK);                                    \
+    } while (0)
+
+    v16f acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int jt = 0; jt < TN; jt++) {
-            const int j = n0 + (wn * TN + jt) * 32 + (lane & 31);
+        for (int j = 0; j < TN; j++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int tok = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float v = acc[i][jt][r];
-                if (EPI == G_ROPE || EPI == G_ROPE_CACHE) {
-                    // RoPE pair (j, j+1) sits in adjacent lanes (main.zig:346-349)
-                    const float partner = __shfl_xor(v, 1, 64);
-                    const int hs = a.head_size;
-                    const int pos = a.pos0 + (tok < a.P ? tok : 0);
-                    const float2 cs = a.rope[(size_t)pos * (size_t)(hs >> 1) +
-                                             (size_t)(((j < a.N ? j : 0) % hs) >> 1)];
-                    v = (j & 1) ? partner * cs.y + v * cs.x    // v0*fci + v1*fcr
-                                : v * cs.x - partner * cs.y;   // v0*fcr - v1*fci
-                }
-                if (tok < a.P && j < a.N) {
-                    if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + j] = v;
-                    else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + j] += v;        // main.zig:711
-                    else if (EPI == G_SWIGLU)
-                        a.out[(size_t)tok * a.ldo + j] = swiglu_merge(a.out[(size_t)tok * a.ldo + j], v);
-                    else a.out[(size_t)(a.pos0 + tok) * a.ldo + j] = v;                  // main.zig:354-358
-                }
-            }
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    // operand addresses (float4 units) of super-step s: row base + ((logical slot) ^ (row & 15))
+    const int hl = lane >> 5, il = lane & 31;
+    constexpr int SPG = SLOTS / KS;   // slots of this wave group per stage
+    constexpr int SS = SPG / 2;       // super-steps (one float4 per k-half each)
+    int arow[TM], brow[TN], asw[TM], bsw[TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int r = wm * 32 * TM + i * 32 + il;
+        arow[i] = r * SLOTS;
+        asw[i] = r & 15;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int r = wn * 32 * TN + j * 32 + il;
+        brow[j] = r * SLOTS;
+        bsw[j] = r & 15;
+    }
+
+    L2Z_DMA_ISSUE(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < a.K; k0 += BK) {
+        if (k0 + BK < a.K) L2Z_DMA_ISSUE(k0 + BK, buf ^ 1);
+        const v4f *xr = (const v4f *)(smem + buf * STAGE), *wr = xr + BMt * SLOTS;
+#pragma unroll
+        for (int s = 0; s < SS; s++) {
+            const int slot = kg * SPG + 2 * s + hl;
+            v4f av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) av[i] = xr[arow[i] + (slot ^ asw[i])];
+#pragma unroll
+            for (int j = 0; j < TN; j++) bv[j] = wr[brow[j] + (slot ^ bsw[j])];
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[j][t], acc[i][j], 0, 0, 0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's loads of the next stage have landed
+        __syncthreads();                                  // everyone's have, and nobody still reads this one
+        buf ^= 1;
+    }
+    if (KS > 1) {
+        float *red = smem;  // [KS-1][4 waves][TM*TN*16][64 lanes]
+        if (kg > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        red[((((kg - 1) * 4 + (wave & 3)) * TM * TN + i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (kg > 0) return;
+#pragma unroll
+        for (int g = 1; g < KS; g++)
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        acc[i][j][r] += red[((((g - 1) * 4 + wave) * TM * TN + i * TN + j) * 16 + r) * 64 + lane];
+    }
+#undef L2Z_DMA_ISSUE
+    gemm_epilogue<EPI, TM, TN>(a, acc, n0, m0, wm, wn, lane);
 }
 
 // Short prompts (P <= 64): the product is bound by streaming W once, like the decode mat-vec, and
@@ -682,6 +831,21 @@ hipError_t gemm_launch_t(const GemmArgs &a, hipStream_t st)
         attr = true;
     }
     dim3 grid((a.N + BNt - 1) / BNt, (a.P + BMt - 1) / BMt);
+    if constexpr (BK == 64 && (BMt / 4) % (4 * KS) == 0 && (BNt / 4) % (4 * KS) == 0) {
+        // direct-to-LDS operand loads: whole 64-float stages only, 16-byte aligned rows
+        if (tunables().pf_dma != 0 && a.K % 64 == 0 && a.ldx % 4 == 0) {
+            size_t lds2 = 2 * (size_t)(BMt + BNt) * 64 * sizeof(float);
+            if (red > lds2) lds2 = red;
+            static bool attr2 = false;
+            if (!attr2 && lds2 > 48 * 1024) {
+                (void)hipFuncSetAttribute((const void *)prefill_gemm_dma<EPI, TM, TN, KS>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                attr2 = true;
+            }
+            hipLaunchKernelGGL((prefill_gemm_dma<EPI, TM, TN, KS>), grid, dim3(256 * KS), lds2, st, a);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((prefill_gemm<EPI, TM, TN, BK, KS>), grid, dim3(256 * KS), lds, st, a);
     return hipGetLastError();
 }

@@ -42,15 +42,6 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
     // Emulated ranks are driven stage by stage, never captured.
     if (comm && comm->world > 1 && !comm->nccl && !comm->p2p) s->use_graphs = false;
     if (comm && comm->nccl && !comm_uses_p2p(comm) && tn.comm_graph == 0) s->use_graphs = false;
-    {   // Cacheable weight loads for models whose per-layer matrices stay in the L2s between tokens:
-        // block b runs on XCD b % 8 and reads the same rows every token, so each 4 MiB L2 sees 1/8 of
-        // the layer weights (stories15M: 26 MB of layers -> 3.2 MB per XCD).  The classifier
-        // (V x dim, 37 MB there) keeps streaming non-temporally so that it does not evict them.
-        const size_t layer_bytes = (size_t)c.n_layers * 4 * ((size_t)2 * c.dim * c.dim + (size_t)2 * c.dim * sh.kvd_loc * sh.world +
-                                                              (size_t)3 * c.dim * c.hidden_dim);
-        const bool fits = layer_bytes / 8 <= ((size_t)7 << 19);  // 3.5 MiB of each XCD's 4
-        s->plain_layer_loads = sh.world == 1 && (tn.nt_small == 0 || (tn.nt_small < 0 && fits));
-    }
     s->fused_qkv_attn = sh.world == 1 && tn.fuse_small != 0 &&
                         fused_qkv_attn_supported(c.dim, c.n_heads, c.n_kv_heads, c.seq_len, g_cus);
     s->n_gathers = 4 * c.n_layers + 1;

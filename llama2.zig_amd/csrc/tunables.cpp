@@ -20,7 +20,6 @@ Tunables read_env()
     env_int("L2Z_ROW_BLOCKS", &t.row_blocks);
     env_int("L2Z_MAX_BLOCKS_PER_CU", &t.max_blocks_per_cu);
     env_int("L2Z_GRID_CAP", &t.grid_cap);
-    env_int("L2Z_NT_SMALL", &t.nt_small);
     env_int("L2Z_ATTN_BLOCK", &t.attn_block);
     env_int("L2Z_ATTN_SPLIT", &t.attn_split);
     env_int("L2Z_ATTN_SPLIT_POS", &t.attn_split_pos);
@@ -40,6 +39,7 @@ Tunables read_env()
     env_int("L2Z_PF_SKINNY_TMS", &t.pf_skinny_tms);
     env_int("L2Z_PF_ATTN", &t.pf_attn);
     env_int("L2Z_PF_FUSE", &t.pf_fuse);
+    env_int("L2Z_PF_DMA", &t.pf_dma);
     env_int("L2Z_UPLOAD_PINNED", &t.upload_pinned);
     if (t.row_blocks < 1) t.row_blocks = 1;
     if (t.max_blocks_per_cu < 1) t.max_blocks_per_cu = 8;
@@ -63,7 +63,7 @@ bool tunables_set(const char *name, long long v)
     Tunables &t = mutable_tunables();
     struct { const char *n; int *p; } ints[] = {
         {"L2Z_ROW_KERNEL", &t.row_kernel}, {"L2Z_ROW_BLOCKS", &t.row_blocks},
-        {"L2Z_MAX_BLOCKS_PER_CU", &t.max_blocks_per_cu}, {"L2Z_GRID_CAP", &t.grid_cap}, {"L2Z_NT_SMALL", &t.nt_small},
+        {"L2Z_MAX_BLOCKS_PER_CU", &t.max_blocks_per_cu}, {"L2Z_GRID_CAP", &t.grid_cap},
         {"L2Z_ATTN_BLOCK", &t.attn_block}, {"L2Z_ATTN_SPLIT", &t.attn_split},
         {"L2Z_ATTN_SPLIT_POS", &t.attn_split_pos}, 
         {"L2Z_FUSE_SMALL", &t.fuse_small}, {"L2Z_NO_GRAPH", &t.no_graph},
@@ -72,7 +72,7 @@ bool tunables_set(const char *name, long long v)
         {"L2Z_PREFILL", &t.prefill}, {"L2Z_PF_CHUNK", &t.pf_chunk},
         {"L2Z_PF_SKINNY_FORM", &t.pf_skinny_form}, {"L2Z_PF_TILE", &t.pf_tile},
         {"L2Z_PF_SKINNY_MAX", &t.pf_skinny_max}, {"L2Z_PF_SKINNY_TMS", &t.pf_skinny_tms},
-        {"L2Z_PF_ATTN", &t.pf_attn}, {"L2Z_PF_FUSE", &t.pf_fuse},
+        {"L2Z_PF_ATTN", &t.pf_attn}, {"L2Z_PF_FUSE", &t.pf_fuse}, {"L2Z_PF_DMA", &t.pf_dma},
         {"L2Z_UPLOAD_PINNED", &t.upload_pinned}};
     for (auto &e : ints)
         if (strcmp(e.n, name) == 0) {

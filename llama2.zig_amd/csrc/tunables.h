@@ -11,8 +11,6 @@ struct Tunables {
     int row_kernel = 1;        // L2Z_ROW_KERNEL      0: wide rows take the per-wave kernel too
     int row_blocks = 2;        // L2Z_ROW_BLOCKS      resident row-kernel blocks per CU
     int max_blocks_per_cu = 8; // L2Z_MAX_BLOCKS_PER_CU
-    int nt_small = -1;         // L2Z_NT_SMALL        1: always non-temporal weight loads, 0: cacheable loads in the
-                               //                     narrow-row kernels, -1: cacheable when a layer fits the L2s
     int grid_cap = 0;          // L2Z_GRID_CAP        max blocks of one mat-vec launch (0: none); set when
                                //                     several ranks share one GPU so that a kernel
                                //                     waiting for a peer leaves the peer room to run
@@ -38,6 +36,7 @@ struct Tunables {
     int pf_skinny_max = -1;    // L2Z_PF_SKINNY_MAX
     int pf_skinny_tms = 0;     // L2Z_PF_SKINNY_TMS
     int pf_attn = 1;           // L2Z_PF_ATTN         0: per-query prefill attention only
+    int pf_dma = 1;            // L2Z_PF_DMA          0: register-staged GEMM operand copies instead of direct-to-LDS loads
     int pf_fuse = 1;           // L2Z_PF_FUSE         0: separate Q / K / V and W1 / W3 GEMMs
     // --- loader (weights.cpp) ---
     int upload_pinned = 1;     // L2Z_UPLOAD_PINNED   0: plain hipMemcpy from the caller's buffer

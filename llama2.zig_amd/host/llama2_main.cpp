@@ -3,6 +3,7 @@
 // transformer() runs on the GPU through include/llama2_hip.h.
 //
 //   llama2 <checkpoint> [-t temp] [-p top_p] [-n steps] [-i prompt] [-s seed] [-v] [-z tokenizer]
+//          [-g n_gpus]   (extension: rows / heads sharded over n GPUs, one process per GPU)
 //
 // At -t 0 the whole generation loop runs on the device (l2z_greedy_run) and the host
 // only prints; otherwise one l2z_transformer + l2z_logits_read per position feeds the
@@ -10,6 +11,7 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <chrono>
@@ -38,7 +40,8 @@ static const char *usage_text =
     " -s, --seed <int>          random seed, default to time\n"
     " -v, --verbose             print model info and tokens/s\n"
     " -z, --tokenizer <path>    path to the tokenizer to use, default to \"tokenizer.bin\"\n"
-    " --tokens                  (extension) also print the token ids to stderr, one line\n";
+    " --tokens                  (extension) also print the token ids to stderr, one line\n"
+    " -g, --gpus <int>          (extension) shard weight rows / heads over this many GPUs, default 1\n";
 
 static bool verbose = false;
 #define LOGV(...)                                 \
@@ -50,6 +53,34 @@ static int die(const char *what)
 {
     fprintf(stderr, "error: %s: %s\n", what, l2z_last_error());
     return 1;
+}
+
+// ---- -g N: one process per GPU.  The parent is rank 0 and forks ranks 1..N-1 BEFORE
+// anything touches the GPU; every rank maps the checkpoint itself and uploads only its own rows
+// (l2z_weights_init with a comm), the ranks exchange the 64-byte IPC handles of their landing
+// arenas through files in a private temporary directory, and then all of them run the very same
+// generation loop -- same tokens in, bit-identical logits out, so they stay in step
+// without talking to each other; only rank 0 prints.
+static int g_rank = 0, g_world = 1;
+
+static bool exchange_handles(const std::string &dir, const void *mine, std::vector<char> *all)
+{
+    const std::string tmp = dir + "/h" + std::to_string(g_rank) + ".tmp", fin = dir + "/h" + std::to_string(g_rank);
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f || fwrite(mine, 1, L2Z_COMM_IPC_BYTES, f) != L2Z_COMM_IPC_BYTES) return false;
+    fclose(f);
+    if (rename(tmp.c_str(), fin.c_str()) != 0) return false;
+    all->resize((size_t)g_world * L2Z_COMM_IPC_BYTES);
+    for (int r = 0; r < g_world; r++) {
+        const std::string p = dir + "/h" + std::to_string(r);
+        FILE *g = nullptr;
+        for (int tries = 0; tries < 6000 && !(g = fopen(p.c_str(), "rb")); tries++) usleep(10000);
+        if (!g) return false;
+        const size_t n = fread(all->data() + (size_t)r * L2Z_COMM_IPC_BYTES, 1, L2Z_COMM_IPC_BYTES, g);
+        fclose(g);
+        if (n != L2Z_COMM_IPC_BYTES) return false;
+    }
+    return true;
 }
 
 int main(int argc, char **argv)
@@ -64,6 +95,7 @@ int main(int argc, char **argv)
     size_t seq_len = 0;
     std::string tokenizer_path = "tokenizer.bin";
     bool dump_tokens = false;
+    int n_gpus = 1;
     Prng prng((uint64_t)std::chrono::system_clock::now().time_since_epoch().count());  // :844-845
 
     auto need = [&](int &i, const char *what) -> const char * {  // :863-867 etc.
@@ -128,6 +160,12 @@ int main(int argc, char **argv)
             verbose = true;
         } else if (a == "--tokens") {
             dump_tokens = true;
+        } else if (a == "-g" || a == "--gpus") {
+            n_gpus = atoi(need(i, "gpus"));
+            if (n_gpus < 1 || n_gpus > 16) {
+                fprintf(stderr, "unable to use --gpus argument '%s'\n", argv[i]);
+                return 1;
+            }
         } else {  // :929-933
             fprintf(stderr, "error: unknown argument '%s'\n", argv[i]);
             fputs(usage_text, stdout);
@@ -139,22 +177,67 @@ int main(int argc, char **argv)
         return 1;
     }
 
+    // ---- ranks (before any GPU call: the children must start with a clean HIP state)
+    std::string xdir;
+    std::vector<pid_t> kids;
+    if (n_gpus > 1) {
+        setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);  // dmabuf IPC
+        char tmpl[] = "/tmp/llama2_ranks_XXXXXX";
+        if (!mkdtemp(tmpl)) {
+            fprintf(stderr, "error: cannot create a temporary directory for the rank hand-shake\n");
+            return 1;
+        }
+        xdir = tmpl;
+        g_world = n_gpus;
+        fflush(stdout);
+        fflush(stderr);
+        for (int r = 1; r < n_gpus; r++) {
+            const pid_t pid = fork();
+            if (pid < 0) {
+                fprintf(stderr, "error: fork failed\n");
+                return 1;
+            }
+            if (pid == 0) {
+                g_rank = r;
+                kids.clear();
+                verbose = false;
+                dump_tokens = false;
+                break;
+            }
+            kids.push_back(pid);
+        }
+    }
+    auto finish = [&](int rc) -> int {  // children leave quietly; rank 0 reaps them and cleans up
+        fflush(stdout);
+        if (g_rank != 0) _exit(rc);
+        for (pid_t k : kids) {
+            int st = 0;
+            waitpid(k, &st, 0);
+            if (rc == 0 && !(WIFEXITED(st) && WEXITSTATUS(st) == 0)) rc = 1;
+        }
+        if (!xdir.empty()) {
+            for (int r = 0; r < g_world; r++) unlink((xdir + "/h" + std::to_string(r)).c_str());
+            rmdir(xdir.c_str());
+        }
+        return rc;
+    };
+
     // ---- checkpoint: 28-byte header + f32 blob (:936-967); mmap instead of a heap copy:
     // l2z_weights_init streams it to the GPU once and the mapping is dropped
     const int fd = open(bin_path, O_RDONLY);
     if (fd < 0) {
-        fprintf(stderr, "error: cannot open checkpoint '%s'\n", bin_path);
-        return 1;
+        if (g_rank == 0) fprintf(stderr, "error: cannot open checkpoint '%s'\n", bin_path);
+        return finish(1);
     }
     struct stat st;
     if (fstat(fd, &st) != 0 || (size_t)st.st_size < sizeof(l2z_config)) {
-        fprintf(stderr, "error: checkpoint '%s' is too small\n", bin_path);
-        return 1;
+        if (g_rank == 0) fprintf(stderr, "error: checkpoint '%s' is too small\n", bin_path);
+        return finish(1);
     }
     void *map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     if (map == MAP_FAILED) {
-        fprintf(stderr, "error: mmap of '%s' failed\n", bin_path);
-        return 1;
+        if (g_rank == 0) fprintf(stderr, "error: mmap of '%s' failed\n", bin_path);
+        return finish(1);
     }
     l2z_config cfg;
     memcpy(&cfg, map, sizeof cfg);                       // :941
@@ -164,34 +247,57 @@ int main(int argc, char **argv)
          cfg.dim, cfg.hidden_dim, cfg.n_layers, cfg.n_heads, cfg.n_kv_heads, cfg.vocab_size, cfg.seq_len);
     LOGV("shared weights: %s\ntemperature: %g\ntop-p: %g\n", shared_weights ? "true" : "false",
          temperature, top_p);
+    int device = 0;
     {
         char name[256] = "";
-        int cus = 0;
+        int cus = 0, n_dev = 0;
         uint64_t hbm = 0;
-        if (l2z_device_info(0, name, sizeof name, &cus, &hbm) != L2Z_OK) return die("no GPU");
-        LOGV("device: %s, %d CUs, %.0f GB HBM\n\n", name, cus, (double)hbm / 1e9);
+        if (l2z_device_count(&n_dev) != L2Z_OK || n_dev < 1) return finish(die("no GPU"));
+        device = g_rank % n_dev;  // fewer GPUs than ranks: ranks share (functional, not fast)
+        if (l2z_device_info(device, name, sizeof name, &cus, &hbm) != L2Z_OK) return finish(die("no GPU"));
+        LOGV("device: %s, %d CUs, %.0f GB HBM%s\n\n", name, cus, (double)hbm / 1e9,
+             g_world > 1 ? " (rank 0 of the shard group)" : "");
+    }
+    l2z_comm *comm = nullptr;
+    if (g_world > 1) {
+        if (l2z_comm_init(g_rank, g_world, nullptr, device, &comm) != L2Z_OK) return finish(die("comm_init"));
+        char handle[L2Z_COMM_IPC_BYTES];
+        const size_t longest = (size_t)std::max(std::max(cfg.dim, cfg.hidden_dim), cfg.vocab_size);
+        std::vector<char> all;
+        if (l2z_comm_p2p_export(comm, longest, handle) != L2Z_OK) return finish(die("p2p_export"));
+        if (!exchange_handles(xdir, handle, &all)) {
+            if (g_rank == 0) fprintf(stderr, "error: rank %d: hand-shake with the other ranks failed\n", g_rank);
+            return finish(1);
+        }
+        if (l2z_comm_p2p_connect(comm, all.data()) != L2Z_OK) return finish(die("p2p_connect"));
     }
     const float *data = reinterpret_cast<const float *>(static_cast<const char *>(map) + sizeof cfg);
     const size_t n_floats = ((size_t)st.st_size - sizeof cfg) / sizeof(float);
     l2z_weights *w = nullptr;
-    if (l2z_weights_init(&cfg, data, n_floats, shared_weights, nullptr, &w) != L2Z_OK)
-        return die("Weights.init");
+    const auto t_up = std::chrono::steady_clock::now();
+    if (l2z_weights_init(&cfg, data, n_floats, shared_weights, comm, &w) != L2Z_OK)
+        return finish(die("Weights.init"));
+    {
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_up).count();
+        LOGV("weights: %.2f GB of the file%s on the GPU in %.2f s\n", (double)st.st_size / 1e9 / g_world,
+             g_world > 1 ? " (this rank's rows)" : "", el);
+    }
     munmap(map, (size_t)st.st_size);
     close(fd);
 
     Tokenizer tok;  // :970
     std::string err;
     if (!tok.from_file(tokenizer_path, (size_t)cfg.vocab_size, &err)) {
-        fprintf(stderr, "error: %s\n", err.c_str());
-        return 1;
+        if (g_rank == 0) fprintf(stderr, "error: %s\n", err.c_str());
+        return finish(1);
     }
     l2z_runstate *s = nullptr;  // :974
-    if (l2z_runstate_init(&cfg, nullptr, &s) != L2Z_OK) return die("RunState.init");
+    if (l2z_runstate_init(&cfg, comm, &s) != L2Z_OK) return finish(die("RunState.init"));
 
     std::vector<int32_t> prompt;  // :978-985
     if (input && !tok.encode(input, &prompt, &err)) {
-        fprintf(stderr, "error: cannot encode the prompt: %s\n", err.c_str());
-        return 1;
+        if (g_rank == 0) fprintf(stderr, "error: cannot encode the prompt: %s\n", err.c_str());
+        return finish(1);
     }
     const size_t prompt_len = prompt.size();
 
@@ -213,11 +319,11 @@ int main(int argc, char **argv)
         if (token == 1 && !piece.empty() && piece[0] == ' ') piece.remove_prefix(1);  // :1022-1025
         const int byte = is_raw_byte(piece);
         if (byte >= 0) {  // :1028-1031: printed, but the timer is not started on this path
-            fputc(byte, stdout);
+            if (g_rank == 0) fputc(byte, stdout);
             token = next;
             return true;
         }
-        fwrite(piece.data(), 1, piece.size(), stdout);
+        if (g_rank == 0) fwrite(piece.data(), 1, piece.size(), stdout);
         token = next;
         if (!timer_started) {  // :1039-1041
             fflush(stdout);
@@ -229,7 +335,7 @@ int main(int argc, char **argv)
 
     if (temperature == 0.0f) {
         // the loop of :995-1042 on the device; prompt override included
-        if (l2z_greedy_begin(s, prompt.data(), (int)prompt_len) != L2Z_OK) return die("greedy_begin");
+        if (l2z_greedy_begin(s, prompt.data(), (int)prompt_len) != L2Z_OK) return finish(die("greedy_begin"));
         std::vector<int32_t> chunk(64);
         bool alive = true;
         while (alive && pos < seq_len) {
@@ -242,7 +348,7 @@ int main(int argc, char **argv)
                 chunk.resize(std::max(chunk.size(), prompt_len));
             }
             int got = 0;
-            if (l2z_greedy_run(&cfg, s, w, want, chunk.data(), &got) != L2Z_OK) return die("greedy_run");
+            if (l2z_greedy_run(&cfg, s, w, want, chunk.data(), &got) != L2Z_OK) return finish(die("greedy_run"));
             if (got == 0) break;
             for (int i = 0; i < got && alive; i++) {
                 alive = emit((size_t)chunk[(size_t)i]);
@@ -257,7 +363,7 @@ int main(int argc, char **argv)
         const char *pf_env = getenv("L2Z_PREFILL");
         bool has_bos = false;
         for (int32_t t : prompt) has_bos = has_bos || t == 1;
-        if (prompt_len >= L2Z_PREFILL_MIN_PROMPT && prompt_len <= seq_len && !has_bos &&
+        if (prompt_len >= L2Z_PREFILL_MIN_PROMPT && prompt_len <= seq_len && !has_bos && g_world == 1 &&
             !(pf_env && atoi(pf_env) == 0)) {
             std::vector<int32_t> in(prompt_len);
             in[0] = 1;
@@ -268,12 +374,12 @@ int main(int argc, char **argv)
             }
         }
         for (; pos < seq_len; pos++) {
-            if (l2z_transformer((int)token, (int)pos, &cfg, s, w) != L2Z_OK) return die("transformer");  // :996
+            if (l2z_transformer((int)token, (int)pos, &cfg, s, w) != L2Z_OK) return finish(die("transformer"));  // :996
             size_t next;
             if (pos < prompt_len) {
                 next = (size_t)prompt[pos];  // :999-1000
             } else {
-                if (l2z_logits_read(s, logits.data()) != L2Z_OK) return die("logits_read");
+                if (l2z_logits_read(s, logits.data()) != L2Z_OK) return finish(die("logits_read"));
                 if (temperature != 1.0f)
                     for (float &v : logits) v /= temperature;  // :1005-1007
                 softmax(logits.data(), logits.size());          // :1008
@@ -297,5 +403,6 @@ int main(int argc, char **argv)
     }
     l2z_runstate_free(s);
     l2z_weights_free(w);
-    return 0;
+    if (comm) l2z_comm_free(comm);
+    return finish(0);
 }

@@ -607,6 +607,27 @@ PREFILL_CONFIGS = [
 ]
 
 
+def test_prefill_gemm_direct_to_lds_equals_register_staged(gpu, ck, options):
+    """The two forms of the tile GEMM (operands by global_load_lds vs staged through registers) pair
+    the k values differently inside an MFMA, nothing else: logits and cache rows of a 300-token
+    prefill agree within the logit tolerance, for 64x64 (P <= 256) and 128x64 (P > 256) tiles."""
+    cfg = ck.Config(dim=512, hidden_dim=1536, n_layers=2, n_heads=8, n_kv_heads=4, vocab_size=2048, seq_len=400)
+    w = gpu.Weights(cfg, None, False, seed=5)
+    rng = np.random.default_rng(3)
+    for n in (100, 300):
+        toks = [1] + rng.integers(2, cfg.vocab_size, n - 1).tolist()
+        res = []
+        for dma in (1, 0):
+            options(L2Z_PF_DMA=dma)
+            s = gpu.RunState(cfg)
+            s.prefill(toks, 0, w)
+            res.append((s.logits(), s.read("key_cache", 0, n * cfg.kv_dim), s.read("value_cache", cfg.seq_len * cfg.kv_dim, n * cfg.kv_dim)))
+            s.close()
+        for a, b in zip(*res):
+            np.testing.assert_allclose(a, b, rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
+    w.close()
+
+
 @pytest.mark.parametrize("name,kw,shared", PREFILL_CONFIGS, ids=[c[0] for c in PREFILL_CONFIGS])
 def test_prefill_equals_token_by_token(gpu, ck, orc, name, kw, shared):
     """l2z_prefill(tokens, pos0) leaves the KV cache and the last position's logits as n calls

@@ -229,3 +229,24 @@ def test_cli_sampling_with_long_prompt_uses_batched_prefill(gpu, ck):
 
     a, b, stepped = run({}), run({}), run({"L2Z_PREFILL": "0"})
     assert a == b and a[:n] == prompt and stepped[:n] == prompt and len(a) > n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_gpus", [2, 4])
+def test_cli_multi_gpu_mode_matches_single(gpu, n_gpus):
+    """`-g N`: one process per rank (forked by the CLI), each rank mmaps the checkpoint and uploads
+    only its rows, peer-write gathers over IPC; greedy (-t 0) and sampled (-t 1.0, fixed seed) token
+    ids equal the single-GPU run's.  The ranks share this box's one GPU (rank % device count)."""
+    exe = os.path.join(HOST, "llama2")
+    ckpt = os.path.join(GOLDEN, "toy_gqa_unshared.bin")  # 4 heads, 2 kv heads: 2 ranks; hidden 172 = 4 * 43
+    if n_gpus == 4:
+        ckpt = os.path.join(GOLDEN, "toy_mha_shared.bin")  # 4 heads, 4 kv heads, hidden 128, vocab 300
+    env = dict(os.environ, L2Z_GRID_CAP=str(max(64, 1024 // n_gpus)), L2Z_P2P_TIMEOUT_S="30", L2Z_FUSE_SMALL="0")
+    for flags in (["-t", "0"], ["-t", "1.0", "-p", "0.9", "-s", "99"]):
+        outs = []
+        for g in (1, n_gpus):
+            r = subprocess.run([exe, ckpt, *flags, "-n", "20", "-z", TOK, "-i", "a b", "--tokens", "-g", str(g)],
+                               capture_output=True, timeout=180, env=env)
+            assert r.returncode == 0, r.stderr.decode(errors="replace")
+            outs.append(([l for l in r.stderr.decode().splitlines() if l.startswith("tokens:")][0], r.stdout))
+        assert outs[0] == outs[1], flags
