@@ -263,6 +263,13 @@ __device__ __forceinline__ void lds_dma16(const float *g, float *lds)
 //  * Two stage buffers; the loads of stage s+1 are issued before stage s is multiplied and waited for
 //    (vmcnt(0)) before the barrier that ends it.  Requires K % 64 == 0 (no zero fill on this path);
 //    rows past P / N are clamped to the last one and feed outputs nobody stores.
+//  * Measured and not kept (7B shape, 512 / 256 tokens, interleaved A/B): three stage buffers with
+//    loads two stages ahead (+2.7 % / +7 % time: memory latency is not what the waves wait for, and
+//    at 256 tokens the third buffer costs the second resident block); the second wave group issuing
+//    its loads mid-stage (+1.4 %); loads and operand reads placed by hand between the MFMA steps
+//    with sched_barrier (+9.5 %: hipcc's own interleaving of this loop is better than the pinned one).
+//    PMC of this kernel: SQ_WAIT_ANY 22 % of the wave cycles (parked at the stage barrier), MFMA
+//    pipe 66 % busy -- the per-stage barrier with one block of 8 waves per CU is what is left.
 template <int EPI, int TM, int TN, int KS>
 __global__ __launch_bounds__(256 * KS) void prefill_gemm_dma(const GemmArgs a)
 {

@@ -36,10 +36,8 @@ struct Tunables {
     int pf_skinny_max = -1;    // L2Z_PF_SKINNY_MAX
     int pf_skinny_tms = 0;     // L2Z_PF_SKINNY_TMS
     int pf_attn = 1;           // L2Z_PF_ATTN         0: per-query prefill attention only
-    int pf_dma = 1;            // L2Z_PF_DMA          0: register-staged GEMM operand copies instead of direct-to-LDS loads
+    int pf_dma = 1;            // L2Z_PF_DMA          0: GEMM operands staged through registers instead of direct-to-LDS loads
     int pf_fuse = 1;           // L2Z_PF_FUSE         0: separate Q / K / V and W1 / W3 GEMMs
-    // --- loader (weights.cpp) ---
-    int upload_pinned = 1;     // L2Z_UPLOAD_PINNED   0: plain hipMemcpy from the caller's buffer
 };
 
 const Tunables &tunables();

@@ -9,7 +9,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
-#include <thread>
 
 #include "l2z_state.h"
 
@@ -174,85 +173,20 @@ size_t local_floats(const l2z_weights *w, const std::vector<TensorDesc> &tt)
 }
 
 // Host -> device copy of weight rows (main.zig:936-967 reads the whole file into the heap first; here
-// the source is the caller's buffer, typically the mmapped checkpoint).  Two pinned staging
-// buffers: while one is on its way over PCIe (hipMemcpyAsync from pinned memory = one DMA at link
-// rate), a few host threads fill the other from the page cache -- a single memcpy thread tops out
-// near 10 GB/s, a fifth of what the link carries.  L2Z_UPLOAD_PINNED=0: plain hipMemcpy from the
-// caller's (pageable) buffer, staged by the runtime.
-class Uploader {
-public:
-    static constexpr size_t kChunk = (size_t)64 << 20;
-    static constexpr int kThreads = 8;
-    ~Uploader()
-    {
-        if (st_) (void)hipStreamSynchronize(st_);
-        for (int i = 0; i < 2; i++) {
-            if (ev_[i]) (void)hipEventDestroy(ev_[i]);
-            if (pin_[i]) (void)hipHostFree(pin_[i]);
-        }
-        if (st_) (void)hipStreamDestroy(st_);
+// the source is the caller's buffer, typically the mmapped checkpoint).  A plain hipMemcpy from the
+// pageable mapping: the runtime stages it through its own pinned buffers at 54-56 GB/s for the
+// 27 GB llama2-7b file (profiles/r02_upload_rate.txt).  An explicit pinned double buffer filled by
+// eight host threads was measured beside it and was no faster (46-53 GB/s), so it is not kept.
+hipError_t upload(float *dst, const float *src, size_t n_floats)
+{
+    const size_t piece = (size_t)256 << 20;  // floats: 1 GiB per call
+    hipError_t e = hipSuccess;
+    for (size_t o = 0; o < n_floats && e == hipSuccess; o += piece) {
+        const size_t n = n_floats - o < piece ? n_floats - o : piece;
+        e = hipMemcpy(dst + o, src + o, n * sizeof(float), hipMemcpyHostToDevice);
     }
-    hipError_t copy(float *dst, const float *src, size_t n_floats)
-    {
-        const size_t bytes = n_floats * sizeof(float);
-        if (!tunables().upload_pinned || bytes < ((size_t)4 << 20)) return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
-        hipError_t e = init();
-        if (e != hipSuccess) return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);  // no pinned memory to be had
-        const char *s = reinterpret_cast<const char *>(src);
-        char *d = reinterpret_cast<char *>(dst);
-        for (size_t off = 0; off < bytes; off += kChunk) {
-            const size_t len = bytes - off < kChunk ? bytes - off : kChunk;
-            const int b = turn_ & 1;
-            if (used_[b] && (e = hipEventSynchronize(ev_[b])) != hipSuccess) return e;  // its last DMA is done
-            fill(static_cast<char *>(pin_[b]), s + off, len);
-            if ((e = hipMemcpyAsync(d + off, pin_[b], len, hipMemcpyHostToDevice, st_)) != hipSuccess) return e;
-            if ((e = hipEventRecord(ev_[b], st_)) != hipSuccess) return e;
-            used_[b] = true;
-            turn_++;
-        }
-        return hipSuccess;
-    }
-    hipError_t finish() { return st_ ? hipStreamSynchronize(st_) : hipSuccess; }
-
-private:
-    hipError_t init()
-    {
-        if (st_) return hipSuccess;
-        hipError_t e = hipStreamCreateWithFlags(&st_, hipStreamNonBlocking);
-        for (int i = 0; i < 2 && e == hipSuccess; i++) {
-            e = hipHostMalloc(&pin_[i], kChunk, hipHostMallocDefault);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming);
-        }
-        if (e != hipSuccess) {
-            for (int i = 0; i < 2; i++) {
-                if (ev_[i]) (void)hipEventDestroy(ev_[i]);
-                if (pin_[i]) (void)hipHostFree(pin_[i]);
-                ev_[i] = nullptr; pin_[i] = nullptr;
-            }
-            if (st_) (void)hipStreamDestroy(st_);
-            st_ = nullptr;
-            (void)hipGetLastError();
-        }
-        return e;
-    }
-    static void fill(char *dst, const char *src, size_t len)
-    {
-        const size_t per = ((len / kThreads) + 4095) & ~(size_t)4095;
-        std::thread th[kThreads];
-        int n = 0;
-        for (size_t o = per; o < len; o += per) {  // slice 0 is done by this thread
-            const size_t l = len - o < per ? len - o : per;
-            th[n++] = std::thread([=] { memcpy(dst + o, src + o, l); });
-        }
-        memcpy(dst, src, len < per ? len : per);
-        for (int i = 0; i < n; i++) th[i].join();
-    }
-    void *pin_[2] = {nullptr, nullptr};
-    hipEvent_t ev_[2] = {nullptr, nullptr};
-    bool used_[2] = {false, false};
-    hipStream_t st_ = nullptr;
-    unsigned turn_ = 0;
-};
+    return e;
+}
 
 int weights_alloc(const l2z_config *config, int shared_weights, const l2z_comm *comm,
                   l2z_weights **out, std::vector<TensorDesc> *tt_out)
@@ -326,10 +260,9 @@ extern "C" int l2z_weights_init(const l2z_config *config, const float *data, siz
         return L2Z_ERR_INVALID;
     }
     hipError_t e = hipSuccess;
-    Uploader up;
     if (w->file_layout) {
         // one allocation, byte-identical to the file blob
-        e = up.copy(w->blob, data, need);
+        e = upload(w->blob, data, need);
     } else {
         // sharded direct upload: only this rank's rows are read from the host blob
         size_t off = 0;
@@ -340,12 +273,11 @@ extern "C" int l2z_weights_init(const l2z_config *config, const float *data, siz
             const size_t rl = r1 - r0;
             for (size_t l = 0; l < d.layers && e == hipSuccess; l++) {
                 const float *src = data + d.offset + (l * d.rows + r0) * d.cols;
-                e = up.copy(w->blob + off + l * rl * d.cols, src, rl * d.cols);
+                e = upload(w->blob + off + l * rl * d.cols, src, rl * d.cols);
             }
             off += d.layers * rl * d.cols;
         }
     }
-    if (e == hipSuccess) e = up.finish();
     if (e != hipSuccess) {
         set_error("weight upload failed: %s", hipGetErrorString(e));
         l2z_weights_free(w);

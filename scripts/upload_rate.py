@@ -1,7 +1,6 @@
 """Host -> device rate of l2z_weights_init at FULL size: a 27 GB llama2-7b-shape checkpoint file
 (seeded synthetic weights, written by checkpoint.py's writer into /dev/shm) is mmapped and uploaded
-the way the CLI does it (host/llama2_main.cpp), with the pinned double-buffered staging and with a
-plain hipMemcpy (L2Z_UPLOAD_PINNED=0); then once more through the CLI itself (-v prints the time),
+the way the CLI does it (host/llama2_main.cpp); then once more through the CLI itself (-v prints the time),
 single GPU and `-g 2` (each rank uploads its own rows).  Spot-checks the device copy against the file."""
 import os, subprocess, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
@@ -20,11 +19,10 @@ probe = [(o, blob[o:o + 1024].copy()) for o in (0, n // 3, n - 1024)]
 del blob
 print(f"wrote {os.path.getsize(path) / 1e9:.2f} GB to {path} in {time.perf_counter() - t0:.1f} s", flush=True)
 c2, sh, mm = ck.read_checkpoint(path)
-for mode in (1, 0, 1, 0):
-    B.option_set("L2Z_UPLOAD_PINNED", mode)
+for rep in range(3):
     t0 = time.perf_counter(); w = B.Weights(c2, np.asarray(mm), sh); dt = time.perf_counter() - t0
     ok = all(np.array_equal(w.read(o, 1024), v) for o, v in probe)
-    print(f"l2z_weights_init from the mmapped file, {'pinned double-buffered staging' if mode else 'plain hipMemcpy'}: "
+    print(f"l2z_weights_init from the mmapped file: "
           f"{n * 4 / 1e9:.2f} GB in {dt:.2f} s = {n * 4 / dt / 1e9:.1f} GB/s  (device copy == file: {ok})", flush=True)
     w.close()
 del mm
