@@ -198,8 +198,12 @@ def main() -> None:
     device = local_rank % n_dev  # several ranks on one GPU only happens in tests
     if world > n_dev:
         # ranks share a chip: a mat-vec launch that may be polling for a peer's words must leave the
-        # peer's kernels room to run (never needed with a GPU per rank)
-        B.option_set("L2Z_GRID_CAP", max(64, 1024 // ((world + n_dev - 1) // n_dev)))
+        # peer's kernels room to run (never needed with a GPU per rank).  Measured: with more than
+        # 512 polling blocks in total (2 per CU) a peer's producer can be left without a slot and the
+        # waits time out; the gather-launch form needs no cap (L2Z_COMM=p2p-gather L2Z_GRID_CAP=0)
+        shared_cap = max(32, 512 // ((world + n_dev - 1) // n_dev))
+    else:
+        shared_cap = 0
 
     def all_ok(ok: bool) -> bool:
         flags = [None] * world
@@ -271,6 +275,7 @@ def main() -> None:
             order = ["rccl"]
         for kind in order:
             B.option_set("L2Z_P2P_CONSUME", 1 if kind == "p2p-consume" else 0)
+            B.option_set("L2Z_GRID_CAP", shared_cap if kind == "p2p-consume" else 0)
             B.option_set("L2Z_COMM_RCCL", 1 if kind == "rccl" else 0)
             comm = make_comm("rccl" if kind == "rccl" else "p2p")
             if comm is None:

@@ -41,6 +41,7 @@ __device__ __forceinline__ float swiglu_merge(float h1, float h3)
 
 struct GemmArgs {
     const float *x;      // [P, K] row-major (ldx floats per row)
+    const float *w2;     // paired form only: the second [N, K] matrix (W3 beside W1)
     const float *w;      // [N, K] row-major
     float *out;          // [P, ldo]; G_*CACHE: cache base, row = pos0 + token
     int P, N, K, ldx, ldo;
@@ -270,40 +271,58 @@ __device__ __forceinline__ void lds_dma16(const float *g, float *lds)
 //    with sched_barrier (+9.5 %: hipcc's own interleaving of this loop is better than the pinned one).
 //    PMC of this kernel: SQ_WAIT_ANY 22 % of the wave cycles (parked at the stage barrier), MFMA
 //    pipe 66 % busy -- the per-stage barrier with one block of 8 waves per CU is what is left.
-template <int EPI, int TM, int TN, int KS>
+//  * PAIR (W1 and W3 of the feed-forward in ONE launch, main.zig:405-416): the block's two n-tiles
+//    are the SAME 32 features per wave column of W1 (tile 0) and of W3 (tile 1), so a lane ends up
+//    holding both products of its (token, feature) and the epilogue writes silu(a) * b directly --
+//    the X tile is loaded once for both, and the [P, hidden] intermediate never goes to memory
+//    (the separate W3 launch was the slowest GEMM: it re-read and re-wrote 45 MB at 512 tokens).
+//  * Also measured and not kept (512 tokens): stages of half the depth (BK = 32, 48 KB per block,
+//    three resident blocks per CU instead of one) +4.9 % time; an XCD-aware block -> tile map that
+//    keeps each XCD on one 128-row X tile (L2 resident, only W streams) +0.6 %; neither LDS
+//    capacity, nor the memory side, nor latency is what the MFMA pipe waits for.
+template <int EPI, int TM, int TN, int KS, bool PAIR = false>
 __global__ __launch_bounds__(256 * KS) void prefill_gemm_dma(const GemmArgs a)
 {
+    static_assert(!PAIR || TN == 2, "paired form: one W1 tile and one W3 tile per wave column");
     constexpr int BK = 64, SLOTS = BK / 4;
+    constexpr int RPI = 64 / SLOTS;                  // tile rows per 1-KB load
     constexpr int BMt = 64 * TM, BNt = 64 * TN;
     constexpr int NW = 4 * KS;                       // waves
-    constexpr int XI = BMt / 4 / NW, WI = BNt / 4 / NW;  // 1-KB loads per wave and stage
-    static_assert(BMt % (4 * NW) == 0 && BNt % (4 * NW) == 0, "tile rows per wave");
+    constexpr int XI = BMt / RPI / NW, WI = BNt / RPI / NW;  // 1-KB loads per wave and stage
+    static_assert(BMt % (RPI * NW) == 0 && BNt % (RPI * NW) == 0, "tile rows per wave");
     constexpr int STAGE = (BMt + BNt) * BK;          // floats
+    auto swz = [](int row) { return row & 15; };
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) & 1, wn = wave & 1, kg = wave >> 2;
-    const int n0 = blockIdx.x * BNt, m0 = blockIdx.y * BMt;
+    const int n0 = blockIdx.x * (PAIR ? BNt / 2 : BNt), m0 = blockIdx.y * BMt;
 
-    // this lane's part of every load: row (within the 4-row group) lane / 16, physical slot lane % 16
-    const int lrow = lane >> 4, pslot = lane & 15;
+    // this lane's part of every load: row (within the RPI-row group) lane / SLOTS, physical slot lane % SLOTS
+    const int lrow = lane / SLOTS, pslot = lane % SLOTS;
     const float *xsrc[XI], *wsrc[WI];
 #pragma unroll
     for (int j = 0; j < XI; j++) {
-        const int r = (wave * XI + j) * 4 + lrow;                 // tile row
-        xsrc[j] = a.x + (size_t)min(m0 + r, a.P - 1) * a.ldx + 4 * (pslot ^ (r & 15));
+        const int r = (wave * XI + j) * RPI + lrow;               // tile row
+        xsrc[j] = a.x + (size_t)min(m0 + r, a.P - 1) * a.ldx + 4 * (pslot ^ swz(r));
     }
 #pragma unroll
     for (int j = 0; j < WI; j++) {
-        const int r = (wave * WI + j) * 4 + lrow;
-        wsrc[j] = a.w + (size_t)min(n0 + r, a.N - 1) * a.K + 4 * (pslot ^ (r & 15));
+        const int r = (wave * WI + j) * RPI + lrow;
+        if (PAIR) {  // LDS row r = wave column r / 64, tile (r % 64) / 32 (0: W1, 1: W3), feature r % 32
+            const float *m = ((r & 63) >> 5) ? a.w2 : a.w;
+            const int f = n0 + (r >> 6) * 32 + (r & 31);
+            wsrc[j] = m + (size_t)min(f, a.N - 1) * a.K + 4 * (pslot ^ swz(r));
+        } else {
+            wsrc[j] = a.w + (size_t)min(n0 + r, a.N - 1) * a.K + 4 * (pslot ^ swz(r));
+        }
     }
 #define L2Z_DMA_ISSUE(k0_, buf_)                                                                          \
     do {                                                                                                  \
         float *xs_ = smem + (buf_) * STAGE, *ws_ = xs_ + BMt * BK;                                        \
         _Pragma("unroll") for (int j = 0; j < XI; j++)                                                    \
-            lds_dma16(xsrc[j] + (k0_), xs_ + (wave * XI + j) * 4 * BK);                                    \
+            lds_dma16(xsrc[j] + (k0_), xs_ + (wave * XI + j) * RPI * BK);                                  \
         _Pragma("unroll") for (int j = 0; j < WI; j++)                                                    \
-            lds_dma16(wsrc[j] + (k0_), ws_ + (wave * WI + j) * 4 * BK);                                    \
+            lds_dma16(wsrc[j] + (k0_), ws_ + (wave * WI + j) * RPI * BK);                                  \
     } while (0)
 
     v16f acc[TM][TN];
@@ -323,13 +342,13 @@ __global__ __launch_bounds__(256 * KS) void prefill_gemm_dma(const GemmArgs a)
     for (int i = 0; i < TM; i++) {
         const int r = wm * 32 * TM + i * 32 + il;
         arow[i] = r * SLOTS;
-        asw[i] = r & 15;
+        asw[i] = swz(r);
     }
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int r = wn * 32 * TN + j * 32 + il;
         brow[j] = r * SLOTS;
-        bsw[j] = r & 15;
+        bsw[j] = swz(r);
     }
 
     L2Z_DMA_ISSUE(0, 0);
@@ -347,12 +366,15 @@ __global__ __launch_bounds__(256 * KS) void prefill_gemm_dma(const GemmArgs a)
             for (int i = 0; i < TM; i++) av[i] = xr[arow[i] + (slot ^ asw[i])];
 #pragma unroll
             for (int j = 0; j < TN; j++) bv[j] = wr[brow[j] + (slot ^ bsw[j])];
+            // four MFMAs back to back on ONE accumulator, then the next accumulator: a dependent
+            // MFMA issues at full rate only straight behind its producer (anything in between, even
+            // an MFMA on another accumulator, costs tens of cycles per step: MI355X_MICROARCH.md)
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+            for (int i = 0; i < TM; i++)
 #pragma unroll
-                for (int i = 0; i < TM; i++)
+                for (int j = 0; j < TN; j++)
 #pragma unroll
-                    for (int j = 0; j < TN; j++)
+                    for (int t = 0; t < 4; t++)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[j][t], acc[i][j], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's loads of the next stage have landed
@@ -383,7 +405,19 @@ __global__ __launch_bounds__(256 * KS) void prefill_gemm_dma(const GemmArgs a)
                         acc[i][j][r] += red[((((g - 1) * 4 + wave) * TM * TN + i * TN + j) * 16 + r) * 64 + lane];
     }
 #undef L2Z_DMA_ISSUE
-    gemm_epilogue<EPI, TM, TN>(a, acc, n0, m0, wm, wn, lane);
+    if constexpr (PAIR) {
+        const int j = n0 + wn * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int tok = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (tok < a.P && j < a.N)
+                    a.out[(size_t)tok * a.ldo + j] = swiglu_merge(acc[i][0][r], acc[i][1][r]);  // :411-416
+            }
+    } else {
+        gemm_epilogue<EPI, TM, TN>(a, acc, n0, m0, wm, wn, lane);
+    }
 }
 
 // Short prompts (P <= 64): the product is bound by streaming W once, like the decode mat-vec, and
@@ -843,14 +877,12 @@ hipError_t gemm_launch_t(const GemmArgs &a, hipStream_t st)
         if (tunables().pf_dma != 0 && a.K % 64 == 0 && a.ldx % 4 == 0) {
             size_t lds2 = 2 * (size_t)(BMt + BNt) * 64 * sizeof(float);
             if (red > lds2) lds2 = red;
-            static bool attr2 = false;
-            if (!attr2 && lds2 > 48 * 1024) {
-                (void)hipFuncSetAttribute((const void *)prefill_gemm_dma<EPI, TM, TN, KS>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-                attr2 = true;
-            }
-            hipLaunchKernelGGL((prefill_gemm_dma<EPI, TM, TN, KS>), grid, dim3(256 * KS), lds2, st, a);
-            return hipGetLastError();
+            const void *fn = (const void *)prefill_gemm_dma<EPI, TM, TN, KS, false>;
+            if (lds2 > 48 * 1024)
+                (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            GemmArgs args = a;
+            void *params[] = {&args};
+            return hipLaunchKernel(fn, grid, dim3(256 * KS), params, lds2, st);
         }
     }
     hipLaunchKernelGGL((prefill_gemm<EPI, TM, TN, BK, KS>), grid, dim3(256 * KS), lds, st, a);
@@ -915,6 +947,30 @@ hipError_t gemm_launch(const GemmArgs &a, hipStream_t st)
 
 }  // namespace
 
+// out[P,N] = silu(X W1^T) * (X W3^T) in one launch (direct-to-LDS tile kernel, paired form).
+// hipErrorNotSupported when the shape does not take that kernel: the caller launches the two GEMMs.
+hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float *w1, const float *w3,
+                                           float *out, int ldo, int P, int N, int K, hipStream_t st)
+{
+    if (tunables().pf_fuse == 0 || tunables().pf_dma == 0 || tunables().pf_tile != 0) return hipErrorNotSupported;
+    const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
+    if (P <= skinny_max || K % 64 != 0 || ldx % 4 != 0) return hipErrorNotSupported;
+    if (((uintptr_t)x & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w3 & 15)) return hipErrorInvalidValue;
+    GemmArgs a = {x, w3, w1, out, P, N, K, ldx, ldo, 0, nullptr, 0};
+    constexpr int KS = 2;
+    const bool big = P > 256;  // 128 tokens x (64 + 64) rows, as the unpaired launches pick their tiles
+    const int TM = big ? 2 : 1, TN = 2;
+    const void *fn = big ? (const void *)prefill_gemm_dma<G_STORE, 2, 2, KS, true>
+                         : (const void *)prefill_gemm_dma<G_STORE, 1, 2, KS, true>;
+    size_t lds = 2 * (size_t)(64 * TM + 64 * TN) * 64 * sizeof(float);
+    const size_t red = (size_t)(KS - 1) * 4 * TM * TN * 16 * 64 * sizeof(float);
+    if (red > lds) lds = red;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid((N + 63) / 64, (P + 64 * TM - 1) / (64 * TM));
+    void *params[] = {&a};
+    return hipLaunchKernel(fn, grid, dim3(256 * KS), params, lds, st);
+}
+
 // C[P,N] (+)= X[P,K] W[N,K]^T with the chosen epilogue; K % 4 == 0, 16-byte aligned rows
 hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w, float *out, int ldo,
                                int P, int N, int K, int pos0, const float2 *rope, int head_size,
@@ -922,7 +978,7 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
 {
     if (P <= 0 || N <= 0 || K <= 0 || (K % 4) != 0 || (ldx % 4) != 0) return hipErrorInvalidValue;
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return hipErrorInvalidValue;
-    GemmArgs a = {x, w, out, P, N, K, ldx, ldo, pos0, rope, head_size};
+    GemmArgs a = {x, nullptr, w, out, P, N, K, ldx, ldo, pos0, rope, head_size};
     switch (epi) {
         case G_STORE: return gemm_launch<G_STORE>(a, st);
         case G_RESID: return gemm_launch<G_RESID>(a, st);

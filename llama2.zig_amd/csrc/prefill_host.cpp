@@ -69,10 +69,19 @@ int prefill_chunk(l2z_runstate *s, const l2z_weights *w, const int32_t *tokens, 
         L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_att, dim, w->wo + (size_t)l * dim * dim, s->pf_x, dim,
                                     P, dim, dim, pos0, s->rope, hs, st));                   // :392-395
         L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, s->pf_x, w->rms_ffn + (size_t)l * dim, dim, P, st));  // :398
-        L2Z_HIP(launch_prefill_gemm(PG_STORE, s->pf_xn, dim, w->w1 + (size_t)l * hid * dim, s->pf_h1, hid,
-                                    P, hid, dim, pos0, s->rope, hs, st));                   // :405
-        L2Z_HIP(launch_prefill_gemm(PG_SWIGLU, s->pf_xn, dim, w->w3 + (size_t)l * hid * dim, s->pf_h1, hid,
-                                    P, hid, dim, pos0, s->rope, hs, st));   // :408 + :411-416 in the epilogue
+        // :405-416: W1 and W3 in one launch with silu(a) * b as its epilogue where the tile kernel
+        // takes the shape, else two GEMMs, the second one merging into the first one's output
+        const hipError_t pe = launch_prefill_gemm_swiglu_pair(s->pf_xn, dim, w->w1 + (size_t)l * hid * dim,
+                                                              w->w3 + (size_t)l * hid * dim, s->pf_h1, hid, P,
+                                                              hid, dim, st);
+        if (pe == hipErrorNotSupported) {
+            L2Z_HIP(launch_prefill_gemm(PG_STORE, s->pf_xn, dim, w->w1 + (size_t)l * hid * dim, s->pf_h1, hid,
+                                        P, hid, dim, pos0, s->rope, hs, st));                   // :405
+            L2Z_HIP(launch_prefill_gemm(PG_SWIGLU, s->pf_xn, dim, w->w3 + (size_t)l * hid * dim, s->pf_h1, hid,
+                                        P, hid, dim, pos0, s->rope, hs, st));   // :408 + :411-416 in the epilogue
+        } else {
+            L2Z_HIP(pe);
+        }
         L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_h1, hid, w->w2 + (size_t)l * dim * hid, s->pf_x, dim,
                                     P, dim, hid, pos0, s->rope, hs, st));                   // :419-422
     }

@@ -1,0 +1,8 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"; O=gpurun_out; mkdir -p $O
+export TMPDIR=/tmp
+python -m pytest tests -m gpu -q --timeout 900 -k "prefill" > $O/r2f_pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/r2f_pytest.log
+tail -5 $O/r2f_pytest.log
+python scripts/prefill_ab.py llama2-7b 512 4 "L2Z_PF_FUSE=0" "" 2>&1 | tee $O/r2f_prefill_ab.txt
+python scripts/prefill_ab.py llama2-7b 256 4 "L2Z_PF_FUSE=0" "" 2>&1 | tee -a $O/r2f_prefill_ab.txt
+python scripts/prefill_ab.py stories110M 512 4 "L2Z_PF_FUSE=0" "" 2>&1 | tee -a $O/r2f_prefill_ab.txt

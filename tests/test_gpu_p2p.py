@@ -28,7 +28,7 @@ MODELS = [
 def grid_cap(world: int) -> str:
     """All ranks share ONE GPU here: a mat-vec launch that may be waiting for a peer's kernel must
     leave that kernel room to run (on real multi-GPU nodes every rank has its own chip)."""
-    return str(max(64, 1024 // world))
+    return str(max(32, 512 // world))
 
 
 def run_ranks(tmp_path, world, spec, env_extra=None, timeout=300):

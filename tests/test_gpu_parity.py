@@ -609,22 +609,25 @@ PREFILL_CONFIGS = [
 
 def test_prefill_gemm_direct_to_lds_equals_register_staged(gpu, ck, options):
     """The two forms of the tile GEMM (operands by global_load_lds vs staged through registers) pair
-    the k values differently inside an MFMA, nothing else: logits and cache rows of a 300-token
-    prefill agree within the logit tolerance, for 64x64 (P <= 256) and 128x64 (P > 256) tiles."""
+    the k values differently inside an MFMA, and the paired W1|W3 launch (L2Z_PF_FUSE) computes
+    silu(a) * b in its epilogue instead of merging into the first GEMM's output -- nothing else:
+    logits and cache rows of a prefill agree within the logit tolerance, for 64-token (P <= 256)
+    and 128-token (P > 256) tiles."""
     cfg = ck.Config(dim=512, hidden_dim=1536, n_layers=2, n_heads=8, n_kv_heads=4, vocab_size=2048, seq_len=400)
     w = gpu.Weights(cfg, None, False, seed=5)
     rng = np.random.default_rng(3)
     for n in (100, 300):
         toks = [1] + rng.integers(2, cfg.vocab_size, n - 1).tolist()
         res = []
-        for dma in (1, 0):
-            options(L2Z_PF_DMA=dma)
+        for dma, fuse in ((1, 1), (0, 1), (1, 0)):
+            options(L2Z_PF_DMA=dma, L2Z_PF_FUSE=fuse)
             s = gpu.RunState(cfg)
             s.prefill(toks, 0, w)
             res.append((s.logits(), s.read("key_cache", 0, n * cfg.kv_dim), s.read("value_cache", cfg.seq_len * cfg.kv_dim, n * cfg.kv_dim)))
             s.close()
-        for a, b in zip(*res):
-            np.testing.assert_allclose(a, b, rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
+        for other in res[1:]:
+            for a, b in zip(res[0], other):
+                np.testing.assert_allclose(a, b, rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
     w.close()
 
 

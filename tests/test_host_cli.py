@@ -241,7 +241,7 @@ def test_cli_multi_gpu_mode_matches_single(gpu, n_gpus):
     ckpt = os.path.join(GOLDEN, "toy_gqa_unshared.bin")  # 4 heads, 2 kv heads: 2 ranks; hidden 172 = 4 * 43
     if n_gpus == 4:
         ckpt = os.path.join(GOLDEN, "toy_mha_shared.bin")  # 4 heads, 4 kv heads, hidden 128, vocab 300
-    env = dict(os.environ, L2Z_GRID_CAP=str(max(64, 1024 // n_gpus)), L2Z_P2P_TIMEOUT_S="30", L2Z_FUSE_SMALL="0")
+    env = dict(os.environ, L2Z_GRID_CAP=str(max(32, 512 // n_gpus)), L2Z_P2P_TIMEOUT_S="30", L2Z_FUSE_SMALL="0")
     for flags in (["-t", "0"], ["-t", "1.0", "-p", "0.9", "-s", "99"]):
         outs = []
         for g in (1, n_gpus):
