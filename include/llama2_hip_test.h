@@ -55,6 +55,12 @@ int l2z_profile_forward(int token, int pos, const l2z_config *config, l2z_runsta
                         const l2z_weights *w, double *ms_by_kind, int *launches_by_kind,
                         int n_kinds);
 int l2z_kind_name(int kind, char *out, size_t cap);
+/* Average duration of ONE launch of `kind` (0..6) at position `pos`: `reps` passes of that kind's
+ * launches for every layer, back to back between ONE event pair on the runstate's stream -- no
+ * per-launch event overhead, every launch streams its own layer's weights.  Comparable with
+ * rocprofv3 --kernel-trace durations.  Unsharded runstates only. */
+int l2z_time_kind(int kind, int pos, const l2z_config *config, l2z_runstate *s, const l2z_weights *w,
+                  int reps, double *avg_ms_per_launch, int *launches);
 
 /* ---- kernel-level test hooks (host pointers in and out; same device code
  *      the forward pass runs).  Names follow src/main.zig. ---- */

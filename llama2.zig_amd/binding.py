@@ -88,6 +88,7 @@ def lib():
                                       C.c_int]
     L.l2z_stream_read_probe.argtypes = [vp, vp, sz, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.l2z_kind_name.argtypes = [C.c_int, C.c_char_p, sz]
+    L.l2z_time_kind.argtypes = [C.c_int, C.c_int, cfgp, vp, vp, C.c_int, C.POINTER(C.c_double), ip]
     L.l2z_synchronize.argtypes = [vp]
     L.l2z_matmul.argtypes = [fp, fp, fp, sz, sz]
     L.l2z_matmul_fused.argtypes = [C.c_int, C.POINTER(fp), fp, C.POINTER(fp), sz, sz]
@@ -274,6 +275,12 @@ class RunState:
         _chk(lib().l2z_profile_forward(token, pos, C.byref(self.cfg), self.h, w.h, ms, cnt,
                                        len(KINDS)))
         return {k: (ms[i], cnt[i]) for i, k in enumerate(KINDS)}
+
+    def time_kind(self, kind: str, pos: int, w: Weights, reps: int = 4):
+        """(average ms per launch, launches) of one kind of launch, back to back between one event pair."""
+        ms, n = C.c_double(0), C.c_int(0)
+        _chk(lib().l2z_time_kind(KINDS.index(kind), pos, C.byref(self.cfg), self.h, w.h, reps, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def stream_read_probe(self, w: Weights, slice_bytes: int = 0, reps: int = 8):
         """(average, best) GB/s of a pure streaming-read kernel over the resident weight blob."""

@@ -57,7 +57,7 @@ int check_pair(const l2z_config *config, const l2z_runstate *s, const l2z_weight
 //               slot while staging x: no launch per gather, 5 nodes per layer as at world == 1;
 //   gather launch after every producer (peer writes without consumer polling, or RCCL).
 int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof *prof,
-                    int only_stage, bool split)
+                    int only_stage, bool split, int only_kind)
 {
     const l2z_config &c = s->cfg;
     const Shard &sh = s->sh;
@@ -66,6 +66,8 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
     const int mb = s->max_blocks;
     int stage = 0;
     auto want = [&]() { return only_stage < 0 || only_stage == stage; };
+    // only_kind >= 0: just the launches of one kind, back to back (l2z_time_kind: kernel duration)
+    auto kind = [&](int k) { return only_kind < 0 || only_kind == k; };
     const bool p2p = s->d_push != nullptr && only_stage < 0;
     const bool consume = p2p && s->ll_consume;
     // Producers push their outputs as LL words straight into the peers' slots (the values travel
@@ -79,7 +81,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
     auto gather = [&](float *buf, size_t count_per_rank) -> int {
         stage++;
         gi++;
-        if (only_stage >= 0) return L2Z_OK;
+        if (only_stage >= 0 || only_kind >= 0) return L2Z_OK;
         const bool was_pushed = pushed;
         pushed = false;
         if (consume) {
@@ -117,7 +119,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         float *kc = s->key_cache + (size_t)l * c.seq_len * sh.kvd_loc;  // :354 loff
         float *vc = s->value_cache + (size_t)l * c.seq_len * sh.kvd_loc;
         const bool fused = s->fused_qkv_attn && !split && only_stage < 0;
-        if (fused) {    // small models: :305-389 in one launch, one block per head (fused_small.hip)
+        if (fused && kind(KIND_QKV)) {    // small models: :305-389 in one launch, one block per head (fused_small.hip)
             FusedQkvAttnArgs a = {};
             a.wq = w->wq + (size_t)l * dim * dim;
             a.wk = w->wk + (size_t)l * dim * dim;
@@ -127,7 +129,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.n = c.dim; a.head_size = sh.hs; a.seq_len = c.seq_len; a.kv_dim = sh.kvd_loc;
             L2Z_LAUNCH(KIND_QKV, launch_fused_qkv_attn(a, c.n_heads, st));
         }
-        if (!fused && want()) {   // rmsnorm (:305) + q,k,v (:308-320) + RoPE (:336-351) + KV write (:354-358)
+        if (!fused && want() && kind(KIND_QKV)) {   // rmsnorm (:305) + q,k,v (:308-320) + RoPE (:336-351) + KV write (:354-358)
             MatvecArgs a = {};
             a.w0 = w->wq + (size_t)l * sh.dim_loc * dim;
             a.w1 = w->wk + (size_t)l * sh.kvd_loc * dim;
@@ -140,7 +142,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.pos_ptr = s->d_pos; a.rope = s->rope; a.head_size = sh.hs; a.rope_segs = 2;
             L2Z_LAUNCH(KIND_QKV, launch_matvec(a, PRO_RMS, EPI_ROPE, mb, g_cus, st));
         }
-        if (!fused && want()) {   // attention (:361-389) over the local heads
+        if (!fused && want() && kind(KIND_ATTN)) {   // attention (:361-389) over the local heads
             AttnArgs a = {};
             a.q = s->q; a.kcache = kc; a.vcache = vc; a.xb = s->xb + sh.dim0;
             a.pos_ptr = s->d_pos; a.head_size = sh.hs; a.kv_dim = sh.kvd_loc;
@@ -158,7 +160,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
                 L2Z_LAUNCH(KIND_ATTN, launch_attention(a, sh.heads_loc, st));
         }
         L2Z_TRY(gather(s->xb, sh.dim_loc));
-        if (want()) {   // wo (:392) + residual (:395)
+        if (want() && kind(KIND_WO)) {   // wo (:392) + residual (:395)
             MatvecArgs a = {};
             a.w0 = w->wo + (size_t)l * sh.dim_loc * dim;
             a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0;
@@ -168,7 +170,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             L2Z_LAUNCH(KIND_WO, launch_matvec(a, PRO_NONE, EPI_RESID, mb, g_cus, st, nullptr, &pushed));
         }
         L2Z_TRY(gather(s->x, sh.dim_loc));
-        if (want()) {   // rmsnorm (:398) + w1,w3 (:405-408) + SiLU*mul (:411-416)
+        if (want() && kind(KIND_FFN13)) {   // rmsnorm (:398) + w1,w3 (:405-408) + SiLU*mul (:411-416)
             MatvecArgs a = {};
             a.w0 = w->w1 + (size_t)l * sh.hid_loc * dim;
             a.w1 = w->w3 + (size_t)l * sh.hid_loc * dim;
@@ -180,7 +182,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             L2Z_LAUNCH(KIND_FFN13, launch_matvec(a, PRO_RMS, EPI_SWIGLU, mb, g_cus, st, nullptr, &pushed));
         }
         L2Z_TRY(gather(s->hb, sh.hid_loc));
-        if (want()) {   // w2 (:419) + residual (:422)
+        if (want() && kind(KIND_FFN2)) {   // w2 (:419) + residual (:422)
             MatvecArgs a = {};
             a.w0 = w->w2 + (size_t)l * sh.dim_loc * hid;
             a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0;
@@ -191,7 +193,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         }
         L2Z_TRY(gather(s->x, sh.dim_loc));
     }
-    if (want()) {   // final rmsnorm (:426) + classifier (:429)
+    if (want() && kind(KIND_CLS)) {   // final rmsnorm (:426) + classifier (:429)
         MatvecArgs a = {};
         a.w0 = w->wcls; a.out0 = s->logits + sh.v0;
         a.rows0 = sh.v_loc; a.n = c.dim; a.rms_w = w->rms_final;
@@ -206,7 +208,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         s->n_part = fuse ? grid : 0;
     }
     L2Z_TRY(gather(s->logits, sh.v_loc));
-    if (with_step && want()) {
+    if (with_step && want() && kind(KIND_ARGMAX)) {
         ArgmaxArgs a = {};
         a.logits = s->logits; a.vocab = c.vocab_size; a.token_ptr = s->d_token;
         if (s->n_part > 0) { a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.n_part = s->n_part; }
@@ -448,6 +450,45 @@ extern "C" int l2z_profile_forward(int token, int pos, const l2z_config *config,
     s->host_pos = pos + 1;
     if (rc != L2Z_OK) return rc;
     L2Z_HIP(e);
+    return L2Z_OK;
+}
+
+// Duration of ONE kind of launch without the per-launch event pair of l2z_profile_forward (an
+// event pair adds ~3 us to a 10-50 us kernel): the launches of that kind for every layer go out back
+// to back -- each streams its own layer's weights, nothing is re-read from cache -- between one event
+// pair on the runstate's stream; the result is the average per launch, directly comparable with
+// rocprofv3's kernel durations.  Unsharded runstates only (a sharded kind would wait for gathers).
+extern "C" int l2z_time_kind(int kind, int pos, const l2z_config *config, l2z_runstate *s,
+                             const l2z_weights *w, int reps, double *avg_ms_per_launch, int *launches)
+{
+    L2Z_TRY(check_pair(config, s, w));
+    L2Z_CHECK(kind >= 0 && kind < KIND_GATHER && avg_ms_per_launch && reps >= 1, L2Z_ERR_INVALID,
+              "l2z_time_kind: bad arguments");
+    L2Z_CHECK(s->sh.world == 1, L2Z_ERR_INVALID, "l2z_time_kind: unsharded runstates only");
+    L2Z_CHECK(pos >= 0 && pos < config->seq_len, L2Z_ERR_STATE, "pos out of range");
+    L2Z_HIP(hipSetDevice(s->device));
+    L2Z_HIP(launch_set_state(1, pos, s->d_token, s->d_pos, w->tok_emb, s->x, config->dim, s->stream));
+    hipEvent_t e0, e1;
+    L2Z_HIP(hipEventCreate(&e0));
+    L2Z_HIP(hipEventCreate(&e1));
+    const int per_pass = kind == KIND_CLS || kind == KIND_ARGMAX ? 1 : config->n_layers;
+    int rc = enqueue_forward(s, w, true, nullptr, -1, use_split(s, pos), kind);  // warm-up pass
+    hipError_t e = hipEventRecord(e0, s->stream);
+    for (int r = 0; r < reps && rc == L2Z_OK; r++) rc = enqueue_forward(s, w, true, nullptr, -1, use_split(s, pos), kind);
+    if (e == hipSuccess) e = hipEventRecord(e1, s->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    // the argmax kind advanced pos; put the loop state back
+    hipError_t e2 = launch_set_state(1, pos, s->d_token, s->d_pos, w->tok_emb, s->x, config->dim, s->stream);
+    if (e2 == hipSuccess) e2 = hipStreamSynchronize(s->stream);
+    if (rc != L2Z_OK) return rc;
+    L2Z_HIP(e);
+    L2Z_HIP(e2);
+    *avg_ms_per_launch = (double)ms / (double)(reps * per_pass);
+    if (launches) *launches = reps * per_pass;
     return L2Z_OK;
 }
 

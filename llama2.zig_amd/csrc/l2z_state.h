@@ -111,7 +111,7 @@ namespace l2z {
 struct Prof;
 int check_pair(const l2z_config *config, const l2z_runstate *s, const l2z_weights *w);
 int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof *prof, int only_stage,
-                    bool split);
+                    bool split, int only_kind = -1);
 bool use_split(const l2z_runstate *s, int pos);
 int run_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, int pos);
 void drop_graphs(l2z_runstate *s);

@@ -24,6 +24,9 @@ for v in variants:
     for k, val in kv.items():
         B.option_set(k, int(val))
     s = B.RunState(cfg)
+    # graphs are captured at the first run, with the options in force THEN (launch-time knobs such as
+    # L2Z_ROW_BLOCKS are read while the launches are enqueued): capture both graph kinds now
+    s.greedy_begin([]); s.greedy_run(w, 2); s.transformer(1, 0, w); s.synchronize()
     states.append(s)
     for k in kv:  # back to the default for the next variant (options apply at RunState creation)
         B.option_set(k, {"L2Z_ATTN_SPLIT": -1, "L2Z_ATTN_SPLIT_POS": -1, "L2Z_ROW_BLOCKS": 2, "L2Z_ATTN_BLOCK": 0,
