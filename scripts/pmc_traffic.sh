@@ -18,7 +18,8 @@ def kind(name, lds):
     if "matvec_row_kernel<1, 1" in n: return "qkv"
     if "matvec_row_kernel<1, 3" in n: return "ffn13"
     if "matvec_row_kernel<1, 4" in n: return "cls"
-    if "matvec_row_kernel<0, 2" in n: return "resid"  # wo and ffn2 alternate: split by dispatch order below
+    if "matvec_row_kernel<0, 2, 12" in n: return "ffn2"   # n = 11008: x staged 12 float4 per thread
+    if "matvec_row_kernel<0, 2, 4" in n: return "wo"      # n = 4096
     if "attention" in n: return "attn"
     return None
 acc = {c: collections.defaultdict(float) for c in ("FETCH_SIZE", "WRITE_SIZE")}
@@ -30,9 +31,6 @@ for c in acc:
     n_resid = 0
     for r in recs:
         k = kind(r["Kernel_Name"], int(r["LDS_Block_Size"]))
-        if k == "resid":  # per layer: wo (:392) comes before w2 (:419)
-            k = "wo" if n_resid % 2 == 0 else "ffn2"
-            n_resid += 1
         if k is None: continue
         acc[c][k] += float(r["Counter_Value"])
         if c == "FETCH_SIZE": cnt[k] += 1

@@ -191,7 +191,7 @@ ATTN_CASES = [
 def test_attention_kernels_vs_oracle(gpu, orc, shape, form, nch, positions):
     """The decode attention kernels the forward pass launches, one layer at a time, against the
     oracle's dot / softmax / weighted-row-sum (main.zig:361-389).  Outputs are convex combinations
-    of V entries (|v| <= 2 here), observed max |diff| ~1e-6; bound 1e-5."""
+    of V entries (|v| <= 2 here); observed max |diff| 4e-7 on MI355X (profiles/r02_parity_numbers.txt), bound 2e-6."""
     H, KV, hs, S = ATTN_SHAPES[shape]
     rng = np.random.default_rng(H * 1000 + hs)
     q = rng.standard_normal(H * hs, dtype=np.float32)
@@ -202,7 +202,7 @@ def test_attention_kernels_vs_oracle(gpu, orc, shape, form, nch, positions):
         got = gpu.attention_decode(q, kc, vc, pos, H, KV, hs, S, form=form, nch=nch)
         ref = attention_ref(orc, q, kc, vc, pos, H, KV, hs)
         worst = max(worst, float(np.abs(got - ref).max()))
-        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5, err_msg=f"{shape} {form} pos {pos}")
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6, err_msg=f"{shape} {form} pos {pos}")
     print(f"attention {shape} {form}{nch or ''}: max |diff| {worst:.2e}")
 
 
