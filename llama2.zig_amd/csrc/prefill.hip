@@ -269,6 +269,8 @@ __device__ __forceinline__ void lds_dma16(const float *g, float *lds)
 //    at 256 tokens the third buffer costs the second resident block); the second wave group issuing
 //    its loads mid-stage (+1.4 %); loads and operand reads placed by hand between the MFMA steps
 //    with sched_barrier (+9.5 %: hipcc's own interleaving of this loop is better than the pinned one).
+//    Operands of super-step s+1 read before the MFMAs of s (two register sets, order pinned with
+//    sched_group_barrier): +0.8 % / +3 % -- LDS latency is not it either.
 //    PMC of this kernel: SQ_WAIT_ANY 22 % of the wave cycles (parked at the stage barrier), MFMA
 //    pipe 66 % busy -- the per-stage barrier with one block of 8 waves per CU is what is left.
 //  * PAIR (W1 and W3 of the feed-forward in ONE launch, main.zig:405-416): the block's two n-tiles

@@ -193,8 +193,14 @@ size_t sample_top_p(const float *probs, size_t n, float p, std::vector<IndexedF3
     for (size_t i = 0; i < n; i++)
         if (probs[i] >= cutoff) scratch.push_back({(uint32_t)i, probs[i]});
     if (scratch.empty()) return argmax(probs, n);  // reference asserts; be safe in release
-    std::sort(scratch.begin(), scratch.end(),
-              [](const IndexedF32 &a, const IndexedF32 &b) { return a.value > b.value; });  // :774
+    // :774 sorts descending by probability with std.sort.pdq, an UNSTABLE sort whose order among
+    // equal probabilities is an implementation detail of Zig's library (not available here).  The
+    // comparator is made total -- ties go to the lower token id -- so that the nucleus and the
+    // sampled token are at least deterministic across standard libraries; with tied probabilities
+    // at the cut they can differ from the reference binary's for the same seed.
+    std::sort(scratch.begin(), scratch.end(), [](const IndexedF32 &a, const IndexedF32 &b) {
+        return a.value > b.value || (a.value == b.value && a.index < b.index);
+    });
     float cumulative = 0.0f;
     size_t cutoff_index = scratch.size() - 1;  // :778
     for (size_t i = 0; i < scratch.size(); i++) {
