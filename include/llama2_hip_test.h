@@ -94,6 +94,11 @@ int l2z_attention_decode(int form, int nch, float *out, const float *q, const fl
 int l2z_comm_init_emulated(int rank, int world, int device, l2z_comm **out);
 int l2z_emu_transformer(int n_ranks, l2z_runstate *const *ss, const l2z_weights *const *ws,
                         int token, int pos);
+/* l2z_prefill for the emulated ranks: every rank's own launches of each stage (llama2.zig_amd/csrc/
+ * prefill_host.cpp), the [tokens, n / world] activation blocks exchanged as device-to-device copies.
+ * Afterwards every rank's KV shard and logits must equal the unsharded l2z_prefill, bit for bit. */
+int l2z_emu_prefill(int n_ranks, l2z_runstate *const *ss, const l2z_weights *const *ws,
+                    const int32_t *tokens, int n_tokens, int pos0);
 
 /* Set one tuning knob by its environment-variable name (csrc/tunables.h), e.g. ("L2Z_P2P_CONSUME", 0).
  * Applies to objects created afterwards.  L2Z_ERR_INVALID for an unknown name. */

@@ -108,6 +108,7 @@ def lib():
     L.l2z_comm_free.restype = None
     L.l2z_comm_init_emulated.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.l2z_emu_transformer.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int]
+    L.l2z_emu_prefill.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int32), C.c_int, C.c_int]
     L.l2z_shard_range.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64),
                                   C.POINTER(C.c_int64)]
     _lib = L
@@ -309,6 +310,15 @@ def emu_transformer(states, weights, token: int, pos: int) -> None:
     ss = (C.c_void_p * n)(*[s.h for s in states])
     ws = (C.c_void_p * n)(*[w.h for w in weights])
     _chk(lib().l2z_emu_transformer(n, ss, ws, token, pos))
+
+
+def emu_prefill(states, weights, tokens, pos0: int) -> None:
+    """l2z_prefill for N emulated ranks on one GPU (l2z_emu_prefill)."""
+    n = len(states)
+    ss = (C.c_void_p * n)(*[s.h for s in states])
+    ws = (C.c_void_p * n)(*[w.h for w in weights])
+    t = np.ascontiguousarray(tokens, dtype=np.int32)
+    _chk(lib().l2z_emu_prefill(n, ss, ws, t.ctypes.data_as(C.POINTER(C.c_int32)), len(t), pos0))
 
 
 # ---- kernel-level hooks (names follow src/main.zig) ----

@@ -117,6 +117,43 @@ int comm_allgather_inplace(const l2z_comm *c, float *buf, size_t count_per_rank,
     return L2Z_OK;
 }
 
+bool comm_bulk_ok(const l2z_comm *c, size_t floats)
+{
+    if (c == nullptr || c->world <= 1) return false;
+    if (comm_uses_p2p(c)) return floats <= c->bulk_floats;
+    return c->nccl != nullptr;
+}
+
+int comm_bulk_allgather(const l2z_comm *c, float *stage, int P, int n_loc, float *dst, int ldd, hipStream_t st)
+{
+    L2Z_CHECK(c != nullptr && c->world > 1, L2Z_ERR_STATE, "bulk all-gather without a shard group");
+    const size_t count = (size_t)P * (size_t)n_loc;
+    BulkArgs a = {};
+    a.stage = stage; a.P = P; a.n_loc = n_loc; a.rank = c->rank; a.world = c->world;
+    if (comm_uses_p2p(c)) {
+        L2Z_CHECK(count * (size_t)c->world <= c->bulk_floats, L2Z_ERR_COMM,
+                  "bulk gather of %zu floats exceeds the bulk landing region (%zu)", count * (size_t)c->world,
+                  c->bulk_floats);
+        for (int r = 0; r < c->world; r++) a.peer_arena[r] = c->peer_arena[r];
+        a.bulk_off = kP2pFlagBytes + 2 * c->slot_floats * 8;
+        a.bulk_floats = c->bulk_floats;
+        a.ctl = c->d_ctl; a.err = c->h_err;
+        a.timeout_ticks = tunables().p2p_timeout_s * 100000000LL;
+        const unsigned long long e = ++c->bulk_epoch;
+        hipError_t he = launch_bulk_push(a, e, st);
+        if (he == hipSuccess) he = launch_bulk_unpack(a, e, 1, dst, ldd, st);
+        L2Z_CHECK(he == hipSuccess, L2Z_ERR_HIP, "bulk gather launch failed: %s", hipGetErrorString(he));
+        return L2Z_OK;
+    }
+    L2Z_CHECK(c->nccl != nullptr, L2Z_ERR_COMM, "bulk all-gather: the shard group has no transport");
+    ncclResult_t r = g_api.AllGather(stage + (size_t)c->rank * count, stage, count, ncclFloat,
+                                     static_cast<ncclComm_t>(c->nccl), st);
+    L2Z_CHECK(r == ncclSuccess, L2Z_ERR_COMM, "ncclAllGather failed: %s", g_api.GetErrorString(r));
+    hipError_t he = launch_bulk_unpack(a, 0, 0, dst, ldd, st);
+    L2Z_CHECK(he == hipSuccess, L2Z_ERR_HIP, "bulk unpack launch failed: %s", hipGetErrorString(he));
+    return L2Z_OK;
+}
+
 }  // namespace l2z
 
 using namespace l2z;
@@ -192,7 +229,12 @@ extern "C" int l2z_comm_p2p_export(l2z_comm *c, size_t max_vector_floats, void *
     static_assert(sizeof(hipIpcMemHandle_t) == L2Z_COMM_IPC_BYTES, "hipIpcMemHandle_t size");
     L2Z_HIP(hipSetDevice(c->device));
     c->slot_floats = (max_vector_floats + 1023) & ~(size_t)1023;
-    const size_t bytes = kP2pFlagBytes + 2 * c->slot_floats * 8;  // 8-byte {value, epoch} words
+    // bulk regions for the sharded prefill's [chunk tokens, dim | hidden_dim] activation matrices
+    // (plain floats); the caller's longest vector bounds both.  L2Z_P2P_BULK_MB overrides, 0 = none
+    // (sharded runstates then step their prompts token by token).
+    c->bulk_floats = tunables().p2p_bulk_mb >= 0 ? ((size_t)tunables().p2p_bulk_mb << 20) / 4
+                                                 : c->slot_floats * (size_t)prefill_chunk_tokens();
+    const size_t bytes = kP2pFlagBytes + 2 * c->slot_floats * 8 + 2 * c->bulk_floats * 4;  // LL: 8-byte {value, epoch} words
     // fine-grained: peers' stores and this rank's flag polls / landing reads are coherent inside
     // a running kernel (ordinary hipMalloc memory is only coherent at kernel boundaries)
     L2Z_HIP(hipExtMallocWithFlags((void **)&c->arena, bytes, hipDeviceMallocFinegrained));

@@ -379,8 +379,7 @@ extern "C" int l2z_greedy_run(const l2z_config *config, l2z_runstate *s, const l
     // prompt, no prompt token is BOS (the loop would stop there, :1017) and L2Z_PREFILL != 0.
     const int np = (int)s->h_prompt.size();
     if (s->host_pos == 0 && np >= kPrefillMinPrompt && remaining >= np && prefill_enabled() &&
-        s->sh.world == 1 && config->dim % 4 == 0 && config->hidden_dim % 4 == 0 &&
-        s->sh.hs % 4 == 0 && s->sh.hs <= 256 &&
+        prefill_usable(s) &&
         std::find(s->h_prompt.begin(), s->h_prompt.end(), 1) == s->h_prompt.end()) {
         std::vector<int32_t> in((size_t)np);
         in[0] = 1;

@@ -10,6 +10,7 @@ constexpr size_t kP2pFlagBytes = 4096;  // reserved head of every arena
 constexpr int kCtlEpoch = 0;  // epochs used up by completed passes: gather gi of the running pass is ctl[0] + gi
 constexpr int kCtlDone = 1;   // blocks of the pass-closing gather that have finished
 constexpr int kCtlErr = 2;    // != 0 once a wait has timed out: later waits give up at once
+constexpr int kCtlBulkDone = 3;  // blocks of the running bulk push that have finished
 constexpr int kCtlInts = 8;
 
 struct l2z_comm {
@@ -24,6 +25,10 @@ struct l2z_comm {
     char *peer_arena[kMaxWorld] = {}; // every rank's arena mapped here ([rank] == arena)
     int *d_ctl = nullptr;             // [kCtlInts] epoch counter, arrival counter, error latch (device)
     int *h_err = nullptr;             // pinned host int: a wait timed out (peer died / desync)
+    // bulk landing regions behind the two LL slots (sharded prefill: [P, n] activation blocks travel
+    // as plain 16-byte stores + one flag per sender in the arena's reserved head); 0: none
+    size_t bulk_floats = 0;
+    mutable unsigned long long bulk_epoch = 0;  // bulk gathers issued (every rank issues the same sequence)
 };
 
 namespace l2z {
@@ -56,6 +61,33 @@ bool comm_p2p_args(const l2z_comm *c, float *buf, size_t count_per_rank, bool se
 LLIn comm_ll_in(const l2z_comm *c, int gi, size_t count_per_rank);
 // the peer-write transport is connected and not overridden by L2Z_COMM=rccl
 bool comm_uses_p2p(const l2z_comm *c);
+
+// ---- bulk all-gather of activation blocks (sharded prefill) ----
+// Every rank holds its [P, n_loc] block (contiguous) at stage + rank * P * n_loc; afterwards
+// dst[t * ldd + p * n_loc + j] = rank p's block[t][j] for every p: the row-major [P, world * n_loc]
+// matrix the next GEMM reads.  Peer-write transport: a push launch stores the block into every peer's
+// bulk region and then one flag per peer; the unpack launch waits for each sender's flag.  RCCL: an
+// in-place ncclAllGather over the staging buffer, then the same unpack without waits.
+int comm_bulk_allgather(const l2z_comm *c, float *stage, int P, int n_loc, float *dst, int ldd, hipStream_t st);
+// whether comm_bulk_allgather can carry P x n_total floats (a transport is there and, peer-write, the
+// bulk regions are large enough)
+bool comm_bulk_ok(const l2z_comm *c, size_t floats);
+
+struct BulkArgs {
+    float *stage;        // [world][P * n_loc]
+    int P, n_loc;
+    int rank, world;
+    char *peer_arena[kMaxWorld];
+    size_t bulk_off;     // bytes from the arena base to bulk region 0
+    size_t bulk_floats;  // floats per region
+    int *ctl, *err;
+    long long timeout_ticks;
+};
+hipError_t launch_bulk_push(const BulkArgs &a, unsigned long long e, hipStream_t st);
+// wait != 0: blocks of peers' data come from this rank's bulk region (e & 1) once the sender's flag
+// says e; else every block is read from the staging buffer
+hipError_t launch_bulk_unpack(const BulkArgs &a, unsigned long long e, int wait, float *dst, int ldd,
+                              hipStream_t st);
 
 #ifdef __HIPCC__
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));

@@ -190,9 +190,10 @@ size_t attention_lds_bytes(int head_size, int seq_len, bool vec);
 // ---- batched prefill (prefill.hip) ----
 enum PrefillGemmEpi { PG_STORE = 0, PG_RESID = 1, PG_ROPE = 2, PG_ROPE_CACHE = 3, PG_CACHE = 4,
                       PG_SWIGLU = 5 };  // out = silu(out) * (X W^T): the W3 product merged into W1's
+// PG_RESID: out = res + X W^T (res == nullptr: in place, res = out, ldres = ldo)
 hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w, float *out, int ldo,
                                int P, int N, int K, int pos0, const float2 *rope, int head_size,
-                               hipStream_t st);
+                               hipStream_t st, const float *res = nullptr, int ldres = 0);
 hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float *w1, const float *w3,
                                            float *out, int ldo, int P, int N, int K, hipStream_t st);
 hipError_t launch_prefill_rmsnorm(float *o, const float *x, const float *w, int n, int P,
@@ -201,7 +202,8 @@ hipError_t launch_prefill_embed(float *x, const float *tok_emb, const int *token
                                 hipStream_t st);
 hipError_t launch_prefill_attention(const float *q, int ldq, const float *kcache, const float *vcache,
                                     float *out, int ldo, int pos0, int P, int n_heads, int head_size,
-                                    int kv_dim, int kv_mul, int seq_len, hipStream_t st);
+                                    int kv_dim, int kv_mul, int seq_len, hipStream_t st,
+                                    int n_heads_model = 0);  // heads of the whole model when n_heads is a shard's
 size_t matvec_lds_bytes(int n);
 
 }  // namespace l2z

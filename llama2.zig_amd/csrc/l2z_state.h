@@ -79,6 +79,7 @@ struct l2z_runstate {
     // batched prefill scratch (allocated on first l2z_prefill): [kPrefillChunk, dim|hidden]
     float *pf_x = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_att = nullptr;
     float *pf_h1 = nullptr;
+    float *pf_stage = nullptr;  // sharded: [world][P, n_loc] blocks of the matrix being gathered
     int *pf_tokens = nullptr;
     float *d_part_val = nullptr;  // classifier launch's per-block argmax candidates
     int *d_part_idx = nullptr;
@@ -119,6 +120,7 @@ void drop_graphs(l2z_runstate *s);
 // prefill_host.cpp
 constexpr int kPrefillMinPrompt = L2Z_PREFILL_MIN_PROMPT;  // shorter prompts: the stepped loop is as fast
 bool prefill_enabled();
+bool prefill_usable(const l2z_runstate *s);
 int prefill_check(const l2z_config *config, const l2z_runstate *s);
 int prefill_tokens(l2z_runstate *s, const l2z_weights *w, const int32_t *tokens, int n_tokens, int pos0);
 

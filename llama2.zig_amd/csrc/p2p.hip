@@ -38,6 +38,7 @@
 #include <hip/hip_runtime.h>
 
 #include "l2z_comm.h"
+#include "tunables.h"
 
 namespace l2z {
 namespace {
@@ -115,7 +116,115 @@ __global__ __launch_bounds__(256) void p2p_allgather_kernel(const P2pArgs a, int
     }
 }
 
+// ---- bulk form (sharded prefill): [P, n_loc] blocks of floats, plain stores, one flag per sender ----
+// A gather of a whole activation matrix is bandwidth-, not latency-bound: the LL form's 8 bytes per
+// float would double the xGMI traffic for nothing.  The sender stores its block into region (e & 1)
+// of every peer's arena (16-byte stores), makes them visible (system-scope release fence, which also
+// waits for the stores to be acknowledged), and the LAST block of the launch to get there writes
+// flag[rank] = e into every peer's reserved head.  The receiver's unpack launch waits per sender for
+// flag[p] >= e (epochs only grow), acquires, and copies that block into the row-major matrix.  Two
+// regions suffice for the same reason two LL slots do: a rank pushes gather g+2 only after its own
+// unpack of g+1 has run, and that waited for every peer's push of g+1, which each peer issued
+// behind its unpack of g.
+constexpr int kBulkBlocksPerPeer = 16;
+
+__device__ __forceinline__ float *bulk_region(char *arena, const BulkArgs &a, u64 e)
+{
+    return (float *)(arena + a.bulk_off) + (size_t)(e & 1) * a.bulk_floats;
+}
+
+__global__ __launch_bounds__(256) void bulk_push_kernel(const BulkArgs a, u64 e)
+{
+    // peers in ring order from this rank, so that the ranks do not all start on the same receiver
+    const int pi = blockIdx.x / kBulkBlocksPerPeer, part = blockIdx.x % kBulkBlocksPerPeer;
+    const int p = (a.rank + 1 + pi) % a.world;
+    const size_t count = (size_t)a.P * a.n_loc;
+    const float *src = a.stage + (size_t)a.rank * count;
+    float *dst = bulk_region(a.peer_arena[p], a, e) + (size_t)a.rank * count;
+    if ((count & 3) == 0) {  // blocks start 16-byte aligned
+        const size_t n4 = count >> 2;
+        for (size_t i = (size_t)part * 256 + threadIdx.x; i < n4; i += (size_t)kBulkBlocksPerPeer * 256)
+            ((float4 *)dst)[i] = ((const float4 *)src)[i];
+    } else {
+        for (size_t i = (size_t)part * 256 + threadIdx.x; i < count; i += (size_t)kBulkBlocksPerPeer * 256)
+            dst[i] = src[i];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0 &&
+        __hip_atomic_fetch_add(a.ctl + kCtlBulkDone, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+        __hip_atomic_store(a.ctl + kCtlBulkDone, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_system();
+        for (int q = 0; q < a.world; q++)
+            if (q != a.rank)
+                __hip_atomic_store((u64 *)a.peer_arena[q] + a.rank, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+__global__ __launch_bounds__(256) void bulk_unpack_kernel(const BulkArgs a, u64 e, int wait, float *dst, int ldd)
+{
+    const int p = blockIdx.x, part = blockIdx.y, parts = gridDim.y;
+    const size_t count = (size_t)a.P * a.n_loc;
+    const float *src = a.stage + (size_t)p * count;
+    if (wait && p != a.rank) {
+        __shared__ int s_fail;
+        if (threadIdx.x == 0) {
+            s_fail = 0;
+            const u64 *flag = (const u64 *)a.peer_arena[a.rank] + p;
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < e) {
+                if (__hip_atomic_load(a.ctl + kCtlErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                    wall_clock64() - t0 > a.timeout_ticks) {
+                    s_fail = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (s_fail) {
+                __hip_atomic_store(a.ctl + kCtlErr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *a.err = 1 + p;
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: the sender's stores, not a stale line
+        src = bulk_region(a.peer_arena[a.rank], a, e) + (size_t)p * count;
+    }
+    // rows of the block -> columns [p * n_loc, (p + 1) * n_loc) of the row-major matrix
+    const int n_loc = a.n_loc;
+    if ((n_loc & 3) == 0 && (ldd & 3) == 0) {
+        const int n4 = n_loc >> 2;
+        const size_t total = (size_t)a.P * n4;
+        for (size_t i = (size_t)part * 256 + threadIdx.x; i < total; i += (size_t)parts * 256) {
+            const size_t t = i / n4, j = i - t * n4;
+            ((float4 *)(dst + t * ldd + (size_t)p * n_loc))[j] = ((const float4 *)(src + t * n_loc))[j];
+        }
+    } else {
+        for (size_t i = (size_t)part * 256 + threadIdx.x; i < count; i += (size_t)parts * 256) {
+            const size_t t = i / n_loc, j = i - t * n_loc;
+            dst[t * ldd + (size_t)p * n_loc + j] = src[i];
+        }
+    }
+}
+
 }  // namespace
+
+hipError_t launch_bulk_push(const BulkArgs &a, unsigned long long e, hipStream_t st)
+{
+    if (a.world < 2) return hipSuccess;
+    hipLaunchKernelGGL(bulk_push_kernel, dim3((a.world - 1) * kBulkBlocksPerPeer), dim3(256), 0, st, a, (u64)e);
+    return hipGetLastError();
+}
+
+hipError_t launch_bulk_unpack(const BulkArgs &a, unsigned long long e, int wait, float *dst, int ldd,
+                              hipStream_t st)
+{
+    // enough blocks to move the matrix at memory speed; when ranks share a GPU (L2Z_GRID_CAP set: the
+    // one-GPU tests) a waiting launch stays small, so that the senders' launches have room to run
+    const int blocks = wait && tunables().grid_cap > 0 ? (tunables().grid_cap < 128 ? tunables().grid_cap : 128) : 512;
+    const int parts = (blocks + a.world - 1) / a.world;
+    hipLaunchKernelGGL(bulk_unpack_kernel, dim3(a.world, parts), dim3(256), 0, st, a, (u64)e, wait, dst, ldd);
+    return hipGetLastError();
+}
 
 hipError_t launch_p2p_allgather(const P2pArgs &a, int gi, int n_gathers, bool pushed, hipStream_t st)
 {

@@ -39,12 +39,56 @@ __device__ __forceinline__ float swiglu_merge(float h1, float h3)
     return v * h3;
 }
 
+// compute units of the current device (tile choice: does the larger tile still give every CU a block?)
+static int g_cus_hint()
+{
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            cus = n;
+        else
+            return 256;
+    }
+    return cus;
+}
+
+// Output tile of the direct-to-LDS kernel for a [P, N] product.  All forms split and order k the same
+// way (two k-groups per 64-k stage, MFMA pairing (8s+t, 8s+4+t)), so the choice never changes a bit of
+// the result (tests: sharded == unsharded, L2Z_PF_TILE forms equal) -- it is purely a question of
+// filling 256 CUs:  cost = tiles in sequence on the busiest CU x tile area / efficiency of the form,
+// efficiencies from interleaved A/B runs on the 7B and 110M shapes (larger tiles bring
+// fewer bytes per flop into the CU).  The 7B shape at 512 tokens keeps 128 x 64; 65..128-token prompts,
+// small models and row shards (N / world features) take the 32-token forms.
+enum TileForm { TILE_128x64 = 0, TILE_64x64, TILE_32x64, TILE_32x32 };
+static TileForm choose_tile(int N, int P, bool pair)
+{
+    const long long cus = g_cus_hint();
+    // tokens, features (of each matrix when paired) per block, relative efficiency
+    static const struct { int tok, feat; double eff; } form[4] = {{128, 64, 1.0}, {64, 64, 0.87}, {32, 64, 0.80}, {32, 32, 0.65}};
+    int best = -1;
+    double best_cost = 0.0;
+    for (int f = 0; f < 4; f++) {
+        if (f == TILE_128x64 && P <= 256) continue;  // (two resident 64 x 64 blocks per CU do better there: measured)
+        const long long blocks = (long long)((N + form[f].feat - 1) / form[f].feat) * ((P + form[f].tok - 1) / form[f].tok);
+        const double cost = (double)((blocks + cus - 1) / cus) * (form[f].tok * form[f].feat) / form[f].eff;
+        if (best < 0 || cost < best_cost * 0.999) {  // ties: the larger tile
+            best = f;
+            best_cost = cost;
+        }
+    }
+    (void)pair;  // the paired forms have twice the area each: the same ranking
+    return (TileForm)best;
+}
+
 struct GemmArgs {
     const float *x;      // [P, K] row-major (ldx floats per row)
     const float *w2;     // paired form only: the second [N, K] matrix (W3 beside W1)
     const float *w;      // [N, K] row-major
     float *out;          // [P, ldo]; G_*CACHE: cache base, row = pos0 + token
-    int P, N, K, ldx, ldo;
+    const float *res;    // G_RESID: out = res + product ([P, ldres]; the unsharded pass has res == out)
+    int P, N, K, ldx, ldo, ldres;
     int pos0;            // position of token 0 (RoPE angle, cache row)
     const float2 *rope;  // (seq_len, head_size/2) {cos, sin}
     int head_size;
@@ -76,7 +120,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, v16f (&acc)[TM]
                 }
                 if (tok < a.P && j < a.N) {
                     if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + j] = v;
-                    else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + j] += v;        // main.zig:711
+                    else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + j] = a.res[(size_t)tok * a.ldres + j] + v;  // main.zig:711
                     else if (EPI == G_SWIGLU)
                         a.out[(size_t)tok * a.ldo + j] = swiglu_merge(a.out[(size_t)tok * a.ldo + j], v);
                     else a.out[(size_t)(a.pos0 + tok) * a.ldo + j] = v;                  // main.zig:354-358
@@ -282,21 +326,26 @@ __device__ __forceinline__ void lds_dma16(const float *g, float *lds)
 //    three resident blocks per CU instead of one) +4.9 % time; an XCD-aware block -> tile map that
 //    keeps each XCD on one 128-row X tile (L2 resident, only W streams) +0.6 %; neither LDS
 //    capacity, nor the memory side, nor latency is what the MFMA pipe waits for.
-template <int EPI, int TM, int TN, int KS, bool PAIR = false>
-__global__ __launch_bounds__(256 * KS) void prefill_gemm_dma(const GemmArgs a)
+//  * Also measured and not kept: 3 / 4 stage buffers (counted vmcnt waits, bare s_barrier) for grids
+//    that leave every block a CU to itself (row shards, 256-token prompts): +0.8 ... +1.3 % time.  A
+//    lone 64 x 64 block already runs at 0.68 of its CU's MFMA peak -- such grids are short of blocks,
+//    not of latency hiding.
+template <int EPI, int TM, int TN, int KS, bool PAIR = false, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const GemmArgs a)
 {
     static_assert(!PAIR || TN == 2, "paired form: one W1 tile and one W3 tile per wave column");
     constexpr int BK = 64, SLOTS = BK / 4;
     constexpr int RPI = 64 / SLOTS;                  // tile rows per 1-KB load
-    constexpr int BMt = 64 * TM, BNt = 64 * TN;
-    constexpr int NW = 4 * KS;                       // waves
+    constexpr int BMt = 32 * WM * TM, BNt = 32 * WN * TN;
+    constexpr int NWG = WM * WN;                     // waves per k-group: WM x WN of them tile the block
+    constexpr int NW = NWG * KS;                     // waves
     constexpr int XI = BMt / RPI / NW, WI = BNt / RPI / NW;  // 1-KB loads per wave and stage
     static_assert(BMt % (RPI * NW) == 0 && BNt % (RPI * NW) == 0, "tile rows per wave");
     constexpr int STAGE = (BMt + BNt) * BK;          // floats
     auto swz = [](int row) { return row & 15; };
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) & 1, wn = wave & 1, kg = wave >> 2;
+    const int wg = wave % NWG, kg = wave / NWG, wm = wg / WN, wn = wg % WN;
     const int n0 = blockIdx.x * (PAIR ? BNt / 2 : BNt), m0 = blockIdx.y * BMt;
 
     // this lane's part of every load: row (within the RPI-row group) lane / SLOTS, physical slot lane % SLOTS
@@ -353,38 +402,38 @@ __global__ __launch_bounds__(256 * KS) void prefill_gemm_dma(const GemmArgs a)
         bsw[j] = swz(r);
     }
 
+#define L2Z_MULTIPLY_STAGE(buf_)                                                                         \
+    do {                                                                                                  \
+        const v4f *xr = (const v4f *)(smem + (buf_) * STAGE), *wr = xr + BMt * SLOTS;                      \
+        _Pragma("unroll") for (int s = 0; s < SS; s++) {                                                   \
+            const int slot = kg * SPG + 2 * s + hl;                                                       \
+            v4f av[TM], bv[TN];                                                                           \
+            _Pragma("unroll") for (int i = 0; i < TM; i++) av[i] = xr[arow[i] + (slot ^ asw[i])];          \
+            _Pragma("unroll") for (int j = 0; j < TN; j++) bv[j] = wr[brow[j] + (slot ^ bsw[j])];          \
+            /* four MFMAs back to back on ONE accumulator, then the next accumulator: a dependent MFMA */ \
+            /* issues at full rate only straight behind its producer (anything in between, even an    */ \
+            /* MFMA on another accumulator, costs tens of cycles per step: MI355X_MICROARCH.md)        */ \
+            _Pragma("unroll") for (int i = 0; i < TM; i++)                                                 \
+                _Pragma("unroll") for (int j = 0; j < TN; j++)                                             \
+                    _Pragma("unroll") for (int t = 0; t < 4; t++)                                          \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[j][t], acc[i][j], 0, 0, 0); \
+        }                                                                                                 \
+    } while (0)
+
     L2Z_DMA_ISSUE(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int buf = 0;
     for (int k0 = 0; k0 < a.K; k0 += BK) {
         if (k0 + BK < a.K) L2Z_DMA_ISSUE(k0 + BK, buf ^ 1);
-        const v4f *xr = (const v4f *)(smem + buf * STAGE), *wr = xr + BMt * SLOTS;
-#pragma unroll
-        for (int s = 0; s < SS; s++) {
-            const int slot = kg * SPG + 2 * s + hl;
-            v4f av[TM], bv[TN];
-#pragma unroll
-            for (int i = 0; i < TM; i++) av[i] = xr[arow[i] + (slot ^ asw[i])];
-#pragma unroll
-            for (int j = 0; j < TN; j++) bv[j] = wr[brow[j] + (slot ^ bsw[j])];
-            // four MFMAs back to back on ONE accumulator, then the next accumulator: a dependent
-            // MFMA issues at full rate only straight behind its producer (anything in between, even
-            // an MFMA on another accumulator, costs tens of cycles per step: MI355X_MICROARCH.md)
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++)
-#pragma unroll
-                    for (int t = 0; t < 4; t++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[j][t], acc[i][j], 0, 0, 0);
-        }
+        L2Z_MULTIPLY_STAGE(buf);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's loads of the next stage have landed
         __syncthreads();                                  // everyone's have, and nobody still reads this one
         buf ^= 1;
     }
+#undef L2Z_MULTIPLY_STAGE
     if (KS > 1) {
-        float *red = smem;  // [KS-1][4 waves][TM*TN*16][64 lanes]
+        float *red = smem;  // [KS-1][NWG waves][TM*TN*16][64 lanes]
         if (kg > 0) {
 #pragma unroll
             for (int i = 0; i < TM; i++)
@@ -392,7 +441,7 @@ __global__ __launch_bounds__(256 * KS) void prefill_gemm_dma(const GemmArgs a)
                 for (int j = 0; j < TN; j++)
 #pragma unroll
                     for (int r = 0; r < 16; r++)
-                        red[((((kg - 1) * 4 + (wave & 3)) * TM * TN + i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+                        red[((((kg - 1) * NWG + wg) * TM * TN + i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
         }
         __syncthreads();
         if (kg > 0) return;
@@ -404,7 +453,7 @@ __global__ __launch_bounds__(256 * KS) void prefill_gemm_dma(const GemmArgs a)
                 for (int j = 0; j < TN; j++)
 #pragma unroll
                     for (int r = 0; r < 16; r++)
-                        acc[i][j][r] += red[((((g - 1) * 4 + wave) * TM * TN + i * TN + j) * 16 + r) * 64 + lane];
+                        acc[i][j][r] += red[((((g - 1) * NWG + wave) * TM * TN + i * TN + j) * 16 + r) * 64 + lane];
     }
 #undef L2Z_DMA_ISSUE
     if constexpr (PAIR) {
@@ -507,7 +556,7 @@ __global__ __launch_bounds__(64 * kSkWaves) void prefill_skinny(const GemmArgs a
         }
         if (tok < a.P && f < a.N) {
             if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + f] = v;
-            else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + f] += v;
+            else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + f] = a.res[(size_t)tok * a.ldres + f] + v;
             else if (EPI == G_SWIGLU) a.out[(size_t)tok * a.ldo + f] = swiglu_merge(a.out[(size_t)tok * a.ldo + f], v);
             else a.out[(size_t)(a.pos0 + tok) * a.ldo + f] = v;
         }
@@ -599,7 +648,7 @@ __global__ __launch_bounds__(kPfBlock) void prefill_skinny_lds(const GemmArgs a)
         }
         if (tok < a.P && f < a.N) {
             if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + f] = v;
-            else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + f] += v;
+            else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + f] = a.res[(size_t)tok * a.ldres + f] + v;
             else if (EPI == G_SWIGLU) a.out[(size_t)tok * a.ldo + f] = swiglu_merge(a.out[(size_t)tok * a.ldo + f], v);
             else a.out[(size_t)(a.pos0 + tok) * a.ldo + f] = v;
         }
@@ -891,6 +940,23 @@ hipError_t gemm_launch_t(const GemmArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
+// the direct-to-LDS tile kernel with fewer waves per block -- 32 x 64 (1 x 2 waves per k-group) and
+// 32 x 32 (1 x 1) output tiles: same k split and order as the 2 x 2 forms (bit-identical results), more
+// blocks for grids that would leave CUs idle.  false: shape not taken (K % 64, alignment, L2Z_PF_DMA=0).
+template <int EPI, int WM, int WN>
+bool gemm_launch_small(const GemmArgs &a, hipStream_t st, hipError_t *err)
+{
+    if (tunables().pf_dma == 0 || a.K % 64 != 0 || a.ldx % 4 != 0) return false;
+    constexpr int KS = 2, BMt = 32 * WM, BNt = 32 * WN;
+    const size_t lds = 2 * (size_t)(BMt + BNt) * 64 * sizeof(float);
+    const void *fn = (const void *)prefill_gemm_dma<EPI, 1, 1, KS, false, WM, WN>;
+    dim3 grid((a.N + BNt - 1) / BNt, (a.P + BMt - 1) / BMt);
+    GemmArgs args = a;
+    void *params[] = {&args};
+    *err = hipLaunchKernel(fn, grid, dim3(64 * WM * WN * KS), params, lds, st);
+    return true;
+}
+
 template <int EPI, int TMS>
 hipError_t skinny_launch_t(const GemmArgs &a, hipStream_t st)
 {
@@ -939,11 +1005,19 @@ hipError_t gemm_launch(const GemmArgs &a, hipStream_t st)
     case 6: return gemm_launch_t<EPI, 1, 2, 64, 2>(a, st);
     case 7: return gemm_launch_t<EPI, 2, 2, 32, 2>(a, st);
     case 8: return gemm_launch_t<EPI, 2, 1, 64, 2>(a, st);
+    case 9: { hipError_t e; if (gemm_launch_small<EPI, 1, 2>(a, st, &e)) return e; break; }
+    case 10: { hipError_t e; if (gemm_launch_small<EPI, 1, 1>(a, st, &e)) return e; break; }
     default: break;
     }
     // 64 x 64 tiles fill the 256 CUs from N = 4096 at 256 tokens; beyond that 128 x 64 halves
     // the LDS operand reads per MFMA (measured on the 7B shape: 94.7 vs 89.5 TFLOP/s at 512)
-    if (a.P > 256) return gemm_launch_t<EPI, 2, 1, 64, 2>(a, st);
+    hipError_t e;
+    switch (choose_tile(a.N, a.P, false)) {
+    case TILE_128x64: return gemm_launch_t<EPI, 2, 1, 64, 2>(a, st);
+    case TILE_32x64: if (gemm_launch_small<EPI, 1, 2>(a, st, &e)) return e; break;
+    case TILE_32x32: if (gemm_launch_small<EPI, 1, 1>(a, st, &e)) return e; break;
+    default: break;
+    }
     return gemm_launch_t<EPI, 1, 1, 64, 2>(a, st);
 }
 
@@ -958,29 +1032,34 @@ hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float 
     const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
     if (P <= skinny_max || K % 64 != 0 || ldx % 4 != 0) return hipErrorNotSupported;
     if (((uintptr_t)x & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w3 & 15)) return hipErrorInvalidValue;
-    GemmArgs a = {x, w3, w1, out, P, N, K, ldx, ldo, 0, nullptr, 0};
+    GemmArgs a = {x, w3, w1, out, out, P, N, K, ldx, ldo, ldo, 0, nullptr, 0};
     constexpr int KS = 2;
-    const bool big = P > 256;  // 128 tokens x (64 + 64) rows, as the unpaired launches pick their tiles
-    const int TM = big ? 2 : 1, TN = 2;
-    const void *fn = big ? (const void *)prefill_gemm_dma<G_STORE, 2, 2, KS, true>
-                         : (const void *)prefill_gemm_dma<G_STORE, 1, 2, KS, true>;
-    size_t lds = 2 * (size_t)(64 * TM + 64 * TN) * 64 * sizeof(float);
-    const size_t red = (size_t)(KS - 1) * 4 * TM * TN * 16 * 64 * sizeof(float);
+    // tokens x (features of W1 + the same features of W3) per block, chosen like the unpaired tiles
+    const TileForm tf = choose_tile(N, P, true);
+    const int tok = tf == TILE_128x64 ? 128 : tf == TILE_64x64 ? 64 : 32, feat = tf == TILE_32x32 ? 32 : 64;
+    const void *fn = tf == TILE_128x64 ? (const void *)prefill_gemm_dma<G_STORE, 2, 2, KS, true>
+                   : tf == TILE_64x64  ? (const void *)prefill_gemm_dma<G_STORE, 1, 2, KS, true>
+                   : tf == TILE_32x64  ? (const void *)prefill_gemm_dma<G_STORE, 1, 2, KS, true, 1, 2>
+                                       : (const void *)prefill_gemm_dma<G_STORE, 1, 2, KS, true, 1, 1>;
+    const int threads = tf == TILE_32x64 ? 64 * 2 * KS : tf == TILE_32x32 ? 64 * KS : 256 * KS;
+    size_t lds = 2 * (size_t)(tok + 2 * feat) * 64 * sizeof(float);
+    const size_t red = (size_t)(KS - 1) * (threads / 64 / KS) * (tf == TILE_128x64 ? 2 : 1) * 2 * 16 * 64 * sizeof(float);  // [KS-1][waves per k-group][TM * TN tiles][16][64]
     if (red > lds) lds = red;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 grid((N + 63) / 64, (P + 64 * TM - 1) / (64 * TM));
+    dim3 grid((N + feat - 1) / feat, (P + tok - 1) / tok);
     void *params[] = {&a};
-    return hipLaunchKernel(fn, grid, dim3(256 * KS), params, lds, st);
+    return hipLaunchKernel(fn, grid, dim3(threads), params, lds, st);
 }
 
 // C[P,N] (+)= X[P,K] W[N,K]^T with the chosen epilogue; K % 4 == 0, 16-byte aligned rows
 hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w, float *out, int ldo,
                                int P, int N, int K, int pos0, const float2 *rope, int head_size,
-                               hipStream_t st)
+                               hipStream_t st, const float *res, int ldres)
 {
     if (P <= 0 || N <= 0 || K <= 0 || (K % 4) != 0 || (ldx % 4) != 0) return hipErrorInvalidValue;
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return hipErrorInvalidValue;
-    GemmArgs a = {x, nullptr, w, out, P, N, K, ldx, ldo, pos0, rope, head_size};
+    if (res == nullptr) { res = out; ldres = ldo; }  // PG_RESID in place
+    GemmArgs a = {x, nullptr, w, out, res, P, N, K, ldx, ldo, ldres, pos0, rope, head_size};
     switch (epi) {
         case G_STORE: return gemm_launch<G_STORE>(a, st);
         case G_RESID: return gemm_launch<G_RESID>(a, st);
@@ -1008,14 +1087,16 @@ hipError_t launch_prefill_embed(float *x, const float *tok_emb, const int *token
 
 hipError_t launch_prefill_attention(const float *q, int ldq, const float *kcache, const float *vcache,
                                     float *out, int ldo, int pos0, int P, int n_heads, int head_size,
-                                    int kv_dim, int kv_mul, int seq_len, hipStream_t st)
+                                    int kv_dim, int kv_mul, int seq_len, hipStream_t st, int n_heads_model)
 {
+    // the two kernels round differently; a shard must take the one the unsharded pass takes
+    if (n_heads_model <= 0) n_heads_model = n_heads;
     const bool naive = tunables().pf_attn == 0;
     const size_t lds_t = (size_t)(3 * 64 * (head_size + 1) + 64 * 65 + 3 * 64) * sizeof(float);
     const int n_ct = (head_size + 31) / 32;  // O column tiles; 2 n_ct tiles over 4 waves
     // one block per (head, 64 queries): worth it once that fills half the CUs (7B: from 256 tokens);
     // below, and for models with few heads, the block-per-(head, query) kernel has more parallelism
-    const bool enough_blocks = n_heads * ((P + 63) / 64) >= 128;
+    const bool enough_blocks = n_heads_model * ((P + 63) / 64) >= 128;
     if (!naive && enough_blocks && lds_t <= 160 * 1024 && n_ct <= 8 && (head_size % 4) == 0 && (kv_dim % 4) == 0) {
         const int tpw = (2 * n_ct + 3) / 4;
         const void *fn = tpw <= 1 ? (const void *)prefill_attention_tiled<1>

@@ -15,13 +15,6 @@ using namespace l2z;
 // every layer, logits of the LAST position left in the runstate -- but every weight matrix is
 // streamed once per chunk of up to kPrefillChunk tokens and multiplied on the fp32 matrix cores.
 namespace {
-static int prefill_chunk_tokens()
-{
-    int n = tunables().pf_chunk > 0 ? tunables().pf_chunk : 512;
-    if (n < 16) n = 16;
-    if (n > 2048) n = 2048;
-    return n;
-}
 #define kPrefillChunk prefill_chunk_tokens()
 
 int prefill_alloc(l2z_runstate *s)
@@ -29,13 +22,16 @@ int prefill_alloc(l2z_runstate *s)
     if (s->pf_tokens) return L2Z_OK;  // the last one allocated: all of them exist
     const l2z_config &c = s->cfg;
     const size_t P = kPrefillChunk;
+    const size_t widest = (size_t)(c.dim > c.hidden_dim ? c.dim : c.hidden_dim);
     struct { void **p; size_t bytes; } want[] = {
         {(void **)&s->pf_x, P * c.dim * 4},   {(void **)&s->pf_xn, P * c.dim * 4},
         {(void **)&s->pf_q, P * c.dim * 4},   {(void **)&s->pf_att, P * c.dim * 4},
         {(void **)&s->pf_h1, P * c.hidden_dim * 4},
+        // sharded: [world][P, n / world] blocks of the matrix being gathered
+        {(void **)&s->pf_stage, s->sh.world > 1 ? P * widest * 4 : 0},
         {(void **)&s->pf_tokens, P * 4}};
     for (auto &b : want) {
-        if (*b.p) continue;  // kept from an earlier, partly failed attempt
+        if (*b.p || b.bytes == 0) continue;  // kept from an earlier, partly failed attempt
         hipError_t e = hipMalloc(b.p, b.bytes);
         if (e != hipSuccess) {
             *b.p = nullptr;
@@ -46,45 +42,113 @@ int prefill_alloc(l2z_runstate *s)
     return L2Z_OK;
 }
 
-int prefill_chunk(l2z_runstate *s, const l2z_weights *w, const int32_t *tokens, int P, int pos0)
+// A layer is four stages, each ending in a [P, n] matrix whose columns are split over the ranks
+// exactly like the decode pass's vectors (forward.cpp): attention output by heads, the two
+// residual updates by rows of wo / w2, the gated hidden row by rows of w1 / w3.
+enum { PF_ATT = 0, PF_WO, PF_H1, PF_W2, PF_STAGES };
+
+struct StageOut {
+    float *dst;  // the row-major [P, ldd] matrix the next stage reads
+    int n_loc, ldd;
+};
+StageOut stage_out(const l2z_runstate *s, int k)
+{
+    const l2z_config &c = s->cfg;
+    const Shard &sh = s->sh;
+    switch (k) {
+        case PF_ATT: return {s->pf_att, sh.dim_loc, c.dim};
+        case PF_H1: return {s->pf_h1, sh.hid_loc, c.hidden_dim};
+        default: return {s->pf_x, sh.dim_loc, c.dim};  // PF_WO, PF_W2
+    }
+}
+
+// The launches of stage k of layer l.  One rank: straight into the destination matrix.  Sharded: this
+// rank's [P, n_loc] block, contiguous, at pf_stage + rank * P * n_loc; the exchange and the unpack
+// into the destination follow (comm_bulk_allgather, or the emulated-rank driver's copies).
+int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, int pos0)
 {
     const l2z_config &c = s->cfg;
     const Shard &sh = s->sh;
     hipStream_t st = s->stream;
     const int dim = c.dim, hid = c.hidden_dim, kvd = sh.kvd_loc, hs = sh.hs;
-    L2Z_HIP(hipMemcpyAsync(s->pf_tokens, tokens, (size_t)P * 4, hipMemcpyHostToDevice, st));
-    L2Z_HIP(launch_prefill_embed(s->pf_x, w->tok_emb, s->pf_tokens, dim, P, st));  // :295
-    for (int l = 0; l < c.n_layers; l++) {
-        float *kc = s->key_cache + (size_t)l * c.seq_len * kvd;
-        float *vc = s->value_cache + (size_t)l * c.seq_len * kvd;
+    const bool sharded = sh.world > 1;
+    const StageOut o = stage_out(s, k);
+    float *out = sharded ? s->pf_stage + (size_t)sh.rank * P * o.n_loc : o.dst;
+    const int ldo = sharded ? o.n_loc : o.ldd;
+    float *kc = s->key_cache + (size_t)l * c.seq_len * kvd;
+    float *vc = s->value_cache + (size_t)l * c.seq_len * kvd;
+    if (k == PF_ATT) {
         L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, s->pf_x, w->rms_att + (size_t)l * dim, dim, P, st));  // :305
-        L2Z_HIP(launch_prefill_gemm(PG_ROPE, s->pf_xn, dim, w->wq + (size_t)l * dim * dim, s->pf_q, dim,
-                                    P, dim, dim, pos0, s->rope, hs, st));                   // :308-351
+        // q of the local heads: [P, dim_loc]
+        L2Z_HIP(launch_prefill_gemm(PG_ROPE, s->pf_xn, dim, w->wq + (size_t)l * sh.dim_loc * dim, s->pf_q,
+                                    sh.dim_loc, P, sh.dim_loc, dim, pos0, s->rope, hs, st));  // :308-351
         L2Z_HIP(launch_prefill_gemm(PG_ROPE_CACHE, s->pf_xn, dim, w->wk + (size_t)l * kvd * dim, kc, kvd,
                                     P, kvd, dim, pos0, s->rope, hs, st));                   // :354-357
         L2Z_HIP(launch_prefill_gemm(PG_CACHE, s->pf_xn, dim, w->wv + (size_t)l * kvd * dim, vc, kvd, P,
                                     kvd, dim, pos0, s->rope, hs, st));                      // :358
-        L2Z_HIP(launch_prefill_attention(s->pf_q, dim, kc, vc, s->pf_att, dim, pos0, P, c.n_heads, hs,
-                                         kvd, c.n_heads / c.n_kv_heads, c.seq_len, st));    // :361-389
-        L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_att, dim, w->wo + (size_t)l * dim * dim, s->pf_x, dim,
-                                    P, dim, dim, pos0, s->rope, hs, st));                   // :392-395
+        L2Z_HIP(launch_prefill_attention(s->pf_q, sh.dim_loc, kc, vc, out, ldo, pos0, P, sh.heads_loc, hs,
+                                         kvd, c.n_heads / c.n_kv_heads, c.seq_len, st, c.n_heads));  // :361-389
+    } else if (k == PF_WO) {
+        const float *res = s->pf_x + sh.dim0;
+        L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_att, dim, w->wo + (size_t)l * sh.dim_loc * dim, out, ldo,
+                                    P, sh.dim_loc, dim, pos0, s->rope, hs, st, res, dim));   // :392-395
+    } else if (k == PF_H1) {
         L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, s->pf_x, w->rms_ffn + (size_t)l * dim, dim, P, st));  // :398
         // :405-416: W1 and W3 in one launch with silu(a) * b as its epilogue where the tile kernel
         // takes the shape, else two GEMMs, the second one merging into the first one's output
-        const hipError_t pe = launch_prefill_gemm_swiglu_pair(s->pf_xn, dim, w->w1 + (size_t)l * hid * dim,
-                                                              w->w3 + (size_t)l * hid * dim, s->pf_h1, hid, P,
-                                                              hid, dim, st);
+        const float *w1 = w->w1 + (size_t)l * sh.hid_loc * dim, *w3 = w->w3 + (size_t)l * sh.hid_loc * dim;
+        const hipError_t pe = launch_prefill_gemm_swiglu_pair(s->pf_xn, dim, w1, w3, out, ldo, P, sh.hid_loc, dim, st);
         if (pe == hipErrorNotSupported) {
-            L2Z_HIP(launch_prefill_gemm(PG_STORE, s->pf_xn, dim, w->w1 + (size_t)l * hid * dim, s->pf_h1, hid,
-                                        P, hid, dim, pos0, s->rope, hs, st));                   // :405
-            L2Z_HIP(launch_prefill_gemm(PG_SWIGLU, s->pf_xn, dim, w->w3 + (size_t)l * hid * dim, s->pf_h1, hid,
-                                        P, hid, dim, pos0, s->rope, hs, st));   // :408 + :411-416 in the epilogue
+            L2Z_HIP(launch_prefill_gemm(PG_STORE, s->pf_xn, dim, w1, out, ldo, P, sh.hid_loc, dim, pos0, s->rope,
+                                        hs, st));                                            // :405
+            L2Z_HIP(launch_prefill_gemm(PG_SWIGLU, s->pf_xn, dim, w3, out, ldo, P, sh.hid_loc, dim, pos0, s->rope,
+                                        hs, st));                   // :408 + :411-416 in the epilogue
         } else {
             L2Z_HIP(pe);
         }
-        L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_h1, hid, w->w2 + (size_t)l * dim * hid, s->pf_x, dim,
-                                    P, dim, hid, pos0, s->rope, hs, st));                   // :419-422
+    } else {
+        const float *res = s->pf_x + sh.dim0;
+        L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_h1, hid, w->w2 + (size_t)l * sh.dim_loc * hid, out, ldo,
+                                    P, sh.dim_loc, hid, pos0, s->rope, hs, st, res, dim));   // :419-422
     }
+    return L2Z_OK;
+}
+
+int prefill_begin_chunk(l2z_runstate *s, const l2z_weights *w, const int32_t *tokens, int P)
+{
+    L2Z_HIP(hipMemcpyAsync(s->pf_tokens, tokens, (size_t)P * 4, hipMemcpyHostToDevice, s->stream));
+    L2Z_HIP(launch_prefill_embed(s->pf_x, w->tok_emb, s->pf_tokens, s->cfg.dim, P, s->stream));  // :295
+    return L2Z_OK;
+}
+
+int prefill_chunk(l2z_runstate *s, const l2z_weights *w, const int32_t *tokens, int P, int pos0)
+{
+    L2Z_TRY(prefill_begin_chunk(s, w, tokens, P));
+    for (int l = 0; l < s->cfg.n_layers; l++)
+        for (int k = 0; k < PF_STAGES; k++) {
+            L2Z_TRY(prefill_stage(s, w, l, k, P, pos0));
+            if (s->sh.world > 1) {
+                const StageOut o = stage_out(s, k);
+                L2Z_TRY(comm_bulk_allgather(s->comm, s->pf_stage, P, o.n_loc, o.dst, o.ldd, s->stream));
+            }
+        }
+    return L2Z_OK;
+}
+
+// the last position's residual row is RunState.x: the usual final rmsnorm + classifier launch
+// (:426-429) over this rank's vocabulary rows; sharded, the caller gathers the logits
+int prefill_classifier(l2z_runstate *s, const l2z_weights *w)
+{
+    const l2z_config &c = s->cfg;
+    const Shard &sh = s->sh;
+    MatvecArgs a = {};
+    a.w0 = w->wcls; a.out0 = s->logits + sh.v0; a.rows0 = sh.v_loc; a.n = c.dim; a.x = s->x;
+    a.rms_w = w->rms_final;
+    a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.row_offset = sh.v0;
+    int grid = 0;
+    const bool fuse = sh.world == 1 && matvec_vector_width(c.dim);  // as in enqueue_forward
+    L2Z_HIP(launch_matvec(a, PRO_RMS, fuse ? EPI_ARGMAX : EPI_STORE, s->max_blocks, g_cus, s->stream, &grid));
+    s->n_part = fuse ? grid : 0;
     return L2Z_OK;
 }
 }  // namespace
@@ -96,12 +160,27 @@ bool prefill_enabled()
     return tunables().prefill != 0;
 }
 
+// whether this runstate can take the batched path at all (shape; sharded: a transport that carries
+// [chunk, hidden_dim] matrices).  Same answer on every rank of a group.
+bool prefill_usable(const l2z_runstate *s)
+{
+    const l2z_config &c = s->cfg;
+    if (c.dim % 4 != 0 || c.hidden_dim % 4 != 0 || s->sh.hs % 4 != 0 || s->sh.hs > 256) return false;
+    if (s->sh.world == 1) return true;
+    if (s->sh.dim_loc % 4 != 0 || s->sh.hid_loc % 4 != 0) return false;
+    const size_t widest = (size_t)(c.dim > c.hidden_dim ? c.dim : c.hidden_dim);
+    return comm_bulk_ok(s->comm, (size_t)kPrefillChunk * widest);
+}
+
 int prefill_check(const l2z_config *config, const l2z_runstate *s)
 {
-    L2Z_CHECK(s->sh.world == 1, L2Z_ERR_INVALID, "l2z_prefill: not available on a sharded runstate");
     L2Z_CHECK(config->dim % 4 == 0 && config->hidden_dim % 4 == 0 && s->sh.hs % 4 == 0 &&
                   s->sh.hs <= 256, L2Z_ERR_INVALID,
               "l2z_prefill: needs dim, hidden_dim, head_size multiples of 4 and head_size <= 256");
+    L2Z_CHECK(prefill_usable(s), L2Z_ERR_INVALID,
+              "l2z_prefill: this sharded runstate has no transport for [%d, hidden_dim] matrices (RCCL "
+              "communicator, or peer-write arena with bulk regions: L2Z_P2P_BULK_MB), or its row shards are "
+              "not multiples of 4", kPrefillChunk);
     return L2Z_OK;
 }
 
@@ -119,6 +198,7 @@ int prefill_tokens(l2z_runstate *s, const l2z_weights *w, const int32_t *tokens,
             L2Z_HIP(hipMemcpyAsync(s->x, s->pf_x + (size_t)(P - 1) * config->dim, (size_t)config->dim * 4,
                                    hipMemcpyDeviceToDevice, s->stream));
         L2Z_HIP(hipStreamSynchronize(s->stream));  // the host token buffer may now be reused
+        L2Z_TRY(comm_check(s->comm));
         done += P;
     }
     return L2Z_OK;
@@ -144,20 +224,90 @@ extern "C" int l2z_prefill(const int32_t *tokens, int n_tokens, int pos0, const 
     const int last_pos = pos0 + n_tokens - 1;
     L2Z_HIP(hipMemcpyAsync(s->d_pos, &last_pos, sizeof(int), hipMemcpyHostToDevice, s->stream));
     L2Z_HIP(hipMemcpyAsync(s->d_token, &tokens[n_tokens - 1], sizeof(int), hipMemcpyHostToDevice, s->stream));
-    {
-        const l2z_config &c = s->cfg;
-        MatvecArgs a = {};
-        a.w0 = w->wcls; a.out0 = s->logits; a.rows0 = c.vocab_size; a.n = c.dim; a.x = s->x;
-        a.rms_w = w->rms_final;
-        a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.row_offset = 0;
-        int grid = 0;
-        const bool fuse = matvec_vector_width(c.dim);  // as in enqueue_forward
-        L2Z_HIP(launch_matvec(a, PRO_RMS, fuse ? EPI_ARGMAX : EPI_STORE, s->max_blocks, g_cus, s->stream,
-                              &grid));
-        s->n_part = fuse ? grid : 0;
-    }
+    L2Z_TRY(prefill_classifier(s, w));
+    // sharded: the logits gather, as a pass of its own (it closes the pass: forward.cpp gather())
+    if (s->sh.world > 1)
+        L2Z_TRY(comm_allgather_inplace(s->comm, s->logits, (size_t)s->sh.v_loc, s->n_gathers, s->n_gathers,
+                                       false, s->stream));
     L2Z_HIP(hipStreamSynchronize(s->stream));
+    L2Z_TRY(comm_check(s->comm));
     s->host_pos = pos0 + n_tokens;
     return L2Z_OK;
 }
 
+
+// Testing support (include/llama2_hip_test.h): l2z_prefill for N emulated ranks in one process on one
+// GPU -- every rank's own launches of each stage, the exchange of the [P, n_loc] blocks as
+// device-to-device copies between the ranks' staging buffers, then every rank's own unpack launch.
+extern "C" int l2z_emu_prefill(int n_ranks, l2z_runstate *const *ss, const l2z_weights *const *ws,
+                               const int32_t *tokens, int n_tokens, int pos0)
+{
+    L2Z_CHECK(n_ranks >= 2 && ss && ws && tokens && n_tokens >= 1, L2Z_ERR_INVALID, "l2z_emu_prefill: bad arguments");
+    const l2z_config &c = ss[0]->cfg;
+    L2Z_CHECK(pos0 >= 0 && pos0 + n_tokens <= c.seq_len, L2Z_ERR_STATE, "l2z_emu_prefill: positions out of range");
+    for (int i = 0; i < n_tokens; i++)
+        L2Z_CHECK(tokens[i] >= 0 && tokens[i] < c.vocab_size, L2Z_ERR_STATE, "l2z_emu_prefill: token out of vocabulary");
+    for (int r = 0; r < n_ranks; r++) {
+        L2Z_TRY(check_pair(&c, ss[r], ws[r]));
+        L2Z_CHECK(ss[r]->sh.world == n_ranks && ss[r]->sh.rank == r, L2Z_ERR_INVALID,
+                  "l2z_emu_prefill: runstate %d is not rank %d of %d", r, r, n_ranks);
+        L2Z_CHECK(c.dim % 4 == 0 && c.hidden_dim % 4 == 0 && ss[r]->sh.hs % 4 == 0 && ss[r]->sh.hs <= 256 &&
+                      ss[r]->sh.dim_loc % 4 == 0 && ss[r]->sh.hid_loc % 4 == 0,
+                  L2Z_ERR_INVALID, "l2z_emu_prefill: shape not supported by the batched path");
+        L2Z_TRY(prefill_alloc(ss[r]));
+    }
+    auto sync_all = [&]() -> int {
+        for (int r = 0; r < n_ranks; r++) L2Z_HIP(hipStreamSynchronize(ss[r]->stream));
+        return L2Z_OK;
+    };
+    // rank src's block of `count` floats at `off(rank)` -> every other rank
+    auto exchange = [&](size_t count, float *(*buf)(l2z_runstate *)) -> int {
+        for (int src = 0; src < n_ranks; src++)
+            for (int dst = 0; dst < n_ranks; dst++)
+                if (dst != src)
+                    L2Z_HIP(hipMemcpy(buf(ss[dst]) + (size_t)src * count, buf(ss[src]) + (size_t)src * count,
+                                      count * sizeof(float), hipMemcpyDeviceToDevice));
+        L2Z_HIP(hipDeviceSynchronize());  // the ranks' streams are non-blocking (forward.cpp l2z_emu_transformer)
+        return L2Z_OK;
+    };
+    int done = 0;
+    while (done < n_tokens) {
+        const int P = n_tokens - done < kPrefillChunk ? n_tokens - done : kPrefillChunk;
+        for (int r = 0; r < n_ranks; r++) L2Z_TRY(prefill_begin_chunk(ss[r], ws[r], tokens + done, P));
+        for (int l = 0; l < c.n_layers; l++)
+            for (int k = 0; k < PF_STAGES; k++) {
+                // one rank at a time: on hardware every rank has a GPU to itself, so kernel times taken from
+                // this driver (scripts/sharded_prefill_emu.py under rocprofv3) should not overlap either
+                for (int r = 0; r < n_ranks; r++) {
+                    L2Z_TRY(prefill_stage(ss[r], ws[r], l, k, P, pos0 + done));
+                    L2Z_HIP(hipStreamSynchronize(ss[r]->stream));
+                }
+                const StageOut o0 = stage_out(ss[0], k);
+                L2Z_TRY(exchange((size_t)P * o0.n_loc, [](l2z_runstate *s) { return s->pf_stage; }));
+                for (int r = 0; r < n_ranks; r++) {
+                    const StageOut o = stage_out(ss[r], k);
+                    BulkArgs a = {};
+                    a.stage = ss[r]->pf_stage; a.P = P; a.n_loc = o.n_loc; a.rank = r; a.world = n_ranks;
+                    L2Z_HIP(launch_bulk_unpack(a, 0, 0, o.dst, o.ldd, ss[r]->stream));
+                    L2Z_HIP(hipStreamSynchronize(ss[r]->stream));
+                }
+            }
+        if (done + P == n_tokens)
+            for (int r = 0; r < n_ranks; r++)
+                L2Z_HIP(hipMemcpyAsync(ss[r]->x, ss[r]->pf_x + (size_t)(P - 1) * c.dim, (size_t)c.dim * 4,
+                                       hipMemcpyDeviceToDevice, ss[r]->stream));
+        L2Z_TRY(sync_all());
+        done += P;
+    }
+    const int last_pos = pos0 + n_tokens - 1;
+    for (int r = 0; r < n_ranks; r++) {
+        L2Z_HIP(hipMemcpyAsync(ss[r]->d_pos, &last_pos, sizeof(int), hipMemcpyHostToDevice, ss[r]->stream));
+        L2Z_HIP(hipMemcpyAsync(ss[r]->d_token, &tokens[n_tokens - 1], sizeof(int), hipMemcpyHostToDevice,
+                               ss[r]->stream));
+        L2Z_TRY(prefill_classifier(ss[r], ws[r]));
+    }
+    L2Z_TRY(sync_all());
+    L2Z_TRY(exchange((size_t)ss[0]->sh.v_loc, [](l2z_runstate *s) { return s->logits; }));
+    for (int r = 0; r < n_ranks; r++) ss[r]->host_pos = pos0 + n_tokens;
+    return L2Z_OK;
+}

@@ -31,6 +31,7 @@ Tunables read_env()
     env_int("L2Z_P2P_CONSUME", &t.p2p_consume);
     if (const char *e = getenv("L2Z_P2P_TIMEOUT_S"))
         if (*e) t.p2p_timeout_s = atoll(e);
+    env_int("L2Z_P2P_BULK_MB", &t.p2p_bulk_mb);
     env_int("L2Z_PREFILL", &t.prefill);
     env_int("L2Z_PF_CHUNK", &t.pf_chunk);
     env_int("L2Z_PF_SKINNY_FORM", &t.pf_skinny_form);
@@ -57,6 +58,14 @@ Tunables &mutable_tunables()
 
 const Tunables &tunables() { return mutable_tunables(); }
 
+int prefill_chunk_tokens()
+{
+    int n = tunables().pf_chunk > 0 ? tunables().pf_chunk : 512;
+    if (n < 16) n = 16;
+    if (n > 2048) n = 2048;
+    return n;
+}
+
 bool tunables_set(const char *name, long long v)
 {
     Tunables &t = mutable_tunables();
@@ -68,6 +77,7 @@ bool tunables_set(const char *name, long long v)
         {"L2Z_FUSE_SMALL", &t.fuse_small}, {"L2Z_NO_GRAPH", &t.no_graph},
         {"L2Z_COMM_GRAPH", &t.comm_graph}, {"L2Z_COMM_RCCL", &t.prefer_rccl},
         {"L2Z_P2P_PUSH", &t.p2p_push}, {"L2Z_P2P_CONSUME", &t.p2p_consume},
+        {"L2Z_P2P_BULK_MB", &t.p2p_bulk_mb},
         {"L2Z_PREFILL", &t.prefill}, {"L2Z_PF_CHUNK", &t.pf_chunk},
         {"L2Z_PF_SKINNY_FORM", &t.pf_skinny_form}, {"L2Z_PF_TILE", &t.pf_tile},
         {"L2Z_PF_SKINNY_MAX", &t.pf_skinny_max}, {"L2Z_PF_SKINNY_TMS", &t.pf_skinny_tms},

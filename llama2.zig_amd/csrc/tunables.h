@@ -28,6 +28,8 @@ struct Tunables {
     int p2p_consume = 1;       // L2Z_P2P_CONSUME     0: keep a gather launch per gathered vector (consumers
                                //                     read plain buffers)
     long long p2p_timeout_s = 20;  // L2Z_P2P_TIMEOUT_S
+    int p2p_bulk_mb = -1;      // L2Z_P2P_BULK_MB     MB per bulk landing region of the peer-write arena (two of
+                               //                     them; sharded prefill); default: longest vector x chunk tokens
     // --- batched prefill (prefill_host.cpp, prefill.hip) ---
     int prefill = 1;           // L2Z_PREFILL         0: prompts are stepped token by token
     int pf_chunk = 0;          // L2Z_PF_CHUNK        tokens per chunk (0: default)
@@ -41,6 +43,7 @@ struct Tunables {
 };
 
 const Tunables &tunables();
+int prefill_chunk_tokens();  // L2Z_PF_CHUNK clamped to [16, 2048], default 512
 // Override one knob by its environment name after start-up (measurement harnesses that try several
 // settings in one process: include/llama2_hip_test.h l2z_option_set).  False: unknown name.
 bool tunables_set(const char *env_name, long long value);

@@ -10,6 +10,7 @@ w = B.Weights(cfg, None, shared, seed=1); s = B.RunState(cfg)
 toks = [1] + np.random.default_rng(1).integers(2, cfg.vocab_size, n - 1).tolist()
 DEF = {"L2Z_PF_DMA": 1, "L2Z_PF_TILE": 0, "L2Z_PF_FUSE": 1, "L2Z_PF_ATTN": 1, "L2Z_PF_CHUNK": 0}
 res = [[] for _ in variants]
+logits = [None for _ in variants]
 flops = 2.0 * n * (cfg.n_layers * (2 * cfg.dim * cfg.dim + 2 * cfg.dim * cfg.kv_dim + 3 * cfg.dim * cfg.hidden_dim))
 for r in range(rounds + 1):
     for i, v in enumerate(variants):
@@ -18,6 +19,8 @@ for r in range(rounds + 1):
         t0 = time.perf_counter(); s.prefill(toks, 0, w); dt = time.perf_counter() - t0
         for k in kv: B.option_set(k, DEF[k])
         if r > 0: res[i].append(dt)
-for v, xs in zip(variants, res):
+        logits[i] = s.logits()
+for i, (v, xs) in enumerate(zip(variants, res)):
     m = float(np.median(xs))
-    print(f"{shape} prefill {n} [{v or 'defaults'}]: median {m*1e3:8.2f} ms  min {min(xs)*1e3:8.2f}  = {flops/m/1e12:6.1f} TFLOP/s ({flops/m/1e12/157.3:.3f} of the f32 MFMA peak)")
+    same = "" if i == 0 else ("  logits == first variant's: %s" % np.array_equal(logits[i], logits[0]))
+    print(f"{shape} prefill {n} [{v or 'defaults'}]: median {m*1e3:8.2f} ms  min {min(xs)*1e3:8.2f}  = {flops/m/1e12:6.1f} TFLOP/s ({flops/m/1e12/157.3:.3f} of the f32 MFMA peak){same}")

@@ -79,7 +79,28 @@ def main() -> None:
     # the stepped API on top of the same state
     s.transformer(int(toks[-1]), len(toks) % cfg.seq_len, w)
     logits2, am = s.logits(), s.argmax()
-    np.savez(os.path.join(d, f"out_{rank}.npz"), toks=toks, logits=logits, logits2=logits2, am=am)
+    extra = {}
+    if spec.get("prefill"):
+        # l2z_prefill itself on the sharded runstate: [tokens, n / world] blocks through the bulk regions,
+        # then the classifier over this rank's vocabulary rows and the logits gather
+        s2 = B.RunState(cfg, comm=comm)
+        n1 = spec["prefill_split"]
+        if expect == "no_bulk":
+            # L2Z_P2P_BULK_MB=0: the arena has no bulk regions, so l2z_prefill must refuse (and the greedy
+            # loop above has stepped through its prompt instead)
+            try:
+                s2.prefill(spec["prefill"][:n1], 0, w)
+            except B.L2ZError as e:
+                assert e.code == B.ERR_INVALID, e
+                np.savez(os.path.join(d, f"out_{rank}.npz"), toks=toks, logits=logits)
+                s2.close(); s.close(); w.close(); comm.close()
+                return
+            raise SystemExit("l2z_prefill ran on a sharded runstate without bulk regions")
+        s2.prefill(spec["prefill"][:n1], 0, w)
+        s2.prefill(spec["prefill"][n1:], n1, w)
+        extra = dict(pf_logits=s2.logits(), pf_key0=s2.read("key_cache", 0, len(spec["prefill"]) * (cfg.kv_dim // world)))
+        s2.close()
+    np.savez(os.path.join(d, f"out_{rank}.npz"), toks=toks, logits=logits, logits2=logits2, am=am, **extra)
     s.close(); w.close(); comm.close()
 
 

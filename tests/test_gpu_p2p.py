@@ -99,3 +99,63 @@ def test_dead_peer_fails_fast(gpu, tmp_path, mode):
     run_ranks(tmp_path, 2, spec, dict(MODE_ENV[mode], L2Z_P2P_TIMEOUT_S="2"), timeout=120)
     took = float((tmp_path / "ok_0").read_text().split()[0])
     assert took < 20.0, f"rank 0 needed {took:.1f} s to report the dead peer"
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_multiprocess_sharded_prefill_through_bulk_regions(gpu, ck, tmp_path, world, options):
+    """Row-sharded batched prefill with REAL processes: every rank computes its column block of each
+    [tokens, n] activation matrix, pushes it into the peers' bulk regions (plain 16-byte peer stores +
+    one flag per sender, csrc/p2p.hip) and unpacks what the peers pushed.  Both callers: the greedy
+    loop with a 150-token prompt (prefill, then sharded decode steps on the LL transport), and
+    l2z_prefill itself in two calls (pos0 > 0; the second call's 141 tokens take the tile GEMMs, the
+    first one's 9 the skinny ones).  Tokens, logits and this rank's KV shard equal the unsharded run's
+    bit for bit."""
+    options(L2Z_FUSE_SMALL=0)
+    kw = dict(dim=512, hidden_dim=1408, n_layers=2, n_heads=16, n_kv_heads=8, vocab_size=1024, seq_len=384)
+    cfg = ck.Config(**kw)
+    rng = np.random.default_rng(8)
+    prompt = rng.integers(2, cfg.vocab_size, 150).tolist()
+    pf = [1] + rng.integers(2, cfg.vocab_size, 149).tolist()
+    steps = 230
+    spec = dict(cfg=kw, shared=False, seed=41, prompt=prompt, steps=steps, blob=False, prefill=pf, prefill_split=9)
+    run_ranks(tmp_path, world, spec)
+    w, s = gpu.Weights(cfg, None, False, seed=41), gpu.RunState(cfg)
+    s.greedy_begin(prompt)
+    toks = s.greedy_run(w, steps)
+    logits = s.logits()
+    s2 = gpu.RunState(cfg)
+    s2.prefill(pf[:9], 0, w)
+    s2.prefill(pf[9:], 9, w)
+    pf_logits = s2.logits()
+    kvd = cfg.kv_dim
+    key0 = s2.read("key_cache", 0, len(pf) * kvd).reshape(len(pf), kvd)
+    assert len(toks) == steps and toks[:150].tolist() == prompt
+    for r in range(world):
+        o = np.load(tmp_path / f"out_{r}.npz")
+        assert np.array_equal(o["toks"], toks), f"rank {r} tokens"
+        assert np.array_equal(o["logits"], logits), f"rank {r} logits after the greedy loop"
+        assert np.array_equal(o["pf_logits"], pf_logits), f"rank {r} logits after l2z_prefill"
+        kvl = kvd // world
+        assert np.array_equal(o["pf_key0"].reshape(len(pf), kvl), key0[:, r * kvl:(r + 1) * kvl]), f"rank {r} key cache"
+    for o_ in (s, s2, w):
+        o_.close()
+
+
+def test_multiprocess_sharded_prefill_needs_bulk_regions(gpu, ck, tmp_path, options):
+    """L2Z_P2P_BULK_MB=0: no bulk regions in the arenas.  l2z_prefill on the sharded runstate is refused
+    (L2Z_ERR_INVALID, nothing launched) and the greedy loop steps through its prompt instead -- with
+    tokens and logits equal to the unsharded STEPPED loop's, bit for bit."""
+    options(L2Z_FUSE_SMALL=0, L2Z_PREFILL=0)
+    kw = dict(dim=512, hidden_dim=1408, n_layers=2, n_heads=16, n_kv_heads=8, vocab_size=1024, seq_len=128)
+    cfg = ck.Config(**kw)
+    prompt = np.random.default_rng(8).integers(2, cfg.vocab_size, 40).tolist()
+    spec = dict(cfg=kw, shared=False, seed=41, prompt=prompt, steps=60, blob=False, prefill=[1] + prompt, prefill_split=9,
+                expect="no_bulk")
+    run_ranks(tmp_path, 2, spec, {"L2Z_P2P_BULK_MB": "0"})
+    w, s = gpu.Weights(cfg, None, False, seed=41), gpu.RunState(cfg)
+    s.greedy_begin(prompt)
+    toks = s.greedy_run(w, 60)
+    for r in range(2):
+        o = np.load(tmp_path / f"out_{r}.npz")
+        assert np.array_equal(o["toks"], toks) and np.array_equal(o["logits"], s.logits()), f"rank {r}"
+    s.close(); w.close()

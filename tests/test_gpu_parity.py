@@ -493,6 +493,57 @@ def test_sharded_hip_path_emulated_ranks(gpu, ck, world, from_blob, options):
         c.close()
 
 
+SHARDED_PREFILL = [
+    # GQA, 530 tokens: two chunks, 128- and 64-token tiles, tiled attention, a partial last chunk
+    ("gqa", dict(dim=512, hidden_dim=1408, n_layers=2, n_heads=16, n_kv_heads=8, vocab_size=1024, seq_len=544), 530),
+    # few heads: the per-query attention kernel; 40 tokens: the skinny (P <= 64) GEMM forms
+    ("mha-short", dict(dim=256, hidden_dim=704, n_layers=3, n_heads=8, n_kv_heads=8, vocab_size=512, seq_len=64), 40),
+]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("name,kw,n_tok", SHARDED_PREFILL, ids=[c[0] for c in SHARDED_PREFILL])
+def test_sharded_prefill_emulated_ranks_bit_identical(gpu, ck, world, name, kw, n_tok, options):
+    """Row-sharded batched prefill (prefill_host.cpp stages: heads / rows of wo, w1|w3, w2 per rank,
+    [tokens, n / world] blocks exchanged and unpacked) on N emulated ranks: every rank's logits, and
+    its shard of every layer's KV cache, are BIT-IDENTICAL to the unsharded l2z_prefill -- a tile's k
+    order does not depend on which rank owns its rows, and shards take the attention form the whole
+    model takes.  Also with pos0 > 0 (a second call continuing the context)."""
+    options(L2Z_FUSE_SMALL=0)  # the decode step at the end: the unsharded pass runs the launches the shards run
+    cfg = ck.Config(**kw)
+    w0, s0 = gpu.Weights(cfg, None, False, seed=23), gpu.RunState(cfg)
+    comms = [gpu.Comm(r, world, None, 0, emulated=True) for r in range(world)]
+    ws = [gpu.Weights(cfg, None, False, seed=23, comm=c) for c in comms]
+    ss = [gpu.RunState(cfg, comm=c) for c in comms]
+    rng = np.random.default_rng(4)
+    toks = [1] + rng.integers(2, cfg.vocab_size, n_tok - 1).tolist()
+    split = 9
+    for lo, hi in ((0, split), (split, n_tok)):
+        s0.prefill(toks[lo:hi], lo, w0)
+        gpu.emu_prefill(ss, ws, toks[lo:hi], lo)
+        ref = s0.logits()
+        for r in range(world):
+            assert np.array_equal(ss[r].logits(), ref), f"rank {r} logits after tokens {lo}..{hi}"
+    kvd, S = cfg.kv_dim, cfg.seq_len
+    kvl = kvd // world
+    for l in range(cfg.n_layers):
+        for nm in ("key_cache", "value_cache"):
+            full = s0.read(nm, l * S * kvd, n_tok * kvd).reshape(n_tok, kvd)
+            for r in range(world):
+                mine = ss[r].read(nm, l * S * kvl, n_tok * kvl).reshape(n_tok, kvl)
+                assert np.array_equal(mine, full[:, r * kvl:(r + 1) * kvl]), f"{nm} layer {l} rank {r}"
+    # decoding continues identically from the sharded state
+    nxt = s0.argmax()
+    s0.transformer(nxt, n_tok, w0)
+    gpu.emu_transformer(ss, ws, nxt, n_tok)
+    for r in range(world):
+        assert np.array_equal(ss[r].logits(), s0.logits())
+    for o in ss + ws + [s0, w0]:
+        o.close()
+    for c in comms:
+        c.close()
+
+
 @pytest.mark.parametrize("nch", [2, 3, 16])
 def test_split_attention_matches_oracle(gpu, ck, orc, nch, options):
     """The flash-decoding attention (nch blocks per head, the last arriver combines) is forced on
