@@ -387,6 +387,29 @@ def main() -> None:
                                             "in the numerator; v_mfma_f32_32x32x2_f32"}}
         except Exception as e:  # noqa: BLE001
             prefill = {"error": str(e)}
+    # sharded runstates: the row-sharded prefill (every rank its column blocks, [tokens, n / world] blocks
+    # exchanged through the bulk regions / RCCL) -- a diagnostic beside the decode figure, like the above
+    prefill_sharded = None
+    if world > 1 and not args.no_extra:
+        err = None
+        dtp = 0.0
+        n_p = min(512, cfg.seq_len - 1)
+        try:
+            toks = [1] + np.random.default_rng(args.seed).integers(2, cfg.vocab_size, n_p - 1).tolist()
+            s.prefill(toks, 0, w)
+            t0 = time.perf_counter()
+            for _ in range(2):
+                s.prefill(toks, 0, w)
+            dtp = (time.perf_counter() - t0) / 2
+        except Exception as e:  # noqa: BLE001  (no bulk regions, a wait timed out, ...)
+            err = e
+        if all_ok(err is None):
+            t = torch.tensor([dtp], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            prefill_sharded = {"prompt_tokens": n_p, "ms": float(t.item()) * 1e3, "tokens_per_s": n_p / float(t.item()),
+                               "ranks_agree": ranks_agree(s)}
+        else:
+            prefill_sharded = {"error": str(err) if err else "failed on another rank"}
     s.close()
     w.close()
 
@@ -416,7 +439,7 @@ def main() -> None:
         ideal_ms = (sum(wb[k] * (1 if k == "cls" else cfg.n_layers) for k in wb) / (rd_avg * 1e9) * 1e3
                     if rd_avg else None)
         out["comm"] = {
-            "transport": transport, "attempts": attempts, "gathers_per_token": n_g,
+            "transport": transport, "attempts": attempts, "prefill_sharded": prefill_sharded, "gathers_per_token": n_g,
             "gather_launches_per_token": launches,
             "us_per_gather_launch": (by_kind["gather"][0] / max(by_kind["gather"][1], 1) * 1e3) if launches else None,
             "graph_nodes_per_layer": 5 + (4 if launches > 1 else 0),
