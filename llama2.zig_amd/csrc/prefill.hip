@@ -289,6 +289,11 @@ __device__ __forceinline__ void lds_dma16(const float *g, float *lds)
 {
     __builtin_amdgcn_global_load_lds(g, lds, 16, 0, 0);
 }
+// the same with the non-temporal policy (aux = 2): a stream that one CU reads once
+__device__ __forceinline__ void lds_dma16_nt(const float *g, float *lds)
+{
+    __builtin_amdgcn_global_load_lds(g, lds, 16, 0, 2);
+}
 
 // The same tile product with the operands brought in by DIRECT-TO-LDS loads
 // (global_load_lds_dwordx4, gfx950): no VGPR round trip and no LDS-write instructions -- in the
@@ -655,6 +660,118 @@ __global__ __launch_bounds__(kPfBlock) void prefill_skinny_lds(const GemmArgs a)
     }
 }
 
+// Short prompts, third form (round 2): prefill_skinny_lds with the operands brought in by
+// direct-to-LDS loads and a ring of SW stages.  The register-staged form keeps one 16-KB stage of W in
+// flight per block, and N = 4096 gives one block per CU: 4 MB on the wire chip-wide where the memory
+// system needs ~13 MB (8 TB/s x latency) -- W streamed at 3.1 TB/s.  Here every wave-wide load still
+// reads 1 KB of ONE row, but it lands in LDS without passing through VGPRs, so SW - 1 stages (48 KB of
+// W per CU at SW = 4) are in flight.  X rides in the same ring: vmcnt retires loads in issue order, so
+// a shallower X ring would drain the W ring with it.  A wave-wide load is exactly one row, so the row
+// pitch is free: 264 floats make the operand reads conflict-free as ds_read_b128 -- lane (j, q) takes
+// the float4 at k = 64 wave + 16 u + 4 q of row j and feeds component c to MFMA (u, c), A and B alike.
+// The W loads carry the non-temporal policy (a stream one CU reads once; X, which every block re-reads
+// from L2, does not).  7B shape, q / k / v / wo (67 MB): 21.6 -> 15.0 us = 4.5 TB/s; 16-token prompt
+// 7.67 -> 6.24 ms, 8 tokens 7.17 -> 5.99, 32 tokens 10.0 -> 8.9 (nt alone: 6.75 -> 6.24 at 16).
+// Measured on top of this and not kept: X loaded straight into a register ring (inline-asm loads the
+// compiler does not wait for) so that two 67-KB blocks fit a CU: +3 %; 8 waves per block: +3 %; each
+// block starting at another stage of K (in case the 4096 row streams camp on a few channels): +9 %.
+// Neither depth, nor waves per CU, nor the LDS read width moves it further; W1 / W3 (688 blocks, one
+// resident per CU: 2.7 rounds) stay at 4.1 TB/s.
+// Needs K % 256 == 0 (whole stages: the 7B and 110M shapes); otherwise the launcher keeps the
+// register-staged form (same sums, another order).
+constexpr int kSkLD2 = kSkBK + 8;
+
+template <int EPI, int TMS, int SW>
+__global__ __launch_bounds__(kPfBlock) void prefill_skinny_dma(const GemmArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int WST = 16 * kSkLD2, XST = 16 * TMS * kSkLD2, ST = WST + XST;  // floats per stage: W rows, then X rows
+    constexpr int LPS = 4 + 4 * TMS;  // this wave's loads per stage
+    static_assert(SW >= 3 && SW <= 4, "ring depth");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * TMS;
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+    // this wave's rows of every stage: W rows 4 wave .. 4 wave + 3, X rows likewise per token tile
+    const float *wsrc[4], *xsrc[TMS][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int r = 4 * wave + i;
+        wsrc[i] = a.w + (size_t)min(n0 + r, a.N - 1) * a.K + 4 * lane;
+#pragma unroll
+        for (int tm = 0; tm < TMS; tm++) xsrc[tm][i] = a.x + (size_t)min(m0 + 16 * tm + r, a.P - 1) * a.ldx + 4 * lane;
+    }
+    auto issue = [&](int st, int buf) {
+        float *ws = smem + buf * ST, *xs = ws + WST;
+#pragma unroll
+        for (int i = 0; i < 4; i++) lds_dma16_nt(wsrc[i] + (size_t)st * kSkBK, ws + (4 * wave + i) * kSkLD2);
+#pragma unroll
+        for (int tm = 0; tm < TMS; tm++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) lds_dma16(xsrc[tm][i] + (size_t)st * kSkBK, xs + (16 * tm + 4 * wave + i) * kSkLD2);
+    };
+    v4f acc[TMS];
+#pragma unroll
+    for (int tm = 0; tm < TMS; tm++) acc[tm] = zero;
+    const int nst = a.K / kSkBK;  // launcher: nst >= SW - 1
+#pragma unroll
+    for (int p = 0; p < SW - 1; p++) issue(p, p);
+    int buf = 0, nbuf = SW - 1;
+    for (int st = 0; st < nst; st++) {
+        // stage st has landed (this wave's part): what may still fly are the younger stages already issued
+        const int younger = min(SW - 2, nst - 1 - st);
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave's part of stage st is in LDS; stage st - 1 has been multiplied
+        if (st + SW - 1 < nst) issue(st + SW - 1, nbuf);  // into the buffer stage st - 1 has just left
+        const float *wr = smem + buf * ST + j * kSkLD2 + 64 * wave + 4 * q;
+        const float *xr = wr + WST;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {  // this wave's quarter of the stage
+            const v4f b = *(const v4f *)(wr + 16 * u);
+            v4f xa[TMS];
+#pragma unroll
+            for (int tm = 0; tm < TMS; tm++) xa[tm] = *(const v4f *)(xr + 16 * tm * kSkLD2 + 16 * u);
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int tm = 0; tm < TMS; tm++)
+                    acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[tm][c], b[c], acc[tm], 0, 0, 0);
+        }
+        buf = buf + 1 == SW ? 0 : buf + 1;
+        nbuf = nbuf + 1 == SW ? 0 : nbuf + 1;
+    }
+    __syncthreads();
+    float *red = smem;  // [4 waves][TMS][4][64]
+#pragma unroll
+    for (int tm = 0; tm < TMS; tm++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[((wave * TMS + tm) * 4 + r) * 64 + lane] = acc[tm][r];
+    __syncthreads();
+    for (int idx = tid; idx < TMS * 256; idx += kPfBlock) {
+        const int tm = idx >> 8, r = (idx >> 6) & 3, l = idx & 63;
+        float v = red[((0 * TMS + tm) * 4 + r) * 64 + l];
+#pragma unroll
+        for (int w = 1; w < 4; w++) v += red[((w * TMS + tm) * 4 + r) * 64 + l];
+        const int tok = m0 + 16 * tm + 4 * (l >> 4) + r;
+        const int f = n0 + (l & 15);
+        if (EPI == G_ROPE || EPI == G_ROPE_CACHE) {
+            const float partner = __shfl_xor(v, 1, 64);  // feature f ^ 1, same token (main.zig:346-349)
+            const int hs = a.head_size;
+            const int pos = a.pos0 + (tok < a.P ? tok : 0);
+            const float2 cs = a.rope[(size_t)pos * (size_t)(hs >> 1) + (size_t)(((f < a.N ? f : 0) % hs) >> 1)];
+            v = (f & 1) ? partner * cs.y + v * cs.x : v * cs.x - partner * cs.y;
+        }
+        if (tok < a.P && f < a.N) {
+            if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + f] = v;
+            else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + f] = a.res[(size_t)tok * a.ldres + f] + v;
+            else if (EPI == G_SWIGLU) a.out[(size_t)tok * a.ldo + f] = swiglu_merge(a.out[(size_t)tok * a.ldo + f], v);
+            else a.out[(size_t)(a.pos0 + tok) * a.ldo + f] = v;
+        }
+    }
+}
+
 // rows of x -> rmsnorm rows (main.zig:432-468), one block per token
 __global__ __launch_bounds__(kPfBlock) void prefill_rmsnorm(float *o, const float *x, const float *w,
                                                             int n, int P)
@@ -964,7 +1081,19 @@ hipError_t skinny_launch_t(const GemmArgs &a, hipStream_t st)
     dim3 grid((a.N + 15) / 16, (a.P + 16 * TMS - 1) / (16 * TMS));
     // LDS-staged form (1-KB row reads): 5-8 % ahead at 16-32 tokens on the 7B shape, level at 8,
     // behind at 64 (83 KB of LDS, one block per CU) -- so only up to two token tiles
-    if (form == 1 && a.K >= kSkBK && TMS <= 2) {
+    // direct-to-LDS ring (whole 256-k stages, 16-byte aligned rows); L2Z_PF_SKINNY_FORM=2 keeps the
+    // register-staged form (same bits)
+    if (form == 1 && a.K % kSkBK == 0 && a.K / kSkBK >= 3 && a.ldx % 4 == 0 && TMS <= 2 && tunables().pf_dma != 0) {
+        constexpr int SW = TMS == 1 ? 4 : 3;
+        const size_t lds = (size_t)SW * (16 + 16 * TMS) * kSkLD2 * sizeof(float);
+        const void *fn = (const void *)prefill_skinny_dma<EPI, TMS, SW>;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        GemmArgs args = a;
+        void *params[] = {&args};
+        return hipLaunchKernel(fn, grid, dim3(kPfBlock), params, lds, st);
+    }
+    if ((form == 1 || form == 2) && a.K >= kSkBK && TMS <= 2) {
         const size_t stage = (size_t)(16 + 16 * TMS) * kSkLD * sizeof(float);
         const size_t red = (size_t)4 * TMS * 4 * 64 * sizeof(float);
         const size_t lds = stage > red ? stage : red;

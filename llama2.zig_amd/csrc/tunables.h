@@ -33,7 +33,7 @@ struct Tunables {
     // --- batched prefill (prefill_host.cpp, prefill.hip) ---
     int prefill = 1;           // L2Z_PREFILL         0: prompts are stepped token by token
     int pf_chunk = 0;          // L2Z_PF_CHUNK        tokens per chunk (0: default)
-    int pf_skinny_form = 1;    // L2Z_PF_SKINNY_FORM
+    int pf_skinny_form = 1;    // L2Z_PF_SKINNY_FORM  short-prompt GEMM: 1 LDS-staged (direct-to-LDS ring where K % 256 == 0), 2 register-staged LDS form only, 0 no LDS
     int pf_tile = 0;           // L2Z_PF_TILE
     int pf_skinny_max = -1;    // L2Z_PF_SKINNY_MAX
     int pf_skinny_tms = 0;     // L2Z_PF_SKINNY_TMS
