@@ -331,7 +331,9 @@ __device__ __forceinline__ void lds_dma16_nt(const float *g, float *lds)
 //    three resident blocks per CU instead of one) +4.9 % time; an XCD-aware block -> tile map that
 //    keeps each XCD on one 128-row X tile (L2 resident, only W streams) +0.6 %; neither LDS
 //    capacity, nor the memory side, nor latency is what the MFMA pipe waits for.
-//  * Also measured and not kept: 3 / 4 stage buffers (counted vmcnt waits, bare s_barrier) for grids
+//  * Also measured and not kept: the non-temporal policy on the W loads (it pays in the short-prompt
+//    kernel, where one CU reads a W row once): 512 tokens +-0, 128 tokens +4 % time -- here every W
+//    tile is re-read by the blocks of the other token tiles.  3 / 4 stage buffers (counted vmcnt waits, bare s_barrier) for grids
 //    that leave every block a CU to itself (row shards, 256-token prompts): +0.8 ... +1.3 % time.  A
 //    lone 64 x 64 block already runs at 0.68 of its CU's MFMA peak -- such grids are short of blocks,
 //    not of latency hiding.
