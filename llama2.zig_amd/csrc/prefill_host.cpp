@@ -19,9 +19,16 @@ namespace {
 
 int prefill_alloc(l2z_runstate *s)
 {
-    if (s->pf_tokens) return L2Z_OK;  // the last one allocated: all of them exist
     const l2z_config &c = s->cfg;
     const size_t P = kPrefillChunk;
+    if (s->pf_cap >= (int)P) return L2Z_OK;
+    // first use, or the chunk length has grown since (L2Z_PF_CHUNK through l2z_option_set): start over
+    L2Z_HIP(hipStreamSynchronize(s->stream));
+    float **bufs[] = {&s->pf_x, &s->pf_xn, &s->pf_q, &s->pf_att, &s->pf_h1, &s->pf_stage};
+    for (float **b : bufs)
+        if (*b) { (void)hipFree(*b); *b = nullptr; }
+    if (s->pf_tokens) { (void)hipFree(s->pf_tokens); s->pf_tokens = nullptr; }
+    s->pf_cap = 0;
     const size_t widest = (size_t)(c.dim > c.hidden_dim ? c.dim : c.hidden_dim);
     struct { void **p; size_t bytes; } want[] = {
         {(void **)&s->pf_x, P * c.dim * 4},   {(void **)&s->pf_xn, P * c.dim * 4},
@@ -31,14 +38,15 @@ int prefill_alloc(l2z_runstate *s)
         {(void **)&s->pf_stage, s->sh.world > 1 ? P * widest * 4 : 0},
         {(void **)&s->pf_tokens, P * 4}};
     for (auto &b : want) {
-        if (*b.p || b.bytes == 0) continue;  // kept from an earlier, partly failed attempt
+        if (b.bytes == 0) continue;
         hipError_t e = hipMalloc(b.p, b.bytes);
         if (e != hipSuccess) {
             *b.p = nullptr;
             set_error("prefill scratch allocation (%zu bytes) failed: %s", b.bytes, hipGetErrorString(e));
-            return e == hipErrorOutOfMemory ? L2Z_ERR_OOM : L2Z_ERR_HIP;
+            return e == hipErrorOutOfMemory ? L2Z_ERR_OOM : L2Z_ERR_HIP;  // what was allocated is freed with the runstate, or on the next attempt
         }
     }
+    s->pf_cap = (int)P;
     return L2Z_OK;
 }
 

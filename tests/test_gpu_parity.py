@@ -493,6 +493,22 @@ def test_sharded_hip_path_emulated_ranks(gpu, ck, world, from_blob, options):
         c.close()
 
 
+def test_prefill_scratch_follows_the_chunk_length(gpu, ck, options):
+    """The prefill scratch is sized for the chunk length in force at first use; a longer chunk set later
+    (L2Z_PF_CHUNK through l2z_option_set) must re-allocate it, not run past it.  (64-token chunks take
+    the short-prompt GEMMs, 256-token chunks the tile GEMMs: same sums in another order.)"""
+    cfg = ck.Config(dim=256, hidden_dim=704, n_layers=2, n_heads=8, n_kv_heads=4, vocab_size=512, seq_len=320)
+    w, s = gpu.Weights(cfg, None, False, seed=3), gpu.RunState(cfg)
+    toks = [1] + np.random.default_rng(2).integers(2, cfg.vocab_size, 299).tolist()
+    options(L2Z_PF_CHUNK=64)
+    s.prefill(toks, 0, w)
+    small = s.logits()
+    options(L2Z_PF_CHUNK=256)
+    s.prefill(toks, 0, w)
+    np.testing.assert_allclose(s.logits(), small, rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
+    s.close(); w.close()
+
+
 SHARDED_PREFILL = [
     # GQA, 530 tokens: two chunks, 128- and 64-token tiles, tiled attention, a partial last chunk
     ("gqa", dict(dim=512, hidden_dim=1408, n_layers=2, n_heads=16, n_kv_heads=8, vocab_size=1024, seq_len=544), 530),
