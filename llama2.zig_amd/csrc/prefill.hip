@@ -92,6 +92,7 @@ struct GemmArgs {
     int pos0;            // position of token 0 (RoPE angle, cache row)
     const float2 *rope;  // (seq_len, head_size/2) {cos, sin}
     int head_size;
+    int n_scale;         // ranks the matrix's rows are sharded over (N * n_scale rows in the whole model)
 };
 
 // epilogue shared by the two tile kernels: per MFMA tile a lane owns one feature and 16 tokens
@@ -1124,7 +1125,9 @@ hipError_t gemm_launch(const GemmArgs &a, hipStream_t st)
     if (a.P <= skinny_max) {
         // a matrix that stays in the on-die caches is cheapest re-read per 16 tokens (more blocks,
         // more waves per CU); one that streams from HBM is read once, tokens tiled in registers
-        const bool cached = (size_t)a.N * (size_t)a.K * sizeof(float) <= ((size_t)16 << 20);
+        // (the WHOLE matrix: a row shard must take the form the unsharded pass takes -- the forms sum in
+        // different orders)
+        const bool cached = (size_t)a.N * (size_t)a.n_scale * (size_t)a.K * sizeof(float) <= ((size_t)16 << 20);
         if (a.P <= 16 || skinny_tms == 1 || cached) return skinny_launch_t<EPI, 1>(a, st);
         if (a.P <= 32 || skinny_tms == 2) return skinny_launch_t<EPI, 2>(a, st);
         return skinny_launch_t<EPI, 4>(a, st);  // more than 64 tokens: grid.y tiles of 64
@@ -1163,7 +1166,7 @@ hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float 
     const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
     if (P <= skinny_max || K % 64 != 0 || ldx % 4 != 0) return hipErrorNotSupported;
     if (((uintptr_t)x & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w3 & 15)) return hipErrorInvalidValue;
-    GemmArgs a = {x, w3, w1, out, out, P, N, K, ldx, ldo, ldo, 0, nullptr, 0};
+    GemmArgs a = {x, w3, w1, out, out, P, N, K, ldx, ldo, ldo, 0, nullptr, 0, 1};
     constexpr int KS = 2;
     // tokens x (features of W1 + the same features of W3) per block, chosen like the unpaired tiles
     const TileForm tf = choose_tile(N, P, true);
@@ -1185,12 +1188,12 @@ hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float 
 // C[P,N] (+)= X[P,K] W[N,K]^T with the chosen epilogue; K % 4 == 0, 16-byte aligned rows
 hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w, float *out, int ldo,
                                int P, int N, int K, int pos0, const float2 *rope, int head_size,
-                               hipStream_t st, const float *res, int ldres)
+                               hipStream_t st, const float *res, int ldres, int n_scale)
 {
     if (P <= 0 || N <= 0 || K <= 0 || (K % 4) != 0 || (ldx % 4) != 0) return hipErrorInvalidValue;
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return hipErrorInvalidValue;
     if (res == nullptr) { res = out; ldres = ldo; }  // PG_RESID in place
-    GemmArgs a = {x, nullptr, w, out, res, P, N, K, ldx, ldo, ldres, pos0, rope, head_size};
+    GemmArgs a = {x, nullptr, w, out, res, P, N, K, ldx, ldo, ldres, pos0, rope, head_size, n_scale > 0 ? n_scale : 1};
     switch (epi) {
         case G_STORE: return gemm_launch<G_STORE>(a, st);
         case G_RESID: return gemm_launch<G_RESID>(a, st);

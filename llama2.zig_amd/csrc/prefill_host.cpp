@@ -89,17 +89,17 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
         L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, s->pf_x, w->rms_att + (size_t)l * dim, dim, P, st));  // :305
         // q of the local heads: [P, dim_loc]
         L2Z_HIP(launch_prefill_gemm(PG_ROPE, s->pf_xn, dim, w->wq + (size_t)l * sh.dim_loc * dim, s->pf_q,
-                                    sh.dim_loc, P, sh.dim_loc, dim, pos0, s->rope, hs, st));  // :308-351
+                                    sh.dim_loc, P, sh.dim_loc, dim, pos0, s->rope, hs, st, nullptr, 0, sh.world));  // :308-351
         L2Z_HIP(launch_prefill_gemm(PG_ROPE_CACHE, s->pf_xn, dim, w->wk + (size_t)l * kvd * dim, kc, kvd,
-                                    P, kvd, dim, pos0, s->rope, hs, st));                   // :354-357
+                                    P, kvd, dim, pos0, s->rope, hs, st, nullptr, 0, sh.world));  // :354-357
         L2Z_HIP(launch_prefill_gemm(PG_CACHE, s->pf_xn, dim, w->wv + (size_t)l * kvd * dim, vc, kvd, P,
-                                    kvd, dim, pos0, s->rope, hs, st));                      // :358
+                                    kvd, dim, pos0, s->rope, hs, st, nullptr, 0, sh.world));  // :358
         L2Z_HIP(launch_prefill_attention(s->pf_q, sh.dim_loc, kc, vc, out, ldo, pos0, P, sh.heads_loc, hs,
                                          kvd, c.n_heads / c.n_kv_heads, c.seq_len, st, c.n_heads));  // :361-389
     } else if (k == PF_WO) {
         const float *res = s->pf_x + sh.dim0;
         L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_att, dim, w->wo + (size_t)l * sh.dim_loc * dim, out, ldo,
-                                    P, sh.dim_loc, dim, pos0, s->rope, hs, st, res, dim));   // :392-395
+                                    P, sh.dim_loc, dim, pos0, s->rope, hs, st, res, dim, sh.world));   // :392-395
     } else if (k == PF_H1) {
         L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, s->pf_x, w->rms_ffn + (size_t)l * dim, dim, P, st));  // :398
         // :405-416: W1 and W3 in one launch with silu(a) * b as its epilogue where the tile kernel
@@ -108,16 +108,16 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
         const hipError_t pe = launch_prefill_gemm_swiglu_pair(s->pf_xn, dim, w1, w3, out, ldo, P, sh.hid_loc, dim, st);
         if (pe == hipErrorNotSupported) {
             L2Z_HIP(launch_prefill_gemm(PG_STORE, s->pf_xn, dim, w1, out, ldo, P, sh.hid_loc, dim, pos0, s->rope,
-                                        hs, st));                                            // :405
+                                        hs, st, nullptr, 0, sh.world));                      // :405
             L2Z_HIP(launch_prefill_gemm(PG_SWIGLU, s->pf_xn, dim, w3, out, ldo, P, sh.hid_loc, dim, pos0, s->rope,
-                                        hs, st));                   // :408 + :411-416 in the epilogue
+                                        hs, st, nullptr, 0, sh.world));  // :408 + :411-416 in the epilogue
         } else {
             L2Z_HIP(pe);
         }
     } else {
         const float *res = s->pf_x + sh.dim0;
         L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_h1, hid, w->w2 + (size_t)l * sh.dim_loc * hid, out, ldo,
-                                    P, sh.dim_loc, hid, pos0, s->rope, hs, st, res, dim));   // :419-422
+                                    P, sh.dim_loc, hid, pos0, s->rope, hs, st, res, dim, sh.world));   // :419-422
     }
     return L2Z_OK;
 }

@@ -40,3 +40,13 @@ def test_random_shapes_and_world_sizes_sharded_bit_identical(gpu):
     lines = []
     bad = _fuzz("fuzz_shards").run(16, 20260926, lines.append)
     assert bad == 0, "\n".join(l for l in lines if not l.startswith("ok "))
+
+
+def test_fuzz_prefill_vs_stepped_and_sharded_vs_unsharded(gpu):
+    """Random shapes x prompt lengths (1 .. 530 tokens: every GEMM form and both attention kernels) x
+    world sizes: the batched prefill against the stepped loop (logit tolerance), and the row-sharded
+    prefill on emulated ranks against the unsharded one, bit for bit (scripts/fuzz_prefill.py; that run
+    found the short-prompt kernel form depending on the SHARD's matrix size)."""
+    lines = []
+    bad = _fuzz("fuzz_prefill").run(28, 20260927, lines.append)
+    assert bad == 0, "\n".join(l for l in lines if not l.startswith("ok "))
