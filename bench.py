@@ -385,6 +385,17 @@ def main() -> None:
                                     "unit": "TFLOP/s", "frac": flops / dtp / 1e12 / MFMA_F32_PEAK_TF,
                                     "note": "whole prefill (GEMMs + attention + norms), GEMM flops only "
                                             "in the numerator; v_mfma_f32_32x32x2_f32"}}
+            # shorter prompts: other kernels (<= 64 tokens: weight-streaming bound short-prompt GEMMs; 65-256:
+            # smaller tiles so that every CU has a block) -- ms per prompt length
+            by_len = {}
+            for n_s in (16, 128):
+                if n_s < cfg.seq_len:
+                    s.prefill(toks[:n_s], 0, w)
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        s.prefill(toks[:n_s], 0, w)
+                    by_len[str(n_s)] = (time.perf_counter() - t0) / 3 * 1e3
+            prefill["ms_by_prompt_tokens"] = by_len
         except Exception as e:  # noqa: BLE001
             prefill = {"error": str(e)}
     # sharded runstates: the row-sharded prefill (every rank its column blocks, [tokens, n / world] blocks

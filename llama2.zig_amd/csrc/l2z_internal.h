@@ -195,6 +195,9 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
                                int P, int N, int K, int pos0, const float2 *rope, int head_size,
                                hipStream_t st, const float *res = nullptr, int ldres = 0,
                                int n_scale = 1);  // n_scale: ranks the rows are sharded over (kernel-form choices look at the whole matrix)
+hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, const float *wk, const float *wv,
+                                   float *q_out, int ldq, float *kcache, float *vcache, int ldkv, int P, int nq,
+                                   int nkv, int K, int pos0, const float2 *rope, int head_size, hipStream_t st);
 hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float *w1, const float *w3,
                                            float *out, int ldo, int P, int N, int K, hipStream_t st);
 hipError_t launch_prefill_rmsnorm(float *o, const float *x, const float *w, int n, int P,

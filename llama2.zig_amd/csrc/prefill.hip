@@ -30,7 +30,8 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 #endif
 constexpr int kPfBlock = 256;
 
-enum GemmEpi { G_STORE = 0, G_RESID = 1, G_ROPE = 2, G_ROPE_CACHE = 3, G_CACHE = 4, G_SWIGLU = 5 };
+enum GemmEpi { G_STORE = 0, G_RESID = 1, G_ROPE = 2, G_ROPE_CACHE = 3, G_CACHE = 4, G_SWIGLU = 5,
+               G_QKV = 6 };  // q | k | v in one launch: the epilogue of the block's column range (direct-to-LDS tile kernel only)
 
 // main.zig:411-416 on the W3 product: out holds W1 x, becomes silu(W1 x) * (W3 x)
 __device__ __forceinline__ float swiglu_merge(float h1, float h3)
@@ -82,6 +83,11 @@ static TileForm choose_tile(int N, int P, bool pair)
     return (TileForm)best;
 }
 
+// 1-D grid of the direct-to-LDS tile kernel for ntx feature tiles x nty token tiles (see the kernel's
+// block -> tile comment); L2Z_PF_ORDER=0 keeps the 2-D grid
+struct GemmArgs;
+static dim3 dma_grid(int ntx, int nty, GemmArgs *a);
+
 struct GemmArgs {
     const float *x;      // [P, K] row-major (ldx floats per row)
     const float *w2;     // paired form only: the second [N, K] matrix (W3 beside W1)
@@ -93,13 +99,57 @@ struct GemmArgs {
     const float2 *rope;  // (seq_len, head_size/2) {cos, sin}
     int head_size;
     int n_scale;         // ranks the matrix's rows are sharded over (N * n_scale rows in the whole model)
+    // G_QKV: features [0, nq) are rows of w (RoPE, out[token][f], ldo), [nq, nq + nkv) rows of wk (RoPE,
+    // key-cache row pos0 + token, ldkv), the last nkv rows of wv (value-cache row); N = nq + 2 nkv
+    const float *wk, *wv;
+    float *outk, *outv;
+    int nq, nkv, ldkv;
+    // direct-to-LDS tile kernel, 1-D grids (dma_grid): feature tiles, token tiles
+    int ntx, nty;
 };
+
+static dim3 dma_grid(int ntx, int nty, GemmArgs *a)
+{
+    if (tunables().pf_order == 0 || nty > 64) {
+        a->ntx = 0; a->nty = 0;
+        return dim3(ntx, nty);
+    }
+    a->ntx = ntx; a->nty = nty;
+    return dim3((unsigned)((ntx + 7) / 8 * 8 * nty));
+}
 
 // epilogue shared by the two tile kernels: per MFMA tile a lane owns one feature and 16 tokens
 template <int EPI, int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, v16f (&acc)[TM][TN], int n0, int m0, int wm,
                                               int wn, int lane)
 {
+    if constexpr (EPI == G_QKV) {
+        // a block's columns lie in ONE of the three ranges (launcher: nq and nkv are multiples of the tile)
+        const int seg = n0 >= a.nq + a.nkv ? 2 : n0 >= a.nq ? 1 : 0;
+        const int f0 = n0 - (seg == 2 ? a.nq + a.nkv : seg == 1 ? a.nq : 0), nseg = seg == 0 ? a.nq : a.nkv;
+        float *o = seg == 0 ? a.out : seg == 1 ? a.outk : a.outv;
+        const int ld = seg == 0 ? a.ldo : a.ldkv;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int jt = 0; jt < TN; jt++) {
+                const int j = f0 + (wn * TN + jt) * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int tok = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    float v = acc[i][jt][r];
+                    const float partner = __shfl_xor(v, 1, 64);  // as G_ROPE below (main.zig:346-349)
+                    if (seg < 2) {
+                        const int hs = a.head_size;
+                        const int pos = a.pos0 + (tok < a.P ? tok : 0);
+                        const float2 cs = a.rope[(size_t)pos * (size_t)(hs >> 1) + (size_t)(((j < nseg ? j : 0) % hs) >> 1)];
+                        v = (j & 1) ? partner * cs.y + v * cs.x : v * cs.x - partner * cs.y;
+                    }
+                    if (tok < a.P && j < nseg) o[(size_t)(seg == 0 ? tok : a.pos0 + tok) * ld + j] = v;  // :354-358
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -354,7 +404,19 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wg = wave % NWG, kg = wave / NWG, wm = wg / WN, wn = wg % WN;
-    const int n0 = blockIdx.x * (PAIR ? BNt / 2 : BNt), m0 = blockIdx.y * BMt;
+    // Block -> tile.  2-D grid: x = feature tile, y = token tile.  1-D grid (a.nty > 0, dma_grid): ids are
+    // dispatched in order and round-robin over the 8 XCDs, so consecutive groups of 8 nty ids take 8
+    // feature tiles x all nty token tiles with id % 8 = feature tile % 8: the nty blocks that read the
+    // same W tile run on ONE XCD (one L2 fill) and at the same time -- also in grids of several waves,
+    // where the 2-D order lets them drift a whole wave apart.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (a.nty > 0) {
+        const int group = 8 * a.nty, g = bx / group, local = bx - g * group;
+        by = local >> 3;
+        bx = g * 8 + (local & 7);
+        if (bx >= a.ntx) return;  // padding of the last group
+    }
+    const int n0 = bx * (PAIR ? BNt / 2 : BNt), m0 = by * BMt;
 
     // this lane's part of every load: row (within the RPI-row group) lane / SLOTS, physical slot lane % SLOTS
     const int lrow = lane / SLOTS, pslot = lane % SLOTS;
@@ -371,6 +433,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
             const float *m = ((r & 63) >> 5) ? a.w2 : a.w;
             const int f = n0 + (r >> 6) * 32 + (r & 31);
             wsrc[j] = m + (size_t)min(f, a.N - 1) * a.K + 4 * (pslot ^ swz(r));
+        } else if (EPI == G_QKV) {  // the matrix of the block's column range
+            const int seg = n0 >= a.nq + a.nkv ? 2 : n0 >= a.nq ? 1 : 0;
+            const float *m = seg == 0 ? a.w : seg == 1 ? a.wk : a.wv;
+            const int f0 = n0 - (seg == 2 ? a.nq + a.nkv : seg == 1 ? a.nq : 0), nseg = seg == 0 ? a.nq : a.nkv;
+            wsrc[j] = m + (size_t)min(f0 + r, nseg - 1) * a.K + 4 * (pslot ^ swz(r));
         } else {
             wsrc[j] = a.w + (size_t)min(n0 + r, a.N - 1) * a.K + 4 * (pslot ^ swz(r));
         }
@@ -1052,8 +1119,9 @@ hipError_t gemm_launch_t(const GemmArgs &a, hipStream_t st)
             if (lds2 > 48 * 1024)
                 (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             GemmArgs args = a;
+            const dim3 grid1 = dma_grid((int)grid.x, (int)grid.y, &args);
             void *params[] = {&args};
-            return hipLaunchKernel(fn, grid, dim3(256 * KS), params, lds2, st);
+            return hipLaunchKernel(fn, grid1, dim3(256 * KS), params, lds2, st);
         }
     }
     hipLaunchKernelGGL((prefill_gemm<EPI, TM, TN, BK, KS>), grid, dim3(256 * KS), lds, st, a);
@@ -1072,8 +1140,9 @@ bool gemm_launch_small(const GemmArgs &a, hipStream_t st, hipError_t *err)
     const void *fn = (const void *)prefill_gemm_dma<EPI, 1, 1, KS, false, WM, WN>;
     dim3 grid((a.N + BNt - 1) / BNt, (a.P + BMt - 1) / BMt);
     GemmArgs args = a;
+    const dim3 grid1 = dma_grid((int)grid.x, (int)grid.y, &args);
     void *params[] = {&args};
-    *err = hipLaunchKernel(fn, grid, dim3(64 * WM * WN * KS), params, lds, st);
+    *err = hipLaunchKernel(fn, grid1, dim3(64 * WM * WN * KS), params, lds, st);
     return true;
 }
 
@@ -1082,10 +1151,9 @@ hipError_t skinny_launch_t(const GemmArgs &a, hipStream_t st)
 {
     const int form = tunables().pf_skinny_form;
     dim3 grid((a.N + 15) / 16, (a.P + 16 * TMS - 1) / (16 * TMS));
-    // LDS-staged form (1-KB row reads): 5-8 % ahead at 16-32 tokens on the 7B shape, level at 8,
-    // behind at 64 (83 KB of LDS, one block per CU) -- so only up to two token tiles
-    // direct-to-LDS ring (whole 256-k stages, 16-byte aligned rows); L2Z_PF_SKINNY_FORM=2 keeps the
-    // register-staged form (same bits)
+    // LDS-staged forms (1-KB row reads), up to two token tiles (at 64 tokens the stage would take 83 KB).
+    // Direct-to-LDS ring where K is whole 256-k stages and rows are 16-byte aligned;
+    // L2Z_PF_SKINNY_FORM=2 keeps the register-staged form (same sums, another order)
     if (form == 1 && a.K % kSkBK == 0 && a.K / kSkBK >= 3 && a.ldx % 4 == 0 && TMS <= 2 && tunables().pf_dma != 0) {
         constexpr int SW = TMS == 1 ? 4 : 3;
         const size_t lds = (size_t)SW * (16 + 16 * TMS) * kSkLD2 * sizeof(float);
@@ -1166,7 +1234,7 @@ hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float 
     const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
     if (P <= skinny_max || K % 64 != 0 || ldx % 4 != 0) return hipErrorNotSupported;
     if (((uintptr_t)x & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w3 & 15)) return hipErrorInvalidValue;
-    GemmArgs a = {x, w3, w1, out, out, P, N, K, ldx, ldo, ldo, 0, nullptr, 0, 1};
+    GemmArgs a = {x, w3, w1, out, out, P, N, K, ldx, ldo, ldo, 0, nullptr, 0, 1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
     constexpr int KS = 2;
     // tokens x (features of W1 + the same features of W3) per block, chosen like the unpaired tiles
     const TileForm tf = choose_tile(N, P, true);
@@ -1180,7 +1248,49 @@ hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float 
     const size_t red = (size_t)(KS - 1) * (threads / 64 / KS) * (tf == TILE_128x64 ? 2 : 1) * 2 * 16 * 64 * sizeof(float);  // [KS-1][waves per k-group][TM * TN tiles][16][64]
     if (red > lds) lds = red;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 grid((N + feat - 1) / feat, (P + tok - 1) / tok);
+    const dim3 grid = dma_grid((N + feat - 1) / feat, (P + tok - 1) / tok, &a);
+    void *params[] = {&a};
+    return hipLaunchKernel(fn, grid, dim3(threads), params, lds, st);
+}
+
+// q | k | v of one layer in ONE launch of the direct-to-LDS tile kernel (main.zig:308-358): N = nq + 2 nkv
+// features, the block's column range picks the matrix and the epilogue (RoPE into q, RoPE into the key
+// cache rows pos0 + token, plain into the value cache rows).  hipErrorNotSupported when the shape does
+// not take that kernel or a tile would straddle two ranges: the caller launches the three GEMMs.
+hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, const float *wk, const float *wv,
+                                   float *q_out, int ldq, float *kcache, float *vcache, int ldkv, int P, int nq,
+                                   int nkv, int K, int pos0, const float2 *rope, int head_size, hipStream_t st)
+{
+    if (tunables().pf_fuse == 0 || tunables().pf_dma == 0 || tunables().pf_tile != 0) return hipErrorNotSupported;
+    const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
+    if (P <= skinny_max || K % 64 != 0 || ldx % 4 != 0) return hipErrorNotSupported;
+    if (((uintptr_t)x & 15) || ((uintptr_t)wq & 15) || ((uintptr_t)wk & 15) || ((uintptr_t)wv & 15)) return hipErrorInvalidValue;
+    const int N = nq + 2 * nkv;
+    TileForm tf = choose_tile(N, P, false);
+    // 128 x 64 tiles mean q alone already gives every CU its one resident block: three such launches
+    // measured 445 us against 453 for the 768-block one (7B, 512 tokens).  With the smaller tiles several
+    // blocks share a CU and the longer grid keeps them supplied: 128 tokens 21.8 -> 19.4 ms fused.
+    if (tf == TILE_128x64) return hipErrorNotSupported;
+    int feat = tf == TILE_32x32 ? 32 : 64;
+    if (nq % feat != 0 || nkv % feat != 0) {
+        if (nq % 32 != 0 || nkv % 32 != 0) return hipErrorNotSupported;
+        tf = TILE_32x32;
+        feat = 32;
+    }
+    GemmArgs a = {x, nullptr, wq, q_out, q_out, P, N, K, ldx, ldq, ldq, pos0, rope, head_size, 1,
+                  wk, wv, kcache, vcache, nq, nkv, ldkv, 0, 0};
+    constexpr int KS = 2;
+    const int tok = tf == TILE_128x64 ? 128 : tf == TILE_64x64 ? 64 : 32;
+    const void *fn = tf == TILE_128x64 ? (const void *)prefill_gemm_dma<G_QKV, 2, 1, KS, false>
+                   : tf == TILE_64x64  ? (const void *)prefill_gemm_dma<G_QKV, 1, 1, KS, false>
+                   : tf == TILE_32x64  ? (const void *)prefill_gemm_dma<G_QKV, 1, 1, KS, false, 1, 2>
+                                       : (const void *)prefill_gemm_dma<G_QKV, 1, 1, KS, false, 1, 1>;
+    const int threads = tf == TILE_32x64 ? 64 * 2 * KS : tf == TILE_32x32 ? 64 * KS : 256 * KS;
+    size_t lds = 2 * (size_t)(tok + feat) * 64 * sizeof(float);
+    const size_t red = (size_t)(KS - 1) * (threads / 64 / KS) * (tf == TILE_128x64 ? 2 : 1) * 16 * 64 * sizeof(float);
+    if (red > lds) lds = red;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const dim3 grid = dma_grid(N / feat, (P + tok - 1) / tok, &a);
     void *params[] = {&a};
     return hipLaunchKernel(fn, grid, dim3(threads), params, lds, st);
 }
@@ -1193,7 +1303,7 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
     if (P <= 0 || N <= 0 || K <= 0 || (K % 4) != 0 || (ldx % 4) != 0) return hipErrorInvalidValue;
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return hipErrorInvalidValue;
     if (res == nullptr) { res = out; ldres = ldo; }  // PG_RESID in place
-    GemmArgs a = {x, nullptr, w, out, res, P, N, K, ldx, ldo, ldres, pos0, rope, head_size, n_scale > 0 ? n_scale : 1};
+    GemmArgs a = {x, nullptr, w, out, res, P, N, K, ldx, ldo, ldres, pos0, rope, head_size, n_scale > 0 ? n_scale : 1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
     switch (epi) {
         case G_STORE: return gemm_launch<G_STORE>(a, st);
         case G_RESID: return gemm_launch<G_RESID>(a, st);

@@ -87,13 +87,22 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
     float *vc = s->value_cache + (size_t)l * c.seq_len * kvd;
     if (k == PF_ATT) {
         L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, s->pf_x, w->rms_att + (size_t)l * dim, dim, P, st));  // :305
-        // q of the local heads: [P, dim_loc]
-        L2Z_HIP(launch_prefill_gemm(PG_ROPE, s->pf_xn, dim, w->wq + (size_t)l * sh.dim_loc * dim, s->pf_q,
-                                    sh.dim_loc, P, sh.dim_loc, dim, pos0, s->rope, hs, st, nullptr, 0, sh.world));  // :308-351
-        L2Z_HIP(launch_prefill_gemm(PG_ROPE_CACHE, s->pf_xn, dim, w->wk + (size_t)l * kvd * dim, kc, kvd,
-                                    P, kvd, dim, pos0, s->rope, hs, st, nullptr, 0, sh.world));  // :354-357
-        L2Z_HIP(launch_prefill_gemm(PG_CACHE, s->pf_xn, dim, w->wv + (size_t)l * kvd * dim, vc, kvd, P,
-                                    kvd, dim, pos0, s->rope, hs, st, nullptr, 0, sh.world));  // :358
+        // q of the local heads ([P, dim_loc]) and the k / v rows of the local kv heads: one launch where
+        // the tile kernel takes the shape (:308-358), else three
+        const float *wq = w->wq + (size_t)l * sh.dim_loc * dim, *wk = w->wk + (size_t)l * kvd * dim,
+                    *wv = w->wv + (size_t)l * kvd * dim;
+        const hipError_t qe = launch_prefill_gemm_qkv(s->pf_xn, dim, wq, wk, wv, s->pf_q, sh.dim_loc, kc, vc, kvd, P,
+                                                      sh.dim_loc, kvd, dim, pos0, s->rope, hs, st);
+        if (qe == hipErrorNotSupported) {
+            L2Z_HIP(launch_prefill_gemm(PG_ROPE, s->pf_xn, dim, wq, s->pf_q, sh.dim_loc, P, sh.dim_loc, dim, pos0,
+                                        s->rope, hs, st, nullptr, 0, sh.world));  // :308-351
+            L2Z_HIP(launch_prefill_gemm(PG_ROPE_CACHE, s->pf_xn, dim, wk, kc, kvd, P, kvd, dim, pos0, s->rope, hs, st,
+                                        nullptr, 0, sh.world));                   // :354-357
+            L2Z_HIP(launch_prefill_gemm(PG_CACHE, s->pf_xn, dim, wv, vc, kvd, P, kvd, dim, pos0, s->rope, hs, st,
+                                        nullptr, 0, sh.world));                   // :358
+        } else {
+            L2Z_HIP(qe);
+        }
         L2Z_HIP(launch_prefill_attention(s->pf_q, sh.dim_loc, kc, vc, out, ldo, pos0, P, sh.heads_loc, hs,
                                          kvd, c.n_heads / c.n_kv_heads, c.seq_len, st, c.n_heads));  // :361-389
     } else if (k == PF_WO) {
