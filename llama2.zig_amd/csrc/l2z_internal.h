@@ -187,7 +187,7 @@ hipError_t launch_synth_fill(float *dst, uint64_t base_idx, uint64_t count, uint
                              float scale, float bias, hipStream_t st);
 size_t attention_lds_bytes(int head_size, int seq_len, bool vec);
 
-// ---- batched prefill (prefill.hip) ----
+// ---- batched prefill (prefill_gemm.hip, prefill_skinny.hip, prefill_attention.hip) ----
 enum PrefillGemmEpi { PG_STORE = 0, PG_RESID = 1, PG_ROPE = 2, PG_ROPE_CACHE = 3, PG_CACHE = 4,
                       PG_SWIGLU = 5 };  // out = silu(out) * (X W^T): the W3 product merged into W1's
 // PG_RESID: out = res + X W^T (res == nullptr: in place, res = out, ldres = ldo)

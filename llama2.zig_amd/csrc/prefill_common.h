@@ -1,0 +1,64 @@
+// prefill_common.h -- shared by the translation units of the batched prompt pass (prefill_gemm.hip,
+// prefill_skinny.hip, prefill_attention.hip; host side: prefill_host.cpp through l2z_internal.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "l2z_internal.h"
+#include "tunables.h"
+
+namespace l2z {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int kPfBlock = 256;
+
+enum GemmEpi { G_STORE = 0, G_RESID = 1, G_ROPE = 2, G_ROPE_CACHE = 3, G_CACHE = 4, G_SWIGLU = 5,
+               G_QKV = 6 };  // q | k | v in one launch: the epilogue of the block's column range (direct-to-LDS tile kernel only)
+
+// main.zig:411-416 on the W3 product: out holds W1 x, becomes silu(W1 x) * (W3 x)
+__device__ __forceinline__ float swiglu_merge(float h1, float h3)
+{
+    const float v = h1 * (1.0f / (1.0f + expf(-h1)));
+    return v * h3;
+}
+
+struct GemmArgs {
+    const float *x;      // [P, K] row-major (ldx floats per row)
+    const float *w2;     // paired form only: the second [N, K] matrix (W3 beside W1)
+    const float *w;      // [N, K] row-major
+    float *out;          // [P, ldo]; G_*CACHE: cache base, row = pos0 + token
+    const float *res;    // G_RESID: out = res + product ([P, ldres]; the unsharded pass has res == out)
+    int P, N, K, ldx, ldo, ldres;
+    int pos0;            // position of token 0 (RoPE angle, cache row)
+    const float2 *rope;  // (seq_len, head_size/2) {cos, sin}
+    int head_size;
+    int n_scale;         // ranks the matrix's rows are sharded over (N * n_scale rows in the whole model)
+    // G_QKV: features [0, nq) are rows of w (RoPE, out[token][f], ldo), [nq, nq + nkv) rows of wk (RoPE,
+    // key-cache row pos0 + token, ldkv), the last nkv rows of wv (value-cache row); N = nq + 2 nkv
+    const float *wk, *wv;
+    float *outk, *outv;
+    int nq, nkv, ldkv;
+    // direct-to-LDS tile kernel, 1-D grids (dma_grid): feature tiles, token tiles
+    int ntx, nty;
+};
+
+// One direct-to-LDS load: 16 bytes per lane from `g` (per lane) to lds + 16 * lane (`lds` wave-uniform).
+// A plain __device__ function: called from the kernel TEMPLATE directly, the builtin makes the
+// host-side instantiation fail silently (no launch stub is emitted, the library then does not link).
+__device__ __forceinline__ void lds_dma16(const float *g, float *lds)
+{
+    __builtin_amdgcn_global_load_lds(g, lds, 16, 0, 0);
+}
+// the same with the non-temporal policy (aux = 2): a stream that one CU reads once
+__device__ __forceinline__ void lds_dma16_nt(const float *g, float *lds)
+{
+    __builtin_amdgcn_global_load_lds(g, lds, 16, 0, 2);
+}
+
+// prefill_skinny.hip: the short-prompt (P <= 64 tokens) GEMM forms; picks the form and the token tiling
+hipError_t launch_prefill_skinny(int epi, const GemmArgs &a, hipStream_t st);
+
+}  // namespace l2z

@@ -1,4 +1,4 @@
-// prefill.hip -- batched prompt processing.
+// prefill_gemm.hip -- the tile GEMMs of the batched prompt pass.
 //
 // The reference feeds the prompt one token at a time through transformer()
 // (src/main.zig:999-1000): every matrix op is a mat-vec and the logits of
@@ -11,34 +11,19 @@
 // Results equal the token-by-token path up to summation order (tested within
 // the same logit tolerance); the KV cache and RunState end in the same state.
 //
-// Kernels: prefill_gemm (LDS-tiled MFMA GEMM with fused epilogues), batched
-// rmsnorm, SwiGLU, embedding gather, causal attention for a chunk (one block
-// per (head, token), the decode kernel's arithmetic).
+// This file: the LDS-tiled MFMA GEMMs with fused epilogues for P > 64 tokens and the public GEMM
+// launchers.  prefill_skinny.hip: P <= 64.  prefill_attention.hip: rmsnorm, embedding gather, causal
+// attention of a chunk.
 #include <cstdlib>
 
-#include "l2z_internal.h"
-#include "tunables.h"
+#include "prefill_common.h"
 
 namespace l2z {
 namespace {
 
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef float v16f __attribute__((ext_vector_type(16)));
-
 #ifndef L2Z_DBG_GEMM
 #define L2Z_DBG_GEMM 0  // timing experiments only: 1 no global loads, 2 no LDS writes, 4 no LDS reads, 8 no barrier
 #endif
-constexpr int kPfBlock = 256;
-
-enum GemmEpi { G_STORE = 0, G_RESID = 1, G_ROPE = 2, G_ROPE_CACHE = 3, G_CACHE = 4, G_SWIGLU = 5,
-               G_QKV = 6 };  // q | k | v in one launch: the epilogue of the block's column range (direct-to-LDS tile kernel only)
-
-// main.zig:411-416 on the W3 product: out holds W1 x, becomes silu(W1 x) * (W3 x)
-__device__ __forceinline__ float swiglu_merge(float h1, float h3)
-{
-    const float v = h1 * (1.0f / (1.0f + expf(-h1)));
-    return v * h3;
-}
 
 // compute units of the current device (tile choice: does the larger tile still give every CU a block?)
 static int g_cus_hint()
@@ -85,29 +70,6 @@ static TileForm choose_tile(int N, int P, bool pair)
 
 // 1-D grid of the direct-to-LDS tile kernel for ntx feature tiles x nty token tiles (see the kernel's
 // block -> tile comment); L2Z_PF_ORDER=0 keeps the 2-D grid
-struct GemmArgs;
-static dim3 dma_grid(int ntx, int nty, GemmArgs *a);
-
-struct GemmArgs {
-    const float *x;      // [P, K] row-major (ldx floats per row)
-    const float *w2;     // paired form only: the second [N, K] matrix (W3 beside W1)
-    const float *w;      // [N, K] row-major
-    float *out;          // [P, ldo]; G_*CACHE: cache base, row = pos0 + token
-    const float *res;    // G_RESID: out = res + product ([P, ldres]; the unsharded pass has res == out)
-    int P, N, K, ldx, ldo, ldres;
-    int pos0;            // position of token 0 (RoPE angle, cache row)
-    const float2 *rope;  // (seq_len, head_size/2) {cos, sin}
-    int head_size;
-    int n_scale;         // ranks the matrix's rows are sharded over (N * n_scale rows in the whole model)
-    // G_QKV: features [0, nq) are rows of w (RoPE, out[token][f], ldo), [nq, nq + nkv) rows of wk (RoPE,
-    // key-cache row pos0 + token, ldkv), the last nkv rows of wv (value-cache row); N = nq + 2 nkv
-    const float *wk, *wv;
-    float *outk, *outv;
-    int nq, nkv, ldkv;
-    // direct-to-LDS tile kernel, 1-D grids (dma_grid): feature tiles, token tiles
-    int ntx, nty;
-};
-
 static dim3 dma_grid(int ntx, int nty, GemmArgs *a)
 {
     if (tunables().pf_order == 0 || nty > 64) {
@@ -333,19 +295,6 @@ __global__ __launch_bounds__(256 * KS) void prefill_gemm(const GemmArgs a)
     gemm_epilogue<EPI, TM, TN>(a, acc, n0, m0, wm, wn, lane);
 }
 
-// One direct-to-LDS load: 16 bytes per lane from `g` (per lane) to lds + 16 * lane (`lds` wave-uniform).
-// A plain __device__ function: called from the kernel TEMPLATE directly, the builtin makes the
-// host-side instantiation fail silently (no launch stub is emitted, the library then does not link).
-__device__ __forceinline__ void lds_dma16(const float *g, float *lds)
-{
-    __builtin_amdgcn_global_load_lds(g, lds, 16, 0, 0);
-}
-// the same with the non-temporal policy (aux = 2): a stream that one CU reads once
-__device__ __forceinline__ void lds_dma16_nt(const float *g, float *lds)
-{
-    __builtin_amdgcn_global_load_lds(g, lds, 16, 0, 2);
-}
-
 // The same tile product with the operands brought in by DIRECT-TO-LDS loads
 // (global_load_lds_dwordx4, gfx950): no VGPR round trip and no LDS-write instructions -- in the
 // register-staged kernel above the copy (6 float4 loads -> 24 ds_write_b32 per thread and stage,
@@ -546,554 +495,6 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
     }
 }
 
-// Short prompts (P <= 64): the product is bound by streaming W once, like the decode mat-vec, and
-// a 64 x 64 tile leaves most CUs without a block (N / 64 blocks).  Here a block owns 16 features
-// and 16 TMS tokens; its 8 waves split K in chunks of 64 and every lane feeds MFMA 16x16x4 straight
-// from global memory -- no LDS staging: each W element is loaded by exactly one lane, X (P x K,
-// L2 resident) by one lane per block.  MFMA 16x16x4 f32 operands:
-//   A: lane l holds A[i = l & 15][k = l >> 4]   B: lane l holds B[k = l >> 4][j = l & 15]
-//   D: lane l, reg r holds D[i = 4 (l >> 4) + r][j = l & 15]
-// Lane (., q) loads the float4 at k = chunk base + 16 u + 4 q; component t of it is "k = q" of MFMA
-// (c, u, t) for both operands, which is all the instruction needs (a sum over k is unordered in
-// exact arithmetic; the fp32 order is fixed by (c, u, t), then the waves in order: deterministic).
-
-template <int EPI, int TMS, int kSkWaves, int CU, bool KTAIL>
-__global__ __launch_bounds__(64 * kSkWaves) void prefill_skinny(const GemmArgs a)
-{
-    // CU float4 loads per lane and chunk (a chunk is 16 CU values of k); KTAIL: K % (16 CU) != 0
-    __shared__ float red[kSkWaves][TMS][4][64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 15, q = lane >> 4;
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * TMS;
-    const v4f zero = {0.f, 0.f, 0.f, 0.f};
-    // rows / tokens past the end are clamped: their products land in outputs nobody stores.
-    // No branch and no select around the loads (either would make the loop wait for them early).
-    const float *wrow = a.w + (size_t)min(n0 + j, a.N - 1) * a.K + 4 * q;
-    const float *xrow[TMS];
-#pragma unroll
-    for (int tm = 0; tm < TMS; tm++) xrow[tm] = a.x + (size_t)min(m0 + 16 * tm + j, a.P - 1) * a.ldx + 4 * q;
-    v4f acc[TMS];
-#pragma unroll
-    for (int tm = 0; tm < TMS; tm++) acc[tm] = zero;
-    constexpr int CK = 16 * CU;
-    const int nchunk = (a.K + CK - 1) / CK;
-    v4f wc[CU], wn[CU], xc[TMS][CU], xn[TMS][CU];
-    auto load = [&](int c, v4f (&wv)[CU], v4f (&xv)[TMS][CU]) {
-#pragma unroll
-        for (int u = 0; u < CU; u++) {
-            int k = CK * c + 16 * u;
-            if (KTAIL && k + 4 * q >= a.K) k = a.K - 4 - 4 * q;  // a lane past the row end re-reads the
-                                                                 // row's last float4; zeroed at use
-            wv[u] = __builtin_nontemporal_load((const v4f *)(wrow + k));
-#pragma unroll
-            for (int tm = 0; tm < TMS; tm++) xv[tm][u] = *(const v4f *)(xrow[tm] + k);
-        }
-    };
-    int c = wave;
-    if (c < nchunk) load(c, wc, xc);
-    for (; c < nchunk; c += kSkWaves) {
-        if (c + kSkWaves < nchunk) load(c + kSkWaves, wn, xn);
-#pragma unroll
-        for (int u = 0; u < CU; u++) {
-            const bool dead = KTAIL && CK * c + 16 * u + 4 * q >= a.K;  // K % 4 == 0
-#pragma unroll
-            for (int t = 0; t < 4; t++)
-#pragma unroll
-                for (int tm = 0; tm < TMS; tm++)
-                    acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(dead ? 0.0f : xc[tm][u][t], wc[u][t], acc[tm], 0, 0, 0);
-        }
-#pragma unroll
-        for (int u = 0; u < CU; u++) {
-            wc[u] = wn[u];
-#pragma unroll
-            for (int tm = 0; tm < TMS; tm++) xc[tm][u] = xn[tm][u];
-        }
-    }
-#pragma unroll
-    for (int tm = 0; tm < TMS; tm++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) red[wave][tm][r][lane] = acc[tm][r];
-    __syncthreads();
-    // TMS * 4 * 64 results; a wave of threads shares (tm, r), lanes are the MFMA lanes
-    for (int idx = tid; idx < TMS * 256; idx += 64 * kSkWaves) {
-        const int tm = idx >> 8, r = (idx >> 6) & 3, l = idx & 63;
-        float v = red[0][tm][r][l];
-#pragma unroll
-        for (int w = 1; w < kSkWaves; w++) v += red[w][tm][r][l];
-        const int tok = m0 + 16 * tm + 4 * (l >> 4) + r;
-        const int f = n0 + (l & 15);
-        if (EPI == G_ROPE || EPI == G_ROPE_CACHE) {
-            const float partner = __shfl_xor(v, 1, 64);  // feature f ^ 1, same token (main.zig:346-349)
-            const int hs = a.head_size;
-            const int pos = a.pos0 + (tok < a.P ? tok : 0);
-            const float2 cs = a.rope[(size_t)pos * (size_t)(hs >> 1) + (size_t)(((f < a.N ? f : 0) % hs) >> 1)];
-            v = (f & 1) ? partner * cs.y + v * cs.x : v * cs.x - partner * cs.y;
-        }
-        if (tok < a.P && f < a.N) {
-            if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + f] = v;
-            else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + f] = a.res[(size_t)tok * a.ldres + f] + v;
-            else if (EPI == G_SWIGLU) a.out[(size_t)tok * a.ldo + f] = swiglu_merge(a.out[(size_t)tok * a.ldo + f], v);
-            else a.out[(size_t)(a.pos0 + tok) * a.ldo + f] = v;
-        }
-    }
-}
-
-// The same 16-feature x 16 TMS-token block as prefill_skinny, but W and X are staged through LDS
-// in chunks of 256 k: every wave-wide global load then reads 1 KB of ONE row instead of 16 rows x
-// 64 bytes, and the MFMA operands come from LDS rows of 260 floats (bank = 4 j + q: conflict-free).
-// Both forms stream W at ~3.4 TB/s, half the decode kernel's rate: N/16 blocks x 16 rows are
-// thousands of concurrent DRAM row streams, where the decode kernel sweeps 2 rows per block in
-// 16-KB bursts -- the price of having 16 features in flight per MFMA.
-// Stage s+1 travels global -> registers while stage s is multiplied; the 4 waves split each
-// stage's 64 k-steps and are summed through LDS at the end (order fixed: deterministic).
-constexpr int kSkBK = 256, kSkLD = kSkBK + 4;
-
-template <int EPI, int TMS>
-__global__ __launch_bounds__(kPfBlock) void prefill_skinny_lds(const GemmArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *ws = smem;                    // 16 x kSkLD
-    float *xs = smem + 16 * kSkLD;       // 16 TMS x kSkLD
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 15, q = lane >> 4;
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * TMS;
-    const v4f zero = {0.f, 0.f, 0.f, 0.f};
-    // float4 slot f = tid + 256 i of a tile: row f / 64, k = 4 (f % 64): a wave reads 1 KB of a row
-    v4f wv[4], xv[TMS][4];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int f = tid + kPfBlock * i, r = f >> 6, k = k0 + 4 * (f & 63);
-            const int kc = min(k, a.K - 4);  // clamped: legal address, zeroed at the LDS store
-            wv[i] = __builtin_nontemporal_load((const v4f *)(a.w + (size_t)min(n0 + r, a.N - 1) * a.K + kc));
-#pragma unroll
-            for (int tm = 0; tm < TMS; tm++)
-                xv[tm][i] = *(const v4f *)(a.x + (size_t)min(m0 + 16 * tm + r, a.P - 1) * a.ldx + kc);
-        }
-    };
-    auto sstore = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int f = tid + kPfBlock * i, r = f >> 6, c = 4 * (f & 63);
-            const bool ok = k0 + c < a.K;  // K % 4 == 0; rows / tokens past the end: junk nobody stores
-            *(v4f *)(ws + r * kSkLD + c) = ok ? wv[i] : zero;
-#pragma unroll
-            for (int tm = 0; tm < TMS; tm++) *(v4f *)(xs + (16 * tm + r) * kSkLD + c) = ok ? xv[tm][i] : zero;
-        }
-    };
-    v4f acc[TMS];
-#pragma unroll
-    for (int tm = 0; tm < TMS; tm++) acc[tm] = zero;
-    gload(0);
-    for (int k0 = 0; k0 < a.K; k0 += kSkBK) {
-        __syncthreads();  // the previous stage has been multiplied
-        sstore(k0);
-        __syncthreads();
-        if (k0 + kSkBK < a.K) gload(k0 + kSkBK);  // flies while this stage is multiplied
-        const float *wr = ws + j * kSkLD + 64 * wave + q;
-        const float *xr = xs + j * kSkLD + 64 * wave + q;
-#pragma unroll
-        for (int st = 0; st < 16; st++) {  // this wave's quarter of the stage: k = 64 wave + 4 st + q
-            const float b = wr[4 * st];
-#pragma unroll
-            for (int tm = 0; tm < TMS; tm++)
-                acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[16 * tm * kSkLD + 4 * st], b, acc[tm], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-    float *red = smem;  // [4 waves][TMS][4][64]
-#pragma unroll
-    for (int tm = 0; tm < TMS; tm++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) red[((wave * TMS + tm) * 4 + r) * 64 + lane] = acc[tm][r];
-    __syncthreads();
-    for (int idx = tid; idx < TMS * 256; idx += kPfBlock) {
-        const int tm = idx >> 8, r = (idx >> 6) & 3, l = idx & 63;
-        float v = red[((0 * TMS + tm) * 4 + r) * 64 + l];
-#pragma unroll
-        for (int w = 1; w < 4; w++) v += red[((w * TMS + tm) * 4 + r) * 64 + l];
-        const int tok = m0 + 16 * tm + 4 * (l >> 4) + r;
-        const int f = n0 + (l & 15);
-        if (EPI == G_ROPE || EPI == G_ROPE_CACHE) {
-            const float partner = __shfl_xor(v, 1, 64);  // feature f ^ 1, same token (main.zig:346-349)
-            const int hs = a.head_size;
-            const int pos = a.pos0 + (tok < a.P ? tok : 0);
-            const float2 cs = a.rope[(size_t)pos * (size_t)(hs >> 1) + (size_t)(((f < a.N ? f : 0) % hs) >> 1)];
-            v = (f & 1) ? partner * cs.y + v * cs.x : v * cs.x - partner * cs.y;
-        }
-        if (tok < a.P && f < a.N) {
-            if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + f] = v;
-            else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + f] = a.res[(size_t)tok * a.ldres + f] + v;
-            else if (EPI == G_SWIGLU) a.out[(size_t)tok * a.ldo + f] = swiglu_merge(a.out[(size_t)tok * a.ldo + f], v);
-            else a.out[(size_t)(a.pos0 + tok) * a.ldo + f] = v;
-        }
-    }
-}
-
-// Short prompts, third form (round 2): prefill_skinny_lds with the operands brought in by
-// direct-to-LDS loads and a ring of SW stages.  The register-staged form keeps one 16-KB stage of W in
-// flight per block, and N = 4096 gives one block per CU: 4 MB on the wire chip-wide where the memory
-// system needs ~13 MB (8 TB/s x latency) -- W streamed at 3.1 TB/s.  Here every wave-wide load still
-// reads 1 KB of ONE row, but it lands in LDS without passing through VGPRs, so SW - 1 stages (48 KB of
-// W per CU at SW = 4) are in flight.  X rides in the same ring: vmcnt retires loads in issue order, so
-// a shallower X ring would drain the W ring with it.  A wave-wide load is exactly one row, so the row
-// pitch is free: 264 floats make the operand reads conflict-free as ds_read_b128 -- lane (j, q) takes
-// the float4 at k = 64 wave + 16 u + 4 q of row j and feeds component c to MFMA (u, c), A and B alike.
-// The W loads carry the non-temporal policy (a stream one CU reads once; X, which every block re-reads
-// from L2, does not).  7B shape, q / k / v / wo (67 MB): 21.6 -> 15.0 us = 4.5 TB/s; 16-token prompt
-// 7.67 -> 6.24 ms, 8 tokens 7.17 -> 5.99, 32 tokens 10.0 -> 8.9 (nt alone: 6.75 -> 6.24 at 16).
-// Measured on top of this and not kept: X loaded straight into a register ring (inline-asm loads the
-// compiler does not wait for) so that two 67-KB blocks fit a CU: +3 %; 8 waves per block: +3 %; each
-// block starting at another stage of K (in case the 4096 row streams camp on a few channels): +9 %.
-// Neither depth, nor waves per CU, nor the LDS read width moves it further; W1 / W3 (688 blocks, one
-// resident per CU: 2.7 rounds) stay at 4.1 TB/s.
-// Needs K % 256 == 0 (whole stages: the 7B and 110M shapes); otherwise the launcher keeps the
-// register-staged form (same sums, another order).
-constexpr int kSkLD2 = kSkBK + 8;
-
-template <int EPI, int TMS, int SW>
-__global__ __launch_bounds__(kPfBlock) void prefill_skinny_dma(const GemmArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int WST = 16 * kSkLD2, XST = 16 * TMS * kSkLD2, ST = WST + XST;  // floats per stage: W rows, then X rows
-    constexpr int LPS = 4 + 4 * TMS;  // this wave's loads per stage
-    static_assert(SW >= 3 && SW <= 4, "ring depth");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 15, q = lane >> 4;
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * TMS;
-    const v4f zero = {0.f, 0.f, 0.f, 0.f};
-    // this wave's rows of every stage: W rows 4 wave .. 4 wave + 3, X rows likewise per token tile
-    const float *wsrc[4], *xsrc[TMS][4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int r = 4 * wave + i;
-        wsrc[i] = a.w + (size_t)min(n0 + r, a.N - 1) * a.K + 4 * lane;
-#pragma unroll
-        for (int tm = 0; tm < TMS; tm++) xsrc[tm][i] = a.x + (size_t)min(m0 + 16 * tm + r, a.P - 1) * a.ldx + 4 * lane;
-    }
-    auto issue = [&](int st, int buf) {
-        float *ws = smem + buf * ST, *xs = ws + WST;
-#pragma unroll
-        for (int i = 0; i < 4; i++) lds_dma16_nt(wsrc[i] + (size_t)st * kSkBK, ws + (4 * wave + i) * kSkLD2);
-#pragma unroll
-        for (int tm = 0; tm < TMS; tm++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) lds_dma16(xsrc[tm][i] + (size_t)st * kSkBK, xs + (16 * tm + 4 * wave + i) * kSkLD2);
-    };
-    v4f acc[TMS];
-#pragma unroll
-    for (int tm = 0; tm < TMS; tm++) acc[tm] = zero;
-    const int nst = a.K / kSkBK;  // launcher: nst >= SW - 1
-#pragma unroll
-    for (int p = 0; p < SW - 1; p++) issue(p, p);
-    int buf = 0, nbuf = SW - 1;
-    for (int st = 0; st < nst; st++) {
-        // stage st has landed (this wave's part): what may still fly are the younger stages already issued
-        const int younger = min(SW - 2, nst - 1 - st);
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // every wave's part of stage st is in LDS; stage st - 1 has been multiplied
-        if (st + SW - 1 < nst) issue(st + SW - 1, nbuf);  // into the buffer stage st - 1 has just left
-        const float *wr = smem + buf * ST + j * kSkLD2 + 64 * wave + 4 * q;
-        const float *xr = wr + WST;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {  // this wave's quarter of the stage
-            const v4f b = *(const v4f *)(wr + 16 * u);
-            v4f xa[TMS];
-#pragma unroll
-            for (int tm = 0; tm < TMS; tm++) xa[tm] = *(const v4f *)(xr + 16 * tm * kSkLD2 + 16 * u);
-#pragma unroll
-            for (int c = 0; c < 4; c++)
-#pragma unroll
-                for (int tm = 0; tm < TMS; tm++)
-                    acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[tm][c], b[c], acc[tm], 0, 0, 0);
-        }
-        buf = buf + 1 == SW ? 0 : buf + 1;
-        nbuf = nbuf + 1 == SW ? 0 : nbuf + 1;
-    }
-    __syncthreads();
-    float *red = smem;  // [4 waves][TMS][4][64]
-#pragma unroll
-    for (int tm = 0; tm < TMS; tm++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) red[((wave * TMS + tm) * 4 + r) * 64 + lane] = acc[tm][r];
-    __syncthreads();
-    for (int idx = tid; idx < TMS * 256; idx += kPfBlock) {
-        const int tm = idx >> 8, r = (idx >> 6) & 3, l = idx & 63;
-        float v = red[((0 * TMS + tm) * 4 + r) * 64 + l];
-#pragma unroll
-        for (int w = 1; w < 4; w++) v += red[((w * TMS + tm) * 4 + r) * 64 + l];
-        const int tok = m0 + 16 * tm + 4 * (l >> 4) + r;
-        const int f = n0 + (l & 15);
-        if (EPI == G_ROPE || EPI == G_ROPE_CACHE) {
-            const float partner = __shfl_xor(v, 1, 64);  // feature f ^ 1, same token (main.zig:346-349)
-            const int hs = a.head_size;
-            const int pos = a.pos0 + (tok < a.P ? tok : 0);
-            const float2 cs = a.rope[(size_t)pos * (size_t)(hs >> 1) + (size_t)(((f < a.N ? f : 0) % hs) >> 1)];
-            v = (f & 1) ? partner * cs.y + v * cs.x : v * cs.x - partner * cs.y;
-        }
-        if (tok < a.P && f < a.N) {
-            if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + f] = v;
-            else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + f] = a.res[(size_t)tok * a.ldres + f] + v;
-            else if (EPI == G_SWIGLU) a.out[(size_t)tok * a.ldo + f] = swiglu_merge(a.out[(size_t)tok * a.ldo + f], v);
-            else a.out[(size_t)(a.pos0 + tok) * a.ldo + f] = v;
-        }
-    }
-}
-
-// rows of x -> rmsnorm rows (main.zig:432-468), one block per token
-__global__ __launch_bounds__(kPfBlock) void prefill_rmsnorm(float *o, const float *x, const float *w,
-                                                            int n, int P)
-{
-    __shared__ float red[8];
-    const int t = blockIdx.x;
-    const float *xr = x + (size_t)t * n;
-    const int n4 = n >> 2;  // n % 4 == 0 on this path
-    constexpr int R = 8;    // float4 kept in registers per lane: one round trip up to n = 8192
-    const bool in_regs = n4 <= R * kPfBlock;
-    v4f xv[R];
-    float ss = 0.0f;
-    if (in_regs) {
-#pragma unroll
-        for (int k = 0; k < R; k++) {
-            const int i = threadIdx.x + kPfBlock * k;
-            xv[k] = i < n4 ? ((const v4f *)xr)[i] : v4f{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int k = 0; k < R; k++) {
-            ss = fmaf(xv[k].x, xv[k].x, ss); ss = fmaf(xv[k].y, xv[k].y, ss);
-            ss = fmaf(xv[k].z, xv[k].z, ss); ss = fmaf(xv[k].w, xv[k].w, ss);
-        }
-    } else {
-        for (int i = threadIdx.x; i < n; i += blockDim.x) ss = fmaf(xr[i], xr[i], ss);
-    }
-    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
-    __syncthreads();
-    float tot = red[0];
-    for (int i = 1; i < (int)(blockDim.x >> 6); i++) tot += red[i];
-    float s = tot / (float)n;  // main.zig:452-455
-    s += 1e-5f;
-    s = 1.0f / sqrtf(s);
-    if (in_regs) {
-#pragma unroll
-        for (int k = 0; k < R; k++) {
-            const int i = threadIdx.x + kPfBlock * k;
-            if (i < n4) {
-                const v4f wv = ((const v4f *)w)[i];
-                v4f r;
-                r.x = (xv[k].x * s) * wv.x; r.y = (xv[k].y * s) * wv.y;
-                r.z = (xv[k].z * s) * wv.z; r.w = (xv[k].w * s) * wv.w;
-                ((v4f *)(o + (size_t)t * n))[i] = r;
-            }
-        }
-    } else {
-        for (int i = threadIdx.x; i < n; i += blockDim.x) o[(size_t)t * n + i] = (xr[i] * s) * w[i];
-    }
-}
-
-// x[t] = embedding row of tokens[t]   (main.zig:295-296)
-__global__ void prefill_embed(float *x, const float *tok_emb, const int *tokens, int dim)
-{
-    const float *row = tok_emb + (size_t)tokens[blockIdx.x] * dim;
-    for (int i = threadIdx.x; i < dim; i += blockDim.x) x[(size_t)blockIdx.x * dim + i] = row[i];
-}
-
-// Causal attention for a chunk (main.zig:361-389): block (h, t) is query token t of head h and
-// attends to cache rows 0..pos0+t.  256 threads = G groups of TPR lanes, as in the decode kernel.
-__global__ __launch_bounds__(kPfBlock) void prefill_attention(const float *q, int ldq,
-                                                              const float *kcache, const float *vcache,
-                                                              float *out, int ldo, int pos0,
-                                                              int head_size, int kv_dim, int kv_mul,
-                                                              int seq_len)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int hs = head_size, E = hs >> 2;
-    int TPR = 1;
-    while (TPR < E && TPR < 64) TPR <<= 1;
-    const int G = kPfBlock / TPR;
-    float *att = lds;                                   // seq_len
-    float *part = att + ((seq_len + 3) & ~3);           // G*hs
-    float *red = part + (size_t)G * hs;                 // 8
-    const int h = blockIdx.x, tok = blockIdx.y;
-    const int T = pos0 + tok + 1;
-    const int kvh = h / kv_mul;
-    const float *kbase = kcache + (size_t)kvh * hs, *vbase = vcache + (size_t)kvh * hs;
-    const int g = threadIdx.x / TPR, c0 = threadIdx.x % TPR;
-    const bool active = c0 < E;
-    const int cc = active ? c0 : 0;
-    const v4f zero = {0.f, 0.f, 0.f, 0.f};
-    const v4f qv = active ? ((const v4f *)(q + (size_t)tok * ldq + (size_t)h * hs))[cc] : zero;
-    const float div = sqrtf((float)hs);
-    for (int t = g; t < T; t += G) {
-        const v4f kv = ((const v4f *)(kbase + (size_t)t * kv_dim))[cc];
-        float p = fmaf(qv.x, kv.x, 0.0f);
-        p = fmaf(qv.y, kv.y, p); p = fmaf(qv.z, kv.z, p); p = fmaf(qv.w, kv.w, p);
-        for (int o = TPR >> 1; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
-        if (c0 == 0) att[t] = p / div;
-    }
-    __syncthreads();
-    float m = -INFINITY;
-    for (int t = threadIdx.x; t < T; t += blockDim.x) m = fmaxf(m, att[t]);
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __syncthreads();
-    float s = 0.0f;
-    for (int t = threadIdx.x; t < T; t += blockDim.x) {
-        const float e = expf(att[t] - m);
-        att[t] = e;
-        s += e;
-    }
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = s;
-    __syncthreads();
-    s = ((red[4] + red[5]) + red[6]) + red[7];
-    v4f acc = zero;
-    for (int t = g; t < T; t += G) {
-        const v4f vv = ((const v4f *)(vbase + (size_t)t * kv_dim))[cc];
-        const float w = att[t] / s;  // main.zig:704
-        acc.x = fmaf(vv.x, w, acc.x); acc.y = fmaf(vv.y, w, acc.y);
-        acc.z = fmaf(vv.z, w, acc.z); acc.w = fmaf(vv.w, w, acc.w);
-    }
-    if (active) ((v4f *)(part + (size_t)g * hs))[cc] = acc;
-    __syncthreads();
-    for (int i = threadIdx.x; i < hs; i += blockDim.x) {
-        float r = part[i];
-        for (int gg = 1; gg < G; gg++) r += part[(size_t)gg * hs + i];
-        out[(size_t)tok * ldo + (size_t)h * hs + i] = r;
-    }
-}
-
-// Tiled causal attention for a chunk (flash form): block (h, 64 query tokens) walks the cache in
-// tiles of 64 timesteps; S = Q K^T and O += P V run on the fp32 matrix cores, the softmax is the
-// running-max form (m, l per query row, O rescaled by e^(m_old - m_new)), so a K/V tile is read
-// once per 64 queries instead of once per query.  Mathematically main.zig:361-389; in floating
-// point the weights are e^(s-m)/l applied after the sum instead of before (a few ulp, same as the
-// decode path's split attention).  LDS: Q, K, V tiles 64 x (hs+1), P tile 64 x 65.
-//   S: wave (wm, wn) owns S[32 wm.., 32 wn..];  O: 32 x 32 tiles (row half, column tile) dealt to
-//   the waves round-robin, TPW per wave.
-template <int TPW>
-__global__ __launch_bounds__(kPfBlock) void prefill_attention_tiled(const float *q, int ldq,
-                                                                    const float *kcache, const float *vcache,
-                                                                    float *out, int ldo, int pos0, int P,
-                                                                    int hs, int kv_dim, int kv_mul, int seq_len)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int LD = hs + 1;
-    float *qs = lds, *ks = qs + 64 * LD, *vs = ks + 64 * LD, *ps = vs + 64 * LD;
-    float *row_m = ps + 64 * 65, *row_l = row_m + 64, *row_a = row_l + 64;
-    const int h = blockIdx.x, q0 = blockIdx.y * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
-    const int kvh = h / kv_mul;  // :369
-    const float *kbase = kcache + (size_t)kvh * hs, *vbase = vcache + (size_t)kvh * hs;
-    const int E = hs >> 2;
-    const v4f zero = {0.f, 0.f, 0.f, 0.f};
-    for (int f = tid; f < 64 * E; f += kPfBlock) {
-        const int r = f / E, c = (f % E) * 4;
-        const v4f v = q0 + r < P ? *(const v4f *)(q + (size_t)(q0 + r) * ldq + (size_t)h * hs + c) : zero;
-        float *d = qs + r * LD + c;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
-    if (tid < 64) { row_m[tid] = -INFINITY; row_l[tid] = 0.0f; }
-    v16f acc[TPW];
-#pragma unroll
-    for (int j = 0; j < TPW; j++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[j][r] = 0.0f;
-    const int last_q = (q0 + 63 < P ? q0 + 63 : P - 1);
-    const int n_kt = (pos0 + last_q) / 64 + 1;  // key tiles 0 .. the one holding the last query's own position
-    const float div = sqrtf((float)hs);
-    // k order of the S product: pairs 32 apart inside chunks of 64 when hs allows (lanes 32..63 then
-    // hit LDS banks 32 away from lanes 0..31), else pairs hs/2 apart
-    const bool chunked = (hs & 63) == 0;
-    const int half = hs >> 1;
-    for (int kt = 0; kt < n_kt; kt++) {
-        const int t0 = kt * 64;
-        __syncthreads();  // the previous tile's P V product is done with ks / vs / ps
-        for (int f = tid; f < 64 * E; f += kPfBlock) {
-            const int r = f / E, c = (f % E) * 4;
-            int t = t0 + r;
-            t = t < seq_len ? t : seq_len - 1;  // rows past the context are masked below
-            const v4f kv = *(const v4f *)(kbase + (size_t)t * kv_dim + c);
-            const v4f vv = *(const v4f *)(vbase + (size_t)t * kv_dim + c);
-            float *dk = ks + r * LD + c, *dv = vs + r * LD + c;
-            dk[0] = kv.x; dk[1] = kv.y; dk[2] = kv.z; dk[3] = kv.w;
-            dv[0] = vv.x; dv[1] = vv.y; dv[2] = vv.z; dv[3] = vv.w;
-        }
-        __syncthreads();
-        {   // S = Q K^T for this wave's 32 x 32 tile (:367-371)
-            v16f sacc;
-#pragma unroll
-            for (int r = 0; r < 16; r++) sacc[r] = 0.0f;
-            const float *qa = qs + (32 * wm + li) * LD, *kb = ks + (32 * wn + li) * LD;
-            for (int st = 0; st < half; st++) {
-                const int k = chunked ? ((st >> 5) << 6) + (st & 31) + 32 * lh : st + half * lh;
-                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[k], kb[k], sacc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * lh, col = 32 * wn + li;
-                const bool live = t0 + col <= pos0 + q0 + row;  // causal: t <= pos of the query
-                ps[row * 65 + col] = live ? sacc[r] / div : -INFINITY;  // :372
-            }
-        }
-        __syncthreads();
-        {   // running softmax, 4 lanes per query row (:687-706 in running-max form)
-            const int row = tid >> 2, q4 = tid & 3;
-            float *pr = ps + row * 65;
-            float mx = -INFINITY;
-            for (int c = q4; c < 64; c += 4) mx = fmaxf(mx, pr[c]);
-            mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-            const float m_old = row_m[row];
-            const float m_new = fmaxf(m_old, mx);  // finite: key 0 is live for every query
-            float sum = 0.0f;
-            for (int c = q4; c < 64; c += 4) {
-                const float e = expf(pr[c] - m_new);
-                pr[c] = e;
-                sum += e;
-            }
-            sum += __shfl_xor(sum, 1, 64);
-            sum += __shfl_xor(sum, 2, 64);
-            if (q4 == 0) {
-                const float alpha = expf(m_old - m_new);
-                row_a[row] = alpha;
-                row_l[row] = row_l[row] * alpha + sum;
-                row_m[row] = m_new;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < TPW; j++) {  // O = O e^(m_old - m_new) + P V  (:381-388)
-            const int ti = wave + 4 * j, rt = ti & 1, ct = ti >> 1;
-            if (ct * 32 < hs) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[j][r] *= row_a[32 * rt + (r & 3) + 8 * (r >> 2) + 4 * lh];
-                const float *pa = ps + (32 * rt + li) * 65 + 32 * lh;
-                const float *vb = vs + (32 * lh) * LD + 32 * ct + li;  // columns >= hs: finite junk, dropped
-#pragma unroll 8
-                for (int st = 0; st < 32; st++)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[st], vb[st * LD], acc[j], 0, 0, 0);
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < TPW; j++) {
-        const int ti = wave + 4 * j, rt = ti & 1, ct = ti >> 1;
-        const int col = 32 * ct + li;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (col < hs && q0 + row < P)
-                out[(size_t)(q0 + row) * ldo + (size_t)h * hs + col] = acc[j][r] / row_l[row];  // :704
-        }
-    }
-}
-
 template <int EPI, int TM, int TN, int BK, int KS>
 hipError_t gemm_launch_t(const GemmArgs &a, hipStream_t st)
 {
@@ -1146,60 +547,11 @@ bool gemm_launch_small(const GemmArgs &a, hipStream_t st, hipError_t *err)
     return true;
 }
 
-template <int EPI, int TMS>
-hipError_t skinny_launch_t(const GemmArgs &a, hipStream_t st)
-{
-    const int form = tunables().pf_skinny_form;
-    dim3 grid((a.N + 15) / 16, (a.P + 16 * TMS - 1) / (16 * TMS));
-    // LDS-staged forms (1-KB row reads), up to two token tiles (at 64 tokens the stage would take 83 KB).
-    // Direct-to-LDS ring where K is whole 256-k stages and rows are 16-byte aligned;
-    // L2Z_PF_SKINNY_FORM=2 keeps the register-staged form (same sums, another order)
-    if (form == 1 && a.K % kSkBK == 0 && a.K / kSkBK >= 3 && a.ldx % 4 == 0 && TMS <= 2 && tunables().pf_dma != 0) {
-        constexpr int SW = TMS == 1 ? 4 : 3;
-        const size_t lds = (size_t)SW * (16 + 16 * TMS) * kSkLD2 * sizeof(float);
-        const void *fn = (const void *)prefill_skinny_dma<EPI, TMS, SW>;
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        GemmArgs args = a;
-        void *params[] = {&args};
-        return hipLaunchKernel(fn, grid, dim3(kPfBlock), params, lds, st);
-    }
-    if ((form == 1 || form == 2) && a.K >= kSkBK && TMS <= 2) {
-        const size_t stage = (size_t)(16 + 16 * TMS) * kSkLD * sizeof(float);
-        const size_t red = (size_t)4 * TMS * 4 * 64 * sizeof(float);
-        const size_t lds = stage > red ? stage : red;
-        static bool attr = false;
-        if (!attr && lds > 48 * 1024) {
-            (void)hipFuncSetAttribute((const void *)prefill_skinny_lds<EPI, TMS>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr = true;
-        }
-        hipLaunchKernelGGL((prefill_skinny_lds<EPI, TMS>), grid, dim3(kPfBlock), lds, st, a);
-    } else if (a.K % 64 == 0) {
-        hipLaunchKernelGGL((prefill_skinny<EPI, TMS, 8, 4, false>), grid, dim3(512), 0, st, a);
-    } else {
-        hipLaunchKernelGGL((prefill_skinny<EPI, TMS, 8, 4, true>), grid, dim3(512), 0, st, a);
-    }
-    return hipGetLastError();
-}
-
 template <int EPI>
 hipError_t gemm_launch(const GemmArgs &a, hipStream_t st)
 {
     const Tunables &tn = tunables();
     const int tile = tn.pf_tile;
-    const int skinny_max = tn.pf_skinny_max >= 0 ? tn.pf_skinny_max : 64;
-    const int skinny_tms = tn.pf_skinny_tms > 0 ? tn.pf_skinny_tms : 4;
-    if (a.P <= skinny_max) {
-        // a matrix that stays in the on-die caches is cheapest re-read per 16 tokens (more blocks,
-        // more waves per CU); one that streams from HBM is read once, tokens tiled in registers
-        // (the WHOLE matrix: a row shard must take the form the unsharded pass takes -- the forms sum in
-        // different orders)
-        const bool cached = (size_t)a.N * (size_t)a.n_scale * (size_t)a.K * sizeof(float) <= ((size_t)16 << 20);
-        if (a.P <= 16 || skinny_tms == 1 || cached) return skinny_launch_t<EPI, 1>(a, st);
-        if (a.P <= 32 || skinny_tms == 2) return skinny_launch_t<EPI, 2>(a, st);
-        return skinny_launch_t<EPI, 4>(a, st);  // more than 64 tokens: grid.y tiles of 64
-    }
     switch (tile) {  // L2Z_PF_TILE: experiments
     case 1: return gemm_launch_t<EPI, 1, 1, 64, 1>(a, st);
     case 2: return gemm_launch_t<EPI, 1, 1, 64, 2>(a, st);
@@ -1304,6 +656,8 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return hipErrorInvalidValue;
     if (res == nullptr) { res = out; ldres = ldo; }  // PG_RESID in place
     GemmArgs a = {x, nullptr, w, out, res, P, N, K, ldx, ldo, ldres, pos0, rope, head_size, n_scale > 0 ? n_scale : 1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
+    const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
+    if (P <= skinny_max) return launch_prefill_skinny(epi, a, st);  // prefill_skinny.hip
     switch (epi) {
         case G_STORE: return gemm_launch<G_STORE>(a, st);
         case G_RESID: return gemm_launch<G_RESID>(a, st);
@@ -1313,67 +667,6 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
         case G_SWIGLU: return gemm_launch<G_SWIGLU>(a, st);
     }
     return hipErrorInvalidValue;
-}
-
-hipError_t launch_prefill_rmsnorm(float *o, const float *x, const float *w, int n, int P,
-                                  hipStream_t st)
-{
-    hipLaunchKernelGGL(prefill_rmsnorm, dim3(P), dim3(kPfBlock), 0, st, o, x, w, n, P);
-    return hipGetLastError();
-}
-
-hipError_t launch_prefill_embed(float *x, const float *tok_emb, const int *tokens, int dim, int P,
-                                hipStream_t st)
-{
-    hipLaunchKernelGGL(prefill_embed, dim3(P), dim3(256), 0, st, x, tok_emb, tokens, dim);
-    return hipGetLastError();
-}
-
-hipError_t launch_prefill_attention(const float *q, int ldq, const float *kcache, const float *vcache,
-                                    float *out, int ldo, int pos0, int P, int n_heads, int head_size,
-                                    int kv_dim, int kv_mul, int seq_len, hipStream_t st, int n_heads_model)
-{
-    // the two kernels round differently; a shard must take the one the unsharded pass takes
-    if (n_heads_model <= 0) n_heads_model = n_heads;
-    const bool naive = tunables().pf_attn == 0;
-    const size_t lds_t = (size_t)(3 * 64 * (head_size + 1) + 64 * 65 + 3 * 64) * sizeof(float);
-    const int n_ct = (head_size + 31) / 32;  // O column tiles; 2 n_ct tiles over 4 waves
-    // one block per (head, 64 queries): worth it once that fills half the CUs (7B: from 256 tokens);
-    // below, and for models with few heads, the block-per-(head, query) kernel has more parallelism
-    const bool enough_blocks = n_heads_model * ((P + 63) / 64) >= 128;
-    if (!naive && enough_blocks && lds_t <= 160 * 1024 && n_ct <= 8 && (head_size % 4) == 0 && (kv_dim % 4) == 0) {
-        const int tpw = (2 * n_ct + 3) / 4;
-        const void *fn = tpw <= 1 ? (const void *)prefill_attention_tiled<1>
-                       : tpw == 2 ? (const void *)prefill_attention_tiled<2>
-                                  : (const void *)prefill_attention_tiled<4>;
-        if (lds_t > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
-            if (e != hipSuccess) return e;
-        }
-        const dim3 grid(n_heads, (P + 63) / 64);
-        if (tpw <= 1)
-            hipLaunchKernelGGL(prefill_attention_tiled<1>, grid, dim3(kPfBlock), lds_t, st, q, ldq, kcache, vcache,
-                               out, ldo, pos0, P, head_size, kv_dim, kv_mul, seq_len);
-        else if (tpw == 2)
-            hipLaunchKernelGGL(prefill_attention_tiled<2>, grid, dim3(kPfBlock), lds_t, st, q, ldq, kcache, vcache,
-                               out, ldo, pos0, P, head_size, kv_dim, kv_mul, seq_len);
-        else
-            hipLaunchKernelGGL(prefill_attention_tiled<4>, grid, dim3(kPfBlock), lds_t, st, q, ldq, kcache, vcache,
-                               out, ldo, pos0, P, head_size, kv_dim, kv_mul, seq_len);
-        return hipGetLastError();
-    }
-    int E = head_size >> 2, TPR = 1;
-    while (TPR < E && TPR < 64) TPR <<= 1;
-    const int G = kPfBlock / TPR;
-    const size_t lds = (size_t)(((seq_len + 3) & ~3) + G * head_size + 8) * sizeof(float);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(prefill_attention),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(prefill_attention, dim3(n_heads, P), dim3(kPfBlock), lds, st, q, ldq, kcache,
-                       vcache, out, ldo, pos0, head_size, kv_dim, kv_mul, seq_len);
-    return hipGetLastError();
 }
 
 }  // namespace l2z

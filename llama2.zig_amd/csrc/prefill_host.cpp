@@ -1,4 +1,4 @@
-// prefill_host.cpp -- host side of the batched prompt prefill (kernels: prefill.hip).
+// prefill_host.cpp -- host side of the batched prompt prefill (kernels: prefill_gemm.hip, prefill_skinny.hip, prefill_attention.hip).
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>

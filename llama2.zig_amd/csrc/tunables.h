@@ -30,7 +30,7 @@ struct Tunables {
     long long p2p_timeout_s = 20;  // L2Z_P2P_TIMEOUT_S
     int p2p_bulk_mb = -1;      // L2Z_P2P_BULK_MB     MB per bulk landing region of the peer-write arena (two of
                                //                     them; sharded prefill); default: longest vector x chunk tokens
-    // --- batched prefill (prefill_host.cpp, prefill.hip) ---
+    // --- batched prefill (prefill_host.cpp, prefill_*.hip) ---
     int prefill = 1;           // L2Z_PREFILL         0: prompts are stepped token by token
     int pf_chunk = 0;          // L2Z_PF_CHUNK        tokens per chunk (0: default)
     int pf_skinny_form = 1;    // L2Z_PF_SKINNY_FORM  short-prompt GEMM: 1 LDS-staged (direct-to-LDS ring where K % 256 == 0), 2 register-staged LDS form only, 0 no LDS
