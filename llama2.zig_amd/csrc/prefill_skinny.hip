@@ -219,7 +219,17 @@ __global__ __launch_bounds__(kPfBlock) void prefill_skinny_dma(const GemmArgs a)
     static_assert(SW >= 3 && SW <= 4, "ring depth");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * TMS;
+    // 1-D grid when there are several token tiles (a.nty > 0): the blocks that read the same 16 rows of W
+    // get ids 8 apart -- one XCD, the same moment -- so that W comes from HBM once (prefill_gemm.hip,
+    // block -> tile)
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (a.nty > 0) {
+        const int group = 8 * a.nty, g = bx / group, local = bx - g * group;
+        by = local >> 3;
+        bx = g * 8 + (local & 7);
+        if (bx >= a.ntx) return;
+    }
+    const int n0 = bx * 16, m0 = by * 16 * TMS;
     const v4f zero = {0.f, 0.f, 0.f, 0.f};
     // this wave's rows of every stage: W rows 4 wave .. 4 wave + 3, X rows likewise per token tile
     const float *wsrc[4], *xsrc[TMS][4];
@@ -230,10 +240,14 @@ __global__ __launch_bounds__(kPfBlock) void prefill_skinny_dma(const GemmArgs a)
 #pragma unroll
         for (int tm = 0; tm < TMS; tm++) xsrc[tm][i] = a.x + (size_t)min(m0 + 16 * tm + r, a.P - 1) * a.ldx + 4 * lane;
     }
+    const bool w_nt = a.nty <= 1;  // a W row read by ONE block: stream it past the caches
     auto issue = [&](int st, int buf) {
         float *ws = smem + buf * ST, *xs = ws + WST;
 #pragma unroll
-        for (int i = 0; i < 4; i++) lds_dma16_nt(wsrc[i] + (size_t)st * kSkBK, ws + (4 * wave + i) * kSkLD2);
+        for (int i = 0; i < 4; i++) {
+            if (w_nt) lds_dma16_nt(wsrc[i] + (size_t)st * kSkBK, ws + (4 * wave + i) * kSkLD2);
+            else lds_dma16(wsrc[i] + (size_t)st * kSkBK, ws + (4 * wave + i) * kSkLD2);
+        }
 #pragma unroll
         for (int tm = 0; tm < TMS; tm++)
 #pragma unroll
@@ -316,8 +330,14 @@ hipError_t skinny_launch_t(const GemmArgs &a, hipStream_t st)
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         GemmArgs args = a;
+        dim3 g1 = grid;
+        args.ntx = 0; args.nty = 0;
+        if (grid.y > 1) {
+            args.ntx = (int)grid.x; args.nty = (int)grid.y;
+            g1 = dim3((grid.x + 7) / 8 * 8 * grid.y);
+        }
         void *params[] = {&args};
-        return hipLaunchKernel(fn, grid, dim3(kPfBlock), params, lds, st);
+        return hipLaunchKernel(fn, g1, dim3(kPfBlock), params, lds, st);
     }
     if ((form == 1 || form == 2) && a.K >= kSkBK && TMS <= 2) {
         const size_t stage = (size_t)(16 + 16 * TMS) * kSkLD * sizeof(float);
@@ -341,15 +361,17 @@ hipError_t skinny_launch_t(const GemmArgs &a, hipStream_t st)
 template <int EPI>
 hipError_t skinny_launch(const GemmArgs &a, hipStream_t st)
 {
-    const int skinny_tms = tunables().pf_skinny_tms > 0 ? tunables().pf_skinny_tms : 4;
-    // a matrix that stays in the on-die caches is cheapest re-read per 16 tokens (more blocks,
-    // more waves per CU); one that streams from HBM is read once, tokens tiled in registers
-    // (the WHOLE matrix: a row shard must take the form the unsharded pass takes -- the forms sum in
-    // different orders)
+    // Token tiles per block (TMS x 16 tokens).  A matrix that stays in the on-die caches is cheapest
+    // re-read per 16 tokens (more blocks, more waves per CU) -- the WHOLE matrix counts: a row shard takes
+    // what the unsharded pass takes.  One that streams from HBM: one or two token tiles per block, and
+    // from 33 tokens several blocks per 16 rows of W, paired on one XCD by the 1-D grid (64 tokens: 17.4 ms
+    // with four token tiles in registers, L2Z_PF_SKINNY_TMS=4, -> 15.8; 40 tokens 15.4 -> 14.0).  The one-
+    // and two-tile forms sum in the same order.
+    const int forced = tunables().pf_skinny_tms;
+    if (forced == 4) return skinny_launch_t<EPI, 4>(a, st);
     const bool cached = (size_t)a.N * (size_t)a.n_scale * (size_t)a.K * sizeof(float) <= ((size_t)16 << 20);
-    if (a.P <= 16 || skinny_tms == 1 || cached) return skinny_launch_t<EPI, 1>(a, st);
-    if (a.P <= 32 || skinny_tms == 2) return skinny_launch_t<EPI, 2>(a, st);
-    return skinny_launch_t<EPI, 4>(a, st);  // more than 64 tokens: grid.y tiles of 64
+    const bool one = forced == 1 || (forced != 2 && (a.P <= 16 || cached || (a.P > 32 && a.P <= 48)));
+    return one ? skinny_launch_t<EPI, 1>(a, st) : skinny_launch_t<EPI, 2>(a, st);
 }
 
 }  // namespace
