@@ -199,7 +199,11 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
                                    float *q_out, int ldq, float *kcache, float *vcache, int ldkv, int P, int nq,
                                    int nkv, int K, int pos0, const float2 *rope, int head_size, hipStream_t st);
 hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float *w1, const float *w3,
-                                           float *out, int ldo, int P, int N, int K, hipStream_t st);
+                                           float *out, int ldo, int P, int N, int K, hipStream_t st,
+                                           int n_scale = 1);
+hipError_t launch_prefill_gemm_kv_pair(const float *x, int ldx, const float *wk, const float *wv, float *kcache,
+                                       float *vcache, int ldkv, int P, int nkv, int K, int pos0, const float2 *rope,
+                                       int head_size, hipStream_t st, int n_scale = 1);
 hipError_t launch_prefill_rmsnorm(float *o, const float *x, const float *w, int n, int P,
                                   hipStream_t st);
 hipError_t launch_prefill_embed(float *x, const float *tok_emb, const int *tokens, int dim, int P,

@@ -96,10 +96,16 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
         if (qe == hipErrorNotSupported) {
             L2Z_HIP(launch_prefill_gemm(PG_ROPE, s->pf_xn, dim, wq, s->pf_q, sh.dim_loc, P, sh.dim_loc, dim, pos0,
                                         s->rope, hs, st, nullptr, 0, sh.world));  // :308-351
-            L2Z_HIP(launch_prefill_gemm(PG_ROPE_CACHE, s->pf_xn, dim, wk, kc, kvd, P, kvd, dim, pos0, s->rope, hs, st,
-                                        nullptr, 0, sh.world));                   // :354-357
-            L2Z_HIP(launch_prefill_gemm(PG_CACHE, s->pf_xn, dim, wv, vc, kvd, P, kvd, dim, pos0, s->rope, hs, st,
-                                        nullptr, 0, sh.world));                   // :358
+            const hipError_t ke = launch_prefill_gemm_kv_pair(s->pf_xn, dim, wk, wv, kc, vc, kvd, P, kvd, dim, pos0,
+                                                              s->rope, hs, st, sh.world);  // short prompts: k | v together
+            if (ke == hipErrorNotSupported) {
+                L2Z_HIP(launch_prefill_gemm(PG_ROPE_CACHE, s->pf_xn, dim, wk, kc, kvd, P, kvd, dim, pos0, s->rope, hs,
+                                            st, nullptr, 0, sh.world));               // :354-357
+                L2Z_HIP(launch_prefill_gemm(PG_CACHE, s->pf_xn, dim, wv, vc, kvd, P, kvd, dim, pos0, s->rope, hs, st,
+                                            nullptr, 0, sh.world));                   // :358
+            } else {
+                L2Z_HIP(ke);
+            }
         } else {
             L2Z_HIP(qe);
         }
@@ -114,7 +120,7 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
         // :405-416: W1 and W3 in one launch with silu(a) * b as its epilogue where the tile kernel
         // takes the shape, else two GEMMs, the second one merging into the first one's output
         const float *w1 = w->w1 + (size_t)l * sh.hid_loc * dim, *w3 = w->w3 + (size_t)l * sh.hid_loc * dim;
-        const hipError_t pe = launch_prefill_gemm_swiglu_pair(s->pf_xn, dim, w1, w3, out, ldo, P, sh.hid_loc, dim, st);
+        const hipError_t pe = launch_prefill_gemm_swiglu_pair(s->pf_xn, dim, w1, w3, out, ldo, P, sh.hid_loc, dim, st, sh.world);
         if (pe == hipErrorNotSupported) {
             L2Z_HIP(launch_prefill_gemm(PG_STORE, s->pf_xn, dim, w1, out, ldo, P, sh.hid_loc, dim, pos0, s->rope,
                                         hs, st, nullptr, 0, sh.world));                      // :405

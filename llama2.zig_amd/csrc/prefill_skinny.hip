@@ -210,13 +210,17 @@ __global__ __launch_bounds__(kPfBlock) void prefill_skinny_lds(const GemmArgs a)
 // register-staged form (same sums, another order).
 constexpr int kSkLD2 = kSkBK + 8;
 
-template <int EPI, int TMS, int SW>
+// NW = 2: TWO weight matrices share the X stage -- w1 | w3 with silu(a) * b as the epilogue (EPI =
+// G_SWIGLU, main.zig:405-416) or wk | wv into the two caches (EPI = G_QKV, :354-358): X is a third of
+// the bytes brought into the CU instead of half, one launch instead of two.
+template <int EPI, int TMS, int SW, int NW = 1>
 __global__ __launch_bounds__(kPfBlock) void prefill_skinny_dma(const GemmArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int WST = 16 * kSkLD2, XST = 16 * TMS * kSkLD2, ST = WST + XST;  // floats per stage: W rows, then X rows
-    constexpr int LPS = 4 + 4 * TMS;  // this wave's loads per stage
+    constexpr int WST = 16 * kSkLD2, XST = 16 * TMS * kSkLD2, ST = NW * WST + XST;  // floats per stage: W rows, then X rows
+    constexpr int LPS = 4 * NW + 4 * TMS;  // this wave's loads per stage
     static_assert(SW >= 3 && SW <= 4, "ring depth");
+    static_assert(NW == 1 || (NW == 2 && (EPI == G_SWIGLU || EPI == G_QKV)), "paired forms");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
     // 1-D grid when there are several token tiles (a.nty > 0): the blocks that read the same 16 rows of W
@@ -231,31 +235,36 @@ __global__ __launch_bounds__(kPfBlock) void prefill_skinny_dma(const GemmArgs a)
     }
     const int n0 = bx * 16, m0 = by * 16 * TMS;
     const v4f zero = {0.f, 0.f, 0.f, 0.f};
-    // this wave's rows of every stage: W rows 4 wave .. 4 wave + 3, X rows likewise per token tile
-    const float *wsrc[4], *xsrc[TMS][4];
+    // this wave's rows of every stage: W rows 4 wave .. 4 wave + 3 (of each matrix), X rows likewise per token tile
+    const float *wsrc[NW][4], *xsrc[TMS][4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int r = 4 * wave + i;
-        wsrc[i] = a.w + (size_t)min(n0 + r, a.N - 1) * a.K + 4 * lane;
+        wsrc[0][i] = a.w + (size_t)min(n0 + r, a.N - 1) * a.K + 4 * lane;
+        if (NW == 2) wsrc[NW - 1][i] = a.w2 + (size_t)min(n0 + r, a.N - 1) * a.K + 4 * lane;
 #pragma unroll
         for (int tm = 0; tm < TMS; tm++) xsrc[tm][i] = a.x + (size_t)min(m0 + 16 * tm + r, a.P - 1) * a.ldx + 4 * lane;
     }
     const bool w_nt = a.nty <= 1;  // a W row read by ONE block: stream it past the caches
     auto issue = [&](int st, int buf) {
-        float *ws = smem + buf * ST, *xs = ws + WST;
+        float *ws = smem + buf * ST, *xs = ws + NW * WST;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            if (w_nt) lds_dma16_nt(wsrc[i] + (size_t)st * kSkBK, ws + (4 * wave + i) * kSkLD2);
-            else lds_dma16(wsrc[i] + (size_t)st * kSkBK, ws + (4 * wave + i) * kSkLD2);
-        }
+        for (int m = 0; m < NW; m++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (w_nt) lds_dma16_nt(wsrc[m][i] + (size_t)st * kSkBK, ws + m * WST + (4 * wave + i) * kSkLD2);
+                else lds_dma16(wsrc[m][i] + (size_t)st * kSkBK, ws + m * WST + (4 * wave + i) * kSkLD2);
+            }
 #pragma unroll
         for (int tm = 0; tm < TMS; tm++)
 #pragma unroll
             for (int i = 0; i < 4; i++) lds_dma16(xsrc[tm][i] + (size_t)st * kSkBK, xs + (16 * tm + 4 * wave + i) * kSkLD2);
     };
-    v4f acc[TMS];
+    v4f acc[NW][TMS];
 #pragma unroll
-    for (int tm = 0; tm < TMS; tm++) acc[tm] = zero;
+    for (int m = 0; m < NW; m++)
+#pragma unroll
+        for (int tm = 0; tm < TMS; tm++) acc[m][tm] = zero;
     const int nst = a.K / kSkBK;  // launcher: nst >= SW - 1
 #pragma unroll
     for (int p = 0; p < SW - 1; p++) issue(p, p);
@@ -269,37 +278,47 @@ __global__ __launch_bounds__(kPfBlock) void prefill_skinny_dma(const GemmArgs a)
         __builtin_amdgcn_s_barrier();  // every wave's part of stage st is in LDS; stage st - 1 has been multiplied
         if (st + SW - 1 < nst) issue(st + SW - 1, nbuf);  // into the buffer stage st - 1 has just left
         const float *wr = smem + buf * ST + j * kSkLD2 + 64 * wave + 4 * q;
-        const float *xr = wr + WST;
+        const float *xr = wr + NW * WST;
 #pragma unroll
         for (int u = 0; u < 4; u++) {  // this wave's quarter of the stage
-            const v4f b = *(const v4f *)(wr + 16 * u);
-            v4f xa[TMS];
+            v4f b[NW], xa[TMS];
+#pragma unroll
+            for (int m = 0; m < NW; m++) b[m] = *(const v4f *)(wr + m * WST + 16 * u);
 #pragma unroll
             for (int tm = 0; tm < TMS; tm++) xa[tm] = *(const v4f *)(xr + 16 * tm * kSkLD2 + 16 * u);
 #pragma unroll
-            for (int c = 0; c < 4; c++)
+            for (int m = 0; m < NW; m++)
 #pragma unroll
-                for (int tm = 0; tm < TMS; tm++)
-                    acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[tm][c], b[c], acc[tm], 0, 0, 0);
+                for (int c = 0; c < 4; c++)
+#pragma unroll
+                    for (int tm = 0; tm < TMS; tm++)
+                        acc[m][tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[tm][c], b[m][c], acc[m][tm], 0, 0, 0);
         }
         buf = buf + 1 == SW ? 0 : buf + 1;
         nbuf = nbuf + 1 == SW ? 0 : nbuf + 1;
     }
     __syncthreads();
-    float *red = smem;  // [4 waves][TMS][4][64]
+    float *red = smem;  // [4 waves][NW][TMS][4][64]
 #pragma unroll
-    for (int tm = 0; tm < TMS; tm++)
+    for (int m = 0; m < NW; m++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) red[((wave * TMS + tm) * 4 + r) * 64 + lane] = acc[tm][r];
+        for (int tm = 0; tm < TMS; tm++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) red[(((wave * NW + m) * TMS + tm) * 4 + r) * 64 + lane] = acc[m][tm][r];
     __syncthreads();
     for (int idx = tid; idx < TMS * 256; idx += kPfBlock) {
         const int tm = idx >> 8, r = (idx >> 6) & 3, l = idx & 63;
-        float v = red[((0 * TMS + tm) * 4 + r) * 64 + l];
+        float v = red[(((0 * NW + 0) * TMS + tm) * 4 + r) * 64 + l], v2 = 0.0f;
 #pragma unroll
-        for (int w = 1; w < 4; w++) v += red[((w * TMS + tm) * 4 + r) * 64 + l];
+        for (int w = 1; w < 4; w++) v += red[(((w * NW + 0) * TMS + tm) * 4 + r) * 64 + l];
+        if (NW == 2) {
+            v2 = red[(((0 * NW + NW - 1) * TMS + tm) * 4 + r) * 64 + l];
+#pragma unroll
+            for (int w = 1; w < 4; w++) v2 += red[(((w * NW + NW - 1) * TMS + tm) * 4 + r) * 64 + l];
+        }
         const int tok = m0 + 16 * tm + 4 * (l >> 4) + r;
         const int f = n0 + (l & 15);
-        if (EPI == G_ROPE || EPI == G_ROPE_CACHE) {
+        if (EPI == G_ROPE || EPI == G_ROPE_CACHE || EPI == G_QKV) {
             const float partner = __shfl_xor(v, 1, 64);  // feature f ^ 1, same token (main.zig:346-349)
             const int hs = a.head_size;
             const int pos = a.pos0 + (tok < a.P ? tok : 0);
@@ -307,7 +326,12 @@ __global__ __launch_bounds__(kPfBlock) void prefill_skinny_dma(const GemmArgs a)
             v = (f & 1) ? partner * cs.y + v * cs.x : v * cs.x - partner * cs.y;
         }
         if (tok < a.P && f < a.N) {
-            if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + f] = v;
+            if (NW == 2 && EPI == G_SWIGLU) a.out[(size_t)tok * a.ldo + f] = swiglu_merge(v, v2);  // :411-416
+            else if (NW == 2) {  // wk | wv: key-cache row (RoPE above), value-cache row
+                a.outk[(size_t)(a.pos0 + tok) * a.ldkv + f] = v;
+                a.outv[(size_t)(a.pos0 + tok) * a.ldkv + f] = v2;
+            }
+            else if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + f] = v;
             else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + f] = a.res[(size_t)tok * a.ldres + f] + v;
             else if (EPI == G_SWIGLU) a.out[(size_t)tok * a.ldo + f] = swiglu_merge(a.out[(size_t)tok * a.ldo + f], v);
             else a.out[(size_t)(a.pos0 + tok) * a.ldo + f] = v;
@@ -358,6 +382,14 @@ hipError_t skinny_launch_t(const GemmArgs &a, hipStream_t st)
     return hipGetLastError();
 }
 
+// one token tile per block?  (see skinny_launch)
+bool skinny_one_tile(const GemmArgs &a)
+{
+    const int forced = tunables().pf_skinny_tms;
+    const bool cached = (size_t)a.N * (size_t)a.n_scale * (size_t)a.K * sizeof(float) <= ((size_t)16 << 20);
+    return forced == 1 || (forced != 2 && forced != 4 && (a.P <= 16 || cached || (a.P > 32 && a.P <= 48)));
+}
+
 template <int EPI>
 hipError_t skinny_launch(const GemmArgs &a, hipStream_t st)
 {
@@ -369,12 +401,36 @@ hipError_t skinny_launch(const GemmArgs &a, hipStream_t st)
     // and two-tile forms sum in the same order.
     const int forced = tunables().pf_skinny_tms;
     if (forced == 4) return skinny_launch_t<EPI, 4>(a, st);
-    const bool cached = (size_t)a.N * (size_t)a.n_scale * (size_t)a.K * sizeof(float) <= ((size_t)16 << 20);
-    const bool one = forced == 1 || (forced != 2 && (a.P <= 16 || cached || (a.P > 32 && a.P <= 48)));
+    const bool one = skinny_one_tile(a);
     return one ? skinny_launch_t<EPI, 1>(a, st) : skinny_launch_t<EPI, 2>(a, st);
 }
 
 }  // namespace
+
+// a.w | a.w2 in one launch of the direct-to-LDS form (epi G_SWIGLU: out = silu(X w^T) * (X w2^T);
+// G_QKV: RoPE(X w^T) into a.outk's rows pos0 + token, X w2^T into a.outv's).  hipErrorNotSupported when
+// the shape takes another short-prompt form: the caller launches the two products separately.
+hipError_t launch_prefill_skinny_pair(int epi, const GemmArgs &a, hipStream_t st)
+{
+    if (tunables().pf_fuse == 0 || tunables().pf_skinny_form != 1 || tunables().pf_dma == 0) return hipErrorNotSupported;
+    if (a.K % kSkBK != 0 || a.K / kSkBK >= 3 == false || a.ldx % 4 != 0 || !skinny_one_tile(a)) return hipErrorNotSupported;
+    constexpr int SW = 3;
+    const size_t lds = (size_t)SW * (32 + 16) * kSkLD2 * sizeof(float);
+    const void *fn = epi == G_SWIGLU ? (const void *)prefill_skinny_dma<G_SWIGLU, 1, SW, 2>
+                   : epi == G_QKV    ? (const void *)prefill_skinny_dma<G_QKV, 1, SW, 2> : nullptr;
+    if (fn == nullptr) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    GemmArgs args = a;
+    dim3 grid((a.N + 15) / 16, (a.P + 15) / 16), g1 = grid;
+    args.ntx = 0; args.nty = 0;
+    if (grid.y > 1) {
+        args.ntx = (int)grid.x; args.nty = (int)grid.y;
+        g1 = dim3((grid.x + 7) / 8 * 8 * grid.y);
+    }
+    void *params[] = {&args};
+    return hipLaunchKernel(fn, g1, dim3(kPfBlock), params, lds, st);
+}
 
 hipError_t launch_prefill_skinny(int epi, const GemmArgs &a, hipStream_t st)
 {
