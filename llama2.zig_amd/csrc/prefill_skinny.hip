@@ -204,8 +204,10 @@ __global__ __launch_bounds__(kPfBlock) void prefill_skinny_lds(const GemmArgs a)
 // Measured on top of this and not kept: X loaded straight into a register ring (inline-asm loads the
 // compiler does not wait for) so that two 67-KB blocks fit a CU: +3 %; 8 waves per block: +3 %; each
 // block starting at another stage of K (in case the 4096 row streams camp on a few channels): +9 %.
-// Neither depth, nor waves per CU, nor the LDS read width moves it further; W1 / W3 (688 blocks, one
-// resident per CU: 2.7 rounds) stay at 4.1 TB/s.
+// Neither depth, nor waves per CU, nor the LDS read width moves it further.  What does: fewer X bytes per
+// W byte (the paired form below: 4.4 -> 5.2 TB/s of W) -- every CU takes in ~13-15 bytes per cycle of
+// W + X together, on all 256 CUs (32 rows of one matrix per block on 128 CUs: 15.6 -> 21.8 us; skipping
+// the X rows past a 4-token prompt, duplicates that hit the L1: no change).
 // Needs K % 256 == 0 (whole stages: the 7B and 110M shapes); otherwise the launcher keeps the
 // register-staged form (same sums, another order).
 constexpr int kSkLD2 = kSkBK + 8;
