@@ -139,6 +139,178 @@ __global__ __launch_bounds__(kPfBlock) void prefill_attention(const float *q, in
 // decode path's split attention).  LDS: Q, K, V tiles 64 x (hs+1), P tile 64 x 65.
 //   S: wave (wm, wn) owns S[32 wm.., 32 wn..];  O: 32 x 32 tiles (row half, column tile) dealt to
 //   the waves round-robin, TPW per wave.
+// Causal attention of a chunk, one block per (head, 64 queries), flash form (round 2): each of the four
+// waves owns 16 queries for the whole kernel -- their running max / sum and the O accumulators never
+// leave its registers, and no block-wide step exists except bringing in the next 64 key / value rows.
+// Everything is computed TRANSPOSED on MFMA 16x16x4 f32 (D[i][j] += A[i][k] B[k][j]; A: lane l holds
+// A[l & 15][l >> 4], B: lane l holds B[l >> 4][l & 15], D: lane l, register r holds D[4 (l >> 4) + r][l & 15]):
+//   S^T[kv][q]  = sum_h K[kv][h] Q[q][h]        A = K rows (LDS), B = Q (registers, loaded once)
+//   O^T[d][q]  += sum_kv V[kv][d] P^T[kv][q]    A = V (LDS),      B = P^T
+// In the D layout a lane holds S^T for ONE query (q = l & 15) and four key rows (4 (l >> 4) + r) per tile;
+// exactly the values P^T's B operand wants from that lane if the k index of the PV product runs over
+// kv' = 4 k + s instead of 4 s + k -- a sum over kv has no order in exact arithmetic and V's operand uses
+// the same kv' -- so P goes from the S accumulators into the PV product without leaving the registers:
+// no transpose, no LDS round trip, no barrier.  A query's softmax statistics: the lane's 16 values, then
+// two shuffles across the four lane groups.  The per-query rescale of O^T is a per-lane scalar.
+// K and V tiles come in by direct-to-LDS loads.  Operands are read as ds_read_b128, one float4 feeding
+// four MFMAs: K's float4 (4 consecutive h) with Q's float4 of the same h -- k-set {16 T + 4 g + c};
+// V's float4 (4 consecutive d) feeds four output tiles, so O^T tile (DT, c) row i is d = 64 DT + 4 i + c.
+// K rows are read 16 rows x one slot at a time: physical slot = logical ^ (row & 15), applied on the
+// source address of the load; V rows are read a row at a time (16 consecutive slots): no swizzle.
+// head_size = 16 NDT, NDT in {4, 8}; two buffers of 64 KB at head_size 128: the next tile travels while
+// this one is multiplied, one barrier per tile.
+// Scores are x / sqrt(head_size) as in main.zig:372; masked scores are -inf: exp gives exactly 0.
+template <int NDT, int KH>
+__global__ __launch_bounds__(256 * KH) void prefill_attention_flash(const float *q, int ldq, const float *kcache,
+                                                                    const float *vcache, float *out, int ldo,
+                                                                    int pos0, int P, int kv_dim, int kv_mul,
+                                                                    int seq_len)
+{
+    constexpr int HS = 16 * NDT, E = HS / 4;  // float4 slots per row
+    constexpr int NWV = 4 * KH;               // waves: 4 query groups x KH parts of every key tile
+    constexpr int JT = 4 / KH;                // 16-row key sub-tiles per wave and tile
+    constexpr int LPW = 4 * NDT / NWV;        // wave-wide loads per wave, tile and matrix (64 E slots / 64 / NWV)
+    static_assert((NDT == 4 || NDT == 8) && (KH == 1 || KH == 2), "head_size 64 or 128; one or two key parts");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // blocks are dispatched in id order: the query tiles with the most key tiles (the LAST queries) first
+    const int h = blockIdx.x, q0 = ((int)gridDim.y - 1 - (int)blockIdx.y) * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qg = wave & 3, kh = wave >> 2;  // query group (16 queries), key part (rows 64 / KH * kh .. of a tile)
+    const int qi = lane & 15, g = lane >> 4;
+    const int kvh = h / kv_mul;  // :369
+    const float *kbase = kcache + (size_t)kvh * HS, *vbase = vcache + (size_t)kvh * HS;
+    const int myq = q0 + 16 * qg + qi;              // this lane's query (token index in the chunk)
+    const int qrow = myq < P ? myq : P - 1;         // past the chunk: a valid row, results dropped
+    v4f qreg[NDT];
+#pragma unroll
+    for (int T = 0; T < NDT; T++) qreg[T] = *(const v4f *)(q + (size_t)qrow * ldq + (size_t)h * HS + 16 * T + 4 * g);
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+    v4f ot[NDT];
+#pragma unroll
+    for (int d = 0; d < NDT; d++) ot[d] = zero;
+    float m = -INFINITY, lsum = 0.0f;
+    const int last_q = (q0 + 63 < P ? q0 + 63 : P - 1);
+    const int n_kt = (pos0 + last_q) / 64 + 1;              // key tiles of the block
+    const int last_live = pos0 + q0 + 16 * qg + 15;         // last key position live for one of this wave's queries
+    const float div = sqrtf((float)HS);
+    // two K / V buffers: tile kt + 1 travels while tile kt is multiplied; one barrier per tile
+    auto issue = [&](int kt, int buf) {
+        const int t0 = kt * 64;
+        float *kd = lds + buf * (2 * 64 * HS), *vd = kd + 64 * HS;
+#pragma unroll
+        for (int i = 0; i < LPW; i++) {  // 64 E float4 slots per matrix, 64 per wave-wide load
+            const int f = (wave * LPW + i) * 64 + lane, row = f / E, cp = f % E;
+            int t = t0 + row;
+            t = t < seq_len ? t : seq_len - 1;  // rows past the context are masked below
+            lds_dma16(kbase + (size_t)t * kv_dim + 4 * (cp ^ (row & 15)), kd + (wave * LPW + i) * 256);
+            lds_dma16(vbase + (size_t)t * kv_dim + 4 * cp, vd + (wave * LPW + i) * 256);
+        }
+    };
+    issue(0, 0);
+    for (int kt = 0; kt < n_kt; kt++) {
+        const int t0 = kt * 64;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of tile kt has landed
+        __syncthreads();  // everyone's has; and every wave is done with tile kt - 1: its buffer is free
+        if (kt + 1 < n_kt) issue(kt + 1, (kt + 1) & 1);
+        const float *ks = lds + (kt & 1) * (2 * 64 * HS), *vs = ks + 64 * HS;
+        const int r0 = (64 / KH) * kh;                 // this wave's rows of the tile: r0 .. r0 + 16 JT - 1
+        if (t0 + r0 > last_live) continue;             // nothing live for this wave (wave-uniform)
+        v4f st[JT];
+#pragma unroll
+        for (int jt = 0; jt < JT; jt++) st[jt] = zero;
+#pragma unroll
+        for (int T = 0; T < NDT; T++)  // the JT accumulators interleaved: independent MFMA chains
+#pragma unroll
+            for (int jt = 0; jt < JT; jt++) {
+                const int row = r0 + 16 * jt + qi;
+                const v4f kq = ((const v4f *)(ks + row * HS))[(4 * T + g) ^ (row & 15)];
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    st[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kq[c], qreg[T][c], st[jt], 0, 0, 0);
+            }
+        // st[jt][r] = S^T[key t0 + r0 + 16 jt + 4 g + r][query myq]: scale, causal mask, running softmax
+        float mx = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < JT; jt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const bool live = t0 + r0 + 16 * jt + 4 * g + r <= pos0 + myq;  // t <= pos of the query
+                st[jt][r] = live ? st[jt][r] / div : -INFINITY;                 // :372
+                mx = fmaxf(mx, st[jt][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx);
+        // a query none of whose keys this wave has seen live yet (KH = 2: the upper key part of the first
+        // tiles): every weight is e^(-inf) = 0 against any finite reference
+        const float mref = m_new == -INFINITY ? 0.0f : m_new;
+        float sum = 0.0f;
+#pragma unroll
+        for (int jt = 0; jt < JT; jt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                st[jt][r] = expf(st[jt][r] - mref);
+                sum += st[jt][r];
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float alpha = expf(m - mref);  // first live tile: e^(-inf) = 0
+        lsum = lsum * alpha + sum;
+        m = m_new;
+#pragma unroll
+        for (int d = 0; d < NDT; d++) ot[d] *= alpha;
+        // O^T += V^T P^T, k index of step (jt, s) = key rows r0 + 16 jt + 4 k + s (:381-388)
+#pragma unroll
+        for (int DT = 0; DT < NDT / 4; DT++)
+#pragma unroll
+            for (int jt = 0; jt < JT; jt++)
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) {
+                    const v4f vq = *(const v4f *)(vs + (r0 + 16 * jt + 4 * g + s4) * HS + 4 * (16 * DT + qi));
+#pragma unroll
+                    for (int c = 0; c < 4; c++)
+                        ot[4 * DT + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(vq[c], st[jt][s4], ot[4 * DT + c], 0, 0, 0);
+                }
+    }
+    if (KH == 2) {
+        // the two key parts of a query group: merge (m, l, O) of the upper part into the lower one
+        // (main.zig:687-706 is one softmax over all keys: rescale both parts to the common maximum)
+        __syncthreads();  // K / V buffers are free
+        float *mg = lds + (size_t)(qg * 64 + lane) * (4 * NDT + 2);
+        if (kh == 1) {
+#pragma unroll
+            for (int d = 0; d < NDT; d++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) mg[4 * d + r] = ot[d][r];
+            mg[4 * NDT] = m;
+            mg[4 * NDT + 1] = lsum;
+        }
+        __syncthreads();
+        if (kh == 1) return;
+        const float m1 = mg[4 * NDT], l1 = mg[4 * NDT + 1];
+        const float mm = fmaxf(m, m1);  // finite: the lower part holds key 0
+        const float a0 = expf(m - mm), a1 = expf(m1 - mm);
+        lsum = lsum * a0 + l1 * a1;
+#pragma unroll
+        for (int d = 0; d < NDT; d++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) ot[d][r] = ot[d][r] * a0 + mg[4 * d + r] * a1;
+    }
+    // ot[4 DT + c][r] = O^T[d = 64 DT + 16 g + 4 r + c][query myq]: 16 consecutive d per (lane, DT)
+    if (myq < P) {
+        float *o = out + (size_t)myq * ldo + (size_t)h * HS;
+#pragma unroll
+        for (int DT = 0; DT < NDT / 4; DT++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                v4f v;
+#pragma unroll
+                for (int c = 0; c < 4; c++) v[c] = ot[4 * DT + c][r] / lsum;  // :704
+                *(v4f *)(o + 64 * DT + 16 * g + 4 * r) = v;
+            }
+    }
+}
+
 template <int TPW>
 __global__ __launch_bounds__(kPfBlock) void prefill_attention_tiled(const float *q, int ldq,
                                                                     const float *kcache, const float *vcache,
@@ -149,7 +321,9 @@ __global__ __launch_bounds__(kPfBlock) void prefill_attention_tiled(const float 
     const int LD = hs + 1;
     float *qs = lds, *ks = qs + 64 * LD, *vs = ks + 64 * LD, *ps = vs + 64 * LD;
     float *row_m = ps + 64 * 65, *row_l = row_m + 64, *row_a = row_l + 64;
-    const int h = blockIdx.x, q0 = blockIdx.y * 64;
+    // blocks are dispatched in id order: the query tiles with the most key tiles (the LAST queries: causal)
+    // go first, so that a grid of several waves does not end on its heaviest blocks
+    const int h = blockIdx.x, q0 = ((int)gridDim.y - 1 - (int)blockIdx.y) * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
     const int kvh = h / kv_mul;  // :369
@@ -286,6 +460,23 @@ hipError_t launch_prefill_attention(const float *q, int ldq, const float *kcache
     // one block per (head, 64 queries): worth it once that fills half the CUs (7B: from 256 tokens);
     // below, and for models with few heads, the block-per-(head, query) kernel has more parallelism
     const bool enough_blocks = n_heads_model * ((P + 63) / 64) >= 128;
+    if (!naive && enough_blocks && tunables().pf_attn != 2 && (head_size == 64 || head_size == 128) && (kv_dim % 4) == 0 &&
+        (ldq % 4) == 0 && (ldo % 4) == 0 && (((uintptr_t)q | (uintptr_t)out | (uintptr_t)kcache | (uintptr_t)vcache) & 15) == 0) {
+        // flash form (L2Z_PF_ATTN=2 keeps the LDS-softmax tiled kernel below)
+        const size_t lds_f = (size_t)2 * 2 * 64 * head_size * sizeof(float);  // two buffers of a K and a V tile
+        // two key parts per tile (8 waves: two per SIMD cover each other's latencies); L2Z_PF_ATTN=3: one
+        const bool two = tunables().pf_attn != 3;
+        const void *fn = head_size == 128 ? (two ? (const void *)prefill_attention_flash<8, 2> : (const void *)prefill_attention_flash<8, 1>)
+                                          : (two ? (const void *)prefill_attention_flash<4, 2> : (const void *)prefill_attention_flash<4, 1>);
+        if (lds_f > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
+            if (e != hipSuccess) return e;
+        }
+        const dim3 grid(n_heads, (P + 63) / 64);
+        void *params[] = {(void *)&q, (void *)&ldq, (void *)&kcache, (void *)&vcache, (void *)&out, (void *)&ldo,
+                          (void *)&pos0, (void *)&P, (void *)&kv_dim, (void *)&kv_mul, (void *)&seq_len};
+        return hipLaunchKernel(fn, grid, dim3(two ? 512 : 256), params, lds_f, st);
+    }
     if (!naive && enough_blocks && lds_t <= 160 * 1024 && n_ct <= 8 && (head_size % 4) == 0 && (kv_dim % 4) == 0) {
         const int tpw = (2 * n_ct + 3) / 4;
         const void *fn = tpw <= 1 ? (const void *)prefill_attention_tiled<1>

@@ -37,7 +37,7 @@ struct Tunables {
     int pf_tile = 0;           // L2Z_PF_TILE
     int pf_skinny_max = -1;    // L2Z_PF_SKINNY_MAX
     int pf_skinny_tms = 0;     // L2Z_PF_SKINNY_TMS
-    int pf_attn = 1;           // L2Z_PF_ATTN         0: per-query prefill attention only
+    int pf_attn = 1;           // L2Z_PF_ATTN         0: per-query prefill attention only; 2: the LDS-softmax tiled kernel instead of the flash form; 3: flash form with one key part (4 waves)
     int pf_dma = 1;            // L2Z_PF_DMA          0: GEMM operands staged through registers instead of direct-to-LDS loads
     int pf_order = 1;          // L2Z_PF_ORDER        0: 2-D grids for the tile GEMM (x = feature tile, y = token tile)
     int pf_fuse = 1;           // L2Z_PF_FUSE         0: separate Q / K / V and W1 / W3 GEMMs
