@@ -460,7 +460,10 @@ hipError_t launch_prefill_attention(const float *q, int ldq, const float *kcache
     // one block per (head, 64 queries): worth it once that fills half the CUs (7B: from 256 tokens);
     // below, and for models with few heads, the block-per-(head, query) kernel has more parallelism
     const bool enough_blocks = n_heads_model * ((P + 63) / 64) >= 128;
-    if (!naive && enough_blocks && tunables().pf_attn != 2 && (head_size == 64 || head_size == 128) && (kv_dim % 4) == 0 &&
+    // the flash form is ahead of the block-per-(head, query) kernel from far fewer blocks (12 heads x 4 query
+    // tiles, stories110M at 256 tokens: 22 -> 16 us)
+    const bool flash_blocks = n_heads_model * ((P + 63) / 64) >= 32;
+    if (!naive && flash_blocks && tunables().pf_attn != 2 && (head_size == 64 || head_size == 128) && (kv_dim % 4) == 0 &&
         (ldq % 4) == 0 && (ldo % 4) == 0 && (((uintptr_t)q | (uintptr_t)out | (uintptr_t)kcache | (uintptr_t)vcache) & 15) == 0) {
         // flash form (L2Z_PF_ATTN=2 keeps the LDS-softmax tiled kernel below)
         const size_t lds_f = (size_t)2 * 2 * 64 * head_size * sizeof(float);  // two buffers of a K and a V tile
