@@ -85,6 +85,14 @@ int l2z_attention_decode(int form, int nch, float *out, const float *q, const fl
                          const float *vcache, int pos, int n_heads, int n_kv_heads, int head_size,
                          int seq_len);
 
+/* The batched prefill's attention kernels (llama2.zig_amd/csrc/prefill_attention.hip) for the n_queries
+ * queries at positions pos0 .. pos0 + n_queries - 1 of one layer: q and out are [n_queries][n_heads * head_size],
+ * the caches [seq_len][n_kv_heads * head_size] with rows 0 .. pos0 + n_queries - 1 filled.
+ * form: 0 as l2z_prefill picks, 1 block per (head, query), 2 tiled with the softmax in LDS, 3 / 4 flash form
+ * with one / two key parts (head sizes 64 and 128). */
+int l2z_prefill_attention(int form, float *out, const float *q, const float *kcache, const float *vcache,
+                          int pos0, int n_queries, int n_heads, int n_kv_heads, int head_size, int seq_len);
+
 /* ---- emulated ranks ---- */
 /* Testing support: N emulated ranks in ONE process on ONE GPU (RCCL refuses two ranks on
  * one device).  l2z_comm_init_emulated makes a rank descriptor without a communicator;

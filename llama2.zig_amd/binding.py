@@ -108,6 +108,7 @@ def lib():
     L.l2z_comm_free.restype = None
     L.l2z_comm_init_emulated.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.l2z_emu_transformer.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int]
+    L.l2z_prefill_attention.argtypes = [C.c_int, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.l2z_emu_prefill.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int32), C.c_int, C.c_int]
     L.l2z_shard_range.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64),
                                   C.POINTER(C.c_int64)]
@@ -310,6 +311,15 @@ def emu_transformer(states, weights, token: int, pos: int) -> None:
     ss = (C.c_void_p * n)(*[s.h for s in states])
     ws = (C.c_void_p * n)(*[w.h for w in weights])
     _chk(lib().l2z_emu_transformer(n, ss, ws, token, pos))
+
+
+def prefill_attention(form: int, q, kcache, vcache, pos0: int, n_heads: int, n_kv_heads: int, head_size: int) -> np.ndarray:
+    """The batched prefill's attention kernels on (q [P, dim], caches [seq_len, kv_dim]); form as in the header."""
+    q, kcache, vcache = _f32(q), _f32(kcache), _f32(vcache)
+    out = np.empty_like(q)
+    _chk(lib().l2z_prefill_attention(form, _fp(out), _fp(q), _fp(kcache), _fp(vcache), pos0, q.shape[0], n_heads,
+                                     n_kv_heads, head_size, kcache.shape[0]))
+    return out
 
 
 def emu_prefill(states, weights, tokens, pos0: int) -> None:

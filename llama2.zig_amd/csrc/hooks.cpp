@@ -3,6 +3,7 @@
 //   l2z_matmul / l2z_matmul_fused   launch_matvec: the forward pass's own kernels for that width
 //   l2z_rmsnorm                     the mat-vec prologue's staging code (xload_issue / xstage_finish)
 //   l2z_attention_decode            the forward pass's attention kernels, every form selectable
+//   l2z_prefill_attention           the batched prefill's attention kernels, every form selectable
 //   l2z_softmax, l2z_vector_dot_product, l2z_vector_weighted_sum_rows
 //                                   the GENERIC attention kernel's device functions (block_softmax,
 //                                   attn_scores, attn_weighted_sum) -- the forms the stories / 7B
@@ -133,6 +134,38 @@ extern "C" int l2z_argmax_host(const float *x, size_t n, size_t *out_index)
     (void)hipFree(didx);
     L2Z_HIP(e);
     *out_index = (size_t)idx;
+    return L2Z_OK;
+}
+
+// src/main.zig:361-389 for the P queries of a prompt chunk at positions pos0 .. pos0 + P - 1, through the
+// batched prefill's attention kernels (prefill_attention.hip).  form: 0 as l2z_prefill picks, 1 block per
+// (head, query), 2 tiled with the softmax in LDS, 3 flash form with one key part, 4 flash form with two.
+extern "C" int l2z_prefill_attention(int form, float *out, const float *q, const float *kcache, const float *vcache,
+                                     int pos0, int n_queries, int n_heads, int n_kv_heads, int head_size, int seq_len)
+{
+    L2Z_CHECK(out && q && kcache && vcache && n_heads > 0 && n_kv_heads > 0 && head_size > 0 && head_size % 4 == 0 &&
+                  n_heads % n_kv_heads == 0 && n_queries > 0 && pos0 >= 0 && pos0 + n_queries <= seq_len,
+              L2Z_ERR_INVALID, "l2z_prefill_attention: bad arguments");
+    L2Z_CHECK(form >= 0 && form <= 4, L2Z_ERR_INVALID, "l2z_prefill_attention: form %d", form);
+    L2Z_CHECK(form < 3 || head_size == 64 || head_size == 128, L2Z_ERR_INVALID,
+              "l2z_prefill_attention: the flash form takes head sizes 64 and 128");
+    L2Z_TRY(ensure_device(current_device_for(nullptr)));
+    const size_t dim = (size_t)n_heads * head_size, kvd = (size_t)n_kv_heads * head_size;
+    DevBuf dq, dk, dv, dout;
+    L2Z_TRY(dq.alloc(n_queries * dim)); L2Z_TRY(dk.alloc(seq_len * kvd)); L2Z_TRY(dv.alloc(seq_len * kvd));
+    L2Z_TRY(dout.alloc(n_queries * dim));
+    L2Z_TRY(dq.up(q, n_queries * dim)); L2Z_TRY(dk.up(kcache, seq_len * kvd)); L2Z_TRY(dv.up(vcache, seq_len * kvd));
+    // the launcher reads L2Z_PF_ATTN and a block-count threshold: force the form through both
+    const int saved = tunables().pf_attn;
+    const int knob[5] = {saved, 0, 2, 3, 1};
+    tunables_set("L2Z_PF_ATTN", knob[form]);
+    const hipError_t e = launch_prefill_attention(dq.p, (int)dim, dk.p, dv.p, dout.p, (int)dim, pos0, n_queries, n_heads,
+                                                  head_size, (int)kvd, n_heads / n_kv_heads, seq_len, nullptr,
+                                                  form >= 2 ? (1 << 20) : n_heads);
+    tunables_set("L2Z_PF_ATTN", saved);
+    L2Z_HIP(e);
+    L2Z_HIP(hipDeviceSynchronize());
+    L2Z_TRY(dout.down(out, n_queries * dim));
     return L2Z_OK;
 }
 

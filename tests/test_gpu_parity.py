@@ -206,6 +206,44 @@ def test_attention_kernels_vs_oracle(gpu, orc, shape, form, nch, positions):
     print(f"attention {shape} {form}{nch or ''}: max |diff| {worst:.2e}")
 
 
+PF_ATTN_FORMS = {"per-query": 1, "tiled": 2, "flash1": 3, "flash2": 4}
+
+
+@pytest.mark.parametrize("H,KV,hs", [(4, 2, 64), (4, 4, 128), (6, 6, 48)], ids=["gqa-hs64", "mha-hs128", "hs48"])
+@pytest.mark.parametrize("form", list(PF_ATTN_FORMS))
+def test_prefill_attention_kernels_vs_softmax_reference(gpu, orc, H, KV, hs, form):
+    """The batched prefill's attention kernels driven directly (l2z_prefill_attention): block per (head,
+    query); tiled with the softmax in LDS; the flash form (S^T / O^T on MFMA 16x16x4, P kept in the
+    accumulators' registers) with one and two key parts.  150 queries at positions 37 .. 186 (three query
+    tiles, the last one partial, key tiles that start before the chunk) against main.zig:361-389 in
+    float64, and a few (query, head) pairs against the oracle's own dot / softmax / weighted sum.  Outputs
+    are convex combinations of V entries (|v| <= 2): bound 3e-6."""
+    if form.startswith("flash") and hs not in (64, 128):
+        pytest.skip("the flash form takes head sizes 64 and 128")
+    pos0, P, S = 37, 150, 200
+    dim, kvd, kv_mul = H * hs, KV * hs, H // KV
+    rng = np.random.default_rng(hs + H)
+    q = rng.standard_normal((P, dim), dtype=np.float32)
+    kc = rng.standard_normal((S, kvd), dtype=np.float32)
+    vc = rng.uniform(-2, 2, (S, kvd)).astype(np.float32)
+    got = gpu.prefill_attention(PF_ATTN_FORMS[form], q, kc, vc, pos0, H, KV, hs)
+    ref = np.empty((P, dim), np.float64)
+    for h in range(H):
+        o = (h // kv_mul) * hs
+        K, V = kc[:, o:o + hs].astype(np.float64), vc[:, o:o + hs].astype(np.float64)
+        sc = q[:, h * hs:(h + 1) * hs].astype(np.float64) @ K.T / np.sqrt(np.float64(hs))
+        for i in range(P):
+            a = sc[i, :pos0 + i + 1]
+            e = np.exp(a - a.max())
+            ref[i, h * hs:(h + 1) * hs] = (e / e.sum()) @ V[:pos0 + i + 1]
+    worst = float(np.abs(got - ref).max())
+    print(f"prefill attention {form} H{H} kv{KV} hs{hs}: max |diff| vs float64 {worst:.2e}")
+    assert worst <= 3e-6
+    for i, h in ((0, 0), (63, 1), (64, H - 1), (P - 1, H - 1)):   # the oracle's kernels on a few rows
+        r = attention_ref(orc, q[i], kc.reshape(-1), vc.reshape(-1), pos0 + i, H, KV, hs)
+        np.testing.assert_allclose(got[i, h * hs:(h + 1) * hs], r[h * hs:(h + 1) * hs], rtol=0, atol=3e-6)
+
+
 def test_attention_auto_picks_the_documented_form(gpu):
     """form 'auto' is what enqueue_forward launches: 256 threads per head (speculative first round)
     for seq_len <= 512, 1024 threads beyond, the split form from pos 256 on -- bit-identical to the
