@@ -401,7 +401,7 @@ def main() -> None:
     # sharded runstates: the row-sharded prefill (every rank its column blocks, [tokens, n / world] blocks
     # exchanged through the bulk regions / RCCL) -- a diagnostic beside the decode figure, like the above
     prefill_sharded = None
-    if world > 1 and not args.no_extra:
+    if world > 1 and not args.no_extra and os.environ.get("L2Z_BENCH_NO_SHARDED_PREFILL", "") != "1":
         err = None
         dtp = 0.0
         n_p = min(512, cfg.seq_len - 1)
