@@ -125,12 +125,12 @@ int l2z_greedy_run(const l2z_config *config, l2z_runstate *s, const l2z_weights 
  * Same state change as l2z_transformer(tokens[i], pos0 + i) for i = 0 .. n_tokens-1 -- the
  * KV-cache rows pos0 .. pos0+n_tokens-1 of every layer are written and the logits of the LAST
  * position are left in the runstate (l2z_argmax / l2z_logits_read) -- but each weight matrix is
- * streamed once per chunk of up to 512 tokens and multiplied as a dense GEMM on the fp32 matrix
+ * streamed once per chunk of up to 1024 tokens and multiplied as a dense GEMM on the fp32 matrix
  * cores (v_mfma_f32_32x32x2_f32).  Values agree with the token-by-token path up to summation
  * order.  Dims must be multiples of 4 (else L2Z_ERR_INVALID, and the caller loops over
  * l2z_transformer).  On a sharded runstate every rank of the group makes the same call: the pass is
  * row-sharded like the decode pass and bit-identical to the unsharded one; it needs a transport for
- * [512, hidden_dim] matrices -- the peer-write arena's bulk regions (allocated by
+ * [1024, hidden_dim] matrices -- the peer-write arena's bulk regions (allocated by
  * l2z_comm_p2p_export unless L2Z_P2P_BULK_MB=0) or an RCCL communicator -- else L2Z_ERR_INVALID.
  * l2z_greedy_run uses the same pass for the prompt positions when its first call after
  * l2z_greedy_begin asks for at least n_prompt steps, n_prompt >= L2Z_PREFILL_MIN_PROMPT and no
@@ -154,7 +154,7 @@ int l2z_synchronize(l2z_runstate *s);
  *    no fences, no collective library, and it can be captured in the step graph.  Preferred when both are set up (L2Z_COMM=rccl overrides).
  *    max_vector_floats must be >= max(dim, hidden_dim, vocab_size) of every config used with the
  *    group: l2z_runstate_init refuses (L2Z_ERR_COMM) a config the landing slots cannot hold.
- *    The arena also carries two bulk regions of max_vector_floats x 512 floats (L2Z_P2P_BULK_MB
+ *    The arena also carries two bulk regions of max_vector_floats x 1024 floats (L2Z_P2P_BULK_MB
  *    overrides, 0 = none) for the sharded prefill's activation matrices: plain 16-byte peer stores
  *    and one flag per sender.
  */

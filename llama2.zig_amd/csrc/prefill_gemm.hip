@@ -47,24 +47,26 @@ static int g_cus_hint()
 // efficiencies from interleaved A/B runs on the 7B and 110M shapes (larger tiles bring
 // fewer bytes per flop into the CU).  The 7B shape at 512 tokens keeps 128 x 64; 65..128-token prompts,
 // small models and row shards (N / world features) take the 32-token forms.
-enum TileForm { TILE_128x64 = 0, TILE_64x64, TILE_32x64, TILE_32x32 };
+enum TileForm { TILE_128x64 = 0, TILE_64x64, TILE_32x64, TILE_32x32, TILE_128x128 };
 static TileForm choose_tile(int N, int P, bool pair)
 {
     const long long cus = g_cus_hint();
     // tokens, features (of each matrix when paired) per block, relative efficiency
-    static const struct { int tok, feat; double eff; } form[4] = {{128, 64, 1.0}, {64, 64, 0.87}, {32, 64, 0.80}, {32, 32, 0.65}};
+    static const struct { int tok, feat; double eff; } form[5] = {{128, 64, 1.0}, {64, 64, 0.87}, {32, 64, 0.80}, {32, 32, 0.65},
+                                                                   {128, 128, 1.12}};
     int best = -1;
     double best_cost = 0.0;
-    for (int f = 0; f < 4; f++) {
+    for (int f = 0; f < 5; f++) {
         if (f == TILE_128x64 && P <= 256) continue;  // (two resident 64 x 64 blocks per CU do better there: measured)
+        // 128 x 128 (32 KB per MFLOP brought into the CU instead of 48): unpaired products of 1024-token chunks
+        if (f == TILE_128x128 && (pair || P < 1024)) continue;
         const long long blocks = (long long)((N + form[f].feat - 1) / form[f].feat) * ((P + form[f].tok - 1) / form[f].tok);
         const double cost = (double)((blocks + cus - 1) / cus) * (form[f].tok * form[f].feat) / form[f].eff;
-        if (best < 0 || cost < best_cost * 0.999) {  // ties: the larger tile
+        if (best < 0 || cost < best_cost * 0.999) {  // ties: the earlier (larger) tile
             best = f;
             best_cost = cost;
         }
     }
-    (void)pair;  // the paired forms have twice the area each: the same ranking
     return (TileForm)best;
 }
 
@@ -559,6 +561,7 @@ hipError_t gemm_launch(const GemmArgs &a, hipStream_t st)
     case 6: return gemm_launch_t<EPI, 1, 2, 64, 2>(a, st);
     case 7: return gemm_launch_t<EPI, 2, 2, 32, 2>(a, st);
     case 8: return gemm_launch_t<EPI, 2, 1, 64, 2>(a, st);
+    case 11: return gemm_launch_t<EPI, 2, 2, 64, 2>(a, st);
     case 9: { hipError_t e; if (gemm_launch_small<EPI, 1, 2>(a, st, &e)) return e; break; }
     case 10: { hipError_t e; if (gemm_launch_small<EPI, 1, 1>(a, st, &e)) return e; break; }
     default: break;
@@ -567,6 +570,7 @@ hipError_t gemm_launch(const GemmArgs &a, hipStream_t st)
     // the LDS operand reads per MFMA (measured on the 7B shape: 94.7 vs 89.5 TFLOP/s at 512)
     hipError_t e;
     switch (choose_tile(a.N, a.P, false)) {
+    case TILE_128x128: return gemm_launch_t<EPI, 2, 2, 64, 2>(a, st);
     case TILE_128x64: return gemm_launch_t<EPI, 2, 1, 64, 2>(a, st);
     case TILE_32x64: if (gemm_launch_small<EPI, 1, 2>(a, st, &e)) return e; break;
     case TILE_32x32: if (gemm_launch_small<EPI, 1, 1>(a, st, &e)) return e; break;
@@ -623,7 +627,7 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
     // 128 x 64 tiles mean q alone already gives every CU its one resident block: three such launches
     // measured 445 us against 453 for the 768-block one (7B, 512 tokens).  With the smaller tiles several
     // blocks share a CU and the longer grid keeps them supplied: 128 tokens 21.8 -> 19.4 ms fused.
-    if (tf == TILE_128x64) return hipErrorNotSupported;
+    if (tf == TILE_128x64 || tf == TILE_128x128) return hipErrorNotSupported;
     int feat = tf == TILE_32x32 ? 32 : 64;
     if (nq % feat != 0 || nkv % feat != 0) {
         if (nq % 32 != 0 || nkv % 32 != 0) return hipErrorNotSupported;

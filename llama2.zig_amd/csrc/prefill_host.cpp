@@ -17,12 +17,13 @@ using namespace l2z;
 namespace {
 #define kPrefillChunk prefill_chunk_tokens()
 
-int prefill_alloc(l2z_runstate *s)
+int prefill_alloc(l2z_runstate *s, int need)
 {
     const l2z_config &c = s->cfg;
-    const size_t P = kPrefillChunk;
-    if (s->pf_cap >= (int)P) return L2Z_OK;
-    // first use, or the chunk length has grown since (L2Z_PF_CHUNK through l2z_option_set): start over
+    if (s->pf_cap >= need) return L2Z_OK;
+    // first use, or a longer chunk than any before (a prompt of >= 1024 tokens; L2Z_PF_CHUNK through
+    // l2z_option_set): start over, in steps of 512 tokens
+    const size_t P = (size_t)(need + 511) / 512 * 512;
     L2Z_HIP(hipStreamSynchronize(s->stream));
     float **bufs[] = {&s->pf_x, &s->pf_xn, &s->pf_q, &s->pf_att, &s->pf_h1, &s->pf_stage};
     for (float **b : bufs)
@@ -212,10 +213,10 @@ int prefill_tokens(l2z_runstate *s, const l2z_weights *w, const int32_t *tokens,
                           int pos0)
 {
     const l2z_config *config = &s->cfg;
-    L2Z_TRY(prefill_alloc(s));
     int done = 0;
     while (done < n_tokens) {
-        const int P = n_tokens - done < kPrefillChunk ? n_tokens - done : kPrefillChunk;
+        const int P = prefill_next_chunk(n_tokens - done);
+        L2Z_TRY(prefill_alloc(s, P));
         L2Z_TRY(prefill_chunk(s, w, tokens + done, P, pos0 + done));
         if (done + P == n_tokens)
             L2Z_HIP(hipMemcpyAsync(s->x, s->pf_x + (size_t)(P - 1) * config->dim, (size_t)config->dim * 4,
@@ -277,7 +278,7 @@ extern "C" int l2z_emu_prefill(int n_ranks, l2z_runstate *const *ss, const l2z_w
         L2Z_CHECK(c.dim % 4 == 0 && c.hidden_dim % 4 == 0 && ss[r]->sh.hs % 4 == 0 && ss[r]->sh.hs <= 256 &&
                       ss[r]->sh.dim_loc % 4 == 0 && ss[r]->sh.hid_loc % 4 == 0,
                   L2Z_ERR_INVALID, "l2z_emu_prefill: shape not supported by the batched path");
-        L2Z_TRY(prefill_alloc(ss[r]));
+        L2Z_TRY(prefill_alloc(ss[r], n_tokens < kPrefillChunk ? n_tokens : kPrefillChunk));
     }
     auto sync_all = [&]() -> int {
         for (int r = 0; r < n_ranks; r++) L2Z_HIP(hipStreamSynchronize(ss[r]->stream));
@@ -295,7 +296,7 @@ extern "C" int l2z_emu_prefill(int n_ranks, l2z_runstate *const *ss, const l2z_w
     };
     int done = 0;
     while (done < n_tokens) {
-        const int P = n_tokens - done < kPrefillChunk ? n_tokens - done : kPrefillChunk;
+        const int P = prefill_next_chunk(n_tokens - done);
         for (int r = 0; r < n_ranks; r++) L2Z_TRY(prefill_begin_chunk(ss[r], ws[r], tokens + done, P));
         for (int l = 0; l < c.n_layers; l++)
             for (int k = 0; k < PF_STAGES; k++) {

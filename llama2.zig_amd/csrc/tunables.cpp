@@ -61,10 +61,19 @@ const Tunables &tunables() { return mutable_tunables(); }
 
 int prefill_chunk_tokens()
 {
-    int n = tunables().pf_chunk > 0 ? tunables().pf_chunk : 512;
+    int n = tunables().pf_chunk > 0 ? tunables().pf_chunk : 1024;
     if (n < 16) n = 16;
     if (n > 2048) n = 2048;
     return n;
+}
+
+int prefill_next_chunk(int remaining)
+{
+    if (tunables().pf_chunk > 0) return remaining < prefill_chunk_tokens() ? remaining : prefill_chunk_tokens();
+    // 1024 tokens at a time while that many are left (128 x 128 tiles: one block per CU for N = 4096), else
+    // 512 (128 x 64 tiles), else the rest -- a chunk of 513 .. 1023 tokens would leave a wave of tiles
+    // mostly empty
+    return remaining >= 1024 ? 1024 : remaining < 512 ? remaining : 512;
 }
 
 bool tunables_set(const char *name, long long v)

@@ -44,7 +44,8 @@ struct Tunables {
 };
 
 const Tunables &tunables();
-int prefill_chunk_tokens();  // L2Z_PF_CHUNK clamped to [16, 2048], default 512
+int prefill_chunk_tokens();          // the longest chunk of a batched prefill: L2Z_PF_CHUNK clamped to [16, 2048], default 1024
+int prefill_next_chunk(int remaining);  // tokens of the next chunk (default: 1024 while that many remain, then 512, then the rest)
 // Override one knob by its environment name after start-up (measurement harnesses that try several
 // settings in one process: include/llama2_hip_test.h l2z_option_set).  False: unknown name.
 bool tunables_set(const char *env_name, long long value);

@@ -26,7 +26,7 @@ def run(n_cfg, seed, log=print):
         if rng.integers(0, 2):  # K % 256 == 0: the direct-to-LDS short-prompt form and whole tile stages
             hidden = max(256, hidden // 256 * 256)
         vocab = world * int(rng.integers(8, 300))
-        n_tok = int(rng.choice([1, 3, 9, 16, 17, 31, 40, 64, 65, 100, 129, 200, 257, 300, 530]))
+        n_tok = int(rng.choice([1, 3, 9, 16, 17, 31, 40, 64, 65, 100, 129, 200, 257, 300, 530, 1030, 1600]))
         seq = n_tok + 8
         cfg = ck.Config(dim, hidden, int(rng.integers(1, 3)), n_heads, n_kv, vocab, seq)
         toks = [1] + rng.integers(2, vocab, n_tok - 1).tolist()
