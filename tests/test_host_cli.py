@@ -138,6 +138,51 @@ def test_samplers(H):
     assert abs(float(x.sum()) - 1) < 1e-6 and np.all(np.diff(x) > 0)
 
 
+def _top_p_reference(p, top_p, r01):
+    """main.zig:745-798 with the candidates ordered by (probability descending, token id ascending) --
+    the total order the host sampler documents -- and float32 running sums."""
+    n = len(p)
+    cutoff = np.float32((np.float32(1.0) - np.float32(top_p)) / (np.float32(n) - np.float32(1.0)))
+    idx = np.nonzero(p >= cutoff)[0]
+    order = idx[np.lexsort((idx, -p[idx].astype(np.float64)))]
+    cum = np.float32(0.0)
+    last = len(order) - 1
+    for i, t in enumerate(order):
+        cum = np.float32(cum + p[t])
+        if cum > np.float32(top_p):
+            last = i
+            break
+    r = np.float32(np.float32(r01) * cum)
+    cdf = np.float32(0.0)
+    for t in order[:last + 1]:
+        cdf = np.float32(cdf + p[t])
+        if r < cdf:
+            return int(t)
+    return int(order[last])
+
+
+def test_top_p_large_vocabulary_matches_the_sorted_reference(H):
+    """The nucleus sampler over a whole 32000-token vocabulary (the reference's default -p 0.9 runs it for
+    every generated token): the radix sort behind it must give the permutation of the documented total
+    order -- near-uniform probabilities with MANY exact ties, a peaked distribution (few candidates: the
+    comparison-sort path), and an exactly uniform one."""
+    rng = np.random.default_rng(11)
+    V = 32000
+    flat = np.round(rng.uniform(1.0, 2.0, V) * 64) / 64          # 64 distinct values: ties everywhere
+    peaked = np.exp(rng.standard_normal(V) * 4.0)
+    cases = [flat, peaked, np.ones(V), np.concatenate([np.full(2000, 3.0), rng.uniform(0.0, 1e-9, V - 2000)])]
+    fl = (C.c_float * 1)()
+    for ci, w in enumerate(cases):
+        p = (w / w.sum()).astype(np.float32)
+        pp = p.ctypes.data_as(C.POINTER(C.c_float))
+        for top_p in (0.9, 0.5, 0.999):
+            for seed in range(12):
+                H.l2zh_prng_floats(seed, fl, 1)
+                want = _top_p_reference(p, top_p, fl[0])
+                got = H.l2zh_sample_top_p(pp, V, C.c_float(top_p), seed)
+                assert got == want, (ci, top_p, seed, got, want)
+
+
 def test_cli_usage_and_errors():
     exe = os.path.join(HOST, "llama2")
     r = subprocess.run([exe], capture_output=True, text=True)
