@@ -17,6 +17,7 @@
  *   transformer(token,pos,c,s,w) :285        l2z_transformer
  *   argmax(state.logits)         :715,:1003  l2z_argmax            (on device)
  *   state.logits after return    :1005-1012  l2z_logits_read       (D2H, for samplers)
+ *   logits / temperature, softmax :1005-1008  l2z_probs_read        (on the device, then D2H)
  *   while (pos < seq_len) loop at -t 0 :995  l2z_greedy_begin / l2z_greedy_run
  *   matmul, rmsnorm, softmax, ... :432-726   kernel-level hooks of the same names, for tests only:
  *                                            include/llama2_hip_test.h
@@ -107,6 +108,10 @@ int l2z_transformer(int token, int pos, const l2z_config *config, l2z_runstate *
 int l2z_argmax(l2z_runstate *s, int *out_token);
 /* copy s.logits (vocab_size floats) to the host */
 int l2z_logits_read(l2z_runstate *s, float *out_logits);
+/* src/main.zig:1005-1008 on the device: out_probs[i] = softmax(logits / temperature)[i] (temperature > 0),
+ * then the device-to-host copy of vocab_size floats; the caller goes on with sample / sample_top_p
+ * (:1009-1012).  32000 exp() on one host core take longer than a small model's forward pass. */
+int l2z_probs_read(l2z_runstate *s, float temperature, float *out_probs);
 /* ---- src/main.zig:987-1042, the generation loop at temperature 0 ----
  * Runs entirely on the device: the forward pass, argmax, the prompt override
  * (main.zig:999-1000) and the token/pos hand-over to the next step are one

@@ -80,6 +80,7 @@ def lib():
     L.l2z_transformer.argtypes = [C.c_int, C.c_int, cfgp, vp, vp]
     L.l2z_argmax.argtypes = [vp, ip]
     L.l2z_logits_read.argtypes = [vp, fp]
+    L.l2z_probs_read.argtypes = [vp, C.c_float, fp]
     L.l2z_runstate_read.argtypes = [vp, C.c_char_p, sz, sz, fp]
     L.l2z_prefill.argtypes = [i32p, C.c_int, C.c_int, cfgp, vp, vp]
     L.l2z_greedy_begin.argtypes = [vp, i32p, C.c_int]
@@ -253,6 +254,12 @@ class RunState:
     def logits(self) -> np.ndarray:
         out = np.empty(self.cfg.vocab_size, np.float32)
         _chk(lib().l2z_logits_read(self.h, _fp(out)))
+        return out
+
+    def probs(self, temperature: float = 1.0) -> np.ndarray:
+        """softmax(logits / temperature) computed on the device (l2z_probs_read)."""
+        out = np.empty(self.cfg.vocab_size, np.float32)
+        _chk(lib().l2z_probs_read(self.h, C.c_float(temperature), _fp(out)))
         return out
 
     def read(self, name: str, offset: int, count: int) -> np.ndarray:

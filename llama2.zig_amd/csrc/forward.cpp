@@ -334,6 +334,21 @@ extern "C" int l2z_logits_read(l2z_runstate *s, float *out_logits)
     return L2Z_OK;
 }
 
+// src/main.zig:1005-1008 on the device: softmax(logits / temperature), then the D2H the samplers need anyway
+extern "C" int l2z_probs_read(l2z_runstate *s, float temperature, float *out_probs)
+{
+    L2Z_CHECK(s && out_probs, L2Z_ERR_INVALID, "l2z_probs_read: null argument");
+    L2Z_CHECK(temperature > 0.0f, L2Z_ERR_INVALID, "l2z_probs_read: temperature %g (0 is the argmax path)", (double)temperature);
+    L2Z_HIP(hipSetDevice(s->device));
+    if (s->d_probs == nullptr) L2Z_HIP(hipMalloc(&s->d_probs, (size_t)s->cfg.vocab_size * sizeof(float)));
+    L2Z_HIP(launch_probs(s->d_probs, s->logits, s->cfg.vocab_size, temperature, s->stream));
+    L2Z_HIP(hipMemcpyAsync(out_probs, s->d_probs, (size_t)s->cfg.vocab_size * sizeof(float), hipMemcpyDeviceToHost,
+                           s->stream));
+    L2Z_HIP(hipStreamSynchronize(s->stream));
+    L2Z_TRY(comm_check(s->comm));
+    return L2Z_OK;
+}
+
 // ---------------------------------------------------------------------------
 // src/main.zig:987-1042 at temperature 0
 extern "C" int l2z_greedy_begin(l2z_runstate *s, const int32_t *prompt, int n_prompt)

@@ -180,6 +180,7 @@ hipError_t launch_set_state(int token, int pos, int *token_ptr, int *pos_ptr, co
                             float *x, int dim, hipStream_t st);
 hipError_t launch_rmsnorm(float *o, const float *x, const float *w, int n, hipStream_t st);
 hipError_t launch_softmax(float *x, int n, hipStream_t st);
+hipError_t launch_probs(float *probs, const float *logits, int n, float temperature, hipStream_t st);
 hipError_t launch_dot(float *out, const float *x, const float *y, int n, hipStream_t st);
 hipError_t launch_weighted_sum_rows(float *xout, int xout_len, const float *rows, int row_stride,
                                     const float *weights, int n_weights, hipStream_t st);

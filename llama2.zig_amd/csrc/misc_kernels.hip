@@ -120,6 +120,16 @@ __global__ __launch_bounds__(kBlock) void softmax_kernel(float *x, int n)
     block_softmax(x, n, scratch);
 }
 
+// main.zig:1005-1008 for the samplers: probs = softmax(logits / temperature), one block of 1024 threads
+// over the vocabulary (the logits are L2 resident: the classifier or the gather has just written them)
+__global__ __launch_bounds__(1024) void probs_kernel(float *probs, const float *logits, int n, float temperature)
+{
+    __shared__ float scratch[kScratch];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) probs[i] = logits[i] / temperature;  // :1006
+    __syncthreads();
+    block_softmax(probs, n, scratch);                                                       // :1008
+}
+
 // Seeded synthetic weights: value(idx) = bias + scale*r(idx,seed); must match
 // oracle/llama2_oracle.c orc_synth_value and checkpoint.py synth_values bit for bit.
 __global__ void synth_fill_kernel(float *dst, uint64_t base_idx, uint64_t count, uint64_t seed,
@@ -167,6 +177,12 @@ hipError_t launch_rmsnorm(float *o, const float *x, const float *w, int n, hipSt
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((rmsnorm_kernel<false>), dim3(1), dim3(kBlock), lds, st, o, x, w, n);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_probs(float *probs, const float *logits, int n, float temperature, hipStream_t st)
+{
+    hipLaunchKernelGGL(probs_kernel, dim3(1), dim3(1024), 0, st, probs, logits, n, temperature);
     return hipGetLastError();
 }
 

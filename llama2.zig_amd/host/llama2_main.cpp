@@ -379,10 +379,9 @@ int main(int argc, char **argv)
             if (pos < prompt_len) {
                 next = (size_t)prompt[pos];  // :999-1000
             } else {
-                if (l2z_logits_read(s, logits.data()) != L2Z_OK) return finish(die("logits_read"));
-                if (temperature != 1.0f)
-                    for (float &v : logits) v /= temperature;  // :1005-1007
-                softmax(logits.data(), logits.size());          // :1008
+                // :1005-1008 (logits / temperature, softmax) on the device, then the copy the samplers need
+                // anyway: 32000 exp() on one host core take as long as a small model's forward pass
+                if (l2z_probs_read(s, temperature, logits.data()) != L2Z_OK) return finish(die("probs_read"));
                 next = (top_p == 0.0f || top_p == 1.0f)         // :1009-1012
                            ? sample(logits.data(), logits.size(), prng)
                            : sample_top_p(logits.data(), logits.size(), top_p, logits_indexed, prng);

@@ -260,6 +260,28 @@ def test_attention_auto_picks_the_documented_form(gpu):
         assert np.array_equal(a, b), (shape, pos, want)
 
 
+def test_probs_read_is_softmax_of_logits_over_temperature(gpu, ck, orc):
+    """l2z_probs_read (main.zig:1005-1008 on the device) against the oracle's softmax of the same logits
+    divided by the temperature on the host, and against the exact (float64) softmax: the device sums in a
+    tree, the host in order; expf differs in the last bit."""
+    cfg = ck.Config(dim=128, hidden_dim=352, n_layers=2, n_heads=8, n_kv_heads=4, vocab_size=32000, seq_len=16)
+    w, s = gpu.Weights(cfg, None, False, seed=9), gpu.RunState(cfg)
+    s.transformer(5, 0, w)
+    lg = s.logits()
+    for temp in (1.0, 0.7, 0.05):
+        got = s.probs(temp)
+        x = (lg / np.float32(temp)).astype(np.float32)
+        e = np.exp(x.astype(np.float64) - float(x.max()))
+        assert abs(float(got.astype(np.float64).sum()) - 1.0) < 1e-5
+        np.testing.assert_allclose(got, e / e.sum(), rtol=3e-6, atol=1e-12)   # the exact softmax
+        # the oracle adds its 32000 terms in order in float32: its normalisation alone is off by ~2e-5
+        np.testing.assert_allclose(got, orc.softmax(x), rtol=1e-4, atol=1e-9)
+        assert int(np.argmax(got)) == int(np.argmax(lg))
+    with pytest.raises(gpu.L2ZError):
+        s.probs(0.0)
+    s.close(); w.close()
+
+
 def test_argmax_tie_rule(gpu, orc):
     """main.zig:720 strict '>' : the lowest index wins ties"""
     x = np.zeros(32000, np.float32)
