@@ -93,6 +93,13 @@ int l2z_attention_decode(int form, int nch, float *out, const float *q, const fl
 int l2z_prefill_attention(int form, float *out, const float *q, const float *kcache, const float *vcache,
                           int pos0, int n_queries, int n_heads, int n_kv_heads, int head_size, int seq_len);
 
+/* Host-side planning of the batched prefill (no device needed).  l2z_prefill_plan: the chunk lengths a
+ * prompt of n_tokens is cut into (returns their number, writes up to cap of them).  l2z_prefill_tile: the
+ * output tile of the direct-to-LDS GEMM for an [n_tokens, n_features] product -- 0: 128x64, 1: 64x64,
+ * 2: 32x64, 3: 32x32, 4: 128x128 (all forms give the same bits; the choice fills the CUs). */
+int l2z_prefill_plan(int n_tokens, int *chunks, int cap);
+int l2z_prefill_tile(int n_features, int n_tokens, int paired);
+
 /* ---- emulated ranks ---- */
 /* Testing support: N emulated ranks in ONE process on ONE GPU (RCCL refuses two ranks on
  * one device).  l2z_comm_init_emulated makes a rank descriptor without a communicator;

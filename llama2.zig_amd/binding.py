@@ -110,6 +110,8 @@ def lib():
     L.l2z_comm_init_emulated.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.l2z_emu_transformer.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int]
     L.l2z_prefill_attention.argtypes = [C.c_int, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.l2z_prefill_plan.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int]
+    L.l2z_prefill_tile.argtypes = [C.c_int, C.c_int, C.c_int]
     L.l2z_emu_prefill.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int32), C.c_int, C.c_int]
     L.l2z_shard_range.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64),
                                   C.POINTER(C.c_int64)]
@@ -327,6 +329,26 @@ def prefill_attention(form: int, q, kcache, vcache, pos0: int, n_heads: int, n_k
     _chk(lib().l2z_prefill_attention(form, _fp(out), _fp(q), _fp(kcache), _fp(vcache), pos0, q.shape[0], n_heads,
                                      n_kv_heads, head_size, kcache.shape[0]))
     return out
+
+
+def prefill_plan(n_tokens: int) -> list[int]:
+    """Chunk lengths of a batched prefill of n_tokens (host logic, no device)."""
+    buf = (C.c_int * 64)()
+    n = lib().l2z_prefill_plan(n_tokens, buf, 64)
+    if n < 0:
+        raise L2ZError(n, lib().l2z_last_error().decode(errors="replace"))
+    return list(buf[:n])
+
+
+TILE_FORMS = ("128x64", "64x64", "32x64", "32x32", "128x128")
+
+
+def prefill_tile(n_features: int, n_tokens: int, paired: bool = False) -> str:
+    """Output tile the direct-to-LDS GEMM takes for an [n_tokens, n_features] product (host logic)."""
+    t = lib().l2z_prefill_tile(n_features, n_tokens, 1 if paired else 0)
+    if t < 0:
+        raise L2ZError(t, lib().l2z_last_error().decode(errors="replace"))
+    return TILE_FORMS[t]
 
 
 def emu_prefill(states, weights, tokens, pos0: int) -> None:

@@ -232,3 +232,23 @@ namespace l2z { hipError_t dbg_ts_read(long long *out); }
 extern "C" int l2z_dbg_ts(long long *out) { return l2z::dbg_ts_read(out) == hipSuccess ? 0 : -3; }
 #endif
 
+// Host-side planning of the batched prefill, no device needed: how a prompt is cut into chunks, and which
+// output tile the direct-to-LDS GEMM takes for a [P, N] product (0: 128x64, 1: 64x64, 2: 32x64, 3: 32x32,
+// 4: 128x128; the CU count is the current device's, 256 without one).
+extern "C" int l2z_prefill_plan(int n_tokens, int *chunks, int cap)
+{
+    L2Z_CHECK(n_tokens >= 0 && (chunks != nullptr || cap == 0), L2Z_ERR_INVALID, "l2z_prefill_plan: bad arguments");
+    int n = 0;
+    for (int done = 0; done < n_tokens; n++) {
+        const int P = prefill_next_chunk(n_tokens - done);
+        if (n < cap) chunks[n] = P;
+        done += P;
+    }
+    return n;
+}
+
+extern "C" int l2z_prefill_tile(int n_features, int n_tokens, int paired)
+{
+    L2Z_CHECK(n_features > 0 && n_tokens > 0, L2Z_ERR_INVALID, "l2z_prefill_tile: bad arguments");
+    return prefill_tile_form(n_features, n_tokens, paired);
+}

@@ -213,6 +213,7 @@ hipError_t launch_prefill_attention(const float *q, int ldq, const float *kcache
                                     float *out, int ldo, int pos0, int P, int n_heads, int head_size,
                                     int kv_dim, int kv_mul, int seq_len, hipStream_t st,
                                     int n_heads_model = 0);  // heads of the whole model when n_heads is a shard's
+int prefill_tile_form(int N, int P, int pair);  // 0: 128x64, 1: 64x64, 2: 32x64, 3: 32x32, 4: 128x128
 size_t matvec_lds_bytes(int n);
 
 }  // namespace l2z

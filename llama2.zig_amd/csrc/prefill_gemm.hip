@@ -688,4 +688,7 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
     return hipErrorInvalidValue;
 }
 
+// host logic behind the launches, for tests (include/llama2_hip_test.h): no device needed
+int prefill_tile_form(int N, int P, int pair) { return (int)choose_tile(N, P, pair != 0); }
+
 }  // namespace l2z

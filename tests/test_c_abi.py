@@ -62,3 +62,21 @@ def test_c_host_runs_the_golden_toy_checkpoints(gpu, tmp_path):
                              [str(t) for t in m["prompt"]], check=True, capture_output=True, text=True).stdout
         got = np.array([int(x) for x in out.split()], np.int32)
         assert np.array_equal(got, exp[:len(got)]) and len(got) == len(exp), (m["checkpoint"], got, exp)
+
+
+def test_prefill_planning_is_pinned(B):
+    """Host logic behind the batched prefill, no device needed (the library loads on a CPU-only machine):
+    a prompt is cut into 1024-token chunks while that many tokens remain, then 512, then the rest; the
+    direct-to-LDS GEMM's output tile follows the grid (256 CUs assumed without a device).  The tile never
+    changes a bit of the result (GPU tests), but these choices are what DESIGN.md 4.5 quotes timings for."""
+    assert B.prefill_plan(0) == [] and B.prefill_plan(5) == [5] and B.prefill_plan(512) == [512]
+    assert B.prefill_plan(600) == [512, 88] and B.prefill_plan(1024) == [1024]
+    assert B.prefill_plan(1500) == [1024, 476] and B.prefill_plan(2047) == [1024, 512, 511]
+    want = {(4096, 512, False): "128x64",    # 7B q / k / v / wo / W2: one 128 x 64 tile per CU
+            (4096, 1024, False): "128x128",  # a 1024-token chunk: fewer bytes per flop into the CU
+            (4096, 256, False): "64x64", (4096, 128, False): "32x64", (4096, 80, False): "32x64",
+            (11008, 512, True): "128x64",    # W1 | W3 paired: 128 tokens x (64 + 64) features
+            (5504, 512, True): "64x64",      # the same on a 2-rank row shard: 2.7 waves of the larger tile -> 3 of the smaller
+            (768, 256, False): "32x32", (512, 512, False): "32x32"}   # stories110M; a 7B row shard of 8 ranks
+    for (n, p, pair), form in want.items():
+        assert B.prefill_tile(n, p, pair) == form, (n, p, pair)
