@@ -342,10 +342,13 @@ extern "C" int l2z_probs_read(l2z_runstate *s, float temperature, float *out_pro
     L2Z_HIP(hipSetDevice(s->device));
     if (s->d_probs == nullptr) L2Z_HIP(hipMalloc(&s->d_probs, (size_t)s->cfg.vocab_size * sizeof(float)));
     L2Z_HIP(launch_probs(s->d_probs, s->logits, s->cfg.vocab_size, temperature, s->stream));
-    L2Z_HIP(hipMemcpyAsync(out_probs, s->d_probs, (size_t)s->cfg.vocab_size * sizeof(float), hipMemcpyDeviceToHost,
-                           s->stream));
+    // through a pinned buffer: a copy into pageable memory is staged by the runtime anyway, slower
+    const size_t bytes = (size_t)s->cfg.vocab_size * sizeof(float);
+    if (s->h_stage == nullptr) L2Z_HIP(hipHostMalloc((void **)&s->h_stage, bytes, hipHostMallocDefault));
+    L2Z_HIP(hipMemcpyAsync(s->h_stage, s->d_probs, bytes, hipMemcpyDeviceToHost, s->stream));
     L2Z_HIP(hipStreamSynchronize(s->stream));
     L2Z_TRY(comm_check(s->comm));
+    memcpy(out_probs, s->h_stage, bytes);
     return L2Z_OK;
 }
 

@@ -83,6 +83,7 @@ struct l2z_runstate {
     int *pf_tokens = nullptr;
     int pf_cap = 0;             // tokens per chunk the scratch above was allocated for
     float *d_probs = nullptr;     // l2z_probs_read: softmax(logits / temperature), allocated on first use
+    float *h_stage = nullptr;     // ... and its pinned host landing buffer
     float *d_part_val = nullptr;  // classifier launch's per-block argmax candidates
     int *d_part_idx = nullptr;
     int n_part = 0;               // 0: argmax scans the logits instead

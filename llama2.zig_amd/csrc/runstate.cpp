@@ -160,6 +160,7 @@ extern "C" void l2z_runstate_free(l2z_runstate *s)
                     s->pf_att, s->pf_h1, s->pf_stage, s->pf_tokens, s->d_push};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (s->h_stage) (void)hipHostFree(s->h_stage);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
