@@ -25,6 +25,9 @@ public:
     int lookup(std::string_view str) const;
     // :219-282  UTF-8 code points -> tokens, then greedy best-score pair merges
     bool encode(std::string_view input, std::vector<int32_t> *out, std::string *err) const;
+    // the merge loop exactly as the reference writes it (O(n^2)); encode() gives the same tokens
+    bool encode_quadratic(std::string_view input, std::vector<int32_t> *out, std::string *err) const;
+    bool encode_code_points(std::string_view input, std::vector<int32_t> *out, std::string *err) const;
 
 private:
     std::unordered_map<std::string, int> first_index_;  // same answer as the linear scan

@@ -30,6 +30,8 @@ def H(B):  # B builds everything if needed
     L.l2zh_tokenizer_token.restype = C.c_size_t
     L.l2zh_tokenizer_encode.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.c_size_t]
     L.l2zh_tokenizer_encode.restype = C.c_long
+    L.l2zh_tokenizer_encode_quadratic.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.c_size_t]
+    L.l2zh_tokenizer_encode_quadratic.restype = C.c_long
     L.l2zh_is_raw_byte.argtypes = [C.c_char_p, C.c_size_t]
     L.l2zh_prng_floats.argtypes = [C.c_uint64, C.POINTER(C.c_float), C.c_size_t]
     L.l2zh_prng_u64.argtypes = [C.c_uint64, C.c_size_t]
@@ -69,6 +71,36 @@ def test_bpe_reference_vectors(H, tok):
     assert encode(H, tok, "A man dying of thirst is suddenly a mineral water critic?") == \
         [68, 767, 27116, 310, 266, 765, 338, 11584, 263, 1375, 13537, 4094, 11164, 66]
     assert encode(H, tok, "中") == [30275]
+
+
+def test_bpe_fast_form_equals_the_reference_merge_loop(H, tok):
+    """encode() runs the reference's greedy merges (main.zig:247-278: best score, leftmost among equals)
+    off a heap in O(n log n); encode_quadratic() is that loop as written.  Same token ids on English,
+    repeated and random-word text, multi-byte characters, runs of spaces and of one letter (every pair
+    ties), and a 6000-character prompt -- where the loop as written needs about a second."""
+    import time
+    rng = np.random.default_rng(12)
+    words = ["the", "a", "Once", "upon", "time", "there", "was", "little", "girl", "named", "Lily", "mineral", "water",
+             "critic", "æther", "naïve", "中文", "日本語", "🙂", "x", "zzzz", "aaaaaaaa", "  ", "\n", "don't", "1234567890"]
+    words = [w for w in words if encode(H, tok, w) is not None]   # code points the vocabulary has (no raw newline, no emoji)
+    assert len(words) >= 20
+    texts = ["", "a", "aa", "aaa", "a" * 64, " " * 33, "abababababababab", "A man dying of thirst is suddenly a mineral water critic?"]
+    for _ in range(40):
+        k = int(rng.integers(1, 60))
+        texts.append(" ".join(words[int(i)] for i in rng.integers(0, len(words), k)))
+    long_text = " ".join(words[int(i)] for i in rng.integers(0, len(words), 1300))[:6000].rsplit(" ", 1)[0]
+    texts.append(long_text)
+    for t in texts:
+        b = t.encode("utf-8")
+        o1, o2 = (C.c_int32 * (len(b) + 1))(), (C.c_int32 * (len(b) + 1))()
+        n1 = H.l2zh_tokenizer_encode(tok, b, len(b), o1, len(b) + 1)
+        n2 = H.l2zh_tokenizer_encode_quadratic(tok, b, len(b), o2, len(b) + 1)
+        assert n1 == n2 >= 0 and list(o1[:n1]) == list(o2[:n2]), t[:60]
+    b = long_text.encode("utf-8")
+    o = (C.c_int32 * (len(b) + 1))()
+    t0 = time.perf_counter()
+    n = H.l2zh_tokenizer_encode(tok, b, len(b), o, len(b) + 1)
+    assert n > 1000 and time.perf_counter() - t0 < 0.25   # the loop as written: ~1 s
 
 
 def test_tokenizer_edges(H, tok):
