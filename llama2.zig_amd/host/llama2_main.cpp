@@ -338,18 +338,27 @@ int main(int argc, char **argv)
         if (l2z_greedy_begin(s, prompt.data(), (int)prompt_len) != L2Z_OK) return finish(die("greedy_begin"));
         std::vector<int32_t> chunk(64);
         bool alive = true;
+        // tokens per call: the text appears in bursts of one call, so keep a call near 40 ms -- 64 tokens for
+        // the small models, ~9 for the 7B shape (a call costs one stream synchronisation, ~20 us)
+        size_t step = 8;
         while (alive && pos < seq_len) {
             // first token alone so the clock starts where the reference starts it; a prompt of
             // L2Z_PREFILL_MIN_PROMPT tokens or more is asked for in one call so that the library
             // runs its positions as one batched pass (they then print in a burst)
-            int want = pos == 0 ? 1 : (int)std::min<size_t>(chunk.size(), seq_len - pos);
+            int want = pos == 0 ? 1 : (int)std::min<size_t>(step, seq_len - pos);
             if (pos == 0 && prompt_len >= L2Z_PREFILL_MIN_PROMPT && prompt_len <= seq_len) {
                 want = (int)prompt_len;
                 chunk.resize(std::max(chunk.size(), prompt_len));
             }
             int got = 0;
+            const auto tc = std::chrono::steady_clock::now();
             if (l2z_greedy_run(&cfg, s, w, want, chunk.data(), &got) != L2Z_OK) return finish(die("greedy_run"));
             if (got == 0) break;
+            if (pos > 0 && got == want && want >= 4) {
+                const double per = std::chrono::duration<double>(std::chrono::steady_clock::now() - tc).count() / got;
+                const double fit = per > 0.0 ? 0.040 / per : 64.0;
+                step = fit < 4.0 ? 4 : fit > 64.0 ? 64 : (size_t)fit;
+            }
             for (int i = 0; i < got && alive; i++) {
                 alive = emit((size_t)chunk[(size_t)i]);
                 if (alive) pos++;
@@ -363,8 +372,8 @@ int main(int argc, char **argv)
         const char *pf_env = getenv("L2Z_PREFILL");
         bool has_bos = false;
         for (int32_t t : prompt) has_bos = has_bos || t == 1;
-        if (prompt_len >= L2Z_PREFILL_MIN_PROMPT && prompt_len <= seq_len && !has_bos && g_world == 1 &&
-            !(pf_env && atoi(pf_env) == 0)) {
+        if (prompt_len >= L2Z_PREFILL_MIN_PROMPT && prompt_len <= seq_len && !has_bos &&
+            !(pf_env && atoi(pf_env) == 0)) {  // (a shard group without a bulk transport refuses: stepped loop)
             std::vector<int32_t> in(prompt_len);
             in[0] = 1;
             for (size_t i = 1; i < prompt_len; i++) in[i] = prompt[i - 1];
