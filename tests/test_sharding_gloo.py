@@ -121,3 +121,107 @@ def test_sharded_schedule_is_bit_identical(world, tmp_path, ck, orc):
         assert got.argmax(1).tolist() == ref.argmax(1).tolist()
         assert np.array_equal(got, np.load(tmp_path / "rank0.npy"))  # all ranks agree bit for bit
     m.close()
+
+
+def _prefill_worker(rank, world, port, kw, shared, seed, toks, out_dir):
+    """The row-sharded BATCHED prefill (csrc/prefill_host.cpp: prefill_stage / comm_bulk_allgather /
+    bulk_unpack_kernel) for one chunk: every stage ends in a [P, n] matrix whose columns are split over
+    the ranks; a rank's [P, n_loc] block sits contiguously at stage[rank], the blocks are all-gathered and
+    unpacked into the row-major matrix the next stage reads."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = ge.load_package()
+    ck, B = pkg.checkpoint, pkg.binding
+    orc = ge.load_oracle()
+    cfg = ck.Config(**kw)
+    W = ck.carve(cfg, ck.synth_blob(cfg, shared, seed), shared)
+    hs, kv_mul, S, P = cfg.head_size, cfg.kv_mul, cfg.seq_len, len(toks)
+    d0, d1 = B.shard_range(cfg.dim, hs, rank, world)
+    k0, k1 = B.shard_range(cfg.kv_dim, hs, rank, world)
+    h0, h1 = B.shard_range(cfg.hidden_dim, 1, rank, world)
+    v0, v1 = B.shard_range(cfg.vocab_size, 1, rank, world)
+    kc = np.zeros((cfg.n_layers, S, k1 - k0), np.float32)
+    vc = np.zeros((cfg.n_layers, S, k1 - k0), np.float32)
+
+    def gather_unpack(block):
+        """block: this rank's [P, n_loc] -> the [P, world * n_loc] matrix (stage[p] -> columns p * n_loc ..)."""
+        n_loc = block.shape[1]
+        stage = [torch.zeros(P * n_loc) for _ in range(world)]          # [world][P * n_loc], contiguous blocks
+        dist.all_gather(stage, torch.from_numpy(np.ascontiguousarray(block).reshape(-1).copy()))
+        out = np.empty((P, world * n_loc), np.float32)
+        for p in range(world):                                           # bulk_unpack_kernel
+            out[:, p * n_loc:(p + 1) * n_loc] = stage[p].numpy().reshape(P, n_loc)
+        return out
+
+    rows = lambda X, Wm: np.stack([orc.matmul(X[t], Wm) for t in range(P)])   # the oracle's dot products per token
+    x = np.stack([W["token_embedding_table"][t] for t in toks]).astype(np.float32)
+    for l in range(cfg.n_layers):
+        xn = np.stack([orc.rmsnorm(x[t], W["rms_att_weight"][l]) for t in range(P)])
+        q, k, v = rows(xn, W["wq"][l][d0:d1]), rows(xn, W["wk"][l][k0:k1]), rows(xn, W["wv"][l][k0:k1])
+        for t in range(P):
+            for i in range(0, d1 - d0, 2):
+                freq = np.float32(1.0) / np.float32(np.power(np.float32(10000.0), np.float32(i % hs) / np.float32(hs), dtype=np.float32))
+                val = np.float32(t) * freq
+                fcr, fci = np.cos(val, dtype=np.float32), np.sin(val, dtype=np.float32)
+                q[t, i], q[t, i + 1] = q[t, i] * fcr - q[t, i + 1] * fci, q[t, i] * fci + q[t, i + 1] * fcr
+                if i < k1 - k0:
+                    k[t, i], k[t, i + 1] = k[t, i] * fcr - k[t, i + 1] * fci, k[t, i] * fci + k[t, i + 1] * fcr
+        kc[l, :P], vc[l, :P] = k, v
+        att = np.zeros((P, d1 - d0), np.float32)
+        for t in range(P):
+            for hl in range((d1 - d0) // hs):
+                kh = (hl // kv_mul) * hs
+                a = np.array([orc.vector_dot_product(q[t, hl * hs:(hl + 1) * hs], kc[l, u, kh:kh + hs])
+                              / np.sqrt(np.float32(hs)) for u in range(t + 1)], np.float32)
+                a = orc.softmax(a)
+                att[t, hl * hs:(hl + 1) * hs] = orc.vector_weighted_sum_rows(
+                    hs, np.ascontiguousarray(vc[l, :t + 1].reshape(-1)[kh:]), k1 - k0, a)
+        att_full = gather_unpack(att)                                                    # PF_ATT
+        x = gather_unpack(x[:, d0:d1] + rows(att_full, W["wo"][l][d0:d1]))               # PF_WO (res = x[:, d0:d1])
+        xn = np.stack([orc.rmsnorm(x[t], W["rms_ffn_weight"][l]) for t in range(P)])
+        a, b = rows(xn, W["w1"][l][h0:h1]), rows(xn, W["w3"][l][h0:h1])
+        one = np.float32(1.0)
+        h1m = gather_unpack((a * (one / (one + np.exp(-a, dtype=np.float32)))) * b)      # PF_H1
+        x = gather_unpack(x[:, d0:d1] + rows(h1m, W["w2"][l][d0:d1]))                    # PF_W2
+    xf = orc.rmsnorm(x[P - 1], W["rms_final_weight"])
+    lg = np.zeros(cfg.vocab_size, np.float32)
+    lg[v0:v1] = orc.matmul(xf, W["wcls"][v0:v1])
+    parts = [torch.zeros(v1 - v0) for _ in range(world)]
+    dist.all_gather(parts, torch.from_numpy(lg[v0:v1].copy()))
+    np.save(os.path.join(out_dir, f"pf_rank{rank}.npy"), np.concatenate([p.numpy() for p in parts]).astype(np.float32))
+    np.save(os.path.join(out_dir, f"pf_k_rank{rank}.npy"), kc[:, :P])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_prefill_schedule(world, tmp_path, ck, orc):
+    """The stage / staging-block / all-gather / unpack schedule of the row-sharded batched prefill on gloo
+    ranks with the oracle's kernels as the per-rank math: the last position's logits equal the oracle's
+    stepped pass (same dot products in the same order whichever rank owns a row), every rank holds the same
+    logits, and the ranks' key-cache shards tile the unsharded cache."""
+    import torch.multiprocessing as mp
+
+    kw = dict(dim=64, hidden_dim=172, n_layers=2, n_heads=8, n_kv_heads=4, vocab_size=512, seq_len=16)
+    shared, seed, toks = False, 78, [1, 40, 300, 7, 9, 11, 500]
+    cfg = ck.Config(**kw)
+    mp.spawn(_prefill_worker, args=(world, _free_port(), kw, shared, seed, toks, str(tmp_path)), nprocs=world, join=True)
+    m = orc.Model(cfg.as_i32(), ck.synth_blob(cfg, shared, seed), shared)
+    ref = None
+    for p, t in enumerate(toks):
+        ref = m.transformer(t, p)
+    for r in range(world):
+        got = np.load(tmp_path / f"pf_rank{r}.npy")
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5)
+        assert int(got.argmax()) == int(ref.argmax())
+        assert np.array_equal(got, np.load(tmp_path / "pf_rank0.npy"))
+    kvl = cfg.kv_dim // world
+    full_k = np.concatenate([np.load(tmp_path / f"pf_k_rank{r}.npy") for r in range(world)], axis=2)
+    assert full_k.shape == (cfg.n_layers, len(toks), cfg.kv_dim) and kvl * world == cfg.kv_dim
+    assert np.isfinite(full_k).all() and float(np.abs(full_k).max()) > 0
+    m.close()
