@@ -32,11 +32,12 @@ struct Tunables {
                                //                     them; sharded prefill); default: longest vector x chunk tokens
     // --- batched prefill (prefill_host.cpp, prefill_*.hip) ---
     int prefill = 1;           // L2Z_PREFILL         0: prompts are stepped token by token
-    int pf_chunk = 0;          // L2Z_PF_CHUNK        tokens per chunk (0: default)
+    int pf_chunk = 0;          // L2Z_PF_CHUNK        tokens per chunk, fixed (0: 1024 while that many remain, then 512, then the rest)
     int pf_skinny_form = 1;    // L2Z_PF_SKINNY_FORM  short-prompt GEMM: 1 LDS-staged (direct-to-LDS ring where K % 256 == 0), 2 register-staged LDS form only, 0 no LDS
-    int pf_tile = 0;           // L2Z_PF_TILE
-    int pf_skinny_max = -1;    // L2Z_PF_SKINNY_MAX
-    int pf_skinny_tms = 0;     // L2Z_PF_SKINNY_TMS
+    int pf_tile = 0;           // L2Z_PF_TILE         force a tile form of the prefill GEMM (experiments: 2 64x64, 8 128x64, 9 32x64, 10 32x32, 11 128x128;
+                               //                     disables the paired / fused launches); 0: chosen by grid fill
+    int pf_skinny_max = -1;    // L2Z_PF_SKINNY_MAX   longest chunk that takes the short-prompt GEMMs (default 64 tokens)
+    int pf_skinny_tms = 0;     // L2Z_PF_SKINNY_TMS   token tiles (of 16) per block of the short-prompt GEMM: 1, 2, 4 (register form); 0: by prompt length
     int pf_attn = 1;           // L2Z_PF_ATTN         0: per-query prefill attention only; 2: the LDS-softmax tiled kernel instead of the flash form; 3: flash form with one key part (4 waves)
     int pf_dma = 1;            // L2Z_PF_DMA          0: GEMM operands staged through registers instead of direct-to-LDS loads
     int pf_order = 1;          // L2Z_PF_ORDER        0: 2-D grids for the tile GEMM (x = feature tile, y = token tile)
