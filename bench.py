@@ -9,23 +9,31 @@ device.  Weights are already resident in HBM when the timed region starts
 
   python bench.py                       # N=1, llama2-7b shape, 255 steps after 1 warm-up
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N   # rows/heads sharded over N GPUs (RCCL, strong scaling)
+         --master-port P bench.py --gpus N   # rows/heads sharded over N GPUs (strong scaling)
 
 The default (steps=255, warmup=1) is exactly the reference's `-n 256 -t 0 -v`
 figure: its clock starts after the first token and the rate is (pos-1)/elapsed
 (src/main.zig:1039-1047).
 
-Rank 0 prints ONE JSON line.  It carries `roofline` for the dominant kernel
-(HIP-event time measured in situ by l2z_profile_forward) and, at N=1,
-`cpu_baseline`: the C oracle (a port, 1 thread -- the reference is single
-threaded, main.zig:5 / README.md:107) timed on this box's host cores on a
-bounded sample of the same workload.
+Rank 0 prints ONE JSON line.  It carries `roofline` for the dominant kernel and, at N=1,
+`cpu_baseline`: the C oracle (a port, 1 thread -- the reference is single threaded, main.zig:5 /
+README.md:107) timed on this box's host cores on a bounded sample of the same workload.
+
+N > 1.  The per-layer all-gathers have three transports and nothing but a real
+multi-GPU node can rank them, so the run times EVERY one of them as its own "leg" -- the same K
+steps, the same barriers, the cross-rank logits check -- and the headline is the fastest leg whose
+ranks agree; all legs are reported in `comm.legs`.  Each leg runs in a child process per rank
+(`bench.py --leg T`), so that a transport that faults on this node (a peer store into an IPC
+mapping, an RCCL abort) costs its own leg, not the whole line.  The RCCL leg always initialises an
+N-rank communicator and reports the rank count RCCL itself returns (`comm.rccl`).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,6 +45,14 @@ import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E vendor peak (MI355X_MICROARCH.md); ~6300 measured copy
 MFMA_F32_PEAK_TF = 157.3  # dense fp32 matrix peak (256 CUs x 256 flop/clk x 2.4 GHz)
+
+LEGS = ["rccl", "p2p-gather", "p2p-consume"]  # run in this order: the library collective first
+LEG_TEXT = {
+    "p2p-consume": "peer writes of LL words over IPC-mapped memory (xGMI), polled by the consuming "
+                   "mat-vec (no gather launch)",
+    "p2p-gather": "peer writes over IPC-mapped memory (xGMI) + a gather launch per vector",
+    "rccl": "RCCL ncclAllGather per vector, captured in the step graph",
+}
 
 
 def weight_bytes_by_kind(cfg, world: int = 1) -> dict:
@@ -53,22 +69,35 @@ def weight_bytes_by_kind(cfg, world: int = 1) -> dict:
     }
 
 
-def cpu_baseline(ck, cfg, shared, name: str) -> dict:
-    """Time the C oracle (port of src/main.zig, 1 thread) on a bounded sample."""
+def weight_bytes_per_token(cfg, world: int = 1) -> int:
+    wb = weight_bytes_by_kind(cfg, world)
+    return sum(wb[k] * (1 if k == "cls" else cfg.n_layers) for k in wb)
+
+
+def cpu_baseline_small(ck, cfg, shared, name: str, n_tok: int = 64) -> dict:
+    """The C oracle (port of src/main.zig, 1 thread) on a whole small model: n_tok greedy tokens."""
     orc = ge.load_oracle()
     orc.set_mode(8, True, True)  # AVX2 width, fused -- the fastest reading of the reference
     ncpu = os.cpu_count() or 1
+    blob = orc.synth_fill(cfg.as_i32(), shared, 1, ncpu)
+    m = orc.Model(cfg.as_i32(), blob, shared)
+    m.transformer(1, 0)  # page everything in once
+    t0 = time.perf_counter()
+    toks, _ = m.generate_greedy([], n_tok)
+    dt = time.perf_counter() - t0
+    m.close()
+    return {"value": len(toks) / dt, "unit": "tokens/s", "cores": 1, "kind": "port",
+            "sample": f"{name}: full model, {len(toks)} greedy tokens from BOS, C oracle "
+                      f"(oracle/llama2_oracle.c, gcc -O3 AVX2+FMA), 1 thread of {ncpu}"}
+
+
+def cpu_baseline(ck, cfg, shared, name: str) -> dict:
+    """Time the C oracle (port of src/main.zig, 1 thread) on a bounded sample."""
+    orc = ge.load_oracle()
+    orc.set_mode(8, True, True)
+    ncpu = os.cpu_count() or 1
     if cfg.n_layers <= 12 and ck.weights_count(cfg, shared) * 4 < (1 << 30):
-        blob = orc.synth_fill(cfg.as_i32(), shared, 1, ncpu)
-        m = orc.Model(cfg.as_i32(), blob, shared)
-        n_tok = 64
-        t0 = time.perf_counter()
-        toks, _ = m.generate_greedy([], n_tok)
-        dt = time.perf_counter() - t0
-        m.close()
-        return {"value": len(toks) / dt, "unit": "tokens/s", "cores": 1, "kind": "port",
-                "sample": f"{name}: full model, {len(toks)} greedy tokens from BOS, C oracle "
-                          f"(oracle/llama2_oracle.c, gcc -O3 AVX2+FMA), 1 thread of {ncpu}"}
+        return cpu_baseline_small(ck, cfg, shared, name)
     # big shape, big host: the real thing -- the full model on one host thread for a dozen tokens
     # (BASELINE.md's plan: "7B on CPU uses -n 16"); the multi-threaded fill is not timed
     try:
@@ -115,11 +144,12 @@ def cpu_baseline(ck, cfg, shared, name: str) -> dict:
 
 
 def run_once(B, cfg, shared, seed, steps, warmup, comm=None, sync_ok=None):
-    """Returns (tokens produced in the timed region, elapsed seconds, runstate, weights).
+    """Returns (tokens produced in the timed region, elapsed seconds on this rank, runstate, weights).
 
     sync_ok(ok) -> bool is the multi-rank barrier: every rank reports whether its phase worked and
     learns whether all did, so that a failure on one rank makes ALL ranks raise here instead of
-    leaving the others waiting in a barrier."""
+    leaving the others waiting in a barrier.  The timed region: barrier, t0, K steps, stream
+    synchronise, t1 (the caller takes the max over ranks), barrier."""
     sync_ok = sync_ok or (lambda ok: ok)
     s = w = None
     err = None
@@ -139,80 +169,286 @@ def run_once(B, cfg, shared, seed, steps, warmup, comm=None, sync_ok=None):
         raise RuntimeError(f"set-up / warm-up failed on some rank ({err})")
     t0 = time.perf_counter()
     toks = ()
+    dt = 0.0
     try:
         toks = s.greedy_run(w, steps)  # synchronises before returning the tokens
         s.synchronize()
+        dt = time.perf_counter() - t0
     except Exception as e:  # noqa: BLE001
         err = e
     ok = sync_ok(err is None)
-    dt = time.perf_counter() - t0
     if not ok:
         s.close(); w.close()
         raise RuntimeError(f"timed region failed on some rank ({err})")
     return len(toks), dt, s, w
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=255)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="llama2-7b",
-                    choices=["llama2-7b", "stories110M", "stories15M"])
-    ap.add_argument("--seed", type=int, default=2024)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the stories15M side measurement")
-    args = ap.parse_args()
+def profile_kinds(B, s, w, cfg, pos0: int, n_prof: int = 4) -> dict:
+    """Per-kind device time by a HIP event pair around every launch, in situ (l2z_profile_forward)."""
+    by_kind = {k: [0.0, 0] for k in B.KINDS}
+    for i in range(n_prof):
+        p = min(pos0 + i, cfg.seq_len - 1)
+        for k, (ms, cnt) in s.profile_forward(1 + i, p, w).items():
+            by_kind[k][0] += ms
+            by_kind[k][1] += cnt
+    return by_kind
+
+
+def roofline_of(B, s, w, cfg, world, by_kind, n_prof, pos0, workload, n_tok, dt) -> tuple[dict, float | None]:
+    """The bench line's `roofline` object for the dominant mat-vec kind, and the stream-read probe's
+    average rate (GB/s) for the comm record."""
+    wb = weight_bytes_by_kind(cfg, world)
+    dom = max(wb, key=lambda k: by_kind[k][0])
+    avg_ms = by_kind[dom][0] / max(by_kind[dom][1], 1)
+    timing = "HIP event pair around every launch, in situ (adds ~3 us per launch)"
+    b2b = {}
+    if world == 1:
+        # kernel durations without the per-launch event overhead: every layer's launch of one kind back to
+        # back between ONE event pair (l2z_time_kind) -- what rocprofv3's kernel trace reports as well
+        try:
+            for k in B.KINDS[:7]:
+                if by_kind[k][1]:
+                    ms_k, n_k = s.time_kind(k, min(pos0, cfg.seq_len - 16), w, reps=4)
+                    b2b[k] = {"ms_per_launch": ms_k, "launches_timed": n_k,
+                              "GBps": wb[k] / (ms_k * 1e-3) / 1e9 if k in wb and ms_k > 0 else None}
+            if dom in b2b:
+                avg_ms = b2b[dom]["ms_per_launch"]
+                timing = ("one HIP event pair around the launches of this kind for all layers back to back, "
+                          "4 passes (l2z_time_kind): average kernel duration, no per-launch event overhead")
+        except Exception as e:  # noqa: BLE001
+            b2b = {"error": str(e)}
+    achieved = wb[dom] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # HBM traffic per launch: PMC counters cannot be read from inside this process; the figure is the one
+    # the committed rocprofv3 --pmc passes gave for this kernel (scripts/pmc_traffic.sh), and says so
+    traffic, traffic_source = None, None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath) and world == 1:  # the PMC passes were taken unsharded
+        try:
+            traffic = json.load(open(tpath)).get(workload, {}).get(dom)
+            if traffic is not None:
+                traffic_source = ("profiles/pmc_traffic.json: replayed from the committed rocprofv3 --pmc "
+                                  "passes of this kernel (scripts/pmc_traffic.sh), NOT read in this run")
+        except Exception:
+            traffic = None
+    kernels = {k: {"ms_per_launch": by_kind[k][0] / max(by_kind[k][1], 1),
+                   "launches_per_token": by_kind[k][1] // n_prof,
+                   "GBps": (wb[k] / (by_kind[k][0] / max(by_kind[k][1], 1) * 1e-3) / 1e9)
+                   if k in wb and by_kind[k][0] > 0 else None}
+               for k in B.KINDS}
+    # a plain streaming-read kernel over the same resident weights, in pieces the size of the dominant
+    # launch (SURVEY.md 8d "a measured device stream on the same box"): context, not a ceiling -- the
+    # mat-vec's lock-step row sweep reads faster than this probe's strided sweep
+    try:
+        rd_avg, rd_best = s.stream_read_probe(w, wb[dom], 12)
+    except Exception:
+        rd_avg = rd_best = None
+    bytes_tok = weight_bytes_per_token(cfg, world)
+    whole = bytes_tok / (dt / n_tok) / 1e9 if dt > 0 and n_tok else 0.0
+    roofline = {"bound": "hbm", "kernel": f"matvec[{dom}]", "achieved": achieved,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_source": traffic_source,
+                "algorithmic_bytes_per_launch": wb[dom],
+                "avg_launch_ms": avg_ms, "timing": timing,
+                "whole_token_GBps": whole, "whole_token_frac": whole / HBM_PEAK_GBS,
+                "whole_token_note": "this rank's weight bytes per token / ms_per_step: every launch, "
+                                    "attention and the gaps between them included",
+                "by_kind_back_to_back": b2b, "by_kind": kernels,
+                "stream_read_probe": {"avg": rd_avg, "best": rd_best, "unit": "GB/s",
+                                      "matvec_over_probe": (achieved / rd_avg) if rd_avg else None,
+                                      "note": "plain nt-load kernel over the resident weights, slices of the "
+                                              "dominant launch's size; NOT a ceiling (the mat-vec's row sweep "
+                                              "beats it): a same-box reference point beside the 8 TB/s spec"}}
+    return roofline, rd_avg
+
+
+def workload_text(args, cfg) -> str:
+    return (f"{args.workload} shape, fp32 llama2.c-v0 checkpoint (dim {cfg.dim}, hidden {cfg.hidden_dim}, "
+            f"L {cfg.n_layers}, H {cfg.n_heads}, kv {cfg.n_kv_heads}, V {cfg.vocab_size}, S {cfg.seq_len}), "
+            "greedy from BOS, seeded synthetic weights")
+
+
+# --------------------------------------------------------------------------------------------------
+# N = 1
+# --------------------------------------------------------------------------------------------------
+def single_gpu(args) -> None:
+    pkg = ge.load_package()
+    B, ck = pkg.binding, pkg.checkpoint
+    shapes = {n: (c, sh) for n, c, sh in ck.iter_configs()}
+    cfg, shared = shapes[args.workload]
+    steps = max(1, min(args.steps, cfg.seq_len - args.warmup))
+    if B.device_count() < 1:
+        raise SystemExit("bench.py: no HIP device visible (the HIP path has no CPU fallback)")
+    n_tok, dt, s, w = run_once(B, cfg, shared, args.seed, steps, args.warmup, None, None)
+    n_prof = 4
+    pos0 = args.warmup + n_tok
+    by_kind = profile_kinds(B, s, w, cfg, pos0, n_prof)
+    roofline, _ = roofline_of(B, s, w, cfg, 1, by_kind, n_prof, pos0, args.workload, n_tok, dt)
+
+    # ---- batched prompt prefill (SURVEY.md 8f row 4): the MFMA-bound part, reported beside the
+    # decode figure, never folded into `value`
+    prefill = None
+    if not args.no_extra:
+        try:
+            n_p = min(512, cfg.seq_len - 1)
+            toks = [1] + np.random.default_rng(args.seed).integers(2, cfg.vocab_size, n_p - 1).tolist()
+            flops_tok = 2.0 * (cfg.n_layers * (2 * cfg.dim * cfg.dim + 2 * cfg.dim * cfg.kv_dim
+                                               + 3 * cfg.dim * cfg.hidden_dim))
+
+            def time_prefill(n, reps=3):
+                s.prefill(toks[:n], 0, w)  # allocations, first-touch
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    s.prefill(toks[:n], 0, w)  # synchronises
+                return (time.perf_counter() - t0) / reps
+            dtp = time_prefill(n_p)
+            prefill = {"prompt_tokens": n_p, "ms": dtp * 1e3, "tokens_per_s": n_p / dtp,
+                       "roofline": {"bound": "mfma", "achieved": flops_tok * n_p / dtp / 1e12, "peak": MFMA_F32_PEAK_TF,
+                                    "unit": "TFLOP/s", "frac": flops_tok * n_p / dtp / 1e12 / MFMA_F32_PEAK_TF,
+                                    "note": "whole prefill (GEMMs + attention + norms), GEMM flops only "
+                                            "in the numerator; v_mfma_f32_32x32x2_f32"}}
+            # shorter prompts: other kernels (<= 64 tokens: weight-streaming bound short-prompt GEMMs; 65-256:
+            # smaller tiles so that every CU has a block) -- ms per prompt length, with the bound that applies
+            by_len, frac_by_len = {}, {}
+            bytes_tok = weight_bytes_per_token(cfg)
+            for n_s in (16, 64, 128):
+                if n_s < cfg.seq_len:
+                    d = time_prefill(n_s)
+                    by_len[str(n_s)] = d * 1e3
+                    frac_by_len[str(n_s)] = ({"bound": "hbm", "frac": bytes_tok / d / 1e9 / HBM_PEAK_GBS} if n_s <= 64 else
+                                             {"bound": "mfma", "frac": flops_tok * n_s / d / 1e12 / MFMA_F32_PEAK_TF})
+            prefill["ms_by_prompt_tokens"] = by_len
+            prefill["frac_by_prompt_tokens"] = frac_by_len
+        except Exception as e:  # noqa: BLE001
+            prefill = {"error": str(e)}
+    s.close()
+    w.close()
+
+    out = {
+        "metric": "tokens/s (argmax, -t 0)", "value": n_tok / dt, "unit": "tokens/s",
+        "n_gpus": 1, "steps": n_tok, "warmup": args.warmup,
+        "ms_per_step": dt / n_tok * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload_text(args, cfg), "parallelism": "1 GPU", "ranks_agree": None,
+                   "weight_bytes_per_token": weight_bytes_per_token(cfg)},
+        "roofline": roofline,
+    }
+    if not args.no_extra and args.workload != "stories15M":
+        c15, sh15 = shapes["stories15M"]
+        n15, dt15, s15, w15 = run_once(B, c15, sh15, args.seed, 255, 1)
+        s15.close(); w15.close()
+        # stories110M (BASELINE config 3's shape): 438 MB of weights per token do not fit the
+        # 256 MB Infinity Cache, so an HBM fraction is meaningful, though launch latency dominates
+        c110, sh110 = shapes["stories110M"]
+        n110, dt110, s110, w110 = run_once(B, c110, sh110, args.seed, 255, 1)
+        s110.close(); w110.close()
+        bytes110 = weight_bytes_per_token(c110)
+        # long context on the headline shape: the prompt fills the cache through the batched
+        # prefill, then 32 greedy positions near the end of the 2048-token context are timed
+        long_ctx = None
+        if args.workload == "llama2-7b":
+            try:
+                w7 = B.Weights(cfg, None, shared, seed=args.seed)
+                s7 = B.RunState(cfg)
+                n_p = cfg.seq_len - 48
+                prompt = np.random.default_rng(1).integers(2, cfg.vocab_size, n_p).tolist()
+                s7.greedy_begin(prompt)
+                s7.greedy_run(w7, n_p + 8)  # prefill + 8 warm-up positions
+                s7.synchronize()
+                t0 = time.perf_counter()
+                n_l = len(s7.greedy_run(w7, 32))
+                s7.synchronize()
+                dtl = time.perf_counter() - t0
+                pr = s7.profile_forward(1, cfg.seq_len - 1, w7)
+                kv_bytes = 8 * cfg.n_layers * (cfg.seq_len - 24) * cfg.kv_dim
+                ms_at, _ = s7.time_kind("attn", cfg.seq_len - 1, w7, reps=4)
+                long_ctx = {"positions": [n_p + 8, n_p + 8 + n_l - 1], "tokens_per_s": n_l / dtl,
+                            "ms_per_token": dtl / n_l * 1e3,
+                            # an event pair per launch adds ~3 us to each; the back-to-back figure is the
+                            # one comparable with rocprofv3's kernel durations
+                            "attention_us_per_layer_at_last_pos": pr["attn"][0] / max(pr["attn"][1], 1) * 1e3,
+                            "attention_us_per_layer_back_to_back": ms_at * 1e3,
+                            "kv_bytes_per_token": kv_bytes,
+                            "hbm_frac_incl_kv": (out["config"]["weight_bytes_per_token"] + kv_bytes)
+                                                / (dtl / n_l) / 1e9 / HBM_PEAK_GBS}
+                s7.close(); w7.close()
+            except Exception as e:  # noqa: BLE001
+                long_ctx = {"error": str(e)}
+        out["extra"] = {"prefill": prefill,
+                        "stories110M": {"tokens_per_s": n110 / dt110, "steps": n110,
+                                        "weight_bytes_per_token": bytes110,
+                                        "hbm_frac": bytes110 / (dt110 / n110) / 1e9 / HBM_PEAK_GBS},
+                        "long_context": long_ctx,
+                        "stories15M_tokens_per_s": n15 / dt15, "stories15M_steps": n15,
+                        # the only figure the reference publishes (BASELINE.md): 660 tok/s, -t 0,
+                        # stories15M, one Ryzen 9 5900X core, Zig 0.11 -- other hardware, indicative
+                        "stories15M_vs_reference_readme_660": (n15 / dt15) / 660.0,
+                        "note": "stories15M shape, -t 0 -n 256; weights fit the on-die "
+                                "cache, launch/latency bound, no HBM fraction quoted"}
+        if not args.no_cpu_baseline:
+            # BASELINE config 1 (the reference's own CPU-runnable case) and config 3's shape on THIS box's
+            # host cores: the C oracle, 1 thread, 64 greedy tokens -- beside the GPU figures above
+            try:
+                by_shape = {}
+                for nm, (c_, sh_), gpu_tps in (("stories15M", shapes["stories15M"], n15 / dt15),
+                                               ("stories110M", shapes["stories110M"], n110 / dt110)):
+                    b = cpu_baseline_small(ck, c_, sh_, nm, 64)
+                    b["gpu_tokens_per_s"] = gpu_tps
+                    by_shape[nm] = b
+                out["extra"]["cpu_baseline_by_shape"] = by_shape
+            except Exception as e:  # noqa: BLE001
+                out["extra"]["cpu_baseline_by_shape"] = {"error": str(e)}
+    elif not args.no_extra:
+        out["extra"] = {"prefill": prefill}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(ck, cfg, shared, args.workload)
+    print(json.dumps(out), flush=True)
+
+
+# --------------------------------------------------------------------------------------------------
+# N > 1: one leg = one transport, run by a child process per rank
+# --------------------------------------------------------------------------------------------------
+def leg_main(args) -> int:
+    """Child of a multi-rank run: this rank's part of ONE leg.  Rank 0 prints the leg's full bench
+    line (one JSON object) on stdout; exit code 0 only if the leg ran and the ranks agree."""
+    kind = args.leg
+    world = int(os.environ["WORLD_SIZE"])
+    rank = int(os.environ["RANK"])
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # a peer that never shows up must fail the peer-write attempt quickly (ranks are within a second of
+    # each other after the handshake)
+    os.environ.setdefault("L2Z_P2P_TIMEOUT_S", "8")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (the only kind the host driver has)
+    # torch is imported BEFORE libllama2_hip.so is loaded: the other order leaves HIP without a visible
+    # device on this image (measured on the MI355X box)
+    import torch
+    import torch.distributed as dist
+    # control plane only (barrier, handle/id exchange, max-reduce of the clock): gloo on CPU.
+    # The data path's all-gathers are issued by libllama2_hip.so itself.
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{args.leg_port}", rank=rank, world_size=world)
 
     pkg = ge.load_package()
     B, ck = pkg.binding, pkg.checkpoint
     shapes = {n: (c, sh) for n, c, sh in ck.iter_configs()}
     cfg, shared = shapes[args.workload]
     steps = max(1, min(args.steps, cfg.seq_len - args.warmup))
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    comm, dist = None, None
-    transport = None
-    force_dist = os.environ.get("L2Z_BENCH_FORCE_DIST") == "1"  # 1-rank RCCL + gloo, for testing
-    if args.gpus > 1 or world > 1 or force_dist:
-        if world != args.gpus:
-            raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with "
-                             "python -m torch.distributed.run --nproc-per-node N ...)")
-        # torch is imported BEFORE libllama2_hip.so is loaded: the other order leaves HIP
-        # without a visible device on this image (measured on the MI355X box)
-        # a peer that never shows up must fail the peer-write attempt quickly, so that the RCCL
-        # fallback still fits the run (ranks are within a second of each other after the handshake)
-        os.environ.setdefault("L2Z_P2P_TIMEOUT_S", "8")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (the only kind the host driver has)
-        import torch
-        import torch.distributed as dist
-        # control plane only (barrier, handle/id exchange, max-reduce of the clock): gloo on CPU.
-        # The data path's all-gathers are issued by libllama2_hip.so itself.
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-
     if B.device_count() < 1:
         raise SystemExit("bench.py: no HIP device visible (the HIP path has no CPU fallback)")
     n_dev = B.device_count()
     device = local_rank % n_dev  # several ranks on one GPU only happens in tests
-    if world > n_dev:
-        # ranks share a chip: a mat-vec launch that may be polling for a peer's words must leave the
-        # peer's kernels room to run (never needed with a GPU per rank).  Measured: with more than
-        # 512 polling blocks in total (2 per CU) a peer's producer can be left without a slot and the
-        # waits time out; the gather-launch form needs no cap (L2Z_COMM=p2p-gather L2Z_GRID_CAP=0)
-        shared_cap = max(32, 512 // ((world + n_dev - 1) // n_dev))
-    else:
-        shared_cap = 0
+    # ranks sharing a chip: a mat-vec launch that may be polling for a peer's words must leave the peer's
+    # kernels room to run (never needed with a GPU per rank).  Measured: with more than 512 polling blocks
+    # in total (2 per CU) a peer's producer can be left without a slot and the waits time out; the
+    # gather-launch form needs no cap
+    shared_cap = max(32, 512 // ((world + n_dev - 1) // n_dev)) if world > n_dev else 0
 
     def all_ok(ok: bool) -> bool:
         flags = [None] * world
         dist.all_gather_object(flags, bool(ok))
         return all(flags)
 
-    def make_comm(kind: str):
-        """'p2p': peer-write gathers over IPC-mapped arenas (xGMI between GPUs); 'rccl': RCCL."""
-        if kind == "p2p":
+    def make_comm():
+        """p2p legs: peer-write gathers over IPC-mapped arenas (xGMI between GPUs); rccl leg: RCCL."""
+        if kind != "rccl":
             c, h = None, b""
             try:
                 c = B.Comm(rank, world, None, device)
@@ -259,149 +495,45 @@ def main() -> None:
         dist.all_gather_object(sigs, sig)
         return all(x == sigs[0] for x in sigs) and bool(np.isfinite(lg).all())
 
-    agree = None
-    attempts = []
-    if dist is not None:
-        # Transports for the per-layer gathers, best first.  A form that cannot be set
-        # up, times out, or leaves the ranks with different logits is dropped for the next one.
-        #   p2p-consume  producers store LL words into every rank's landing slot, consumers poll
-        #                them while staging x: 5 graph nodes per layer, one gather launch per token
-        #   p2p-gather   the same stores, collected by a gather launch per vector (9 nodes per layer)
-        #   rccl         ncclAllGather per vector, captured into the step graph when that works
-        want = os.environ.get("L2Z_COMM", "")
-        order = {"": ["p2p-consume", "p2p-gather", "rccl"], "p2p": ["p2p-consume", "p2p-gather", "rccl"],
-                 "p2p-consume": ["p2p-consume"], "p2p-gather": ["p2p-gather"], "rccl": ["rccl"]}[want]
-        if force_dist:
-            order = ["rccl"]
-        for kind in order:
-            B.option_set("L2Z_P2P_CONSUME", 1 if kind == "p2p-consume" else 0)
-            B.option_set("L2Z_GRID_CAP", shared_cap if kind == "p2p-consume" else 0)
-            B.option_set("L2Z_COMM_RCCL", 1 if kind == "rccl" else 0)
-            comm = make_comm("rccl" if kind == "rccl" else "p2p")
-            if comm is None:
-                attempts.append({"transport": kind, "ok": False, "why": "set-up failed"})
-                continue
-            transport = kind
-            s = w = None
-            try:
-                n_tok, dt, s, w = run_once(B, cfg, shared, args.seed, steps, args.warmup, comm, all_ok)
-                ran = True
-            except Exception as e:  # noqa: BLE001  (a gather timed out, a launch failed, ...)
-                print(f"[rank {rank}] run with transport {transport} failed: {e}", file=sys.stderr)
-                ran = False
-            agree = ranks_agree(s) if all_ok(ran) else False
-            attempts.append({"transport": kind, "ok": bool(agree), "why": None if agree else
-                             ("ranks disagree" if ran else "run failed")})
-            if agree:
-                break
-            print(f"[rank {rank}] transport {transport} unusable here (ran={ran}); trying the next one",
-                  file=sys.stderr)
-            for o in (s, w, comm):
-                if o is not None:
-                    o.close()
-            comm = None
-        if comm is None:
-            raise SystemExit(f"bench.py: no working transport for the shard group: {attempts}")
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    else:
-        n_tok, dt, s, w = run_once(B, cfg, shared, args.seed, steps, args.warmup, None, None)
+    def fail(why: str) -> int:
+        if rank == 0:
+            print(json.dumps({"leg": {"transport": kind, "ok": False, "why": why}}), flush=True)
+        dist.destroy_process_group()
+        return 3
 
-    # ---- roofline of the dominant kernel, HIP events in situ ----
-    by_kind = {k: [0.0, 0] for k in B.KINDS}
-    pos0 = args.warmup + n_tok
-    n_prof = 4
-    for i in range(n_prof):
-        p = min(pos0 + i, cfg.seq_len - 1)
-        for k, (ms, cnt) in s.profile_forward(1 + i, p, w).items():
-            by_kind[k][0] += ms
-            by_kind[k][1] += cnt
-    wb = weight_bytes_by_kind(cfg, world)
-    dom = max(wb, key=lambda k: by_kind[k][0])
-    avg_ms = by_kind[dom][0] / max(by_kind[dom][1], 1)
-    timing = "HIP event pair around every launch, in situ (adds ~3 us per launch)"
-    b2b = {}
-    if world == 1:
-        # kernel durations without the per-launch event overhead: every layer's launch of one kind back to
-        # back between ONE event pair (l2z_time_kind) -- what rocprofv3's kernel trace reports as well
-        try:
-            for k in B.KINDS[:7]:
-                if by_kind[k][1]:
-                    ms_k, n_k = s.time_kind(k, min(pos0, cfg.seq_len - 16), w, reps=4)
-                    b2b[k] = {"ms_per_launch": ms_k, "launches_timed": n_k,
-                              "GBps": wb[k] / (ms_k * 1e-3) / 1e9 if k in wb and ms_k > 0 else None}
-            if dom in b2b:
-                avg_ms = b2b[dom]["ms_per_launch"]
-                timing = ("one HIP event pair around the launches of this kind for all layers back to back, "
-                          "4 passes (l2z_time_kind): average kernel duration, no per-launch event overhead")
-        except Exception as e:  # noqa: BLE001
-            b2b = {"error": str(e)}
-    achieved = wb[dom] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath) and world == 1:  # the PMC passes were taken unsharded
-        try:
-            traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
-        except Exception:
-            traffic = None
-    kernels = {k: {"ms_per_launch": by_kind[k][0] / max(by_kind[k][1], 1),
-                   "launches_per_token": by_kind[k][1] // n_prof,
-                   "GBps": (wb[k] / (by_kind[k][0] / max(by_kind[k][1], 1) * 1e-3) / 1e9)
-                   if k in wb and by_kind[k][0] > 0 else None}
-               for k in B.KINDS}
-    # the measured ceiling on this box: a pure streaming-read kernel over the same resident
-    # weights, in pieces the size of the dominant launch -- context, not the peak
+    B.option_set("L2Z_P2P_CONSUME", 1 if kind == "p2p-consume" else 0)
+    B.option_set("L2Z_GRID_CAP", shared_cap if kind == "p2p-consume" else 0)
+    B.option_set("L2Z_COMM_RCCL", 1 if kind == "rccl" else 0)
+    comm = make_comm()
+    if comm is None:
+        return fail("set-up failed")
+    tr = comm.transports()
+    trs = [None] * world
+    dist.all_gather_object(trs, tr)
+    s = w = None
     try:
-        rd_avg, rd_best = s.stream_read_probe(w, wb[dom], 12)
-    except Exception:
-        rd_avg = rd_best = None
-    roofline = {"bound": "hbm", "kernel": f"matvec[{dom}]", "achieved": achieved,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "algorithmic_bytes_per_launch": wb[dom],
-                "avg_launch_ms": avg_ms, "timing": timing, "by_kind_back_to_back": b2b,
-                "by_kind": kernels,
-                "measured_stream_read": {"avg": rd_avg, "best": rd_best, "unit": "GB/s",
-                                         "frac_of_measured": (achieved / rd_avg) if rd_avg else None,
-                                         "note": "pure nt-load kernel over the resident weights, "
-                                                 "slices of the dominant launch's size"}}
-    # ---- batched prompt prefill: the MFMA-bound part, reported beside the
-    # decode figure, never folded into `value`
-    prefill = None
-    if rank == 0 and world == 1 and not args.no_extra:
-        try:
-            n_p = min(512, cfg.seq_len - 1)
-            toks = [1] + np.random.default_rng(args.seed).integers(2, cfg.vocab_size, n_p - 1).tolist()
-            s.prefill(toks, 0, w)  # allocations, first-touch
-            t0 = time.perf_counter()
-            reps = 3
-            for _ in range(reps):
-                s.prefill(toks, 0, w)  # synchronises
-            dtp = (time.perf_counter() - t0) / reps
-            flops = 2.0 * n_p * (cfg.n_layers * (2 * cfg.dim * cfg.dim + 2 * cfg.dim * cfg.kv_dim
-                                                 + 3 * cfg.dim * cfg.hidden_dim))
-            prefill = {"prompt_tokens": n_p, "ms": dtp * 1e3, "tokens_per_s": n_p / dtp,
-                       "roofline": {"bound": "mfma", "achieved": flops / dtp / 1e12, "peak": MFMA_F32_PEAK_TF,
-                                    "unit": "TFLOP/s", "frac": flops / dtp / 1e12 / MFMA_F32_PEAK_TF,
-                                    "note": "whole prefill (GEMMs + attention + norms), GEMM flops only "
-                                            "in the numerator; v_mfma_f32_32x32x2_f32"}}
-            # shorter prompts: other kernels (<= 64 tokens: weight-streaming bound short-prompt GEMMs; 65-256:
-            # smaller tiles so that every CU has a block) -- ms per prompt length
-            by_len = {}
-            for n_s in (16, 128):
-                if n_s < cfg.seq_len:
-                    s.prefill(toks[:n_s], 0, w)
-                    t0 = time.perf_counter()
-                    for _ in range(3):
-                        s.prefill(toks[:n_s], 0, w)
-                    by_len[str(n_s)] = (time.perf_counter() - t0) / 3 * 1e3
-            prefill["ms_by_prompt_tokens"] = by_len
-        except Exception as e:  # noqa: BLE001
-            prefill = {"error": str(e)}
-    # sharded runstates: the row-sharded prefill (every rank its column blocks, [tokens, n / world] blocks
-    # exchanged through the bulk regions / RCCL) -- a diagnostic beside the decode figure, like the above
+        n_tok, dt, s, w = run_once(B, cfg, shared, args.seed, steps, args.warmup, comm, all_ok)
+        ran = True
+    except Exception as e:  # noqa: BLE001  (a gather timed out, a launch failed, ...)
+        print(f"[rank {rank}] run with transport {kind} failed: {e}", file=sys.stderr)
+        ran = False
+    if not all_ok(ran):
+        return fail("run failed")
+    agree = ranks_agree(s)
+    t = torch.tensor([dt], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    n_prof = 4
+    pos0 = args.warmup + n_tok
+    by_kind = profile_kinds(B, s, w, cfg, pos0, n_prof)
+    roofline, rd_avg = roofline_of(B, s, w, cfg, world, by_kind, n_prof, pos0, args.workload, n_tok, dt)
+
+    # the row-sharded prefill (every rank its column blocks, [tokens, n / world] blocks exchanged through
+    # the arena's bulk regions on the p2p legs, ncclAllGather on the RCCL leg): a diagnostic beside the
+    # decode figure
     prefill_sharded = None
-    if world > 1 and not args.no_extra and os.environ.get("L2Z_BENCH_NO_SHARDED_PREFILL", "") != "1":
+    if not args.no_extra and os.environ.get("L2Z_BENCH_NO_SHARDED_PREFILL", "") != "1":
         err = None
         dtp = 0.0
         n_p = min(512, cfg.seq_len - 1)
@@ -418,107 +550,167 @@ def main() -> None:
             t = torch.tensor([dtp], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             prefill_sharded = {"prompt_tokens": n_p, "ms": float(t.item()) * 1e3, "tokens_per_s": n_p / float(t.item()),
+                               "exchange": "ncclAllGather + unpack" if kind == "rccl" else
+                                           "bulk regions of the peer-write arena (plain 16-byte peer stores + a flag per sender)",
                                "ranks_agree": ranks_agree(s)}
         else:
             prefill_sharded = {"error": str(err) if err else "failed on another rank"}
     s.close()
     w.close()
 
+    n_g = 4 * cfg.n_layers + 1
+    launches = by_kind["gather"][1] // n_prof
+    bytes_tok = weight_bytes_per_token(cfg, world)
+    ideal_ms = bytes_tok / (rd_avg * 1e9) * 1e3 if rd_avg else None
+    leg = {"transport": kind, "ok": bool(agree), "why": None if agree else "ranks disagree",
+           "tokens_per_s": n_tok / dt, "ms_per_step": dt / n_tok * 1e3, "steps": n_tok, "ranks_agree": bool(agree),
+           "gathers": n_g, "gather_launches_per_token": launches,
+           "us_per_gather": (by_kind["gather"][0] / max(by_kind["gather"][1], 1) * 1e3) if launches else None,
+           "graph_nodes_per_layer": 5 + (4 if launches > 1 else 0),
+           "rccl_ranks": [x["rccl_ranks"] for x in trs], "p2p_connected": [x["p2p"] for x in trs],
+           # this rank's weight bytes at the plain streaming-read rate measured on this box: roughly what a
+           # step would take with free gathers; the rest of ms_per_step is gather + launch overhead
+           "ms_per_step_at_stream_read_rate": ideal_ms,
+           "overhead_ms_per_step": (dt / n_tok * 1e3 - ideal_ms) if ideal_ms else None,
+           "prefill_sharded": prefill_sharded}
     out = {
         "metric": "tokens/s (argmax, -t 0)", "value": n_tok / dt, "unit": "tokens/s",
         "n_gpus": args.gpus, "steps": n_tok, "warmup": args.warmup,
         "ms_per_step": dt / n_tok * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload} shape, fp32 llama2.c-v0 checkpoint "
-                               f"(dim {cfg.dim}, hidden {cfg.hidden_dim}, L {cfg.n_layers}, "
-                               f"H {cfg.n_heads}, kv {cfg.n_kv_heads}, V {cfg.vocab_size}, "
-                               f"S {cfg.seq_len}), greedy from BOS, seeded synthetic weights",
-                   "parallelism": (f"rows/heads sharded x{args.gpus}, all-gathers by "
-                                   + {"p2p-consume": "peer writes of LL words over IPC-mapped memory (xGMI), "
-                                                     "polled by the consuming mat-vec (no gather launch)",
-                                      "p2p-gather": "peer writes over IPC-mapped memory (xGMI) + a gather "
-                                                    "launch per vector",
-                                      "rccl": "RCCL ncclAllGather"}[transport]) if transport else "1 GPU",
-                   "ranks_agree": agree,
-                   "weight_bytes_per_token": sum(
-                       wb[k] * (1 if k == "cls" else cfg.n_layers) for k in wb) * world},
+        "config": {"workload": workload_text(args, cfg),
+                   "parallelism": f"rows/heads sharded x{args.gpus}, all-gathers by {LEG_TEXT[kind]}",
+                   "ranks_agree": bool(agree),
+                   "weight_bytes_per_token": bytes_tok * world},
         "roofline": roofline,
+        "leg": leg,
     }
-    if transport:
-        n_g = 4 * cfg.n_layers + 1
-        launches = by_kind["gather"][1] // n_prof
-        ideal_ms = (sum(wb[k] * (1 if k == "cls" else cfg.n_layers) for k in wb) / (rd_avg * 1e9) * 1e3
-                    if rd_avg else None)
-        out["comm"] = {
-            "transport": transport, "attempts": attempts, "prefill_sharded": prefill_sharded, "gathers_per_token": n_g,
-            "gather_launches_per_token": launches,
-            "us_per_gather_launch": (by_kind["gather"][0] / max(by_kind["gather"][1], 1) * 1e3) if launches else None,
-            "graph_nodes_per_layer": 5 + (4 if launches > 1 else 0),
-            # this rank's weight bytes at the streaming-read rate measured on this box: what a step
-            # would take with free gathers; the rest of ms_per_step is gather + launch overhead
-            "ideal_ms_per_step_at_measured_stream_rate": ideal_ms,
-            "overhead_ms_per_step": (dt / n_tok * 1e3 - ideal_ms) if ideal_ms else None,
-            "note": "kernel times in roofline.by_kind include the consumer-side polling of the gathered "
-                    "input (p2p-consume) -- compare with the N=1 line",
-        }
-    if rank == 0 and args.gpus == 1:
-        if not args.no_extra and args.workload != "stories15M":
-            c15, sh15 = shapes["stories15M"]
-            n15, dt15, s15, w15 = run_once(B, c15, sh15, args.seed, 255, 1)
-            s15.close(); w15.close()
-            # stories110M (BASELINE config 3's shape): 438 MB of weights per token do not fit the
-            # 256 MB Infinity Cache, so an HBM fraction is meaningful, though launch latency dominates
-            c110, sh110 = shapes["stories110M"]
-            n110, dt110, s110, w110 = run_once(B, c110, sh110, args.seed, 255, 1)
-            s110.close(); w110.close()
-            wb110 = weight_bytes_by_kind(c110)
-            bytes110 = sum(wb110[k] * (1 if k == "cls" else c110.n_layers) for k in wb110)
-            # long context on the headline shape: the prompt fills the cache through the batched
-            # prefill, then 32 greedy positions near the end of the 2048-token context are timed
-            long_ctx = None
-            if args.workload == "llama2-7b":
-                try:
-                    w7 = B.Weights(cfg, None, shared, seed=args.seed)
-                    s7 = B.RunState(cfg)
-                    n_p = cfg.seq_len - 48
-                    prompt = np.random.default_rng(1).integers(2, cfg.vocab_size, n_p).tolist()
-                    s7.greedy_begin(prompt)
-                    s7.greedy_run(w7, n_p + 8)  # prefill + 8 warm-up positions
-                    s7.synchronize()
-                    t0 = time.perf_counter()
-                    n_l = len(s7.greedy_run(w7, 32))
-                    s7.synchronize()
-                    dtl = time.perf_counter() - t0
-                    pr = s7.profile_forward(1, cfg.seq_len - 1, w7)
-                    kv_bytes = 8 * cfg.n_layers * (cfg.seq_len - 24) * cfg.kv_dim
-                    long_ctx = {"positions": [n_p + 8, n_p + 8 + n_l - 1], "tokens_per_s": n_l / dtl,
-                                "ms_per_token": dtl / n_l * 1e3,
-                                "attention_us_per_layer_at_last_pos": pr["attn"][0] / max(pr["attn"][1], 1) * 1e3,
-                                "kv_bytes_per_token": kv_bytes,
-                                "hbm_frac_incl_kv": (out["config"]["weight_bytes_per_token"] + kv_bytes)
-                                                    / (dtl / n_l) / 1e9 / HBM_PEAK_GBS}
-                    s7.close(); w7.close()
-                except Exception as e:  # noqa: BLE001
-                    long_ctx = {"error": str(e)}
-            out["extra"] = {"prefill": prefill,
-                            "stories110M": {"tokens_per_s": n110 / dt110, "steps": n110,
-                                            "weight_bytes_per_token": bytes110,
-                                            "hbm_frac": bytes110 / (dt110 / n110) / 1e9 / HBM_PEAK_GBS},
-                            "long_context": long_ctx,
-                            "stories15M_tokens_per_s": n15 / dt15, "stories15M_steps": n15,
-                            # the only figure the reference publishes: 660 tok/s, -t 0,
-                            # stories15M, one Ryzen 9 5900X core, Zig 0.11 -- other hardware, indicative
-                            "stories15M_vs_reference_readme_660": (n15 / dt15) / 660.0,
-                            "note": "stories15M shape, -t 0 -n 256; weights fit the on-die "
-                                    "cache, launch/latency bound, no HBM fraction quoted"}
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ck, cfg, shared, args.workload)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if comm is not None:
-        comm.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    comm.close()
+    dist.destroy_process_group()
+    return 0 if agree else 4
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def multi_main(args) -> None:
+    """Parent of a multi-rank run (one per torchrun rank; touches no GPU itself): runs every leg as a
+    child process per rank, collects rank 0's leg lines, ranks them."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with "
+                         "python -m torch.distributed.run --nproc-per-node N ...)")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    want = os.environ.get("L2Z_COMM", "")
+    order = {"": LEGS, "p2p": ["p2p-gather", "p2p-consume"], "p2p-consume": ["p2p-consume"],
+             "p2p-gather": ["p2p-gather"], "rccl": ["rccl"]}[want]
+    if os.environ.get("L2Z_BENCH_FORCE_DIST") == "1":  # 1-rank RCCL + gloo, for testing
+        order = ["rccl"]
+    leg_timeout = float(os.environ.get("L2Z_BENCH_LEG_TIMEOUT_S", "150"))
+    legs, lines = [], {}
+    for kind in order:
+        port = [free_port() if rank == 0 else None]
+        dist.broadcast_object_list(port, src=0)
+        cmd = [sys.executable, os.path.abspath(__file__), "--leg", kind, "--leg-port", str(port[0]),
+               "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--workload", args.workload, "--seed", str(args.seed)]
+        if args.no_extra:
+            cmd.append("--no-extra")
+        # the child makes its own gloo group on the leg's port: torchrun's agent-store settings must not
+        # reach it (with TORCHELASTIC_USE_AGENT_STORE a tcp:// rendezvous looks for the agent's store)
+        env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+        t0 = time.perf_counter()
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)  # stderr: inherited
+        try:
+            so, _ = p.communicate(timeout=leg_timeout)
+            rc = p.returncode
+        except subprocess.TimeoutExpired:
+            p.kill()  # the exact child; its peers run into their own timeouts
+            so, _ = p.communicate()
+            rc = -9
+        took = time.perf_counter() - t0
+        line = None
+        for ln in so.decode(errors="replace").splitlines():
+            if ln.startswith("{"):
+                try:
+                    line = json.loads(ln)
+                except Exception:  # noqa: BLE001
+                    pass
+        rcs = [None] * world
+        dist.all_gather_object(rcs, rc)
+        if rank != 0:
+            continue
+        rec = (line or {}).get("leg") or {"transport": kind, "ok": False, "why": None}
+        rec["exit_codes"] = rcs
+        rec["wall_s"] = took
+        if any(c != 0 for c in rcs):
+            rec["ok"] = False
+            if not rec.get("why"):
+                bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+                rec["why"] = ("timed out after %.0f s" % leg_timeout if any(c == -9 for _, c in bad) else
+                              "child process failed") + f" (rank, exit code): {bad}"
+        legs.append(rec)
+        if rec["ok"] and line is not None:
+            lines[kind] = line
+    final_rc = [0]
+    if rank == 0:
+        rccl = next((l for l in legs if l["transport"] == "rccl"), None)
+        rccl_rec = ({"initialised": bool(rccl.get("rccl_ranks")) and all(n == world for n in rccl["rccl_ranks"]),
+                     "ranks_reported_by_ncclCommCount": rccl.get("rccl_ranks"), "leg_ok": rccl["ok"],
+                     "why": rccl.get("why")} if rccl else {"initialised": False, "why": "leg not run (L2Z_COMM)"})
+        ok = [l for l in legs if l["ok"]]
+        if not ok:
+            print(json.dumps({"metric": "tokens/s (argmax, -t 0)", "value": None, "unit": "tokens/s",
+                              "n_gpus": args.gpus, "error": "no transport produced agreeing ranks",
+                              "comm": {"legs": legs, "rccl": rccl_rec}}), flush=True)
+            final_rc[0] = 1
+        else:
+            best = max(ok, key=lambda l: l["tokens_per_s"])
+            out = lines[best["transport"]]
+            out.pop("leg", None)
+            out["comm"] = {"transport": best["transport"],
+                           "selection": "fastest leg whose ranks hold bit-identical logits",
+                           "legs": legs, "rccl": rccl_rec,
+                           "prefill_sharded": best.get("prefill_sharded"),
+                           "note": "every leg times the same steps between the same barriers; kernel times in "
+                                   "roofline.by_kind of a p2p-consume leg include the consumer-side polling of the "
+                                   "gathered input -- compare with the N=1 line"}
+            print(json.dumps(out), flush=True)
+    dist.broadcast_object_list(final_rc, src=0)
+    dist.destroy_process_group()
+    if final_rc[0]:
+        raise SystemExit(final_rc[0])
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=255)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="llama2-7b",
+                    choices=["llama2-7b", "stories110M", "stories15M"])
+    ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the side measurements")
+    ap.add_argument("--leg", default=None, choices=LEGS, help=argparse.SUPPRESS)  # child of an N > 1 run
+    ap.add_argument("--leg-port", type=int, default=0, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.leg:
+        sys.exit(leg_main(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1 or os.environ.get("L2Z_BENCH_FORCE_DIST") == "1":
+        multi_main(args)
+    else:
+        single_gpu(args)
 
 
 if __name__ == "__main__":

@@ -115,6 +115,11 @@ int l2z_emu_transformer(int n_ranks, l2z_runstate *const *ss, const l2z_weights 
 int l2z_emu_prefill(int n_ranks, l2z_runstate *const *ss, const l2z_weights *const *ws,
                     const int32_t *tokens, int n_tokens, int pos0);
 
+/* What a shard group's transports are (bench.py's comm{} record): the rank count RCCL itself reports
+ * for the communicator (ncclCommCount; 0 when the group has none) and whether the peer-write arenas
+ * are connected. */
+int l2z_comm_transports(const l2z_comm *c, int *rccl_ranks, int *p2p_connected);
+
 /* Set one tuning knob by its environment-variable name (csrc/tunables.h), e.g. ("L2Z_P2P_CONSUME", 0).
  * Applies to objects created afterwards.  L2Z_ERR_INVALID for an unknown name. */
 int l2z_option_set(const char *env_name, long long value);

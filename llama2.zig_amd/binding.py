@@ -105,6 +105,7 @@ def lib():
     L.l2z_comm_p2p_export.argtypes = [vp, sz, vp]
     L.l2z_comm_p2p_connect.argtypes = [vp, vp]
     L.l2z_comm_rank.argtypes = [vp, ip, ip]
+    L.l2z_comm_transports.argtypes = [vp, ip, ip]
     L.l2z_comm_free.argtypes = [vp]
     L.l2z_comm_free.restype = None
     L.l2z_comm_init_emulated.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
@@ -182,6 +183,12 @@ class Comm:
         assert len(handles) == COMM_IPC_BYTES * self.world
         buf = C.create_string_buffer(handles, len(handles))
         _chk(lib().l2z_comm_p2p_connect(self.h, buf))
+
+    def transports(self) -> dict:
+        """{"rccl_ranks": ranks RCCL reports for the communicator (0: none), "p2p": arenas connected}"""
+        n, p = C.c_int(0), C.c_int(0)
+        _chk(lib().l2z_comm_transports(self.h, C.byref(n), C.byref(p)))
+        return {"rccl_ranks": n.value, "p2p": bool(p.value)}
 
     @staticmethod
     def unique_id() -> bytes:

@@ -21,6 +21,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t,
                               hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -44,6 +45,7 @@ int load_rccl()
     SYM(GetUniqueId, "ncclGetUniqueId");
     SYM(CommInitRank, "ncclCommInitRank");
     SYM(CommDestroy, "ncclCommDestroy");
+    SYM(CommCount, "ncclCommCount");
     SYM(AllGather, "ncclAllGather");
     SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
@@ -290,6 +292,21 @@ extern "C" int l2z_comm_rank(const l2z_comm *c, int *rank, int *world)
     L2Z_CHECK(c != nullptr, L2Z_ERR_INVALID, "l2z_comm_rank: null comm");
     if (rank) *rank = c->rank;
     if (world) *world = c->world;
+    return L2Z_OK;
+}
+
+// What the group's transports really are, for the bench line: the rank count RCCL itself reports for
+// the communicator (ncclCommCount; 0 without one) and whether the peer-write arenas are connected.
+extern "C" int l2z_comm_transports(const l2z_comm *c, int *rccl_ranks, int *p2p_connected)
+{
+    L2Z_CHECK(c != nullptr, L2Z_ERR_INVALID, "l2z_comm_transports: null comm");
+    int n = 0;
+    if (c->nccl != nullptr) {
+        ncclResult_t r = g_api.CommCount(static_cast<ncclComm_t>(c->nccl), &n);
+        L2Z_CHECK(r == ncclSuccess, L2Z_ERR_COMM, "ncclCommCount failed: %s", g_api.GetErrorString(r));
+    }
+    if (rccl_ranks) *rccl_ranks = n;
+    if (p2p_connected) *p2p_connected = c->p2p ? 1 : 0;
     return L2Z_OK;
 }
 

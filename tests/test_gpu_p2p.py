@@ -159,3 +159,33 @@ def test_multiprocess_sharded_prefill_needs_bulk_regions(gpu, ck, tmp_path, opti
         o = np.load(tmp_path / f"out_{r}.npz")
         assert np.array_equal(o["toks"], toks) and np.array_equal(o["logits"], s.logits()), f"rank {r}"
     s.close(); w.close()
+
+
+def test_bench_legs_on_one_gpu(gpu, tmp_path):
+    """bench.py --gpus 2 with both ranks on the one GPU of this box: every transport runs as its own leg
+    (child process per rank), all of them are reported, and the headline is the fastest leg whose ranks
+    agree.  RCCL refuses two ranks on one device, so its leg must FAIL here -- and the line must say so
+    instead of the run dying with it; both peer-write legs must work."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, L2Z_BENCH_LEG_TIMEOUT_S="200", L2Z_P2P_TIMEOUT_S="20")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "48", "--warmup", "1", "--workload", "stories110M", "--no-extra"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, p.stdout.decode()[-3000:] + p.stderr.decode()[-3000:]
+    out = json.loads(lines[0])
+    legs = {l["transport"]: l for l in out["comm"]["legs"]}
+    assert set(legs) == {"rccl", "p2p-gather", "p2p-consume"}
+    ok = [t for t, l in legs.items() if l["ok"]]
+    assert "p2p-gather" in ok and "p2p-consume" in ok, legs
+    for t in ok:
+        assert legs[t]["ranks_agree"] and legs[t]["steps"] == 48 and legs[t]["tokens_per_s"] > 0
+    assert out["comm"]["transport"] == max(ok, key=lambda t: legs[t]["tokens_per_s"])
+    assert out["value"] == legs[out["comm"]["transport"]]["tokens_per_s"] and out["n_gpus"] == 2
+    if not legs["rccl"]["ok"]:
+        assert legs["rccl"]["why"], legs["rccl"]
+        assert out["comm"]["rccl"]["initialised"] is False
+    print({t: (l["ok"], l.get("tokens_per_s"), l.get("why")) for t, l in legs.items()})

@@ -102,11 +102,18 @@ def _worker(rank, world, port, kw, shared, seed, toks, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+def _toy(world):
+    """8 ranks (BASELINE config 5's rank count) need 8 kv heads and dims that split eight ways."""
+    if world == 8:
+        return dict(dim=128, hidden_dim=176, n_layers=2, n_heads=16, n_kv_heads=8, vocab_size=512, seq_len=16)
+    return dict(dim=64, hidden_dim=172, n_layers=2, n_heads=8, n_kv_heads=4, vocab_size=512, seq_len=16)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_schedule_is_bit_identical(world, tmp_path, ck, orc):
     import torch.multiprocessing as mp
 
-    kw = dict(dim=64, hidden_dim=172, n_layers=2, n_heads=8, n_kv_heads=4, vocab_size=512, seq_len=16)
+    kw = _toy(world)
     shared, seed, toks = False, 77, [1, 40, 300, 7, 9]
     cfg = ck.Config(**kw)
     mp.spawn(_worker, args=(world, _free_port(), kw, shared, seed, toks, str(tmp_path)),
@@ -199,7 +206,7 @@ def _prefill_worker(rank, world, port, kw, shared, seed, toks, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_prefill_schedule(world, tmp_path, ck, orc):
     """The stage / staging-block / all-gather / unpack schedule of the row-sharded batched prefill on gloo
     ranks with the oracle's kernels as the per-rank math: the last position's logits equal the oracle's
@@ -207,7 +214,7 @@ def test_sharded_prefill_schedule(world, tmp_path, ck, orc):
     logits, and the ranks' key-cache shards tile the unsharded cache."""
     import torch.multiprocessing as mp
 
-    kw = dict(dim=64, hidden_dim=172, n_layers=2, n_heads=8, n_kv_heads=4, vocab_size=512, seq_len=16)
+    kw = _toy(world)
     shared, seed, toks = False, 78, [1, 40, 300, 7, 9, 11, 500]
     cfg = ck.Config(**kw)
     mp.spawn(_prefill_worker, args=(world, _free_port(), kw, shared, seed, toks, str(tmp_path)), nprocs=world, join=True)
