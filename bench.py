@@ -452,7 +452,7 @@ def leg_main(args) -> int:
             c, h = None, b""
             try:
                 c = B.Comm(rank, world, None, device)
-                h = c.p2p_export(max(cfg.dim, cfg.hidden_dim, cfg.vocab_size))
+                h = c.p2p_export(max(cfg.dim, cfg.hidden_dim, cfg.vocab_size), max(cfg.dim, cfg.hidden_dim))
             except Exception as e:  # noqa: BLE001
                 print(f"[rank {rank}] peer-write export failed: {e}", file=sys.stderr)
             hs = [None] * world

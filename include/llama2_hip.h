@@ -169,6 +169,10 @@ int l2z_comm_init(int rank, int world, const void *id, int device, l2z_comm **ou
 #define L2Z_COMM_IPC_BYTES 64
 /* max_vector_floats: the longest vector that will be gathered = max(dim, hidden_dim, vocab_size) */
 int l2z_comm_p2p_export(l2z_comm *c, size_t max_vector_floats, void *handle_out);
+/* the same with the bulk regions sized separately: max_matrix_width = max(dim, hidden_dim), the widest
+ * [tokens, n] matrix the sharded prefill gathers (the vocabulary only ever travels as a vector), so the
+ * arena holds 2 x max_matrix_width x 1024 floats of bulk space instead of 2 x max_vector_floats x 1024 */
+int l2z_comm_p2p_export_sized(l2z_comm *c, size_t max_vector_floats, size_t max_matrix_width, void *handle_out);
 int l2z_comm_p2p_connect(l2z_comm *c, const void *handles /* world x L2Z_COMM_IPC_BYTES */);
 int l2z_comm_rank(const l2z_comm *c, int *rank, int *world);
 void l2z_comm_free(l2z_comm *c);

@@ -103,6 +103,7 @@ def lib():
     L.l2z_comm_unique_id.argtypes = [vp]
     L.l2z_comm_init.argtypes = [C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp)]
     L.l2z_comm_p2p_export.argtypes = [vp, sz, vp]
+    L.l2z_comm_p2p_export_sized.argtypes = [vp, sz, sz, vp]
     L.l2z_comm_p2p_connect.argtypes = [vp, vp]
     L.l2z_comm_rank.argtypes = [vp, ip, ip]
     L.l2z_comm_transports.argtypes = [vp, ip, ip]
@@ -172,10 +173,14 @@ class Comm:
             _chk(lib().l2z_comm_init(rank, world, buf, device, C.byref(self.h)))
         self.rank, self.world = rank, world
 
-    def p2p_export(self, max_vector_floats: int) -> bytes:
-        """Allocate this rank's landing arena; returns its 64-byte IPC handle (to be all-gathered)."""
+    def p2p_export(self, max_vector_floats: int, max_matrix_width: int | None = None) -> bytes:
+        """Allocate this rank's landing arena; returns its 64-byte IPC handle (to be all-gathered).
+        max_matrix_width = max(dim, hidden_dim) sizes the sharded prefill's bulk regions."""
         buf = C.create_string_buffer(COMM_IPC_BYTES)
-        _chk(lib().l2z_comm_p2p_export(self.h, max_vector_floats, buf))
+        if max_matrix_width is None:
+            _chk(lib().l2z_comm_p2p_export(self.h, max_vector_floats, buf))
+        else:
+            _chk(lib().l2z_comm_p2p_export_sized(self.h, max_vector_floats, max_matrix_width, buf))
         return buf.raw
 
     def p2p_connect(self, handles: bytes) -> None:

@@ -224,6 +224,13 @@ extern "C" int l2z_comm_init_emulated(int rank, int world, int device, l2z_comm 
 // ---- peer-write all-gather: arena export / connect (protocol in p2p.hip) ----
 extern "C" int l2z_comm_p2p_export(l2z_comm *c, size_t max_vector_floats, void *handle_out)
 {
+    // without a separate width the bulk regions are sized for matrices as wide as the longest vector
+    return l2z_comm_p2p_export_sized(c, max_vector_floats, max_vector_floats, handle_out);
+}
+
+extern "C" int l2z_comm_p2p_export_sized(l2z_comm *c, size_t max_vector_floats, size_t max_matrix_width,
+                                         void *handle_out)
+{
     L2Z_CHECK(c != nullptr && handle_out != nullptr && max_vector_floats > 0, L2Z_ERR_INVALID,
               "l2z_comm_p2p_export: bad arguments");
     L2Z_CHECK(c->world <= kMaxWorld, L2Z_ERR_INVALID, "peer-write gathers support up to %d ranks", kMaxWorld);
@@ -232,10 +239,12 @@ extern "C" int l2z_comm_p2p_export(l2z_comm *c, size_t max_vector_floats, void *
     L2Z_HIP(hipSetDevice(c->device));
     c->slot_floats = (max_vector_floats + 1023) & ~(size_t)1023;
     // bulk regions for the sharded prefill's [chunk tokens, dim | hidden_dim] activation matrices
-    // (plain floats); the caller's longest vector bounds both.  L2Z_P2P_BULK_MB overrides, 0 = none
-    // (sharded runstates then step their prompts token by token).
+    // (plain floats): max_matrix_width = max(dim, hidden_dim) -- the vocabulary is only ever gathered as
+    // a vector (7B shape: 2 x 11008 x 1024 floats = 90 MB instead of 256 MB at the vocabulary's width).
+    // L2Z_P2P_BULK_MB overrides, 0 = none (sharded runstates then step their prompts token by token).
+    const size_t width = ((max_matrix_width ? max_matrix_width : max_vector_floats) + 63) & ~(size_t)63;
     c->bulk_floats = tunables().p2p_bulk_mb >= 0 ? ((size_t)tunables().p2p_bulk_mb << 20) / 4
-                                                 : c->slot_floats * (size_t)prefill_chunk_tokens();
+                                                 : width * (size_t)prefill_chunk_tokens();
     const size_t bytes = kP2pFlagBytes + 2 * c->slot_floats * 8 + 2 * c->bulk_floats * 4;  // LL: 8-byte {value, epoch} words
     // fine-grained: peers' stores and this rank's flag polls / landing reads are coherent inside
     // a running kernel (ordinary hipMalloc memory is only coherent at kernel boundaries)

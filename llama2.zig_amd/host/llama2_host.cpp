@@ -302,6 +302,13 @@ static void sort_desc(std::vector<IndexedF32> &v)
 size_t sample_top_p(const float *probs, size_t n, float p, std::vector<IndexedF32> &scratch,
                     Prng &rng)
 {
+    return sample_top_p_margin(probs, n, p, scratch, rng, nullptr);
+}
+
+size_t sample_top_p_margin(const float *probs, size_t n, float p, std::vector<IndexedF32> &scratch,
+                           Prng &rng, float *margin)
+{
+    if (margin) *margin = 1.0f;
     // :759-770 candidates below (1-p)/(n-1) cannot be in the nucleus
     const float cutoff = (1.0f - p) / ((float)n - 1.0f);
     scratch.clear();
@@ -325,6 +332,15 @@ size_t sample_top_p(const float *probs, size_t n, float p, std::vector<IndexedF3
     }
     const float r = rng.next_f32() * cumulative;  // :789
     float cdf = 0.0f;
+    if (margin) {  // how close the draw is to a boundary of the truncated cdf (tests: is a flip a near tie?)
+        float m = r;  // the boundary at 0
+        for (size_t i = 0; i < cutoff_index; i++) {  // the last boundary is not one: everything beyond falls to :797
+            cdf += scratch[i].value;
+            m = std::fmin(m, std::fabs(r - cdf));
+        }
+        *margin = m;
+        cdf = 0.0f;
+    }
     for (size_t i = 0; i <= cutoff_index; i++) {
         cdf += scratch[i].value;
         if (r < cdf) return scratch[i].index;
@@ -424,4 +440,13 @@ size_t l2zh_sample_top_p(const float *probs, size_t n, float p, uint64_t seed)
     return sample_top_p(probs, n, p, scratch, r);
 }
 void l2zh_softmax(float *x, size_t n) { softmax(x, n); }
+// one generator across calls, as the generation loop uses it (main.zig:845 / :926, then :1009-1012 per position)
+void *l2zh_prng_open(uint64_t seed) { return new Prng(seed); }
+void l2zh_prng_close(void *rng) { delete static_cast<Prng *>(rng); }
+size_t l2zh_sample_top_p_rng(const float *probs, size_t n, float p, void *rng, float *margin)
+{
+    std::vector<IndexedF32> scratch;
+    return sample_top_p_margin(probs, n, p, scratch, *static_cast<Prng *>(rng), margin);
+}
+size_t l2zh_sample_rng(const float *probs, size_t n, void *rng) { return sample(probs, n, *static_cast<Prng *>(rng)); }
 }

@@ -60,6 +60,10 @@ struct IndexedF32 {
 };
 size_t sample_top_p(const float *probs, size_t n, float p, std::vector<IndexedF32> &scratch,
                     Prng &rng);
+// the same draw; *margin (if not null) = distance of the scaled coin to the nearest inner boundary of the
+// truncated cumulative distribution: how close this draw was to picking a neighbouring candidate
+size_t sample_top_p_margin(const float *probs, size_t n, float p, std::vector<IndexedF32> &scratch,
+                           Prng &rng, float *margin);
 // :1055-1076  "<0xXX>" -> byte, only if printable or whitespace; -1 otherwise
 int is_raw_byte(std::string_view s);
 

@@ -63,18 +63,44 @@ static int die(const char *what)
 // without talking to each other; only rank 0 prints.
 static int g_rank = 0, g_world = 1;
 
-static bool exchange_handles(const std::string &dir, const void *mine, std::vector<char> *all)
+// A rank that cannot take part (comm_init / p2p_export failed on its GPU) leaves an error marker so that
+// the others stop waiting at once instead of polling for its handle for a minute.
+static void mark_failed(const std::string &dir)
+{
+    if (dir.empty()) return;
+    FILE *f = fopen((dir + "/e" + std::to_string(g_rank)).c_str(), "wb");
+    if (f) fclose(f);
+}
+
+static bool any_rank_failed(const std::string &dir, const std::vector<pid_t> &kids)
+{
+    for (int r = 0; r < g_world; r++)
+        if (access((dir + "/e" + std::to_string(r)).c_str(), F_OK) == 0) return true;
+    for (pid_t k : kids) {  // rank 0 only: a child that has already gone will never write its handle
+        siginfo_t si;
+        si.si_pid = 0;
+        if (waitid(P_PID, (id_t)k, &si, WEXITED | WNOHANG | WNOWAIT) == 0 && si.si_pid == k) return true;
+    }
+    return false;
+}
+
+static bool exchange_handles(const std::string &dir, const std::vector<pid_t> &kids, const void *mine,
+                             std::vector<char> *all)
 {
     const std::string tmp = dir + "/h" + std::to_string(g_rank) + ".tmp", fin = dir + "/h" + std::to_string(g_rank);
     FILE *f = fopen(tmp.c_str(), "wb");
-    if (!f || fwrite(mine, 1, L2Z_COMM_IPC_BYTES, f) != L2Z_COMM_IPC_BYTES) return false;
-    fclose(f);
+    if (!f) return false;
+    const bool wrote = fwrite(mine, 1, L2Z_COMM_IPC_BYTES, f) == L2Z_COMM_IPC_BYTES;
+    if (fclose(f) != 0 || !wrote) return false;
     if (rename(tmp.c_str(), fin.c_str()) != 0) return false;
     all->resize((size_t)g_world * L2Z_COMM_IPC_BYTES);
     for (int r = 0; r < g_world; r++) {
         const std::string p = dir + "/h" + std::to_string(r);
         FILE *g = nullptr;
-        for (int tries = 0; tries < 6000 && !(g = fopen(p.c_str(), "rb")); tries++) usleep(10000);
+        for (int tries = 0; tries < 6000 && !(g = fopen(p.c_str(), "rb")); tries++) {
+            if ((tries % 10) == 9 && any_rank_failed(dir, kids)) return false;
+            usleep(10000);
+        }
         if (!g) return false;
         const size_t n = fread(all->data() + (size_t)r * L2Z_COMM_IPC_BYTES, 1, L2Z_COMM_IPC_BYTES, g);
         fclose(g);
@@ -216,7 +242,10 @@ int main(int argc, char **argv)
             if (rc == 0 && !(WIFEXITED(st) && WEXITSTATUS(st) == 0)) rc = 1;
         }
         if (!xdir.empty()) {
-            for (int r = 0; r < g_world; r++) unlink((xdir + "/h" + std::to_string(r)).c_str());
+            for (int r = 0; r < g_world; r++) {
+                unlink((xdir + "/h" + std::to_string(r)).c_str());
+                unlink((xdir + "/e" + std::to_string(r)).c_str());
+            }
             rmdir(xdir.c_str());
         }
         return rc;
@@ -254,19 +283,36 @@ int main(int argc, char **argv)
         uint64_t hbm = 0;
         if (l2z_device_count(&n_dev) != L2Z_OK || n_dev < 1) return finish(die("no GPU"));
         device = g_rank % n_dev;  // fewer GPUs than ranks: ranks share (functional, not fast)
+        if (g_world > n_dev) {
+            // Ranks sharing a chip: a mat-vec that polls for a peer's words must leave the peer's producer
+            // room to run, else the waits time out (at most 512 polling blocks on the chip in
+            // total).  The library reads its knobs once, at first use -- nothing has used them yet.
+            const int per_dev = (g_world + n_dev - 1) / n_dev;
+            const int cap = 512 / per_dev < 32 ? 32 : 512 / per_dev;
+            setenv("L2Z_GRID_CAP", std::to_string(cap).c_str(), 0);
+        }
         if (l2z_device_info(device, name, sizeof name, &cus, &hbm) != L2Z_OK) return finish(die("no GPU"));
         LOGV("device: %s, %d CUs, %.0f GB HBM%s\n\n", name, cus, (double)hbm / 1e9,
              g_world > 1 ? " (rank 0 of the shard group)" : "");
     }
     l2z_comm *comm = nullptr;
     if (g_world > 1) {
-        if (l2z_comm_init(g_rank, g_world, nullptr, device, &comm) != L2Z_OK) return finish(die("comm_init"));
+        if (l2z_comm_init(g_rank, g_world, nullptr, device, &comm) != L2Z_OK) {
+            mark_failed(xdir);
+            return finish(die("comm_init"));
+        }
         char handle[L2Z_COMM_IPC_BYTES];
         const size_t longest = (size_t)std::max(std::max(cfg.dim, cfg.hidden_dim), cfg.vocab_size);
+        const size_t widest = (size_t)std::max(cfg.dim, cfg.hidden_dim);  // bulk regions: [chunk, dim | hidden_dim]
         std::vector<char> all;
-        if (l2z_comm_p2p_export(comm, longest, handle) != L2Z_OK) return finish(die("p2p_export"));
-        if (!exchange_handles(xdir, handle, &all)) {
-            if (g_rank == 0) fprintf(stderr, "error: rank %d: hand-shake with the other ranks failed\n", g_rank);
+        if (l2z_comm_p2p_export_sized(comm, longest, widest, handle) != L2Z_OK) {
+            mark_failed(xdir);
+            return finish(die("p2p_export"));
+        }
+        if (!exchange_handles(xdir, kids, handle, &all)) {
+            mark_failed(xdir);
+            fprintf(stderr, "error: rank %d: hand-shake with the other ranks failed (a rank could not set up "
+                            "its GPU, or died)\n", g_rank);
             return finish(1);
         }
         if (l2z_comm_p2p_connect(comm, all.data()) != L2Z_OK) return finish(die("p2p_connect"));
@@ -341,6 +387,21 @@ int main(int argc, char **argv)
         // tokens per call: the text appears in bursts of one call, so keep a call near 40 ms -- 64 tokens for
         // the small models, ~9 for the 7B shape (a call costs one stream synchronisation, ~20 us)
         size_t step = 8;
+        if (g_world > 1) {
+            // The ranks share no control plane: they stay in step only because every rank makes the SAME
+            // sequence of calls.  A step sized from this rank's own clock can differ between ranks (9 vs 8
+            // tokens), and when a BOS then ends the sequence inside a call the rank that asked for more has
+            // queued passes its peers never run (a 20 s gather timeout, stores into a freed arena).  So the
+            // step is a function of the model and the rank count only: this rank's weight bytes per token at
+            // ~5 TB/s plus ~5 us per gather, sized for the same ~40 ms bursts.
+            const double wbytes = 4.0 * ((double)cfg.n_layers * (2.0 * cfg.dim * cfg.dim +
+                                                                2.0 * cfg.dim * (cfg.dim / cfg.n_heads) * cfg.n_kv_heads +
+                                                                3.0 * cfg.dim * cfg.hidden_dim) +
+                                         (double)cfg.vocab_size * cfg.dim) / g_world;
+            const double per = wbytes / 5.0e12 + (4.0 * cfg.n_layers + 1.0) * 5.0e-6;
+            const double fit = 0.040 / per;
+            step = fit < 4.0 ? 4 : fit > 64.0 ? 64 : (size_t)fit;
+        }
         while (alive && pos < seq_len) {
             // first token alone so the clock starts where the reference starts it; a prompt of
             // L2Z_PREFILL_MIN_PROMPT tokens or more is asked for in one call so that the library
@@ -354,7 +415,7 @@ int main(int argc, char **argv)
             const auto tc = std::chrono::steady_clock::now();
             if (l2z_greedy_run(&cfg, s, w, want, chunk.data(), &got) != L2Z_OK) return finish(die("greedy_run"));
             if (got == 0) break;
-            if (pos > 0 && got == want && want >= 4) {
+            if (g_world == 1 && pos > 0 && got == want && want >= 4) {
                 const double per = std::chrono::duration<double>(std::chrono::steady_clock::now() - tc).count() / got;
                 const double fit = per > 0.0 ? 0.040 / per : 64.0;
                 step = fit < 4.0 ? 4 : fit > 64.0 ? 64 : (size_t)fit;
@@ -369,6 +430,11 @@ int main(int argc, char **argv)
         // one batched pass when the prompt is long enough; the tokens print in a burst, then the
         // loop continues at pos = prompt_len.  Any refusal (odd dims, L2Z_PREFILL=0, a BOS inside
         // the prompt, which would end the loop at :1017) leaves the stepped loop below to do it.
+        // L2Z_HOST_SOFTMAX=1: divide + softmax on the host in the reference's order (:1005-1008) instead of
+        // l2z_probs_read -- the device reduces the denominator as a tree, so probabilities can differ in the
+        // last ulp and a fixed seed can (rarely) land on the other side of a cdf boundary
+        const char *hs_env = getenv("L2Z_HOST_SOFTMAX");
+        const bool host_softmax = hs_env && atoi(hs_env) != 0;
         const char *pf_env = getenv("L2Z_PREFILL");
         bool has_bos = false;
         for (int32_t t : prompt) has_bos = has_bos || t == 1;
@@ -390,7 +456,13 @@ int main(int argc, char **argv)
             } else {
                 // :1005-1008 (logits / temperature, softmax) on the device, then the copy the samplers need
                 // anyway: 32000 exp() on one host core take as long as a small model's forward pass
-                if (l2z_probs_read(s, temperature, logits.data()) != L2Z_OK) return finish(die("probs_read"));
+                if (host_softmax) {
+                    if (l2z_logits_read(s, logits.data()) != L2Z_OK) return finish(die("logits_read"));
+                    for (float &v : logits) v /= temperature;  // :1006
+                    softmax(logits.data(), logits.size());      // :1008
+                } else if (l2z_probs_read(s, temperature, logits.data()) != L2Z_OK) {
+                    return finish(die("probs_read"));
+                }
                 next = (top_p == 0.0f || top_p == 1.0f)         // :1009-1012
                            ? sample(logits.data(), logits.size(), prng)
                            : sample_top_p(logits.data(), logits.size(), top_p, logits_indexed, prng);

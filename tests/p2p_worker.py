@@ -26,7 +26,7 @@ def main() -> None:
     expect = spec.get("expect", "ok")
     comm = B.Comm(rank, world, None, 0)  # every rank on device 0: this is a one-GPU test
     longest = max(cfg.dim, cfg.hidden_dim, cfg.vocab_size)
-    h = comm.p2p_export(longest // 2 if expect == "slot_error" else longest)
+    h = comm.p2p_export(longest // 2 if expect == "slot_error" else longest, max(cfg.dim, cfg.hidden_dim))
     with open(os.path.join(d, f"h_{rank}.tmp"), "wb") as f:
         f.write(h)
     os.rename(os.path.join(d, f"h_{rank}.tmp"), os.path.join(d, f"h_{rank}.bin"))

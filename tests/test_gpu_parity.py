@@ -812,3 +812,24 @@ def test_prefill_equals_token_by_token(gpu, ck, orc, name, kw, shared):
                 np.testing.assert_allclose(b, a, rtol=2e-4, atol=2e-4, err_msg=f"n={n} {name_} l={l}")
     for o in (s1, s2, s3, w):
         o.close()
+
+
+@pytest.mark.parametrize("temp", [1.0, 0.7])
+def test_probs_read_vs_host_softmax(gpu, ck, orc, temp):
+    """l2z_probs_read = main.zig:1005-1008 (logits / temperature, softmax) on the device, for the host
+    samplers.  The device reduces the denominator as a tree and uses the OCML expf; the reference sums in
+    order with its own exp.  Stated bound on that deliberate trade: every probability within 4e-6 relative
+    (+1e-12) of the host's in-order softmax of the SAME logits, and the probabilities sum to 1 within 1e-5
+    -- far below what moves a draw except at a cdf boundary (tests/test_host_cli.py reports those)."""
+    cfg = ck.Config(dim=288, hidden_dim=768, n_layers=2, n_heads=6, n_kv_heads=6, vocab_size=32000, seq_len=64)
+    w, s = gpu.Weights(cfg, None, True, seed=3), gpu.RunState(cfg)
+    for pos, tok in enumerate([1, 500, 9999]):
+        s.transformer(tok, pos, w)
+        lg = s.logits()
+        got = s.probs(temp)
+        ref = orc.softmax((lg / np.float32(temp)).astype(np.float32))
+        assert np.all(np.abs(got - ref) <= 4e-6 * ref + 1e-12), float(np.max(np.abs(got - ref) / (ref + 1e-30)))
+        assert abs(float(got.astype(np.float64).sum()) - 1.0) < 1e-5
+        assert int(np.argmax(got)) == int(np.argmax(ref))
+        assert np.array_equal(s.logits(), lg)   # the logits themselves are left untouched
+    s.close(); w.close()

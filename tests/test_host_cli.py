@@ -327,3 +327,94 @@ def test_cli_multi_gpu_mode_matches_single(gpu, n_gpus):
             assert r.returncode == 0, r.stderr.decode(errors="replace")
             outs.append(([l for l in r.stderr.decode().splitlines() if l.startswith("tokens:")][0], r.stdout))
         assert outs[0] == outs[1], flags
+
+
+@pytest.mark.gpu
+def test_cli_multi_gpu_mode_ends_cleanly_on_bos(gpu, ck, orc, tmp_path):
+    """`-g 2 -t 0` on a model whose greedy sequence ends with BOS (main.zig:1017) in the middle of a
+    device call: the ranks share no control plane, so they only stay in step if every rank asks for the
+    same number of positions per call (the step is a function of the model and the rank count, not of a
+    rank's own clock -- ADVICE r2).  The run must print the oracle's tokens, exit 0 and not sit in a
+    gather timeout."""
+    import time
+    exe = os.path.join(HOST, "llama2")
+    cfg = ck.Config(dim=64, hidden_dim=172, n_layers=2, n_heads=4, n_kv_heads=2, vocab_size=64, seq_len=128)
+    blob = ck.synth_blob(cfg, False, 7)   # seed found with the oracle: BOS is the 71st greedy token
+    m = orc.Model(cfg.as_i32(), blob, False)
+    ref, margins = m.generate_greedy([], 128)
+    m.close()
+    assert len(ref) < 128 and ref[-1] == 1 and len(ref) > 20, "the seed no longer ends on BOS"
+    path = str(tmp_path / "bos.bin")
+    ck.write_checkpoint(path, cfg, blob, False)
+    env = dict(os.environ, L2Z_P2P_TIMEOUT_S="20", L2Z_FUSE_SMALL="0")
+    env.pop("L2Z_GRID_CAP", None)   # the CLI sets the cap itself when ranks share a GPU
+    for g in (1, 2):
+        t0 = time.time()
+        r = subprocess.run([exe, path, "-t", "0", "-n", "128", "-z", TOK, "--tokens", "-g", str(g)],
+                           capture_output=True, timeout=180, env=env)
+        took = time.time() - t0
+        assert r.returncode == 0, r.stderr.decode(errors="replace")
+        line = [l for l in r.stderr.decode().splitlines() if l.startswith("tokens:")][0]
+        got = [int(v) for v in line.split()[1:]]
+        assert got == ref.tolist(), (g, got, ref.tolist(), float(margins.min()))
+        assert took < 15.0, f"-g {g} needed {took:.1f} s: a rank sat in a gather timeout"
+
+
+def _cli_tokens(r):
+    return [int(v) for v in [l for l in r.stderr.decode().splitlines() if l.startswith("tokens:")][0].split()[1:]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["toy", "stories15M-2layers"])
+def test_cli_sampled_tokens_equal_host_replay(gpu, ck, orc, tmp_path, shape):
+    """BASELINE config 3's flags (-t 1.0 -p 0.9) as a COMPARISON, not a property: the CLI's token ids
+    against a host replay of main.zig:996-1012 -- the ORACLE's logits -> logits / temperature ->
+    softmax (:1006-1008) -> sample_top_p (:1011) with the same seed through the same host sampler
+    (libllama2_host.so).  Both the device softmax (l2z_probs_read, default) and the host softmax
+    (L2Z_HOST_SOFTMAX=1) must give the replay's ids; a divergence is only accepted where the drawn
+    number lies within 2e-6 of a boundary of the cumulative distribution (the two sides differ by
+    ~1e-6 in the logits and by ulps in the probabilities), and is reported."""
+    exe = os.path.join(HOST, "llama2")
+    H = C.CDLL(os.path.join(HOST, "libllama2_host.so"))
+    if shape == "toy":
+        cfg, shared, seed_w = ck.Config(dim=64, hidden_dim=172, n_layers=2, n_heads=4, n_kv_heads=2, vocab_size=512, seq_len=96), False, 5
+    else:
+        cfg, shared, seed_w = ck.Config(dim=288, hidden_dim=768, n_layers=2, n_heads=6, n_kv_heads=6, vocab_size=32000, seq_len=256), True, 15
+    blob = ck.synth_blob(cfg, shared, seed_w)
+    path = str(tmp_path / "m.bin")
+    ck.write_checkpoint(path, cfg, blob, shared)
+    n, temp, top_p, seed = 64, 1.0, 0.9, 4242
+    # the replay: ONE generator across the positions, as the loop holds it (main.zig:845 / :926)
+    H.l2zh_prng_open.restype = C.c_void_p
+    H.l2zh_sample_top_p_rng.restype = C.c_size_t
+    rng = C.c_void_p(H.l2zh_prng_open(C.c_uint64(seed)))
+    m = orc.Model(cfg.as_i32(), blob, shared)
+    tok, want, margins = 1, [], []
+    for pos in range(n):
+        lg = m.transformer(tok, pos)
+        pp = np.ascontiguousarray(lg / np.float32(temp), np.float32)      # :1006
+        H.l2zh_softmax(pp.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(pp.size))   # :1008
+        mg = C.c_float(0)
+        nxt = H.l2zh_sample_top_p_rng(pp.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(cfg.vocab_size),
+                                      C.c_float(top_p), rng, C.byref(mg))  # :1011
+        margins.append(float(mg.value))
+        want.append(int(nxt))
+        if nxt == 1:
+            break
+        tok = int(nxt)
+    H.l2zh_prng_close(rng)
+    m.close()
+    for env_extra in ({}, {"L2Z_HOST_SOFTMAX": "1"}):
+        r = subprocess.run([exe, path, "-t", str(temp), "-p", str(top_p), "-n", str(n), "-s", str(seed), "-z", TOK,
+                            "--tokens"], capture_output=True, timeout=180, env=dict(os.environ, **env_extra))
+        assert r.returncode == 0, r.stderr.decode(errors="replace")
+        got = _cli_tokens(r)
+        k = next((i for i, (a, b) in enumerate(zip(got, want)) if a != b), min(len(got), len(want)))
+        if k < min(len(got), len(want)):
+            print(f"{shape} {env_extra}: first divergence at pos {k} (cli {got[k]} vs replay {want[k]}), "
+                  f"cdf margin there {margins[k]:.3e}")
+            assert margins[k] < 2e-6, (shape, env_extra, k, got[k], want[k], margins[k])
+        else:
+            assert len(got) == len(want)
+            print(f"{shape} {env_extra}: {len(got)} sampled token ids identical to the host replay; "
+                  f"min cdf margin {min(margins):.3e}")
