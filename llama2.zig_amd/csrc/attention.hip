@@ -164,12 +164,6 @@ constexpr int kAttnFastBlock = 1024;  // long contexts: 16 waves per head (32 gr
 
 // NT = 256 for short contexts (seq_len <= 512: launch latency matters most),
 // NT = 1024 for long ones (more rows in flight per head).
-#ifdef L2Z_DBG_TS
-__device__ long long g_dbg_ts[16];
-#define L2Z_TS(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dbg_ts[i] = clock64(); } while (0)
-#else
-#define L2Z_TS(i) do { } while (0)
-#endif
 template <int NT, bool SPEC>
 __global__ __launch_bounds__(NT) void attention_fast_kernel(const AttnArgs a)
 {
@@ -190,7 +184,6 @@ __global__ __launch_bounds__(NT) void attention_fast_kernel(const AttnArgs a)
     const int step = ge.G * kFastUB;
     const v4f zero = {0.f, 0.f, 0.f, 0.f};
 
-    L2Z_TS(0);
     // SPEC (small models, latency-bound): the first round is requested without waiting for
     // pos -- rows past pos exist and are masked -- so pos, q, K and V travel in one round trip.
     // !SPEC (large heads): one CU pulls only ~45 GB/s, speculative rows would cost more than the
@@ -211,7 +204,6 @@ __global__ __launch_bounds__(NT) void attention_fast_kernel(const AttnArgs a)
         t = t < lim ? t : lim - 1;
         vr[i] = ((const v4f *)(vbase + (size_t)t * stride))[cc];
     }
-    L2Z_TS(1);
     const float div = sqrtf((float)hs);
     for (int t0 = g;;) {  // scores (:367-375)
 #pragma unroll
@@ -230,11 +222,8 @@ __global__ __launch_bounds__(NT) void attention_fast_kernel(const AttnArgs a)
             kr[i] = ((const v4f *)(kbase + (size_t)t * stride))[cc];
         }
     }
-    L2Z_TS(2);
     __syncthreads();
-    L2Z_TS(3);
     wave_softmax(att, prob, T);  // :378
-    L2Z_TS(4);
     v4f acc = zero;
     for (int t0 = g;;) {  // att . V (:381-388), increasing t within the group
 #pragma unroll
@@ -255,15 +244,12 @@ __global__ __launch_bounds__(NT) void attention_fast_kernel(const AttnArgs a)
             vr[i] = ((const v4f *)(vbase + (size_t)t * stride))[cc];
         }
     }
-    L2Z_TS(5);
     if (active) ((v4f *)(part + (size_t)g * hs))[cc] = acc;
     __syncthreads();
-    L2Z_TS(6);
     // sharded: a.xb already points at this rank's slice, head h of it starts at h * hs
     reduce_partials(part, ge.G, hs, a.xb + (size_t)h * hs, a.push,
                     a.push ? a.push_ctl[kCtlEpoch] + a.push_gi : 0,
                     a.push ? (size_t)a.push->rank * a.push->count + (size_t)h * hs : 0);
-    L2Z_TS(7);
 }
 
 // ---------------------------------------------------------------------------
@@ -588,13 +574,6 @@ hipError_t launch_attention(const AttnArgs &a_in, int n_heads_local, hipStream_t
     }
     return hipGetLastError();
 }
-
-#ifdef L2Z_DBG_TS
-hipError_t dbg_ts_read(long long *out)
-{
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_ts), 16 * sizeof(long long));
-}
-#endif
 
 hipError_t launch_dot(float *out, const float *x, const float *y, int n, hipStream_t st)
 {

@@ -227,11 +227,6 @@ extern "C" int l2z_option_set(const char *env_name, long long value)
     return L2Z_OK;
 }
 
-#ifdef L2Z_DBG_TS
-namespace l2z { hipError_t dbg_ts_read(long long *out); }
-extern "C" int l2z_dbg_ts(long long *out) { return l2z::dbg_ts_read(out) == hipSuccess ? 0 : -3; }
-#endif
-
 // Host-side planning of the batched prefill, no device needed: how a prompt is cut into chunks, and which
 // output tile the direct-to-LDS GEMM takes for a [P, N] product (0: 128x64, 1: 64x64, 2: 32x64, 3: 32x32,
 // 4: 128x128; the CU count is the current device's, 256 without one).

@@ -462,20 +462,14 @@ __global__ __launch_bounds__(kBlock) void matvec_row_kernel(const MatvecArgs a)
             load(b_next * (kBlock * U));
         }
         if (unit_done) {
-#ifdef L2Z_DBG_NOREDUCE
-            const float sa = hsum4(acc_a), sb = hsum4(acc_b);
-#else
             const float sa = wave_sum(hsum4(acc_a));
             const float sb = wave_sum(hsum4(acc_b));
-#endif
             float *pp = part + parity * (2 * kWaves);
             if (lane == 0) {
                 pp[wave] = sa;
                 pp[kWaves + wave] = sb;
             }
-#ifndef L2Z_DBG_NOBARRIER
             __syncthreads();
-#endif
             if (tid == 0) {
                 const float ta = ((pp[0] + pp[1]) + pp[2]) + pp[3];
                 const float tb = ((pp[kWaves] + pp[kWaves + 1]) + pp[kWaves + 2]) + pp[kWaves + 3];

@@ -21,10 +21,6 @@
 namespace l2z {
 namespace {
 
-#ifndef L2Z_DBG_GEMM
-#define L2Z_DBG_GEMM 0  // timing experiments only: 1 no global loads, 2 no LDS writes, 4 no LDS reads, 8 no barrier
-#endif
-
 // compute units of the current device (tile choice: does the larger tile still give every CU a block?)
 static int g_cus_hint()
 {
@@ -248,12 +244,8 @@ __global__ __launch_bounds__(256 * KS) void prefill_gemm(const GemmArgs a)
             if (t + AH < STEPS) lds_read(t + AH);
 #pragma unroll
             for (int p = (t * PIECES) / STEPS; p < ((t + 1) * PIECES) / STEPS; p++) {
-#if !(L2Z_DBG_GEMM & 2)
                 sstore_piece(p, k0 + BK);
-#endif
-#if !(L2Z_DBG_GEMM & 1)
                 gload_piece(p, k0 + 2 * BK);
-#endif
             }
 #pragma unroll
             for (int i = 0; i < TM; i++)
@@ -264,9 +256,7 @@ __global__ __launch_bounds__(256 * KS) void prefill_gemm(const GemmArgs a)
             // the top of the stage and sinks the global loads to its end
             __builtin_amdgcn_sched_barrier(0);
         }
-#if !(L2Z_DBG_GEMM & 8)
         __syncthreads();
-#endif
         buf ^= 1;
     }
     if (KS > 1) {
