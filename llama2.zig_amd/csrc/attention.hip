@@ -175,9 +175,9 @@ __global__ __launch_bounds__(NT) void attention_fast_kernel(const AttnArgs a)
     float *part = prob + ((a.seq_len + 3) & ~3);       // G*hs
     const int h = blockIdx.x;
     const int kvh = h / a.kv_mul;                      // :369 (h / kv_mul) * head_size
-    const float *kbase = a.kcache + (size_t)kvh * hs;
-    const float *vbase = a.vcache + (size_t)kvh * hs;
-    const size_t stride = (size_t)a.kv_dim;
+    const float *kbase = a.kcache + (size_t)kvh * a.kv_head;  // head-major cache: this head's rows are contiguous
+    const float *vbase = a.vcache + (size_t)kvh * a.kv_head;
+    const size_t stride = (size_t)a.kv_row;
     const int g = threadIdx.x / ge.TPR, c0 = threadIdx.x % ge.TPR;
     const bool active = c0 < ge.E;
     const int cc = active ? c0 : 0;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(NT) void attention_fast_kernel(const AttnArgs a)
 // Split attention (flash-decoding form).  One CU pulls only ~45 GB/s, so one block per
 // head (attention_fast_kernel) leaves 7/8 of a 256-CU chip idle at 32 heads and spends its
 // time waiting for its own K/V rows (measured with s_memtime: 6 of 10 us).  Here head h is
-// shared by `nch` blocks; block (h, c) owns timesteps t = c, c+nch, c+2*nch, ... and writes
+// shared by `nch` blocks; block (h, c) owns a contiguous range of timesteps (see the kernel) and writes
 //     m_c = max score,  l_c = sum exp(score - m_c),  o_c[i] = sum exp(score - m_c) * V[t][i]
 // the combine then forms  out[i] = (sum_c o_c[i] e^(m_c-M)) / (sum_c l_c e^(m_c-M)),
 // M = max_c m_c.  Mathematically main.zig:361-389; in floating point the weights are
@@ -322,9 +322,7 @@ __global__ __launch_bounds__(NT) void attention_split_kernel(const AttnArgs a, i
     float *part = wt + ((max_local + 3) & ~3);         // G*hs
     const int h = blockIdx.x / nch, c = blockIdx.x % nch;
     const int kvh = h / a.kv_mul;                      // :369
-    const float *kbase = a.kcache + (size_t)kvh * hs;
-    const float *vbase = a.vcache + (size_t)kvh * hs;
-    const size_t stride = (size_t)a.kv_dim;
+    const size_t stride = (size_t)a.kv_row;
     const int g = threadIdx.x / ge.TPR, c0 = threadIdx.x % ge.TPR;
     const bool active = c0 < ge.E;
     const int cc = active ? c0 : 0;
@@ -332,10 +330,18 @@ __global__ __launch_bounds__(NT) void attention_split_kernel(const AttnArgs a, i
     const v4f zero = {0.f, 0.f, 0.f, 0.f};
 
     const int T = *a.pos_ptr + 1;                      // :367
-    const int Tc = T > c ? (T - c + nch - 1) / nch : 0;  // timesteps owned by this block
+    // chunk c owns the CONTIGUOUS timesteps [c * per, c * per + Tc): in the head-major cache that is one
+    // run of Tc * head_size floats of K and one of V -- a linear stream per block (the (seq_len, kv_dim)
+    // order gave 512-byte pieces 16 KB apart at the 7B shape).  per is even: a wave's two rows stay
+    // 1 KB aligned.  Late chunks are empty while pos is small.
+    const int per = (((T + nch - 1) / nch) + 1) & ~1;
+    const int t_lo = c * per;
+    const int Tc = T > t_lo ? (T - t_lo < per ? T - t_lo : per) : 0;  // timesteps owned by this block
+    const float *kbase = a.kcache + (size_t)kvh * a.kv_head + (size_t)t_lo * stride;
+    const float *vbase = a.vcache + (size_t)kvh * a.kv_head + (size_t)t_lo * stride;
     float *po = part_out + ((size_t)h * nch + c) * (size_t)(hs + 4);
     float m = -INFINITY, l = 0.0f;
-    if (Tc == 0) {  // pos < c: empty chunk (uniform branch)
+    if (Tc == 0) {  // pos < t_lo: empty chunk (uniform branch)
         for (int i = threadIdx.x; i < hs; i += blockDim.x)
             __hip_atomic_store(po + i, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
@@ -347,16 +353,16 @@ __global__ __launch_bounds__(NT) void attention_split_kernel(const AttnArgs a, i
         for (int i = 0; i < kFastUB; i++) {  // rows clamped to the chunk's last one (duplicates hit L1)
             int j = g + ge.G * i;
             j = j < Tc ? j : Tc - 1;
-            kr[i] = ldg_nt((const v4f *)(kbase + (size_t)(c + nch * j) * stride) + cc);
+            kr[i] = ldg_nt((const v4f *)(kbase + (size_t)j * stride) + cc);
         }
 #pragma unroll
         for (int i = 0; i < kFastUB; i++) {
             int j = g + ge.G * i;
             j = j < Tc ? j : Tc - 1;
-            vr[i] = ldg_nt((const v4f *)(vbase + (size_t)(c + nch * j) * stride) + cc);
+            vr[i] = ldg_nt((const v4f *)(vbase + (size_t)j * stride) + cc);
         }
         const float div = sqrtf((float)hs);
-        for (int j0 = g;;) {  // scores (:367-375), local index j <-> t = c + nch*j
+        for (int j0 = g;;) {  // scores (:367-375), local index j <-> t = t_lo + j
 #pragma unroll
             for (int i = 0; i < kFastUB; i++) {
                 float p = hsum4(fma4(qv, kr[i], zero));
@@ -370,7 +376,7 @@ __global__ __launch_bounds__(NT) void attention_split_kernel(const AttnArgs a, i
             for (int i = 0; i < kFastUB; i++) {
                 int j = j0 + ge.G * i;
                 j = j < Tc ? j : Tc - 1;
-                kr[i] = ldg_nt((const v4f *)(kbase + (size_t)(c + nch * j) * stride) + cc);
+                kr[i] = ldg_nt((const v4f *)(kbase + (size_t)j * stride) + cc);
             }
         }
         __syncthreads();
@@ -399,7 +405,7 @@ __global__ __launch_bounds__(NT) void attention_split_kernel(const AttnArgs a, i
             for (int i = 0; i < kFastUB; i++) {
                 int j = j0 + ge.G * i;
                 j = j < Tc ? j : Tc - 1;
-                vr[i] = ldg_nt((const v4f *)(vbase + (size_t)(c + nch * j) * stride) + cc);
+                vr[i] = ldg_nt((const v4f *)(vbase + (size_t)j * stride) + cc);
             }
         }
         if (active) ((v4f *)(part + (size_t)g * hs))[cc] = acc;
@@ -446,10 +452,10 @@ __global__ __launch_bounds__(kBlock) void attention_kernel(const AttnArgs a)
     const int T = *a.pos_ptr + 1;                     // timesteps 0..pos inclusive (:367)
     for (int i = threadIdx.x; i < hs; i += blockDim.x) qs[i] = a.q[(size_t)h * hs + i];
     __syncthreads();
-    attn_scores<VEC>(qs, a.kcache + (size_t)kvh * hs, a.kv_dim, hs, T, sqrtf((float)hs), att);
+    attn_scores<VEC>(qs, a.kcache + (size_t)kvh * a.kv_head, a.kv_row, hs, T, sqrtf((float)hs), att);
     __syncthreads();
     block_softmax(att, T, scratch);                   // :378
-    attn_weighted_sum<VEC>(att, a.vcache + (size_t)kvh * hs, a.kv_dim, hs, T, part,
+    attn_weighted_sum<VEC>(att, a.vcache + (size_t)kvh * a.kv_head, a.kv_row, hs, T, part,
                            a.xb + (size_t)h * hs);    // :381-388
 }
 
@@ -487,6 +493,23 @@ size_t attention_lds_bytes(int head_size, int seq_len, bool vec)
         if (f2 > fl) fl = f2;
     }
     return fl * sizeof(float);
+}
+
+// Below this position the one-block-per-head kernel runs in its 256-thread form with the speculative first
+// round whatever the model's seq_len (0: never): a short context is a latency chain -- pos, q, K and V in ONE
+// round trip, 4 waves instead of 16 to launch, 16 groups instead of 64 to combine -- and the 1024-thread
+// form only pays once a head has more rows than 256 threads keep in flight.  Two rounds of the 256-thread
+// geometry: 256 positions at head sizes <= 64 (stories110M: 7.3 -> ~4.5 us per layer at pos < 66), 128 at
+// head size 128 (7B: the forms cross there, profiles/r02_kind_scan.txt).  A function of the MODEL only, so
+// every rank of a shard group takes the same form at the same position.
+int attention_short_pos(int head_size, int seq_len)
+{
+    const int forced = tunables().attn_short_pos;
+    if (forced >= 0) return forced < seq_len ? forced : seq_len;
+    if (seq_len <= 512 || (head_size % 4) != 0 || head_size > 256) return 0;  // that form at every position anyway
+    const AttnGeom ge = attn_geom(head_size, true, kBlock);
+    const int two_rounds = 2 * ge.G * kFastUB;
+    return two_rounds < 256 ? two_rounds : 256;
 }
 
 int attention_split_chunks(int n_heads_local, int n_cus)
@@ -527,13 +550,13 @@ hipError_t launch_attention_split(const AttnArgs &a_in, int n_heads_local, int n
 
 bool attention_push_supported(const AttnArgs &a)
 {
-    return (a.head_size % 4) == 0 && (a.kv_dim % 4) == 0 && a.head_size <= 256 && aligned16(a.q) &&
+    return (a.head_size % 4) == 0 && (a.kv_row % 4) == 0 && (a.kv_head % 4) == 0 && a.head_size <= 256 && aligned16(a.q) &&
            aligned16(a.kcache) && aligned16(a.vcache);  // the fast / split kernels, not the generic one
 }
 
 bool attention_split_supported(const AttnArgs &a)
 {
-    return (a.head_size % 4) == 0 && a.head_size <= 256 && (a.kv_dim % 4) == 0 && aligned16(a.q) &&
+    return (a.head_size % 4) == 0 && a.head_size <= 256 && (a.kv_row % 4) == 0 && (a.kv_head % 4) == 0 && aligned16(a.q) &&
            aligned16(a.kcache) && aligned16(a.vcache);
 }
 
@@ -542,7 +565,7 @@ bool attention_split_supported(const AttnArgs &a)
 hipError_t launch_attention(const AttnArgs &a_in, int n_heads_local, hipStream_t st, int form)
 {
     const AttnArgs &a = a_in;
-    const bool vec = (a.head_size % 4) == 0 && (a.kv_dim % 4) == 0 && aligned16(a.q) &&
+    const bool vec = (a.head_size % 4) == 0 && (a.kv_row % 4) == 0 && (a.kv_head % 4) == 0 && aligned16(a.q) &&
                      aligned16(a.kcache) && aligned16(a.vcache);
     const size_t lds = attention_lds_bytes(a.head_size, a.seq_len, vec);
     if (vec && a.head_size <= 256 && form != 4) {

@@ -57,8 +57,9 @@ int check_pair(const l2z_config *config, const l2z_runstate *s, const l2z_weight
 //               slot while staging x: no launch per gather, 5 nodes per layer as at world == 1;
 //   gather launch after every producer (peer writes without consumer polling, or RCCL).
 int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof *prof,
-                    int only_stage, bool split, int only_kind)
+                    int only_stage, int variant, int only_kind)
 {
+    const bool split = variant == ATTN_SPLIT;
     const l2z_config &c = s->cfg;
     const Shard &sh = s->sh;
     hipStream_t st = s->stream;
@@ -116,8 +117,11 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         a.push_gi = gi + 1;
     };
     for (int l = 0; l < c.n_layers; l++) {
-        float *kc = s->key_cache + (size_t)l * c.seq_len * sh.kvd_loc;  // :354 loff
+        // :354 loff; inside a layer the device cache is head-major, [kv heads][seq_len][head_size]: the rows
+        // one head's attention reads are one contiguous run
+        float *kc = s->key_cache + (size_t)l * c.seq_len * sh.kvd_loc;
         float *vc = s->value_cache + (size_t)l * c.seq_len * sh.kvd_loc;
+        const size_t kvh_stride = (size_t)c.seq_len * sh.hs;
         const bool fused = s->fused_qkv_attn && !split && only_stage < 0;
         if (fused && kind(KIND_QKV)) {    // small models: :305-389 in one launch, one block per head (fused_small.hip)
             FusedQkvAttnArgs a = {};
@@ -127,6 +131,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.rms_w = w->rms_att + (size_t)l * dim; a.x = s->x; a.q_out = s->q;
             a.kcache = kc; a.vcache = vc; a.xb = s->xb; a.pos_ptr = s->d_pos; a.rope = s->rope;
             a.n = c.dim; a.head_size = sh.hs; a.seq_len = c.seq_len; a.kv_dim = sh.kvd_loc;
+            a.kv_row = sh.hs; a.kv_head = kvh_stride;
             L2Z_LAUNCH(KIND_QKV, launch_fused_qkv_attn(a, c.n_heads, st));
         }
         if (!fused && want() && kind(KIND_QKV)) {   // rmsnorm (:305) + q,k,v (:308-320) + RoPE (:336-351) + KV write (:354-358)
@@ -136,7 +141,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.w2 = w->wv + (size_t)l * sh.kvd_loc * dim;
             a.out0 = s->q; a.out1 = kc; a.out2 = vc;
             a.rows0 = sh.dim_loc; a.rows1 = sh.kvd_loc; a.rows2 = sh.kvd_loc;
-            a.pos_stride1 = sh.kvd_loc; a.pos_stride2 = sh.kvd_loc;
+            a.pos_stride1 = sh.hs; a.pos_stride2 = sh.hs; a.kv_head_stride = kvh_stride;
             a.n = c.dim; a.rms_w = w->rms_att + (size_t)l * dim;
             x_in(a, s->x, gi, sh.dim_loc);  // layer 0: the embedding row, a plain buffer (gi == 0)
             a.pos_ptr = s->d_pos; a.rope = s->rope; a.head_size = sh.hs; a.rope_segs = 2;
@@ -145,7 +150,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         if (!fused && want() && kind(KIND_ATTN)) {   // attention (:361-389) over the local heads
             AttnArgs a = {};
             a.q = s->q; a.kcache = kc; a.vcache = vc; a.xb = s->xb + sh.dim0;
-            a.pos_ptr = s->d_pos; a.head_size = sh.hs; a.kv_dim = sh.kvd_loc;
+            a.pos_ptr = s->d_pos; a.head_size = sh.hs; a.kv_row = sh.hs; a.kv_head = kvh_stride;
             a.kv_mul = c.n_heads / c.n_kv_heads; a.seq_len = c.seq_len;
             if (can_push && attention_push_supported(a)) {
                 a.push = s->d_push + 0;
@@ -157,7 +162,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
                 L2Z_LAUNCH(KIND_ATTN, launch_attention_split(a, sh.heads_loc, s->attn_nch,
                                                              s->d_attn_part, s->d_attn_cnt, st));
             else
-                L2Z_LAUNCH(KIND_ATTN, launch_attention(a, sh.heads_loc, st));
+                L2Z_LAUNCH(KIND_ATTN, launch_attention(a, sh.heads_loc, st, variant == ATTN_SHORT ? 1 : 0));
         }
         L2Z_TRY(gather(s->xb, sh.dim_loc));
         if (want() && kind(KIND_WO)) {   // wo (:392) + residual (:395)
@@ -220,14 +225,18 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
     return L2Z_OK;
 }
 
-bool use_split(const l2z_runstate *s, int pos) { return s->attn_nch > 1 && pos >= s->attn_split_pos; }
+int attn_variant(const l2z_runstate *s, int pos)
+{
+    if (s->attn_nch > 1 && pos >= s->attn_split_pos) return ATTN_SPLIT;
+    return pos < s->attn_short_pos ? ATTN_SHORT : ATTN_HEAD;
+}
 
-int build_graph(l2z_runstate *s, const l2z_weights *w, bool with_step, bool split,
+int build_graph(l2z_runstate *s, const l2z_weights *w, bool with_step, int variant,
                 hipGraphExec_t *out)
 {
     hipGraph_t graph = nullptr;
     L2Z_HIP(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-    int rc = enqueue_forward(s, w, with_step, nullptr, -1, split);
+    int rc = enqueue_forward(s, w, with_step, nullptr, -1, variant);
     hipError_t e = hipStreamEndCapture(s->stream, &graph);
     if (rc != L2Z_OK) {
         if (graph) (void)hipGraphDestroy(graph);
@@ -242,7 +251,7 @@ int build_graph(l2z_runstate *s, const l2z_weights *w, bool with_step, bool spli
 
 void drop_graphs(l2z_runstate *s)
 {
-    for (int v = 0; v < 2; v++) {
+    for (int v = 0; v < ATTN_VARIANTS; v++) {
         if (s->g_forward[v]) { (void)hipGraphExecDestroy(s->g_forward[v]); s->g_forward[v] = nullptr; }
         if (s->g_step[v]) { (void)hipGraphExecDestroy(s->g_step[v]); s->g_step[v] = nullptr; }
     }
@@ -252,13 +261,14 @@ void drop_graphs(l2z_runstate *s)
 int ensure_graphs(l2z_runstate *s, const l2z_weights *w)
 {
     if (!s->use_graphs) return L2Z_OK;
-    if (s->graph_w_uid == w->uid && s->g_forward[0] && s->g_step[0]) return L2Z_OK;
+    if (s->graph_w_uid == w->uid && s->g_forward[ATTN_HEAD] && s->g_step[ATTN_HEAD]) return L2Z_OK;
     drop_graphs(s);
-    const int n_var = s->attn_nch > 1 ? 2 : 1;
     int rc = L2Z_OK;
-    for (int v = 0; v < n_var && rc == L2Z_OK; v++) {
-        rc = build_graph(s, w, false, v == 1, &s->g_forward[v]);
-        if (rc == L2Z_OK) rc = build_graph(s, w, true, v == 1, &s->g_step[v]);
+    for (int v = 0; v < ATTN_VARIANTS && rc == L2Z_OK; v++) {
+        // only the variants some position of this model takes (attn_variant)
+        if ((v == ATTN_SHORT && s->attn_short_pos <= 0) || (v == ATTN_SPLIT && s->attn_nch <= 1)) continue;
+        rc = build_graph(s, w, false, v, &s->g_forward[v]);
+        if (rc == L2Z_OK) rc = build_graph(s, w, true, v, &s->g_step[v]);
     }
     if (rc != L2Z_OK) {
         // capture is an optimisation, not a requirement: run the same launches eagerly
@@ -275,18 +285,17 @@ int ensure_graphs(l2z_runstate *s, const l2z_weights *w)
 // one forward pass at position `pos` (the host mirrors the device-side pos)
 int run_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, int pos)
 {
-    const bool split = use_split(s, pos);
+    const int variant = attn_variant(s, pos);
     L2Z_CHECK(s->sh.world == 1 || (s->comm && (s->comm->nccl || s->comm->p2p)), L2Z_ERR_STATE,
               "sharded runstate without a transport: connect the group (RCCL id or "
               "l2z_comm_p2p_export/_connect), or drive emulated ranks with l2z_emu_transformer");
     L2Z_TRY(comm_check(s->comm));
     L2Z_TRY(ensure_graphs(s, w));
     if (s->use_graphs) {
-        const int v = split ? 1 : 0;
-        L2Z_HIP(hipGraphLaunch(with_step ? s->g_step[v] : s->g_forward[v], s->stream));
+        L2Z_HIP(hipGraphLaunch(with_step ? s->g_step[variant] : s->g_forward[variant], s->stream));
         return L2Z_OK;
     }
-    return enqueue_forward(s, w, with_step, nullptr, -1, split);
+    return enqueue_forward(s, w, with_step, nullptr, -1, variant);
 }
 
 
@@ -451,7 +460,7 @@ extern "C" int l2z_profile_forward(int token, int pos, const l2z_config *config,
     L2Z_HIP(launch_set_state(token, pos, s->d_token, s->d_pos, w->tok_emb, s->x, config->dim,
                              s->stream));
     Prof prof;
-    int rc = enqueue_forward(s, w, true, &prof, -1, use_split(s, pos));
+    int rc = enqueue_forward(s, w, true, &prof, -1, attn_variant(s, pos));
     hipError_t e = hipStreamSynchronize(s->stream);
     for (int k = 0; k < n_kinds; k++) { ms_by_kind[k] = 0.0; launches_by_kind[k] = 0; }
     if (rc == L2Z_OK && e == hipSuccess) {
@@ -489,9 +498,9 @@ extern "C" int l2z_time_kind(int kind, int pos, const l2z_config *config, l2z_ru
     L2Z_HIP(hipEventCreate(&e0));
     L2Z_HIP(hipEventCreate(&e1));
     const int per_pass = kind == KIND_CLS || kind == KIND_ARGMAX ? 1 : config->n_layers;
-    int rc = enqueue_forward(s, w, true, nullptr, -1, use_split(s, pos), kind);  // warm-up pass
+    int rc = enqueue_forward(s, w, true, nullptr, -1, attn_variant(s, pos), kind);  // warm-up pass
     hipError_t e = hipEventRecord(e0, s->stream);
-    for (int r = 0; r < reps && rc == L2Z_OK; r++) rc = enqueue_forward(s, w, true, nullptr, -1, use_split(s, pos), kind);
+    for (int r = 0; r < reps && rc == L2Z_OK; r++) rc = enqueue_forward(s, w, true, nullptr, -1, attn_variant(s, pos), kind);
     if (e == hipSuccess) e = hipEventRecord(e1, s->stream);
     if (e == hipSuccess) e = hipEventSynchronize(e1);
     float ms = 0.0f;
@@ -530,7 +539,7 @@ extern "C" int l2z_emu_transformer(int n_ranks, l2z_runstate *const *ss,
     const int n_stages = 4 * c.n_layers + 1;
     for (int stage = 0; stage < n_stages; stage++) {
         for (int r = 0; r < n_ranks; r++)
-            L2Z_TRY(enqueue_forward(ss[r], ws[r], false, nullptr, stage, use_split(ss[r], pos)));
+            L2Z_TRY(enqueue_forward(ss[r], ws[r], false, nullptr, stage, attn_variant(ss[r], pos)));
         for (int r = 0; r < n_ranks; r++) L2Z_HIP(hipStreamSynchronize(ss[r]->stream));
         // which buffer this stage produced, and the per-rank slice length
         const Shard &sh0 = ss[0]->sh;

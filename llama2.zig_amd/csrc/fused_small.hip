@@ -61,8 +61,8 @@ __global__ __launch_bounds__(kFusedBlock) void fused_qkv_attn_kernel(const Fused
     const int g = tid / ge.TPR, c0 = tid % ge.TPR;
     const bool active = c0 < ge.E;
     const int cc = active ? c0 : 0;
-    const size_t stride = (size_t)a.kv_dim;
-    const float *kbase = a.kcache + (size_t)h * hs, *vbase = a.vcache + (size_t)h * hs;
+    const size_t stride = (size_t)a.kv_row;
+    const float *kbase = a.kcache + (size_t)h * a.kv_head, *vbase = a.vcache + (size_t)h * a.kv_head;
     // lane L of wave w asks for the float4 it will use itself: LDS slot [i][tid] (a wave's 64 slots
     // are the 1 KB the instruction writes, lane-linear from the wave-uniform base)
 #pragma unroll
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kFusedBlock) void fused_qkv_attn_kernel(const Fused
             cur[seg * hs + 2 * lp] = o0;
             cur[seg * hs + 2 * lp + 1] = o1;
             float *dst = seg == 0 ? a.q_out + (size_t)h * hs
-                                  : (seg == 1 ? a.kcache : a.vcache) + (size_t)pos * stride + (size_t)h * hs;
+                                  : (seg == 1 ? a.kcache : a.vcache) + (size_t)pos * stride + (size_t)h * a.kv_head;
             dst[2 * lp] = o0;
             dst[2 * lp + 1] = o1;
         }

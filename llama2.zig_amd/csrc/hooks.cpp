@@ -137,6 +137,20 @@ extern "C" int l2z_argmax_host(const float *x, size_t n, size_t *out_index)
     return L2Z_OK;
 }
 
+// The reference's cache order (seq_len, kv_dim) (main.zig:354) -> the device's head-major order
+// [kv head][seq_len][head_size], so that the hooks drive the kernels on the layout the forward
+// pass gives them.
+static std::vector<float> to_head_major(const float *src, int seq_len, int n_kv_heads, int head_size)
+{
+    const size_t kvd = (size_t)n_kv_heads * head_size;
+    std::vector<float> out((size_t)seq_len * kvd);
+    for (int h = 0; h < n_kv_heads; h++)
+        for (int t = 0; t < seq_len; t++)
+            memcpy(out.data() + ((size_t)h * seq_len + t) * head_size, src + (size_t)t * kvd + (size_t)h * head_size,
+                   (size_t)head_size * sizeof(float));
+    return out;
+}
+
 // src/main.zig:361-389 for the P queries of a prompt chunk at positions pos0 .. pos0 + P - 1, through the
 // batched prefill's attention kernels (prefill_attention.hip).  form: 0 as l2z_prefill picks, 1 block per
 // (head, query), 2 tiled with the softmax in LDS, 3 flash form with one key part, 4 flash form with two.
@@ -154,14 +168,16 @@ extern "C" int l2z_prefill_attention(int form, float *out, const float *q, const
     DevBuf dq, dk, dv, dout;
     L2Z_TRY(dq.alloc(n_queries * dim)); L2Z_TRY(dk.alloc(seq_len * kvd)); L2Z_TRY(dv.alloc(seq_len * kvd));
     L2Z_TRY(dout.alloc(n_queries * dim));
-    L2Z_TRY(dq.up(q, n_queries * dim)); L2Z_TRY(dk.up(kcache, seq_len * kvd)); L2Z_TRY(dv.up(vcache, seq_len * kvd));
+    const std::vector<float> hk = to_head_major(kcache, seq_len, n_kv_heads, head_size),
+                             hv = to_head_major(vcache, seq_len, n_kv_heads, head_size);
+    L2Z_TRY(dq.up(q, n_queries * dim)); L2Z_TRY(dk.up(hk.data(), seq_len * kvd)); L2Z_TRY(dv.up(hv.data(), seq_len * kvd));
     // the launcher reads L2Z_PF_ATTN and a block-count threshold: force the form through both
     const int saved = tunables().pf_attn;
     const int knob[5] = {saved, 0, 2, 3, 1};
     tunables_set("L2Z_PF_ATTN", knob[form]);
     const hipError_t e = launch_prefill_attention(dq.p, (int)dim, dk.p, dv.p, dout.p, (int)dim, pos0, n_queries, n_heads,
-                                                  head_size, (int)kvd, n_heads / n_kv_heads, seq_len, nullptr,
-                                                  form >= 2 ? (1 << 20) : n_heads);
+                                                  head_size, head_size, (size_t)seq_len * head_size, n_heads / n_kv_heads,
+                                                  seq_len, nullptr, form >= 2 ? (1 << 20) : n_heads);
     tunables_set("L2Z_PF_ATTN", saved);
     L2Z_HIP(e);
     L2Z_HIP(hipDeviceSynchronize());
@@ -184,10 +200,13 @@ extern "C" int l2z_attention_decode(int form, int nch, float *out, const float *
     DevBuf dq, dk, dv, dout, dpart;
     int *dpos = nullptr, *dcnt = nullptr;
     L2Z_TRY(dq.alloc(dim)); L2Z_TRY(dk.alloc(kvn)); L2Z_TRY(dv.alloc(kvn)); L2Z_TRY(dout.alloc(dim));
-    L2Z_TRY(dq.up(q, dim)); L2Z_TRY(dk.up(kcache, kvn)); L2Z_TRY(dv.up(vcache, kvn));
+    const std::vector<float> hk = to_head_major(kcache, seq_len, n_kv_heads, head_size),
+                             hv = to_head_major(vcache, seq_len, n_kv_heads, head_size);
+    L2Z_TRY(dq.up(q, dim)); L2Z_TRY(dk.up(hk.data(), kvn)); L2Z_TRY(dv.up(hv.data(), kvn));
     AttnArgs a = {};
     a.q = dq.p; a.kcache = dk.p; a.vcache = dv.p; a.xb = dout.p;
-    a.head_size = head_size; a.kv_dim = (int)kvd; a.kv_mul = n_heads / n_kv_heads; a.seq_len = seq_len;
+    a.head_size = head_size; a.kv_row = head_size; a.kv_head = (size_t)seq_len * head_size;
+    a.kv_mul = n_heads / n_kv_heads; a.seq_len = seq_len;
     const bool fast_ok = attention_split_supported(a);  // same conditions as the fast kernels
     L2Z_CHECK(form == 0 || form == 4 || fast_ok, L2Z_ERR_INVALID,
               "l2z_attention_decode: form %d needs head_size %% 4 == 0 and <= 256", form);
@@ -211,7 +230,9 @@ extern "C" int l2z_attention_decode(int form, int nch, float *out, const float *
         if (e == hipSuccess) e = launch_attention_split(a, n_heads, use_nch, dpart.p, dcnt, nullptr);
         if (e == hipSuccess) e = launch_attention_split(a, n_heads, use_nch, dpart.p, dcnt, nullptr);
     } else if (e == hipSuccess) {
-        e = launch_attention(a, n_heads, nullptr, form == 3 ? 0 : form);
+        // form 0: what the forward pass launches at this position (attn_variant: the short-context form first)
+        const int auto_form = pos < attention_short_pos(head_size, seq_len) ? 1 : 0;
+        e = launch_attention(a, n_heads, nullptr, form == 3 || form == 0 ? auto_form : form);
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     (void)hipFree(dpos);

@@ -96,7 +96,11 @@ struct MatvecArgs {
     const float *w0, *w1, *w2;   // unused segments: null, rows = 0
     float *out0, *out1, *out2;
     int rows0, rows1, rows2;
-    int pos_stride1, pos_stride2;  // out1/out2 += pos * stride (KV-cache row select)
+    int pos_stride1, pos_stride2;  // out1/out2 += pos * stride (row select of a flat (rows, stride) buffer)
+    // EPI_ROPE into the device KV cache: out1 / out2 are one layer's head-major caches
+    // [kv_heads][seq_len][head_size]; row r of the segment goes to (r / head_size) * kv_head_stride +
+    // pos * head_size + r % head_size.  0: flat form above.
+    size_t kv_head_stride;
     int n;                    // columns = length of x
     const float *x;
     const float *rms_w;       // PRO_RMS: rmsnorm weight (n)
@@ -124,12 +128,13 @@ struct MatvecArgs {
 // main.zig:361-389: scores, softmax, att.V for the local heads of one layer
 struct AttnArgs {
     const float *q;        // (n_heads_local * head_size)
-    const float *kcache;   // this layer: (seq_len, kv_dim_local)
+    const float *kcache;   // this layer: [kv_heads_local][seq_len][head_size] (head-major)
     const float *vcache;
     float *xb;             // (n_heads_local * head_size)
     const int *pos_ptr;
     int head_size;
-    int kv_dim;            // local row stride of the caches
+    int kv_row;            // floats between consecutive timesteps of one kv head (head-major: head_size)
+    size_t kv_head;        // floats between kv heads (head-major: seq_len * head_size)
     int kv_mul;
     int seq_len;
     const P2pArgs *push;   // as in MatvecArgs, for xb (fast / split-combine kernels); may be null
@@ -144,12 +149,14 @@ struct FusedQkvAttnArgs {
     const float *wq, *wk, *wv;   // this layer: (dim, dim) each (MHA: kv_dim == dim)
     const float *rms_w, *x;      // (dim)
     float *q_out;                // RunState.q (dim)
-    float *kcache, *vcache;      // this layer: (seq_len, kv_dim); row pos is written
+    float *kcache, *vcache;      // this layer: [heads][seq_len][head_size]; row pos of every head is written
     float *xb;                   // (dim) attention output
     const int *pos_ptr;
     const float2 *rope;
     int n;                       // dim
     int head_size, seq_len, kv_dim;
+    int kv_row;                  // floats between timesteps of one head, and between heads (as AttnArgs)
+    size_t kv_head;
 };
 bool fused_qkv_attn_supported(int dim, int n_heads, int n_kv_heads, int seq_len, int n_cus);
 hipError_t launch_fused_qkv_attn(const FusedQkvAttnArgs &a, int n_heads, hipStream_t st);
@@ -168,7 +175,9 @@ bool matvec_vector_width(int n);
 // out: >= 8 * n_cus floats of scratch (never written in practice)
 hipError_t launch_stream_read(const float *p, size_t n_floats, float *out, int n_cus, hipStream_t st);  // upper bound of the grid launch_matvec picks
 hipError_t launch_attention(const AttnArgs &a, int n_heads_local, hipStream_t st, int form = 0);
-// flash-decoding form: `nch` blocks per head + a combine launch (attention.hip)
+// positions below this take the 256-thread speculative one-block-per-head form whatever seq_len is (attention.hip)
+int attention_short_pos(int head_size, int seq_len);
+// flash-decoding form: `nch` blocks per head, the last arriver combines (attention.hip)
 int attention_split_chunks(int n_heads_local, int n_cus);
 size_t attention_split_part_floats(int n_heads_local, int head_size, int nch);
 bool attention_split_supported(const AttnArgs &a);
@@ -195,23 +204,26 @@ enum PrefillGemmEpi { PG_STORE = 0, PG_RESID = 1, PG_ROPE = 2, PG_ROPE_CACHE = 3
 hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w, float *out, int ldo,
                                int P, int N, int K, int pos0, const float2 *rope, int head_size,
                                hipStream_t st, const float *res = nullptr, int ldres = 0,
-                               int n_scale = 1);  // n_scale: ranks the rows are sharded over (kernel-form choices look at the whole matrix)
+                               int n_scale = 1,  // n_scale: ranks the rows are sharded over (kernel-form choices look at the whole matrix)
+                               size_t kv_head_stride = 0);  // PG_*CACHE: out is a head-major cache (MatvecArgs::kv_head_stride)
 hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, const float *wk, const float *wv,
                                    float *q_out, int ldq, float *kcache, float *vcache, int ldkv, int P, int nq,
-                                   int nkv, int K, int pos0, const float2 *rope, int head_size, hipStream_t st);
+                                   int nkv, int K, int pos0, const float2 *rope, int head_size, hipStream_t st,
+                                   size_t kv_head_stride = 0);
 hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float *w1, const float *w3,
                                            float *out, int ldo, int P, int N, int K, hipStream_t st,
                                            int n_scale = 1);
 hipError_t launch_prefill_gemm_kv_pair(const float *x, int ldx, const float *wk, const float *wv, float *kcache,
                                        float *vcache, int ldkv, int P, int nkv, int K, int pos0, const float2 *rope,
-                                       int head_size, hipStream_t st, int n_scale = 1);
+                                       int head_size, hipStream_t st, int n_scale = 1, size_t kv_head_stride = 0);
 hipError_t launch_prefill_rmsnorm(float *o, const float *x, const float *w, int n, int P,
                                   hipStream_t st);
 hipError_t launch_prefill_embed(float *x, const float *tok_emb, const int *tokens, int dim, int P,
                                 hipStream_t st);
+// kv_row / kv_head: floats between timesteps of one kv head / between kv heads (AttnArgs)
 hipError_t launch_prefill_attention(const float *q, int ldq, const float *kcache, const float *vcache,
                                     float *out, int ldo, int pos0, int P, int n_heads, int head_size,
-                                    int kv_dim, int kv_mul, int seq_len, hipStream_t st,
+                                    int kv_row, size_t kv_head, int kv_mul, int seq_len, hipStream_t st,
                                     int n_heads_model = 0);  // heads of the whole model when n_heads is a shard's
 int prefill_tile_form(int N, int P, int pair);  // 0: 128x64, 1: 64x64, 2: 32x64, 3: 32x32, 4: 128x128
 size_t matvec_lds_bytes(int n);

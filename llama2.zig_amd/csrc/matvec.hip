@@ -72,6 +72,7 @@ struct MvLocals {
     const float2 *rope;
     int rows0, r01, total_rows, n_pairs, n, head_size, rope_segs, pos;
     size_t ps1, ps2;
+    size_t kv_head_stride;  // != 0: out1 / out2 are head-major caches (MatvecArgs::kv_head_stride)
     const P2pArgs *push;  // sharded: LL words of the outputs go straight to the peers
     int push_e;
     size_t push_base;     // index of out0[0] in the gathered vector
@@ -90,6 +91,7 @@ __device__ __forceinline__ MvLocals mv_locals(const MatvecArgs &a)
     m.pos = (EPI == EPI_ROPE) ? *a.pos_ptr : 0;
     m.ps1 = (size_t)m.pos * (size_t)a.pos_stride1;
     m.ps2 = (size_t)m.pos * (size_t)a.pos_stride2;
+    m.kv_head_stride = (EPI == EPI_ROPE) ? a.kv_head_stride : 0;
     m.push = a.push;
     m.push_e = m.push ? a.push_ctl[kCtlEpoch] + a.push_gi : 0;
     m.push_base = m.push ? (size_t)m.push->rank * m.push->count : 0;
@@ -187,8 +189,14 @@ __device__ __forceinline__ void pair_epilogue(const MvLocals &m, int p, float sa
             o1 = sa * cs.y + sb * cs.x;  // :349
         }
         if (writer && valid_a) {  // q, or the pos row of the K / V cache (:354-358)
-            oa[row_a] = o0;
-            if (valid_b) ob[row_b] = o1;
+            size_t ia = (size_t)row_a, ib = (size_t)row_b;
+            if (m.kv_head_stride) {  // head-major cache: [kv head][pos][i]; ps1 / ps2 = pos * head_size
+                const int hs = m.head_size;
+                if (a1) ia = (size_t)(row_a / hs) * m.kv_head_stride + (size_t)(row_a % hs);
+                if (b1) ib = (size_t)(row_b / hs) * m.kv_head_stride + (size_t)(row_b % hs);
+            }
+            oa[ia] = o0;
+            if (valid_b) ob[ib] = o1;
         }
     } else if (EPI == EPI_RESID) {
         if (writer && valid_a) {

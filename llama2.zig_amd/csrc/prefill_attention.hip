@@ -69,7 +69,7 @@ __global__ void prefill_embed(float *x, const float *tok_emb, const int *tokens,
 __global__ __launch_bounds__(kPfBlock) void prefill_attention(const float *q, int ldq,
                                                               const float *kcache, const float *vcache,
                                                               float *out, int ldo, int pos0,
-                                                              int head_size, int kv_dim, int kv_mul,
+                                                              int head_size, int kv_dim, size_t kv_head, int kv_mul,
                                                               int seq_len)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kPfBlock) void prefill_attention(const float *q, in
     const int h = blockIdx.x, tok = blockIdx.y;
     const int T = pos0 + tok + 1;
     const int kvh = h / kv_mul;
-    const float *kbase = kcache + (size_t)kvh * hs, *vbase = vcache + (size_t)kvh * hs;
+    const float *kbase = kcache + (size_t)kvh * kv_head, *vbase = vcache + (size_t)kvh * kv_head;  // kv_dim: row stride
     const int g = threadIdx.x / TPR, c0 = threadIdx.x % TPR;
     const bool active = c0 < E;
     const int cc = active ? c0 : 0;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(kPfBlock) void prefill_attention(const float *q, in
 template <int NDT, int KH>
 __global__ __launch_bounds__(256 * KH) void prefill_attention_flash(const float *q, int ldq, const float *kcache,
                                                                     const float *vcache, float *out, int ldo,
-                                                                    int pos0, int P, int kv_dim, int kv_mul,
+                                                                    int pos0, int P, int kv_dim, size_t kv_head, int kv_mul,
                                                                     int seq_len)
 {
     constexpr int HS = 16 * NDT, E = HS / 4;  // float4 slots per row
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256 * KH) void prefill_attention_flash(const float 
     const int qg = wave & 3, kh = wave >> 2;  // query group (16 queries), key part (rows 64 / KH * kh .. of a tile)
     const int qi = lane & 15, g = lane >> 4;
     const int kvh = h / kv_mul;  // :369
-    const float *kbase = kcache + (size_t)kvh * HS, *vbase = vcache + (size_t)kvh * HS;
+    const float *kbase = kcache + (size_t)kvh * kv_head, *vbase = vcache + (size_t)kvh * kv_head;  // kv_dim: row stride
     const int myq = q0 + 16 * qg + qi;              // this lane's query (token index in the chunk)
     const int qrow = myq < P ? myq : P - 1;         // past the chunk: a valid row, results dropped
     v4f qreg[NDT];
@@ -315,7 +315,7 @@ template <int TPW>
 __global__ __launch_bounds__(kPfBlock) void prefill_attention_tiled(const float *q, int ldq,
                                                                     const float *kcache, const float *vcache,
                                                                     float *out, int ldo, int pos0, int P,
-                                                                    int hs, int kv_dim, int kv_mul, int seq_len)
+                                                                    int hs, int kv_dim, size_t kv_head, int kv_mul, int seq_len)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int LD = hs + 1;
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(kPfBlock) void prefill_attention_tiled(const float 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
     const int kvh = h / kv_mul;  // :369
-    const float *kbase = kcache + (size_t)kvh * hs, *vbase = vcache + (size_t)kvh * hs;
+    const float *kbase = kcache + (size_t)kvh * kv_head, *vbase = vcache + (size_t)kvh * kv_head;  // kv_dim: row stride
     const int E = hs >> 2;
     const v4f zero = {0.f, 0.f, 0.f, 0.f};
     for (int f = tid; f < 64 * E; f += kPfBlock) {
@@ -450,8 +450,9 @@ hipError_t launch_prefill_embed(float *x, const float *tok_emb, const int *token
 
 hipError_t launch_prefill_attention(const float *q, int ldq, const float *kcache, const float *vcache,
                                     float *out, int ldo, int pos0, int P, int n_heads, int head_size,
-                                    int kv_dim, int kv_mul, int seq_len, hipStream_t st, int n_heads_model)
+                                    int kv_dim, size_t kv_head, int kv_mul, int seq_len, hipStream_t st, int n_heads_model)
 {
+    // kv_dim here: floats between consecutive timesteps of one kv head (head-major cache: head_size)
     // the two kernels round differently; a shard must take the one the unsharded pass takes
     if (n_heads_model <= 0) n_heads_model = n_heads;
     const bool naive = tunables().pf_attn == 0;
@@ -477,7 +478,7 @@ hipError_t launch_prefill_attention(const float *q, int ldq, const float *kcache
         }
         const dim3 grid(n_heads, (P + 63) / 64);
         void *params[] = {(void *)&q, (void *)&ldq, (void *)&kcache, (void *)&vcache, (void *)&out, (void *)&ldo,
-                          (void *)&pos0, (void *)&P, (void *)&kv_dim, (void *)&kv_mul, (void *)&seq_len};
+                          (void *)&pos0, (void *)&P, (void *)&kv_dim, (void *)&kv_head, (void *)&kv_mul, (void *)&seq_len};
         return hipLaunchKernel(fn, grid, dim3(two ? 512 : 256), params, lds_f, st);
     }
     if (!naive && enough_blocks && lds_t <= 160 * 1024 && n_ct <= 8 && (head_size % 4) == 0 && (kv_dim % 4) == 0) {
@@ -492,13 +493,13 @@ hipError_t launch_prefill_attention(const float *q, int ldq, const float *kcache
         const dim3 grid(n_heads, (P + 63) / 64);
         if (tpw <= 1)
             hipLaunchKernelGGL(prefill_attention_tiled<1>, grid, dim3(kPfBlock), lds_t, st, q, ldq, kcache, vcache,
-                               out, ldo, pos0, P, head_size, kv_dim, kv_mul, seq_len);
+                               out, ldo, pos0, P, head_size, kv_dim, kv_head, kv_mul, seq_len);
         else if (tpw == 2)
             hipLaunchKernelGGL(prefill_attention_tiled<2>, grid, dim3(kPfBlock), lds_t, st, q, ldq, kcache, vcache,
-                               out, ldo, pos0, P, head_size, kv_dim, kv_mul, seq_len);
+                               out, ldo, pos0, P, head_size, kv_dim, kv_head, kv_mul, seq_len);
         else
             hipLaunchKernelGGL(prefill_attention_tiled<4>, grid, dim3(kPfBlock), lds_t, st, q, ldq, kcache, vcache,
-                               out, ldo, pos0, P, head_size, kv_dim, kv_mul, seq_len);
+                               out, ldo, pos0, P, head_size, kv_dim, kv_head, kv_mul, seq_len);
         return hipGetLastError();
     }
     int E = head_size >> 2, TPR = 1;
@@ -511,7 +512,7 @@ hipError_t launch_prefill_attention(const float *q, int ldq, const float *kcache
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(prefill_attention, dim3(n_heads, P), dim3(kPfBlock), lds, st, q, ldq, kcache,
-                       vcache, out, ldo, pos0, head_size, kv_dim, kv_mul, seq_len);
+                       vcache, out, ldo, pos0, head_size, kv_dim, kv_head, kv_mul, seq_len);
     return hipGetLastError();
 }
 

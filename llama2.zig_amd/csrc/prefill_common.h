@@ -41,9 +41,20 @@ struct GemmArgs {
     const float *wk, *wv;
     float *outk, *outv;
     int nq, nkv, ldkv;
+    // cache epilogues: != 0: the key / value caches are head-major [kv_heads][seq_len][head_size] and this is
+    // seq_len * head_size; 0: flat rows of ldkv (ldo) floats
+    size_t kv_head_stride;
     // direct-to-LDS tile kernel, 1-D grids (dma_grid): feature tiles, token tiles
     int ntx, nty;
 };
+
+// where feature f of position pos lives in a cache whose flat form has rows of ld floats
+__device__ __forceinline__ size_t kv_index(const GemmArgs &a, int ld, int pos, int f)
+{
+    return a.kv_head_stride ? (size_t)(f / a.head_size) * a.kv_head_stride + (size_t)pos * (size_t)a.head_size +
+                                  (size_t)(f % a.head_size)
+                            : (size_t)pos * (size_t)ld + (size_t)f;
+}
 
 // One direct-to-LDS load: 16 bytes per lane from `g` (per lane) to lds + 16 * lane (`lds` wave-uniform).
 // A plain __device__ function: called from the kernel TEMPLATE directly, the builtin makes the

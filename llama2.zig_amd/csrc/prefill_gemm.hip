@@ -105,7 +105,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, v16f (&acc)[TM]
                         const float2 cs = a.rope[(size_t)pos * (size_t)(hs >> 1) + (size_t)(((j < nseg ? j : 0) % hs) >> 1)];
                         v = (j & 1) ? partner * cs.y + v * cs.x : v * cs.x - partner * cs.y;
                     }
-                    if (tok < a.P && j < nseg) o[(size_t)(seg == 0 ? tok : a.pos0 + tok) * ld + j] = v;  // :354-358
+                    if (tok < a.P && j < nseg) o[seg == 0 ? (size_t)tok * ld + j : kv_index(a, ld, a.pos0 + tok, j)] = v;  // :354-358
                 }
             }
         return;
@@ -134,7 +134,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, v16f (&acc)[TM]
                     else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + j] = a.res[(size_t)tok * a.ldres + j] + v;  // main.zig:711
                     else if (EPI == G_SWIGLU)
                         a.out[(size_t)tok * a.ldo + j] = swiglu_merge(a.out[(size_t)tok * a.ldo + j], v);
-                    else a.out[(size_t)(a.pos0 + tok) * a.ldo + j] = v;                  // main.zig:354-358
+                    else a.out[kv_index(a, a.ldo, a.pos0 + tok, j)] = v;                  // main.zig:354-358
                 }
             }
         }
@@ -578,7 +578,7 @@ hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float 
 {
     if (tunables().pf_fuse == 0 || tunables().pf_dma == 0 || tunables().pf_tile != 0) return hipErrorNotSupported;
     if (((uintptr_t)x & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w3 & 15)) return hipErrorInvalidValue;
-    GemmArgs a = {x, w3, w1, out, out, P, N, K, ldx, ldo, ldo, 0, nullptr, 0, n_scale > 0 ? n_scale : 1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
+    GemmArgs a = {x, w3, w1, out, out, P, N, K, ldx, ldo, ldo, 0, nullptr, 0, n_scale > 0 ? n_scale : 1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
     const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
     if (P <= skinny_max) return launch_prefill_skinny_pair(G_SWIGLU, a, st);  // prefill_skinny.hip (or not supported)
     if (K % 64 != 0 || ldx % 4 != 0) return hipErrorNotSupported;
@@ -606,7 +606,8 @@ hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float 
 // not take that kernel or a tile would straddle two ranges: the caller launches the three GEMMs.
 hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, const float *wk, const float *wv,
                                    float *q_out, int ldq, float *kcache, float *vcache, int ldkv, int P, int nq,
-                                   int nkv, int K, int pos0, const float2 *rope, int head_size, hipStream_t st)
+                                   int nkv, int K, int pos0, const float2 *rope, int head_size, hipStream_t st,
+                                   size_t kv_head_stride)
 {
     if (tunables().pf_fuse == 0 || tunables().pf_dma == 0 || tunables().pf_tile != 0) return hipErrorNotSupported;
     const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
@@ -625,7 +626,7 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
         feat = 32;
     }
     GemmArgs a = {x, nullptr, wq, q_out, q_out, P, N, K, ldx, ldq, ldq, pos0, rope, head_size, 1,
-                  wk, wv, kcache, vcache, nq, nkv, ldkv, 0, 0};
+                  wk, wv, kcache, vcache, nq, nkv, ldkv, kv_head_stride, 0, 0};
     constexpr int KS = 2;
     const int tok = tf == TILE_128x64 ? 128 : tf == TILE_64x64 ? 64 : 32;
     const void *fn = tf == TILE_128x64 ? (const void *)prefill_gemm_dma<G_QKV, 2, 1, KS, false>
@@ -646,25 +647,25 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
 // brought into the CU once for both).  hipErrorNotSupported otherwise: the caller launches the two.
 hipError_t launch_prefill_gemm_kv_pair(const float *x, int ldx, const float *wk, const float *wv, float *kcache,
                                        float *vcache, int ldkv, int P, int nkv, int K, int pos0, const float2 *rope,
-                                       int head_size, hipStream_t st, int n_scale)
+                                       int head_size, hipStream_t st, int n_scale, size_t kv_head_stride)
 {
     const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
     if (P > skinny_max) return hipErrorNotSupported;
     if (((uintptr_t)x & 15) || ((uintptr_t)wk & 15) || ((uintptr_t)wv & 15)) return hipErrorInvalidValue;
     GemmArgs a = {x, wv, wk, kcache, kcache, P, nkv, K, ldx, ldkv, ldkv, pos0, rope, head_size, n_scale > 0 ? n_scale : 1,
-                  wk, wv, kcache, vcache, 0, nkv, ldkv, 0, 0};
+                  wk, wv, kcache, vcache, 0, nkv, ldkv, kv_head_stride, 0, 0};
     return launch_prefill_skinny_pair(G_QKV, a, st);
 }
 
 // C[P,N] (+)= X[P,K] W[N,K]^T with the chosen epilogue; K % 4 == 0, 16-byte aligned rows
 hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w, float *out, int ldo,
                                int P, int N, int K, int pos0, const float2 *rope, int head_size,
-                               hipStream_t st, const float *res, int ldres, int n_scale)
+                               hipStream_t st, const float *res, int ldres, int n_scale, size_t kv_head_stride)
 {
     if (P <= 0 || N <= 0 || K <= 0 || (K % 4) != 0 || (ldx % 4) != 0) return hipErrorInvalidValue;
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return hipErrorInvalidValue;
     if (res == nullptr) { res = out; ldres = ldo; }  // PG_RESID in place
-    GemmArgs a = {x, nullptr, w, out, res, P, N, K, ldx, ldo, ldres, pos0, rope, head_size, n_scale > 0 ? n_scale : 1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
+    GemmArgs a = {x, nullptr, w, out, res, P, N, K, ldx, ldo, ldres, pos0, rope, head_size, n_scale > 0 ? n_scale : 1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, kv_head_stride, 0, 0};
     const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
     if (P <= skinny_max) return launch_prefill_skinny(epi, a, st);  // prefill_skinny.hip
     switch (epi) {

@@ -84,8 +84,9 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
     const StageOut o = stage_out(s, k);
     float *out = sharded ? s->pf_stage + (size_t)sh.rank * P * o.n_loc : o.dst;
     const int ldo = sharded ? o.n_loc : o.ldd;
-    float *kc = s->key_cache + (size_t)l * c.seq_len * kvd;
+    float *kc = s->key_cache + (size_t)l * c.seq_len * kvd;  // this layer: [kv heads][seq_len][hs]
     float *vc = s->value_cache + (size_t)l * c.seq_len * kvd;
+    const size_t kvh_stride = (size_t)c.seq_len * hs;
     if (k == PF_ATT) {
         L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, s->pf_x, w->rms_att + (size_t)l * dim, dim, P, st));  // :305
         // q of the local heads ([P, dim_loc]) and the k / v rows of the local kv heads: one launch where
@@ -93,17 +94,17 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
         const float *wq = w->wq + (size_t)l * sh.dim_loc * dim, *wk = w->wk + (size_t)l * kvd * dim,
                     *wv = w->wv + (size_t)l * kvd * dim;
         const hipError_t qe = launch_prefill_gemm_qkv(s->pf_xn, dim, wq, wk, wv, s->pf_q, sh.dim_loc, kc, vc, kvd, P,
-                                                      sh.dim_loc, kvd, dim, pos0, s->rope, hs, st);
+                                                      sh.dim_loc, kvd, dim, pos0, s->rope, hs, st, kvh_stride);
         if (qe == hipErrorNotSupported) {
             L2Z_HIP(launch_prefill_gemm(PG_ROPE, s->pf_xn, dim, wq, s->pf_q, sh.dim_loc, P, sh.dim_loc, dim, pos0,
                                         s->rope, hs, st, nullptr, 0, sh.world));  // :308-351
             const hipError_t ke = launch_prefill_gemm_kv_pair(s->pf_xn, dim, wk, wv, kc, vc, kvd, P, kvd, dim, pos0,
-                                                              s->rope, hs, st, sh.world);  // short prompts: k | v together
+                                                              s->rope, hs, st, sh.world, kvh_stride);  // short prompts: k | v together
             if (ke == hipErrorNotSupported) {
                 L2Z_HIP(launch_prefill_gemm(PG_ROPE_CACHE, s->pf_xn, dim, wk, kc, kvd, P, kvd, dim, pos0, s->rope, hs,
-                                            st, nullptr, 0, sh.world));               // :354-357
+                                            st, nullptr, 0, sh.world, kvh_stride));   // :354-357
                 L2Z_HIP(launch_prefill_gemm(PG_CACHE, s->pf_xn, dim, wv, vc, kvd, P, kvd, dim, pos0, s->rope, hs, st,
-                                            nullptr, 0, sh.world));                   // :358
+                                            nullptr, 0, sh.world, kvh_stride));       // :358
             } else {
                 L2Z_HIP(ke);
             }
@@ -111,7 +112,7 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
             L2Z_HIP(qe);
         }
         L2Z_HIP(launch_prefill_attention(s->pf_q, sh.dim_loc, kc, vc, out, ldo, pos0, P, sh.heads_loc, hs,
-                                         kvd, c.n_heads / c.n_kv_heads, c.seq_len, st, c.n_heads));  // :361-389
+                                         hs, kvh_stride, c.n_heads / c.n_kv_heads, c.seq_len, st, c.n_heads));  // :361-389
     } else if (k == PF_WO) {
         const float *res = s->pf_x + sh.dim0;
         L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_att, dim, w->wo + (size_t)l * sh.dim_loc * dim, out, ldo,

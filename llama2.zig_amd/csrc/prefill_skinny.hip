@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64 * kSkWaves) void prefill_skinny(const GemmArgs a
             if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + f] = v;
             else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + f] = a.res[(size_t)tok * a.ldres + f] + v;
             else if (EPI == G_SWIGLU) a.out[(size_t)tok * a.ldo + f] = swiglu_merge(a.out[(size_t)tok * a.ldo + f], v);
-            else a.out[(size_t)(a.pos0 + tok) * a.ldo + f] = v;
+            else a.out[kv_index(a, a.ldo, a.pos0 + tok, f)] = v;
         }
     }
 }
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kPfBlock) void prefill_skinny_lds(const GemmArgs a)
             if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + f] = v;
             else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + f] = a.res[(size_t)tok * a.ldres + f] + v;
             else if (EPI == G_SWIGLU) a.out[(size_t)tok * a.ldo + f] = swiglu_merge(a.out[(size_t)tok * a.ldo + f], v);
-            else a.out[(size_t)(a.pos0 + tok) * a.ldo + f] = v;
+            else a.out[kv_index(a, a.ldo, a.pos0 + tok, f)] = v;
         }
     }
 }
@@ -330,13 +330,13 @@ __global__ __launch_bounds__(kPfBlock) void prefill_skinny_dma(const GemmArgs a)
         if (tok < a.P && f < a.N) {
             if (NW == 2 && EPI == G_SWIGLU) a.out[(size_t)tok * a.ldo + f] = swiglu_merge(v, v2);  // :411-416
             else if (NW == 2) {  // wk | wv: key-cache row (RoPE above), value-cache row
-                a.outk[(size_t)(a.pos0 + tok) * a.ldkv + f] = v;
-                a.outv[(size_t)(a.pos0 + tok) * a.ldkv + f] = v2;
+                a.outk[kv_index(a, a.ldkv, a.pos0 + tok, f)] = v;
+                a.outv[kv_index(a, a.ldkv, a.pos0 + tok, f)] = v2;
             }
             else if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + f] = v;
             else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + f] = a.res[(size_t)tok * a.ldres + f] + v;
             else if (EPI == G_SWIGLU) a.out[(size_t)tok * a.ldo + f] = swiglu_merge(a.out[(size_t)tok * a.ldo + f], v);
-            else a.out[(size_t)(a.pos0 + tok) * a.ldo + f] = v;
+            else a.out[kv_index(a, a.ldo, a.pos0 + tok, f)] = v;
         }
     }
 }

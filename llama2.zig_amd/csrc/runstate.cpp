@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "l2z_state.h"
 
@@ -92,6 +93,8 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
         s->attn_split_pos = mode > 0 ? 0 : 256;
         if (tn.attn_split_pos >= 0) s->attn_split_pos = tn.attn_split_pos;
         if (mode == 0 || c.seq_len <= s->attn_split_pos) nch = 0;
+        s->attn_short_pos = attention_short_pos(sh.hs, c.seq_len);
+        if (nch > 1 && s->attn_short_pos > s->attn_split_pos) s->attn_short_pos = s->attn_split_pos;
         if (nch > 1) {
             s->attn_nch = nch;
             alloc((void **)&s->d_attn_part, attention_split_part_floats(sh.heads_loc, sh.hs, nch) * 4);
@@ -103,7 +106,7 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
         // the vector mat-vec kernels and the vector attention kernels
         AttnArgs aa = {};
         aa.q = s->q; aa.kcache = s->key_cache; aa.vcache = s->value_cache;
-        aa.head_size = sh.hs; aa.kv_dim = sh.kvd_loc;
+        aa.head_size = sh.hs; aa.kv_row = sh.hs; aa.kv_head = (size_t)c.seq_len * sh.hs;
         s->ll_consume = tn.p2p_push && tn.p2p_consume && matvec_ll_supported(c.dim) &&
                         matvec_ll_supported(c.hidden_dim) && attention_push_supported(aa);
         P2pArgs t[4];
@@ -150,7 +153,7 @@ extern "C" void l2z_runstate_free(l2z_runstate *s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    for (int v = 0; v < 2; v++) {
+    for (int v = 0; v < l2z::ATTN_VARIANTS; v++) {
         if (s->g_forward[v]) (void)hipGraphExecDestroy(s->g_forward[v]);
         if (s->g_step[v]) (void)hipGraphExecDestroy(s->g_step[v]);
     }
@@ -185,6 +188,21 @@ extern "C" int l2z_runstate_read(l2z_runstate *s, const char *name, size_t offse
     L2Z_CHECK(offset + count <= n, L2Z_ERR_INVALID, "l2z_runstate_read: out of range");
     L2Z_HIP(hipSetDevice(s->device));
     L2Z_HIP(hipStreamSynchronize(s->stream));
+    if (k == "key_cache" || k == "value_cache") {
+        // offset / count address the REFERENCE's order (layer, pos, kv_dim) (main.zig:354); a layer of the
+        // device cache is head-major, [kv head][pos][head_size]: permute on the way out
+        const size_t S = (size_t)c.seq_len, kvd = (size_t)s->sh.kvd_loc, hs = (size_t)s->sh.hs, layer = S * kvd;
+        std::vector<float> host(layer);
+        for (size_t l = offset / layer; l * layer < offset + count; l++) {
+            L2Z_HIP(hipMemcpy(host.data(), p + l * layer, layer * sizeof(float), hipMemcpyDeviceToHost));
+            const size_t lo = std::max(offset, l * layer), hi = std::min(offset + count, (l + 1) * layer);
+            for (size_t i = lo; i < hi; i++) {
+                const size_t r = i - l * layer, t = r / kvd, f = r % kvd;
+                out[i - offset] = host[(f / hs) * S * hs + t * hs + f % hs];
+            }
+        }
+        return L2Z_OK;
+    }
     L2Z_HIP(hipMemcpy(out, p + offset, count * sizeof(float), hipMemcpyDeviceToHost));
     return L2Z_OK;
 }

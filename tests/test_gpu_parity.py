@@ -245,11 +245,14 @@ def test_prefill_attention_kernels_vs_softmax_reference(gpu, orc, H, KV, hs, for
 
 
 def test_attention_auto_picks_the_documented_form(gpu):
-    """form 'auto' is what enqueue_forward launches: 256 threads per head (speculative first round)
-    for seq_len <= 512, 1024 threads beyond, the split form from pos 256 on -- bit-identical to the
-    same form asked for by name."""
+    """form 'auto' is what enqueue_forward launches at a position (csrc/forward.cpp attn_variant): 256
+    threads per head with the speculative first round while the context is short -- every position of a
+    seq_len <= 512 model, pos < 256 at head sizes <= 64, pos < 128 at head size 128 (attention_short_pos)
+    -- then 1024 threads per head, and the split form from pos 256 on; bit-identical to the same form
+    asked for by name."""
     rng = np.random.default_rng(5)
-    for shape, pos, want, nch in (("stories15M", 200, "fast256", 0), ("stories110M", 200, "fast1024", 0),
+    for shape, pos, want, nch in (("stories15M", 200, "fast256", 0), ("stories110M", 200, "fast256", 0),
+                                  ("llama2-7b", 100, "fast256", 0), ("llama2-7b", 200, "fast1024", 0),
                                   ("stories110M", 700, "split", 0), ("llama2-7b", 2047, "split", 0)):
         H, KV, hs, S = ATTN_SHAPES[shape]
         q = rng.standard_normal(H * hs, dtype=np.float32)
@@ -817,18 +820,32 @@ def test_prefill_equals_token_by_token(gpu, ck, orc, name, kw, shared):
 @pytest.mark.parametrize("temp", [1.0, 0.7])
 def test_probs_read_vs_host_softmax(gpu, ck, orc, temp):
     """l2z_probs_read = main.zig:1005-1008 (logits / temperature, softmax) on the device, for the host
-    samplers.  The device reduces the denominator as a tree and uses the OCML expf; the reference sums in
-    order with its own exp.  Stated bound on that deliberate trade: every probability within 4e-6 relative
-    (+1e-12) of the host's in-order softmax of the SAME logits, and the probabilities sum to 1 within 1e-5
-    -- far below what moves a draw except at a cdf boundary (tests/test_host_cli.py reports those)."""
+    samplers -- a deliberate parity trade, bounded here.  The device divides and exponentiates like the host
+    (IEEE divide, expf within an ulp or two) but reduces the DENOMINATOR as a tree; the reference adds the
+    32000 terms in order, and that in-order fp32 sum itself sits ~1e-5 away from the exact sum (measured:
+    5e-6 at -t 1.0, 1.6e-5 at -t 0.7).  So: (a) against an exact (float64) softmax of the same logits the
+    device is within 2e-6 relative; (b) against the host's in-order softmax within 5e-5 relative, and the
+    difference is ONE common factor (the two denominators): got / ref is constant over the vocabulary to
+    1e-6.  A common factor cancels in sample_top_p's r = coin * cumulative, so draws only move at a cdf
+    boundary (tests/test_host_cli.py compares token ids against a host replay and reports the margin)."""
     cfg = ck.Config(dim=288, hidden_dim=768, n_layers=2, n_heads=6, n_kv_heads=6, vocab_size=32000, seq_len=64)
     w, s = gpu.Weights(cfg, None, True, seed=3), gpu.RunState(cfg)
     for pos, tok in enumerate([1, 500, 9999]):
         s.transformer(tok, pos, w)
         lg = s.logits()
         got = s.probs(temp)
-        ref = orc.softmax((lg / np.float32(temp)).astype(np.float32))
-        assert np.all(np.abs(got - ref) <= 4e-6 * ref + 1e-12), float(np.max(np.abs(got - ref) / (ref + 1e-30)))
+        x = (lg / np.float32(temp)).astype(np.float32)
+        ref = orc.softmax(x)
+        e = np.exp(x.astype(np.float64) - float(x.max()))
+        exact = e / e.sum()
+        rel_exact = float(np.max(np.abs(got - exact) / exact))
+        rel_host = float(np.max(np.abs(got - ref) / (ref + 1e-30)))
+        ratio = got.astype(np.float64) / ref.astype(np.float64)
+        big = ref > 1e-7   # where an ulp of the value is small against the common factor
+        print(f"-t {temp} pos {pos}: device vs exact {rel_exact:.2e}, device vs in-order host {rel_host:.2e}, "
+              f"spread of got/ref {float(ratio[big].max() - ratio[big].min()):.2e}")
+        assert rel_exact <= 2e-6 and rel_host <= 5e-5
+        assert float(ratio[big].max() - ratio[big].min()) <= 1e-6
         assert abs(float(got.astype(np.float64).sum()) - 1.0) < 1e-5
         assert int(np.argmax(got)) == int(np.argmax(ref))
         assert np.array_equal(s.logits(), lg)   # the logits themselves are left untouched
