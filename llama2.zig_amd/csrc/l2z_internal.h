@@ -205,17 +205,22 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
                                int P, int N, int K, int pos0, const float2 *rope, int head_size,
                                hipStream_t st, const float *res = nullptr, int ldres = 0,
                                int n_scale = 1,  // n_scale: ranks the rows are sharded over (kernel-form choices look at the whole matrix)
-                               size_t kv_head_stride = 0);  // PG_*CACHE: out is a head-major cache (MatvecArgs::kv_head_stride)
+                               size_t kv_head_stride = 0,  // PG_*CACHE: out is a head-major cache (MatvecArgs::kv_head_stride)
+                               const float *rms_w = nullptr);  // x holds raw rows, the launch applies the rmsnorm (prefill_skinny_rms_ok)
 hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, const float *wk, const float *wv,
                                    float *q_out, int ldq, float *kcache, float *vcache, int ldkv, int P, int nq,
                                    int nkv, int K, int pos0, const float2 *rope, int head_size, hipStream_t st,
                                    size_t kv_head_stride = 0);
 hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float *w1, const float *w3,
                                            float *out, int ldo, int P, int N, int K, hipStream_t st,
-                                           int n_scale = 1);
+                                           int n_scale = 1, const float *rms_w = nullptr);
 hipError_t launch_prefill_gemm_kv_pair(const float *x, int ldx, const float *wk, const float *wv, float *kcache,
                                        float *vcache, int ldkv, int P, int nkv, int K, int pos0, const float2 *rope,
-                                       int head_size, hipStream_t st, int n_scale = 1, size_t kv_head_stride = 0);
+                                       int head_size, hipStream_t st, int n_scale = 1, size_t kv_head_stride = 0,
+                                       const float *rms_w = nullptr);
+// the short-prompt launches of a [P, K] x [N, K]^T product (N rows on this rank of n_scale) take the form that
+// applies the rmsnorm itself, so that no prefill_rmsnorm launch is needed before them (prefill_skinny.hip)
+bool prefill_skinny_rms_ok(int P, int N, int K, int ldx, int n_scale);
 hipError_t launch_prefill_rmsnorm(float *o, const float *x, const float *w, int n, int P,
                                   hipStream_t st);
 hipError_t launch_prefill_embed(float *x, const float *tok_emb, const int *tokens, int dim, int P,

@@ -46,6 +46,10 @@ struct GemmArgs {
     size_t kv_head_stride;
     // direct-to-LDS tile kernel, 1-D grids (dma_grid): feature tiles, token tiles
     int ntx, nty;
+    // short-prompt direct-to-LDS form only: x holds the RAW residual rows and the kernel applies the rmsnorm
+    // (main.zig:432-468) itself -- weight rms_w[k] on the operand, the per-token scale in the epilogue -- instead
+    // of reading rows a prefill_rmsnorm launch prepared; null: x is used as it is
+    const float *rms_w;
 };
 
 // where feature f of position pos lives in a cache whose flat form has rows of ld floats
@@ -72,5 +76,6 @@ __device__ __forceinline__ void lds_dma16_nt(const float *g, float *lds)
 // prefill_skinny.hip: the short-prompt (P <= 64 tokens) GEMM forms; picks the form and the token tiling
 hipError_t launch_prefill_skinny(int epi, const GemmArgs &a, hipStream_t st);
 hipError_t launch_prefill_skinny_pair(int epi, const GemmArgs &a, hipStream_t st);  // G_SWIGLU: w | w2 gated; G_QKV: wk | wv
+
 
 }  // namespace l2z

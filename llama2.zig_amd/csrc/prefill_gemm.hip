@@ -574,13 +574,16 @@ hipError_t gemm_launch(const GemmArgs &a, hipStream_t st)
 // out[P,N] = silu(X W1^T) * (X W3^T) in one launch (direct-to-LDS tile kernel, paired form).
 // hipErrorNotSupported when the shape does not take that kernel: the caller launches the two GEMMs.
 hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float *w1, const float *w3,
-                                           float *out, int ldo, int P, int N, int K, hipStream_t st, int n_scale)
+                                           float *out, int ldo, int P, int N, int K, hipStream_t st, int n_scale,
+                                           const float *rms_w)
 {
     if (tunables().pf_fuse == 0 || tunables().pf_dma == 0 || tunables().pf_tile != 0) return hipErrorNotSupported;
-    if (((uintptr_t)x & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w3 & 15)) return hipErrorInvalidValue;
+    if (((uintptr_t)x & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w3 & 15) || ((uintptr_t)rms_w & 15)) return hipErrorInvalidValue;
     GemmArgs a = {x, w3, w1, out, out, P, N, K, ldx, ldo, ldo, 0, nullptr, 0, n_scale > 0 ? n_scale : 1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
+    a.rms_w = rms_w;
     const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
     if (P <= skinny_max) return launch_prefill_skinny_pair(G_SWIGLU, a, st);  // prefill_skinny.hip (or not supported)
+    if (rms_w != nullptr) return hipErrorNotSupported;  // the tile kernel reads prepared rows
     if (K % 64 != 0 || ldx % 4 != 0) return hipErrorNotSupported;
     constexpr int KS = 2;
     // tokens x (features of W1 + the same features of W3) per block, chosen like the unpaired tiles
@@ -647,27 +650,32 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
 // brought into the CU once for both).  hipErrorNotSupported otherwise: the caller launches the two.
 hipError_t launch_prefill_gemm_kv_pair(const float *x, int ldx, const float *wk, const float *wv, float *kcache,
                                        float *vcache, int ldkv, int P, int nkv, int K, int pos0, const float2 *rope,
-                                       int head_size, hipStream_t st, int n_scale, size_t kv_head_stride)
+                                       int head_size, hipStream_t st, int n_scale, size_t kv_head_stride,
+                                       const float *rms_w)
 {
     const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
     if (P > skinny_max) return hipErrorNotSupported;
-    if (((uintptr_t)x & 15) || ((uintptr_t)wk & 15) || ((uintptr_t)wv & 15)) return hipErrorInvalidValue;
+    if (((uintptr_t)x & 15) || ((uintptr_t)wk & 15) || ((uintptr_t)wv & 15) || ((uintptr_t)rms_w & 15)) return hipErrorInvalidValue;
     GemmArgs a = {x, wv, wk, kcache, kcache, P, nkv, K, ldx, ldkv, ldkv, pos0, rope, head_size, n_scale > 0 ? n_scale : 1,
                   wk, wv, kcache, vcache, 0, nkv, ldkv, kv_head_stride, 0, 0};
+    a.rms_w = rms_w;
     return launch_prefill_skinny_pair(G_QKV, a, st);
 }
 
 // C[P,N] (+)= X[P,K] W[N,K]^T with the chosen epilogue; K % 4 == 0, 16-byte aligned rows
 hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w, float *out, int ldo,
                                int P, int N, int K, int pos0, const float2 *rope, int head_size,
-                               hipStream_t st, const float *res, int ldres, int n_scale, size_t kv_head_stride)
+                               hipStream_t st, const float *res, int ldres, int n_scale, size_t kv_head_stride,
+                               const float *rms_w)
 {
     if (P <= 0 || N <= 0 || K <= 0 || (K % 4) != 0 || (ldx % 4) != 0) return hipErrorInvalidValue;
-    if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return hipErrorInvalidValue;
+    if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)rms_w & 15)) return hipErrorInvalidValue;
     if (res == nullptr) { res = out; ldres = ldo; }  // PG_RESID in place
     GemmArgs a = {x, nullptr, w, out, res, P, N, K, ldx, ldo, ldres, pos0, rope, head_size, n_scale > 0 ? n_scale : 1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, kv_head_stride, 0, 0};
+    a.rms_w = rms_w;
     const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
     if (P <= skinny_max) return launch_prefill_skinny(epi, a, st);  // prefill_skinny.hip
+    if (rms_w != nullptr) return hipErrorNotSupported;  // the tile kernels read prepared rows
     switch (epi) {
         case G_STORE: return gemm_launch<G_STORE>(a, st);
         case G_RESID: return gemm_launch<G_RESID>(a, st);

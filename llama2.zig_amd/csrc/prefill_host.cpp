@@ -87,7 +87,17 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
     float *kc = s->key_cache + (size_t)l * c.seq_len * kvd;  // this layer: [kv heads][seq_len][hs]
     float *vc = s->value_cache + (size_t)l * c.seq_len * kvd;
     const size_t kvh_stride = (size_t)c.seq_len * hs;
-    if (k == PF_ATT) {
+    if (k == PF_ATT && prefill_skinny_rms_ok(P, sh.dim_loc, dim, dim, sh.world) &&
+        prefill_skinny_rms_ok(P, kvd, dim, dim, sh.world)) {
+        // short prompts: the q and k | v launches read the raw rows and apply the rmsnorm (:305) themselves
+        const float *g = w->rms_att + (size_t)l * dim;
+        L2Z_HIP(launch_prefill_gemm(PG_ROPE, s->pf_x, dim, w->wq + (size_t)l * sh.dim_loc * dim, s->pf_q, sh.dim_loc, P,
+                                    sh.dim_loc, dim, pos0, s->rope, hs, st, nullptr, 0, sh.world, 0, g));  // :308-351
+        L2Z_HIP(launch_prefill_gemm_kv_pair(s->pf_x, dim, w->wk + (size_t)l * kvd * dim, w->wv + (size_t)l * kvd * dim,
+                                            kc, vc, kvd, P, kvd, dim, pos0, s->rope, hs, st, sh.world, kvh_stride, g));
+        L2Z_HIP(launch_prefill_attention(s->pf_q, sh.dim_loc, kc, vc, out, ldo, pos0, P, sh.heads_loc, hs,
+                                         hs, kvh_stride, c.n_heads / c.n_kv_heads, c.seq_len, st, c.n_heads));  // :361-389
+    } else if (k == PF_ATT) {
         L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, s->pf_x, w->rms_att + (size_t)l * dim, dim, P, st));  // :305
         // q of the local heads ([P, dim_loc]) and the k / v rows of the local kv heads: one launch where
         // the tile kernel takes the shape (:308-358), else three
@@ -117,6 +127,11 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
         const float *res = s->pf_x + sh.dim0;
         L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_att, dim, w->wo + (size_t)l * sh.dim_loc * dim, out, ldo,
                                     P, sh.dim_loc, dim, pos0, s->rope, hs, st, res, dim, sh.world));   // :392-395
+    } else if (k == PF_H1 && prefill_skinny_rms_ok(P, sh.hid_loc, dim, dim, sh.world)) {
+        // short prompts: rmsnorm (:398) inside the W1 | W3 launch
+        L2Z_HIP(launch_prefill_gemm_swiglu_pair(s->pf_x, dim, w->w1 + (size_t)l * sh.hid_loc * dim,
+                                                w->w3 + (size_t)l * sh.hid_loc * dim, out, ldo, P, sh.hid_loc, dim, st,
+                                                sh.world, w->rms_ffn + (size_t)l * dim));  // :398-416
     } else if (k == PF_H1) {
         L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, s->pf_x, w->rms_ffn + (size_t)l * dim, dim, P, st));  // :398
         // :405-416: W1 and W3 in one launch with silu(a) * b as its epilogue where the tile kernel

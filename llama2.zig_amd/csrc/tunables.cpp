@@ -41,6 +41,7 @@ Tunables read_env()
     env_int("L2Z_PF_SKINNY_TMS", &t.pf_skinny_tms);
     env_int("L2Z_PF_ATTN", &t.pf_attn);
     env_int("L2Z_PF_FUSE", &t.pf_fuse);
+    env_int("L2Z_PF_RMS_FUSE", &t.pf_rms_fuse);
     env_int("L2Z_PF_DMA", &t.pf_dma);
     env_int("L2Z_PF_ORDER", &t.pf_order);
     if (t.row_blocks < 1) t.row_blocks = 1;
@@ -85,7 +86,6 @@ bool tunables_set(const char *name, long long v)
         {"L2Z_MAX_BLOCKS_PER_CU", &t.max_blocks_per_cu}, {"L2Z_GRID_CAP", &t.grid_cap},
         {"L2Z_ATTN_BLOCK", &t.attn_block}, {"L2Z_ATTN_SPLIT", &t.attn_split},
         {"L2Z_ATTN_SPLIT_POS", &t.attn_split_pos}, {"L2Z_ATTN_SHORT_POS", &t.attn_short_pos},
-        
         {"L2Z_FUSE_SMALL", &t.fuse_small}, {"L2Z_NO_GRAPH", &t.no_graph},
         {"L2Z_COMM_GRAPH", &t.comm_graph}, {"L2Z_COMM_RCCL", &t.prefer_rccl},
         {"L2Z_P2P_PUSH", &t.p2p_push}, {"L2Z_P2P_CONSUME", &t.p2p_consume},
@@ -93,7 +93,8 @@ bool tunables_set(const char *name, long long v)
         {"L2Z_PREFILL", &t.prefill}, {"L2Z_PF_CHUNK", &t.pf_chunk},
         {"L2Z_PF_SKINNY_FORM", &t.pf_skinny_form}, {"L2Z_PF_TILE", &t.pf_tile},
         {"L2Z_PF_SKINNY_MAX", &t.pf_skinny_max}, {"L2Z_PF_SKINNY_TMS", &t.pf_skinny_tms},
-        {"L2Z_PF_ATTN", &t.pf_attn}, {"L2Z_PF_FUSE", &t.pf_fuse}, {"L2Z_PF_DMA", &t.pf_dma}, {"L2Z_PF_ORDER", &t.pf_order}};
+        {"L2Z_PF_ATTN", &t.pf_attn}, {"L2Z_PF_FUSE", &t.pf_fuse}, {"L2Z_PF_DMA", &t.pf_dma}, {"L2Z_PF_ORDER", &t.pf_order},
+        {"L2Z_PF_RMS_FUSE", &t.pf_rms_fuse}};
     for (auto &e : ints)
         if (strcmp(e.n, name) == 0) {
             *e.p = (int)v;
