@@ -198,6 +198,18 @@ hipError_t launch_synth_fill(float *dst, uint64_t base_idx, uint64_t count, uint
 size_t attention_lds_bytes(int head_size, int seq_len, bool vec);
 
 // ---- batched prefill (prefill_gemm.hip, prefill_skinny.hip, prefill_attention.hip) ----
+// workspace of the tile GEMM's split-K family (prefill_gemm.hip SPLIT), owned by the runstate: accumulator
+// dumps of the K ranges and one arrival counter per output tile (zero between launches)
+struct SplitKWs {
+    float *part;
+    int *cnt;
+    size_t part_floats;
+    int cnt_ints;
+};
+constexpr int kSplitKMaxTokens = 256;  // longest chunk the split-K family takes
+// K ranges per output tile for a [P, K] x [n_whole, K]^T product (1: the unsplit family).  Part of the
+// arithmetic, so a function of the chunk length and the WHOLE model's matrix only -- never of a rank's share.
+int prefill_split_k(long long n_whole, int P, int K, bool pair);
 enum PrefillGemmEpi { PG_STORE = 0, PG_RESID = 1, PG_ROPE = 2, PG_ROPE_CACHE = 3, PG_CACHE = 4,
                       PG_SWIGLU = 5 };  // out = silu(out) * (X W^T): the W3 product merged into W1's
 // PG_RESID: out = res + X W^T (res == nullptr: in place, res = out, ldres = ldo)
@@ -206,21 +218,17 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
                                hipStream_t st, const float *res = nullptr, int ldres = 0,
                                int n_scale = 1,  // n_scale: ranks the rows are sharded over (kernel-form choices look at the whole matrix)
                                size_t kv_head_stride = 0,  // PG_*CACHE: out is a head-major cache (MatvecArgs::kv_head_stride)
-                               const float *rms_w = nullptr);  // x holds raw rows, the launch applies the rmsnorm (prefill_skinny_rms_ok)
+                               int sk = 1, const SplitKWs *ws = nullptr);  // sk > 1: the split-K family (prefill_split_k)
 hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, const float *wk, const float *wv,
                                    float *q_out, int ldq, float *kcache, float *vcache, int ldkv, int P, int nq,
                                    int nkv, int K, int pos0, const float2 *rope, int head_size, hipStream_t st,
-                                   size_t kv_head_stride = 0);
+                                   size_t kv_head_stride = 0, int n_scale = 1, int sk = 1, const SplitKWs *ws = nullptr);
 hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float *w1, const float *w3,
                                            float *out, int ldo, int P, int N, int K, hipStream_t st,
-                                           int n_scale = 1, const float *rms_w = nullptr);
+                                           int n_scale = 1, int sk = 1, const SplitKWs *ws = nullptr);
 hipError_t launch_prefill_gemm_kv_pair(const float *x, int ldx, const float *wk, const float *wv, float *kcache,
                                        float *vcache, int ldkv, int P, int nkv, int K, int pos0, const float2 *rope,
-                                       int head_size, hipStream_t st, int n_scale = 1, size_t kv_head_stride = 0,
-                                       const float *rms_w = nullptr);
-// the short-prompt launches of a [P, K] x [N, K]^T product (N rows on this rank of n_scale) take the form that
-// applies the rmsnorm itself, so that no prefill_rmsnorm launch is needed before them (prefill_skinny.hip)
-bool prefill_skinny_rms_ok(int P, int N, int K, int ldx, int n_scale);
+                                       int head_size, hipStream_t st, int n_scale = 1, size_t kv_head_stride = 0);
 hipError_t launch_prefill_rmsnorm(float *o, const float *x, const float *w, int n, int P,
                                   hipStream_t st);
 hipError_t launch_prefill_embed(float *x, const float *tok_emb, const int *tokens, int dim, int P,

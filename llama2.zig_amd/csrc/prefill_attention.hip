@@ -463,7 +463,10 @@ hipError_t launch_prefill_attention(const float *q, int ldq, const float *kcache
     const bool enough_blocks = n_heads_model * ((P + 63) / 64) >= 128;
     // the flash form is ahead of the block-per-(head, query) kernel from far fewer blocks (12 heads x 4 query
     // tiles, stories110M at 256 tokens: 22 -> 16 us)
-    const bool flash_blocks = n_heads_model * ((P + 63) / 64) >= 32;
+    // ... but not for chunks of <= 32 tokens: 32 heads x one query tile of mostly masked rows is a 12.5 us latency
+    // chain, the per-query blocks (heads x tokens of them) take ~8 (7B shape, 16-token prompt: 5.74 -> 5.60 ms,
+    // 4 tokens 5.89 -> 5.73; profiles/r03_prefill_short_ab.txt)
+    const bool flash_blocks = n_heads_model * ((P + 63) / 64) >= 32 && P > 32;
     if (!naive && flash_blocks && tunables().pf_attn != 2 && (head_size == 64 || head_size == 128) && (kv_dim % 4) == 0 &&
         (ldq % 4) == 0 && (ldo % 4) == 0 && (((uintptr_t)q | (uintptr_t)out | (uintptr_t)kcache | (uintptr_t)vcache) & 15) == 0) {
         // flash form (L2Z_PF_ATTN=2 keeps the LDS-softmax tiled kernel below)

@@ -46,11 +46,14 @@ struct GemmArgs {
     size_t kv_head_stride;
     // direct-to-LDS tile kernel, 1-D grids (dma_grid): feature tiles, token tiles
     int ntx, nty;
-    // short-prompt direct-to-LDS form only: x holds the RAW residual rows and the kernel applies the rmsnorm
-    // (main.zig:432-468) itself -- weight rms_w[k] on the operand, the per-token scale in the epilogue -- instead
-    // of reading rows a prefill_rmsnorm launch prepared; null: x is used as it is
-    const float *rms_w;
+    // split-K family of the direct-to-LDS tile kernel (sk = 2 or 4; 0 / 1: none): the sk blocks of a tile each
+    // multiply a contiguous K / sk range, leave their accumulators in sk_part and bump the tile's counter in
+    // sk_cnt; whichever arrives last adds the sk partials IN RANGE ORDER and runs the epilogue
+    float *sk_part;
+    int *sk_cnt;
+    int sk;
 };
+
 
 // where feature f of position pos lives in a cache whose flat form has rows of ld floats
 __device__ __forceinline__ size_t kv_index(const GemmArgs &a, int ld, int pos, int f)

@@ -70,12 +70,13 @@ static TileForm choose_tile(int N, int P, bool pair)
 // block -> tile comment); L2Z_PF_ORDER=0 keeps the 2-D grid
 static dim3 dma_grid(int ntx, int nty, GemmArgs *a)
 {
+    const unsigned z = a->sk > 1 ? (unsigned)a->sk : 1u;  // split-K family: blockIdx.z = the block's K range
     if (tunables().pf_order == 0 || nty > 64) {
         a->ntx = 0; a->nty = 0;
-        return dim3(ntx, nty);
+        return dim3(ntx, nty, z);
     }
     a->ntx = ntx; a->nty = nty;
-    return dim3((unsigned)((ntx + 7) / 8 * 8 * nty));
+    return dim3((unsigned)((ntx + 7) / 8 * 8 * nty), 1, z);
 }
 
 // epilogue shared by the two tile kernels: per MFMA tile a lane owns one feature and 16 tokens
@@ -329,7 +330,17 @@ __global__ __launch_bounds__(256 * KS) void prefill_gemm(const GemmArgs a)
 //    that leave every block a CU to itself (row shards, 256-token prompts): +0.8 ... +1.3 % time.  A
 //    lone 64 x 64 block already runs at 0.68 of its CU's MFMA peak -- such grids are short of blocks,
 //    not of latency hiding.
-template <int EPI, int TM, int TN, int KS, bool PAIR = false, int WM = 2, int WN = 2>
+//  * SPLIT (round 3, the split-K family): grids that leave CUs without a block -- prompts of 33 ... 256 tokens:
+//    N = 4096 at 128 tokens is 256 blocks of 32 x 64, one 4-wave block per CU at 0.45 of the peak -- take a
+//    LARGER tile and cut K into a.sk contiguous ranges, one block each (blockIdx.z): as many blocks, fewer
+//    operand bytes per flop.  A block leaves its accumulators in a.sk_part with write-through stores, drains
+//    them and bumps the tile's arrival counter; the block that arrives last -- whichever it is, nobody waits --
+//    acquires once, adds the a.sk partials IN RANGE ORDER (its own read back like the others: one fixed
+//    order) and runs the epilogue (the hand-off recipe of attention.hip's split kernel).  The sum of range
+//    partials rounds differently from one k-ordered chain, so sk is part of the arithmetic: it is chosen from
+//    the WHOLE model's shape and the chunk length (choose_sk), never from a rank's share of the rows, and
+//    every tile form gives the same bits for the same sk.
+template <int EPI, int TM, int TN, int KS, bool PAIR = false, int WM = 2, int WN = 2, bool SPLIT = false>
 __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const GemmArgs a)
 {
     static_assert(!PAIR || TN == 2, "paired form: one W1 tile and one W3 tile per wave column");
@@ -358,6 +369,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
         if (bx >= a.ntx) return;  // padding of the last group
     }
     const int n0 = bx * (PAIR ? BNt / 2 : BNt), m0 = by * BMt;
+    // SPLIT: this block's K range (launcher: K % (64 sk) == 0)
+    const int klen = SPLIT ? a.K / a.sk : a.K;
+    const int kbeg = SPLIT ? (int)blockIdx.z * klen : 0, kend = kbeg + klen;
 
     // this lane's part of every load: row (within the RPI-row group) lane / SLOTS, physical slot lane % SLOTS
     const int lrow = lane / SLOTS, pslot = lane % SLOTS;
@@ -436,12 +450,12 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
         }                                                                                                 \
     } while (0)
 
-    L2Z_DMA_ISSUE(0, 0);
+    L2Z_DMA_ISSUE(kbeg, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int buf = 0;
-    for (int k0 = 0; k0 < a.K; k0 += BK) {
-        if (k0 + BK < a.K) L2Z_DMA_ISSUE(k0 + BK, buf ^ 1);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        if (k0 + BK < kend) L2Z_DMA_ISSUE(k0 + BK, buf ^ 1);
         L2Z_MULTIPLY_STAGE(buf);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's loads of the next stage have landed
         __syncthreads();                                  // everyone's have, and nobody still reads this one
@@ -472,6 +486,47 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
                         acc[i][j][r] += red[((((g - 1) * NWG + wave) * TM * TN + i * TN + j) * 16 + r) * 64 + lane];
     }
 #undef L2Z_DMA_ISSUE
+    if constexpr (SPLIT) {
+        // the k-group-0 waves hold the block's sums (the others have left; a barrier only counts live waves)
+        constexpr int PT = NWG * TM * TN * 16 * 64;  // floats per partial = the tile's outputs
+        const int ntx_all = a.nty > 0 ? a.ntx : (int)gridDim.x;
+        const size_t tile = (size_t)by * ntx_all + bx;
+        float *part = a.sk_part + tile * (size_t)a.sk * PT;
+        float *mine = part + (size_t)blockIdx.z * PT + (size_t)wg * (TM * TN * 16 * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    __hip_atomic_store(mine + ((i * TN + j) * 16 + r) * 64, acc[i][j][r], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);  // write-through
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its partial
+        __syncthreads();
+        int *flag = (int *)smem;  // stage buffers and the k-group sums are dead
+        if (tid == 0) {
+            const int prev = __hip_atomic_fetch_add(a.sk_cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = prev == a.sk - 1;
+            if (last) {
+                __hip_atomic_store(a.sk_cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this CU's stale lines of the partials
+            }
+            *flag = last;
+        }
+        __syncthreads();
+        if (!*flag) return;
+        const float *p0 = part + (size_t)wg * (TM * TN * 16 * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    float v = p0[((i * TN + j) * 16 + r) * 64];  // range 0, then 1, ... in order
+                    for (int z = 1; z < a.sk; z++) v += p0[(size_t)z * PT + ((i * TN + j) * 16 + r) * 64];
+                    acc[i][j][r] = v;
+                }
+    }
     if constexpr (PAIR) {
         const int j = n0 + wn * 32 + (lane & 31);
 #pragma unroll
@@ -569,22 +624,96 @@ hipError_t gemm_launch(const GemmArgs &a, hipStream_t st)
     return gemm_launch_t<EPI, 1, 1, 64, 2>(a, st);
 }
 
+// ---- the split-K family (prefill_gemm_dma SPLIT) ----
+// Output tile for a product whose K is cut into sk ranges: the same cost model as choose_tile with sk times the
+// blocks and 1 / sk of the work per block.  Every form gives the same bits for the same sk.
+enum SkTile { SKT_128x64 = 0, SKT_64x64, SKT_32x64 };
+static SkTile choose_tile_sk(int N, int P, int sk)
+{
+    const long long cus = g_cus_hint();
+    static const struct { int tok; double eff; } form[3] = {{128, 1.0}, {64, 0.87}, {32, 0.80}};
+    int best = -1;
+    double best_cost = 0.0;
+    for (int f = 0; f < 3; f++) {
+        if (f == SKT_128x64 && P <= 64) continue;
+        const long long blocks = (long long)((N + 63) / 64) * ((P + form[f].tok - 1) / form[f].tok) * sk;
+        const double cost = (double)((blocks + cus - 1) / cus) * (form[f].tok * 64) / sk / form[f].eff;
+        if (best < 0 || cost < best_cost * 0.999) {
+            best = f;
+            best_cost = cost;
+        }
+    }
+    return (SkTile)best;
+}
+
+template <int EPI, int TM, int TN, bool PAIR, int WM, int WN>
+hipError_t dma_launch_split(GemmArgs a, int n_feat, int sk, const SplitKWs *ws, hipStream_t st)
+{
+    constexpr int KS = 2, BMt = 32 * WM * TM, BNt = 32 * WN * TN, NWG = WM * WN;
+    constexpr int feat = PAIR ? BNt / 2 : BNt;  // features (of each matrix when paired) per block
+    if (ws == nullptr || ws->part == nullptr || ws->cnt == nullptr) return hipErrorInvalidValue;
+    const int ntx = (n_feat + feat - 1) / feat, nty = (a.P + BMt - 1) / BMt;
+    if ((size_t)ntx * nty * sk * BMt * BNt > ws->part_floats || ntx * nty > ws->cnt_ints) return hipErrorOutOfMemory;
+    a.sk = sk; a.sk_part = ws->part; a.sk_cnt = ws->cnt;
+    size_t lds = 2 * (size_t)(BMt + BNt) * 64 * sizeof(float);
+    const size_t red = (size_t)(KS - 1) * NWG * TM * TN * 16 * 64 * sizeof(float);
+    if (red > lds) lds = red;
+    const void *fn = (const void *)prefill_gemm_dma<EPI, TM, TN, KS, PAIR, WM, WN, true>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const dim3 grid = dma_grid(ntx, nty, &a);
+    void *params[] = {&a};
+    return hipLaunchKernel(fn, grid, dim3(64 * NWG * KS), params, lds, st);
+}
+
+// unpaired / fused-qkv products (TN = 1 forms) and the paired W1 | W3 product (TN = 2 forms)
+template <int EPI, bool PAIR>
+hipError_t gemm_launch_sk(const GemmArgs &a, int n_feat, int sk, const SplitKWs *ws, hipStream_t st)
+{
+    constexpr int TN = PAIR ? 2 : 1;
+    switch (choose_tile_sk(n_feat, a.P, sk)) {
+    case SKT_128x64: return dma_launch_split<EPI, 2, TN, PAIR, 2, 2>(a, n_feat, sk, ws, st);
+    case SKT_64x64: return dma_launch_split<EPI, 1, TN, PAIR, 2, 2>(a, n_feat, sk, ws, st);
+    default: return dma_launch_split<EPI, 1, TN, PAIR, 1, 2>(a, n_feat, sk, ws, st);
+    }
+}
+
 }  // namespace
+
+// K ranges per output tile (see l2z_internal.h).  Chunks of 33 ... 256 tokens leave most CUs one small block
+// (or none) in the unsplit family; the split family gives them a larger tile of 1 / sk of the depth each.
+int prefill_split_k(long long n_whole, int P, int K, bool pair)
+{
+    const Tunables &tn = tunables();
+    const int skinny_max = tn.pf_skinny_max >= 0 ? tn.pf_skinny_max : 64;
+    if (P > kSplitKMaxTokens || P <= skinny_max || tn.pf_dma == 0 || tn.pf_tile != 0 || tn.pf_fuse == 0) return 1;
+    int sk = 1;
+    if (tn.pf_splitk >= 0) {
+        sk = tn.pf_splitk >= 4 ? 4 : tn.pf_splitk >= 2 ? 2 : 1;
+    } else {
+        // by shape: as many ranges as keep every CU one block of the LARGEST tile the chunk admits
+        const long long cus = g_cus_hint();
+        const int tok = P > 64 ? 128 : 64;
+        const long long tiles = ((n_whole + 63) / 64) * ((P + tok - 1) / tok) * (pair ? 1 : 1);
+        if (tiles * 4 <= cus + cus / 2) sk = 4;
+        else if (tiles * 2 <= cus + cus / 2) sk = 2;
+    }
+    while (sk > 1 && K % (64 * sk) != 0) sk >>= 1;
+    return sk;
+}
 
 // out[P,N] = silu(X W1^T) * (X W3^T) in one launch (direct-to-LDS tile kernel, paired form).
 // hipErrorNotSupported when the shape does not take that kernel: the caller launches the two GEMMs.
 hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float *w1, const float *w3,
                                            float *out, int ldo, int P, int N, int K, hipStream_t st, int n_scale,
-                                           const float *rms_w)
+                                           int sk, const SplitKWs *ws)
 {
     if (tunables().pf_fuse == 0 || tunables().pf_dma == 0 || tunables().pf_tile != 0) return hipErrorNotSupported;
-    if (((uintptr_t)x & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w3 & 15) || ((uintptr_t)rms_w & 15)) return hipErrorInvalidValue;
+    if (((uintptr_t)x & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w3 & 15)) return hipErrorInvalidValue;
     GemmArgs a = {x, w3, w1, out, out, P, N, K, ldx, ldo, ldo, 0, nullptr, 0, n_scale > 0 ? n_scale : 1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
-    a.rms_w = rms_w;
     const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
     if (P <= skinny_max) return launch_prefill_skinny_pair(G_SWIGLU, a, st);  // prefill_skinny.hip (or not supported)
-    if (rms_w != nullptr) return hipErrorNotSupported;  // the tile kernel reads prepared rows
     if (K % 64 != 0 || ldx % 4 != 0) return hipErrorNotSupported;
+    if (sk > 1) return gemm_launch_sk<G_STORE, true>(a, N, sk, ws, st);
     constexpr int KS = 2;
     // tokens x (features of W1 + the same features of W3) per block, chosen like the unpaired tiles
     const TileForm tf = choose_tile(N, P, true);
@@ -610,13 +739,19 @@ hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float 
 hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, const float *wk, const float *wv,
                                    float *q_out, int ldq, float *kcache, float *vcache, int ldkv, int P, int nq,
                                    int nkv, int K, int pos0, const float2 *rope, int head_size, hipStream_t st,
-                                   size_t kv_head_stride)
+                                   size_t kv_head_stride, int n_scale, int sk, const SplitKWs *ws)
 {
     if (tunables().pf_fuse == 0 || tunables().pf_dma == 0 || tunables().pf_tile != 0) return hipErrorNotSupported;
     const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
     if (P <= skinny_max || K % 64 != 0 || ldx % 4 != 0) return hipErrorNotSupported;
     if (((uintptr_t)x & 15) || ((uintptr_t)wq & 15) || ((uintptr_t)wk & 15) || ((uintptr_t)wv & 15)) return hipErrorInvalidValue;
     const int N = nq + 2 * nkv;
+    if (sk > 1) {  // the split family: 64-feature tiles (a tile must not straddle q | k | v)
+        if (nq % 64 != 0 || nkv % 64 != 0) return hipErrorNotSupported;
+        GemmArgs as = {x, nullptr, wq, q_out, q_out, P, N, K, ldx, ldq, ldq, pos0, rope, head_size, n_scale > 0 ? n_scale : 1,
+                       wk, wv, kcache, vcache, nq, nkv, ldkv, kv_head_stride, 0, 0};
+        return gemm_launch_sk<G_QKV, false>(as, N, sk, ws, st);
+    }
     TileForm tf = choose_tile(N, P, false);
     // 128 x 64 tiles mean q alone already gives every CU its one resident block: three such launches
     // measured 445 us against 453 for the 768-block one (7B, 512 tokens).  With the smaller tiles several
@@ -650,15 +785,13 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
 // brought into the CU once for both).  hipErrorNotSupported otherwise: the caller launches the two.
 hipError_t launch_prefill_gemm_kv_pair(const float *x, int ldx, const float *wk, const float *wv, float *kcache,
                                        float *vcache, int ldkv, int P, int nkv, int K, int pos0, const float2 *rope,
-                                       int head_size, hipStream_t st, int n_scale, size_t kv_head_stride,
-                                       const float *rms_w)
+                                       int head_size, hipStream_t st, int n_scale, size_t kv_head_stride)
 {
     const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
     if (P > skinny_max) return hipErrorNotSupported;
-    if (((uintptr_t)x & 15) || ((uintptr_t)wk & 15) || ((uintptr_t)wv & 15) || ((uintptr_t)rms_w & 15)) return hipErrorInvalidValue;
+    if (((uintptr_t)x & 15) || ((uintptr_t)wk & 15) || ((uintptr_t)wv & 15)) return hipErrorInvalidValue;
     GemmArgs a = {x, wv, wk, kcache, kcache, P, nkv, K, ldx, ldkv, ldkv, pos0, rope, head_size, n_scale > 0 ? n_scale : 1,
                   wk, wv, kcache, vcache, 0, nkv, ldkv, kv_head_stride, 0, 0};
-    a.rms_w = rms_w;
     return launch_prefill_skinny_pair(G_QKV, a, st);
 }
 
@@ -666,16 +799,26 @@ hipError_t launch_prefill_gemm_kv_pair(const float *x, int ldx, const float *wk,
 hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w, float *out, int ldo,
                                int P, int N, int K, int pos0, const float2 *rope, int head_size,
                                hipStream_t st, const float *res, int ldres, int n_scale, size_t kv_head_stride,
-                               const float *rms_w)
+                               int sk, const SplitKWs *ws)
 {
     if (P <= 0 || N <= 0 || K <= 0 || (K % 4) != 0 || (ldx % 4) != 0) return hipErrorInvalidValue;
-    if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)rms_w & 15)) return hipErrorInvalidValue;
+    if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return hipErrorInvalidValue;
     if (res == nullptr) { res = out; ldres = ldo; }  // PG_RESID in place
     GemmArgs a = {x, nullptr, w, out, res, P, N, K, ldx, ldo, ldres, pos0, rope, head_size, n_scale > 0 ? n_scale : 1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, kv_head_stride, 0, 0};
-    a.rms_w = rms_w;
     const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
     if (P <= skinny_max) return launch_prefill_skinny(epi, a, st);  // prefill_skinny.hip
-    if (rms_w != nullptr) return hipErrorNotSupported;  // the tile kernels read prepared rows
+    if (sk > 1) {
+        if (K % (64 * sk) != 0) return hipErrorInvalidValue;
+        switch (epi) {
+            case G_STORE: return gemm_launch_sk<G_STORE, false>(a, N, sk, ws, st);
+            case G_RESID: return gemm_launch_sk<G_RESID, false>(a, N, sk, ws, st);
+            case G_ROPE: return gemm_launch_sk<G_ROPE, false>(a, N, sk, ws, st);
+            case G_ROPE_CACHE: return gemm_launch_sk<G_ROPE_CACHE, false>(a, N, sk, ws, st);
+            case G_CACHE: return gemm_launch_sk<G_CACHE, false>(a, N, sk, ws, st);
+            case G_SWIGLU: return gemm_launch_sk<G_SWIGLU, false>(a, N, sk, ws, st);
+        }
+        return hipErrorInvalidValue;
+    }
     switch (epi) {
         case G_STORE: return gemm_launch<G_STORE>(a, st);
         case G_RESID: return gemm_launch<G_RESID>(a, st);

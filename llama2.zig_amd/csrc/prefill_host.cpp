@@ -48,6 +48,23 @@ int prefill_alloc(l2z_runstate *s, int need)
         }
     }
     s->pf_cap = (int)P;
+    if (s->pf_sk.part == nullptr) {
+        // split-K family of the tile GEMM (chunks of 33 ... 256 tokens): accumulator dumps of up to 4 K ranges of
+        // the widest launch of a layer (q | k | v, or W1 | W3 side by side), one arrival counter per output tile
+        const Shard &sh = s->sh;
+        const size_t widest_launch = std::max((size_t)sh.dim_loc + 2 * (size_t)sh.kvd_loc, 2 * (size_t)sh.hid_loc) + 128;
+        const size_t floats = (size_t)kSplitKMaxTokens * widest_launch * 4;
+        const int n_cnt = 1 << 16;
+        hipError_t e = hipMalloc((void **)&s->pf_sk.part, floats * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&s->pf_sk.cnt, (size_t)n_cnt * 4);
+        if (e == hipSuccess) e = hipMemset(s->pf_sk.cnt, 0, (size_t)n_cnt * 4);
+        if (e != hipSuccess) {
+            set_error("prefill split-K workspace allocation failed: %s", hipGetErrorString(e));
+            return e == hipErrorOutOfMemory ? L2Z_ERR_OOM : L2Z_ERR_HIP;
+        }
+        s->pf_sk.part_floats = floats;
+        s->pf_sk.cnt_ints = n_cnt;
+    }
     return L2Z_OK;
 }
 
@@ -87,34 +104,32 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
     float *kc = s->key_cache + (size_t)l * c.seq_len * kvd;  // this layer: [kv heads][seq_len][hs]
     float *vc = s->value_cache + (size_t)l * c.seq_len * kvd;
     const size_t kvh_stride = (size_t)c.seq_len * hs;
-    if (k == PF_ATT && prefill_skinny_rms_ok(P, sh.dim_loc, dim, dim, sh.world) &&
-        prefill_skinny_rms_ok(P, kvd, dim, dim, sh.world)) {
-        // short prompts: the q and k | v launches read the raw rows and apply the rmsnorm (:305) themselves
-        const float *g = w->rms_att + (size_t)l * dim;
-        L2Z_HIP(launch_prefill_gemm(PG_ROPE, s->pf_x, dim, w->wq + (size_t)l * sh.dim_loc * dim, s->pf_q, sh.dim_loc, P,
-                                    sh.dim_loc, dim, pos0, s->rope, hs, st, nullptr, 0, sh.world, 0, g));  // :308-351
-        L2Z_HIP(launch_prefill_gemm_kv_pair(s->pf_x, dim, w->wk + (size_t)l * kvd * dim, w->wv + (size_t)l * kvd * dim,
-                                            kc, vc, kvd, P, kvd, dim, pos0, s->rope, hs, st, sh.world, kvh_stride, g));
-        L2Z_HIP(launch_prefill_attention(s->pf_q, sh.dim_loc, kc, vc, out, ldo, pos0, P, sh.heads_loc, hs,
-                                         hs, kvh_stride, c.n_heads / c.n_kv_heads, c.seq_len, st, c.n_heads));  // :361-389
-    } else if (k == PF_ATT) {
+    // K ranges per output tile (split-K family, prefill_gemm.hip): part of the arithmetic, so taken from the WHOLE
+    // model's matrices -- q | k | v as one launch's width whether or not they go out as one launch
+    const int kvd_whole = c.n_kv_heads * hs;
+    const int sk_qkv = prefill_split_k((long long)dim + 2 * kvd_whole, P, dim, false);
+    const int sk_wo = prefill_split_k(dim, P, dim, false), sk_w2 = prefill_split_k(dim, P, hid, false);
+    const int sk_h1 = prefill_split_k(hid, P, dim, true);
+    const SplitKWs *ws = &s->pf_sk;
+    if (k == PF_ATT) {
         L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, s->pf_x, w->rms_att + (size_t)l * dim, dim, P, st));  // :305
         // q of the local heads ([P, dim_loc]) and the k / v rows of the local kv heads: one launch where
         // the tile kernel takes the shape (:308-358), else three
         const float *wq = w->wq + (size_t)l * sh.dim_loc * dim, *wk = w->wk + (size_t)l * kvd * dim,
                     *wv = w->wv + (size_t)l * kvd * dim;
         const hipError_t qe = launch_prefill_gemm_qkv(s->pf_xn, dim, wq, wk, wv, s->pf_q, sh.dim_loc, kc, vc, kvd, P,
-                                                      sh.dim_loc, kvd, dim, pos0, s->rope, hs, st, kvh_stride);
+                                                      sh.dim_loc, kvd, dim, pos0, s->rope, hs, st, kvh_stride, sh.world,
+                                                      sk_qkv, ws);
         if (qe == hipErrorNotSupported) {
             L2Z_HIP(launch_prefill_gemm(PG_ROPE, s->pf_xn, dim, wq, s->pf_q, sh.dim_loc, P, sh.dim_loc, dim, pos0,
-                                        s->rope, hs, st, nullptr, 0, sh.world));  // :308-351
+                                        s->rope, hs, st, nullptr, 0, sh.world, 0, sk_qkv, ws));  // :308-351
             const hipError_t ke = launch_prefill_gemm_kv_pair(s->pf_xn, dim, wk, wv, kc, vc, kvd, P, kvd, dim, pos0,
                                                               s->rope, hs, st, sh.world, kvh_stride);  // short prompts: k | v together
             if (ke == hipErrorNotSupported) {
                 L2Z_HIP(launch_prefill_gemm(PG_ROPE_CACHE, s->pf_xn, dim, wk, kc, kvd, P, kvd, dim, pos0, s->rope, hs,
-                                            st, nullptr, 0, sh.world, kvh_stride));   // :354-357
+                                            st, nullptr, 0, sh.world, kvh_stride, sk_qkv, ws));   // :354-357
                 L2Z_HIP(launch_prefill_gemm(PG_CACHE, s->pf_xn, dim, wv, vc, kvd, P, kvd, dim, pos0, s->rope, hs, st,
-                                            nullptr, 0, sh.world, kvh_stride));       // :358
+                                            nullptr, 0, sh.world, kvh_stride, sk_qkv, ws));       // :358
             } else {
                 L2Z_HIP(ke);
             }
@@ -126,30 +141,26 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
     } else if (k == PF_WO) {
         const float *res = s->pf_x + sh.dim0;
         L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_att, dim, w->wo + (size_t)l * sh.dim_loc * dim, out, ldo,
-                                    P, sh.dim_loc, dim, pos0, s->rope, hs, st, res, dim, sh.world));   // :392-395
-    } else if (k == PF_H1 && prefill_skinny_rms_ok(P, sh.hid_loc, dim, dim, sh.world)) {
-        // short prompts: rmsnorm (:398) inside the W1 | W3 launch
-        L2Z_HIP(launch_prefill_gemm_swiglu_pair(s->pf_x, dim, w->w1 + (size_t)l * sh.hid_loc * dim,
-                                                w->w3 + (size_t)l * sh.hid_loc * dim, out, ldo, P, sh.hid_loc, dim, st,
-                                                sh.world, w->rms_ffn + (size_t)l * dim));  // :398-416
+                                    P, sh.dim_loc, dim, pos0, s->rope, hs, st, res, dim, sh.world, 0, sk_wo, ws));   // :392-395
     } else if (k == PF_H1) {
         L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, s->pf_x, w->rms_ffn + (size_t)l * dim, dim, P, st));  // :398
         // :405-416: W1 and W3 in one launch with silu(a) * b as its epilogue where the tile kernel
         // takes the shape, else two GEMMs, the second one merging into the first one's output
         const float *w1 = w->w1 + (size_t)l * sh.hid_loc * dim, *w3 = w->w3 + (size_t)l * sh.hid_loc * dim;
-        const hipError_t pe = launch_prefill_gemm_swiglu_pair(s->pf_xn, dim, w1, w3, out, ldo, P, sh.hid_loc, dim, st, sh.world);
+        const hipError_t pe = launch_prefill_gemm_swiglu_pair(s->pf_xn, dim, w1, w3, out, ldo, P, sh.hid_loc, dim, st, sh.world,
+                                                              sk_h1, ws);
         if (pe == hipErrorNotSupported) {
             L2Z_HIP(launch_prefill_gemm(PG_STORE, s->pf_xn, dim, w1, out, ldo, P, sh.hid_loc, dim, pos0, s->rope,
-                                        hs, st, nullptr, 0, sh.world));                      // :405
+                                        hs, st, nullptr, 0, sh.world, 0, sk_h1, ws));                      // :405
             L2Z_HIP(launch_prefill_gemm(PG_SWIGLU, s->pf_xn, dim, w3, out, ldo, P, sh.hid_loc, dim, pos0, s->rope,
-                                        hs, st, nullptr, 0, sh.world));  // :408 + :411-416 in the epilogue
+                                        hs, st, nullptr, 0, sh.world, 0, sk_h1, ws));  // :408 + :411-416 in the epilogue
         } else {
             L2Z_HIP(pe);
         }
     } else {
         const float *res = s->pf_x + sh.dim0;
         L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_h1, hid, w->w2 + (size_t)l * sh.dim_loc * hid, out, ldo,
-                                    P, sh.dim_loc, hid, pos0, s->rope, hs, st, res, dim, sh.world));   // :419-422
+                                    P, sh.dim_loc, hid, pos0, s->rope, hs, st, res, dim, sh.world, 0, sk_w2, ws));   // :419-422
     }
     return L2Z_OK;
 }

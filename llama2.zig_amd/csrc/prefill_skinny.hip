@@ -215,20 +215,12 @@ constexpr int kSkLD2 = kSkBK + 8;
 // NW = 2: TWO weight matrices share the X stage -- w1 | w3 with silu(a) * b as the epilogue (EPI =
 // G_SWIGLU, main.zig:405-416) or wk | wv into the two caches (EPI = G_QKV, :354-358): X is a third of
 // the bytes brought into the CU instead of half, one launch instead of two.
-// RMS (round 3): the X rows are the RAW residual rows and the rmsnorm that precedes these products
-// (main.zig:305 / :398) happens here instead of in a launch of its own (two launches of ~5 us per layer, 6 %
-// of a 16-token prompt): the stage carries one more 1-KB row, rms_w[k0 .. k0 + 255] (wave 0 brings it in);
-// an X operand is multiplied by its weights as it leaves LDS, every lane adds up the squares of the raw
-// values it reads -- each X element is read as an operand exactly once per block -- and the per-token scale
-// 1 / sqrt(mean(x^2) + 1e-5) multiplies the finished sums in the epilogue: s * sum_k (x_k g_k) w_k where the
-// reference rounds ((x_k s) g_k) w_k -- the same value up to fp32 rounding, inside the prefill's tolerance.
-template <int EPI, int TMS, int SW, int NW = 1, bool RMS = false>
+template <int EPI, int TMS, int SW, int NW = 1>
 __global__ __launch_bounds__(kPfBlock) void prefill_skinny_dma(const GemmArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int WST = 16 * kSkLD2, XST = 16 * TMS * kSkLD2;
-    constexpr int ST = NW * WST + XST + (RMS ? kSkLD2 : 0);  // floats per stage: W rows, X rows, (rmsnorm weights)
-    constexpr int LPS = 4 * NW + 4 * TMS;  // this wave's loads per stage (wave 0 with RMS: one more)
+    constexpr int WST = 16 * kSkLD2, XST = 16 * TMS * kSkLD2, ST = NW * WST + XST;  // floats per stage: W rows, then X rows
+    constexpr int LPS = 4 * NW + 4 * TMS;  // this wave's loads per stage
     static_assert(SW >= 3 && SW <= 4, "ring depth");
     static_assert(NW == 1 || (NW == 2 && (EPI == G_SWIGLU || EPI == G_QKV)), "paired forms");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -269,12 +261,7 @@ __global__ __launch_bounds__(kPfBlock) void prefill_skinny_dma(const GemmArgs a)
         for (int tm = 0; tm < TMS; tm++)
 #pragma unroll
             for (int i = 0; i < 4; i++) lds_dma16(xsrc[tm][i] + (size_t)st * kSkBK, xs + (16 * tm + 4 * wave + i) * kSkLD2);
-        if (RMS && wave == 0) lds_dma16(a.rms_w + (size_t)st * kSkBK + 4 * lane, xs + XST);
     };
-    const int lps = LPS + (RMS && wave == 0 ? 1 : 0);  // wave-uniform
-    float ss[TMS];  // RMS: this lane's share of sum x^2 of token j of each token tile
-#pragma unroll
-    for (int tm = 0; tm < TMS; tm++) ss[tm] = 0.0f;
     v4f acc[NW][TMS];
 #pragma unroll
     for (int m = 0; m < NW; m++)
@@ -287,15 +274,9 @@ __global__ __launch_bounds__(kPfBlock) void prefill_skinny_dma(const GemmArgs a)
     for (int st = 0; st < nst; st++) {
         // stage st has landed (this wave's part): what may still fly are the younger stages already issued
         const int younger = min(SW - 2, nst - 1 - st);
-        if (lps == LPS) {
-            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (LPS + 1)) : "memory");
-            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS + 1) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // every wave's part of stage st is in LDS; stage st - 1 has been multiplied
         if (st + SW - 1 < nst) issue(st + SW - 1, nbuf);  // into the buffer stage st - 1 has just left
         const float *wr = smem + buf * ST + j * kSkLD2 + 64 * wave + 4 * q;
@@ -307,18 +288,6 @@ __global__ __launch_bounds__(kPfBlock) void prefill_skinny_dma(const GemmArgs a)
             for (int m = 0; m < NW; m++) b[m] = *(const v4f *)(wr + m * WST + 16 * u);
 #pragma unroll
             for (int tm = 0; tm < TMS; tm++) xa[tm] = *(const v4f *)(xr + 16 * tm * kSkLD2 + 16 * u);
-            if (RMS) {
-                // the weights of this lane's four k: the same address for the 16 token lanes (an LDS broadcast)
-                const v4f g4 = *(const v4f *)(smem + buf * ST + NW * WST + XST + 64 * wave + 4 * q + 16 * u);
-#pragma unroll
-                for (int tm = 0; tm < TMS; tm++) {
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        ss[tm] = fmaf(xa[tm][c], xa[tm][c], ss[tm]);  // :441-450 on the raw values
-                        xa[tm][c] = xa[tm][c] * g4[c];                // :462's weights (the scale follows in the epilogue)
-                    }
-                }
-            }
 #pragma unroll
             for (int m = 0; m < NW; m++)
 #pragma unroll
@@ -380,14 +349,10 @@ hipError_t skinny_launch_t(const GemmArgs &a, hipStream_t st)
     // LDS-staged forms (1-KB row reads), up to two token tiles (at 64 tokens the stage would take 83 KB).
     // Direct-to-LDS ring where K is whole 256-k stages and rows are 16-byte aligned;
     // L2Z_PF_SKINNY_FORM=2 keeps the register-staged form (same sums, another order)
-    if (a.rms_w != nullptr && !(TMS == 1 && (EPI == G_ROPE || EPI == G_STORE))) return hipErrorNotSupported;
     if (form == 1 && a.K % kSkBK == 0 && a.K / kSkBK >= 3 && a.ldx % 4 == 0 && TMS <= 2 && tunables().pf_dma != 0) {
         constexpr int SW = TMS == 1 ? 4 : 3;
-        constexpr bool kRmsForm = TMS == 1 && (EPI == G_ROPE || EPI == G_STORE);  // the products that follow a rmsnorm
-        const bool rms = kRmsForm && a.rms_w != nullptr;
-        const size_t lds = (size_t)SW * (16 + 16 * TMS + (rms ? 1 : 0)) * kSkLD2 * sizeof(float);
-        const void *fn = rms ? (const void *)prefill_skinny_dma<EPI, TMS, SW, 1, kRmsForm>
-                             : (const void *)prefill_skinny_dma<EPI, TMS, SW>;
+        const size_t lds = (size_t)SW * (16 + 16 * TMS) * kSkLD2 * sizeof(float);
+        const void *fn = (const void *)prefill_skinny_dma<EPI, TMS, SW>;
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         GemmArgs args = a;
@@ -400,7 +365,6 @@ hipError_t skinny_launch_t(const GemmArgs &a, hipStream_t st)
         void *params[] = {&args};
         return hipLaunchKernel(fn, g1, dim3(kPfBlock), params, lds, st);
     }
-    if (a.rms_w != nullptr) return hipErrorNotSupported;  // only the direct-to-LDS form applies the rmsnorm itself
     if ((form == 1 || form == 2) && a.K >= kSkBK && TMS <= 2) {
         const size_t stage = (size_t)(16 + 16 * TMS) * kSkLD * sizeof(float);
         const size_t red = (size_t)4 * TMS * 4 * 64 * sizeof(float);
@@ -453,12 +417,9 @@ hipError_t launch_prefill_skinny_pair(int epi, const GemmArgs &a, hipStream_t st
     if (tunables().pf_fuse == 0 || tunables().pf_skinny_form != 1 || tunables().pf_dma == 0) return hipErrorNotSupported;
     if (a.K % kSkBK != 0 || a.K / kSkBK >= 3 == false || a.ldx % 4 != 0 || !skinny_one_tile(a)) return hipErrorNotSupported;
     constexpr int SW = 3;
-    const bool rms = a.rms_w != nullptr;
-    const size_t lds = (size_t)SW * (32 + 16 + (rms ? 1 : 0)) * kSkLD2 * sizeof(float);
-    const void *fn = epi == G_SWIGLU ? (rms ? (const void *)prefill_skinny_dma<G_SWIGLU, 1, SW, 2, true>
-                                            : (const void *)prefill_skinny_dma<G_SWIGLU, 1, SW, 2>)
-                   : epi == G_QKV    ? (rms ? (const void *)prefill_skinny_dma<G_QKV, 1, SW, 2, true>
-                                            : (const void *)prefill_skinny_dma<G_QKV, 1, SW, 2>) : nullptr;
+    const size_t lds = (size_t)SW * (32 + 16) * kSkLD2 * sizeof(float);
+    const void *fn = epi == G_SWIGLU ? (const void *)prefill_skinny_dma<G_SWIGLU, 1, SW, 2>
+                   : epi == G_QKV    ? (const void *)prefill_skinny_dma<G_QKV, 1, SW, 2> : nullptr;
     if (fn == nullptr) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -471,19 +432,6 @@ hipError_t launch_prefill_skinny_pair(int epi, const GemmArgs &a, hipStream_t st
     }
     void *params[] = {&args};
     return hipLaunchKernel(fn, g1, dim3(kPfBlock), params, lds, st);
-}
-
-// Whether every short-prompt launch that follows a rmsnorm -- q, k | v, W1 | W3: all [P, K] x [N, K]^T with the
-// model's dim as K -- takes the direct-to-LDS one-tile form, which can apply the rmsnorm itself (RMS above).
-bool prefill_skinny_rms_ok(int P, int N, int K, int ldx, int n_scale)
-{
-    const Tunables &tn = tunables();
-    const int skinny_max = tn.pf_skinny_max >= 0 ? tn.pf_skinny_max : 64;
-    if (tn.pf_rms_fuse == 0 || tn.pf_fuse == 0 || tn.pf_skinny_form != 1 || tn.pf_dma == 0 || tn.pf_tile != 0) return false;
-    if (P > skinny_max || K % kSkBK != 0 || K / kSkBK < 3 || ldx % 4 != 0) return false;
-    GemmArgs a = {};
-    a.P = P; a.N = N; a.K = K; a.n_scale = n_scale > 0 ? n_scale : 1;
-    return skinny_one_tile(a) && tn.pf_skinny_tms != 4;
 }
 
 hipError_t launch_prefill_skinny(int epi, const GemmArgs &a, hipStream_t st)

@@ -44,7 +44,8 @@ struct Tunables {
     int pf_dma = 1;            // L2Z_PF_DMA          0: GEMM operands staged through registers instead of direct-to-LDS loads
     int pf_order = 1;          // L2Z_PF_ORDER        0: 2-D grids for the tile GEMM (x = feature tile, y = token tile)
     int pf_fuse = 1;           // L2Z_PF_FUSE         0: separate Q / K / V and W1 / W3 GEMMs
-    int pf_rms_fuse = 1;       // L2Z_PF_RMS_FUSE     0: short prompts keep the rmsnorm launches (1: the one-tile short-prompt GEMMs apply it themselves)
+    int pf_splitk = -1;        // L2Z_PF_SPLITK       K ranges per output tile of the tile GEMM for chunks of <= 256 tokens: -1 by shape,
+                               //                     1 none, 2 / 4 forced (changes rounding: the range partials are added in range order)
 };
 
 const Tunables &tunables();
