@@ -679,23 +679,31 @@ hipError_t gemm_launch_sk(const GemmArgs &a, int n_feat, int sk, const SplitKWs 
 
 }  // namespace
 
-// K ranges per output tile (see l2z_internal.h).  Chunks of 33 ... 256 tokens leave most CUs one small block
-// (or none) in the unsplit family; the split family gives them a larger tile of 1 / sk of the depth each.
+// K ranges per output tile (see l2z_internal.h); > 1 also means "the tile kernel, not the short-prompt kernels".
+// Measured on the 7B shape, whole prefill, interleaved (profiles/r03_prefill_splitk_ab.txt):
+//   64 tokens   short-prompt kernels 15.8 ms | 64 x 64 tiles unsplit 14.6 | 2 ranges 12.7 | 4 ranges 12.5
+//   40 tokens   12.5 | 14.7 | 12.7 | 12.6        100 tokens  unsplit 19.1 | 2 ranges 18.4 | 4 ranges 21.9
+//   128 tokens  19.2 | 18.5 | 21.9               200 / 256 tokens: every split slower (29.6 -> 33.8, 31.5 -> 34.0)
+// and on the 110M shape (matrices of <= 6 MB, cache resident) every split and the tile kernel below 65 tokens
+// lose.  So: matrices that stream from HBM (> 16 MB over the whole model) take 4 ranges at 49 ... 64 tokens --
+// where the short-prompt kernels would read W twice -- and 2 ranges at 65 ... 128; everything else stays as
+// it was.  The hand-off (accumulator dump, counter, the last arriver's re-read) costs 6-8 us per launch, which is
+// why 4 ranges of a 30-60 us product lose what the larger tile wins.
 int prefill_split_k(long long n_whole, int P, int K, bool pair)
 {
+    (void)pair;
     const Tunables &tn = tunables();
     const int skinny_max = tn.pf_skinny_max >= 0 ? tn.pf_skinny_max : 64;
-    if (P > kSplitKMaxTokens || P <= skinny_max || tn.pf_dma == 0 || tn.pf_tile != 0 || tn.pf_fuse == 0) return 1;
+    if (P > kSplitKMaxTokens || tn.pf_dma == 0 || tn.pf_tile != 0 || tn.pf_fuse == 0) return 1;
     int sk = 1;
-    if (tn.pf_splitk >= 0) {
+    if (tn.pf_splitk >= 0) {  // forced (experiments): beyond the short-prompt kernels' range only
+        if (P <= skinny_max) return 1;
         sk = tn.pf_splitk >= 4 ? 4 : tn.pf_splitk >= 2 ? 2 : 1;
     } else {
-        // by shape: as many ranges as keep every CU one block of the LARGEST tile the chunk admits
-        const long long cus = g_cus_hint();
-        const int tok = P > 64 ? 128 : 64;
-        const long long tiles = ((n_whole + 63) / 64) * ((P + tok - 1) / tok) * (pair ? 1 : 1);
-        if (tiles * 4 <= cus + cus / 2) sk = 4;
-        else if (tiles * 2 <= cus + cus / 2) sk = 2;
+        if (tn.pf_skinny_max >= 0 && P <= tn.pf_skinny_max) return 1;  // that range was set by hand
+        const bool streams = n_whole * (long long)K * 4 > ((long long)16 << 20);
+        if (streams && P >= 49 && P <= 64) sk = 4;
+        else if (streams && P > 64 && P <= 128) sk = 2;
     }
     while (sk > 1 && K % (64 * sk) != 0) sk >>= 1;
     return sk;
@@ -711,7 +719,7 @@ hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float 
     if (((uintptr_t)x & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w3 & 15)) return hipErrorInvalidValue;
     GemmArgs a = {x, w3, w1, out, out, P, N, K, ldx, ldo, ldo, 0, nullptr, 0, n_scale > 0 ? n_scale : 1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
     const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
-    if (P <= skinny_max) return launch_prefill_skinny_pair(G_SWIGLU, a, st);  // prefill_skinny.hip (or not supported)
+    if (P <= skinny_max && sk <= 1) return launch_prefill_skinny_pair(G_SWIGLU, a, st);  // prefill_skinny.hip (or not supported)
     if (K % 64 != 0 || ldx % 4 != 0) return hipErrorNotSupported;
     if (sk > 1) return gemm_launch_sk<G_STORE, true>(a, N, sk, ws, st);
     constexpr int KS = 2;
@@ -743,7 +751,7 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
 {
     if (tunables().pf_fuse == 0 || tunables().pf_dma == 0 || tunables().pf_tile != 0) return hipErrorNotSupported;
     const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
-    if (P <= skinny_max || K % 64 != 0 || ldx % 4 != 0) return hipErrorNotSupported;
+    if ((P <= skinny_max && sk <= 1) || K % 64 != 0 || ldx % 4 != 0) return hipErrorNotSupported;
     if (((uintptr_t)x & 15) || ((uintptr_t)wq & 15) || ((uintptr_t)wk & 15) || ((uintptr_t)wv & 15)) return hipErrorInvalidValue;
     const int N = nq + 2 * nkv;
     if (sk > 1) {  // the split family: 64-feature tiles (a tile must not straddle q | k | v)
@@ -785,10 +793,10 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
 // brought into the CU once for both).  hipErrorNotSupported otherwise: the caller launches the two.
 hipError_t launch_prefill_gemm_kv_pair(const float *x, int ldx, const float *wk, const float *wv, float *kcache,
                                        float *vcache, int ldkv, int P, int nkv, int K, int pos0, const float2 *rope,
-                                       int head_size, hipStream_t st, int n_scale, size_t kv_head_stride)
+                                       int head_size, hipStream_t st, int n_scale, size_t kv_head_stride, int sk)
 {
     const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
-    if (P > skinny_max) return hipErrorNotSupported;
+    if (P > skinny_max || sk > 1) return hipErrorNotSupported;  // sk > 1: the tile kernel's split-K family takes it
     if (((uintptr_t)x & 15) || ((uintptr_t)wk & 15) || ((uintptr_t)wv & 15)) return hipErrorInvalidValue;
     GemmArgs a = {x, wv, wk, kcache, kcache, P, nkv, K, ldx, ldkv, ldkv, pos0, rope, head_size, n_scale > 0 ? n_scale : 1,
                   wk, wv, kcache, vcache, 0, nkv, ldkv, kv_head_stride, 0, 0};
@@ -806,7 +814,7 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
     if (res == nullptr) { res = out; ldres = ldo; }  // PG_RESID in place
     GemmArgs a = {x, nullptr, w, out, res, P, N, K, ldx, ldo, ldres, pos0, rope, head_size, n_scale > 0 ? n_scale : 1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, kv_head_stride, 0, 0};
     const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
-    if (P <= skinny_max) return launch_prefill_skinny(epi, a, st);  // prefill_skinny.hip
+    if (P <= skinny_max && sk <= 1) return launch_prefill_skinny(epi, a, st);  // prefill_skinny.hip
     if (sk > 1) {
         if (K % (64 * sk) != 0) return hipErrorInvalidValue;
         switch (epi) {

@@ -219,11 +219,11 @@ def test_stories110M_across_the_attention_switch_over(gpu, ck, orc):
     s.close(); w.close(); m.close()
 
 
-@pytest.mark.parametrize("n", [16, 20, 40, 300, 1024])
+@pytest.mark.parametrize("n", [16, 20, 40, 60, 100, 300, 1024])
 def test_7b_prefill_equals_stepped_loop(gpu, model7b, n):
-    """Batched prefill at the full 7B shape (16x16x4 skinny kernels for 20 and 40 tokens, the
-    direct-to-LDS 32x32x2 GEMM with 128x64 tiles for 300, one 1024-token chunk with 128x128 tiles and
-    the flash-form attention for 1024) leaves the logits and KV rows the stepped loop leaves, within the
+    """Batched prefill at the full 7B shape (16x16x4 skinny kernels for 16, 20 and 40 tokens, the tile GEMM's
+    split-K family for 60 (4 K ranges per tile) and 100 tokens (2), the direct-to-LDS 32x32x2 GEMM with
+    128x64 tiles for 300, one 1024-token chunk with 128x128 tiles and the flash-form attention for 1024) leaves the logits and KV rows the stepped loop leaves, within the
     LOGIT tolerance of the oracle tests (5e-5: fp32 sums in a different order, nothing else) -- the
     stepped loop itself is pinned against the oracle at this shape (test_7b_full_forward_logits_vs_oracle)."""
     cfg, w, s = model7b
@@ -374,5 +374,12 @@ def test_stories110M_prefill_paths_vs_oracle(gpu, ck, orc, options):
         options(L2Z_PF_TILE=tile)
         assert np.array_equal(check(300, f"forced {name}"), base[300]), f"tile form {name} changed the bits"
     options(L2Z_PF_TILE=0)
+    # the split-K family (K cut into 2 / 4 ranges per output tile, the last arriver adds the range partials in
+    # order): this shape's matrices are cache resident, so it is forced here; another rounding, same tolerance
+    for sk in (2, 4):
+        options(L2Z_PF_SPLITK=sk)
+        got = check(100, f"split-K {sk}")
+        assert not np.array_equal(got, base[100]), f"split-K {sk}: identical bits, the split family did not run"
+    options(L2Z_PF_SPLITK=-1)
     w.close()
 

@@ -577,6 +577,11 @@ SHARDED_PREFILL = [
     ("gqa", dict(dim=512, hidden_dim=1408, n_layers=2, n_heads=16, n_kv_heads=8, vocab_size=1024, seq_len=544), 530),
     # few heads: the per-query attention kernel; 40 tokens: the skinny (P <= 64) GEMM forms
     ("mha-short", dict(dim=256, hidden_dim=704, n_layers=3, n_heads=8, n_kv_heads=8, vocab_size=512, seq_len=64), 40),
+    # matrices that stream from HBM (> 16 MB each): the tile GEMM's split-K family -- 4 K ranges per tile for the
+    # 51-token second call, 2 for a 101-token one -- whose range count comes from the WHOLE model's shape, so a
+    # rank's [tokens, n / world] block has the bits of the unsharded pass
+    ("streams-60", dict(dim=3072, hidden_dim=8192, n_layers=2, n_heads=24, n_kv_heads=8, vocab_size=2048, seq_len=128), 60),
+    ("streams-110", dict(dim=3072, hidden_dim=8192, n_layers=2, n_heads=24, n_kv_heads=8, vocab_size=2048, seq_len=128), 110),
 ]
 
 
