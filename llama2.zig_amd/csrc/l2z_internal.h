@@ -123,6 +123,7 @@ struct MatvecArgs {
     int push_gi;              // index of the gather the outputs belong to
     // x is a gathered vector that is read as LL words from this rank's landing slot (xin.slots != null)
     LLIn xin;
+    int tail_skip;            // row kernel, n > 4096: out-of-row steps of a row's last batch load nothing (set by the launcher)
 };
 
 // main.zig:361-389: scores, softmax, att.V for the local heads of one layer

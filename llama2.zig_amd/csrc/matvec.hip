@@ -434,7 +434,16 @@ __global__ __launch_bounds__(kBlock) void matvec_row_kernel(const MatvecArgs a)
         const int wbase = cb + (tid & ~63);
 #pragma unroll
         for (int k = 0; k < U; k++) {
-            const int off = (wbase + kBlock * k < n4) ? kBlock * k : -(cb + (tid & ~63));
+            const bool in_row = wbase + kBlock * k < n4;  // wave-uniform
+            if (XC == 12 && a.tail_skip && !in_row) {
+                // rows that do not fill their last batch (n = 11008: 704 of 1024 float4): the out-of-row steps
+                // load NOTHING (their x is the zero padding) -- the re-reads of the row start were 11.6 % of
+                // W2's load instructions and, the nt lines long evicted, 2.7 % extra HBM traffic (PMC 1.027x)
+                wa[k] = v4f{0.f, 0.f, 0.f, 0.f};
+                wb[k] = v4f{0.f, 0.f, 0.f, 0.f};
+                continue;
+            }
+            const int off = in_row ? kBlock * k : -(cb + (tid & ~63));
             wa[k] = ldg_nt(a4 + off);  // out-of-row steps re-read the row start; their x is 0
             wb[k] = ldg_nt(b4 + off);
         }
@@ -727,6 +736,7 @@ hipError_t launch_matvec(const MatvecArgs &a_in, int pro, int epi, int max_block
     // only single-segment epilogues of the vector kernels push (wo, ffn13, ffn2, classifier)
     if (!vec || epi == EPI_ROPE || a.rows2 != 0 || (epi != EPI_SWIGLU && a.rows1 != 0)) a.push = nullptr;
     if (pushed) *pushed = a.push != nullptr;
+    a.tail_skip = tn.row_tail_skip;
     void *args[] = {&a};
     return hipLaunchKernel(k.fn, dim3(grid), dim3(kBlock), args, lds, st);
 }

@@ -18,6 +18,7 @@ Tunables read_env()
     Tunables t;
     env_int("L2Z_ROW_KERNEL", &t.row_kernel);
     env_int("L2Z_ROW_BLOCKS", &t.row_blocks);
+    env_int("L2Z_ROW_TAIL_SKIP", &t.row_tail_skip);
     env_int("L2Z_MAX_BLOCKS_PER_CU", &t.max_blocks_per_cu);
     env_int("L2Z_GRID_CAP", &t.grid_cap);
     env_int("L2Z_ATTN_BLOCK", &t.attn_block);
@@ -82,7 +83,7 @@ bool tunables_set(const char *name, long long v)
 {
     Tunables &t = mutable_tunables();
     struct { const char *n; int *p; } ints[] = {
-        {"L2Z_ROW_KERNEL", &t.row_kernel}, {"L2Z_ROW_BLOCKS", &t.row_blocks},
+        {"L2Z_ROW_KERNEL", &t.row_kernel}, {"L2Z_ROW_BLOCKS", &t.row_blocks}, {"L2Z_ROW_TAIL_SKIP", &t.row_tail_skip},
         {"L2Z_MAX_BLOCKS_PER_CU", &t.max_blocks_per_cu}, {"L2Z_GRID_CAP", &t.grid_cap},
         {"L2Z_ATTN_BLOCK", &t.attn_block}, {"L2Z_ATTN_SPLIT", &t.attn_split},
         {"L2Z_ATTN_SPLIT_POS", &t.attn_split_pos}, {"L2Z_ATTN_SHORT_POS", &t.attn_short_pos},

@@ -10,6 +10,7 @@ struct Tunables {
     // --- decode mat-vec (matvec.hip) ---
     int row_kernel = 1;        // L2Z_ROW_KERNEL      0: wide rows take the per-wave kernel too
     int row_blocks = 2;        // L2Z_ROW_BLOCKS      resident row-kernel blocks per CU
+    int row_tail_skip = 1;     // L2Z_ROW_TAIL_SKIP   0: a wide row's last, partly filled batch re-reads the row start instead of skipping the loads
     int max_blocks_per_cu = 8; // L2Z_MAX_BLOCKS_PER_CU
     int grid_cap = 0;          // L2Z_GRID_CAP        max blocks of one mat-vec launch (0: none); set when
                                //                     several ranks share one GPU so that a kernel
