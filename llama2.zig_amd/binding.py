@@ -103,10 +103,12 @@ def lib():
     L.l2z_comm_unique_id.argtypes = [vp]
     L.l2z_comm_init.argtypes = [C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp)]
     L.l2z_comm_p2p_export.argtypes = [vp, sz, vp]
-    L.l2z_comm_p2p_export_sized.argtypes = [vp, sz, sz, vp]
+    if hasattr(L, "l2z_comm_p2p_export_sized"):
+        L.l2z_comm_p2p_export_sized.argtypes = [vp, sz, sz, vp]
     L.l2z_comm_p2p_connect.argtypes = [vp, vp]
     L.l2z_comm_rank.argtypes = [vp, ip, ip]
-    L.l2z_comm_transports.argtypes = [vp, ip, ip]
+    if hasattr(L, "l2z_comm_transports"):  # an older build loaded through L2Z_LIB (A/B runs) lacks the newer entry points
+        L.l2z_comm_transports.argtypes = [vp, ip, ip]
     L.l2z_comm_free.argtypes = [vp]
     L.l2z_comm_free.restype = None
     L.l2z_comm_init_emulated.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]

@@ -686,8 +686,8 @@ hipError_t gemm_launch_sk(const GemmArgs &a, int n_feat, int sk, const SplitKWs 
 //   128 tokens  19.2 | 18.5 | 21.9               200 / 256 tokens: every split slower (29.6 -> 33.8, 31.5 -> 34.0)
 // and on the 110M shape (matrices of <= 6 MB, cache resident) every split and the tile kernel below 65 tokens
 // lose.  So: matrices that stream from HBM (> 16 MB over the whole model) take 4 ranges at 49 ... 64 tokens --
-// where the short-prompt kernels would read W twice -- and 2 ranges at 65 ... 128; everything else stays as
-// it was.  The hand-off (accumulator dump, counter, the last arriver's re-read) costs 6-8 us per launch, which is
+// where the short-prompt kernels would read W twice -- and the block-starved ones 2 ranges at 65 ... 128;
+// everything else stays as it was.  The hand-off (accumulator dump, counter, the last arriver's re-read) costs 6-8 us per launch, which is
 // why 4 ranges of a 30-60 us product lose what the larger tile wins.
 int prefill_split_k(long long n_whole, int P, int K, bool pair)
 {
@@ -702,8 +702,12 @@ int prefill_split_k(long long n_whole, int P, int K, bool pair)
     } else {
         if (tn.pf_skinny_max >= 0 && P <= tn.pf_skinny_max) return 1;  // that range was set by hand
         const bool streams = n_whole * (long long)K * 4 > ((long long)16 << 20);
+        // 65 ... 128 tokens: only the launches the unsplit family leaves block-starved (wo, W2: N = 4096 is 256
+        // blocks of 32 x 64, one per CU); q | k | v and W1 | W3 already have ~3 blocks per CU there and LOSE with
+        // two ranges (rocprofv3, 128 tokens: wo 61 -> 54 us, W2 162 -> 130, but q|k|v 126 -> 133, W1|W3 237 -> 256)
+        const long long unsplit_blocks = ((n_whole + 63) / 64) * ((P + 31) / 32);
         if (streams && P >= 49 && P <= 64) sk = 4;
-        else if (streams && P > 64 && P <= 128) sk = 2;
+        else if (streams && P > 64 && P <= 128 && 2 * unsplit_blocks <= 3 * g_cus_hint()) sk = 2;
     }
     while (sk > 1 && K % (64 * sk) != 0) sk >>= 1;
     return sk;
