@@ -30,7 +30,11 @@ def run(n_cfg, seed, log=print):
         seq = n_tok + 8
         cfg = ck.Config(dim, hidden, int(rng.integers(1, 3)), n_heads, n_kv, vocab, seq)
         toks = [1] + rng.integers(2, vocab, n_tok - 1).tolist()
-        tag = f"world {world} dim {dim} hs {hs} H {n_heads} kv {n_kv} hid {hidden} V {vocab} L {cfg.n_layers} tokens {n_tok}"
+        # the tile GEMM's split-K family: as the shape picks it (-1), or forced for 65 ... 256-token chunks -- the
+        # same setting for the unsharded pass and the shards, which must stay bit-identical in every family
+        sk = int(rng.choice([-1, -1, 2, 4]))
+        B.option_set("L2Z_PF_SPLITK", sk)
+        tag = f"world {world} dim {dim} hs {hs} H {n_heads} kv {n_kv} hid {hidden} V {vocab} L {cfg.n_layers} tokens {n_tok} splitk {sk}"
         try:
             w0 = B.Weights(cfg, None, False, seed=70 + it)
             s0, s1 = B.RunState(cfg), B.RunState(cfg)
@@ -74,6 +78,7 @@ def run(n_cfg, seed, log=print):
         except Exception as e:  # noqa: BLE001
             log(f"ERR {tag}: {e}")
             bad += 1
+    B.option_set("L2Z_PF_SPLITK", -1)
     return bad
 
 
