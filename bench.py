@@ -446,6 +446,8 @@ def leg_main(args) -> int:
         dist.all_gather_object(flags, bool(ok))
         return all(flags)
 
+    setup_errors = []  # what this rank's transport set-up said when it failed (goes into the leg's `why`)
+
     def make_comm():
         """p2p legs: peer-write gathers over IPC-mapped arenas (xGMI between GPUs); rccl leg: RCCL."""
         if kind != "rccl":
@@ -454,6 +456,7 @@ def leg_main(args) -> int:
                 c = B.Comm(rank, world, None, device)
                 h = c.p2p_export(max(cfg.dim, cfg.hidden_dim, cfg.vocab_size), max(cfg.dim, cfg.hidden_dim))
             except Exception as e:  # noqa: BLE001
+                setup_errors.append(f"peer-write export: {e}")
                 print(f"[rank {rank}] peer-write export failed: {e}", file=sys.stderr)
             hs = [None] * world
             dist.all_gather_object(hs, h)
@@ -462,6 +465,7 @@ def leg_main(args) -> int:
                 try:
                     c.p2p_connect(b"".join(hs))
                 except Exception as e:  # noqa: BLE001
+                    setup_errors.append(f"peer-write connect: {e}")
                     print(f"[rank {rank}] peer-write connect failed: {e}", file=sys.stderr)
                     ok = False
             if all_ok(ok):
@@ -473,6 +477,7 @@ def leg_main(args) -> int:
         try:
             uid = [B.Comm.unique_id() if rank == 0 else None]
         except Exception as e:  # noqa: BLE001
+            setup_errors.append(f"ncclGetUniqueId: {e}")
             print(f"[rank {rank}] ncclGetUniqueId failed: {e}", file=sys.stderr)
             uid = [None]
         dist.broadcast_object_list(uid, src=0)
@@ -480,6 +485,7 @@ def leg_main(args) -> int:
             try:
                 c = B.Comm(rank, world, uid[0], device)
             except Exception as e:  # noqa: BLE001
+                setup_errors.append(f"RCCL communicator: {e}")
                 print(f"[rank {rank}] RCCL communicator failed: {e}", file=sys.stderr)
         if all_ok(c is not None):
             return c
@@ -506,7 +512,10 @@ def leg_main(args) -> int:
     B.option_set("L2Z_COMM_RCCL", 1 if kind == "rccl" else 0)
     comm = make_comm()
     if comm is None:
-        return fail("set-up failed")
+        errs = [None] * world
+        dist.all_gather_object(errs, "; ".join(setup_errors))
+        first = next((f"rank {r}: {e}" for r, e in enumerate(errs) if e), "no message")
+        return fail(f"set-up failed ({first})")
     tr = comm.transports()
     trs = [None] * world
     dist.all_gather_object(trs, tr)
@@ -537,6 +546,10 @@ def leg_main(args) -> int:
         err = None
         dtp = 0.0
         n_p = min(512, cfg.seq_len - 1)
+        if shared_cap:
+            # ranks sharing one chip (the one-GPU proxy only): the unpack launch that waits for the peers' blocks
+            # must leave their push launches room to run, whatever the leg's decode transport is
+            B.option_set("L2Z_GRID_CAP", shared_cap)
         try:
             toks = [1] + np.random.default_rng(args.seed).integers(2, cfg.vocab_size, n_p - 1).tolist()
             s.prefill(toks, 0, w)

@@ -340,22 +340,35 @@ __global__ __launch_bounds__(256 * KS) void prefill_gemm(const GemmArgs a)
 //    partials rounds differently from one k-ordered chain, so sk is part of the arithmetic: it is chosen from
 //    the WHOLE model's shape and the chunk length (choose_sk), never from a rank's share of the rows, and
 //    every tile form gives the same bits for the same sk.
-template <int EPI, int TM, int TN, int KS, bool PAIR = false, int WM = 2, int WN = 2, bool SPLIT = false>
+//  * SPLIT == 2 (round 3, "k-groups on two blocks"): the two k-groups of a stage -- slots 0..7 and 8..15 of every
+//    64-k stage, two wave groups of one block in every other form -- run as TWO blocks of NWG waves each
+//    (blockIdx.z = the k-group).  A block brings in only its half of every stage (LDS rows of 8 slots, 128 B;
+//    a 1-KB load is 8 half rows; swizzle row & 7: a b128 read's 16-lane phase then meets each bank twice --
+//    LDS reads are ~5 % of a stage), so a tile costs half the LDS and twice the blocks exist.  Whichever block
+//    of a tile draws its counter first dumps its accumulators (write-through), drains and raises the tile's
+//    flag; the other one waits for the flag (the first is running: it drew before), adds the dump to its own
+//    accumulators and runs the epilogue.  kg0 + kg1 is exactly the sum the one-block forms form in LDS, and
+//    a + b == b + a: THE SAME BITS as every other form of the unsplit family -- so this one is chosen by grid
+//    fill alone, shards included.
+template <int EPI, int TM, int TN, int KS, bool PAIR = false, int WM = 2, int WN = 2, int SPLIT = 0>
 __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const GemmArgs a)
 {
     static_assert(!PAIR || TN == 2, "paired form: one W1 tile and one W3 tile per wave column");
-    constexpr int BK = 64, SLOTS = BK / 4;
+    static_assert(SPLIT != 2 || KS == 2, "k-groups on two blocks: two k-groups");
+    constexpr bool KGS = SPLIT == 2;
+    constexpr int BK = 64, SLOTS = KGS ? BK / 4 / KS : BK / 4;  // float4 slots per LDS row (KGS: this block's half)
     constexpr int RPI = 64 / SLOTS;                  // tile rows per 1-KB load
     constexpr int BMt = 32 * WM * TM, BNt = 32 * WN * TN;
     constexpr int NWG = WM * WN;                     // waves per k-group: WM x WN of them tile the block
-    constexpr int NW = NWG * KS;                     // waves
+    constexpr int NW = KGS ? NWG : NWG * KS;         // waves
     constexpr int XI = BMt / RPI / NW, WI = BNt / RPI / NW;  // 1-KB loads per wave and stage
     static_assert(BMt % (RPI * NW) == 0 && BNt % (RPI * NW) == 0, "tile rows per wave");
-    constexpr int STAGE = (BMt + BNt) * BK;          // floats
-    auto swz = [](int row) { return row & 15; };
+    constexpr int STAGE = (BMt + BNt) * 4 * SLOTS;   // floats
+    auto swz = [](int row) { return row & (SLOTS - 1); };
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wg = wave % NWG, kg = wave / NWG, wm = wg / WN, wn = wg % WN;
+    const int wg = KGS ? wave : wave % NWG, kg = KGS ? (int)blockIdx.z : wave / NWG, wm = wg / WN, wn = wg % WN;
+    const int kslot0 = KGS ? kg * SLOTS : 0;         // first slot of the 64-k stage this block's LDS rows hold
     // Block -> tile.  2-D grid: x = feature tile, y = token tile.  1-D grid (a.nty > 0, dma_grid): ids are
     // dispatched in order and round-robin over the 8 XCDs, so consecutive groups of 8 nty ids take 8
     // feature tiles x all nty token tiles with id % 8 = feature tile % 8: the nty blocks that read the
@@ -369,9 +382,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
         if (bx >= a.ntx) return;  // padding of the last group
     }
     const int n0 = bx * (PAIR ? BNt / 2 : BNt), m0 = by * BMt;
-    // SPLIT: this block's K range (launcher: K % (64 sk) == 0)
-    const int klen = SPLIT ? a.K / a.sk : a.K;
-    const int kbeg = SPLIT ? (int)blockIdx.z * klen : 0, kend = kbeg + klen;
+    // SPLIT == 1: this block's K range (launcher: K % (64 sk) == 0)
+    const int klen = SPLIT == 1 ? a.K / a.sk : a.K;
+    const int kbeg = SPLIT == 1 ? (int)blockIdx.z * klen : 0, kend = kbeg + klen;
 
     // this lane's part of every load: row (within the RPI-row group) lane / SLOTS, physical slot lane % SLOTS
     const int lrow = lane / SLOTS, pslot = lane % SLOTS;
@@ -379,7 +392,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
 #pragma unroll
     for (int j = 0; j < XI; j++) {
         const int r = (wave * XI + j) * RPI + lrow;               // tile row
-        xsrc[j] = a.x + (size_t)min(m0 + r, a.P - 1) * a.ldx + 4 * (pslot ^ swz(r));
+        xsrc[j] = a.x + (size_t)min(m0 + r, a.P - 1) * a.ldx + 4 * (kslot0 + (pslot ^ swz(r)));
     }
 #pragma unroll
     for (int j = 0; j < WI; j++) {
@@ -387,23 +400,23 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
         if (PAIR) {  // LDS row r = wave column r / 64, tile (r % 64) / 32 (0: W1, 1: W3), feature r % 32
             const float *m = ((r & 63) >> 5) ? a.w2 : a.w;
             const int f = n0 + (r >> 6) * 32 + (r & 31);
-            wsrc[j] = m + (size_t)min(f, a.N - 1) * a.K + 4 * (pslot ^ swz(r));
+            wsrc[j] = m + (size_t)min(f, a.N - 1) * a.K + 4 * (kslot0 + (pslot ^ swz(r)));
         } else if (EPI == G_QKV) {  // the matrix of the block's column range
             const int seg = n0 >= a.nq + a.nkv ? 2 : n0 >= a.nq ? 1 : 0;
             const float *m = seg == 0 ? a.w : seg == 1 ? a.wk : a.wv;
             const int f0 = n0 - (seg == 2 ? a.nq + a.nkv : seg == 1 ? a.nq : 0), nseg = seg == 0 ? a.nq : a.nkv;
-            wsrc[j] = m + (size_t)min(f0 + r, nseg - 1) * a.K + 4 * (pslot ^ swz(r));
+            wsrc[j] = m + (size_t)min(f0 + r, nseg - 1) * a.K + 4 * (kslot0 + (pslot ^ swz(r)));
         } else {
-            wsrc[j] = a.w + (size_t)min(n0 + r, a.N - 1) * a.K + 4 * (pslot ^ swz(r));
+            wsrc[j] = a.w + (size_t)min(n0 + r, a.N - 1) * a.K + 4 * (kslot0 + (pslot ^ swz(r)));
         }
     }
 #define L2Z_DMA_ISSUE(k0_, buf_)                                                                          \
     do {                                                                                                  \
-        float *xs_ = smem + (buf_) * STAGE, *ws_ = xs_ + BMt * BK;                                        \
+        float *xs_ = smem + (buf_) * STAGE, *ws_ = xs_ + BMt * 4 * SLOTS;                                 \
         _Pragma("unroll") for (int j = 0; j < XI; j++)                                                    \
-            lds_dma16(xsrc[j] + (k0_), xs_ + (wave * XI + j) * RPI * BK);                                  \
+            lds_dma16(xsrc[j] + (k0_), xs_ + (wave * XI + j) * 256);  /* a 1-KB load: RPI whole LDS rows */ \
         _Pragma("unroll") for (int j = 0; j < WI; j++)                                                    \
-            lds_dma16(wsrc[j] + (k0_), ws_ + (wave * WI + j) * RPI * BK);                                  \
+            lds_dma16(wsrc[j] + (k0_), ws_ + (wave * WI + j) * 256);                                       \
     } while (0)
 
     v16f acc[TM][TN];
@@ -416,7 +429,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
 
     // operand addresses (float4 units) of super-step s: row base + ((logical slot) ^ (row & 15))
     const int hl = lane >> 5, il = lane & 31;
-    constexpr int SPG = SLOTS / KS;   // slots of this wave group per stage
+    constexpr int SPG = KGS ? SLOTS : SLOTS / KS;   // slots of this wave group per stage
     constexpr int SS = SPG / 2;       // super-steps (one float4 per k-half each)
     int arow[TM], brow[TN], asw[TM], bsw[TN];
 #pragma unroll
@@ -436,7 +449,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
     do {                                                                                                  \
         const v4f *xr = (const v4f *)(smem + (buf_) * STAGE), *wr = xr + BMt * SLOTS;                      \
         _Pragma("unroll") for (int s = 0; s < SS; s++) {                                                   \
-            const int slot = kg * SPG + 2 * s + hl;                                                       \
+            const int slot = (KGS ? 0 : kg * SPG) + 2 * s + hl;                                           \
             v4f av[TM], bv[TN];                                                                           \
             _Pragma("unroll") for (int i = 0; i < TM; i++) av[i] = xr[arow[i] + (slot ^ asw[i])];          \
             _Pragma("unroll") for (int j = 0; j < TN; j++) bv[j] = wr[brow[j] + (slot ^ bsw[j])];          \
@@ -462,7 +475,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
         buf ^= 1;
     }
 #undef L2Z_MULTIPLY_STAGE
-    if (KS > 1) {
+    if (KS > 1 && !KGS) {
         float *red = smem;  // [KS-1][NWG waves][TM*TN*16][64 lanes]
         if (kg > 0) {
 #pragma unroll
@@ -486,7 +499,46 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
                         acc[i][j][r] += red[((((g - 1) * NWG + wave) * TM * TN + i * TN + j) * 16 + r) * 64 + lane];
     }
 #undef L2Z_DMA_ISSUE
-    if constexpr (SPLIT) {
+    if constexpr (SPLIT == 2) {
+        // every wave of this block holds its k-group's sums for its 32 TM x 32 TN outputs
+        constexpr int PT = NWG * TM * TN * 16 * 64;  // floats per dump = the tile's outputs
+        const int ntx_all = a.nty > 0 ? a.ntx : (int)gridDim.x;
+        const size_t tile = (size_t)by * ntx_all + bx;
+        float *dump = a.sk_part + tile * PT + (size_t)wg * (TM * TN * 16 * 64) + lane;
+        int *cnt = a.sk_cnt + 2 * tile, *flag = cnt + 1;
+        int *role = (int *)smem;
+        __syncthreads();  // every wave is done with the stage buffers
+        if (tid == 0) *role = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*role == 0) {  // drew first: leave the sums for the other block of this tile
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        __hip_atomic_store(dump + ((i * TN + j) * 16 + r) * 64, acc[i][j][r], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);  // write-through
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its part
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (tid == 0) {  // drew second: the first one is running (it drew before) and will raise the flag
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
+            __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this CU's stale lines of the dump
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] += dump[((i * TN + j) * 16 + r) * 64];  // kg0 + kg1 (a + b == b + a)
+    }
+    if constexpr (SPLIT == 1) {
         // the k-group-0 waves hold the block's sums (the others have left; a barrier only counts live waves)
         constexpr int PT = NWG * TM * TN * 16 * 64;  // floats per partial = the tile's outputs
         const int ntx_all = a.nty > 0 ? a.ntx : (int)gridDim.x;
@@ -658,7 +710,7 @@ hipError_t dma_launch_split(GemmArgs a, int n_feat, int sk, const SplitKWs *ws, 
     size_t lds = 2 * (size_t)(BMt + BNt) * 64 * sizeof(float);
     const size_t red = (size_t)(KS - 1) * NWG * TM * TN * 16 * 64 * sizeof(float);
     if (red > lds) lds = red;
-    const void *fn = (const void *)prefill_gemm_dma<EPI, TM, TN, KS, PAIR, WM, WN, true>;
+    const void *fn = (const void *)prefill_gemm_dma<EPI, TM, TN, KS, PAIR, WM, WN, 1>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const dim3 grid = dma_grid(ntx, nty, &a);
     void *params[] = {&a};
@@ -674,6 +726,78 @@ hipError_t gemm_launch_sk(const GemmArgs &a, int n_feat, int sk, const SplitKWs 
     case SKT_128x64: return dma_launch_split<EPI, 2, TN, PAIR, 2, 2>(a, n_feat, sk, ws, st);
     case SKT_64x64: return dma_launch_split<EPI, 1, TN, PAIR, 2, 2>(a, n_feat, sk, ws, st);
     default: return dma_launch_split<EPI, 1, TN, PAIR, 1, 2>(a, n_feat, sk, ws, st);
+    }
+}
+
+// ---- k-groups on two blocks (prefill_gemm_dma SPLIT == 2): the unsplit family's bits with twice the blocks ----
+template <int EPI, int TM, int TN, bool PAIR, int WM, int WN>
+hipError_t dma_launch_kgs(GemmArgs a, int n_feat, const SplitKWs *ws, hipStream_t st)
+{
+    constexpr int KS = 2, BMt = 32 * WM * TM, BNt = 32 * WN * TN, NWG = WM * WN;
+    constexpr int feat = PAIR ? BNt / 2 : BNt;
+    const int ntx = (n_feat + feat - 1) / feat, nty = (a.P + BMt - 1) / BMt;
+    if ((size_t)ntx * nty * BMt * BNt > ws->part_floats || 2 * ntx * nty > ws->cnt_ints) return hipErrorOutOfMemory;
+    a.sk = 2; a.sk_part = ws->part; a.sk_cnt = ws->cnt;  // sk: the grid's z extent (dma_grid)
+    const size_t lds = 2 * (size_t)(BMt + BNt) * 32 * sizeof(float);  // two stage buffers of half rows
+    const void *fn = (const void *)prefill_gemm_dma<EPI, TM, TN, KS, PAIR, WM, WN, 2>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const dim3 grid = dma_grid(ntx, nty, &a);
+    void *params[] = {&a};
+    return hipLaunchKernel(fn, grid, dim3(64 * NWG), params, lds, st);
+}
+
+// Whether a [P, N] product (N = features of each matrix when paired) goes out in the two-block form, and on which
+// tile.  Same bits either way, so this is grid fill only: the cost model of choose_tile with twice the blocks of
+// half the depth, plus the hand-off (~7 us: a dump, a counter, the other block's read) in the model's units.
+struct KgsChoice { bool use; TileForm tile; };
+static KgsChoice choose_kgs(int N, int P, int K, bool pair, const SplitKWs *ws)
+{
+    const Tunables &tn = tunables();
+    KgsChoice none = {false, TILE_64x64};
+    if (ws == nullptr || ws->part == nullptr || tn.pf_kgs == 0 || tn.pf_dma == 0 || tn.pf_tile != 0 || tn.pf_fuse == 0 ||
+        K % 64 != 0)
+        return none;
+    static const struct { int tok, feat; double eff; } form[5] = {{128, 64, 1.0}, {64, 64, 0.87}, {32, 64, 0.80}, {32, 32, 0.65},
+                                                                   {128, 128, 1.12}};
+    if (tn.pf_kgs >= 10) {  // forced (experiments): 10 + tile form
+        const int f = tn.pf_kgs - 10;
+        if (f < 0 || f > 4 || f == TILE_32x32 || (pair && f == TILE_128x128)) return none;
+        return {true, (TileForm)f};
+    }
+    const long long cus = g_cus_hint();
+    const double handoff = 7e-6 * (157.3e12 / 256.0) / (2.0 * K);  // in "outputs per block" like the areas below
+    // the best unsplit form, as choose_tile sees it
+    const TileForm tu = choose_tile(N, P, pair);
+    const long long bu = (long long)((N + form[tu].feat - 1) / form[tu].feat) * ((P + form[tu].tok - 1) / form[tu].tok);
+    const double cost_u = (double)((bu + cus - 1) / cus) * (form[tu].tok * form[tu].feat) / form[tu].eff;
+    int best = -1;
+    double best_cost = cost_u;
+    for (int f = 0; f < 5; f++) {
+        if (f == TILE_32x32 || (pair && f == TILE_128x128)) continue;
+        if (form[f].tok > 64 && P <= 64) continue;
+        const long long blocks = 2LL * ((N + form[f].feat - 1) / form[f].feat) * ((P + form[f].tok - 1) / form[f].tok);
+        const double cost = (double)((blocks + cus - 1) / cus) * (form[f].tok * form[f].feat) / 2.0 / form[f].eff + handoff;
+        if (cost < best_cost * 0.97) {  // it has to pay clearly: the hand-off is the uncertain part of the model
+            best = f;
+            best_cost = cost;
+        }
+    }
+    if (best < 0) return none;
+    return {true, (TileForm)best};
+}
+
+// unpaired products with a residual epilogue, the fused q | k | v launch (TN = 1 forms) and the paired W1 | W3 product
+template <int EPI, bool PAIR>
+hipError_t gemm_launch_kgs(const GemmArgs &a, int n_feat, TileForm tile, const SplitKWs *ws, hipStream_t st)
+{
+    constexpr int TN = PAIR ? 2 : 1;
+    switch (tile) {
+    case TILE_128x128:
+        if constexpr (!PAIR) return dma_launch_kgs<EPI, 2, 2, false, 2, 2>(a, n_feat, ws, st);
+        return hipErrorInvalidValue;
+    case TILE_128x64: return dma_launch_kgs<EPI, 2, TN, PAIR, 2, 2>(a, n_feat, ws, st);
+    case TILE_64x64: return dma_launch_kgs<EPI, 1, TN, PAIR, 2, 2>(a, n_feat, ws, st);
+    default: return dma_launch_kgs<EPI, 1, TN, PAIR, 1, 2>(a, n_feat, ws, st);
     }
 }
 
@@ -726,6 +850,10 @@ hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float 
     if (P <= skinny_max && sk <= 1) return launch_prefill_skinny_pair(G_SWIGLU, a, st);  // prefill_skinny.hip (or not supported)
     if (K % 64 != 0 || ldx % 4 != 0) return hipErrorNotSupported;
     if (sk > 1) return gemm_launch_sk<G_STORE, true>(a, N, sk, ws, st);
+    {
+        const KgsChoice c = choose_kgs(N, P, K, true, ws);
+        if (c.use) return gemm_launch_kgs<G_STORE, true>(a, N, c.tile, ws, st);
+    }
     constexpr int KS = 2;
     // tokens x (features of W1 + the same features of W3) per block, chosen like the unpaired tiles
     const TileForm tf = choose_tile(N, P, true);
@@ -763,6 +891,15 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
         GemmArgs as = {x, nullptr, wq, q_out, q_out, P, N, K, ldx, ldq, ldq, pos0, rope, head_size, n_scale > 0 ? n_scale : 1,
                        wk, wv, kcache, vcache, nq, nkv, ldkv, kv_head_stride, 0, 0};
         return gemm_launch_sk<G_QKV, false>(as, N, sk, ws, st);
+    }
+    {
+        const KgsChoice c = choose_kgs(N, P, K, false, ws);
+        const int feat_k = c.tile == TILE_128x128 ? 128 : 64;  // a tile must not straddle q | k | v
+        if (c.use && nq % feat_k == 0 && nkv % feat_k == 0) {
+            GemmArgs ak = {x, nullptr, wq, q_out, q_out, P, N, K, ldx, ldq, ldq, pos0, rope, head_size, n_scale > 0 ? n_scale : 1,
+                           wk, wv, kcache, vcache, nq, nkv, ldkv, kv_head_stride, 0, 0};
+            return gemm_launch_kgs<G_QKV, false>(ak, N, c.tile, ws, st);
+        }
     }
     TileForm tf = choose_tile(N, P, false);
     // 128 x 64 tiles mean q alone already gives every CU its one resident block: three such launches
@@ -830,6 +967,10 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
             case G_SWIGLU: return gemm_launch_sk<G_SWIGLU, false>(a, N, sk, ws, st);
         }
         return hipErrorInvalidValue;
+    }
+    if (epi == G_RESID) {  // wo, W2: the two-block form where the grid is short of blocks (same bits)
+        const KgsChoice c = choose_kgs(N, P, K, false, ws);
+        if (c.use) return gemm_launch_kgs<G_RESID, false>(a, N, c.tile, ws, st);
     }
     switch (epi) {
         case G_STORE: return gemm_launch<G_STORE>(a, st);

@@ -43,6 +43,7 @@ Tunables read_env()
     env_int("L2Z_PF_ATTN", &t.pf_attn);
     env_int("L2Z_PF_FUSE", &t.pf_fuse);
     env_int("L2Z_PF_SPLITK", &t.pf_splitk);
+    env_int("L2Z_PF_KGS", &t.pf_kgs);
     env_int("L2Z_PF_DMA", &t.pf_dma);
     env_int("L2Z_PF_ORDER", &t.pf_order);
     if (t.row_blocks < 1) t.row_blocks = 1;
@@ -95,7 +96,7 @@ bool tunables_set(const char *name, long long v)
         {"L2Z_PF_SKINNY_FORM", &t.pf_skinny_form}, {"L2Z_PF_TILE", &t.pf_tile},
         {"L2Z_PF_SKINNY_MAX", &t.pf_skinny_max}, {"L2Z_PF_SKINNY_TMS", &t.pf_skinny_tms},
         {"L2Z_PF_ATTN", &t.pf_attn}, {"L2Z_PF_FUSE", &t.pf_fuse}, {"L2Z_PF_DMA", &t.pf_dma}, {"L2Z_PF_ORDER", &t.pf_order},
-        {"L2Z_PF_SPLITK", &t.pf_splitk}};
+        {"L2Z_PF_SPLITK", &t.pf_splitk}, {"L2Z_PF_KGS", &t.pf_kgs}};
     for (auto &e : ints)
         if (strcmp(e.n, name) == 0) {
             *e.p = (int)v;

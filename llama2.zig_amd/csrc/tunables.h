@@ -45,6 +45,8 @@ struct Tunables {
     int pf_dma = 1;            // L2Z_PF_DMA          0: GEMM operands staged through registers instead of direct-to-LDS loads
     int pf_order = 1;          // L2Z_PF_ORDER        0: 2-D grids for the tile GEMM (x = feature tile, y = token tile)
     int pf_fuse = 1;           // L2Z_PF_FUSE         0: separate Q / K / V and W1 / W3 GEMMs
+    int pf_kgs = -1;           // L2Z_PF_KGS          the tile GEMM's two k-groups on two blocks (same bits, twice the blocks): -1 by grid fill,
+                               //                     0 never, 10 + f: always, on tile form f (0 128x64, 1 64x64, 2 32x64, 4 128x128)
     int pf_splitk = -1;        // L2Z_PF_SPLITK       K ranges per output tile of the tile GEMM for chunks of <= 256 tokens: -1 by shape,
                                //                     1 none, 2 / 4 forced (changes rounding: the range partials are added in range order)
 };
