@@ -764,26 +764,18 @@ static KgsChoice choose_kgs(int N, int P, int K, bool pair, const SplitKWs *ws)
         if (f < 0 || f > 4 || f == TILE_32x32 || (pair && f == TILE_128x128)) return none;
         return {true, (TileForm)f};
     }
-    const long long cus = g_cus_hint();
-    const double handoff = 7e-6 * (157.3e12 / 256.0) / (2.0 * K);  // in "outputs per block" like the areas below
-    // the best unsplit form, as choose_tile sees it
+    // Measured (7B shape, whole prefill, interleaved; profiles/r03_prefill_kgs_ab.txt): the form pays where the
+    // unsplit family runs ONE 8-wave block of a 128-token tile per CU -- two independent 4-wave blocks of half
+    // the LDS hide each other's stage barriers: 512 tokens 58.56 -> 57.32 ms on 128 x 64 tiles -- and loses or
+    // ties wherever smaller tiles already put several blocks on a CU (100 ... 300 tokens: -2 ... +4 %; the
+    // 110M shape: +10 %).  A cost model of the choose_tile kind picked it for q | k | v and W1 | W3 at 256
+    // tokens and lost 5 %: so the rule is the measured one -- chunks of >= 512 tokens, on the 128-token tile the
+    // unsplit family takes.
+    (void)form;
+    if (P < 512) return none;
     const TileForm tu = choose_tile(N, P, pair);
-    const long long bu = (long long)((N + form[tu].feat - 1) / form[tu].feat) * ((P + form[tu].tok - 1) / form[tu].tok);
-    const double cost_u = (double)((bu + cus - 1) / cus) * (form[tu].tok * form[tu].feat) / form[tu].eff;
-    int best = -1;
-    double best_cost = cost_u;
-    for (int f = 0; f < 5; f++) {
-        if (f == TILE_32x32 || (pair && f == TILE_128x128)) continue;
-        if (form[f].tok > 64 && P <= 64) continue;
-        const long long blocks = 2LL * ((N + form[f].feat - 1) / form[f].feat) * ((P + form[f].tok - 1) / form[f].tok);
-        const double cost = (double)((blocks + cus - 1) / cus) * (form[f].tok * form[f].feat) / 2.0 / form[f].eff + handoff;
-        if (cost < best_cost * 0.97) {  // it has to pay clearly: the hand-off is the uncertain part of the model
-            best = f;
-            best_cost = cost;
-        }
-    }
-    if (best < 0) return none;
-    return {true, (TileForm)best};
+    if (tu != TILE_128x64 && tu != TILE_128x128) return none;
+    return {true, tu};
 }
 
 // unpaired products with a residual epilogue, the fused q | k | v launch (TN = 1 forms) and the paired W1 | W3 product

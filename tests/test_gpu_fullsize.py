@@ -374,6 +374,12 @@ def test_stories110M_prefill_paths_vs_oracle(gpu, ck, orc, options):
         options(L2Z_PF_TILE=tile)
         assert np.array_equal(check(300, f"forced {name}"), base[300]), f"tile form {name} changed the bits"
     options(L2Z_PF_TILE=0)
+    # the two k-groups of a stage on two blocks (csrc/prefill_gemm.hip SPLIT == 2): kg0 + kg1 is the sum the
+    # one-block forms form in LDS, so every tile of this form must give the SAME bits as well
+    for f, name in ((10, "128x64"), (11, "64x64"), (12, "32x64"), (14, "128x128")):
+        options(L2Z_PF_KGS=f)
+        assert np.array_equal(check(300, f"two-block form {name}"), base[300]), f"two-block form on {name} changed the bits"
+    options(L2Z_PF_KGS=-1)
     # the split-K family (K cut into 2 / 4 ranges per output tile, the last arriver adds the range partials in
     # order): this shape's matrices are cache resident, so it is forced here; another rounding, same tolerance
     for sk in (2, 4):
