@@ -9,5 +9,5 @@ rm -rf /tmp/prof_sp$world
 rocprofv3 --kernel-trace --stats -d /tmp/prof_sp$world -o p -- python $repo/scripts/sharded_prefill_emu.py llama2-7b 512 $world > /tmp/prof_sp$world.log 2>&1 || tail -5 /tmp/prof_sp$world.log
 tail -3 /tmp/prof_sp$world.log
 db=$(find /tmp/prof_sp$world -name "*.db" | head -1)
-python $repo/scripts/rocprof_summary.py $db "round 2 ($tag): rocprofv3 --kernel-trace --stats -- python scripts/sharded_prefill_emu.py llama2-7b 512 $world  (4 unsharded prefills, then 4 prefills of $world emulated ranks)" > $O/${tag}_sharded_prefill_w${world}_kernel_stats.md
+python $repo/scripts/rocprof_summary.py $db "($tag): rocprofv3 --kernel-trace --stats -- python scripts/sharded_prefill_emu.py llama2-7b 512 $world  (4 unsharded prefills, then 4 prefills of $world emulated ranks)" > $O/${tag}_sharded_prefill_w${world}_kernel_stats.md
 head -30 $O/${tag}_sharded_prefill_w${world}_kernel_stats.md
