@@ -99,6 +99,11 @@ int l2z_prefill_attention(int form, float *out, const float *q, const float *kca
  * 2: 32x64, 3: 32x32, 4: 128x128 (all forms give the same bits; the choice fills the CUs). */
 int l2z_prefill_plan(int n_tokens, int *chunks, int cap);
 int l2z_prefill_tile(int n_features, int n_tokens, int paired);
+/* K ranges per output tile of the tile GEMM's split-K family for an [n_tokens, k] x [n_features_whole, k]^T
+ * product (1: the unsplit family; > 1 also means the tile kernel instead of the short-prompt kernels).  Part of
+ * the arithmetic -- the range partials are added in range order -- hence a function of the chunk length and the
+ * WHOLE model's matrix, never of a rank's share of its rows. */
+int l2z_prefill_split_k(long long n_features_whole, int n_tokens, int k, int paired);
 
 /* ---- emulated ranks ---- */
 /* Testing support: N emulated ranks in ONE process on ONE GPU (RCCL refuses two ranks on

@@ -116,6 +116,8 @@ def lib():
     L.l2z_prefill_attention.argtypes = [C.c_int, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.l2z_prefill_plan.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int]
     L.l2z_prefill_tile.argtypes = [C.c_int, C.c_int, C.c_int]
+    if hasattr(L, "l2z_prefill_split_k"):
+        L.l2z_prefill_split_k.argtypes = [C.c_longlong, C.c_int, C.c_int, C.c_int]
     L.l2z_emu_prefill.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int32), C.c_int, C.c_int]
     L.l2z_shard_range.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64),
                                   C.POINTER(C.c_int64)]
@@ -363,6 +365,14 @@ def prefill_tile(n_features: int, n_tokens: int, paired: bool = False) -> str:
     if t < 0:
         raise L2ZError(t, lib().l2z_last_error().decode(errors="replace"))
     return TILE_FORMS[t]
+
+
+def prefill_split_k(n_features_whole: int, n_tokens: int, k: int, paired: bool = False) -> int:
+    """K ranges per output tile the tile GEMM takes for this product (host logic; 1 = the unsplit family)."""
+    r = lib().l2z_prefill_split_k(n_features_whole, n_tokens, k, 1 if paired else 0)
+    if r < 0:
+        raise L2ZError(r, lib().l2z_last_error().decode(errors="replace"))
+    return r
 
 
 def emu_prefill(states, weights, tokens, pos0: int) -> None:

@@ -263,6 +263,12 @@ extern "C" int l2z_prefill_plan(int n_tokens, int *chunks, int cap)
     return n;
 }
 
+extern "C" int l2z_prefill_split_k(long long n_features_whole, int n_tokens, int k, int paired)
+{
+    L2Z_CHECK(n_features_whole > 0 && n_tokens > 0 && k > 0, L2Z_ERR_INVALID, "l2z_prefill_split_k: bad arguments");
+    return prefill_split_k(n_features_whole, n_tokens, k, paired != 0);
+}
+
 extern "C" int l2z_prefill_tile(int n_features, int n_tokens, int paired)
 {
     L2Z_CHECK(n_features > 0 && n_tokens > 0, L2Z_ERR_INVALID, "l2z_prefill_tile: bad arguments");

@@ -80,3 +80,14 @@ def test_prefill_planning_is_pinned(B):
             (768, 256, False): "32x32", (512, 512, False): "32x32"}   # stories110M; a 7B row shard of 8 ranks
     for (n, p, pair), form in want.items():
         assert B.prefill_tile(n, p, pair) == form, (n, p, pair)
+    # the split-K family (K ranges per output tile; the partials are added in range order, so this is part of
+    # the arithmetic and a function of the WHOLE model's matrix): matrices that stream from HBM take 4 ranges at
+    # 49-64 tokens, the block-starved ones (wo, W2: N = 4096) 2 at 65-128; nothing else, and never a matrix
+    # that stays in the on-die caches
+    sk = {(4096, 64, 4096): 4, (4096, 49, 4096): 4, (4096, 48, 4096): 1, (12288, 60, 4096): 4, (11008, 64, 4096): 4,
+          (4096, 100, 4096): 2, (4096, 128, 11008): 2, (12288, 128, 4096): 1, (11008, 128, 4096): 1,
+          (4096, 129, 4096): 1, (4096, 256, 4096): 1, (4096, 512, 4096): 1,
+          (768, 64, 768): 1, (2048, 100, 768): 1,          # stories110M: cache resident
+          (4096, 64, 4160): 1}                             # K not a multiple of 64 x ranges: fewer ranges
+    for (n, p, k), want_sk in sk.items():
+        assert B.prefill_split_k(n, p, k) == want_sk, (n, p, k)
