@@ -34,7 +34,7 @@ constexpr int kFusedUB = 4;  // timesteps per lane group: seq_len <= 4 G (K and 
 constexpr int kFusedWaves = kFusedBlock / kWave;
 constexpr int kRowU = 6;  // float4 per row per lane: LPR * 6 >= n/4 (fused_small_supported)
 
-template <int LPR, bool LATEV>
+template <int LPR>
 __global__ __launch_bounds__(kFusedBlock) void fused_qkv_attn_kernel(const FusedQkvAttnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -146,7 +146,15 @@ __global__ __launch_bounds__(kFusedBlock) void fused_qkv_attn_kernel(const Fused
 
     // ---- phase 2: the head's q, k, v rows (main.zig:308-320) + RoPE (:336-351) + cache write (:354-358)
     const v4f *xs4 = (const v4f *)xs;
-    auto consume_unit = [&]() {  // the unit whose rows are in wa / wb
+    // Most waves own one unit (stories15M: 18 units, 16 waves); a wave's later units are issued only
+    // after the previous one is consumed -- prefetching them would need a second set of 48 row
+    // registers, which a 1024-thread block does not have.
+    for (; u < n_units; u += kFusedWaves) {
+        if (u != wave) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue_unit(u);
+            cs = seg < 2 ? a.rope[(size_t)pos * (size_t)half + (size_t)(valid ? lp : 0)] : make_float2(1.0f, 0.0f);
+        }
         v4f acc_a = zero, acc_b = zero;
 #pragma unroll
         for (int k = 0; k < kRowU; k++) {
@@ -169,38 +177,17 @@ __global__ __launch_bounds__(kFusedBlock) void fused_qkv_attn_kernel(const Fused
             dst[2 * lp] = o0;
             dst[2 * lp + 1] = o1;
         }
-    };
-    // Most waves own one unit (stories15M: 18 units, 16 waves); a wave cannot hold two units' rows at once (a
-    // second set of 48 row registers: a 1024-thread block does not have them), so a second unit's rows are
-    // requested only after the first is consumed -- one more dependent round trip.  Round 3: when all q and k
-    // units fit the first pass (the units beyond are V rows, which nothing needs before the weighted sum), the
-    // second pass is requested BEFORE the scores and consumed after the softmax: its round trip runs under
-    // them instead of in front of them (stories15M: 8.2 -> ~7 us per launch).
-    constexpr bool late_v = LATEV;  // launcher: kFusedWaves < n_units <= 2 kFusedWaves and 2 ups <= kFusedWaves
-    if (!late_v) {
-        for (; u < n_units; u += kFusedWaves) {
-            if (u != wave) {
-                __builtin_amdgcn_sched_barrier(0);
-                issue_unit(u);
-                cs = seg < 2 ? a.rope[(size_t)pos * (size_t)half + (size_t)(valid ? lp : 0)] : make_float2(1.0f, 0.0f);
-            }
-            consume_unit();
-        }
-    } else if (u < n_units) {
-        consume_unit();
     }
+    __syncthreads();
+
     // ---- phase 3: attention of head h (main.zig:361-389); row `pos` comes from this launch
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's direct-to-LDS rows have landed
-    __syncthreads();  // q and k of this token (late_v: and the first-pass V rows) are in cur[]
-    const bool second = late_v && wave + kFusedWaves < n_units;  // wave-uniform
-    if (second) {  // a V unit: in flight during the scores and the softmax
-        issue_unit(wave + kFusedWaves);
-        cs = make_float2(1.0f, 0.0f);
-        __builtin_amdgcn_sched_barrier(0);  // the requests go out here, not next to their use
-    }
     v4f kr[UB], vr[UB];
 #pragma unroll
-    for (int i = 0; i < UB; i++) kr[i] = kv_lds[(size_t)i * kFusedBlock + tid];
+    for (int i = 0; i < UB; i++) {
+        kr[i] = kv_lds[(size_t)i * kFusedBlock + tid];
+        vr[i] = kv_lds[(size_t)(UB + i) * kFusedBlock + tid];
+    }
     const v4f qv = active ? ((const v4f *)cur)[cc] : zero;
     const float div = sqrtf((float)hs);
 #pragma unroll
@@ -213,12 +200,6 @@ __global__ __launch_bounds__(kFusedBlock) void fused_qkv_attn_kernel(const Fused
     }
     __syncthreads();
     wave_softmax(att, prob, T);  // :378
-    if (late_v) {
-        if (second) consume_unit();  // the V rows requested before the scores
-        __syncthreads();             // v of this token is complete in cur[]
-    }
-#pragma unroll
-    for (int i = 0; i < UB; i++) vr[i] = kv_lds[(size_t)(UB + i) * kFusedBlock + tid];
     v4f acc = zero;
 #pragma unroll
     for (int i = 0; i < UB; i++) {  // att . V (:381-388), increasing t within the group
@@ -264,21 +245,9 @@ size_t fused_lds_bytes(const FusedQkvAttnArgs &a)
 template <int LPR>
 hipError_t launch_lpr(const FusedQkvAttnArgs &a, int n_heads, size_t lds, hipStream_t st)
 {
-    // units of RW row pairs per segment (as the kernel counts them): the second pass under the scores only when
-    // it holds V units alone
-    constexpr int RW = kWave / LPR;
-    const int ups = ((a.head_size >> 1) + RW - 1) / RW, n_units = 3 * ups;
-    const bool late_v = tunables().fuse_small_late_v != 0 && n_units > kFusedWaves && n_units <= 2 * kFusedWaves &&
-                        2 * ups <= kFusedWaves;
-    if (late_v) {
-        hipError_t e = ensure_lds(fused_qkv_attn_kernel<LPR, true>, lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((fused_qkv_attn_kernel<LPR, true>), dim3(n_heads), dim3(kFusedBlock), lds, st, a);
-        return hipGetLastError();
-    }
-    hipError_t e = ensure_lds(fused_qkv_attn_kernel<LPR, false>, lds);
+    hipError_t e = ensure_lds(fused_qkv_attn_kernel<LPR>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((fused_qkv_attn_kernel<LPR, false>), dim3(n_heads), dim3(kFusedBlock), lds, st, a);
+    hipLaunchKernelGGL((fused_qkv_attn_kernel<LPR>), dim3(n_heads), dim3(kFusedBlock), lds, st, a);
     return hipGetLastError();
 }
 
