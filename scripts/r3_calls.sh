@@ -170,16 +170,16 @@ cat $O/r03_sharded_prefill_emu.txt
 bash scripts/r2_sharded_prefill_prof.sh 8 r03 > $O/r03_sp8.log 2>&1; head -16 $O/r03_sharded_prefill_w8_kernel_stats.md | cut -c1-150
 ;;
 n)
-# round 3, GPU call N: the fused qkv + attention launch of small MHA models with its second pass of row units (V rows)
-# requested before the scores and consumed after the softmax -- parity (fused tests, 15M greedy ids), interleaved A/B
+# round 3, GPU call N: the fused qkv + attention launch of small MHA models with 8 lanes x 9 float4 per row pair (all
+# of a head's 72 pairs requested in one pass) -- parity (fused tests, 15M greedy ids), interleaved A/B
 timeout 900 python -m pytest tests -m gpu -q -rA -k "fused or stories15M or greedy_token or golden or fuzz" > $O/r03n_pytest_gpu.log 2>&1
 echo "pytest rc=$?" >> $O/r03n_pytest_gpu.log
 grep -E "passed|failed|^FAILED" $O/r03n_pytest_gpu.log | tail -n 8
 {
-python scripts/ab.py stories15M 255 7 "" "L2Z_FUSE_SMALL_LATE_V=0" "L2Z_FUSE_SMALL=0"
-python scripts/kind_scan.py stories15M "" "L2Z_FUSE_SMALL_LATE_V=0"
-} > $O/r03_fused_late_v_ab.txt 2>&1
-cat $O/r03_fused_late_v_ab.txt
+python scripts/ab.py stories15M 255 7 "" "L2Z_FUSE_SMALL_LPR8=0" "L2Z_FUSE_SMALL=0"
+python scripts/kind_scan.py stories15M "" "L2Z_FUSE_SMALL_LPR8=0"
+} > $O/r03_fused_lpr8_ab.txt 2>&1
+cat $O/r03_fused_lpr8_ab.txt
 ;;
 *) echo "usage: r3_calls.sh a|b|c|d|e|g|h|i|j|k|l|m|n"; exit 2;;
 esac
