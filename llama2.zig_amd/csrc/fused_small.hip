@@ -33,16 +33,10 @@ constexpr int kFusedBlock = 1024;
 constexpr int kFusedUB = 4;  // timesteps per lane group: seq_len <= 4 G (K and V rows of all of them sit in LDS)
 constexpr int kFusedWaves = kFusedBlock / kWave;
 constexpr int kRowU = 6;  // float4 per row per lane: LPR * 6 >= n/4 (fused_small_supported)
-// Round 3: 8 lanes x 9 float4 per row where the row fits (n/4 <= 72: the stories15M shape).  With 16 lanes per
-// pair a wave holds 4 pairs, 16 waves 64, and the head's 72 pairs need a SECOND, dependent pass on two waves;
-// with 8 lanes a wave holds 8 pairs and all 72 are requested at once (9 waves busy, 18 loads of 16 B per lane in
-// flight instead of 12).
-constexpr int kRowU8 = 9;
 
-template <int LPR, int RU = kRowU>
+template <int LPR>
 __global__ __launch_bounds__(kFusedBlock) void fused_qkv_attn_kernel(const FusedQkvAttnArgs a)
 {
-    constexpr int kRowU = RU;  // float4 per row per lane (shadows the default)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hs = a.head_size, n = a.n, n4 = n >> 2;
@@ -231,12 +225,8 @@ __global__ __launch_bounds__(kFusedBlock) void fused_qkv_attn_kernel(const Fused
     }
 }
 
-// 8 lanes x 9 float4 per row (see kRowU8); L2Z_FUSE_SMALL_LPR8=0 keeps the 16-lane form
-bool fused_lpr8(int n4) { return n4 <= 8 * kRowU8 && tunables().fuse_small_lpr8 != 0; }
-
 int fused_lpr(int n4)
 {
-    if (fused_lpr8(n4)) return 8;
     int l = 8;
     while (l < 64 && l * kRowU < n4) l <<= 1;
     return l;
@@ -244,8 +234,8 @@ int fused_lpr(int n4)
 
 size_t fused_lds_bytes(const FusedQkvAttnArgs &a)
 {
-    const int n4 = a.n >> 2, lpr = fused_lpr(n4), ru = fused_lpr8(n4) ? kRowU8 : kRowU;
-    const int n4_pad = ((n4 + lpr * ru - 1) / (lpr * ru)) * (lpr * ru);
+    const int n4 = a.n >> 2, lpr = fused_lpr(n4);
+    const int n4_pad = ((n4 + lpr * kRowU - 1) / (lpr * kRowU)) * (lpr * kRowU);
     const AttnGeom ge = attn_geom(a.head_size, true, kFusedBlock);
     return (size_t)(4 * n4_pad + kScratch + ((3 * a.head_size + 3) & ~3) + 2 * ((a.seq_len + 3) & ~3) +
                     ge.G * a.head_size) * sizeof(float) +
@@ -271,7 +261,7 @@ bool fused_qkv_attn_supported(int dim, int n_heads, int n_kv_heads, int seq_len,
     if (n_heads != n_kv_heads || dim % n_heads != 0 || dim % 4 != 0) return false;
     const int hs = dim / n_heads, n4 = dim >> 2;
     if (hs % 4 != 0 || hs > 256 || (hs & 1)) return false;
-    if (n4 > kFusedBlock || (!fused_lpr8(n4) && fused_lpr(n4) * kRowU < n4)) return false;
+    if (n4 > kFusedBlock || fused_lpr(n4) * kRowU < n4) return false;
     const AttnGeom ge = attn_geom(hs, true, kFusedBlock);
     if (ge.G * kFusedUB < seq_len) return false;
     if ((size_t)3 * hs * dim * sizeof(float) > ((size_t)256 << 10)) return false;
@@ -288,12 +278,6 @@ hipError_t launch_fused_qkv_attn(const FusedQkvAttnArgs &a, int n_heads, hipStre
         return hipErrorInvalidValue;
     const int lpr = fused_lpr(a.n >> 2);
     const size_t lds = fused_lds_bytes(a);
-    if (fused_lpr8(a.n >> 2)) {
-        hipError_t e = ensure_lds(fused_qkv_attn_kernel<8, kRowU8>, lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((fused_qkv_attn_kernel<8, kRowU8>), dim3(n_heads), dim3(kFusedBlock), lds, st, a);
-        return hipGetLastError();
-    }
     switch (lpr) {
         case 8: return launch_lpr<8>(a, n_heads, lds, st);
         case 16: return launch_lpr<16>(a, n_heads, lds, st);

@@ -22,7 +22,6 @@ struct Tunables {
     int attn_split_pos = -1;   // L2Z_ATTN_SPLIT_POS  first position that uses the split form (default 256)
     int attn_short_pos = -1;   // L2Z_ATTN_SHORT_POS  positions below this take the 256-thread one-block-per-head kernel with the
                                //                     speculative first round whatever seq_len is (default: by head size, 0: never)
-    int fuse_small_lpr8 = 1;   // L2Z_FUSE_SMALL_LPR8  0: the fused launch keeps 16 lanes per row pair for rows of <= 288 floats
     int fuse_small = 1;        // L2Z_FUSE_SMALL      0: small models keep separate qkv / attention launches
     // --- graphs / transport (runstate.cpp, comm.cpp, forward.cpp) ---
     int no_graph = 0;          // L2Z_NO_GRAPH        1: launch eagerly

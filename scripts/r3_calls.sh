@@ -171,7 +171,8 @@ bash scripts/r2_sharded_prefill_prof.sh 8 r03 > $O/r03_sp8.log 2>&1; head -16 $O
 ;;
 n)
 # round 3, GPU call N: the fused qkv + attention launch of small MHA models with 8 lanes x 9 float4 per row pair (all
-# of a head's 72 pairs requested in one pass) -- parity (fused tests, 15M greedy ids), interleaved A/B
+# of a head's 72 pairs requested in one pass; measured slower and reverted, like the late-V form before it: git log)
+# -- parity (fused tests, 15M greedy ids), interleaved A/B
 timeout 900 python -m pytest tests -m gpu -q -rA -k "fused or stories15M or greedy_token or golden or fuzz" > $O/r03n_pytest_gpu.log 2>&1
 echo "pytest rc=$?" >> $O/r03n_pytest_gpu.log
 grep -E "passed|failed|^FAILED" $O/r03n_pytest_gpu.log | tail -n 8
