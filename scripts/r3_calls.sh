@@ -182,5 +182,17 @@ python scripts/kind_scan.py stories15M "" "L2Z_FUSE_SMALL_LPR8=0"
 } > $O/r03_fused_lpr8_ab.txt 2>&1
 cat $O/r03_fused_lpr8_ab.txt
 ;;
-*) echo "usage: r3_calls.sh a|b|c|d|e|g|h|i|j|k|l|m|n"; exit 2;;
+o)
+# round 3, GPU call O: the narrow-row mat-vec's grid -- resident blocks per CU assumed (L2Z_MV_OCC) instead of the
+# occupancy query's answer (rocprofv3 shows 500 blocks for the 15M classifier's 4000 units: two units per wave).
+# Needs the L2Z_MV_OCC knob of commit-time only (git log: measured, more blocks are slower, knob removed again).
+{
+python scripts/kind_scan.py stories15M "" "L2Z_MV_OCC=4" "L2Z_MV_OCC=8"
+python scripts/kind_scan.py stories110M "" "L2Z_MV_OCC=4" "L2Z_MV_OCC=8"
+python scripts/ab.py stories15M 255 5 "" "L2Z_MV_OCC=4" "L2Z_MV_OCC=8"
+python scripts/ab.py stories110M 255 5 "" "L2Z_MV_OCC=4" "L2Z_MV_OCC=8"
+} > $O/r03_mv_occ_ab.txt 2>&1
+cat $O/r03_mv_occ_ab.txt
+;;
+*) echo "usage: r3_calls.sh a|b|c|d|e|g|h|i|j|k|l|m|n|o"; exit 2;;
 esac
