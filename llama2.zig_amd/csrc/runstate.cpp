@@ -81,9 +81,11 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
     alloc((void **)&s->d_part_idx, (size_t)matvec_max_grid(g_cus) * 4);
     {   // Attention form by position.  One block per head is fastest while the
         // context is short; from pos 256 on, the split form (nch blocks per head + combine)
-        // wins and keeps winning (2.4x at pos 2047 on the 7B shape).  The host knows pos, so it
-        // replays one of two captured graphs.  Tunables attn_split: 0 = never, n = n chunks at every
-        // position (tests); attn_split_pos moves the switch-over.
+        // wins and keeps winning (2.4x at pos 2047 on the 7B shape); below it the one-block form runs
+        // with 256 threads and a speculative first round while the context is short (attn_short_pos),
+        // with 1024 threads beyond.  The host knows pos, so it replays the graph captured for the
+        // position's variant (forward.cpp attn_variant).  Tunables attn_split: 0 = never, n = n chunks
+        // at every position (tests); attn_split_pos / attn_short_pos move the switch-overs.
         const int mode = tn.attn_split;
         // The chunk count is part of the arithmetic (the combine rounds per chunk), so it is taken
         // from the model's TOTAL head count, not this rank's share: sharded and unsharded runs then
