@@ -167,6 +167,10 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
 
 int prefill_begin_chunk(l2z_runstate *s, const l2z_weights *w, const int32_t *tokens, int P)
 {
+    // the split forms' arrival counters and flags are left at zero by every launch that completes; a pass that was
+    // cut short (a peer-write wait that timed out, a failed launch) must not leave a later one a half-counted tile
+    if (s->pf_sk.cnt)
+        L2Z_HIP(hipMemsetAsync(s->pf_sk.cnt, 0, (size_t)s->pf_sk.cnt_ints * sizeof(int), s->stream));
     L2Z_HIP(hipMemcpyAsync(s->pf_tokens, tokens, (size_t)P * 4, hipMemcpyHostToDevice, s->stream));
     L2Z_HIP(launch_prefill_embed(s->pf_x, w->tok_emb, s->pf_tokens, s->cfg.dim, P, s->stream));  // :295
     return L2Z_OK;
