@@ -525,12 +525,24 @@ size_t attention_split_part_floats(int n_heads_local, int head_size, int nch)
     return (size_t)n_heads_local * nch * (size_t)(head_size + 4);
 }
 
+// Positions from which the split form runs 1024 threads per block; below, 256.  With 8 chunks per head (7B,
+// profiles/r03_attn_split_scan.txt, us per layer back to back): pos 256 10.0 vs 12.4, pos 511 11.1 vs 13.2, pos 1023
+// 14.9 vs 15.0, pos 2047 21.8 vs 19.9 -- a chunk of <= 128 timesteps is four rounds of a 256-thread block's rows and
+// a quarter of the waves to launch and to combine.  A function of the model and the position only.
+int attention_split_wide_pos(int seq_len)
+{
+    const int forced = tunables().attn_split_wide_pos;
+    if (forced >= 0) return forced;
+    return seq_len > 512 ? 1024 : seq_len;  // small contexts: 256 threads throughout (as before)
+}
+
+// small: 256 threads per block (the position is below attention_split_wide_pos)
 hipError_t launch_attention_split(const AttnArgs &a_in, int n_heads_local, int nch, float *part,
-                                  int *arrivals, hipStream_t st)
+                                  int *arrivals, hipStream_t st, bool small)
 {
     const AttnArgs &a = a_in;
     const int forced = tunables().attn_block;
-    const int nt = forced ? forced : (a.seq_len > 512 ? kAttnFastBlock : kBlock);
+    const int nt = forced ? forced : (small ? kBlock : kAttnFastBlock);
     const AttnGeom ge = attn_geom(a.head_size, true, nt);
     const int max_local = (a.seq_len + nch - 1) / nch;
     const size_t lds = (size_t)(2 * ((max_local + 3) & ~3) + ge.G * a.head_size) * sizeof(float);

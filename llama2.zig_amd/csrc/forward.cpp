@@ -59,7 +59,7 @@ int check_pair(const l2z_config *config, const l2z_runstate *s, const l2z_weight
 int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof *prof,
                     int only_stage, int variant, int only_kind)
 {
-    const bool split = variant == ATTN_SPLIT;
+    const bool split = variant == ATTN_SPLIT || variant == ATTN_SPLIT_S;
     const l2z_config &c = s->cfg;
     const Shard &sh = s->sh;
     hipStream_t st = s->stream;
@@ -160,7 +160,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             }
             if (split && s->attn_nch > 1 && attention_split_supported(a))
                 L2Z_LAUNCH(KIND_ATTN, launch_attention_split(a, sh.heads_loc, s->attn_nch,
-                                                             s->d_attn_part, s->d_attn_cnt, st));
+                                                             s->d_attn_part, s->d_attn_cnt, st, variant == ATTN_SPLIT_S));
             else
                 L2Z_LAUNCH(KIND_ATTN, launch_attention(a, sh.heads_loc, st, variant == ATTN_SHORT ? 1 : 0));
         }
@@ -227,7 +227,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
 
 int attn_variant(const l2z_runstate *s, int pos)
 {
-    if (s->attn_nch > 1 && pos >= s->attn_split_pos) return ATTN_SPLIT;
+    if (s->attn_nch > 1 && pos >= s->attn_split_pos) return pos < s->attn_split_wide_pos ? ATTN_SPLIT_S : ATTN_SPLIT;
     return pos < s->attn_short_pos ? ATTN_SHORT : ATTN_HEAD;
 }
 
@@ -258,27 +258,37 @@ void drop_graphs(l2z_runstate *s)
     s->graph_w_uid = 0;
 }
 
-int ensure_graphs(l2z_runstate *s, const l2z_weights *w)
+// the captured graph of one attention variant (with or without the loop hand-over); a model only ever pays for the
+// variants its positions take (attn_variant)
+int ensure_graph(l2z_runstate *s, const l2z_weights *w, int variant, bool with_step)
 {
     if (!s->use_graphs) return L2Z_OK;
-    if (s->graph_w_uid == w->uid && s->g_forward[ATTN_HEAD] && s->g_step[ATTN_HEAD]) return L2Z_OK;
-    drop_graphs(s);
     int rc = L2Z_OK;
-    for (int v = 0; v < ATTN_VARIANTS && rc == L2Z_OK; v++) {
-        // only the variants some position of this model takes (attn_variant)
-        if ((v == ATTN_SHORT && s->attn_short_pos <= 0) || (v == ATTN_SPLIT && s->attn_nch <= 1)) continue;
-        rc = build_graph(s, w, false, v, &s->g_forward[v]);
-        if (rc == L2Z_OK) rc = build_graph(s, w, true, v, &s->g_step[v]);
+    if (s->graph_w_uid != w->uid) {
+        // first use with these weights: capture every variant some position of this model takes, now -- not in
+        // the middle of a generation loop (the positions either side of every switch-over name them all)
+        drop_graphs(s);
+        s->graph_w_uid = w->uid;
+        const int edges[] = {0, s->attn_short_pos, s->attn_split_pos, s->attn_split_wide_pos, s->cfg.seq_len};
+        bool reach[ATTN_VARIANTS] = {};
+        for (int e : edges)
+            for (int p = e - 1; p <= e; p++)
+                if (p >= 0 && p < s->cfg.seq_len) reach[attn_variant(s, p)] = true;
+        for (int v = 0; v < ATTN_VARIANTS && rc == L2Z_OK; v++) {
+            if (!reach[v]) continue;
+            rc = build_graph(s, w, false, v, &s->g_forward[v]);
+            if (rc == L2Z_OK) rc = build_graph(s, w, true, v, &s->g_step[v]);
+        }
     }
-    if (rc != L2Z_OK) {
+    hipGraphExec_t *slot = with_step ? &s->g_step[variant] : &s->g_forward[variant];
+    if (rc == L2Z_OK && *slot) return L2Z_OK;
+    if (rc != L2Z_OK || build_graph(s, w, with_step, variant, slot) != L2Z_OK) {
         // capture is an optimisation, not a requirement: run the same launches eagerly
         fprintf(stderr, "llama2_hip: hipGraph capture failed (%s); launching eagerly\n", l2z_last_error());
         drop_graphs(s);
         s->use_graphs = false;
         (void)hipGetLastError();
-        return L2Z_OK;
     }
-    s->graph_w_uid = w->uid;
     return L2Z_OK;
 }
 
@@ -290,7 +300,7 @@ int run_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, int pos)
               "sharded runstate without a transport: connect the group (RCCL id or "
               "l2z_comm_p2p_export/_connect), or drive emulated ranks with l2z_emu_transformer");
     L2Z_TRY(comm_check(s->comm));
-    L2Z_TRY(ensure_graphs(s, w));
+    L2Z_TRY(ensure_graph(s, w, variant, with_step));
     if (s->use_graphs) {
         L2Z_HIP(hipGraphLaunch(with_step ? s->g_step[variant] : s->g_forward[variant], s->stream));
         return L2Z_OK;

@@ -227,8 +227,9 @@ extern "C" int l2z_attention_decode(int form, int nch, float *out, const float *
         e = hipMalloc(&dcnt, (size_t)n_heads * sizeof(int));
         if (e == hipSuccess) e = hipMemset(dcnt, 0, (size_t)n_heads * sizeof(int));
         // twice: the second launch finds the counters as the first one left them
-        if (e == hipSuccess) e = launch_attention_split(a, n_heads, use_nch, dpart.p, dcnt, nullptr);
-        if (e == hipSuccess) e = launch_attention_split(a, n_heads, use_nch, dpart.p, dcnt, nullptr);
+        const bool small = pos < attention_split_wide_pos(seq_len);  // as the forward pass picks at this position
+        if (e == hipSuccess) e = launch_attention_split(a, n_heads, use_nch, dpart.p, dcnt, nullptr, small);
+        if (e == hipSuccess) e = launch_attention_split(a, n_heads, use_nch, dpart.p, dcnt, nullptr, small);
     } else if (e == hipSuccess) {
         // form 0: what the forward pass launches at this position (attn_variant: the short-context form first)
         const int auto_form = pos < attention_short_pos(head_size, seq_len) ? 1 : 0;

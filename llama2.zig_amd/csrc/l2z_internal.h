@@ -183,8 +183,10 @@ int attention_split_chunks(int n_heads_local, int n_cus);
 size_t attention_split_part_floats(int n_heads_local, int head_size, int nch);
 bool attention_split_supported(const AttnArgs &a);
 // arrivals: one int per local head, zero before the first launch (the kernel leaves them at zero)
+// small: 256 threads per block instead of 1024 (positions below attention_split_wide_pos)
 hipError_t launch_attention_split(const AttnArgs &a, int n_heads_local, int nch, float *part,
-                                  int *arrivals, hipStream_t st);
+                                  int *arrivals, hipStream_t st, bool small = false);
+int attention_split_wide_pos(int seq_len);
 hipError_t launch_argmax(const ArgmaxArgs &a, hipStream_t st);
 hipError_t launch_set_state(int token, int pos, int *token_ptr, int *pos_ptr, const float *tok_emb,
                             float *x, int dim, hipStream_t st);

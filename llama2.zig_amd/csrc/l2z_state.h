@@ -93,10 +93,11 @@ struct l2z_runstate {
     int attn_nch = 0;             // 0: one block per head at every position
     int attn_split_pos = 0;       // positions >= this use the split form (host picks the graph)
     int attn_short_pos = 0;       // positions < this use the 256-thread speculative one-block-per-head form
+    int attn_split_wide_pos = 0;  // split form: 256 threads per block below this position, 1024 from it on
     // graphs, keyed by the uid of the weights they were captured with (a freed object's address
     // is commonly handed to the next one)
     uint64_t graph_w_uid = 0;
-    hipGraphExec_t g_forward[3] = {nullptr, nullptr, nullptr}, g_step[3] = {nullptr, nullptr, nullptr};  // [attention variant]
+    hipGraphExec_t g_forward[4] = {nullptr, nullptr, nullptr, nullptr}, g_step[4] = {nullptr, nullptr, nullptr, nullptr};  // [attention variant]
     bool use_graphs = true;
     int host_pos = 0;   // next position the greedy loop will run
     bool done = false;  // greedy loop saw BOS
@@ -117,8 +118,9 @@ namespace l2z {
 struct Prof;
 int check_pair(const l2z_config *config, const l2z_runstate *s, const l2z_weights *w);
 // attention variant of a position (the host knows pos and replays the graph captured for its variant):
-// 0 short context (256-thread speculative form), 1 one block per head as the shape picks, 2 split
-enum { ATTN_SHORT = 0, ATTN_HEAD = 1, ATTN_SPLIT = 2, ATTN_VARIANTS = 3 };
+// 0 short context (256-thread speculative form), 1 one block per head as the shape picks, 2 split with 256
+// threads per block, 3 split with 1024
+enum { ATTN_SHORT = 0, ATTN_HEAD = 1, ATTN_SPLIT_S = 2, ATTN_SPLIT = 3, ATTN_VARIANTS = 4 };
 int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof *prof, int only_stage,
                     int variant, int only_kind = -1);
 int attn_variant(const l2z_runstate *s, int pos);

@@ -39,7 +39,7 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
     s->use_graphs = tn.no_graph == 0;
     // Peer-write gathers are plain kernels (or no launch at all): captured with the rest of the
     // step.  RCCL collectives are captured too (stream capture of ncclAllGather; if the capture
-    // fails the step is launched eagerly, ensure_graphs); L2Z_COMM_GRAPH=0 keeps them eager.
+    // fails the step is launched eagerly, ensure_graph); L2Z_COMM_GRAPH=0 keeps them eager.
     // Emulated ranks are driven stage by stage, never captured.
     if (comm && comm->world > 1 && !comm->nccl && !comm->p2p) s->use_graphs = false;
     if (comm && comm->nccl && !comm_uses_p2p(comm) && tn.comm_graph == 0) s->use_graphs = false;
@@ -95,6 +95,7 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
         s->attn_split_pos = mode > 0 ? 0 : 256;
         if (tn.attn_split_pos >= 0) s->attn_split_pos = tn.attn_split_pos;
         if (mode == 0 || c.seq_len <= s->attn_split_pos) nch = 0;
+        s->attn_split_wide_pos = attention_split_wide_pos(c.seq_len);
         s->attn_short_pos = attention_short_pos(sh.hs, c.seq_len);
         if (nch > 1 && s->attn_short_pos > s->attn_split_pos) s->attn_short_pos = s->attn_split_pos;
         if (nch > 1) {

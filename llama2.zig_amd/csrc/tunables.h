@@ -20,6 +20,7 @@ struct Tunables {
     int attn_split = -1;       // L2Z_ATTN_SPLIT      0: never split; n > 0: n chunks at every position
                                //                     (changes rounding: chunk count is part of the arithmetic)
     int attn_split_pos = -1;   // L2Z_ATTN_SPLIT_POS  first position that uses the split form (default 256)
+    int attn_split_wide_pos = -1;  // L2Z_ATTN_SPLIT_WIDE_POS  first position at which the split form runs 1024 threads per block (256 below; default 1024)
     int attn_short_pos = -1;   // L2Z_ATTN_SHORT_POS  positions below this take the 256-thread one-block-per-head kernel with the
                                //                     speculative first round whatever seq_len is (default: by head size, 0: never)
     int fuse_small = 1;        // L2Z_FUSE_SMALL      0: small models keep separate qkv / attention launches

@@ -29,7 +29,7 @@ for v in variants:
     s.greedy_begin([]); s.greedy_run(w, 2); s.transformer(1, 0, w); s.synchronize()
     states.append(s)
     for k in kv:  # back to the default for the next variant (options apply at RunState creation)
-        B.option_set(k, {"L2Z_ATTN_SPLIT": -1, "L2Z_ATTN_SPLIT_POS": -1, "L2Z_ATTN_SHORT_POS": -1, "L2Z_ROW_TAIL_SKIP": 1, "L2Z_ROW_BLOCKS": 2, "L2Z_ATTN_BLOCK": 0,
+        B.option_set(k, {"L2Z_ATTN_SPLIT": -1, "L2Z_ATTN_SPLIT_POS": -1, "L2Z_ATTN_SHORT_POS": -1, "L2Z_ATTN_SPLIT_WIDE_POS": -1, "L2Z_ROW_TAIL_SKIP": 1, "L2Z_ROW_BLOCKS": 2, "L2Z_ATTN_BLOCK": 0,
                          "L2Z_FUSE_SMALL": 1, "L2Z_NO_GRAPH": 0, "L2Z_ROW_KERNEL": 1,
                          "L2Z_MAX_BLOCKS_PER_CU": 8}.get(k, 0))
 res = [[] for _ in variants]

@@ -194,5 +194,21 @@ python scripts/ab.py stories110M 255 5 "" "L2Z_MV_OCC=4" "L2Z_MV_OCC=8"
 } > $O/r03_mv_occ_ab.txt 2>&1
 cat $O/r03_mv_occ_ab.txt
 ;;
-*) echo "usage: r3_calls.sh a|b|c|d|e|g|h|i|j|k|l|m|n|o"; exit 2;;
+p)
+# round 3, GPU call P: split attention with 256 threads per block below pos 1024 (profiles/r03_attn_split_scan.txt) --
+# parity (attention kernels, split tests, 110M across the switch-overs, 7B sharded positions), interleaved A/B
+timeout 900 python -m pytest tests -m gpu -q -rA -k "attention or split or across or 7b_sharded or fuzz_longctx or random_shapes" > $O/r03p_pytest_gpu.log 2>&1
+echo "pytest rc=$?" >> $O/r03p_pytest_gpu.log
+grep -E "passed|failed|^FAILED" $O/r03p_pytest_gpu.log | tail -n 8
+{
+python scripts/ab.py llama2-7b 64 3 300 "" "L2Z_ATTN_SPLIT_WIDE_POS=0"
+python scripts/ab.py llama2-7b 64 3 700 "" "L2Z_ATTN_SPLIT_WIDE_POS=0"
+python scripts/ab.py llama2-7b 32 3 1960 "" "L2Z_ATTN_SPLIT_WIDE_POS=0"
+python scripts/ab.py stories110M 255 3 300 "" "L2Z_ATTN_SPLIT_WIDE_POS=0"
+python scripts/attn_time_scan.py llama2-7b 255 256 511 1023 1024 2047
+timeout 300 python scripts/fuzz_longctx.py 6 43 | tail -n 3
+} > $O/r03_attn_split_nt_ab.txt 2>&1
+cat $O/r03_attn_split_nt_ab.txt
+;;
+*) echo "usage: r3_calls.sh a|b|c|d|e|g|h|i|j|k|l|m|n|o|p"; exit 2;;
 esac

@@ -176,7 +176,7 @@ ATTN_CASES = [
     ("stories110M", "fast256", 0, (300,)),
     ("stories110M", "split", 0, (256, 1023)),
     ("llama2-7b", "fast1024", 0, (0, 100, 255)),
-    ("llama2-7b", "split", 0, (0, 3, 300, 2047)),
+    ("llama2-7b", "split", 0, (0, 3, 300, 1023, 1024, 2047)),   # 256 threads per block below pos 1024, 1024 from there
     ("llama2-7b", "split", 16, (2047,)),
     ("gqa", "fast256", 0, (0, 63)),
     ("gqa", "split", 2, (0, 1, 63)),
@@ -248,8 +248,9 @@ def test_attention_auto_picks_the_documented_form(gpu):
     """form 'auto' is what enqueue_forward launches at a position (csrc/forward.cpp attn_variant): 256
     threads per head with the speculative first round while the context is short -- every position of a
     seq_len <= 512 model, pos < 256 at head sizes <= 64, pos < 128 at head size 128 (attention_short_pos)
-    -- then 1024 threads per head, and the split form from pos 256 on; bit-identical to the same form
-    asked for by name."""
+    -- then 1024 threads per head, and the split form from pos 256 on (256 threads per block below pos 1024,
+    1024 from there: the hook's 'split' takes the block size of the position too); bit-identical to the same
+    form asked for by name."""
     rng = np.random.default_rng(5)
     for shape, pos, want, nch in (("stories15M", 200, "fast256", 0), ("stories110M", 200, "fast256", 0),
                                   ("llama2-7b", 100, "fast256", 0), ("llama2-7b", 200, "fast1024", 0),
