@@ -512,10 +512,13 @@ int attention_short_pos(int head_size, int seq_len)
     return two_rounds < 256 ? two_rounds : 256;
 }
 
+// Chunks per head of the split form: one block per CU, at most 8.  More chunks than that shorten nothing -- the
+// launch is a latency chain (partials, counter, combine), not a stream: stories110M (12 heads), us per layer at
+// pos 256 / 1023: 16 chunks 9.3 / 9.8, 8 chunks 8.3 / 9.0, 4 chunks 8.0 / 11.8 (profiles/r03_attn_split_scan_110M.txt).
 int attention_split_chunks(int n_heads_local, int n_cus)
 {
     int nch = n_cus / (n_heads_local > 0 ? n_heads_local : 1);
-    if (nch > 16) nch = 16;
+    if (nch > 8) nch = 8;
     if (nch < 1) nch = 1;
     return nch;
 }
