@@ -232,7 +232,7 @@ hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float 
 hipError_t launch_prefill_gemm_kv_pair(const float *x, int ldx, const float *wk, const float *wv, float *kcache,
                                        float *vcache, int ldkv, int P, int nkv, int K, int pos0, const float2 *rope,
                                        int head_size, hipStream_t st, int n_scale = 1, size_t kv_head_stride = 0,
-                                       int sk = 1, const SplitKWs *ws = nullptr);
+                                       int sk = 1);
 hipError_t launch_prefill_rmsnorm(float *o, const float *x, const float *w, int n, int P,
                                   hipStream_t st);
 hipError_t launch_prefill_embed(float *x, const float *tok_emb, const int *tokens, int dim, int P,

@@ -77,9 +77,8 @@ __device__ __forceinline__ void lds_dma16_nt(const float *g, float *lds)
 }
 
 // prefill_skinny.hip: the short-prompt (P <= 64 tokens) GEMM forms; picks the form and the token tiling
-// ws: the split-K workspace (partials, arrival counters) -- the K-sliced form for matrices that stream needs it
-hipError_t launch_prefill_skinny(int epi, const GemmArgs &a, hipStream_t st, const SplitKWs *ws);
-hipError_t launch_prefill_skinny_pair(int epi, const GemmArgs &a, hipStream_t st, const SplitKWs *ws);  // G_SWIGLU: w | w2 gated; G_QKV: wk | wv
+hipError_t launch_prefill_skinny(int epi, const GemmArgs &a, hipStream_t st);
+hipError_t launch_prefill_skinny_pair(int epi, const GemmArgs &a, hipStream_t st);  // G_SWIGLU: w | w2 gated; G_QKV: wk | wv
 
 
 }  // namespace l2z

@@ -839,7 +839,7 @@ hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float 
     if (((uintptr_t)x & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w3 & 15)) return hipErrorInvalidValue;
     GemmArgs a = {x, w3, w1, out, out, P, N, K, ldx, ldo, ldo, 0, nullptr, 0, n_scale > 0 ? n_scale : 1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
     const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
-    if (P <= skinny_max && sk <= 1) return launch_prefill_skinny_pair(G_SWIGLU, a, st, ws);  // prefill_skinny.hip (or not supported)
+    if (P <= skinny_max && sk <= 1) return launch_prefill_skinny_pair(G_SWIGLU, a, st);  // prefill_skinny.hip (or not supported)
     if (K % 64 != 0 || ldx % 4 != 0) return hipErrorNotSupported;
     if (sk > 1) return gemm_launch_sk<G_STORE, true>(a, N, sk, ws, st);
     {
@@ -926,15 +926,14 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
 // brought into the CU once for both).  hipErrorNotSupported otherwise: the caller launches the two.
 hipError_t launch_prefill_gemm_kv_pair(const float *x, int ldx, const float *wk, const float *wv, float *kcache,
                                        float *vcache, int ldkv, int P, int nkv, int K, int pos0, const float2 *rope,
-                                       int head_size, hipStream_t st, int n_scale, size_t kv_head_stride, int sk,
-                                       const SplitKWs *ws)
+                                       int head_size, hipStream_t st, int n_scale, size_t kv_head_stride, int sk)
 {
     const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
     if (P > skinny_max || sk > 1) return hipErrorNotSupported;  // sk > 1: the tile kernel's split-K family takes it
     if (((uintptr_t)x & 15) || ((uintptr_t)wk & 15) || ((uintptr_t)wv & 15)) return hipErrorInvalidValue;
     GemmArgs a = {x, wv, wk, kcache, kcache, P, nkv, K, ldx, ldkv, ldkv, pos0, rope, head_size, n_scale > 0 ? n_scale : 1,
                   wk, wv, kcache, vcache, 0, nkv, ldkv, kv_head_stride, 0, 0};
-    return launch_prefill_skinny_pair(G_QKV, a, st, ws);
+    return launch_prefill_skinny_pair(G_QKV, a, st);
 }
 
 // C[P,N] (+)= X[P,K] W[N,K]^T with the chosen epilogue; K % 4 == 0, 16-byte aligned rows
@@ -948,7 +947,7 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
     if (res == nullptr) { res = out; ldres = ldo; }  // PG_RESID in place
     GemmArgs a = {x, nullptr, w, out, res, P, N, K, ldx, ldo, ldres, pos0, rope, head_size, n_scale > 0 ? n_scale : 1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, kv_head_stride, 0, 0};
     const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
-    if (P <= skinny_max && sk <= 1) return launch_prefill_skinny(epi, a, st, ws);  // prefill_skinny.hip
+    if (P <= skinny_max && sk <= 1) return launch_prefill_skinny(epi, a, st);  // prefill_skinny.hip
     if (sk > 1) {
         if (K % (64 * sk) != 0) return hipErrorInvalidValue;
         switch (epi) {

@@ -124,7 +124,7 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
             L2Z_HIP(launch_prefill_gemm(PG_ROPE, s->pf_xn, dim, wq, s->pf_q, sh.dim_loc, P, sh.dim_loc, dim, pos0,
                                         s->rope, hs, st, nullptr, 0, sh.world, 0, sk_qkv, ws));  // :308-351
             const hipError_t ke = launch_prefill_gemm_kv_pair(s->pf_xn, dim, wk, wv, kc, vc, kvd, P, kvd, dim, pos0,
-                                                              s->rope, hs, st, sh.world, kvh_stride, sk_qkv, ws);  // short prompts: k | v together
+                                                              s->rope, hs, st, sh.world, kvh_stride, sk_qkv);  // short prompts: k | v together
             if (ke == hipErrorNotSupported) {
                 L2Z_HIP(launch_prefill_gemm(PG_ROPE_CACHE, s->pf_xn, dim, wk, kc, kvd, P, kvd, dim, pos0, s->rope, hs,
                                             st, nullptr, 0, sh.world, kvh_stride, sk_qkv, ws));   // :354-357

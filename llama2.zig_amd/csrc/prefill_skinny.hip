@@ -341,326 +341,6 @@ __global__ __launch_bounds__(kPfBlock) void prefill_skinny_dma(const GemmArgs a)
     }
 }
 
-// Short prompts, fourth form (round 3): the K-sliced "slab".  The forms above bring X into the CU again with
-// every 16 rows of W, through the same LDS ring as W, and run 4 waves per CU; measured, a wave keeps ~16 KB on
-// the wire whatever the ring's depth, so 4 waves stream W at 4.4-5.2 TB/s.  Here a block is 8 waves and owns a
-// SLICE of K (NST stages of 256 k): its slice of X sits in REGISTERS as MFMA operands for the whole launch
-// (16 TMS tokens x 256 NST k = 8 TMS NST VGPRs per lane), so LDS holds nothing but a ring of W stages and W is
-// all the CU takes in.  The block walks feature groups of 16 rows (of each of NW matrices) through the ring,
-// which never drains between groups; per group the 8 waves' sums (each wave multiplies its 32-k eighth of
-// every stage) are added through LDS in wave order.  With one slice (K <= 256 NST) that sum goes through the
-// epilogue at once.  With S slices it leaves as the slice's partial, write-through; a block that has finished
-// its groups drains its stores once and bumps each group's arrival counter, and whoever arrives last at a group
-// adds the S partials IN SLICE ORDER and runs the epilogue (the hand-off of the split-K tile family: nobody
-// waits for anybody).  Slice s visits the groups in another order than slice s' (group i nb + (b - s i) mod nb),
-// so the groups a block shares with any other block are few and the late combines are spread over the chip.
-// Arithmetic: a function of K, NST and the token tile only (slices in order, inside a slice the waves' eighths
-// in order) -- not of N, the grid or the CU count: a row shard computes what the whole matrix computes.
-constexpr int kSlabWaves = 8, kSlabBlock = 64 * kSlabWaves;
-constexpr int kSlabMaxS = 12;  // slices the combine keeps in flight
-
-static int slab_cus()
-{
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-            cus = n;
-        else
-            return 256;
-    }
-    return cus;
-}
-
-// epilogue of one output (pair): lane = the MFMA lane (feature n0 + (lane & 15)), every lane of the wave calls
-template <int EPI, int NW>
-__device__ __forceinline__ void slab_finish(const GemmArgs &a, float v, float v2, int tok, int f)
-{
-    if (EPI == G_ROPE || EPI == G_ROPE_CACHE || EPI == G_QKV) {
-        const float partner = __shfl_xor(v, 1, 64);  // feature f ^ 1, same token (main.zig:346-349)
-        const int hs = a.head_size;
-        const int pos = a.pos0 + (tok < a.P ? tok : 0);
-        const float2 cs = a.rope[(size_t)pos * (size_t)(hs >> 1) + (size_t)(((f < a.N ? f : 0) % hs) >> 1)];
-        v = (f & 1) ? partner * cs.y + v * cs.x : v * cs.x - partner * cs.y;
-    }
-    if (tok < a.P && f < a.N) {
-        if (NW == 2 && EPI == G_SWIGLU) a.out[(size_t)tok * a.ldo + f] = swiglu_merge(v, v2);  // :411-416
-        else if (NW == 2) {  // wk | wv: key-cache row (RoPE above), value-cache row
-            a.outk[kv_index(a, a.ldkv, a.pos0 + tok, f)] = v;
-            a.outv[kv_index(a, a.ldkv, a.pos0 + tok, f)] = v2;
-        }
-        else if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + f] = v;
-        else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + f] = a.res[(size_t)tok * a.ldres + f] + v;
-        else if (EPI == G_SWIGLU) a.out[(size_t)tok * a.ldo + f] = swiglu_merge(a.out[(size_t)tok * a.ldo + f], v);
-        else a.out[kv_index(a, a.ldo, a.pos0 + tok, f)] = v;
-    }
-}
-
-constexpr int slab_ring(int NW, int TMS) { return NW == 1 ? 8 : TMS == 2 ? 3 : 4; }  // stage buffers: <= 160 KB with the sums
-
-template <int EPI, int TMS, int NW, int NST>
-__global__ __launch_bounds__(kSlabBlock) void prefill_slab(const GemmArgs a, int nb, int G)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int SW = slab_ring(NW, TMS);
-    constexpr int WST = 16 * kSkLD2, ST = NW * WST;  // floats per matrix and per stage
-    constexpr int LPS = 2 * NW;                      // this wave's loads per stage: rows 2 w, 2 w + 1 of each matrix
-    constexpr int NV = NW * TMS;                     // 16 x 16 output tiles per group
-    static_assert((SW - 2) * LPS <= 63, "vmcnt is a 6-bit counter");
-    float *ring = smem;
-    float *red = smem + SW * ST;                     // [8 waves][NV][4][64]
-    int *last_of = (int *)(red + kSlabWaves * NV * 256);  // [units of this block]: 1 = this block combines the group
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 15, q = lane >> 4;
-    const int b = blockIdx.x, s = blockIdx.y, S = gridDim.y;
-    const int st0 = s * NST;
-    const int nst = min(NST, a.K / kSkBK - st0);     // stages of this slice (the last slice may be short)
-    const v4f zero = {0.f, 0.f, 0.f, 0.f};
-    const bool stamp = (a.sk & 64) && EPI == G_ROPE && tid == 0 && (int)blockIdx.x == a.ntx && blockIdx.y == 0;
-    unsigned *ts = (unsigned *)(a.sk_part + 22000000);
-    int nts = 0;
-#define SLAB_STAMP() do { if (stamp) ts[nts++] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
-    SLAB_STAMP();
-
-    // this block's slice of X: lane (j, q) of wave w keeps, per stage and u, the float4 it feeds to MFMA (u, c)
-    v4f xa[NST][2][TMS];
-#pragma unroll
-    for (int st = 0; st < NST; st++)
-#pragma unroll
-        for (int u = 0; u < 2; u++)
-#pragma unroll
-            for (int tm = 0; tm < TMS; tm++)
-                xa[st][u][tm] = (st < nst && !(a.sk & 4)) ? *(const v4f *)(a.x + (size_t)min(16 * tm + j, a.P - 1) * a.ldx +
-                                                          (size_t)(st0 + st) * kSkBK + 32 * wave + 16 * u + 4 * q)
-                                         : zero;
-
-    // group of unit i: row i of the [U x nb] arrangement of the G groups, column (b - s i) mod nb
-    const int U = (G + nb - 1) / nb;
-    auto group_of = [&](int i) {
-        int c = (b - s * i) % nb;
-        if (c < 0) c += nb;
-        return i * nb + c;
-    };
-    const int n_units = U > 0 && group_of(U - 1) >= G ? U - 1 : U;  // only the last row can be ragged
-    const int total = n_units * nst;
-
-    const float *wsrc[NW][2];
-    auto set_unit = [&](int i) {
-        const int n0 = 16 * group_of(i);
-#pragma unroll
-        for (int ii = 0; ii < 2; ii++) {
-            const size_t off = (size_t)min(n0 + 2 * wave + ii, a.N - 1) * a.K + (size_t)st0 * kSkBK + 4 * lane;
-            wsrc[0][ii] = a.w + off;
-            if (NW == 2) wsrc[NW - 1][ii] = a.w2 + off;
-        }
-    };
-    int iss_i = 0, iss_st = 0, nbuf = 0, issued = 0;
-    auto issue_one = [&]() {
-        float *ws = ring + nbuf * ST;
-#pragma unroll
-        for (int m = 0; m < NW; m++)
-#pragma unroll
-            for (int ii = 0; ii < 2; ii++)
-                if (a.sk & 16) lds_dma16(wsrc[m][ii] + (size_t)iss_st * kSkBK, ws + m * WST + (2 * wave + ii) * kSkLD2);
-                else lds_dma16_nt(wsrc[m][ii] + (size_t)iss_st * kSkBK, ws + m * WST + (2 * wave + ii) * kSkLD2);
-        nbuf = nbuf + 1 == SW ? 0 : nbuf + 1;
-        issued++;
-        if (++iss_st == nst) {
-            iss_st = 0;
-            if (++iss_i < n_units) set_unit(iss_i);
-        }
-    };
-    if (n_units > 0) set_unit(0);
-    for (int p = 0; p < SW - 1 && issued < total; p++) issue_one();
-
-    float *part = a.sk_part + (size_t)s * G * (NV * 256);  // this slice's partials: [G][NV][256]
-    int buf = 0, done = 0;
-    for (int i = 0; i < n_units; i++) {
-        v4f acc[NW][TMS];
-#pragma unroll
-        for (int m = 0; m < NW; m++)
-#pragma unroll
-            for (int tm = 0; tm < TMS; tm++) acc[m][tm] = zero;
-#pragma unroll
-        for (int st = 0; st < NST; st++) {
-            if (st < nst) {
-                // the oldest stage in flight has landed (this wave's rows); the stores of earlier groups share
-                // the counter and can only make this wait longer, never shorter (loads retire in issue order)
-                const int younger = issued - done - 1;
-                if (SW > 7 && younger >= 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * LPS) : "memory");
-                else if (SW > 6 && younger == 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * LPS) : "memory");
-                else if (SW > 5 && younger == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPS) : "memory");
-                else if (SW > 4 && younger == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS) : "memory");
-                else if (SW > 3 && younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-                else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                SLAB_STAMP();
-                if (!(a.sk & 32)) __builtin_amdgcn_s_barrier();  // every wave's rows are in LDS; the stage before has been multiplied
-                SLAB_STAMP();
-                const float *wr = ring + buf * ST + j * kSkLD2 + 32 * wave + 4 * q;
-                if (!(a.sk & 8))
-#pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    v4f bw[NW];
-#pragma unroll
-                    for (int m = 0; m < NW; m++) bw[m] = *(const v4f *)(wr + m * WST + 16 * u);
-#pragma unroll
-                    for (int m = 0; m < NW; m++)
-#pragma unroll
-                        for (int c = 0; c < 4; c++)
-#pragma unroll
-                            for (int tm = 0; tm < TMS; tm++)
-                                acc[m][tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[st][u][tm][c], bw[m][c], acc[m][tm], 0, 0, 0);
-                }
-                // after the multiply: a wave whose loads queue behind a full memory pipe stalls AT the issue, and what
-                // stands behind it in program order would not overlap the stream (measured: 1,600 cycles per 2 loads)
-                if (issued < total) issue_one();
-                buf = buf + 1 == SW ? 0 : buf + 1;
-                done++;
-                SLAB_STAMP();
-            }
-        }
-        if (a.sk & 2) continue;
-        // the group's sums over this slice: the 8 waves' eighths in wave order
-#pragma unroll
-        for (int m = 0; m < NW; m++)
-#pragma unroll
-            for (int tm = 0; tm < TMS; tm++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) red[((wave * NV + m * TMS + tm) * 4 + r) * 64 + lane] = acc[m][tm][r];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // bare: the ring's loads stay in flight
-        asm volatile("" ::: "memory");
-        const int g = group_of(i), t = tid & 255;
-        for (int tm = tid >> 8; tm < TMS; tm += 2) {  // wave-uniform
-            float v = red[tm * 256 + t], v2 = 0.0f;
-#pragma unroll
-            for (int w = 1; w < kSlabWaves; w++) v += red[(w * NV + tm) * 256 + t];
-            if (NW == 2) {
-                v2 = red[(TMS + tm) * 256 + t];
-#pragma unroll
-                for (int w = 1; w < kSlabWaves; w++) v2 += red[(w * NV + TMS + tm) * 256 + t];
-            }
-            if (S == 1) {
-                slab_finish<EPI, NW>(a, v, v2, 16 * tm + 4 * (lane >> 4) + (t >> 6), 16 * g + (lane & 15));
-            } else {  // out as the slice's partial, write-through
-                float *pg = part + (size_t)g * (NV * 256) + t;
-                __hip_atomic_store(pg + tm * 256, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (NW == 2) __hip_atomic_store(pg + (TMS + tm) * 256, v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        // red is written again after the next group's stage barriers
-        SLAB_STAMP();
-    }
-    if (stamp) ts[255] = nts;
-    if (S == 1 || (a.sk & 1)) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its partials
-    __syncthreads();
-    if (tid < n_units) {
-        int *cnt = a.sk_cnt + group_of(tid);
-        const int prev = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = prev == S - 1;
-        if (last) {
-            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this CU's stale lines of the partials
-        }
-        last_of[tid] = last;
-    }
-    __syncthreads();
-    // the groups this block arrived last at, one per wave at a time: all S partials of a token tile are requested
-    // at once (one round trip), then added in slice order
-    const size_t slice = (size_t)G * (NV * 256);
-    for (int i = wave; i < n_units; i += kSlabWaves) {
-        if (!last_of[i]) continue;  // wave-uniform
-        const int g = group_of(i), n0 = 16 * g;
-        const float *p0 = a.sk_part + (size_t)g * (NV * 256) + lane;
-#pragma unroll
-        for (int tm = 0; tm < TMS; tm++) {
-            float p[NW][4][kSlabMaxS];
-#pragma unroll
-            for (int z = 0; z < kSlabMaxS; z++)
-#pragma unroll
-                for (int m = 0; m < NW; m++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        p[m][r][z] = z < S ? p0[(size_t)z * slice + (m * TMS + tm) * 256 + r * 64] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float v = p[0][r][0], v2 = NW == 2 ? p[NW - 1][r][0] : 0.0f;  // slice 0, then 1, ... in order
-#pragma unroll
-                for (int z = 1; z < kSlabMaxS; z++)
-                    if (z < S) {
-                        v += p[0][r][z];
-                        if (NW == 2) v2 += p[NW - 1][r][z];
-                    }
-                slab_finish<EPI, NW>(a, v, v2, 16 * tm + 4 * (lane >> 4) + r, n0 + (lane & 15));
-            }
-        }
-    }
-}
-
-// stages of 256 k per slice for a chunk of P tokens and rows of K floats: one slice (no hand-off) where the
-// slice of X fits the registers, else the fewest equal-ish slices.  A function of K and P only.
-int slab_nst(int P, int K)
-{
-    const int forced = tunables().pf_slab_nst;
-    const int nst_all = K / kSkBK;
-    const int cap = P <= 16 ? 16 : 8;
-    if (forced == 4 || forced == 8 || forced == 16) return forced <= cap ? forced : cap;
-    return nst_all <= cap ? cap : nst_all <= 2 * cap ? cap : cap;
-}
-
-// Does the slab form take this product?  A function of the WHOLE matrix, K and the chunk length only.
-bool slab_takes(const GemmArgs &a, const SplitKWs *ws)
-{
-    const Tunables &tn = tunables();
-    if (tn.pf_slab == 0 || tn.pf_dma == 0 || tn.pf_skinny_form != 1) return false;
-    if (a.P > 32 || a.K % kSkBK != 0 || a.K / kSkBK < 8 || a.ldx % 4 != 0) return false;
-    const int S = (a.K / kSkBK + slab_nst(a.P, a.K) - 1) / slab_nst(a.P, a.K);
-    if (S > kSlabMaxS) return false;
-    if (S > 1 && (ws == nullptr || ws->part == nullptr || ws->cnt == nullptr)) return false;
-    const bool streams = (size_t)a.N * (size_t)a.n_scale * (size_t)a.K * sizeof(float) > ((size_t)16 << 20);
-    return streams || tn.pf_slab == 2;  // 2: forced (tests on small shapes)
-}
-
-template <int EPI, int TMS, int NW, int NST>
-hipError_t slab_launch_n(const GemmArgs &a, const SplitKWs *ws, hipStream_t st)
-{
-    constexpr int SW = slab_ring(NW, TMS), NV = NW * TMS;
-    const int G = (a.N + 15) / 16, S = (a.K / kSkBK + NST - 1) / NST;
-    int nb = slab_cus() / S;
-    if (nb < 1) nb = 1;
-    if (nb > G) nb = G;
-    const int U = (G + nb - 1) / nb;
-    if (U > kSlabBlock) return hipErrorOutOfMemory;
-    if (S > 1 && (ws == nullptr || (size_t)S * G * NV * 256 > ws->part_floats || G > ws->cnt_ints)) return hipErrorOutOfMemory;
-    const size_t lds = ((size_t)SW * NW * 16 * kSkLD2 + (size_t)kSlabWaves * NV * 256) * sizeof(float) + (size_t)U * sizeof(int);
-    const void *fn = (const void *)prefill_slab<EPI, TMS, NW, NST>;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    GemmArgs args = a;
-    args.sk_part = ws ? ws->part : nullptr; args.sk_cnt = ws ? ws->cnt : nullptr;
-    args.sk = tunables().pf_slab_dbg & 255;
-    args.ntx = tunables().pf_slab_dbg >> 8;  // stamped block
-    int nb_arg = nb, g_arg = G;
-    void *params[] = {&args, &nb_arg, &g_arg};
-    return hipLaunchKernel(fn, dim3(nb, S), dim3(kSlabBlock), params, lds, st);
-}
-
-template <int EPI, int NW>
-hipError_t slab_launch(const GemmArgs &a, const SplitKWs *ws, hipStream_t st)
-{
-    const int nst = slab_nst(a.P, a.K);
-    if (a.P <= 16) {
-        if (nst == 16) return slab_launch_n<EPI, 1, NW, 16>(a, ws, st);
-        if (nst == 8) return slab_launch_n<EPI, 1, NW, 8>(a, ws, st);
-        return slab_launch_n<EPI, 1, NW, 4>(a, ws, st);
-    }
-    if (nst == 8) return slab_launch_n<EPI, 2, NW, 8>(a, ws, st);
-    return slab_launch_n<EPI, 2, NW, 4>(a, ws, st);
-}
-
 template <int EPI, int TMS>
 hipError_t skinny_launch_t(const GemmArgs &a, hipStream_t st)
 {
@@ -713,9 +393,8 @@ bool skinny_one_tile(const GemmArgs &a)
 }
 
 template <int EPI>
-hipError_t skinny_launch(const GemmArgs &a, hipStream_t st, const SplitKWs *ws)
+hipError_t skinny_launch(const GemmArgs &a, hipStream_t st)
 {
-    if (slab_takes(a, ws)) return slab_launch<EPI, 1>(a, ws, st);
     // Token tiles per block (TMS x 16 tokens).  A matrix that stays in the on-die caches is cheapest
     // re-read per 16 tokens (more blocks, more waves per CU) -- the WHOLE matrix counts: a row shard takes
     // what the unsharded pass takes.  One that streams from HBM: one or two token tiles per block, and
@@ -733,14 +412,9 @@ hipError_t skinny_launch(const GemmArgs &a, hipStream_t st, const SplitKWs *ws)
 // a.w | a.w2 in one launch of the direct-to-LDS form (epi G_SWIGLU: out = silu(X w^T) * (X w2^T);
 // G_QKV: RoPE(X w^T) into a.outk's rows pos0 + token, X w2^T into a.outv's).  hipErrorNotSupported when
 // the shape takes another short-prompt form: the caller launches the two products separately.
-hipError_t launch_prefill_skinny_pair(int epi, const GemmArgs &a, hipStream_t st, const SplitKWs *ws)
+hipError_t launch_prefill_skinny_pair(int epi, const GemmArgs &a, hipStream_t st)
 {
     if (tunables().pf_fuse == 0 || tunables().pf_skinny_form != 1 || tunables().pf_dma == 0) return hipErrorNotSupported;
-    if (slab_takes(a, ws)) {
-        if (epi == G_SWIGLU) return slab_launch<G_SWIGLU, 2>(a, ws, st);
-        if (epi == G_QKV) return slab_launch<G_QKV, 2>(a, ws, st);
-        return hipErrorInvalidValue;
-    }
     if (a.K % kSkBK != 0 || a.K / kSkBK >= 3 == false || a.ldx % 4 != 0 || !skinny_one_tile(a)) return hipErrorNotSupported;
     constexpr int SW = 3;
     const size_t lds = (size_t)SW * (32 + 16) * kSkLD2 * sizeof(float);
@@ -760,15 +434,15 @@ hipError_t launch_prefill_skinny_pair(int epi, const GemmArgs &a, hipStream_t st
     return hipLaunchKernel(fn, g1, dim3(kPfBlock), params, lds, st);
 }
 
-hipError_t launch_prefill_skinny(int epi, const GemmArgs &a, hipStream_t st, const SplitKWs *ws)
+hipError_t launch_prefill_skinny(int epi, const GemmArgs &a, hipStream_t st)
 {
     switch (epi) {
-        case G_STORE: return skinny_launch<G_STORE>(a, st, ws);
-        case G_RESID: return skinny_launch<G_RESID>(a, st, ws);
-        case G_ROPE: return skinny_launch<G_ROPE>(a, st, ws);
-        case G_ROPE_CACHE: return skinny_launch<G_ROPE_CACHE>(a, st, ws);
-        case G_CACHE: return skinny_launch<G_CACHE>(a, st, ws);
-        case G_SWIGLU: return skinny_launch<G_SWIGLU>(a, st, ws);
+        case G_STORE: return skinny_launch<G_STORE>(a, st);
+        case G_RESID: return skinny_launch<G_RESID>(a, st);
+        case G_ROPE: return skinny_launch<G_ROPE>(a, st);
+        case G_ROPE_CACHE: return skinny_launch<G_ROPE_CACHE>(a, st);
+        case G_CACHE: return skinny_launch<G_CACHE>(a, st);
+        case G_SWIGLU: return skinny_launch<G_SWIGLU>(a, st);
     }
     return hipErrorInvalidValue;
 }

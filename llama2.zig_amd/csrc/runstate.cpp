@@ -187,7 +187,6 @@ extern "C" int l2z_runstate_read(l2z_runstate *s, const char *name, size_t offse
     else if (k == "logits") { p = s->logits; n = c.vocab_size; }
     else if (k == "key_cache") { p = s->key_cache; n = kv; }
     else if (k == "value_cache") { p = s->value_cache; n = kv; }
-    else if (k == "pf_sk_part") { p = s->pf_sk.part; n = s->pf_sk.part_floats; }
     L2Z_CHECK(p != nullptr, L2Z_ERR_INVALID, "l2z_runstate_read: unknown buffer '%s'", name);
     L2Z_CHECK(offset + count <= n, L2Z_ERR_INVALID, "l2z_runstate_read: out of range");
     L2Z_HIP(hipSetDevice(s->device));

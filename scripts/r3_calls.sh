@@ -211,12 +211,10 @@ timeout 300 python scripts/fuzz_longctx.py 6 43 | tail -n 3
 cat $O/r03_attn_split_nt_ab.txt
 ;;
 q)
-# round 3, GPU call Q: the K-sliced short-prompt GEMM (prefill_slab) -- parity, then timing against the forms it replaces
-timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -m gpu -k "k_sliced or (sharded_prefill and streams) or prefill_equals" > $O/r03q_pytest.log 2>&1
-echo "pytest rc=$?" >> $O/r03q_pytest.log
-tail -n 6 $O/r03q_pytest.log
-for n in 4 16 32; do python scripts/prefill_ab.py llama2-7b $n 4 "" "L2Z_PF_SLAB=0"; done > $O/r03_prefill_slab_ab.txt 2>&1
-cat $O/r03_prefill_slab_ab.txt
+# round 3, GPU call Q (and the ones after it): the K-sliced short-prompt GEMM with X in registers (commit 93b3cc1, removed
+# again in the next one) against the short-prompt kernels, and scripts/dma_pattern_probe -- profiles/r03_dma_pattern_probe.txt
+for i in $(seq 0 22); do timeout 60 ./scripts/dma_pattern_probe $i 2>&1 | tail -n 1; done > $O/r03_dma_pattern_probe.txt
+cat $O/r03_dma_pattern_probe.txt
 ;;
 *) echo "usage: r3_calls.sh a|b|c|d|e|g|h|i|j|k|l|m|n|o|p|q"; exit 2;;
 esac

@@ -583,8 +583,8 @@ SHARDED_PREFILL = [
     # rank's [tokens, n / world] block has the bits of the unsharded pass
     ("streams-60", dict(dim=3072, hidden_dim=8192, n_layers=2, n_heads=24, n_kv_heads=8, vocab_size=2048, seq_len=128), 60),
     ("streams-110", dict(dim=3072, hidden_dim=8192, n_layers=2, n_heads=24, n_kv_heads=8, vocab_size=2048, seq_len=128), 110),
-    # the same matrices, chunks of 9 and 21 tokens: the K-sliced short-prompt form (X in registers, slices of
-    # 1024 k summed in order by whoever arrives last) -- slices are a function of K alone
+    # the same matrices, chunks of 9 and 21 tokens: the short-prompt kernels on matrices that stream (one and two
+    # token tiles per block by the chunk length alone, W1 | W3 and wk | wv paired)
     ("streams-30", dict(dim=3072, hidden_dim=8192, n_layers=2, n_heads=24, n_kv_heads=8, vocab_size=2048, seq_len=128), 30),
 ]
 
@@ -823,49 +823,6 @@ def test_prefill_equals_token_by_token(gpu, ck, orc, name, kw, shared):
                 b = s3.read(name_, l * S * kvd, n * kvd)
                 np.testing.assert_allclose(b, a, rtol=2e-4, atol=2e-4, err_msg=f"n={n} {name_} l={l}")
     for o in (s1, s2, s3, w):
-        o.close()
-
-
-@pytest.mark.parametrize("nst", [0, 4, 8])
-def test_prefill_k_sliced_form_vs_stepped_and_oracle(gpu, ck, orc, options, nst):
-    """The K-sliced short-prompt GEMM (prefill_skinny.hip prefill_slab: chunks <= 32 tokens of matrices that
-    stream from HBM) forced onto a shape the oracle steps through in seconds: dim 2304 = 9 stages of 256 k
-    (slices of 4, 4, 1), hidden 5632 = 22 stages (5 slices of 4 and one of 2), 1 and 2 token tiles, ragged
-    token counts, pos0 > 0.  Last-position logits and the KV rows against the stepped loop and the oracle."""
-    options(L2Z_PF_SLAB=2, L2Z_PF_SLAB_NST=nst)  # nst = 0: one slice where X fits the registers (dim), else two
-    cfg = ck.Config(dim=2304, hidden_dim=5632, n_layers=2, n_heads=18, n_kv_heads=6, vocab_size=640, seq_len=48)
-    blob = ck.synth_blob(cfg, False, seed=17)
-    w = gpu.Weights(cfg, blob, False)
-    s1, s2 = gpu.RunState(cfg), gpu.RunState(cfg)
-    rng = np.random.default_rng(3)
-    toks = [1] + rng.integers(2, cfg.vocab_size, 43).tolist()
-    m = orc.Model(cfg.as_i32(), blob, False)
-    ref = {}
-    for pos, t in enumerate(toks):
-        s1.transformer(t, pos, w)
-        lg = m.transformer(t, pos)
-        if pos + 1 in (1, 7, 16, 17, 31, 32, 44):
-            ref[pos + 1] = (s1.logits().copy(), np.array(lg, copy=True))
-    kvd, S = cfg.kv_dim, cfg.seq_len
-    kv_ref = {(l, nm): s1.read(nm, l * S * kvd, len(toks) * kvd) for l in range(cfg.n_layers) for nm in ("key_cache", "value_cache")}
-    for n in (1, 7, 16, 17, 31, 32):
-        s2.prefill(toks[:n], 0, w)
-        np.testing.assert_allclose(s2.logits(), ref[n][0], rtol=LOGIT_RTOL, atol=LOGIT_ATOL, err_msg=f"n={n} vs stepped")
-        np.testing.assert_allclose(s2.logits(), ref[n][1], rtol=LOGIT_RTOL, atol=LOGIT_ATOL, err_msg=f"n={n} vs oracle")
-        for (l, nm), a in kv_ref.items():
-            np.testing.assert_allclose(s2.read(nm, l * S * kvd, n * kvd), a[:n * kvd], rtol=2e-4, atol=2e-4, err_msg=f"n={n} {nm} l={l}")
-    # 44 tokens as 32 + 12 with pos0 > 0 for the second call
-    s2.prefill(toks[:32], 0, w)
-    s2.prefill(toks[32:], 32, w)
-    np.testing.assert_allclose(s2.logits(), ref[44][1], rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
-    for (l, nm), a in kv_ref.items():
-        np.testing.assert_allclose(s2.read(nm, l * S * kvd, 44 * kvd), a, rtol=2e-4, atol=2e-4)
-    # the forms it replaces give the same numbers within the same bound, not the same bits
-    options(L2Z_PF_SLAB=0)
-    s2.prefill(toks[:16], 0, w)
-    np.testing.assert_allclose(s2.logits(), ref[16][1], rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
-    m.close()
-    for o in (s1, s2, w):
         o.close()
 
 
