@@ -242,6 +242,10 @@ def roofline_of(B, s, w, cfg, world, by_kind, n_prof, pos0, workload, n_tok, dt)
         rd_avg, rd_best = s.stream_read_probe(w, wb[dom], 12)
     except Exception:
         rd_avg = rd_best = None
+    try:  # the other same-box reference point of SURVEY.md 8d: a device-to-device copy of the same pieces
+        cp_avg, cp_best = s.d2d_copy_probe(w, wb[dom], 8)
+    except Exception:
+        cp_avg = cp_best = None
     bytes_tok = weight_bytes_per_token(cfg, world)
     whole = bytes_tok / (dt / n_tok) / 1e9 if dt > 0 and n_tok else 0.0
     roofline = {"bound": "hbm", "kernel": f"matvec[{dom}]", "achieved": achieved,
@@ -257,7 +261,11 @@ def roofline_of(B, s, w, cfg, world, by_kind, n_prof, pos0, workload, n_tok, dt)
                                       "matvec_over_probe": (achieved / rd_avg) if rd_avg else None,
                                       "note": "plain nt-load kernel over the resident weights, slices of the "
                                               "dominant launch's size; NOT a ceiling (the mat-vec's row sweep "
-                                              "beats it): a same-box reference point beside the 8 TB/s spec"}}
+                                              "beats it): a same-box reference point beside the 8 TB/s spec"},
+                "d2d_copy_probe": {"copied_avg": cp_avg, "copied_best": cp_best, "unit": "GB/s",
+                                   "traffic_avg": 2 * cp_avg if cp_avg else None,
+                                   "note": "hipMemcpyAsync device to device of pieces of the dominant launch's size: "
+                                           "bytes copied per second; the memory moves twice that (read + write)"}}
     return roofline, rd_avg
 
 

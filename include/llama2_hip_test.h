@@ -51,6 +51,10 @@ int l2z_runstate_read(l2z_runstate *s, const char *name, size_t offset, size_t c
 #define L2Z_N_KINDS 8
 int l2z_stream_read_probe(l2z_runstate *s, const l2z_weights *w, size_t slice_bytes, int reps,
                           double *avg_gbps, double *best_gbps);
+/* the same pieces copied device to device (hipMemcpyAsync) into a scratch allocation: GB/s of bytes COPIED
+ * (memory traffic is twice that), SURVEY.md 8d's "measured device-to-device copy on the same box" */
+int l2z_d2d_copy_probe(l2z_runstate *s, const l2z_weights *w, size_t slice_bytes, int reps,
+                       double *avg_gbps, double *best_gbps);
 int l2z_profile_forward(int token, int pos, const l2z_config *config, l2z_runstate *s,
                         const l2z_weights *w, double *ms_by_kind, int *launches_by_kind,
                         int n_kinds);

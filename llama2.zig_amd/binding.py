@@ -88,6 +88,8 @@ def lib():
     L.l2z_profile_forward.argtypes = [C.c_int, C.c_int, cfgp, vp, vp, C.POINTER(C.c_double), ip,
                                       C.c_int]
     L.l2z_stream_read_probe.argtypes = [vp, vp, sz, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    if hasattr(L, "l2z_d2d_copy_probe"):
+        L.l2z_d2d_copy_probe.argtypes = [vp, vp, sz, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.l2z_kind_name.argtypes = [C.c_int, C.c_char_p, sz]
     L.l2z_time_kind.argtypes = [C.c_int, C.c_int, cfgp, vp, vp, C.c_int, C.POINTER(C.c_double), ip]
     L.l2z_synchronize.argtypes = [vp]
@@ -313,6 +315,12 @@ class RunState:
         """(average, best) GB/s of a pure streaming-read kernel over the resident weight blob."""
         avg, best = C.c_double(0), C.c_double(0)
         _chk(lib().l2z_stream_read_probe(self.h, w.h, slice_bytes, reps, C.byref(avg), C.byref(best)))
+        return avg.value, best.value
+
+    def d2d_copy_probe(self, w: Weights, slice_bytes: int = 0, reps: int = 8):
+        """(average, best) GB/s of bytes copied by a device-to-device hipMemcpyAsync of pieces of the weight blob."""
+        avg, best = C.c_double(0), C.c_double(0)
+        _chk(lib().l2z_d2d_copy_probe(self.h, w.h, slice_bytes, reps, C.byref(avg), C.byref(best)))
         return avg.value, best.value
 
     def synchronize(self) -> None:

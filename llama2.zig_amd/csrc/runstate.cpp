@@ -256,6 +256,50 @@ extern "C" int l2z_stream_read_probe(l2z_runstate *s, const l2z_weights *w, size
     return L2Z_OK;
 }
 
+// The other same-box reference point SURVEY.md 8d names: a device-to-device copy (hipMemcpyAsync) of
+// `slice_bytes` pieces of the resident weight blob into a scratch allocation of that size, a different
+// piece every time.  Rate in GB/s of bytes COPIED (the memory moves twice that: read + write).
+extern "C" int l2z_d2d_copy_probe(l2z_runstate *s, const l2z_weights *w, size_t slice_bytes, int reps,
+                                  double *avg_gbps, double *best_gbps)
+{
+    L2Z_CHECK(s && w && avg_gbps && best_gbps && reps >= 1, L2Z_ERR_INVALID, "l2z_d2d_copy_probe: bad arguments");
+    L2Z_HIP(hipSetDevice(s->device));
+    const size_t blob_bytes = w->blob_floats * sizeof(float);
+    if (slice_bytes == 0 || slice_bytes > blob_bytes) slice_bytes = blob_bytes;
+    slice_bytes &= ~(size_t)4095;
+    L2Z_CHECK(slice_bytes >= (1u << 20), L2Z_ERR_INVALID, "l2z_d2d_copy_probe: blob too small");
+    const size_t n_slices = blob_bytes / slice_bytes;
+    void *dst = nullptr;
+    L2Z_HIP(hipMalloc(&dst, slice_bytes));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    double tot = 0.0, best = 1e30;
+    for (int r = 0; r < reps + 2 && e == hipSuccess; r++) {  // two untimed warm-ups
+        const float *p = w->blob + (size_t)(r % n_slices) * (slice_bytes / sizeof(float));
+        e = hipEventRecord(e0, s->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dst, p, slice_bytes, hipMemcpyDeviceToDevice, s->stream);
+        if (e == hipSuccess) e = hipEventRecord(e1, s->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess && r >= 2) {
+            tot += ms;
+            if (ms < best) best = ms;
+        }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(dst);
+    if (e != hipSuccess) {
+        set_error("l2z_d2d_copy_probe: %s", hipGetErrorString(e));
+        return L2Z_ERR_HIP;
+    }
+    *avg_gbps = (double)slice_bytes / (tot / reps * 1e-3) / 1e9;
+    *best_gbps = (double)slice_bytes / (best * 1e-3) / 1e9;
+    return L2Z_OK;
+}
+
 extern "C" int l2z_synchronize(l2z_runstate *s)
 {
     L2Z_CHECK(s != nullptr, L2Z_ERR_INVALID, "l2z_synchronize: null runstate");

@@ -28,13 +28,14 @@ def test_bench_line_has_the_contract_fields(gpu):
     assert "workload" in out["config"] and "stories110M" in out["config"]["workload"]
     r = out["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "whole_token_frac", "kernel",
-              "algorithmic_bytes_per_launch", "avg_launch_ms", "stream_read_probe"):
+              "algorithmic_bytes_per_launch", "avg_launch_ms", "stream_read_probe", "d2d_copy_probe"):
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1.0
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     assert r["traffic"] is None or "NOT read in this run" in r["traffic_source"]
     assert "NOT a ceiling" in r["stream_read_probe"]["note"]
+    assert r["d2d_copy_probe"]["copied_avg"] and r["d2d_copy_probe"]["copied_avg"] > 100.0  # GB/s copied; traffic is twice that
     c = out["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "oracle" in c["sample"]
     by_shape = out["extra"]["cpu_baseline_by_shape"]
