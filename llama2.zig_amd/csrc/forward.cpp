@@ -177,8 +177,8 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         L2Z_TRY(gather(s->x, sh.dim_loc));
         if (want() && kind(KIND_FFN13)) {   // rmsnorm (:398) + w1,w3 (:405-408) + SiLU*mul (:411-416)
             MatvecArgs a = {};
-            a.w0 = w->w1 + (size_t)l * sh.hid_loc * dim;
-            a.w1 = w->w3 + (size_t)l * sh.hid_loc * dim;
+            a.w0 = w->w1 + (size_t)l * sh.hid_loc * 2 * dim;  // W1 | W3 row-interleaved: one linear sweep
+            a.w1 = w->w3 + (size_t)l * sh.hid_loc * 2 * dim;  // = a.w0 + dim; the kernels derive it from a.w0
             a.out0 = s->hb + sh.hid0;
             a.rows0 = sh.hid_loc; a.rows1 = sh.hid_loc; a.n = c.dim;
             a.rms_w = w->rms_ffn + (size_t)l * dim;

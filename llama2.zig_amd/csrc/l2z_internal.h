@@ -93,7 +93,9 @@ struct ArgmaxArgs {
 // :395/:422, SiLU*mul :411-416) each call.  Named scalar fields on purpose:
 // arrays here get indexed dynamically by the optimiser and land in scratch.
 struct MatvecArgs {
-    const float *w0, *w1, *w2;   // unused segments: null, rows = 0
+    // unused segments: null, rows = 0.  EPI_SWIGLU: w0 is W1 | W3 ROW-INTERLEAVED (row 2p = W1 row p, row 2p + 1 =
+    // W3 row p: the device layout of the weights), rows0 = rows1 = pairs, w1 is not read
+    const float *w0, *w1, *w2;
     float *out0, *out1, *out2;
     int rows0, rows1, rows2;
     int pos_stride1, pos_stride2;  // out1/out2 += pos * stride (row select of a flat (rows, stride) buffer)
@@ -196,8 +198,11 @@ hipError_t launch_probs(float *probs, const float *logits, int n, float temperat
 hipError_t launch_dot(float *out, const float *x, const float *y, int n, hipStream_t st);
 hipError_t launch_weighted_sum_rows(float *xout, int xout_len, const float *rows, int row_stride,
                                     const float *weights, int n_weights, hipStream_t st);
+// row_len != 0: element i goes to dst[(i / row_len) * row_pitch + i % row_len] (rows of a strided matrix)
 hipError_t launch_synth_fill(float *dst, uint64_t base_idx, uint64_t count, uint64_t seed,
-                             float scale, float bias, hipStream_t st);
+                             float scale, float bias, hipStream_t st, uint64_t row_len = 0, uint64_t row_pitch = 0);
+// dst row r (dpitch floats apart) = src row r (contiguous rows of cols floats); both on the device
+hipError_t launch_copy_rows(float *dst, size_t dpitch, const float *src, size_t rows, size_t cols, hipStream_t st);
 size_t attention_lds_bytes(int head_size, int seq_len, bool vec);
 
 // ---- batched prefill (prefill_gemm.hip, prefill_skinny.hip, prefill_attention.hip) ----
@@ -221,14 +226,15 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
                                hipStream_t st, const float *res = nullptr, int ldres = 0,
                                int n_scale = 1,  // n_scale: ranks the rows are sharded over (kernel-form choices look at the whole matrix)
                                size_t kv_head_stride = 0,  // PG_*CACHE: out is a head-major cache (MatvecArgs::kv_head_stride)
-                               int sk = 1, const SplitKWs *ws = nullptr);  // sk > 1: the split-K family (prefill_split_k)
+                               int sk = 1, const SplitKWs *ws = nullptr,   // sk > 1: the split-K family (prefill_split_k)
+                               int ldw = 0);  // floats between rows of w (0: K; W1 / W3 of the device blob: 2 K)
 hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, const float *wk, const float *wv,
                                    float *q_out, int ldq, float *kcache, float *vcache, int ldkv, int P, int nq,
                                    int nkv, int K, int pos0, const float2 *rope, int head_size, hipStream_t st,
                                    size_t kv_head_stride = 0, int n_scale = 1, int sk = 1, const SplitKWs *ws = nullptr);
 hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float *w1, const float *w3,
                                            float *out, int ldo, int P, int N, int K, hipStream_t st,
-                                           int n_scale = 1, int sk = 1, const SplitKWs *ws = nullptr);
+                                           int n_scale = 1, int sk = 1, const SplitKWs *ws = nullptr, int ldw = 0);
 hipError_t launch_prefill_gemm_kv_pair(const float *x, int ldx, const float *wk, const float *wv, float *kcache,
                                        float *vcache, int ldkv, int P, int nkv, int K, int pos0, const float2 *rope,
                                        int head_size, hipStream_t st, int n_scale = 1, size_t kv_head_stride = 0,

@@ -49,12 +49,17 @@ struct l2z_weights {
     int shared;
     int device;
     l2z::Shard sh;
-    float *blob = nullptr;       // one allocation; world==1: identical to the file blob
+    // one allocation: the tensors of the file in file order (this rank's rows of each), EXCEPT that W1 and W3
+    // share one slot where W1 stood, row-interleaved -- [layer][row][W1 row | W3 row] -- so that the pair of rows
+    // a feed-forward output needs is one contiguous run; W3's own slot is empty
+    float *blob = nullptr;
     size_t blob_floats = 0;
-    bool file_layout = false;
+    bool file_layout = false;    // world == 1: every tensor of the file is resident (the unread freq_cis tables too)
+    std::vector<size_t> dev_off; // device offset (floats) of each tensor of the table; W3: that of the shared slot + cols
     // carved device pointers (local shards when world > 1)
     const float *tok_emb = nullptr, *rms_att = nullptr, *rms_ffn = nullptr, *rms_final = nullptr;
     const float *wq = nullptr, *wk = nullptr, *wv = nullptr, *wo = nullptr;
+    // w1 / w3: row 0 of W1 / of W3 in the shared slot; consecutive rows of either are 2 * dim floats apart
     const float *w1 = nullptr, *w2 = nullptr, *w3 = nullptr, *wcls = nullptr;
 };
 

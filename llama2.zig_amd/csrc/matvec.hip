@@ -104,9 +104,9 @@ __device__ __forceinline__ void pair_rows(const MvLocals &m, int p, const float 
                                           const float *&pb)
 {
     if (p >= m.n_pairs) p = m.n_pairs - 1;
-    if (EPI == EPI_SWIGLU) {
-        pa = m.w0 + (size_t)p * (size_t)m.n;
-        pb = m.w1 + (size_t)p * (size_t)m.n;
+    if (EPI == EPI_SWIGLU) {  // w0: W1 | W3 row-interleaved (MatvecArgs): the pair is one contiguous run like any other
+        pa = m.w0 + (size_t)(2 * p) * (size_t)m.n;
+        pb = pa + m.n;
     } else {
         const int ga = 2 * p;
         const int gb = (ga + 1 < m.total_rows) ? ga + 1 : ga;

@@ -132,8 +132,9 @@ __global__ __launch_bounds__(1024) void probs_kernel(float *probs, const float *
 
 // Seeded synthetic weights: value(idx) = bias + scale*r(idx,seed); must match
 // oracle/llama2_oracle.c orc_synth_value and checkpoint.py synth_values bit for bit.
+// row_len != 0: element i lands at dst[(i / row_len) * row_pitch + i % row_len] (rows of a strided matrix)
 __global__ void synth_fill_kernel(float *dst, uint64_t base_idx, uint64_t count, uint64_t seed,
-                                  float scale, float bias)
+                                  float scale, float bias, uint64_t row_len, uint64_t row_pitch)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
@@ -143,8 +144,17 @@ __global__ void synth_fill_kernel(float *dst, uint64_t base_idx, uint64_t count,
         z = z ^ (z >> 31);
         const uint32_t u = (uint32_t)(z >> 41);
         const float r = __fsub_rn(__fmul_rn((float)u, 0x1p-22f), 1.0f);
-        dst[i] = __fadd_rn(bias, __fmul_rn(scale, r));
+        const uint64_t at = row_len ? (i / row_len) * row_pitch + i % row_len : i;
+        dst[at] = __fadd_rn(bias, __fmul_rn(scale, r));
     }
+}
+
+// dst row r (dpitch floats apart) = src row r (contiguous rows of cols floats)
+__global__ void copy_rows_kernel(float *dst, size_t dpitch, const float *src, size_t rows, size_t cols)
+{
+    const size_t n = rows * cols, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        dst[(i / cols) * dpitch + i % cols] = src[i];
 }
 
 }  // namespace
@@ -193,13 +203,22 @@ hipError_t launch_softmax(float *x, int n, hipStream_t st)
 }
 
 hipError_t launch_synth_fill(float *dst, uint64_t base_idx, uint64_t count, uint64_t seed,
-                             float scale, float bias, hipStream_t st)
+                             float scale, float bias, hipStream_t st, uint64_t row_len, uint64_t row_pitch)
 {
     if (count == 0) return hipSuccess;
     uint64_t blocks = (count + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(synth_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dst, base_idx,
-                       count, seed, scale, bias);
+                       count, seed, scale, bias, row_len, row_pitch);
+    return hipGetLastError();
+}
+
+hipError_t launch_copy_rows(float *dst, size_t dpitch, const float *src, size_t rows, size_t cols, hipStream_t st)
+{
+    if (rows == 0 || cols == 0) return hipSuccess;
+    size_t blocks = (rows * cols + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dst, dpitch, src, rows, cols);
     return hipGetLastError();
 }
 

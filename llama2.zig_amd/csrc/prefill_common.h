@@ -52,6 +52,9 @@ struct GemmArgs {
     float *sk_part;
     int *sk_cnt;
     int sk;
+    // floats between consecutive rows of w (and of w2): K for a plain [N, K] matrix, 2 K for W1 / W3, whose rows
+    // alternate in one slot of the device blob.  Set by the launchers (0 is never valid).
+    int ldw;
 };
 
 

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256 * KS) void prefill_gemm(const GemmArgs a)
         } else {
             const int f = tid + NT * (p - XL), r = f / RF, c = (f % RF) * 4;
             wv[p - XL] = __builtin_nontemporal_load(
-                (const v4f *)(a.w + (size_t)min(n0 + r, a.N - 1) * a.K + min(k0 + c, a.K - 4)));
+                (const v4f *)(a.w + (size_t)min(n0 + r, a.N - 1) * a.ldw + min(k0 + c, a.K - 4)));
         }
     };
     auto sstore_piece = [&](int p, int k0) {
@@ -400,14 +400,14 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
         if (PAIR) {  // LDS row r = wave column r / 64, tile (r % 64) / 32 (0: W1, 1: W3), feature r % 32
             const float *m = ((r & 63) >> 5) ? a.w2 : a.w;
             const int f = n0 + (r >> 6) * 32 + (r & 31);
-            wsrc[j] = m + (size_t)min(f, a.N - 1) * a.K + 4 * (kslot0 + (pslot ^ swz(r)));
+            wsrc[j] = m + (size_t)min(f, a.N - 1) * a.ldw + 4 * (kslot0 + (pslot ^ swz(r)));
         } else if (EPI == G_QKV) {  // the matrix of the block's column range
             const int seg = n0 >= a.nq + a.nkv ? 2 : n0 >= a.nq ? 1 : 0;
             const float *m = seg == 0 ? a.w : seg == 1 ? a.wk : a.wv;
             const int f0 = n0 - (seg == 2 ? a.nq + a.nkv : seg == 1 ? a.nq : 0), nseg = seg == 0 ? a.nq : a.nkv;
-            wsrc[j] = m + (size_t)min(f0 + r, nseg - 1) * a.K + 4 * (kslot0 + (pslot ^ swz(r)));
+            wsrc[j] = m + (size_t)min(f0 + r, nseg - 1) * a.ldw + 4 * (kslot0 + (pslot ^ swz(r)));
         } else {
-            wsrc[j] = a.w + (size_t)min(n0 + r, a.N - 1) * a.K + 4 * (kslot0 + (pslot ^ swz(r)));
+            wsrc[j] = a.w + (size_t)min(n0 + r, a.N - 1) * a.ldw + 4 * (kslot0 + (pslot ^ swz(r)));
         }
     }
 #define L2Z_DMA_ISSUE(k0_, buf_)                                                                          \
@@ -833,11 +833,12 @@ int prefill_split_k(long long n_whole, int P, int K, bool pair)
 // hipErrorNotSupported when the shape does not take that kernel: the caller launches the two GEMMs.
 hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float *w1, const float *w3,
                                            float *out, int ldo, int P, int N, int K, hipStream_t st, int n_scale,
-                                           int sk, const SplitKWs *ws)
+                                           int sk, const SplitKWs *ws, int ldw)
 {
     if (tunables().pf_fuse == 0 || tunables().pf_dma == 0 || tunables().pf_tile != 0) return hipErrorNotSupported;
     if (((uintptr_t)x & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w3 & 15)) return hipErrorInvalidValue;
     GemmArgs a = {x, w3, w1, out, out, P, N, K, ldx, ldo, ldo, 0, nullptr, 0, n_scale > 0 ? n_scale : 1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
+    a.ldw = ldw > 0 ? ldw : K;
     const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
     if (P <= skinny_max && sk <= 1) return launch_prefill_skinny_pair(G_SWIGLU, a, st);  // prefill_skinny.hip (or not supported)
     if (K % 64 != 0 || ldx % 4 != 0) return hipErrorNotSupported;
@@ -882,6 +883,7 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
         if (nq % 64 != 0 || nkv % 64 != 0) return hipErrorNotSupported;
         GemmArgs as = {x, nullptr, wq, q_out, q_out, P, N, K, ldx, ldq, ldq, pos0, rope, head_size, n_scale > 0 ? n_scale : 1,
                        wk, wv, kcache, vcache, nq, nkv, ldkv, kv_head_stride, 0, 0};
+        as.ldw = K;
         return gemm_launch_sk<G_QKV, false>(as, N, sk, ws, st);
     }
     {
@@ -890,6 +892,7 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
         if (c.use && nq % feat_k == 0 && nkv % feat_k == 0) {
             GemmArgs ak = {x, nullptr, wq, q_out, q_out, P, N, K, ldx, ldq, ldq, pos0, rope, head_size, n_scale > 0 ? n_scale : 1,
                            wk, wv, kcache, vcache, nq, nkv, ldkv, kv_head_stride, 0, 0};
+            ak.ldw = K;
             return gemm_launch_kgs<G_QKV, false>(ak, N, c.tile, ws, st);
         }
     }
@@ -906,6 +909,7 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
     }
     GemmArgs a = {x, nullptr, wq, q_out, q_out, P, N, K, ldx, ldq, ldq, pos0, rope, head_size, 1,
                   wk, wv, kcache, vcache, nq, nkv, ldkv, kv_head_stride, 0, 0};
+    a.ldw = K;
     constexpr int KS = 2;
     const int tok = tf == TILE_128x64 ? 128 : tf == TILE_64x64 ? 64 : 32;
     const void *fn = tf == TILE_128x64 ? (const void *)prefill_gemm_dma<G_QKV, 2, 1, KS, false>
@@ -933,6 +937,7 @@ hipError_t launch_prefill_gemm_kv_pair(const float *x, int ldx, const float *wk,
     if (((uintptr_t)x & 15) || ((uintptr_t)wk & 15) || ((uintptr_t)wv & 15)) return hipErrorInvalidValue;
     GemmArgs a = {x, wv, wk, kcache, kcache, P, nkv, K, ldx, ldkv, ldkv, pos0, rope, head_size, n_scale > 0 ? n_scale : 1,
                   wk, wv, kcache, vcache, 0, nkv, ldkv, kv_head_stride, 0, 0};
+    a.ldw = K;
     return launch_prefill_skinny_pair(G_QKV, a, st);
 }
 
@@ -940,12 +945,13 @@ hipError_t launch_prefill_gemm_kv_pair(const float *x, int ldx, const float *wk,
 hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w, float *out, int ldo,
                                int P, int N, int K, int pos0, const float2 *rope, int head_size,
                                hipStream_t st, const float *res, int ldres, int n_scale, size_t kv_head_stride,
-                               int sk, const SplitKWs *ws)
+                               int sk, const SplitKWs *ws, int ldw)
 {
     if (P <= 0 || N <= 0 || K <= 0 || (K % 4) != 0 || (ldx % 4) != 0) return hipErrorInvalidValue;
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return hipErrorInvalidValue;
     if (res == nullptr) { res = out; ldres = ldo; }  // PG_RESID in place
     GemmArgs a = {x, nullptr, w, out, res, P, N, K, ldx, ldo, ldres, pos0, rope, head_size, n_scale > 0 ? n_scale : 1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, kv_head_stride, 0, 0};
+    a.ldw = ldw > 0 ? ldw : K;
     const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
     if (P <= skinny_max && sk <= 1) return launch_prefill_skinny(epi, a, st);  // prefill_skinny.hip
     if (sk > 1) {

@@ -146,14 +146,15 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
         L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, s->pf_x, w->rms_ffn + (size_t)l * dim, dim, P, st));  // :398
         // :405-416: W1 and W3 in one launch with silu(a) * b as its epilogue where the tile kernel
         // takes the shape, else two GEMMs, the second one merging into the first one's output
-        const float *w1 = w->w1 + (size_t)l * sh.hid_loc * dim, *w3 = w->w3 + (size_t)l * sh.hid_loc * dim;
+        // W1 | W3 share one slot of the device blob, rows alternating: rows of either are 2 dim apart
+        const float *w1 = w->w1 + (size_t)l * sh.hid_loc * 2 * dim, *w3 = w->w3 + (size_t)l * sh.hid_loc * 2 * dim;
         const hipError_t pe = launch_prefill_gemm_swiglu_pair(s->pf_xn, dim, w1, w3, out, ldo, P, sh.hid_loc, dim, st, sh.world,
-                                                              sk_h1, ws);
+                                                              sk_h1, ws, 2 * dim);
         if (pe == hipErrorNotSupported) {
             L2Z_HIP(launch_prefill_gemm(PG_STORE, s->pf_xn, dim, w1, out, ldo, P, sh.hid_loc, dim, pos0, s->rope,
-                                        hs, st, nullptr, 0, sh.world, 0, sk_h1, ws));                      // :405
+                                        hs, st, nullptr, 0, sh.world, 0, sk_h1, ws, 2 * dim));                      // :405
             L2Z_HIP(launch_prefill_gemm(PG_SWIGLU, s->pf_xn, dim, w3, out, ldo, P, sh.hid_loc, dim, pos0, s->rope,
-                                        hs, st, nullptr, 0, sh.world, 0, sk_h1, ws));  // :408 + :411-416 in the epilogue
+                                        hs, st, nullptr, 0, sh.world, 0, sk_h1, ws, 2 * dim));  // :408 + :411-416 in the epilogue
         } else {
             L2Z_HIP(pe);
         }

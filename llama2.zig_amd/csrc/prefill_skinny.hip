@@ -27,7 +27,7 @@ __global__ __launch_bounds__(64 * kSkWaves) void prefill_skinny(const GemmArgs a
     const v4f zero = {0.f, 0.f, 0.f, 0.f};
     // rows / tokens past the end are clamped: their products land in outputs nobody stores.
     // No branch and no select around the loads (either would make the loop wait for them early).
-    const float *wrow = a.w + (size_t)min(n0 + j, a.N - 1) * a.K + 4 * q;
+    const float *wrow = a.w + (size_t)min(n0 + j, a.N - 1) * a.ldw + 4 * q;
     const float *xrow[TMS];
 #pragma unroll
     for (int tm = 0; tm < TMS; tm++) xrow[tm] = a.x + (size_t)min(m0 + 16 * tm + j, a.P - 1) * a.ldx + 4 * q;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kPfBlock) void prefill_skinny_lds(const GemmArgs a)
         for (int i = 0; i < 4; i++) {
             const int f = tid + kPfBlock * i, r = f >> 6, k = k0 + 4 * (f & 63);
             const int kc = min(k, a.K - 4);  // clamped: legal address, zeroed at the LDS store
-            wv[i] = __builtin_nontemporal_load((const v4f *)(a.w + (size_t)min(n0 + r, a.N - 1) * a.K + kc));
+            wv[i] = __builtin_nontemporal_load((const v4f *)(a.w + (size_t)min(n0 + r, a.N - 1) * a.ldw + kc));
 #pragma unroll
             for (int tm = 0; tm < TMS; tm++)
                 xv[tm][i] = *(const v4f *)(a.x + (size_t)min(m0 + 16 * tm + r, a.P - 1) * a.ldx + kc);
@@ -242,8 +242,8 @@ __global__ __launch_bounds__(kPfBlock) void prefill_skinny_dma(const GemmArgs a)
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int r = 4 * wave + i;
-        wsrc[0][i] = a.w + (size_t)min(n0 + r, a.N - 1) * a.K + 4 * lane;
-        if (NW == 2) wsrc[NW - 1][i] = a.w2 + (size_t)min(n0 + r, a.N - 1) * a.K + 4 * lane;
+        wsrc[0][i] = a.w + (size_t)min(n0 + r, a.N - 1) * a.ldw + 4 * lane;
+        if (NW == 2) wsrc[NW - 1][i] = a.w2 + (size_t)min(n0 + r, a.N - 1) * a.ldw + 4 * lane;
 #pragma unroll
         for (int tm = 0; tm < TMS; tm++) xsrc[tm][i] = a.x + (size_t)min(m0 + 16 * tm + r, a.P - 1) * a.ldx + 4 * lane;
     }

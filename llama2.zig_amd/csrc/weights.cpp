@@ -132,17 +132,31 @@ using namespace l2z;
 
 namespace {
 
+bool is_w1(const TensorDesc &d) { return strcmp(d.name, "w1") == 0; }
+bool is_w3(const TensorDesc &d) { return strcmp(d.name, "w3") == 0; }
+
+// floats a tensor takes in the device blob: this rank's rows; W1's slot also holds W3's rows (interleaved),
+// W3 has none of its own; the never-read freq_cis tables stay resident only in the unsharded layout (weights_read)
+size_t slot_floats(const l2z_weights *w, const TensorDesc &d)
+{
+    size_t r0, r1;
+    shard_rows(d, w->sh, &r0, &r1);
+    if (d.kind == SKIP && !w->file_layout) return 0;
+    if (is_w3(d)) return 0;
+    return d.layers * (r1 - r0) * d.cols * (is_w1(d) ? 2 : 1);
+}
+
 void carve_local(l2z_weights *w, const std::vector<TensorDesc> &tt)
 {
-    // local layout: same tensor order, each tensor (layers, rows_loc, cols); SKIP kept only
-    // in file layout
-    size_t off = 0;
+    // device layout: the file's tensor order, each tensor (layers, rows_loc, cols); W1 | W3 row-interleaved in W1's slot
+    size_t off = 0, off_w1 = 0;
     const float *base = w->blob;
-    for (const auto &d : tt) {
-        size_t r0, r1;
-        shard_rows(d, w->sh, &r0, &r1);
-        const bool present = w->file_layout || d.kind != SKIP;
-        const float *p = base + off;
+    w->dev_off.assign(tt.size(), 0);
+    for (size_t i = 0; i < tt.size(); i++) {
+        const auto &d = tt[i];
+        if (is_w1(d)) off_w1 = off;
+        w->dev_off[i] = is_w3(d) ? off_w1 + d.cols : off;
+        const float *p = base + w->dev_off[i];
         const std::string n = d.name;
         if (n == "token_embedding_table") w->tok_emb = p;
         else if (n == "rms_att_weight") w->rms_att = p;
@@ -156,7 +170,7 @@ void carve_local(l2z_weights *w, const std::vector<TensorDesc> &tt)
         else if (n == "w3") w->w3 = p;
         else if (n == "rms_final_weight") w->rms_final = p;
         else if (n == "wcls") w->wcls = p;
-        if (present) off += d.layers * (r1 - r0) * d.cols;
+        off += slot_floats(w, d);
     }
     if (w->shared) w->wcls = w->tok_emb + (size_t)w->sh.v0 * w->cfg.dim;  // main.zig:112
 }
@@ -164,11 +178,7 @@ void carve_local(l2z_weights *w, const std::vector<TensorDesc> &tt)
 size_t local_floats(const l2z_weights *w, const std::vector<TensorDesc> &tt)
 {
     size_t off = 0;
-    for (const auto &d : tt) {
-        size_t r0, r1;
-        shard_rows(d, w->sh, &r0, &r1);
-        if (w->file_layout || d.kind != SKIP) off += d.layers * (r1 - r0) * d.cols;
-    }
+    for (const auto &d : tt) off += slot_floats(w, d);
     return off;
 }
 
@@ -259,25 +269,32 @@ extern "C" int l2z_weights_init(const l2z_config *config, const float *data, siz
         l2z_weights_free(w);
         return L2Z_ERR_INVALID;
     }
+    // this rank's rows of every tensor, straight from the caller's buffer (typically the mmapped checkpoint);
+    // W1 / W3 rows go through a device staging buffer of one layer and are spread over the shared slot there
     hipError_t e = hipSuccess;
-    if (w->file_layout) {
-        // one allocation, byte-identical to the file blob
-        e = upload(w->blob, data, need);
-    } else {
-        // sharded direct upload: only this rank's rows are read from the host blob
-        size_t off = 0;
-        for (const auto &d : tt) {
-            if (d.kind == SKIP) continue;
-            size_t r0, r1;
-            shard_rows(d, w->sh, &r0, &r1);
-            const size_t rl = r1 - r0;
+    float *stage = nullptr;
+    for (size_t i = 0; i < tt.size() && e == hipSuccess; i++) {
+        const auto &d = tt[i];
+        if (d.kind == SKIP && !w->file_layout) continue;
+        size_t r0, r1;
+        shard_rows(d, w->sh, &r0, &r1);
+        const size_t rl = r1 - r0;
+        float *dst = w->blob + w->dev_off[i];
+        if (is_w1(d) || is_w3(d)) {
+            if (stage == nullptr) e = hipMalloc((void **)&stage, rl * d.cols * sizeof(float));
             for (size_t l = 0; l < d.layers && e == hipSuccess; l++) {
-                const float *src = data + d.offset + (l * d.rows + r0) * d.cols;
-                e = upload(w->blob + off + l * rl * d.cols, src, rl * d.cols);
+                e = upload(stage, data + d.offset + (l * d.rows + r0) * d.cols, rl * d.cols);
+                if (e == hipSuccess) e = launch_copy_rows(dst + l * rl * 2 * d.cols, 2 * d.cols, stage, rl, d.cols, nullptr);
+                if (e == hipSuccess) e = hipDeviceSynchronize();  // the staging buffer is reused
             }
-            off += d.layers * rl * d.cols;
+        } else if (rl == d.rows) {
+            e = upload(dst, data + d.offset, d.count());
+        } else {
+            for (size_t l = 0; l < d.layers && e == hipSuccess; l++)
+                e = upload(dst + l * rl * d.cols, data + d.offset + (l * d.rows + r0) * d.cols, rl * d.cols);
         }
     }
+    if (stage) (void)hipFree(stage);
     if (e != hipSuccess) {
         set_error("weight upload failed: %s", hipGetErrorString(e));
         l2z_weights_free(w);
@@ -294,18 +311,18 @@ extern "C" int l2z_weights_init_synthetic(const l2z_config *config, int shared_w
     l2z_weights *w = nullptr;
     L2Z_TRY(weights_alloc(config, shared_weights, comm, &w, &tt));
     hipError_t e = hipSuccess;
-    size_t off = 0;
-    for (const auto &d : tt) {
+    for (size_t i = 0; i < tt.size(); i++) {
+        const auto &d = tt[i];
         if (d.kind == SKIP && !w->file_layout) continue;
         size_t r0, r1;
         shard_rows(d, w->sh, &r0, &r1);
         const size_t rl = r1 - r0;
+        const bool pair = is_w1(d) || is_w3(d);  // rows 2 * cols apart in the shared slot
         for (size_t l = 0; l < d.layers && e == hipSuccess; l++) {
             const uint64_t base = d.offset + (l * d.rows + r0) * d.cols;
-            e = launch_synth_fill(w->blob + off + l * rl * d.cols, base, rl * d.cols, seed, d.scale,
-                                  d.bias, nullptr);
+            e = launch_synth_fill(w->blob + w->dev_off[i] + l * rl * d.cols * (pair ? 2 : 1), base, rl * d.cols, seed, d.scale,
+                                  d.bias, nullptr, pair ? d.cols : 0, pair ? 2 * d.cols : 0);
         }
-        off += d.layers * rl * d.cols;
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
@@ -317,13 +334,33 @@ extern "C" int l2z_weights_init_synthetic(const l2z_config *config, int shared_w
     return L2Z_OK;
 }
 
+// offset / count address the FILE's order (main.zig:85-112); the device blob differs from it in W1 / W3 (rows
+// interleaved in one slot), so the range is served tensor by tensor and, there, row by row
 extern "C" int l2z_weights_read(const l2z_weights *w, size_t offset, size_t count, float *out)
 {
     L2Z_CHECK(w != nullptr && out != nullptr, L2Z_ERR_INVALID, "l2z_weights_read: null argument");
     L2Z_CHECK(w->file_layout, L2Z_ERR_INVALID, "l2z_weights_read: only for unsharded weights");
     L2Z_CHECK(offset + count <= w->blob_floats, L2Z_ERR_INVALID, "l2z_weights_read: out of range");
     L2Z_HIP(hipSetDevice(w->device));
-    L2Z_HIP(hipMemcpy(out, w->blob + offset, count * sizeof(float), hipMemcpyDeviceToHost));
+    const std::vector<TensorDesc> tt = tensor_table(w->cfg, w->shared != 0);
+    const size_t lo = offset, hi = offset + count;
+    for (size_t i = 0; i < tt.size(); i++) {
+        const auto &d = tt[i];
+        const size_t t0 = std::max(lo, d.offset), t1 = std::min(hi, d.offset + d.count());
+        if (t0 >= t1) continue;
+        if (!(is_w1(d) || is_w3(d))) {
+            L2Z_HIP(hipMemcpy(out + (t0 - lo), w->blob + w->dev_off[i] + (t0 - d.offset), (t1 - t0) * sizeof(float),
+                              hipMemcpyDeviceToHost));
+            continue;
+        }
+        for (size_t f = t0; f < t1;) {  // file row by file row: row r of the tensor sits 2 * cols * r into the slot
+            const size_t r = (f - d.offset) / d.cols, c = (f - d.offset) % d.cols;
+            const size_t n = std::min(d.cols - c, t1 - f);
+            L2Z_HIP(hipMemcpy(out + (f - lo), w->blob + w->dev_off[i] + r * 2 * d.cols + c, n * sizeof(float),
+                              hipMemcpyDeviceToHost));
+            f += n;
+        }
+    }
     return L2Z_OK;
 }
 
