@@ -234,6 +234,13 @@ __global__ __launch_bounds__(kPfBlock) void prefill_skinny_dma(const GemmArgs a)
         by = local >> 3;
         bx = g * 8 + (local & 7);
         if (bx >= a.ntx) return;
+    } else if (a.ntx > 0) {
+        // one token tile, a matrix that streams: block ids go round-robin over the 8 XCDs, so id b takes group
+        // (b % 8) * per + b / 8 -- every XCD sweeps its own eighth of the rows linearly instead of all of them
+        // advancing through one window (7B, 4 / 16 tokens: 5.97 / 6.17 -> 5.30 / 5.60 ms with W1 | W3 interleaved)
+        const int per = (int)gridDim.x >> 3;
+        bx = (bx & 7) * per + (bx >> 3);
+        if (bx >= a.ntx) return;  // padding of the last window
     }
     const int n0 = bx * 16, m0 = by * 16 * TMS;
     const v4f zero = {0.f, 0.f, 0.f, 0.f};
@@ -341,6 +348,13 @@ __global__ __launch_bounds__(kPfBlock) void prefill_skinny_dma(const GemmArgs a)
     }
 }
 
+// feature groups dealt to the XCDs window by window (see the kernel)?  Matrices that stream from HBM, enough groups
+bool skinny_spread(const GemmArgs &a)
+{
+    const bool streams = (size_t)a.N * (size_t)a.n_scale * (size_t)a.K * sizeof(float) > ((size_t)16 << 20);
+    return tunables().pf_skinny_spread != 0 && streams && a.N >= 16 * 64;
+}
+
 template <int EPI, int TMS>
 hipError_t skinny_launch_t(const GemmArgs &a, hipStream_t st)
 {
@@ -358,6 +372,10 @@ hipError_t skinny_launch_t(const GemmArgs &a, hipStream_t st)
         GemmArgs args = a;
         dim3 g1 = grid;
         args.ntx = 0; args.nty = 0;
+        if (grid.y == 1 && skinny_spread(a)) {
+            args.ntx = (int)grid.x;
+            g1 = dim3((grid.x + 7) / 8 * 8);
+        }
         if (grid.y > 1) {
             args.ntx = (int)grid.x; args.nty = (int)grid.y;
             g1 = dim3((grid.x + 7) / 8 * 8 * grid.y);
@@ -426,6 +444,10 @@ hipError_t launch_prefill_skinny_pair(int epi, const GemmArgs &a, hipStream_t st
     GemmArgs args = a;
     dim3 grid((a.N + 15) / 16, (a.P + 15) / 16), g1 = grid;
     args.ntx = 0; args.nty = 0;
+    if (grid.y == 1 && skinny_spread(a)) {
+        args.ntx = (int)grid.x;
+        g1 = dim3((grid.x + 7) / 8 * 8);
+    }
     if (grid.y > 1) {
         args.ntx = (int)grid.x; args.nty = (int)grid.y;
         g1 = dim3((grid.x + 7) / 8 * 8 * grid.y);

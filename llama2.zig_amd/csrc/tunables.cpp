@@ -40,6 +40,7 @@ Tunables read_env()
     env_int("L2Z_PF_SKINNY_FORM", &t.pf_skinny_form);
     env_int("L2Z_PF_TILE", &t.pf_tile);
     env_int("L2Z_PF_SKINNY_MAX", &t.pf_skinny_max);
+    env_int("L2Z_PF_SKINNY_SPREAD", &t.pf_skinny_spread);
     env_int("L2Z_PF_SKINNY_TMS", &t.pf_skinny_tms);
     env_int("L2Z_PF_ATTN", &t.pf_attn);
     env_int("L2Z_PF_FUSE", &t.pf_fuse);
@@ -95,7 +96,7 @@ bool tunables_set(const char *name, long long v)
         {"L2Z_P2P_BULK_MB", &t.p2p_bulk_mb},
         {"L2Z_PREFILL", &t.prefill}, {"L2Z_PF_CHUNK", &t.pf_chunk},
         {"L2Z_PF_SKINNY_FORM", &t.pf_skinny_form}, {"L2Z_PF_TILE", &t.pf_tile},
-        {"L2Z_PF_SKINNY_MAX", &t.pf_skinny_max}, {"L2Z_PF_SKINNY_TMS", &t.pf_skinny_tms},
+        {"L2Z_PF_SKINNY_MAX", &t.pf_skinny_max}, {"L2Z_PF_SKINNY_SPREAD", &t.pf_skinny_spread}, {"L2Z_PF_SKINNY_TMS", &t.pf_skinny_tms},
         {"L2Z_PF_ATTN", &t.pf_attn}, {"L2Z_PF_FUSE", &t.pf_fuse}, {"L2Z_PF_DMA", &t.pf_dma}, {"L2Z_PF_ORDER", &t.pf_order},
         {"L2Z_PF_SPLITK", &t.pf_splitk}, {"L2Z_PF_KGS", &t.pf_kgs}};
     for (auto &e : ints)

@@ -40,6 +40,7 @@ struct Tunables {
     int pf_skinny_form = 1;    // L2Z_PF_SKINNY_FORM  short-prompt GEMM: 1 LDS-staged (direct-to-LDS ring where K % 256 == 0), 2 register-staged LDS form only, 0 no LDS
     int pf_tile = 0;           // L2Z_PF_TILE         force a tile form of the prefill GEMM (experiments: 2 64x64, 8 128x64, 9 32x64, 10 32x32, 11 128x128;
                                //                     disables the paired / fused launches); 0: chosen by grid fill
+    int pf_skinny_spread = 1;  // L2Z_PF_SKINNY_SPREAD 0: the short-prompt kernels' blocks take the feature groups in order, not one window of rows per XCD
     int pf_skinny_max = -1;    // L2Z_PF_SKINNY_MAX   longest chunk that takes the short-prompt GEMMs (default 64 tokens)
     int pf_skinny_tms = 0;     // L2Z_PF_SKINNY_TMS   token tiles (of 16) per block of the short-prompt GEMM: 1, 2, 4 (register form); 0: by prompt length
     int pf_attn = 1;           // L2Z_PF_ATTN         0: per-query prefill attention only; 2: the LDS-softmax tiled kernel instead of the flash form; 3: flash form with one key part (4 waves)
