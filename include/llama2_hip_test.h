@@ -25,7 +25,8 @@ extern "C" {
  * PCIe upload is not part of the measured path). */
 int l2z_weights_init_synthetic(const l2z_config *config, int shared_weights, uint64_t seed,
                                const l2z_comm *comm, l2z_weights **out);
-/* Copy `count` floats starting at blob index `offset` back to the host
+/* Copy `count` floats starting at index `offset` of the checkpoint's weight blob (FILE order, main.zig:85-112)
+ * back to the host -- the device copy keeps W1 | W3 row-interleaved, this call undoes that
  * (single-GPU weights only; used by tests to check uploads / the generator). */
 int l2z_weights_read(const l2z_weights *w, size_t offset, size_t count, float *out);
 
