@@ -353,12 +353,19 @@ extern "C" int l2z_weights_read(const l2z_weights *w, size_t offset, size_t coun
                               hipMemcpyDeviceToHost));
             continue;
         }
-        for (size_t f = t0; f < t1;) {  // file row by file row: row r of the tensor sits 2 * cols * r into the slot
+        for (size_t f = t0; f < t1;) {  // row r of the tensor sits 2 * cols * r into the slot
             const size_t r = (f - d.offset) / d.cols, c = (f - d.offset) % d.cols;
-            const size_t n = std::min(d.cols - c, t1 - f);
-            L2Z_HIP(hipMemcpy(out + (f - lo), w->blob + w->dev_off[i] + r * 2 * d.cols + c, n * sizeof(float),
-                              hipMemcpyDeviceToHost));
-            f += n;
+            const float *src = w->blob + w->dev_off[i] + r * 2 * d.cols + c;
+            const size_t whole = c == 0 ? (t1 - f) / d.cols : 0;  // whole rows from here: one strided copy
+            if (whole > 0) {
+                L2Z_HIP(hipMemcpy2D(out + (f - lo), d.cols * sizeof(float), src, 2 * d.cols * sizeof(float),
+                                    d.cols * sizeof(float), whole, hipMemcpyDeviceToHost));
+                f += whole * d.cols;
+            } else {  // a partial row at either end of the range
+                const size_t n = std::min(d.cols - c, t1 - f);
+                L2Z_HIP(hipMemcpy(out + (f - lo), src, n * sizeof(float), hipMemcpyDeviceToHost));
+                f += n;
+            }
         }
     }
     return L2Z_OK;

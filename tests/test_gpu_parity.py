@@ -318,6 +318,23 @@ def test_upload_is_byte_identical(gpu, ck):
     w.close()
 
 
+def test_weights_read_serves_file_order_across_the_interleaved_slot(gpu, ck):
+    """The device copy keeps W1 | W3 row-interleaved in one slot; l2z_weights_read addresses the
+    FILE's order: ranges that start and end inside rows of w1 / w3, run from w1 into w2 and from w2 into w3 and
+    past it, for an uploaded blob and for the device-side generator."""
+    cfg = ck.Config(dim=48, hidden_dim=136, n_layers=3, n_heads=4, n_kv_heads=2, vocab_size=300, seq_len=24)
+    blob = ck.synth_blob(cfg, False, 11)
+    t = {d.name: d for d in ck.tensor_table(cfg, False)}
+    dim, hid = cfg.dim, cfg.hidden_dim
+    w1, w2, w3 = t["w1"].offset, t["w2"].offset, t["w3"].offset
+    ranges = [(w1 + 5, 7), (w1 + 5, 3 * dim), (w1 + dim * hid - 10, 30 + dim), (w2 - 17, 40),
+              (w3 - 9, 2 * dim + 20), (w3 + (2 * hid + 3) * dim + 11, 5 * dim), (w3 + 3 * hid * dim - 4, 40), (w1, w3 + 3 * hid * dim - w1)]
+    for w in (gpu.Weights(cfg, blob, False), gpu.Weights(cfg, None, False, seed=11)):
+        for off, n in ranges:
+            assert np.array_equal(w.read(off, n), blob[off:off + n]), (off, n)
+        w.close()
+
+
 # ---------------------------------------------------------------- whole forward pass
 CONFIGS = [
     ("toy-gqa-unshared", dict(TOY), False),
