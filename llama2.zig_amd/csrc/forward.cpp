@@ -56,35 +56,75 @@ int check_pair(const l2z_config *config, const l2z_runstate *s, const l2z_weight
 //   ll_consume  producers push LL words to every rank, consumers read them from their own landing
 //               slot while staging x: no launch per gather, 5 nodes per layer as at world == 1;
 //   gather launch after every producer (peer writes without consumer polling, or RCCL).
+// Overlapped chain (s->ovl; world == 1, wide-row models).  The launches of a pass go out on TWO
+// streams with no edge between consecutive mat-vecs: a consumer whose input edge is overlapped runs in the other
+// chain than its producer, becomes resident while the producer still streams, issues its first weight batch and
+// only then waits for its input vector, which the producer hands over as LL words {value, epoch} in this
+// process's own landing slots (the peer-write transport of sharded runs with one rank: p2p.hip).  Edges, per layer:
+// bit 0 attention -> wo, 1 wo -> w1|w3, 2 w1|w3 -> w2, 3 w2 -> next qkv / classifier.  qkv -> attention (q and the
+// new K / V row are plain buffers) and classifier -> argmax stay stream-ordered.  A kernel only ever reads plain
+// buffers written earlier in ITS OWN chain or before the pass began; the residual of wo / w2 comes as the LL words
+// of the previous hand-over of x.  Every mat-vec is the duo kernel (one 8-wave block per CU) and every attention
+// form a 256-thread one, so a waiting launch can never keep the launch it waits for from becoming resident.
+struct Hint { unsigned h0 = 0, n = 0, stride = 0; };
+
+// the elements a mat-vec producer writes in its last sweep over the units (virtual grid vgrid)
+static Hint mv_hint(int n_pairs, int vgrid, int epi)
+{
+    Hint h;
+    if (vgrid <= 0 || n_pairs <= 0) return h;
+    const int u0 = ((n_pairs - 1) / vgrid) * vgrid;
+    h.n = (unsigned)(n_pairs - u0);
+    if (epi == EPI_SWIGLU) { h.h0 = (unsigned)u0; h.stride = 1; }
+    else { h.h0 = (unsigned)(2 * u0 + 1); h.stride = 2; }
+    return h;
+}
+
 int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof *prof,
                     int only_stage, int variant, int only_kind)
 {
     const bool split = variant == ATTN_SPLIT || variant == ATTN_SPLIT_S;
     const l2z_config &c = s->cfg;
     const Shard &sh = s->sh;
-    hipStream_t st = s->stream;
+    const Tunables &tn = tunables();
+    const bool duo = s->duo;  // such a runstate runs the duo mat-vecs in every mode (what is timed is what runs)
+    const bool ovl = s->ovl && only_stage < 0 && only_kind < 0 && prof == nullptr;
+    const unsigned emask = ovl ? (unsigned)s->ovl_edges : 0u;
+    hipStream_t sts[2] = {s->stream, ovl ? s->stream2 : s->stream};
+    int chain = 0;
+    hipStream_t st = sts[0];
+    const l2z_comm *lc = ovl ? s->self_comm : s->comm;
     const size_t dim = c.dim, hid = c.hidden_dim;
     const int mb = s->max_blocks;
     int stage = 0;
     auto want = [&]() { return only_stage < 0 || only_stage == stage; };
     // only_kind >= 0: just the launches of one kind, back to back (l2z_time_kind: kernel duration)
     auto kind = [&](int k) { return only_kind < 0 || only_kind == k; };
-    const bool p2p = s->d_push != nullptr && only_stage < 0;
-    const bool consume = p2p && s->ll_consume;
+    const bool p2p = ovl || (s->d_push != nullptr && only_stage < 0 && sh.world > 1);
+    const bool consume = ovl || (p2p && s->ll_consume);
     // Producers push their outputs as LL words straight into the peers' slots (the values travel
     // while the launch still runs).  With gather launches, not while profiling: the gather's share
     // would be hidden in the producer's time.
-    const bool can_push = p2p && tunables().p2p_push && (consume || prof == nullptr);
+    const bool can_push = ovl || (p2p && tn.p2p_push && (consume || prof == nullptr));
     const int n_g = s->n_gathers;
     int gi = 0;           // gathers issued so far in this pass
     bool pushed = false;  // the launch just made pushed its outputs itself
-    const int *ctl = s->comm ? s->comm->d_ctl : nullptr;
+    Hint hint;            // overlapped chain: where the launch just made writes last
+    const int *ctl = lc ? lc->d_ctl : nullptr;
+    if (ovl) {  // fork: the second chain starts behind whatever precedes the pass on the runstate's stream
+        L2Z_HIP(hipEventRecord(s->ev_fork, sts[0]));
+        L2Z_HIP(hipStreamWaitEvent(sts[1], s->ev_fork, 0));
+    }
     auto gather = [&](float *buf, size_t count_per_rank) -> int {
         stage++;
         gi++;
         if (only_stage >= 0 || only_kind >= 0) return L2Z_OK;
         const bool was_pushed = pushed;
         pushed = false;
+        if (ovl) {  // nothing is collected: consumers read the words (or, stream-ordered edges, the plain buffer)
+            L2Z_CHECK(was_pushed || gi == n_g, L2Z_ERR_STATE, "overlapped chain, hand-over %d: the producer did not push", gi);
+            return L2Z_OK;
+        }
         if (consume) {
             L2Z_CHECK(was_pushed, L2Z_ERR_STATE, "consumer-side gather %d: the producer did not push", gi);
             if (gi < n_g) return L2Z_OK;  // the consumer collects; only the logits get a launch
@@ -105,9 +145,24 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         }
         return L2Z_OK;
     };
-    // input of a consumer: the vector gathered as number g (consumer-side form), else the plain buffer
-    auto x_in = [&](MatvecArgs &a, const float *plain, int g, size_t count_per_rank) {
+    // input of a consumer: the vector gathered as number g (consumer-side form), else the plain buffer.
+    // Overlapped chain: `edge` = the bit of the edge this input arrives over; set -> the consumer runs in the
+    // other chain than the producer and reads the words behind the producer's hint, clear -> same chain, plain.
+    auto x_in = [&](MatvecArgs &a, const float *plain, int g, size_t count_per_rank, unsigned edge = 0) {
         a.x = plain;
+        a.duo = duo ? 1 : 0;
+        if (ovl) {
+            if (g >= 1 && (emask & edge)) {
+                chain ^= 1;
+                a.xin = comm_ll_in(lc, g, count_per_rank);
+                if (tn.overlap_hint && hint.n) {
+                    a.xin.hint0 = hint.h0; a.xin.hint_n = hint.n; a.xin.hint_stride = hint.stride;
+                    a.xin.hint_sleep = tn.overlap_hint_sleep;
+                }
+            }
+            st = sts[chain];
+            return;
+        }
         if (consume && g >= 1) a.xin = comm_ll_in(s->comm, g, count_per_rank);
     };
     auto push_to = [&](MatvecArgs &a, int which) {
@@ -143,7 +198,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.rows0 = sh.dim_loc; a.rows1 = sh.kvd_loc; a.rows2 = sh.kvd_loc;
             a.pos_stride1 = sh.hs; a.pos_stride2 = sh.hs; a.kv_head_stride = kvh_stride;
             a.n = c.dim; a.rms_w = w->rms_att + (size_t)l * dim;
-            x_in(a, s->x, gi, sh.dim_loc);  // layer 0: the embedding row, a plain buffer (gi == 0)
+            x_in(a, s->x, gi, sh.dim_loc, 8u);  // layer 0: the embedding row, a plain buffer (gi == 0)
             a.pos_ptr = s->d_pos; a.rope = s->rope; a.head_size = sh.hs; a.rope_segs = 2;
             L2Z_LAUNCH(KIND_QKV, launch_matvec(a, PRO_RMS, EPI_ROPE, mb, g_cus, st));
         }
@@ -157,12 +212,13 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
                 a.push_ctl = ctl;
                 a.push_gi = gi + 1;
                 pushed = true;
+                hint.h0 = (unsigned)(sh.hs - 1); hint.n = (unsigned)sh.heads_loc; hint.stride = (unsigned)sh.hs;  // a head's last element
             }
             if (split && s->attn_nch > 1 && attention_split_supported(a))
                 L2Z_LAUNCH(KIND_ATTN, launch_attention_split(a, sh.heads_loc, s->attn_nch,
                                                              s->d_attn_part, s->d_attn_cnt, st, variant == ATTN_SPLIT_S));
             else
-                L2Z_LAUNCH(KIND_ATTN, launch_attention(a, sh.heads_loc, st, variant == ATTN_SHORT ? 1 : 0));
+                L2Z_LAUNCH(KIND_ATTN, launch_attention(a, sh.heads_loc, st, (variant == ATTN_SHORT || s->attn_all256) ? 1 : 0));
         }
         L2Z_TRY(gather(s->xb, sh.dim_loc));
         if (want() && kind(KIND_WO)) {   // wo (:392) + residual (:395)
@@ -170,9 +226,12 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.w0 = w->wo + (size_t)l * sh.dim_loc * dim;
             a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0;
             a.rows0 = sh.dim_loc; a.n = c.dim;
-            x_in(a, s->xb, gi, sh.dim_loc);
+            x_in(a, s->xb, gi, sh.dim_loc, 1u);
+            if (ovl && gi >= 2) a.resid_in = comm_ll_in(lc, gi - 1, sh.dim_loc);  // x as the previous layer's w2 handed it over
             push_to(a, 1);
-            L2Z_LAUNCH(KIND_WO, launch_matvec(a, PRO_NONE, EPI_RESID, mb, g_cus, st, nullptr, &pushed));
+            int vg = 0;
+            L2Z_LAUNCH(KIND_WO, launch_matvec(a, PRO_NONE, EPI_RESID, mb, g_cus, st, &vg, &pushed));
+            hint = mv_hint((sh.dim_loc + 1) / 2, vg, EPI_RESID);
         }
         L2Z_TRY(gather(s->x, sh.dim_loc));
         if (want() && kind(KIND_FFN13)) {   // rmsnorm (:398) + w1,w3 (:405-408) + SiLU*mul (:411-416)
@@ -182,9 +241,11 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.out0 = s->hb + sh.hid0;
             a.rows0 = sh.hid_loc; a.rows1 = sh.hid_loc; a.n = c.dim;
             a.rms_w = w->rms_ffn + (size_t)l * dim;
-            x_in(a, s->x, gi, sh.dim_loc);
+            x_in(a, s->x, gi, sh.dim_loc, 2u);
             push_to(a, 2);
-            L2Z_LAUNCH(KIND_FFN13, launch_matvec(a, PRO_RMS, EPI_SWIGLU, mb, g_cus, st, nullptr, &pushed));
+            int vg = 0;
+            L2Z_LAUNCH(KIND_FFN13, launch_matvec(a, PRO_RMS, EPI_SWIGLU, mb, g_cus, st, &vg, &pushed));
+            hint = mv_hint(sh.hid_loc, vg, EPI_SWIGLU);
         }
         L2Z_TRY(gather(s->hb, sh.hid_loc));
         if (want() && kind(KIND_FFN2)) {   // w2 (:419) + residual (:422)
@@ -192,9 +253,12 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.w0 = w->w2 + (size_t)l * sh.dim_loc * hid;
             a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0;
             a.rows0 = sh.dim_loc; a.n = c.hidden_dim;
-            x_in(a, s->hb, gi, sh.hid_loc);
+            x_in(a, s->hb, gi, sh.hid_loc, 4u);
+            if (ovl) a.resid_in = comm_ll_in(lc, gi - 1, sh.dim_loc);  // x as this layer's wo handed it over
             push_to(a, 1);
-            L2Z_LAUNCH(KIND_FFN2, launch_matvec(a, PRO_NONE, EPI_RESID, mb, g_cus, st, nullptr, &pushed));
+            int vg = 0;
+            L2Z_LAUNCH(KIND_FFN2, launch_matvec(a, PRO_NONE, EPI_RESID, mb, g_cus, st, &vg, &pushed));
+            hint = mv_hint((sh.dim_loc + 1) / 2, vg, EPI_RESID);
         }
         L2Z_TRY(gather(s->x, sh.dim_loc));
     }
@@ -202,12 +266,12 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         MatvecArgs a = {};
         a.w0 = w->wcls; a.out0 = s->logits + sh.v0;
         a.rows0 = sh.v_loc; a.n = c.dim; a.rms_w = w->rms_final;
-        x_in(a, s->x, gi, sh.dim_loc);
+        x_in(a, s->x, gi, sh.dim_loc, 8u);
         a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.row_offset = sh.v0;
         // single GPU, vector path: the launch also leaves one argmax candidate per block
         const bool fuse = sh.world == 1 && matvec_vector_width(c.dim);
         int grid = 0;
-        push_to(a, 3);
+        if (!ovl) push_to(a, 3);
         L2Z_LAUNCH(KIND_CLS, launch_matvec(a, PRO_RMS, fuse ? EPI_ARGMAX : EPI_STORE, mb, g_cus, st,
                                            &grid, &pushed));
         s->n_part = fuse ? grid : 0;
@@ -220,7 +284,14 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         a.pos_ptr = s->d_pos; a.prompt = s->d_prompt; a.n_prompt_ptr = s->d_n_prompt;
         a.out_tokens = s->d_out_tokens; a.argmax_out = s->d_argmax; a.tok_emb = w->tok_emb;
         a.x = s->x; a.dim = c.dim; a.advance = 1;
+        if (ovl) { a.epoch_ctl = lc->d_ctl; a.epoch_add = n_g; }  // the pass is over: its epochs are used up
         L2Z_LAUNCH(KIND_ARGMAX, launch_argmax(a, st));
+    } else if (ovl) {
+        L2Z_HIP(launch_epoch_advance(lc->d_ctl, n_g, st));
+    }
+    if (ovl) {  // join: the runstate's stream continues behind both chains
+        L2Z_HIP(hipEventRecord(s->ev_join, sts[1]));
+        L2Z_HIP(hipStreamWaitEvent(sts[0], s->ev_join, 0));
     }
     return L2Z_OK;
 }
@@ -300,6 +371,7 @@ int run_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, int pos)
               "sharded runstate without a transport: connect the group (RCCL id or "
               "l2z_comm_p2p_export/_connect), or drive emulated ranks with l2z_emu_transformer");
     L2Z_TRY(comm_check(s->comm));
+    L2Z_TRY(comm_check(s->self_comm));
     L2Z_TRY(ensure_graph(s, w, variant, with_step));
     if (s->use_graphs) {
         L2Z_HIP(hipGraphLaunch(with_step ? s->g_step[variant] : s->g_forward[variant], s->stream));
@@ -350,6 +422,7 @@ extern "C" int l2z_logits_read(l2z_runstate *s, float *out_logits)
                            hipMemcpyDeviceToHost, s->stream));
     L2Z_HIP(hipStreamSynchronize(s->stream));
     L2Z_TRY(comm_check(s->comm));
+    L2Z_TRY(comm_check(s->self_comm));
     return L2Z_OK;
 }
 
@@ -367,6 +440,7 @@ extern "C" int l2z_probs_read(l2z_runstate *s, float temperature, float *out_pro
     L2Z_HIP(hipMemcpyAsync(s->h_stage, s->d_probs, bytes, hipMemcpyDeviceToHost, s->stream));
     L2Z_HIP(hipStreamSynchronize(s->stream));
     L2Z_TRY(comm_check(s->comm));
+    L2Z_TRY(comm_check(s->self_comm));
     memcpy(out_probs, s->h_stage, bytes);
     return L2Z_OK;
 }
@@ -438,6 +512,7 @@ extern "C" int l2z_greedy_run(const l2z_config *config, l2z_runstate *s, const l
                                (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s->stream));
         L2Z_HIP(hipStreamSynchronize(s->stream));
         L2Z_TRY(comm_check(s->comm));
+        L2Z_TRY(comm_check(s->self_comm));
         int got = n;
         for (int i = 0; i < n; i++) {
             if (out_tokens[produced + i] == 1) {  // BOS ends the sequence

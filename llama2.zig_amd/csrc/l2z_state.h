@@ -115,6 +115,16 @@ struct l2z_runstate {
                               // as LL words from the landing slot; no gather launch except the logits
     bool fused_qkv_attn = false;  // small models: qkv + RoPE + KV write + attention in one launch
     int max_blocks = 0;
+    // overlapped decode chain (world == 1, wide-row models; forward.cpp): the pass runs as two
+    // chains of launches on two streams, consecutive mat-vecs hand their vectors over as LL words in
+    // self_comm's landing slots (d_push then describes those)
+    bool attn_all256 = false;      // wide-row model: 256-thread attention forms at every position
+    bool duo = false;              // every mat-vec is matvec_duo_kernel (world == 1, attn_all256)
+    bool ovl = false;              // ... and the pass runs as two chains
+    int ovl_edges = 0;             // which hand-overs of a layer are overlapped (bit 0 attn->wo, 1 wo->w1|w3, 2 w1|w3->w2, 3 w2->qkv/cls)
+    l2z_comm *self_comm = nullptr; // owned: arena, epoch counter, error latch of the hand-overs
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 namespace l2z {

@@ -76,6 +76,11 @@ struct MvLocals {
     const P2pArgs *push;  // sharded: LL words of the outputs go straight to the peers
     int push_e;
     size_t push_base;     // index of out0[0] in the gathered vector
+    const unsigned long long *resid_slot;  // EPI_RESID, overlapped chain: residual as LL words (else null)
+    unsigned resid_e;
+    int *resid_ctl;
+    int *resid_herr;
+    long long resid_timeout;
 };
 
 template <int EPI>
@@ -95,6 +100,13 @@ __device__ __forceinline__ MvLocals mv_locals(const MatvecArgs &a)
     m.push = a.push;
     m.push_e = m.push ? a.push_ctl[kCtlEpoch] + a.push_gi : 0;
     m.push_base = m.push ? (size_t)m.push->rank * m.push->count : 0;
+    m.resid_slot = nullptr; m.resid_e = 0; m.resid_ctl = nullptr; m.resid_herr = nullptr; m.resid_timeout = 0;
+    if (EPI == EPI_RESID && a.resid_in.slots != nullptr) {
+        const int e = a.resid_in.ctl[kCtlEpoch] + a.resid_in.gi;
+        m.resid_e = (unsigned)e;
+        m.resid_slot = a.resid_in.slots + (size_t)(e & 1) * a.resid_in.slot_floats;
+        m.resid_ctl = a.resid_in.ctl; m.resid_herr = a.resid_in.h_err; m.resid_timeout = a.resid_in.timeout_ticks;
+    }
     return m;
 }
 
@@ -129,18 +141,23 @@ __device__ __forceinline__ void pair_rows(const MvLocals &m, int p, const float 
 struct EpiIn {
     float ra, rb;
     float2 cs;
+    v4u rw;  // LL residual: the two words as loaded at prefetch time (validated in the epilogue)
 };
 
 template <int EPI>
 __device__ __forceinline__ EpiIn epi_prefetch(const MvLocals &m, int p, bool writer)
 {
     EpiIn e;
-    e.ra = 0.0f; e.rb = 0.0f; e.cs = make_float2(1.0f, 0.0f);
+    e.ra = 0.0f; e.rb = 0.0f; e.cs = make_float2(1.0f, 0.0f); e.rw = v4u{0u, 0u, 0u, 0u};
     if (!writer || p >= m.n_pairs) return e;
     if (EPI == EPI_RESID) {  // single segment: rows 2p, 2p+1
         const int ga = 2 * p, gb = ga + 1;
-        e.ra = m.resid[ga];
-        if (gb < m.total_rows) e.rb = m.resid[gb];
+        if (m.resid_slot) {  // words 2p, 2p+1 of the handed-over vector: one 16-byte load, never waited for here
+            e.rw = ll_load2(m.resid_slot, (size_t)ga);
+        } else {
+            e.ra = m.resid[ga];
+            if (gb < m.total_rows) e.rb = m.resid[gb];
+        }
     } else if (EPI == EPI_ROPE) {
         const int ga = 2 * p;
         const bool a1 = ga >= m.rows0, a2 = ga >= m.r01;
@@ -200,7 +217,24 @@ __device__ __forceinline__ void pair_epilogue(const MvLocals &m, int p, float sa
         }
     } else if (EPI == EPI_RESID) {
         if (writer && valid_a) {
-            const float va = in.ra + sa, vb = in.rb + sb;  // :711 a[i] += b[i]  (resid[row] prefetched)
+            float ra = in.ra, rb = in.rb;
+            if (m.resid_slot) {  // the prefetched words carry their epoch; late ones (never, in practice) are re-read
+                v4u w = in.rw;
+                const long long t0 = wall_clock64();
+                while (!(w.y == m.resid_e && (w.w == m.resid_e || !valid_b))) {
+                    if (__hip_atomic_load(m.resid_ctl + kCtlErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    if (wall_clock64() - t0 > m.resid_timeout) {
+                        __hip_atomic_store(m.resid_ctl + kCtlErr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        *m.resid_herr = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(4);
+                    w = ll_load2(m.resid_slot, (size_t)ga);
+                }
+                ra = __uint_as_float(w.x);
+                rb = __uint_as_float(w.z);
+            }
+            const float va = ra + sa, vb = rb + sb;  // :711 a[i] += b[i]  (resid[row] prefetched)
             oa[row_a] = va;
             if (valid_b) ob[row_b] = vb;
             if (m.push) {  // single segment on this path: row == index in the slice
@@ -512,6 +546,138 @@ __global__ __launch_bounds__(kBlock) void matvec_row_kernel(const MatvecArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------
+// "Duo" form of the wide-row kernel, for the OVERLAPPED decode chain.  One 512-thread
+// block = two HALVES of four waves; half h of block b is exactly one matvec_row_kernel block with index
+// 2b + h of a grid of 2 * gridDim.x: the same units, the same thread -> column map, the same summation
+// order (so the same bits), the same linear sweep of the matrix.  What the halves share is the staged x:
+// one copy per CU instead of two -- half the LL words to sweep when x is a handed-over vector -- and the
+// footprint: every mat-vec of the chain is ONE 8-wave block per CU with <= 128 VGPRs and <= 48 KB of
+// LDS, so any two such blocks fit one CU and launch k + 1 can always become resident beside launch k
+// (and launch k can always finish becoming resident beside a waiting launch k + 1: no scheduling
+// deadlock, whatever the dispatcher's placement).
+//   LL: x arrives as {value, epoch} words written by the PREVIOUS launch of the chain, which may still
+//   be running (kernel_common.h duo_stage_x): the block issues its first weight batch, then lane 0 waits
+//   for the hint word, then everybody sweeps the vector.
+// rmsnorm: the sum of squares is formed by threads 0..255 in the 256-thread kernel's order.
+// ---------------------------------------------------------------------------
+template <int PRO, int EPI, bool BIGX, bool LL>
+__global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
+{
+    constexpr int U = 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const MvLocals m = mv_locals<EPI>(a);
+    const int n4 = m.n >> 2;
+    const int n_batches = (n4 + kBlock * U - 1) / (kBlock * U);
+    const int n4_pad = n_batches * (kBlock * U);
+    float *xs = lds;
+    float *scratch = lds + 4 * n4_pad;            // kScratch floats
+    float *part = scratch + kScratch;             // [half][parity][2][kWaves] wave partials
+    const v4f *xs4 = (const v4f *)xs;
+    const int tid = threadIdx.x, half = tid >> 8, ht = tid & (kBlock - 1), lane = tid & 63, hw = ht >> 6;
+    const int n_units = m.n_pairs;
+    const int ustride = 2 * gridDim.x;            // virtual grid: 2 * gridDim.x <= n_units
+
+    constexpr int GC = BIGX ? 6 : 2;              // rmsnorm weights of this thread (n <= GC * 2048)
+    v4f gr[GC];
+    if (PRO == PRO_RMS) {
+        const v4f *g4 = (const v4f *)a.rms_w;
+#pragma unroll
+        for (int k = 0; k < GC; k++) {
+            const int j = tid + kDuo * k;
+            gr[k] = (j < n4) ? g4[j] : v4f{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    int u = 2 * blockIdx.x + half;
+    bool has = u < n_units;
+    const float *pa, *pb;
+    pair_rows<EPI>(m, u, pa, pb);   // clamped to the last pair when the half has no unit
+    v4f wa[U], wb[U];
+    auto load = [&](int cb) {  // columns cb + ht + 256k; validity is wave-uniform (n4 % 64 == 0)
+        const v4f *a4 = (const v4f *)pa + cb + ht, *b4 = (const v4f *)pb + cb + ht;
+        const int wbase = cb + (ht & ~63);
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const bool in_row = wbase + kBlock * k < n4;  // wave-uniform
+            if (BIGX && a.tail_skip && !in_row) {  // as matvec_row_kernel: out-of-row steps load nothing
+                wa[k] = v4f{0.f, 0.f, 0.f, 0.f};
+                wb[k] = v4f{0.f, 0.f, 0.f, 0.f};
+                continue;
+            }
+            const int off = in_row ? kBlock * k : -(cb + (ht & ~63));
+            wa[k] = ldg_nt(a4 + off);
+            wb[k] = ldg_nt(b4 + off);
+        }
+    };
+    // the epilogue's own inputs: plain buffers of a launch that ended before this one began, or -- the
+    // residual of an overlapped chain -- LL words of an earlier hand-over (epi_prefetch_ll)
+    EpiIn ein = epi_prefetch<EPI>(m, u, ht == 0 && has);
+    EpiIn ein_next = ein;
+    if (has) load(0);
+    duo_stage_x<PRO, GC, LL>(a, m.n, n4_pad, gr, xs, scratch);
+
+    v4f acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
+    float best_v = -INFINITY;
+    int best_i = 0x7fffffff;
+    int b = 0, parity = 0;
+    while (true) {
+        if (has) {
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                const v4f xv = xs4[b * (kBlock * U) + ht + kBlock * k];
+                acc_a = fma4(wa[k], xv, acc_a);
+                acc_b = fma4(wb[k], xv, acc_b);
+            }
+        }
+        const bool unit_done = (b + 1 == n_batches);
+        const int u_next = unit_done ? u + ustride : u;
+        const int b_next = unit_done ? 0 : b + 1;
+        const bool more = has && u_next < n_units;
+        const bool more0 = u_next - half < n_units;  // half 0 of this block (block-uniform: the loop's trip count)
+        if (more) {
+            if (unit_done) {
+                pair_rows<EPI>(m, u_next, pa, pb);
+                ein_next = epi_prefetch<EPI>(m, u_next, ht == 0);
+            }
+            load(b_next * (kBlock * U));
+        }
+        if (unit_done) {
+            float *pp = part + (half * 2 + parity) * (2 * kWaves);
+            if (has) {
+                const float sa = wave_sum(hsum4(acc_a));
+                const float sb = wave_sum(hsum4(acc_b));
+                if (lane == 0) {
+                    pp[hw] = sa;
+                    pp[kWaves + hw] = sb;
+                }
+            }
+            __syncthreads();
+            if (has && ht == 0) {
+                const float ta = ((pp[0] + pp[1]) + pp[2]) + pp[3];
+                const float tb = ((pp[kWaves] + pp[kWaves + 1]) + pp[kWaves + 2]) + pp[kWaves + 3];
+                pair_epilogue<EPI>(m, u, ta, tb, true, ein);
+                if (EPI == EPI_ARGMAX) {
+                    const int ra_ = 2 * u, rb_ = ra_ + 1;
+                    if (ta > best_v || best_i == 0x7fffffff) { best_v = ta; best_i = ra_ + a.row_offset; }
+                    if (rb_ < m.total_rows && tb > best_v) { best_v = tb; best_i = rb_ + a.row_offset; }
+                }
+            }
+            ein = ein_next;
+            parity ^= 1;
+            acc_a = v4f{0.f, 0.f, 0.f, 0.f};
+            acc_b = v4f{0.f, 0.f, 0.f, 0.f};
+        }
+        if (!more0) break;
+        has = more;
+        u = u_next;
+        b = b_next;
+    }
+    if (EPI == EPI_ARGMAX && ht == 0) {  // one candidate per virtual block (units ascend: first index kept)
+        a.part_val[2 * blockIdx.x + half] = best_v;
+        a.part_idx[2 * blockIdx.x + half] = best_i;
+    }
+}
+
 // Generic form: any n, any alignment (the reference's 3x3 / 2x12 known-answer
 // tests land here).  One pair per wave, scalar loads.
 template <int PRO, int EPI>
@@ -590,6 +756,26 @@ const void *mv_row_pick(int pro, int epi, bool big_x, bool ll)
     return nullptr;
 }
 
+template <int PRO, int EPI, bool LL>
+const void *mv_duo_fn(bool big_x)
+{
+    return big_x ? reinterpret_cast<const void *>(&matvec_duo_kernel<PRO, EPI, true, LL>)
+                 : reinterpret_cast<const void *>(&matvec_duo_kernel<PRO, EPI, false, LL>);
+}
+
+// the launches of the overlapped decode chain: qkv, wo / w2, w1|w3, classifier -- x plain or handed over
+const void *mv_duo_pick(int pro, int epi, bool big_x, bool ll)
+{
+#define L2Z_MVD(P, E)                                                  \
+    if (pro == P && epi == E) return ll ? mv_duo_fn<P, E, true>(big_x) : mv_duo_fn<P, E, false>(big_x);
+    L2Z_MVD(PRO_RMS, EPI_ROPE)
+    L2Z_MVD(PRO_NONE, EPI_RESID)
+    L2Z_MVD(PRO_RMS, EPI_SWIGLU)
+    L2Z_MVD(PRO_RMS, EPI_ARGMAX)
+#undef L2Z_MVD
+    return nullptr;
+}
+
 MvLaunch mv_pick_pe(int pro, int epi, int lpr, bool big_x, bool vec, bool ll)
 {
 #define L2Z_MV(P, E)                                                                      \
@@ -651,6 +837,17 @@ bool matvec_vector_width(int n)
 // vector kernels (16-byte aligned operands assumed: every buffer here is a hipMalloc or a row of one)
 bool matvec_ll_supported(int n) { return matvec_vector_width(n); }
 
+// widths matvec_duo_kernel takes: the wide-row kernel's, with x + scratch inside 48 KB of LDS (two such
+// blocks, or one beside any other kernel of the chain, always fit a CU)
+bool matvec_duo_supported(int n)
+{
+    if (n <= 0 || (n % 4) != 0) return false;
+    const int n4 = n >> 2;
+    if (n4 < 1024 || (n4 % 64) != 0 || !tunables().row_kernel) return false;
+    const int n4_pad = ((n4 + 1023) / 1024) * 1024;
+    return (size_t)(4 * n4_pad + kScratch + 8 * kWaves) * sizeof(float) <= 64 * 1024;
+}
+
 hipError_t launch_stream_read(const float *p, size_t n_floats, float *out, int n_cus, hipStream_t st)
 {
     hipLaunchKernelGGL(stream_read_kernel, dim3(n_cus * 8), dim3(256), 0, st, (const v4f *)p, n_floats / 4, out);
@@ -678,6 +875,29 @@ hipError_t launch_matvec(const MatvecArgs &a_in, int pro, int epi, int max_block
     const bool use_row = vec && tn.row_kernel && n4 >= 1024 && (n4 % 64) == 0;
     const bool ll = a.xin.slots != nullptr;
     if (ll && !vec) return hipErrorNotSupported;  // callers ask matvec_ll_supported() first
+    if (a.duo) {  // overlapped decode chain: one 512-thread block per CU (callers ask matvec_duo_supported() first)
+        if (!vec || !matvec_duo_supported(a.n)) return hipErrorNotSupported;
+        const void *fn = mv_duo_pick(pro, epi, a.n > 4096, ll);
+        if (fn == nullptr) return hipErrorNotSupported;
+        const int n4_pad = ((n4 + 1023) / 1024) * 1024;
+        const size_t lds = (size_t)(4 * n4_pad + kScratch + 8 * kWaves) * sizeof(float);
+        int resident = 2 * n_cus;  // virtual blocks (halves): one block of two per CU
+        if (tn.grid_cap > 0 && resident > tn.grid_cap) resident = tn.grid_cap;
+        int vgrid = n_pairs;
+        if (vgrid > resident) {
+            const int per_block = (n_pairs + resident - 1) / resident;
+            vgrid = (n_pairs + per_block - 1) / per_block;
+        }
+        // an even number of virtual blocks, every one with at least one unit
+        if (vgrid & 1) vgrid = (vgrid + 1 <= n_pairs && vgrid + 1 <= resident) ? vgrid + 1 : vgrid - 1;
+        if (vgrid < 2) return hipErrorNotSupported;
+        if (out_grid) *out_grid = vgrid;
+        if (epi == EPI_ROPE || a.rows2 != 0 || (epi != EPI_SWIGLU && a.rows1 != 0) || epi == EPI_ARGMAX) a.push = nullptr;
+        if (pushed) *pushed = a.push != nullptr;
+        a.tail_skip = tn.row_tail_skip;
+        void *args[] = {&a};
+        return hipLaunchKernel(fn, dim3(vgrid / 2), dim3(kDuo), args, lds, st);
+    }
     MvLaunch k = mv_pick_pe(pro, epi, lpr, a.n > 4096, vec, ll);
     if (use_row) k.fn = mv_row_pick(pro, epi, a.n > 4096, ll);
     if (k.fn == nullptr) return hipErrorInvalidValue;

@@ -46,6 +46,12 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
     s->fused_qkv_attn = sh.world == 1 && tn.fuse_small != 0 &&
                         fused_qkv_attn_supported(c.dim, c.n_heads, c.n_kv_heads, c.seq_len, g_cus);
     s->n_gathers = 4 * c.n_layers + 1;
+    // Wide-row models (every mat-vec takes matvec_duo_kernel): 256-thread attention forms at every position -- what
+    // lets a waiting launch of the overlapped chain share a CU with the attention it waits behind.
+    // A function of the MODEL, not of the rank count or the mode, so sharded, unsharded, overlapped and
+    // single-chain passes pick the same form at the same position and keep the same bits.
+    s->attn_all256 = tn.duo != 0 && !s->fused_qkv_attn && matvec_duo_supported(c.dim) &&
+                     matvec_duo_supported(c.hidden_dim);
     if (comm_uses_p2p(comm)) {
         // the producers store straight into the peers' landing slots: they must hold the longest vector
         const size_t longest = (size_t)std::max(std::max(c.dim, c.hidden_dim), c.vocab_size);
@@ -95,8 +101,8 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
         s->attn_split_pos = mode > 0 ? 0 : 256;
         if (tn.attn_split_pos >= 0) s->attn_split_pos = tn.attn_split_pos;
         if (mode == 0 || c.seq_len <= s->attn_split_pos) nch = 0;
-        s->attn_split_wide_pos = attention_split_wide_pos(c.seq_len);
-        s->attn_short_pos = attention_short_pos(sh.hs, c.seq_len);
+        s->attn_split_wide_pos = attention_split_wide_pos(c.seq_len, s->attn_all256);
+        s->attn_short_pos = attention_short_pos(sh.hs, c.seq_len, s->attn_all256);
         if (nch > 1 && s->attn_short_pos > s->attn_split_pos) s->attn_short_pos = s->attn_split_pos;
         if (nch > 1) {
             s->attn_nch = nch;
@@ -119,6 +125,32 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
         comm_p2p_args(comm, s->logits, (size_t)sh.v_loc, false, &t[3]);
         alloc((void **)&s->d_push, sizeof t);
         if (e == hipSuccess) e = hipMemcpy(s->d_push, t, sizeof t, hipMemcpyHostToDevice);
+    }
+    if (sh.world == 1 && s->attn_all256 && e == hipSuccess) {
+        AttnArgs aa = {};
+        aa.q = s->q; aa.kcache = s->key_cache; aa.vcache = s->value_cache;
+        aa.head_size = sh.hs; aa.kv_row = sh.hs; aa.kv_head = (size_t)c.seq_len * sh.hs;
+        s->duo = attention_push_supported(aa);
+    }
+    if (s->duo && tn.overlap != 0 && e == hipSuccess) {
+        // the overlapped chain: a second stream, fork / join events, and this process's own landing slots
+        s->self_comm = comm_self_create(dev, (size_t)std::max(c.dim, c.hidden_dim));
+        if (s->self_comm == nullptr) {
+            l2z_runstate_free(s);
+            return L2Z_ERR_HIP;
+        }
+        P2pArgs t[4];
+        comm_self_args(s->self_comm, s->xb, (size_t)c.dim, &t[0]);
+        comm_self_args(s->self_comm, s->x, (size_t)c.dim, &t[1]);
+        comm_self_args(s->self_comm, s->hb, (size_t)c.hidden_dim, &t[2]);
+        comm_self_args(s->self_comm, s->logits, (size_t)c.vocab_size, &t[3]);  // never pushed: the slots do not hold it
+        alloc((void **)&s->d_push, sizeof t);
+        if (e == hipSuccess) e = hipMemcpy(s->d_push, t, sizeof t, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming);
+        s->ovl = e == hipSuccess;
+        s->ovl_edges = tn.overlap_edges & 15;
     }
     if (e != hipSuccess) {
         set_error("RunState allocation failed: %s", hipGetErrorString(e));
@@ -167,6 +199,13 @@ extern "C" void l2z_runstate_free(l2z_runstate *s)
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->h_stage) (void)hipHostFree(s->h_stage);
+    if (s->stream2) {
+        (void)hipStreamSynchronize(s->stream2);
+        (void)hipStreamDestroy(s->stream2);
+    }
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+    if (s->self_comm) l2z_comm_free(s->self_comm);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -306,5 +345,6 @@ extern "C" int l2z_synchronize(l2z_runstate *s)
     L2Z_HIP(hipSetDevice(s->device));
     L2Z_HIP(hipStreamSynchronize(s->stream));
     L2Z_TRY(comm_check(s->comm));
+    L2Z_TRY(comm_check(s->self_comm));
     return L2Z_OK;
 }

@@ -24,6 +24,14 @@ struct Tunables {
     int attn_short_pos = -1;   // L2Z_ATTN_SHORT_POS  positions below this take the 256-thread one-block-per-head kernel with the
                                //                     speculative first round whatever seq_len is (default: by head size, 0: never)
     int fuse_small = 1;        // L2Z_FUSE_SMALL      0: small models keep separate qkv / attention launches
+    // --- overlapped decode chain (forward.cpp, runstate.cpp) ---
+    int overlap = 1;           // L2Z_OVERLAP         0: one chain of launches on one stream (the duo mat-vecs and the attention
+                               //                     forms by position stay: same bits either way)
+    int overlap_edges = 15;    // L2Z_OVERLAP_EDGES   hand-overs of a layer that are overlapped: bit 0 attention -> wo, 1 wo -> w1|w3,
+                               //                     2 w1|w3 -> w2, 3 w2 -> next qkv / classifier
+    int overlap_hint = 1;      // L2Z_OVERLAP_HINT    0: waiting blocks poll their whole input vector instead of one hint word first
+    int overlap_hint_sleep = 2;  // L2Z_OVERLAP_HINT_SLEEP  s_sleep(8) instructions between polls of the hint word
+    int duo = 1;               // L2Z_DUO             0: wide-row models keep the 256-thread mat-vecs and the attention forms of round 3 (no overlap)
     // --- graphs / transport (runstate.cpp, comm.cpp, forward.cpp) ---
     int no_graph = 0;          // L2Z_NO_GRAPH        1: launch eagerly
     int comm_graph = 1;        // L2Z_COMM_GRAPH      0: RCCL collectives are launched eagerly, not captured

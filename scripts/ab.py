@@ -31,7 +31,19 @@ for v in variants:
     for k in kv:  # back to the default for the next variant (options apply at RunState creation)
         B.option_set(k, {"L2Z_ATTN_SPLIT": -1, "L2Z_ATTN_SPLIT_POS": -1, "L2Z_ATTN_SHORT_POS": -1, "L2Z_ATTN_SPLIT_WIDE_POS": -1, "L2Z_ROW_TAIL_SKIP": 1, "L2Z_ROW_BLOCKS": 2, "L2Z_ATTN_BLOCK": 0,
                          "L2Z_FUSE_SMALL": 1, "L2Z_NO_GRAPH": 0, "L2Z_ROW_KERNEL": 1,
-                         "L2Z_MAX_BLOCKS_PER_CU": 8}.get(k, 0))
+                         "L2Z_MAX_BLOCKS_PER_CU": 8, "L2Z_OVERLAP": 1, "L2Z_OVERLAP_EDGES": 15, "L2Z_OVERLAP_HINT": 1,
+                         "L2Z_OVERLAP_HINT_SLEEP": 2, "L2Z_DUO": 1}.get(k, 0))
+# the variants' arithmetic side by side: logits of one pass at pos0 and the first greedy tokens, against variant 0
+ref_logits = ref_toks = None
+for v, s in zip(variants, states):
+    B.option_set("L2Z_PREFILL", 0)
+    s.greedy_begin(list(range(2, 2 + pos0)) if pos0 else [])
+    toks = np.array(s.greedy_run(w, pos0 + 24))
+    s.transformer(7, pos0, w); lg = s.logits().copy()
+    if ref_logits is None:
+        ref_logits, ref_toks = lg, toks
+    print(f"  [{v or 'defaults'}] logits == variant 0: {bool(np.array_equal(lg, ref_logits))} (max |d| {float(np.abs(lg - ref_logits).max()):.3g}), "
+          f"tokens == variant 0: {bool(np.array_equal(toks, ref_toks))}", flush=True)
 res = [[] for _ in variants]
 for r in range(rounds + 1):
     for i, s in enumerate(states):
