@@ -277,6 +277,13 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         s->n_part = fuse ? grid : 0;
     }
     L2Z_TRY(gather(s->logits, sh.v_loc));
+    if (ovl) {
+        // Join BEFORE the hand-over: the argmax launch writes the next step's x, token and pos -- plain buffers the
+        // launches of both chains read or wrote -- and closes the pass's epochs, so it runs behind every launch of
+        // the pass (the chain it is not in has long drained: the classifier consumed that chain's last vector).
+        L2Z_HIP(hipEventRecord(s->ev_join, sts[chain ^ 1]));
+        L2Z_HIP(hipStreamWaitEvent(sts[chain], s->ev_join, 0));
+    }
     if (with_step && want() && kind(KIND_ARGMAX)) {
         ArgmaxArgs a = {};
         a.logits = s->logits; a.vocab = c.vocab_size; a.token_ptr = s->d_token;
@@ -289,9 +296,9 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
     } else if (ovl) {
         L2Z_HIP(launch_epoch_advance(lc->d_ctl, n_g, st));
     }
-    if (ovl) {  // join: the runstate's stream continues behind both chains
-        L2Z_HIP(hipEventRecord(s->ev_join, sts[1]));
-        L2Z_HIP(hipStreamWaitEvent(sts[0], s->ev_join, 0));
+    if (ovl && chain == 1) {  // the pass ended in the second chain: the runstate's stream continues behind it
+        L2Z_HIP(hipEventRecord(s->ev_tail, sts[1]));
+        L2Z_HIP(hipStreamWaitEvent(sts[0], s->ev_tail, 0));
     }
     return L2Z_OK;
 }

@@ -124,7 +124,7 @@ struct l2z_runstate {
     int ovl_edges = 0;             // which hand-overs of a layer are overlapped (bit 0 attn->wo, 1 wo->w1|w3, 2 w1|w3->w2, 3 w2->qkv/cls)
     l2z_comm *self_comm = nullptr; // owned: arena, epoch counter, error latch of the hand-overs
     hipStream_t stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_tail = nullptr;
 };
 
 namespace l2z {

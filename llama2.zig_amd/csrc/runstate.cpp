@@ -149,6 +149,7 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_tail, hipEventDisableTiming);
         s->ovl = e == hipSuccess;
         s->ovl_edges = tn.overlap_edges & 15;
     }
@@ -205,6 +206,7 @@ extern "C" void l2z_runstate_free(l2z_runstate *s)
     }
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     if (s->ev_join) (void)hipEventDestroy(s->ev_join);
+    if (s->ev_tail) (void)hipEventDestroy(s->ev_tail);
     if (s->self_comm) l2z_comm_free(s->self_comm);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
