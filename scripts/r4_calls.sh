@@ -24,4 +24,25 @@ timeout 900 python -m pytest tests -m gpu -q -x -k "transformer or greedy or gol
 echo "pytest rc=$?" >> $O/r04a_pytest_gpu.log
 tail -n 15 $O/r04a_pytest_gpu.log
 ;;
+b)
+# round 4, GPU call B: WHERE the overlapped chain loses -- rocprofv3 kernel timelines (start / end per launch and
+# queue) of four modes, per-kind durations duo vs row kernel, and the polling period
+export L2Z_P2P_TIMEOUT_S=3
+cd /tmp
+i=0
+for mode in "" "L2Z_OVERLAP_EDGES=8" "L2Z_OVERLAP=0" "L2Z_DUO=0"; do
+  i=$((i+1))
+  rm -rf /tmp/tl_$i
+  env $mode rocprofv3 --kernel-trace -d /tmp/tl_$i -o t -- python $GRAFT_REPO_ROOT/scripts/decode_steps.py llama2-7b 12 > /tmp/tl_$i.log 2>&1 || tail -5 /tmp/tl_$i.log
+  tail -n 1 /tmp/tl_$i.log
+  python $GRAFT_REPO_ROOT/scripts/timeline_report.py $(find /tmp/tl_$i -name "*.db" | head -1) "round 4 (r04b): [${mode:-defaults}] rocprofv3 --kernel-trace -- python scripts/decode_steps.py llama2-7b 12" > $GRAFT_REPO_ROOT/$O/r04b_timeline_$i.md 2>&1
+done
+cd $GRAFT_REPO_ROOT
+cat $O/r04b_timeline_*.md
+{
+timeout 200 python scripts/kind_ab.py llama2-7b 8 "" "L2Z_DUO=0"
+timeout 300 python scripts/ab.py llama2-7b 128 3 "L2Z_OVERLAP_HINT_SLEEP=6" "L2Z_OVERLAP_HINT_SLEEP=32" "L2Z_OVERLAP_EDGES=8,L2Z_OVERLAP_HINT_SLEEP=6" "L2Z_OVERLAP_EDGES=8,L2Z_OVERLAP_HINT_SLEEP=32" "L2Z_OVERLAP_EDGES=8,L2Z_OVERLAP_HINT_SLEEP=200"
+} > $O/r04b_ab.txt 2>&1
+cat $O/r04b_ab.txt
+;;
 esac
