@@ -589,7 +589,6 @@ __global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
         }
     }
     int u = 2 * blockIdx.x + half;
-    bool has = u < n_units;
     const float *pa, *pb;
     pair_rows<EPI>(m, u, pa, pb);   // clamped to the last pair when the half has no unit
     v4f wa[U], wb[U];
@@ -610,30 +609,32 @@ __global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
         }
     };
     // the epilogue's own inputs: plain buffers of a launch that ended before this one began, or -- the
-    // residual of an overlapped chain -- LL words of an earlier hand-over (epi_prefetch_ll)
-    EpiIn ein = epi_prefetch<EPI>(m, u, ht == 0 && has);
+    // residual of an overlapped chain -- LL words of an earlier hand-over (EpiIn::rw)
+    EpiIn ein = epi_prefetch<EPI>(m, u, ht == 0);
     EpiIn ein_next = ein;
-    if (has) load(0);
+    load(0);
     duo_stage_x<PRO, GC, LL>(a, m.n, n4_pad, gr, xs, scratch);
 
+    // The loop is the row kernel's, with one difference: its trip count is half 0's (block-uniform: the
+    // barrier), so in the last sweep a half without a unit runs one unit's FMAs on whatever its registers
+    // hold and skips the epilogue -- no branch around the loads or the FMAs (a conditional consume kept
+    // hipcc from hoisting the next batch's loads above it: 72-82 VGPRs, one batch in flight, 4-9 % slower).
     v4f acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
     float best_v = -INFINITY;
     int best_i = 0x7fffffff;
     int b = 0, parity = 0;
     while (true) {
-        if (has) {
 #pragma unroll
-            for (int k = 0; k < U; k++) {
-                const v4f xv = xs4[b * (kBlock * U) + ht + kBlock * k];
-                acc_a = fma4(wa[k], xv, acc_a);
-                acc_b = fma4(wb[k], xv, acc_b);
-            }
+        for (int k = 0; k < U; k++) {
+            const v4f xv = xs4[b * (kBlock * U) + ht + kBlock * k];
+            acc_a = fma4(wa[k], xv, acc_a);
+            acc_b = fma4(wb[k], xv, acc_b);
         }
         const bool unit_done = (b + 1 == n_batches);
         const int u_next = unit_done ? u + ustride : u;
         const int b_next = unit_done ? 0 : b + 1;
-        const bool more = has && u_next < n_units;
-        const bool more0 = u_next - half < n_units;  // half 0 of this block (block-uniform: the loop's trip count)
+        const bool more = u_next < n_units;
+        const bool more0 = u_next - half < n_units;  // half 0 of this block
         if (more) {
             if (unit_done) {
                 pair_rows<EPI>(m, u_next, pa, pb);
@@ -642,17 +643,15 @@ __global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
             load(b_next * (kBlock * U));
         }
         if (unit_done) {
+            const float sa = wave_sum(hsum4(acc_a));
+            const float sb = wave_sum(hsum4(acc_b));
             float *pp = part + (half * 2 + parity) * (2 * kWaves);
-            if (has) {
-                const float sa = wave_sum(hsum4(acc_a));
-                const float sb = wave_sum(hsum4(acc_b));
-                if (lane == 0) {
-                    pp[hw] = sa;
-                    pp[kWaves + hw] = sb;
-                }
+            if (lane == 0) {
+                pp[hw] = sa;
+                pp[kWaves + hw] = sb;
             }
             __syncthreads();
-            if (has && ht == 0) {
+            if (ht == 0 && u < n_units) {
                 const float ta = ((pp[0] + pp[1]) + pp[2]) + pp[3];
                 const float tb = ((pp[kWaves] + pp[kWaves + 1]) + pp[kWaves + 2]) + pp[kWaves + 3];
                 pair_epilogue<EPI>(m, u, ta, tb, true, ein);
@@ -668,7 +667,6 @@ __global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
             acc_b = v4f{0.f, 0.f, 0.f, 0.f};
         }
         if (!more0) break;
-        has = more;
         u = u_next;
         b = b_next;
     }

@@ -45,4 +45,16 @@ timeout 300 python scripts/ab.py llama2-7b 128 3 "L2Z_OVERLAP_HINT_SLEEP=6" "L2Z
 } > $O/r04b_ab.txt 2>&1
 cat $O/r04b_ab.txt
 ;;
+c)
+# round 4, GPU call C: (1) what a merely RESIDENT kernel in another HW queue costs a chain of streaming launches
+# (scripts/coresident_probe.hip); (2) the duo mat-vec without the conditional consume: per-kind durations and A/B
+hipcc --offload-arch=gfx950 -O3 -o /tmp/coresident_probe scripts/coresident_probe.hip && timeout 120 /tmp/coresident_probe > $O/r04c_coresident_probe.txt 2>&1
+cat $O/r04c_coresident_probe.txt
+export L2Z_P2P_TIMEOUT_S=3
+{
+timeout 200 python scripts/kind_ab.py llama2-7b 8 "" "L2Z_DUO=0"
+timeout 300 python scripts/ab.py llama2-7b 128 3 "" "L2Z_OVERLAP=0" "L2Z_DUO=0"
+} > $O/r04c_ab.txt 2>&1
+cat $O/r04c_ab.txt
+;;
 esac
