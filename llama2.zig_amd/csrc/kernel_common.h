@@ -354,8 +354,33 @@ __device__ __forceinline__ void ll_hint_wait(const LLPoll &p, const LLIn &in)
     }
 }
 
+// plain x: this thread's first GC float4 (zero past the end), issued ahead of the weight stream
+template <int GC>
+__device__ __forceinline__ void duo_xload(const float *__restrict__ x, int n4, v4f (&xr)[GC])
+{
+    const v4f *x4 = (const v4f *)x;
+#pragma unroll
+    for (int k = 0; k < GC; k++) {
+        const int j = threadIdx.x + kDuo * k;
+        xr[k] = (j < n4) ? x4[j] : v4f{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// one lane: until *word carries id (bounded like every wait here; giving up only costs the pacing)
+__device__ __forceinline__ void ll_word_wait(const unsigned long long *word, unsigned id, const LLIn &in)
+{
+    const long long t0 = wall_clock64();
+    for (;;) {
+        const unsigned long long w = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((unsigned)(w >> 32) == id) break;
+        if (__hip_atomic_load(in.ctl + kCtlErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        if (wall_clock64() - t0 > in.timeout_ticks) break;
+        for (int i = 0; i < in.hint_sleep; i++) __builtin_amdgcn_s_sleep(8);
+    }
+}
+
 template <int PRO, int GC, bool LL>
-__device__ __forceinline__ void duo_stage_x(const MatvecArgs &a, int n, int n4_pad, v4f (&gr)[GC],
+__device__ __forceinline__ void duo_stage_x(const MatvecArgs &a, int n, int n4_pad, v4f (&gr)[GC], v4f (&xr)[LL ? 1 : GC],
                                             float *xs, float *scratch)
 {
     const int tid = threadIdx.x;
@@ -388,8 +413,15 @@ __device__ __forceinline__ void duo_stage_x(const MatvecArgs &a, int n, int n4_p
             }
         }
     } else {
+        // xr[]: this thread's float4 tid + 512 k of x, requested BEFORE the first weight batch (duo_xload: VMEM
+        // returns in order, x must not queue behind 8 KB of weights per wave)
         const v4f *x4 = (const v4f *)a.x;
-        for (int j = tid; j < n4_pad; j += kDuo) xs4[j] = j < n4 ? x4[j] : zero;
+#pragma unroll
+        for (int k = 0; k < (LL ? 1 : GC); k++) {
+            const int j = tid + kDuo * k;
+            if (j < n4_pad) xs4[j] = xr[k];
+        }
+        for (int j = tid + kDuo * GC; j < n4_pad; j += kDuo) xs4[j] = j < n4 ? x4[j] : zero;
     }
     __syncthreads();
     if (PRO == PRO_RMS) {

@@ -578,8 +578,9 @@ __global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
     const int n_units = m.n_pairs;
     const int ustride = 2 * gridDim.x;            // virtual grid: 2 * gridDim.x <= n_units
 
-    constexpr int GC = BIGX ? 6 : 2;              // rmsnorm weights of this thread (n <= GC * 2048)
-    v4f gr[GC];
+    constexpr int GC = BIGX ? 6 : 2;              // x / rmsnorm weights of this thread held in registers (n <= GC * 2048)
+    v4f gr[GC], xr[LL ? 1 : GC];
+    if constexpr (!LL) duo_xload<GC>(a.x, n4, xr);
     if (PRO == PRO_RMS) {
         const v4f *g4 = (const v4f *)a.rms_w;
 #pragma unroll
@@ -612,8 +613,17 @@ __global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
     // residual of an overlapped chain -- LL words of an earlier hand-over (EpiIn::rw)
     EpiIn ein = epi_prefetch<EPI>(m, u, ht == 0);
     EpiIn ein_next = ein;
+    if constexpr (LL) {
+        if (a.pace_words != nullptr && a.defer_kind >= 0) {  // run-ahead pacing: not before the launch ahead of this one streams
+            if (tid == 0)
+                ll_word_wait(a.pace_words + 16 * a.defer_kind + (blockIdx.x & 15),
+                             (unsigned)(a.pace_ctl[kCtlEpoch] + a.defer_off), a.xin);
+            __syncthreads();
+        }
+    }
     load(0);
-    duo_stage_x<PRO, GC, LL>(a, m.n, n4_pad, gr, xs, scratch);
+    duo_stage_x<PRO, GC, LL>(a, m.n, n4_pad, gr, xr, xs, scratch);
+    bool first_unit = a.pace_words != nullptr && a.mark_kind >= 0 && 2 * blockIdx.x + half < 16;
 
     // The loop is the row kernel's, with one difference: its trip count is half 0's (block-uniform: the
     // barrier), so in the last sweep a half without a unit runs one unit's FMAs on whatever its registers
@@ -660,7 +670,12 @@ __global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
                     if (ta > best_v || best_i == 0x7fffffff) { best_v = ta; best_i = ra_ + a.row_offset; }
                     if (rb_ < m.total_rows && tb > best_v) { best_v = tb; best_i = rb_ + a.row_offset; }
                 }
+                if (first_unit)  // this launch streams: later launches may request their weights now
+                    __hip_atomic_store(a.pace_words + 16 * a.mark_kind + 2 * blockIdx.x + half,
+                                       ((unsigned long long)(unsigned)(a.pace_ctl[kCtlEpoch] + a.mark_off) << 32) | 1ull,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
+            first_unit = false;
             ein = ein_next;
             parity ^= 1;
             acc_a = v4f{0.f, 0.f, 0.f, 0.f};

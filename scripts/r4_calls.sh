@@ -57,4 +57,13 @@ timeout 300 python scripts/ab.py llama2-7b 128 3 "" "L2Z_OVERLAP=0" "L2Z_DUO=0"
 } > $O/r04c_ab.txt 2>&1
 cat $O/r04c_ab.txt
 ;;
+d)
+# round 4, GPU call D: duo staging with x requested ahead of the weights; hint one sweep early; paced run-ahead
+export L2Z_P2P_TIMEOUT_S=3
+{
+timeout 200 python scripts/kind_ab.py llama2-7b 8 "" "L2Z_DUO=0"
+timeout 400 python scripts/ab.py llama2-7b 128 3 "" "L2Z_OVERLAP_DEFER=0" "L2Z_OVERLAP_HINT_BACK=0" "L2Z_OVERLAP_DEFER=0,L2Z_OVERLAP_HINT_BACK=0" "L2Z_OVERLAP_HINT_BACK=2" "L2Z_OVERLAP_EDGES=1" "L2Z_OVERLAP_EDGES=9" "L2Z_OVERLAP=0" "L2Z_DUO=0"
+} > $O/r04d_ab.txt 2>&1
+cat $O/r04d_ab.txt
+;;
 esac
