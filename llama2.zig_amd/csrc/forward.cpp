@@ -69,15 +69,12 @@ int check_pair(const l2z_config *config, const l2z_runstate *s, const l2z_weight
 struct Hint { unsigned h0 = 0, n = 0, stride = 0; };
 
 // the elements a mat-vec producer writes in its last sweep over the units (virtual grid vgrid)
-static Hint mv_hint(int n_pairs, int vgrid, int epi, int back)
+static Hint mv_hint(int n_pairs, int vgrid, int epi)
 {
     Hint h;
     if (vgrid <= 0 || n_pairs <= 0) return h;
-    int u0 = ((n_pairs - 1) / vgrid) * vgrid;
+    const int u0 = ((n_pairs - 1) / vgrid) * vgrid;
     h.n = (unsigned)(n_pairs - u0);
-    // `back` sweeps earlier: the blocks then sweep the vector while the producer's last sweep is still running
-    // and only the threads that hold its last elements keep polling (every word validates itself)
-    for (int i = 0; i < back && u0 >= vgrid; i++) { u0 -= vgrid; h.n = (unsigned)vgrid; }
     if (epi == EPI_SWIGLU) { h.h0 = (unsigned)u0; h.stride = 1; }
     else { h.h0 = (unsigned)(2 * u0 + 1); h.stride = 2; }
     return h;
@@ -168,18 +165,6 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         }
         if (consume && g >= 1) a.xin = comm_ll_in(s->comm, g, count_per_rank);
     };
-    // run-ahead pacing (MatvecArgs::pace_words): the launch of kind k (0 qkv, 1 wo, 2 w1|w3, 3 w2) of layer l announces
-    // that it streams as id ctl[0] + 4 l + 1 in its kind's words; a launch whose input is handed over requests its
-    // first weight batch only once launch (after, after_layer) has announced itself -- the launch that is collecting
-    // its own input at the moment this one becomes resident
-    auto pace = [&](MatvecArgs &a, int k, int l, int after, int after_layer) {
-        a.mark_kind = a.defer_kind = -1;
-        if (!ovl || !tn.overlap_defer) return;
-        a.pace_words = reinterpret_cast<unsigned long long *>(lc->arena);  // the arena's reserved head
-        a.pace_ctl = lc->d_ctl;
-        if (k >= 0) { a.mark_kind = k; a.mark_off = 4 * l + 1; }
-        if (after >= 0 && after_layer >= 0 && a.xin.slots != nullptr) { a.defer_kind = after; a.defer_off = 4 * after_layer + 1; }
-    };
     auto push_to = [&](MatvecArgs &a, int which) {
         if (!can_push) return;
         a.push = s->d_push + which;
@@ -215,7 +200,6 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.n = c.dim; a.rms_w = w->rms_att + (size_t)l * dim;
             x_in(a, s->x, gi, sh.dim_loc, 8u);  // layer 0: the embedding row, a plain buffer (gi == 0)
             a.pos_ptr = s->d_pos; a.rope = s->rope; a.head_size = sh.hs; a.rope_segs = 2;
-            pace(a, 0, l, 3, l - 1);
             L2Z_LAUNCH(KIND_QKV, launch_matvec(a, PRO_RMS, EPI_ROPE, mb, g_cus, st));
         }
         if (!fused && want() && kind(KIND_ATTN)) {   // attention (:361-389) over the local heads
@@ -245,10 +229,9 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             x_in(a, s->xb, gi, sh.dim_loc, 1u);
             if (ovl && gi >= 2) a.resid_in = comm_ll_in(lc, gi - 1, sh.dim_loc);  // x as the previous layer's w2 handed it over
             push_to(a, 1);
-            pace(a, 1, l, 0, l);
             int vg = 0;
             L2Z_LAUNCH(KIND_WO, launch_matvec(a, PRO_NONE, EPI_RESID, mb, g_cus, st, &vg, &pushed));
-            hint = mv_hint((sh.dim_loc + 1) / 2, vg, EPI_RESID, tn.overlap_hint_back);
+            hint = mv_hint((sh.dim_loc + 1) / 2, vg, EPI_RESID);
         }
         L2Z_TRY(gather(s->x, sh.dim_loc));
         if (want() && kind(KIND_FFN13)) {   // rmsnorm (:398) + w1,w3 (:405-408) + SiLU*mul (:411-416)
@@ -260,10 +243,9 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.rms_w = w->rms_ffn + (size_t)l * dim;
             x_in(a, s->x, gi, sh.dim_loc, 2u);
             push_to(a, 2);
-            pace(a, 2, l, 1, l);
             int vg = 0;
             L2Z_LAUNCH(KIND_FFN13, launch_matvec(a, PRO_RMS, EPI_SWIGLU, mb, g_cus, st, &vg, &pushed));
-            hint = mv_hint(sh.hid_loc, vg, EPI_SWIGLU, tn.overlap_hint_back);
+            hint = mv_hint(sh.hid_loc, vg, EPI_SWIGLU);
         }
         L2Z_TRY(gather(s->hb, sh.hid_loc));
         if (want() && kind(KIND_FFN2)) {   // w2 (:419) + residual (:422)
@@ -274,10 +256,9 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             x_in(a, s->hb, gi, sh.hid_loc, 4u);
             if (ovl) a.resid_in = comm_ll_in(lc, gi - 1, sh.dim_loc);  // x as this layer's wo handed it over
             push_to(a, 1);
-            pace(a, 3, l, 2, l);
             int vg = 0;
             L2Z_LAUNCH(KIND_FFN2, launch_matvec(a, PRO_NONE, EPI_RESID, mb, g_cus, st, &vg, &pushed));
-            hint = mv_hint((sh.dim_loc + 1) / 2, vg, EPI_RESID, tn.overlap_hint_back);
+            hint = mv_hint((sh.dim_loc + 1) / 2, vg, EPI_RESID);
         }
         L2Z_TRY(gather(s->x, sh.dim_loc));
     }
@@ -291,7 +272,6 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         const bool fuse = sh.world == 1 && matvec_vector_width(c.dim);
         int grid = 0;
         if (!ovl) push_to(a, 3);
-        pace(a, -1, 0, 3, c.n_layers - 1);
         L2Z_LAUNCH(KIND_CLS, launch_matvec(a, PRO_RMS, fuse ? EPI_ARGMAX : EPI_STORE, mb, g_cus, st,
                                            &grid, &pushed));
         s->n_part = fuse ? grid : 0;

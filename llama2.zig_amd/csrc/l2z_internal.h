@@ -136,15 +136,6 @@ struct MatvecArgs {
     // (the launch that wrote the plain buffer may be in the other chain); slots == null: plain `resid`
     LLIn resid_in;
     int duo;                  // 1: matvec_duo_kernel (512-thread blocks, one per CU; wide rows only)
-    // Overlapped chain, pacing of the run-ahead.  A launch becomes resident the moment the launch
-    // two before it ends -- exactly while the launch just before it is collecting ITS input -- and a 64 KB burst
-    // of weight requests per CU at that moment queues ahead of that collection.  So a launch announces that it is
-    // streaming (mark: its first 16 virtual blocks store {id} after their first unit) and the run-ahead of a
-    // later launch waits for that announcement (defer) before it requests its first weight batch.
-    unsigned long long *pace_words;  // [4 kinds][16] announcement words (null: no pacing)
-    const int *pace_ctl;             // l2z_comm::d_ctl: ids are ctl[kCtlEpoch] + offset
-    int mark_kind, mark_off;         // this launch announces itself in pace_words[16 * mark_kind ...] (kind < 0: not)
-    int defer_kind, defer_off;       // ... and requests its first weight batch once that launch has (kind < 0: at once)
     int tail_skip;            // row kernel, n > 4096: out-of-row steps of a row's last batch load nothing (set by the launcher)
 };
 

@@ -171,9 +171,11 @@ __device__ __forceinline__ EpiIn epi_prefetch(const MvLocals &m, int p, bool wri
     return e;
 }
 
+// stash != null (duo kernel of an overlapped chain): the values that would be pushed as LL words are left in
+// stash[0], stash[1] instead and pushed by the block when its units are done (matvec_duo_kernel)
 template <int EPI>
 __device__ __forceinline__ void pair_epilogue(const MvLocals &m, int p, float sa, float sb,
-                                              bool writer, const EpiIn &in)
+                                              bool writer, const EpiIn &in, float *stash = nullptr)
 {
     const bool valid_a = p < m.n_pairs;
     if (EPI == EPI_SWIGLU) {
@@ -182,7 +184,8 @@ __device__ __forceinline__ void pair_epilogue(const MvLocals &m, int p, float sa
         v = v * sb;                          // :416
         if (writer && valid_a) {
             m.out0[p] = v;
-            if (m.push) p2p_ll_push(m.push, m.push_e, m.push_base + (size_t)p, v);
+            if (stash) stash[0] = v;
+            else if (m.push) p2p_ll_push(m.push, m.push_e, m.push_base + (size_t)p, v);
         }
         return;
     }
@@ -237,7 +240,10 @@ __device__ __forceinline__ void pair_epilogue(const MvLocals &m, int p, float sa
             const float va = ra + sa, vb = rb + sb;  // :711 a[i] += b[i]  (resid[row] prefetched)
             oa[row_a] = va;
             if (valid_b) ob[row_b] = vb;
-            if (m.push) {  // single segment on this path: row == index in the slice
+            if (stash) {
+                stash[0] = va;
+                stash[1] = vb;
+            } else if (m.push) {  // single segment on this path: row == index in the slice
                 p2p_ll_push(m.push, m.push_e, m.push_base + (size_t)row_a, va);
                 if (valid_b) p2p_ll_push(m.push, m.push_e, m.push_base + (size_t)row_b, vb);
             }
@@ -561,6 +567,8 @@ __global__ __launch_bounds__(kBlock) void matvec_row_kernel(const MatvecArgs a)
 //   for the hint word, then everybody sweeps the vector.
 // rmsnorm: the sum of squares is formed by threads 0..255 in the 256-thread kernel's order.
 // ---------------------------------------------------------------------------
+constexpr int kDuoStash = 64;  // units per half whose outputs wait in LDS for the block's hand-over (more: pushed as they come)
+
 template <int PRO, int EPI, bool BIGX, bool LL>
 __global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
 {
@@ -613,17 +621,8 @@ __global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
     // residual of an overlapped chain -- LL words of an earlier hand-over (EpiIn::rw)
     EpiIn ein = epi_prefetch<EPI>(m, u, ht == 0);
     EpiIn ein_next = ein;
-    if constexpr (LL) {
-        if (a.pace_words != nullptr && a.defer_kind >= 0) {  // run-ahead pacing: not before the launch ahead of this one streams
-            if (tid == 0)
-                ll_word_wait(a.pace_words + 16 * a.defer_kind + (blockIdx.x & 15),
-                             (unsigned)(a.pace_ctl[kCtlEpoch] + a.defer_off), a.xin);
-            __syncthreads();
-        }
-    }
     load(0);
     duo_stage_x<PRO, GC, LL>(a, m.n, n4_pad, gr, xr, xs, scratch);
-    bool first_unit = a.pace_words != nullptr && a.mark_kind >= 0 && 2 * blockIdx.x + half < 16;
 
     // The loop is the row kernel's, with one difference: its trip count is half 0's (block-uniform: the
     // barrier), so in the last sweep a half without a unit runs one unit's FMAs on whatever its registers
@@ -632,7 +631,9 @@ __global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
     v4f acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
     float best_v = -INFINITY;
     int best_i = 0x7fffffff;
-    int b = 0, parity = 0;
+    int b = 0, parity = 0, k_unit = 0;
+    float *stash = part + 4 * (2 * kWaves);       // [half][kDuoStash][2] outputs waiting for the hand-over
+    const bool stash_on = m.push != nullptr && (EPI == EPI_RESID || EPI == EPI_SWIGLU);
     while (true) {
 #pragma unroll
         for (int k = 0; k < U; k++) {
@@ -664,18 +665,15 @@ __global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
             if (ht == 0 && u < n_units) {
                 const float ta = ((pp[0] + pp[1]) + pp[2]) + pp[3];
                 const float tb = ((pp[kWaves] + pp[kWaves + 1]) + pp[kWaves + 2]) + pp[kWaves + 3];
-                pair_epilogue<EPI>(m, u, ta, tb, true, ein);
+                float *st = (stash_on && k_unit < kDuoStash) ? stash + (half * kDuoStash + k_unit) * 2 : nullptr;
+                pair_epilogue<EPI>(m, u, ta, tb, true, ein, st);
                 if (EPI == EPI_ARGMAX) {
                     const int ra_ = 2 * u, rb_ = ra_ + 1;
                     if (ta > best_v || best_i == 0x7fffffff) { best_v = ta; best_i = ra_ + a.row_offset; }
                     if (rb_ < m.total_rows && tb > best_v) { best_v = tb; best_i = rb_ + a.row_offset; }
                 }
-                if (first_unit)  // this launch streams: later launches may request their weights now
-                    __hip_atomic_store(a.pace_words + 16 * a.mark_kind + 2 * blockIdx.x + half,
-                                       ((unsigned long long)(unsigned)(a.pace_ctl[kCtlEpoch] + a.mark_off) << 32) | 1ull,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
-            first_unit = false;
+            k_unit++;
             ein = ein_next;
             parity ^= 1;
             acc_a = v4f{0.f, 0.f, 0.f, 0.f};
@@ -684,6 +682,25 @@ __global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
         if (!more0) break;
         u = u_next;
         b = b_next;
+    }
+    if (stash_on) {
+        // The hand-over, once per block: lane k of each half's first wave stores the LL words of the half's k-th unit.
+        // Per-unit pushes sat in the streaming waves' own memory queue -- a system-scope store is acknowledged by the
+        // memory, microseconds under a saturated stream, and the wave's next wait on its weight loads is behind it.
+        __syncthreads();
+        const int u0 = 2 * blockIdx.x + half;
+        if (ht < kDuoStash) {
+            const int uk = u0 + ht * ustride;
+            if (uk < n_units) {
+                const float *sv = stash + (half * kDuoStash + ht) * 2;
+                if (EPI == EPI_SWIGLU) {
+                    p2p_ll_push(m.push, m.push_e, m.push_base + (size_t)uk, sv[0]);
+                } else {
+                    p2p_ll_push(m.push, m.push_e, m.push_base + (size_t)(2 * uk), sv[0]);
+                    if (2 * uk + 1 < m.total_rows) p2p_ll_push(m.push, m.push_e, m.push_base + (size_t)(2 * uk + 1), sv[1]);
+                }
+            }
+        }
     }
     if (EPI == EPI_ARGMAX && ht == 0) {  // one candidate per virtual block (units ascend: first index kept)
         a.part_val[2 * blockIdx.x + half] = best_v;
@@ -858,7 +875,7 @@ bool matvec_duo_supported(int n)
     const int n4 = n >> 2;
     if (n4 < 1024 || (n4 % 64) != 0 || !tunables().row_kernel) return false;
     const int n4_pad = ((n4 + 1023) / 1024) * 1024;
-    return (size_t)(4 * n4_pad + kScratch + 8 * kWaves) * sizeof(float) <= 64 * 1024;
+    return (size_t)(4 * n4_pad + kScratch + 8 * kWaves + 4 * kDuoStash) * sizeof(float) <= 64 * 1024;
 }
 
 hipError_t launch_stream_read(const float *p, size_t n_floats, float *out, int n_cus, hipStream_t st)
@@ -893,7 +910,7 @@ hipError_t launch_matvec(const MatvecArgs &a_in, int pro, int epi, int max_block
         const void *fn = mv_duo_pick(pro, epi, a.n > 4096, ll);
         if (fn == nullptr) return hipErrorNotSupported;
         const int n4_pad = ((n4 + 1023) / 1024) * 1024;
-        const size_t lds = (size_t)(4 * n4_pad + kScratch + 8 * kWaves) * sizeof(float);
+        const size_t lds = (size_t)(4 * n4_pad + kScratch + 8 * kWaves + 4 * kDuoStash) * sizeof(float);
         int resident = 2 * n_cus;  // virtual blocks (halves): one block of two per CU
         if (tn.grid_cap > 0 && resident > tn.grid_cap) resident = tn.grid_cap;
         int vgrid = n_pairs;

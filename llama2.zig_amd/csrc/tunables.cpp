@@ -31,8 +31,6 @@ Tunables read_env()
     env_int("L2Z_OVERLAP_EDGES", &t.overlap_edges);
     env_int("L2Z_OVERLAP_HINT", &t.overlap_hint);
     env_int("L2Z_OVERLAP_HINT_SLEEP", &t.overlap_hint_sleep);
-    env_int("L2Z_OVERLAP_HINT_BACK", &t.overlap_hint_back);
-    env_int("L2Z_OVERLAP_DEFER", &t.overlap_defer);
     env_int("L2Z_DUO", &t.duo);
     env_int("L2Z_NO_GRAPH", &t.no_graph);
     env_int("L2Z_COMM_GRAPH", &t.comm_graph);
@@ -100,7 +98,6 @@ bool tunables_set(const char *name, long long v)
         {"L2Z_FUSE_SMALL", &t.fuse_small}, {"L2Z_NO_GRAPH", &t.no_graph},
         {"L2Z_OVERLAP", &t.overlap}, {"L2Z_OVERLAP_EDGES", &t.overlap_edges}, {"L2Z_OVERLAP_HINT", &t.overlap_hint},
         {"L2Z_OVERLAP_HINT_SLEEP", &t.overlap_hint_sleep}, {"L2Z_DUO", &t.duo},
-        {"L2Z_OVERLAP_HINT_BACK", &t.overlap_hint_back}, {"L2Z_OVERLAP_DEFER", &t.overlap_defer},
         {"L2Z_COMM_GRAPH", &t.comm_graph}, {"L2Z_COMM_RCCL", &t.prefer_rccl},
         {"L2Z_P2P_PUSH", &t.p2p_push}, {"L2Z_P2P_CONSUME", &t.p2p_consume},
         {"L2Z_P2P_BULK_MB", &t.p2p_bulk_mb},

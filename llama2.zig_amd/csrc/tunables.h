@@ -31,8 +31,6 @@ struct Tunables {
                                //                     2 w1|w3 -> w2, 3 w2 -> next qkv / classifier
     int overlap_hint = 1;      // L2Z_OVERLAP_HINT    0: waiting blocks poll their whole input vector instead of one hint word first
     int overlap_hint_sleep = 2;  // L2Z_OVERLAP_HINT_SLEEP  s_sleep(8) instructions between polls of the hint word
-    int overlap_hint_back = 1; // L2Z_OVERLAP_HINT_BACK  the hint word is an element of the producer's n-th sweep before its last (0: the last)
-    int overlap_defer = 1;     // L2Z_OVERLAP_DEFER   0: a waiting launch requests its first weight batch at once, not after the launch ahead of it streams
     int duo = 1;               // L2Z_DUO             0: wide-row models keep the 256-thread mat-vecs and the attention forms of round 3 (no overlap)
     // --- graphs / transport (runstate.cpp, comm.cpp, forward.cpp) ---
     int no_graph = 0;          // L2Z_NO_GRAPH        1: launch eagerly

@@ -66,4 +66,12 @@ timeout 400 python scripts/ab.py llama2-7b 128 3 "" "L2Z_OVERLAP_DEFER=0" "L2Z_O
 } > $O/r04d_ab.txt 2>&1
 cat $O/r04d_ab.txt
 ;;
+e)
+# round 4, GPU call E: hand-over once per block (outputs wait in LDS) instead of LL stores after every unit
+export L2Z_P2P_TIMEOUT_S=3
+{
+timeout 400 python scripts/ab.py llama2-7b 128 3 "" "L2Z_OVERLAP_EDGES=1" "L2Z_OVERLAP_EDGES=8" "L2Z_OVERLAP_EDGES=14" "L2Z_OVERLAP_HINT_SLEEP=1" "L2Z_OVERLAP=0" "L2Z_DUO=0"
+} > $O/r04e_ab.txt 2>&1
+cat $O/r04e_ab.txt
+;;
 esac
