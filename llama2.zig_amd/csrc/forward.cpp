@@ -151,6 +151,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
     auto x_in = [&](MatvecArgs &a, const float *plain, int g, size_t count_per_rank, unsigned edge = 0) {
         a.x = plain;
         a.duo = duo ? 1 : 0;
+        a.tl_seq = s->tl_seq++;
         if (ovl) {
             if (g >= 1 && (emask & edge)) {
                 chain ^= 1;

@@ -327,6 +327,18 @@ __device__ __forceinline__ void xstage_finish_ll(const LLPoll &p, const float *_
     });
 }
 
+#ifdef L2Z_TIMELINE
+// Measurement build only (scripts/timeline_build.sh -> libllama2_hip_tl.so; never the product library): wall-clock
+// stamps (100 MHz) of every duo launch -- [0] kind (epi * 65536 + n / 4), [1] entry of block 0, [2] last block past
+// the hint gate, [3] last block with x staged, [4] last block done with its FIRST unit, [5] last block out of the unit
+// loop, [6] last block with its hand-over stores acknowledged, [7] first block out of the unit loop (as 2^62 - t).  Read with l2z_timeline_dump.
+constexpr int kTlMax = 16384;
+__device__ long long g_tl[kTlMax * 8];
+#define L2Z_TL_MAX(slot) do { if (threadIdx.x == 0 && tl_seq < kTlMax) atomicMax((unsigned long long *)&g_tl[tl_seq * 8 + (slot)], (unsigned long long)wall_clock64()); } while (0)
+#else
+#define L2Z_TL_MAX(slot) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------
 // x staging of the duo kernel (matvec.hip matvec_duo_kernel): 512 threads fill ONE copy of x per CU.
 // LL: x is a vector handed over by the previous launch of an overlapped chain, which may still be running
@@ -393,6 +405,9 @@ __device__ __forceinline__ void duo_stage_x(const MatvecArgs &a, int n, int n4_p
             if (tid == 0) ll_hint_wait(p, a.xin);
             __syncthreads();
         }
+#ifdef L2Z_TIMELINE
+        if (tid == 0 && (unsigned)a.tl_seq < 16384u) atomicMax((unsigned long long *)&g_tl[(size_t)a.tl_seq * 8 + 2], (unsigned long long)wall_clock64());
+#endif
         constexpr int R = 4;
         for (int j0 = tid; j0 < n4_pad; j0 += kDuo * R) {
             v4u w[2 * R];

@@ -136,6 +136,7 @@ struct MatvecArgs {
     // (the launch that wrote the plain buffer may be in the other chain); slots == null: plain `resid`
     LLIn resid_in;
     int duo;                  // 1: matvec_duo_kernel (512-thread blocks, one per CU; wide rows only)
+    int tl_seq;               // launch number since the runstate was made (read by measurement builds only: L2Z_TIMELINE)
     int tail_skip;            // row kernel, n > 4096: out-of-row steps of a row's last batch load nothing (set by the launcher)
 };
 

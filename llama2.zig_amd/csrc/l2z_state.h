@@ -125,6 +125,7 @@ struct l2z_runstate {
     l2z_comm *self_comm = nullptr; // owned: arena, epoch counter, error latch of the hand-overs
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_tail = nullptr;
+    int tl_seq = 0;                // mat-vec launches enqueued so far (MatvecArgs::tl_seq, measurement builds)
 };
 
 namespace l2z {

@@ -586,6 +586,13 @@ __global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
     const int n_units = m.n_pairs;
     const int ustride = 2 * gridDim.x;            // virtual grid: 2 * gridDim.x <= n_units
 
+#ifdef L2Z_TIMELINE
+    const unsigned tl_seq = (unsigned)a.tl_seq;  // host-assigned (eager launches: L2Z_NO_GRAPH=1)
+    if (threadIdx.x == 0 && blockIdx.x == 0 && tl_seq < kTlMax) {
+        g_tl[tl_seq * 8 + 0] = (long long)EPI * 65536 + (m.n >> 2) + (LL ? (1LL << 32) : 0);
+        g_tl[tl_seq * 8 + 1] = wall_clock64();
+    }
+#endif
     constexpr int GC = BIGX ? 6 : 2;              // x / rmsnorm weights of this thread held in registers (n <= GC * 2048)
     v4f gr[GC], xr[LL ? 1 : GC];
     if constexpr (!LL) duo_xload<GC>(a.x, n4, xr);
@@ -623,6 +630,7 @@ __global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
     EpiIn ein_next = ein;
     load(0);
     duo_stage_x<PRO, GC, LL>(a, m.n, n4_pad, gr, xr, xs, scratch);
+    L2Z_TL_MAX(3);
 
     // The loop is the row kernel's, with one difference: its trip count is half 0's (block-uniform: the
     // barrier), so in the last sweep a half without a unit runs one unit's FMAs on whatever its registers
@@ -673,6 +681,7 @@ __global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
                     if (rb_ < m.total_rows && tb > best_v) { best_v = tb; best_i = rb_ + a.row_offset; }
                 }
             }
+            if (k_unit == 0) L2Z_TL_MAX(4);
             k_unit++;
             ein = ein_next;
             parity ^= 1;
@@ -683,6 +692,10 @@ __global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
         u = u_next;
         b = b_next;
     }
+    L2Z_TL_MAX(5);
+#ifdef L2Z_TIMELINE
+    if (threadIdx.x == 0 && tl_seq < kTlMax) atomicMax((unsigned long long *)&g_tl[tl_seq * 8 + 7], (unsigned long long)((1LL << 62) - wall_clock64()));
+#endif
     if (stash_on) {
         // The hand-over, once per block: lane k of each half's first wave stores the LL words of the half's k-th unit.
         // Per-unit pushes sat in the streaming waves' own memory queue -- a system-scope store is acknowledged by the
@@ -701,6 +714,10 @@ __global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
                 }
             }
         }
+#ifdef L2Z_TIMELINE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        L2Z_TL_MAX(6);
+#endif
     }
     if (EPI == EPI_ARGMAX && ht == 0) {  // one candidate per virtual block (units ascend: first index kept)
         a.part_val[2 * blockIdx.x + half] = best_v;
@@ -992,3 +1009,12 @@ hipError_t launch_matvec(const MatvecArgs &a_in, int pro, int epi, int max_block
 }
 
 }  // namespace l2z
+
+#ifdef L2Z_TIMELINE
+extern "C" int l2z_timeline_dump(long long *out, int max_launches)
+{
+    const int n = max_launches < l2z::kTlMax ? max_launches : l2z::kTlMax;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(l2z::g_tl), (size_t)n * 8 * sizeof(long long)) != hipSuccess) return 1;
+    return 0;
+}
+#endif

@@ -74,4 +74,14 @@ timeout 400 python scripts/ab.py llama2-7b 128 3 "" "L2Z_OVERLAP_EDGES=1" "L2Z_O
 } > $O/r04e_ab.txt 2>&1
 cat $O/r04e_ab.txt
 ;;
+f)
+# round 4, GPU call F: the hand-over as the GPU's own clock sees it (measurement build with stamps in the duo kernel)
+export L2Z_P2P_TIMEOUT_S=3 L2Z_LIB=$PWD/llama2.zig_amd/libllama2_hip_tl.so L2Z_NO_GRAPH=1
+{
+for mode in "L2Z_OVERLAP=1" "L2Z_OVERLAP_EDGES=8" "L2Z_OVERLAP_EDGES=1" "L2Z_OVERLAP=0"; do
+  env $mode timeout 200 python scripts/decode_timeline.py llama2-7b 8
+done
+} > $O/r04f_timeline.txt 2>&1
+cat $O/r04f_timeline.txt
+;;
 esac
