@@ -269,7 +269,7 @@ __device__ __forceinline__ v4f ll_wait4(const LLPoll &p, int j, v4u a, v4u b)
         bool give_up = __hip_atomic_load(p.ctl + kCtlErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
         const long long t0 = wall_clock64();
         while (!give_up) {
-            __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_s_sleep(16);
             a = ll_load2(p.slot, (size_t)4 * j);
             b = ll_load2(p.slot, (size_t)4 * j + 2);
             if (ll_ready2(a, p.e) && ll_ready2(b, p.e)) break;
@@ -352,14 +352,20 @@ __device__ long long g_tl[kTlMax * 8];
 // rmsnorm (main.zig:432-468): the sum of squares is formed by threads 0..255 over float4 t, t+256, ... in
 // increasing order, wave sum, four partials in wave order -- the 256-thread kernels' order, bit for bit.
 // ---------------------------------------------------------------------------
+constexpr int kHintLanes = 16;
+// called by lanes 0 .. kHintLanes-1 of the block's first wave: lane i polls the hint element of another producer
+// block (spread evenly over the producer's last sweep, so over its XCDs); all of them must carry the epoch.  One
+// producer block's word fired up to 14 us before the slowest block was done (the blocks' exits spread that much),
+// and a block that is let through early sweeps and then re-polls every late word beside the producer's tail.
 __device__ __forceinline__ void ll_hint_wait(const LLPoll &p, const LLIn &in)
 {
-    const unsigned idx = in.hint0 + (blockIdx.x % in.hint_n) * in.hint_stride;
+    const unsigned step = in.hint_n >= kHintLanes ? in.hint_n / kHintLanes : 1u;
+    const unsigned idx = in.hint0 + ((blockIdx.x + threadIdx.x * step) % in.hint_n) * in.hint_stride;
     const long long t0 = wall_clock64();
     for (;;) {
         const unsigned long long w =
             __hip_atomic_load(p.slot + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if ((unsigned)(w >> 32) == p.e) break;
+        if (__all((unsigned)(w >> 32) == p.e)) break;
         if (__hip_atomic_load(p.ctl + kCtlErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
         if (wall_clock64() - t0 > p.timeout_ticks) break;  // the sweep's own waits latch and report it
         for (int i = 0; i < in.hint_sleep; i++) __builtin_amdgcn_s_sleep(8);  // 8 x 64 clocks each
@@ -402,7 +408,7 @@ __device__ __forceinline__ void duo_stage_x(const MatvecArgs &a, int n, int n4_p
     if constexpr (LL) {
         const LLPoll p = ll_poll_init(a.xin);
         if (a.xin.hint_n != 0) {
-            if (tid == 0) ll_hint_wait(p, a.xin);
+            if (tid < kHintLanes) ll_hint_wait(p, a.xin);
             __syncthreads();
         }
 #ifdef L2Z_TIMELINE

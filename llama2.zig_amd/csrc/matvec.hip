@@ -81,6 +81,7 @@ struct MvLocals {
     int *resid_ctl;
     int *resid_herr;
     long long resid_timeout;
+    bool resid_pre;  // duo kernel: the residual words of all the block's units were requested at entry (EpiIn::rw is filled from LDS)
 };
 
 template <int EPI>
@@ -100,7 +101,7 @@ __device__ __forceinline__ MvLocals mv_locals(const MatvecArgs &a)
     m.push = a.push;
     m.push_e = m.push ? a.push_ctl[kCtlEpoch] + a.push_gi : 0;
     m.push_base = m.push ? (size_t)m.push->rank * m.push->count : 0;
-    m.resid_slot = nullptr; m.resid_e = 0; m.resid_ctl = nullptr; m.resid_herr = nullptr; m.resid_timeout = 0;
+    m.resid_slot = nullptr; m.resid_e = 0; m.resid_ctl = nullptr; m.resid_herr = nullptr; m.resid_timeout = 0; m.resid_pre = false;
     if (EPI == EPI_RESID && a.resid_in.slots != nullptr) {
         const int e = a.resid_in.ctl[kCtlEpoch] + a.resid_in.gi;
         m.resid_e = (unsigned)e;
@@ -153,7 +154,7 @@ __device__ __forceinline__ EpiIn epi_prefetch(const MvLocals &m, int p, bool wri
     if (EPI == EPI_RESID) {  // single segment: rows 2p, 2p+1
         const int ga = 2 * p, gb = ga + 1;
         if (m.resid_slot) {  // words 2p, 2p+1 of the handed-over vector: one 16-byte load, never waited for here
-            e.rw = ll_load2(m.resid_slot, (size_t)ga);
+            if (!m.resid_pre) e.rw = ll_load2(m.resid_slot, (size_t)ga);
         } else {
             e.ra = m.resid[ga];
             if (gb < m.total_rows) e.rb = m.resid[gb];
@@ -574,7 +575,8 @@ __global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
 {
     constexpr int U = 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const MvLocals m = mv_locals<EPI>(a);
+    MvLocals m = mv_locals<EPI>(a);
+    m.resid_pre = m.resid_slot != nullptr;
     const int n4 = m.n >> 2;
     const int n_batches = (n4 + kBlock * U - 1) / (kBlock * U);
     const int n4_pad = n_batches * (kBlock * U);
@@ -628,8 +630,18 @@ __global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
     // residual of an overlapped chain -- LL words of an earlier hand-over (EpiIn::rw)
     EpiIn ein = epi_prefetch<EPI>(m, u, ht == 0);
     EpiIn ein_next = ein;
+    // LL residual: lane k of each half's first wave requests the two words of the half's k-th unit now -- one load
+    // instruction per half instead of an uncached load ahead of every unit's weight batch (loads return in order:
+    // the wave's weights waited behind it, and the block's per-unit barrier behind that wave)
+    v4u rs_mine = {0u, 0u, 0u, 0u};
+    if (EPI == EPI_RESID && m.resid_pre && ht < kDuoStash) {
+        const int uk = 2 * blockIdx.x + half + ht * ustride;
+        if (uk < n_units) rs_mine = ll_load2(m.resid_slot, (size_t)(2 * uk));
+    }
     load(0);
     duo_stage_x<PRO, GC, LL>(a, m.n, n4_pad, gr, xr, xs, scratch);
+    v4u *rsd = (v4u *)(part + 4 * (2 * kWaves) + 4 * kDuoStash);  // [half][kDuoStash] residual words as requested at entry
+    if (EPI == EPI_RESID && m.resid_pre && ht < kDuoStash) rsd[half * kDuoStash + ht] = rs_mine;  // read after >= 1 barrier
     L2Z_TL_MAX(3);
 
     // The loop is the row kernel's, with one difference: its trip count is half 0's (block-uniform: the
@@ -674,6 +686,8 @@ __global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
                 const float ta = ((pp[0] + pp[1]) + pp[2]) + pp[3];
                 const float tb = ((pp[kWaves] + pp[kWaves + 1]) + pp[kWaves + 2]) + pp[kWaves + 3];
                 float *st = (stash_on && k_unit < kDuoStash) ? stash + (half * kDuoStash + k_unit) * 2 : nullptr;
+                if (EPI == EPI_RESID && m.resid_pre)
+                    ein.rw = k_unit < kDuoStash ? rsd[half * kDuoStash + k_unit] : ll_load2(m.resid_slot, (size_t)(2 * u));
                 pair_epilogue<EPI>(m, u, ta, tb, true, ein, st);
                 if (EPI == EPI_ARGMAX) {
                     const int ra_ = 2 * u, rb_ = ra_ + 1;
@@ -892,7 +906,7 @@ bool matvec_duo_supported(int n)
     const int n4 = n >> 2;
     if (n4 < 1024 || (n4 % 64) != 0 || !tunables().row_kernel) return false;
     const int n4_pad = ((n4 + 1023) / 1024) * 1024;
-    return (size_t)(4 * n4_pad + kScratch + 8 * kWaves + 4 * kDuoStash) * sizeof(float) <= 64 * 1024;
+    return (size_t)(4 * n4_pad + kScratch + 8 * kWaves + 12 * kDuoStash) * sizeof(float) <= 64 * 1024;
 }
 
 hipError_t launch_stream_read(const float *p, size_t n_floats, float *out, int n_cus, hipStream_t st)
@@ -927,7 +941,7 @@ hipError_t launch_matvec(const MatvecArgs &a_in, int pro, int epi, int max_block
         const void *fn = mv_duo_pick(pro, epi, a.n > 4096, ll);
         if (fn == nullptr) return hipErrorNotSupported;
         const int n4_pad = ((n4 + 1023) / 1024) * 1024;
-        const size_t lds = (size_t)(4 * n4_pad + kScratch + 8 * kWaves + 4 * kDuoStash) * sizeof(float);
+        const size_t lds = (size_t)(4 * n4_pad + kScratch + 8 * kWaves + 12 * kDuoStash) * sizeof(float);
         int resident = 2 * n_cus;  // virtual blocks (halves): one block of two per CU
         if (tn.grid_cap > 0 && resident > tn.grid_cap) resident = tn.grid_cap;
         int vgrid = n_pairs;

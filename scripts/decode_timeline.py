@@ -39,7 +39,7 @@ for i in range(1, len(rows)):
               us(done, staged), us(acked, done) if acked else np.nan, us(done, first_done), us(packed, pdone) if packed else np.nan))
 print(f"# decode timeline from in-kernel stamps: {wl}, pos0 {pos0}, {os.environ.get('L2Z_OVERLAP_EDGES', '')} overlap={os.environ.get('L2Z_OVERLAP', '1')}")
 print("\nus relative to the moment the PRODUCER's last block left its unit loop (producer = the previous mat-vec; for wo that is qkv, with the attention launch in between):\n")
-print("| launch | n | block 0 entered | last block past the hint | last block staged x | last block did its first unit | last block out of the loop | staged -> out of loop | spread of the blocks' exits | own stores acknowledged after exit | producer's stores acknowledged |")
+print("| launch | n | block 0 entered | last block past the hint | last block staged x | last block did its first unit | last block out of the loop | staged -> out of loop | own stores acknowledged after exit | spread of the blocks' exits | producer's stores acknowledged after its exit |")
 print("|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
 for k in ("qkv", "wo", "ffn13", "ffn2", "cls"):
     if k in acc:

@@ -84,4 +84,15 @@ done
 } > $O/r04f_timeline.txt 2>&1
 cat $O/r04f_timeline.txt
 ;;
+g)
+# round 4, GPU call G: hint = 16 producer blocks' words, LL residual requested once per block at entry
+export L2Z_P2P_TIMEOUT_S=3
+{
+timeout 400 python scripts/ab.py llama2-7b 128 3 "" "L2Z_OVERLAP_EDGES=1" "L2Z_OVERLAP_EDGES=8" "L2Z_OVERLAP_EDGES=11" "L2Z_OVERLAP=0" "L2Z_DUO=0"
+for mode in "L2Z_OVERLAP=1" "L2Z_OVERLAP=0"; do
+  env $mode L2Z_LIB=$PWD/llama2.zig_amd/libllama2_hip_tl.so L2Z_NO_GRAPH=1 timeout 200 python scripts/decode_timeline.py llama2-7b 8
+done
+} > $O/r04g_ab.txt 2>&1
+cat $O/r04g_ab.txt
+;;
 esac
