@@ -329,14 +329,15 @@ __device__ __forceinline__ void xstage_finish_ll(const LLPoll &p, const float *_
 
 #ifdef L2Z_TIMELINE
 // Measurement build only (scripts/timeline_build.sh -> libllama2_hip_tl.so; never the product library): wall-clock
-// stamps (100 MHz) of every duo launch -- [0] kind (epi * 65536 + n / 4), [1] entry of block 0, [2] last block past
-// the hint gate, [3] last block with x staged, [4] last block done with its FIRST unit, [5] last block out of the unit
-// loop, [6] last block with its hand-over stores acknowledged, [7] first block out of the unit loop (as 2^62 - t).  Read with l2z_timeline_dump.
-constexpr int kTlMax = 16384;
-__device__ long long g_tl[kTlMax * 8];
-#define L2Z_TL_MAX(slot) do { if (threadIdx.x == 0 && tl_seq < kTlMax) atomicMax((unsigned long long *)&g_tl[tl_seq * 8 + (slot)], (unsigned long long)wall_clock64()); } while (0)
+// stamps (100 MHz) of every block of every duo launch, kept in registers and stored when the block is done (a stamp
+// written on the spot is a memory operation the block's next wait on its loads would wait behind).  Per (launch,
+// block): [0] kind (epi * 65536 + n / 4, bit 32: x handed over), [1] entry, [2] past the hint gate, [3] x staged,
+// [4] first unit done, [5] out of the unit loop, [6] hand-over stores acknowledged.  Read with l2z_timeline_dump.
+constexpr int kTlMax = 2048, kTlBlocks = 256;
+__device__ long long g_tl[kTlMax * kTlBlocks * 8];
+#define L2Z_TL(var) var = wall_clock64()
 #else
-#define L2Z_TL_MAX(slot) do { } while (0)
+#define L2Z_TL(var) do { } while (0)
 #endif
 
 // ---------------------------------------------------------------------------
@@ -412,7 +413,7 @@ __device__ __forceinline__ void duo_stage_x(const MatvecArgs &a, int n, int n4_p
             __syncthreads();
         }
 #ifdef L2Z_TIMELINE
-        if (tid == 0 && (unsigned)a.tl_seq < 16384u) atomicMax((unsigned long long *)&g_tl[(size_t)a.tl_seq * 8 + 2], (unsigned long long)wall_clock64());
+        if (tid == 0) ((long long *)scratch)[8] = wall_clock64();  // scratch floats 16, 17: nothing else uses them
 #endif
         constexpr int R = 4;
         for (int j0 = tid; j0 < n4_pad; j0 += kDuo * R) {

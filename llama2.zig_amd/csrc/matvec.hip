@@ -589,11 +589,7 @@ __global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
     const int ustride = 2 * gridDim.x;            // virtual grid: 2 * gridDim.x <= n_units
 
 #ifdef L2Z_TIMELINE
-    const unsigned tl_seq = (unsigned)a.tl_seq;  // host-assigned (eager launches: L2Z_NO_GRAPH=1)
-    if (threadIdx.x == 0 && blockIdx.x == 0 && tl_seq < kTlMax) {
-        g_tl[tl_seq * 8 + 0] = (long long)EPI * 65536 + (m.n >> 2) + (LL ? (1LL << 32) : 0);
-        g_tl[tl_seq * 8 + 1] = wall_clock64();
-    }
+    long long tl_entry = wall_clock64(), tl_staged = 0, tl_first = 0, tl_done = 0, tl_acked = 0;
 #endif
     constexpr int GC = BIGX ? 6 : 2;              // x / rmsnorm weights of this thread held in registers (n <= GC * 2048)
     v4f gr[GC], xr[LL ? 1 : GC];
@@ -642,7 +638,7 @@ __global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
     duo_stage_x<PRO, GC, LL>(a, m.n, n4_pad, gr, xr, xs, scratch);
     v4u *rsd = (v4u *)(part + 4 * (2 * kWaves) + 4 * kDuoStash);  // [half][kDuoStash] residual words as requested at entry
     if (EPI == EPI_RESID && m.resid_pre && ht < kDuoStash) rsd[half * kDuoStash + ht] = rs_mine;  // read after >= 1 barrier
-    L2Z_TL_MAX(3);
+    L2Z_TL(tl_staged);
 
     // The loop is the row kernel's, with one difference: its trip count is half 0's (block-uniform: the
     // barrier), so in the last sweep a half without a unit runs one unit's FMAs on whatever its registers
@@ -695,7 +691,7 @@ __global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
                     if (rb_ < m.total_rows && tb > best_v) { best_v = tb; best_i = rb_ + a.row_offset; }
                 }
             }
-            if (k_unit == 0) L2Z_TL_MAX(4);
+            if (k_unit == 0) L2Z_TL(tl_first);
             k_unit++;
             ein = ein_next;
             parity ^= 1;
@@ -706,10 +702,7 @@ __global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
         u = u_next;
         b = b_next;
     }
-    L2Z_TL_MAX(5);
-#ifdef L2Z_TIMELINE
-    if (threadIdx.x == 0 && tl_seq < kTlMax) atomicMax((unsigned long long *)&g_tl[tl_seq * 8 + 7], (unsigned long long)((1LL << 62) - wall_clock64()));
-#endif
+    L2Z_TL(tl_done);
     if (stash_on) {
         // The hand-over, once per block: lane k of each half's first wave stores the LL words of the half's k-th unit.
         // Per-unit pushes sat in the streaming waves' own memory queue -- a system-scope store is acknowledged by the
@@ -730,9 +723,17 @@ __global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
         }
 #ifdef L2Z_TIMELINE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        L2Z_TL_MAX(6);
+        L2Z_TL(tl_acked);
 #endif
     }
+#ifdef L2Z_TIMELINE
+    if (threadIdx.x == 0 && (unsigned)a.tl_seq < (unsigned)kTlMax && blockIdx.x < kTlBlocks) {
+        long long *o = g_tl + ((size_t)a.tl_seq * kTlBlocks + blockIdx.x) * 8;
+        o[0] = (long long)EPI * 65536 + (m.n >> 2) + (LL ? (1LL << 32) : 0);
+        o[1] = tl_entry; o[2] = LL ? ((long long *)scratch)[8] : 0; o[3] = tl_staged; o[4] = tl_first; o[5] = tl_done; o[6] = tl_acked;
+        o[7] = gridDim.x;
+    }
+#endif
     if (EPI == EPI_ARGMAX && ht == 0) {  // one candidate per virtual block (units ascend: first index kept)
         a.part_val[2 * blockIdx.x + half] = best_v;
         a.part_idx[2 * blockIdx.x + half] = best_i;
@@ -1028,7 +1029,7 @@ hipError_t launch_matvec(const MatvecArgs &a_in, int pro, int epi, int max_block
 extern "C" int l2z_timeline_dump(long long *out, int max_launches)
 {
     const int n = max_launches < l2z::kTlMax ? max_launches : l2z::kTlMax;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(l2z::g_tl), (size_t)n * 8 * sizeof(long long)) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(l2z::g_tl), (size_t)n * l2z::kTlBlocks * 8 * sizeof(long long)) != hipSuccess) return 1;
     return 0;
 }
 #endif

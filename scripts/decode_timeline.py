@@ -1,7 +1,8 @@
-"""The decode pass as the GPU's own clock saw it: wall-clock stamps written by the duo mat-vec kernels of the measurement
-build (scripts/timeline_build.sh, -DL2Z_TIMELINE), eager launches.  Per kind of launch: when the last block was past the
-hint gate, had x staged, finished its first unit, left the unit loop, had its hand-over stores acknowledged -- relative to
-the moment its PRODUCER's last block left the unit loop (the earliest the input could have been complete).
+"""The decode pass as the GPU's own clock saw it: wall-clock stamps (100 MHz) kept in registers by every block of the duo
+mat-vec kernels of the measurement build (scripts/timeline_build.sh, -DL2Z_TIMELINE) and stored when the block is done;
+eager launches (the host numbers them).  Per kind of launch, relative to the moment its PRODUCER's last block left the
+unit loop -- the earliest its input could have been complete:
+  entered / past the hint gate / x staged / first unit done / out of the unit loop   (last block each; first block for entry)
 usage: L2Z_LIB=llama2.zig_amd/libllama2_hip_tl.so L2Z_NO_GRAPH=1 [mode knobs] decode_timeline.py <workload> <tokens> [pos0]"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
@@ -14,37 +15,46 @@ w = B.Weights(cfg, None, shared, seed=2024)
 s = B.RunState(cfg)
 B.option_set("L2Z_PREFILL", 0)
 s.greedy_begin(list(range(2, 2 + pos0)) if pos0 else [])
-s.greedy_run(w, pos0 + toks); s.synchronize()
+import time
+s.greedy_run(w, pos0 + 2); s.synchronize()
+t0 = time.perf_counter(); n = len(s.greedy_run(w, toks)); s.synchronize(); dt = time.perf_counter() - t0
 L = B.lib()
-n_max = 16384
-buf = (C.c_longlong * (n_max * 8))()
+n_max, nb = 2048, 256
+buf = (C.c_longlong * (n_max * nb * 8))()
 assert L.l2z_timeline_dump(buf, n_max) == 0
-t = np.frombuffer(buf, dtype=np.int64).reshape(n_max, 8)
-t = t[t[:, 1] != 0]
+t = np.frombuffer(buf, dtype=np.int64).reshape(n_max, nb, 8)
 per_tok = 4 * cfg.n_layers + 1
-t = t[-per_tok * min(toks, 6):]                 # the last tokens
+n_launch = per_tok * (pos0 + 2 + toks)
+assert n_launch <= n_max, "too many launches for the stamp buffer: fewer tokens"
+t = t[n_launch - per_tok * min(toks, 6):n_launch]
 kind = {(1, cfg.dim // 4): "qkv", (2, cfg.dim // 4): "wo", (3, cfg.dim // 4): "ffn13", (2, cfg.hidden_dim // 4): "ffn2", (4, cfg.dim // 4): "cls"}
 rows = []
 for r in t:
-    k = kind.get((int(r[0] & 0xffffffff) >> 16, int(r[0] & 0xffff)))
-    rows.append((k, bool(r[0] >> 32), r[1], r[2], r[3], r[4], r[5], r[6], (1 << 62) - r[7]))
-# host enqueue order == data-flow order: the producer of a launch is the previous mat-vec (attention sits between qkv and wo)
+    g = int(r[0, 7])                    # blocks of the launch
+    r = r[:g]
+    k = kind.get((int(r[0, 0] & 0xffffffff) >> 16, int(r[0, 0] & 0xffff)))
+    ll = bool(r[0, 0] >> 32)
+    rows.append(dict(k=k, ll=ll, entry0=r[:, 1].min(), entry=r[:, 1].max(), gate=r[:, 2].max() if ll else 0, staged=r[:, 3].max(),
+                     first=r[:, 4].max(), done=r[:, 5].max(), done0=r[:, 5].min(), acked=r[:, 6].max(), gate0=r[:, 2].min() if ll else 0,
+                     stage_span=(r[:, 3] - r[:, 2]).mean() if ll else (r[:, 3] - r[:, 1]).mean(), first_span=(r[:, 4] - r[:, 3]).mean()))
 us = lambda a, b: (a - b) / 100.0
 acc = {}
 for i in range(1, len(rows)):
-    k, ll, entry, gate, staged, first, done, acked, first_done = rows[i]
-    pk, _, pentry, _, _, _, pdone, packed, pfirst_done = rows[i - 1]
-    d = acc.setdefault(k, [])
-    d.append((us(entry, pdone), us(gate, pdone) if ll and gate else np.nan, us(staged, pdone), us(first, pdone), us(done, pdone),
-              us(done, staged), us(acked, done) if acked else np.nan, us(done, first_done), us(packed, pdone) if packed else np.nan))
-print(f"# decode timeline from in-kernel stamps: {wl}, pos0 {pos0}, {os.environ.get('L2Z_OVERLAP_EDGES', '')} overlap={os.environ.get('L2Z_OVERLAP', '1')}")
-print("\nus relative to the moment the PRODUCER's last block left its unit loop (producer = the previous mat-vec; for wo that is qkv, with the attention launch in between):\n")
-print("| launch | n | block 0 entered | last block past the hint | last block staged x | last block did its first unit | last block out of the loop | staged -> out of loop | own stores acknowledged after exit | spread of the blocks' exits | producer's stores acknowledged after its exit |")
-print("|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
+    c, p = rows[i], rows[i - 1]   # host enqueue order == data-flow order (attention sits between qkv and wo)
+    acc.setdefault(c["k"], []).append((us(c["entry0"], p["done"]), us(c["gate0"], p["done"]) if c["ll"] else np.nan, us(c["gate"], p["done"]) if c["ll"] else np.nan,
+                                       us(c["staged"], p["done"]), us(c["first"], p["done"]), us(c["done"], p["done"]), us(c["done"], c["staged"]),
+                                       us(c["done"], c["done0"]), us(p["acked"], p["done"]) if p["acked"] else np.nan, c["stage_span"] / 100.0, c["first_span"] / 100.0))
+mode = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("L2Z_O") or k == "L2Z_DUO") or "defaults"
+print(f"# decode timeline from in-kernel stamps: {wl}, pos0 {pos0}, [{mode}], {n / dt:.1f} tok/s ({1e3 * dt / n:.3f} ms/token) with the stamps, eager launches")
+print("\nus after the PRODUCER's last block left its unit loop (producer = the previous mat-vec; for wo that is qkv, with the attention launch in between):\n")
+print("| launch | n | first block entered | first block past the hint | last block past the hint | last block staged x | last block did its first unit | last block out of the loop | "
+      "staged -> out of loop | spread of the blocks' exits | producer's hand-over stores acknowledged | per block: gate (or entry) -> staged | per block: staged -> first unit |")
+print("|---|" + "---:|" * 12)
 for k in ("qkv", "wo", "ffn13", "ffn2", "cls"):
     if k in acc:
         a = np.array(acc[k], dtype=float)
-        m = np.nanmean(a, axis=0)
-        print(f"| {k} | {len(a)} | " + " | ".join(f"{x:.2f}" for x in m) + " |")
-tok_us = us(rows[-1][6], rows[-1 - per_tok][6])
-print(f"\nlast token: {tok_us:.1f} us between the classifier's exits")
+        with np.errstate(all="ignore"):
+            m = np.nanmean(a, axis=0)
+        print(f"| {k} | {len(a)} | " + " | ".join("" if np.isnan(x) else f"{x:.2f}" for x in m) + " |")
+tok_us = us(rows[-1]["done"], rows[-1 - per_tok]["done"])
+print(f"\nlast token: {tok_us:.1f} us between the classifier's exits\n")

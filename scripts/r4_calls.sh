@@ -95,4 +95,14 @@ done
 } > $O/r04g_ab.txt 2>&1
 cat $O/r04g_ab.txt
 ;;
+h)
+# round 4, GPU call H: the timeline again with stamps that do not perturb (registers, stored at block end)
+export L2Z_P2P_TIMEOUT_S=3
+{
+for mode in "L2Z_OVERLAP=1" "L2Z_OVERLAP_EDGES=1" "L2Z_OVERLAP=0"; do
+  env $mode L2Z_LIB=$PWD/llama2.zig_amd/libllama2_hip_tl.so L2Z_NO_GRAPH=1 timeout 200 python scripts/decode_timeline.py llama2-7b 6
+done
+} > $O/r04h_timeline.txt 2>&1
+cat $O/r04h_timeline.txt
+;;
 esac
