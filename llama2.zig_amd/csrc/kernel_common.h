@@ -22,7 +22,15 @@ constexpr int kDuo = 512;     // threads of a matvec_duo_kernel block (two halve
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// Device-memory ("global") address space, spelled out.  The compiler infers it for pointers that arrive as kernel
+// arguments; a pointer read out of a structure in memory is generic to it -- flat_load / flat_store, which count on
+// both memory counters, so that every LDS wait also waits for the weight stream (engine.hip reads its mat-vec
+// descriptions from device memory).
+#define L2Z_G __attribute__((address_space(1)))
+template <typename T> __device__ __forceinline__ L2Z_G T *as_g(T *p) { return (L2Z_G T *)p; }
+
 __device__ __forceinline__ v4f ldg_nt(const v4f *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ v4f ldg_nt(const L2Z_G v4f *p) { return __builtin_nontemporal_load(p); }
 
 // Cross-lane reductions.  Inside a 16-lane row the exchange is a DPP modifier on a VALU op
 // (a few cycles); ds_bpermute-based __shfl_xor (~100 cycles each, and the five steps of one

@@ -140,6 +140,29 @@ struct MatvecArgs {
     int tail_skip;            // row kernel, n > 4096: out-of-row steps of a row's last batch load nothing (set by the launcher)
 };
 
+// engine.hip: a chunk of consecutive mat-vecs run by one persistent launch.  op[k].a is what launch_matvec would get
+// for mat-vec k (duo form): x plain for the first (written before the launch) or xin (LL words written by mat-vec
+// k - 1 of the same launch), resid or resid_in, push for every mat-vec whose output the next one reads.
+constexpr int kEngMaxOps = 4;
+struct EngOp {
+    MatvecArgs a;
+    int pro, epi;
+    int n_pairs;   // units (row pairs)
+    int nb;        // batches of 1024 float4 per row
+};
+struct EngChunk {
+    int n_ops;
+    int *ctl, *h_err;          // l2z_comm::d_ctl / h_err of the hand-overs
+    long long timeout_ticks;
+    const float *dummy;        // >= 2 KB of finite, cache-resident floats (what out-of-row steps read)
+    EngOp op[kEngMaxOps];
+};
+size_t engine_lds_bytes(int xs_floats);
+int engine_xs_floats(int n_max);
+bool engine_units_ok(int n_pairs, int grid);
+// d_chunk: device memory.  grid blocks of 576 threads, all of which must be resident at once (grid <= CUs)
+hipError_t launch_engine(const EngChunk *d_chunk, int grid, int xs_floats, hipStream_t st);
+
 // main.zig:361-389: scores, softmax, att.V for the local heads of one layer
 struct AttnArgs {
     const float *q;        // (n_heads_local * head_size)
