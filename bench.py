@@ -278,6 +278,48 @@ def workload_text(args, cfg) -> str:
 # --------------------------------------------------------------------------------------------------
 # N = 1
 # --------------------------------------------------------------------------------------------------
+def scaling_model(B, cfg, shared, seed, pos: int, worlds=(2, 4, 8)) -> dict:
+    """Config 5 (the 7B shape row / head-sharded over N GPUs) has never run on N GPUs here; what CAN be measured on one
+    is what one rank's launches cost: rank 0 of an N-rank group as an EMULATED rank (its shard of the weights, its
+    shard geometry, no transport), every kind of launch timed back to back (l2z_time_kind) and summed over a token.
+    That is a LOWER bound on the per-rank time of a sharded token -- the gathers' latency (4 per layer + 1) comes on
+    top -- so 1 / per_rank_ms is an UPPER bound on tokens/s at N GPUs.  A bound to check the first real run against,
+    not a measurement of it."""
+    out = {}
+    launches_per_kind = {"qkv": cfg.n_layers, "attn": cfg.n_layers, "wo": cfg.n_layers, "ffn13": cfg.n_layers,
+                         "ffn2": cfg.n_layers, "cls": 1, "argmax": 1}
+    for world in (1,) + tuple(worlds):
+        if cfg.n_heads % world or cfg.n_kv_heads % world or cfg.hidden_dim % world or cfg.vocab_size % world:
+            continue
+        comm = B.Comm(0, world, None, 0, emulated=True) if world > 1 else None
+        w = s = None
+        try:
+            w = B.Weights(cfg, None, shared, seed=seed, comm=comm)
+            s = B.RunState(cfg, comm=comm)
+            us = {}
+            for k in launches_per_kind:
+                ms, _ = s.time_kind(k, pos, w, reps=3)
+                us[k] = ms * 1e3
+            n_launch = sum(launches_per_kind.values())
+            per_rank_ms = sum(us[k] * n for k, n in launches_per_kind.items()) / 1e3
+            stream_ms = weight_bytes_per_token(cfg, world) / 7.3e12 * 1e3  # what the rank's bytes take at the marginal rate of the mat-vecs
+            out[str(world)] = {"per_rank_ms": per_rank_ms, "launches": n_launch, "us_by_kind": us,
+                               "weight_bytes_per_rank": weight_bytes_per_token(cfg, world),
+                               "fixed_us_per_launch": (per_rank_ms - stream_ms) * 1e3 / n_launch,
+                               "predicted_tok_s_upper_bound": 1e3 / per_rank_ms,
+                               "gathers_per_token_not_included": 0 if world == 1 else 4 * cfg.n_layers + 1}
+        finally:
+            for o in (s, w, comm):
+                if o is not None:
+                    o.close()
+    if "1" in out:
+        for k, v in out.items():
+            v["speedup_upper_bound_vs_1"] = out["1"]["per_rank_ms"] / v["per_rank_ms"]
+    out["note"] = ("rank 0 of N as an emulated rank on ONE GPU: kernel time only, back to back per kind; gather latency, rank skew and "
+                   "xGMI are NOT in it -- an upper bound on tokens/s at N GPUs, not a measurement")
+    return out
+
+
 def single_gpu(args) -> None:
     pkg = ge.load_package()
     B, ck = pkg.binding, pkg.checkpoint
@@ -291,6 +333,25 @@ def single_gpu(args) -> None:
     pos0 = args.warmup + n_tok
     by_kind = profile_kinds(B, s, w, cfg, pos0, n_prof)
     roofline, _ = roofline_of(B, s, w, cfg, 1, by_kind, n_prof, pos0, args.workload, n_tok, dt)
+    # the headline as a distribution: the same timed region five more times in this process (`value` stays the first,
+    # driver-argument run); one process = one draw of the allocation-placement / clock mode (profiles/r03_process_variance.txt)
+    repeats = None
+    if not args.no_extra:
+        try:
+            xs = []
+            for _ in range(5):
+                s.greedy_begin([])
+                if args.warmup > 0:
+                    s.greedy_run(w, args.warmup)
+                s.synchronize()
+                t0 = time.perf_counter()
+                k = len(s.greedy_run(w, steps))
+                s.synchronize()
+                xs.append(k / (time.perf_counter() - t0))
+            repeats = {"n": len(xs), "min": float(np.min(xs)), "median": float(np.median(xs)), "max": float(np.max(xs)),
+                       "tokens_per_s": [float(x) for x in xs], "first_run_value": n_tok / dt}
+        except Exception as e:  # noqa: BLE001
+            repeats = {"error": str(e)}
 
     # ---- batched prompt prefill: the MFMA-bound part, reported beside the
     # decode figure, never folded into `value`
@@ -381,7 +442,13 @@ def single_gpu(args) -> None:
                 s7.close(); w7.close()
             except Exception as e:  # noqa: BLE001
                 long_ctx = {"error": str(e)}
-        out["extra"] = {"prefill": prefill,
+        sm = None
+        if args.workload == "llama2-7b":
+            try:
+                sm = scaling_model(B, cfg, shared, args.seed, 8)
+            except Exception as e:  # noqa: BLE001
+                sm = {"error": str(e)}
+        out["extra"] = {"prefill": prefill, "repeats": repeats, "scaling_model": sm,
                         "stories110M": {"tokens_per_s": n110 / dt110, "steps": n110,
                                         "weight_bytes_per_token": bytes110,
                                         "hbm_frac": bytes110 / (dt110 / n110) / 1e9 / HBM_PEAK_GBS},
@@ -406,7 +473,7 @@ def single_gpu(args) -> None:
             except Exception as e:  # noqa: BLE001
                 out["extra"]["cpu_baseline_by_shape"] = {"error": str(e)}
     elif not args.no_extra:
-        out["extra"] = {"prefill": prefill}
+        out["extra"] = {"prefill": prefill, "repeats": repeats}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ck, cfg, shared, args.workload)
     print(json.dumps(out), flush=True)

@@ -264,6 +264,10 @@ __global__ __launch_bounds__(NT) void attention_fast_kernel(const AttnArgs a)
 // tolerance, and independent of GPU count (attention is head-local).
 // part layout: [head][chunk][head_size + 4] floats = o_c[head_size], m_c, l_c, pad, pad
 // ---------------------------------------------------------------------------
+// timesteps per chunk when T timesteps are cut into nch contiguous ranges: even, so that a wave's two rows stay 1 KB
+// aligned.  The kernel's ranges (T = pos + 1) and the launcher's LDS carve (T = seq_len) both come from here.
+__host__ __device__ inline int attn_split_per(int T, int nch) { return (((T + nch - 1) / nch) + 1) & ~1; }
+
 // Combine of one head's chunk partials (see above); nt threads of one block, i < hs.
 __device__ __forceinline__ void combine_chunks(const float *p, int nch, int hs, float *xb_h,
                                                const P2pArgs *push, int push_e, size_t push_idx0)
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(NT) void attention_split_kernel(const AttnArgs a, i
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int hs = a.head_size;
     const AttnGeom ge = attn_geom(hs, true, NT);
-    const int max_local = (a.seq_len + nch - 1) / nch;
+    const int max_local = attn_split_per(a.seq_len, nch);
     float *sc = lds;                                   // local scores
     float *wt = sc + ((max_local + 3) & ~3);           // local unnormalised weights
     float *part = wt + ((max_local + 3) & ~3);         // G*hs
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(NT) void attention_split_kernel(const AttnArgs a, i
     // run of Tc * head_size floats of K and one of V -- a linear stream per block (the (seq_len, kv_dim)
     // order gave 512-byte pieces 16 KB apart at the 7B shape).  per is even: a wave's two rows stay
     // 1 KB aligned.  Late chunks are empty while pos is small.
-    const int per = (((T + nch - 1) / nch) + 1) & ~1;
+    const int per = attn_split_per(T, nch);
     const int t_lo = c * per;
     const int Tc = T > t_lo ? (T - t_lo < per ? T - t_lo : per) : 0;  // timesteps owned by this block
     const float *kbase = a.kcache + (size_t)kvh * a.kv_head + (size_t)t_lo * stride;
@@ -551,7 +555,7 @@ hipError_t launch_attention_split(const AttnArgs &a_in, int n_heads_local, int n
     const int forced = tunables().attn_block;
     const int nt = forced ? forced : (small ? kBlock : kAttnFastBlock);
     const AttnGeom ge = attn_geom(a.head_size, true, nt);
-    const int max_local = (a.seq_len + nch - 1) / nch;
+    const int max_local = attn_split_per(a.seq_len, nch);  // the kernel's own bound on a chunk's length
     const size_t lds = (size_t)(2 * ((max_local + 3) & ~3) + ge.G * a.head_size) * sizeof(float);
     if (nt == kAttnFastBlock) {
         hipError_t e = ensure_lds(attention_split_kernel<kAttnFastBlock>, lds);
@@ -588,7 +592,9 @@ hipError_t launch_attention(const AttnArgs &a_in, int n_heads_local, hipStream_t
                      aligned16(a.kcache) && aligned16(a.vcache);
     const size_t lds = attention_lds_bytes(a.head_size, a.seq_len, vec);
     if (vec && a.head_size <= 256 && form != 4) {
-        const int forced = form == 1 ? kBlock : form == 2 ? kAttnFastBlock : tunables().attn_block;
+        // L2Z_ATTN_BLOCK, when set, overrides the form the caller picked by position as well
+        const int tb = tunables().attn_block;
+        const int forced = tb ? tb : form == 1 ? kBlock : form == 2 ? kAttnFastBlock : 0;
         const int nt = forced ? forced : (a.seq_len > 512 ? kAttnFastBlock : kBlock);
         const AttnGeom gf = attn_geom(a.head_size, true, nt);
         const size_t lds_fast = (size_t)(2 * ((a.seq_len + 3) & ~3) + gf.G * a.head_size) * sizeof(float);

@@ -576,14 +576,17 @@ extern "C" int l2z_profile_forward(int token, int pos, const l2z_config *config,
 // event pair adds ~3 us to a 10-50 us kernel): the launches of that kind for every layer go out back
 // to back -- each streams its own layer's weights, nothing is re-read from cache -- between one event
 // pair on the runstate's stream; the result is the average per launch, directly comparable with
-// rocprofv3's kernel durations.  Unsharded runstates only (a sharded kind would wait for gathers).
+// rocprofv3's kernel durations.  Unsharded runstates, or emulated ranks of a shard group.
 extern "C" int l2z_time_kind(int kind, int pos, const l2z_config *config, l2z_runstate *s,
                              const l2z_weights *w, int reps, double *avg_ms_per_launch, int *launches)
 {
     L2Z_TRY(check_pair(config, s, w));
     L2Z_CHECK(kind >= 0 && kind < KIND_GATHER && avg_ms_per_launch && reps >= 1, L2Z_ERR_INVALID,
               "l2z_time_kind: bad arguments");
-    L2Z_CHECK(s->sh.world == 1, L2Z_ERR_INVALID, "l2z_time_kind: unsharded runstates only");
+    // a shard's launches can be timed on an EMULATED rank (no transport: every input is a plain buffer, nothing waits):
+    // the per-rank kernel time of a sharded pass, measured on one GPU (bench.py extra.scaling_model)
+    L2Z_CHECK(s->sh.world == 1 || (s->comm && !s->comm->nccl && !s->comm->p2p), L2Z_ERR_INVALID,
+              "l2z_time_kind: unsharded runstates or emulated ranks only (a connected shard would wait for its peers)");
     L2Z_CHECK(pos >= 0 && pos < config->seq_len, L2Z_ERR_STATE, "pos out of range");
     L2Z_HIP(hipSetDevice(s->device));
     L2Z_HIP(launch_set_state(1, pos, s->d_token, s->d_pos, w->tok_emb, s->x, config->dim, s->stream));

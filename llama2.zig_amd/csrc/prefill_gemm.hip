@@ -762,7 +762,7 @@ static KgsChoice choose_kgs(int N, int P, int K, bool pair, const SplitKWs *ws)
     if (tn.pf_kgs >= 10) {  // forced (experiments): 10 + tile form
         const int f = tn.pf_kgs - 10;
         if (f < 0 || f > 4 || f == TILE_32x32 || (pair && f == TILE_128x128)) return none;
-        return {true, (TileForm)f};
+        return {true, (TileForm)f};  // (experiments: a grid beyond the workspace is reported by the launch)
     }
     // Measured (7B shape, whole prefill, interleaved; profiles/r03_prefill_kgs_ab.txt): the form pays where the
     // unsplit family runs ONE 8-wave block of a 128-token tile per CU -- two independent 4-wave blocks of half
@@ -775,6 +775,12 @@ static KgsChoice choose_kgs(int N, int P, int K, bool pair, const SplitKWs *ws)
     if (P < 512) return none;
     const TileForm tu = choose_tile(N, P, pair);
     if (tu != TILE_128x64 && tu != TILE_128x128) return none;
+    {   // the dump of one k-group per tile and two counters per tile must fit the runstate's workspace (sized for
+        // 1024-token chunks: L2Z_PF_CHUNK up to 2048 does not fit) -- else the one-block form, same bits
+        const size_t bm = 128, bn = tu == TILE_128x128 ? 128 : (pair ? 128 : 64), feat = pair ? bn / 2 : bn;
+        const size_t ntx = ((size_t)N + feat - 1) / feat, nty = ((size_t)P + bm - 1) / bm;
+        if (ntx * nty * bm * bn > ws->part_floats || 2 * ntx * nty > (size_t)ws->cnt_ints) return none;
+    }
     return {true, tu};
 }
 
@@ -823,7 +829,9 @@ int prefill_split_k(long long n_whole, int P, int K, bool pair)
         // two ranges (rocprofv3, 128 tokens: wo 61 -> 54 us, W2 162 -> 130, but q|k|v 126 -> 133, W1|W3 237 -> 256)
         const long long unsplit_blocks = ((n_whole + 63) / 64) * ((P + 31) / 32);
         if (streams && P >= 49 && P <= 64) sk = 4;
-        else if (streams && P > 64 && P <= 128 && 2 * unsplit_blocks <= 3 * g_cus_hint()) sk = 2;
+        // (1.5 blocks per CU of a 256-CU part, as a constant: the split is part of the arithmetic and must not depend
+        // on the device a rank happens to run on)
+        else if (streams && P > 64 && P <= 128 && 2 * unsplit_blocks <= 3 * 256) sk = 2;
     }
     while (sk > 1 && K % (64 * sk) != 0) sk >>= 1;
     return sk;

@@ -281,12 +281,22 @@ extern "C" int l2z_weights_init(const l2z_config *config, const float *data, siz
         const size_t rl = r1 - r0;
         float *dst = w->blob + w->dev_off[i];
         if (is_w1(d) || is_w3(d)) {
-            if (stage == nullptr) e = hipMalloc((void **)&stage, rl * d.cols * sizeof(float));
+            // in pieces of <= 64 MB through TWO staging buffers: a whole layer (180 MB at the 7B shape, ~1 GB at wider
+            // ones) allocated after the blob could be the allocation that no longer fits, and a device-wide
+            // synchronise per layer serialised the load.  A staging buffer is written again two pieces later; the
+            // host-to-device copy and the spreading kernel both run in the null stream, in order.
+            const size_t piece_rows = std::max<size_t>(1, std::min<size_t>(rl, ((size_t)64 << 20) / (d.cols * sizeof(float))));
+            if (stage == nullptr) e = hipMalloc((void **)&stage, 2 * piece_rows * d.cols * sizeof(float));
+            size_t n_piece = 0;
             for (size_t l = 0; l < d.layers && e == hipSuccess; l++) {
-                e = upload(stage, data + d.offset + (l * d.rows + r0) * d.cols, rl * d.cols);
-                if (e == hipSuccess) e = launch_copy_rows(dst + l * rl * 2 * d.cols, 2 * d.cols, stage, rl, d.cols, nullptr);
-                if (e == hipSuccess) e = hipDeviceSynchronize();  // the staging buffer is reused
+                for (size_t r = 0; r < rl && e == hipSuccess; r += piece_rows, n_piece++) {
+                    const size_t nr = std::min(piece_rows, rl - r);
+                    float *sb = stage + (n_piece & 1) * piece_rows * d.cols;
+                    e = upload(sb, data + d.offset + (l * d.rows + r0 + r) * d.cols, nr * d.cols);
+                    if (e == hipSuccess) e = launch_copy_rows(dst + (l * rl + r) * 2 * d.cols, 2 * d.cols, sb, nr, d.cols, nullptr);
+                }
             }
+            if (e == hipSuccess) e = hipDeviceSynchronize();
         } else if (rl == d.rows) {
             e = upload(dst, data + d.offset, d.count());
         } else {

@@ -366,8 +366,9 @@ def test_transformer_logits_and_state(gpu, ck, orc, name, kw, shared):
     for l in range(cfg.n_layers):
         k_ref = m.state("key_cache", cfg.n_layers * S * kvd)[l * S * kvd:(l * S + n_pos) * kvd]
         v_ref = m.state("value_cache", cfg.n_layers * S * kvd)[l * S * kvd:(l * S + n_pos) * kvd]
-        np.testing.assert_allclose(s.read("key_cache", l * S * kvd, n_pos * kvd), k_ref, rtol=2e-4, atol=2e-4)
-        np.testing.assert_allclose(s.read("value_cache", l * S * kvd, n_pos * kvd), v_ref, rtol=2e-4, atol=2e-4)
+        # the bound the prefill tests hold their KV rows to (round 3: 2e-4)
+        np.testing.assert_allclose(s.read("key_cache", l * S * kvd, n_pos * kvd), k_ref, rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(s.read("value_cache", l * S * kvd, n_pos * kvd), v_ref, rtol=2e-5, atol=2e-5)
     s.close(); w.close(); m.close()
 
 
