@@ -105,4 +105,17 @@ done
 } > $O/r04h_timeline.txt 2>&1
 cat $O/r04h_timeline.txt
 ;;
+i)
+# round 4, GPU call I: the per-rank cost model of a sharded decode token (emulated ranks), process-to-process variance
+# of the headline, the whole gpu-marked suite (KV tolerance 2e-5, ADVICE fixes), the bench line with repeats + scaling_model
+timeout 300 python scripts/sharded_decode_emu.py 8 1024 > $O/r04_sharded_decode_emu.md 2>&1
+cat $O/r04_sharded_decode_emu.md
+{ for i in 1 2 3 4 5 6; do timeout 120 python scripts/decode_steps.py llama2-7b 255; done; } > $O/r04i_process_variance.txt 2>&1
+cat $O/r04i_process_variance.txt
+timeout 1500 python -m pytest tests -m gpu -q -rA --durations=8 > $O/r04i_pytest_gpu.log 2>&1
+echo "pytest rc=$?" >> $O/r04i_pytest_gpu.log
+grep -E "passed|failed|^FAILED|rc=" $O/r04i_pytest_gpu.log | tail -n 8
+timeout 600 python bench.py > $O/r04i_bench.json 2> $O/r04i_bench.err
+tail -c 1500 $O/r04i_bench.json; tail -n 3 $O/r04i_bench.err
+;;
 esac
