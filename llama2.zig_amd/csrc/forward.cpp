@@ -67,6 +67,7 @@ int check_pair(const l2z_config *config, const l2z_runstate *s, const l2z_weight
 // of the previous hand-over of x.  Every mat-vec is the duo kernel (one 8-wave block per CU) and every attention
 // form a 256-thread one, so a waiting launch can never keep the launch it waits for from becoming resident.
 struct Hint { unsigned h0 = 0, n = 0, stride = 0; };
+static int enqueue_engine(l2z_runstate *s, const l2z_weights *w, bool with_step, int variant);
 
 // the elements a mat-vec producer writes in its last sweep over the units (virtual grid vgrid)
 static Hint mv_hint(int n_pairs, int vgrid, int epi)
@@ -83,6 +84,7 @@ static Hint mv_hint(int n_pairs, int vgrid, int epi)
 int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof *prof,
                     int only_stage, int variant, int only_kind)
 {
+    if (s->eng && only_stage < 0 && only_kind < 0 && prof == nullptr) return enqueue_engine(s, w, with_step, variant);
     const bool split = variant == ATTN_SPLIT || variant == ATTN_SPLIT_S;
     const l2z_config &c = s->cfg;
     const Shard &sh = s->sh;
@@ -304,6 +306,144 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
     return L2Z_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The pass as persistent launches (engine.hip; world == 1, wide-row models, L2Z_ENGINE=1):
+//   launch 0: q|k|v of layer 0        then per layer l: attention(l) -- its own launch, plain buffers either side --
+//   launch l + 1: wo(l), w1|w3(l), w2(l) and q|k|v(l + 1) (the classifier after the last layer) as ONE launch whose
+//   mat-vecs hand x / hb / x over as LL words in this process's own landing slots (the gathers 4l+2, 4l+3, 4l+4 of
+//   the sharded pass's numbering; epochs advance with the argmax launch, as in the overlapped chain).
+// Same units, same summation order, same epilogues as the launch chain: the same bits.
+// ---------------------------------------------------------------------------------------------------------------
+static int engine_prepare(l2z_runstate *s, const l2z_weights *w)
+{
+    if (s->eng_w_uid == w->uid) return L2Z_OK;
+    const l2z_config &c = s->cfg;
+    const Shard &sh = s->sh;
+    const l2z_comm *lc = s->self_comm;
+    const size_t dim = c.dim, hid = c.hidden_dim;
+    const int L = c.n_layers, vgrid = 2 * s->eng_grid;
+    const Tunables &tn = tunables();
+    std::vector<EngChunk> ch((size_t)L + 1);
+    auto nb_of = [](int n) { return ((n >> 2) + 1023) / 1024; };
+    auto set_op = [&](EngOp &o, const MatvecArgs &a, int pro, int epi) {
+        o.a = a; o.pro = pro; o.epi = epi;
+        const int rows = a.rows0 + a.rows1 + a.rows2;
+        o.n_pairs = epi == EPI_SWIGLU ? a.rows0 : (rows + 1) / 2;
+        o.nb = nb_of(a.n);
+    };
+    auto ll_in = [&](MatvecArgs &a, int g, size_t count, const Hint &h) {
+        a.xin = comm_ll_in(lc, g, count);
+        if (tn.overlap_hint && h.n) {
+            a.xin.hint0 = h.h0; a.xin.hint_n = h.n; a.xin.hint_stride = h.stride; a.xin.hint_sleep = tn.overlap_hint_sleep;
+        }
+    };
+    auto push = [&](MatvecArgs &a, int which, int g) { a.push = s->d_push + which; a.push_ctl = lc->d_ctl; a.push_gi = g; };
+    auto qkv_op = [&](EngOp &o, int l, bool plain) {
+        MatvecArgs a = {};
+        a.w0 = w->wq + (size_t)l * sh.dim_loc * dim;
+        a.w1 = w->wk + (size_t)l * sh.kvd_loc * dim;
+        a.w2 = w->wv + (size_t)l * sh.kvd_loc * dim;
+        a.out0 = s->q;
+        a.out1 = s->key_cache + (size_t)l * c.seq_len * sh.kvd_loc;
+        a.out2 = s->value_cache + (size_t)l * c.seq_len * sh.kvd_loc;
+        a.rows0 = sh.dim_loc; a.rows1 = sh.kvd_loc; a.rows2 = sh.kvd_loc;
+        a.pos_stride1 = sh.hs; a.pos_stride2 = sh.hs; a.kv_head_stride = (size_t)c.seq_len * sh.hs;
+        a.n = c.dim; a.rms_w = w->rms_att + (size_t)l * dim;
+        a.x = s->x;
+        if (!plain) ll_in(a, 4 * l, dim, mv_hint((c.dim + 1) / 2, vgrid, EPI_RESID));   // x as the previous layer's w2 handed it over
+        a.pos_ptr = s->d_pos; a.rope = s->rope; a.head_size = sh.hs; a.rope_segs = 2;
+        set_op(o, a, PRO_RMS, EPI_ROPE);
+    };
+    for (int i = 0; i <= L; i++) {
+        EngChunk &k = ch[(size_t)i];
+        memset(&k, 0, sizeof k);
+        k.ctl = lc->d_ctl; k.h_err = lc->h_err;
+        k.timeout_ticks = tn.p2p_timeout_s * 100000000LL;
+        k.dummy = w->tok_emb;
+        if (i == 0) {
+            k.n_ops = 1;
+            qkv_op(k.op[0], 0, true);
+            continue;
+        }
+        const int l = i - 1;
+        k.n_ops = 4;
+        {   // wo (:392) + residual (:395): xb and x are plain buffers (the attention launch, the launch before it)
+            MatvecArgs a = {};
+            a.w0 = w->wo + (size_t)l * dim * dim;
+            a.out0 = s->x; a.resid = s->x; a.rows0 = c.dim; a.n = c.dim; a.x = s->xb;
+            push(a, 1, 4 * l + 2);
+            set_op(k.op[0], a, PRO_NONE, EPI_RESID);
+        }
+        {   // rmsnorm (:398) + w1, w3 (:405-408) + SiLU * mul (:411-416)
+            MatvecArgs a = {};
+            a.w0 = w->w1 + (size_t)l * hid * 2 * dim;
+            a.w1 = w->w3 + (size_t)l * hid * 2 * dim;
+            a.out0 = s->hb; a.rows0 = c.hidden_dim; a.rows1 = c.hidden_dim; a.n = c.dim;
+            a.rms_w = w->rms_ffn + (size_t)l * dim; a.x = s->x;
+            ll_in(a, 4 * l + 2, dim, mv_hint((c.dim + 1) / 2, vgrid, EPI_RESID));
+            push(a, 2, 4 * l + 3);
+            set_op(k.op[1], a, PRO_RMS, EPI_SWIGLU);
+        }
+        {   // w2 (:419) + residual (:422): the residual is x as this launch's wo handed it over
+            MatvecArgs a = {};
+            a.w0 = w->w2 + (size_t)l * dim * hid;
+            a.out0 = s->x; a.resid = s->x; a.rows0 = c.dim; a.n = c.hidden_dim; a.x = s->hb;
+            ll_in(a, 4 * l + 3, hid, mv_hint(c.hidden_dim, vgrid, EPI_SWIGLU));
+            a.resid_in = comm_ll_in(lc, 4 * l + 2, dim);
+            push(a, 1, 4 * l + 4);
+            set_op(k.op[2], a, PRO_NONE, EPI_RESID);
+        }
+        if (l + 1 < L) {
+            qkv_op(k.op[3], l + 1, false);
+        } else {   // final rmsnorm (:426) + classifier (:429) + one argmax candidate per virtual block
+            MatvecArgs a = {};
+            a.w0 = w->wcls; a.out0 = s->logits; a.rows0 = c.vocab_size; a.n = c.dim; a.rms_w = w->rms_final; a.x = s->x;
+            ll_in(a, 4 * L, dim, mv_hint((c.dim + 1) / 2, vgrid, EPI_RESID));
+            a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.row_offset = 0;
+            set_op(k.op[3], a, PRO_RMS, EPI_ARGMAX);
+        }
+    }
+    L2Z_HIP(hipMemcpy(s->d_eng, ch.data(), ch.size() * sizeof(EngChunk), hipMemcpyHostToDevice));
+    s->eng_w_uid = w->uid;
+    return L2Z_OK;
+}
+
+static int enqueue_engine(l2z_runstate *s, const l2z_weights *w, bool with_step, int variant)
+{
+    const l2z_config &c = s->cfg;
+    const Shard &sh = s->sh;
+    hipStream_t st = s->stream;
+    const bool split = variant == ATTN_SPLIT || variant == ATTN_SPLIT_S;
+    L2Z_HIP(launch_engine(s->d_eng, s->eng_grid, s->eng_xs_floats, st));
+    for (int l = 0; l < c.n_layers; l++) {
+        AttnArgs a = {};
+        a.q = s->q;
+        a.kcache = s->key_cache + (size_t)l * c.seq_len * sh.kvd_loc;
+        a.vcache = s->value_cache + (size_t)l * c.seq_len * sh.kvd_loc;
+        a.xb = s->xb; a.pos_ptr = s->d_pos; a.head_size = sh.hs; a.kv_row = sh.hs; a.kv_head = (size_t)c.seq_len * sh.hs;
+        a.kv_mul = c.n_heads / c.n_kv_heads; a.seq_len = c.seq_len;
+        if (split && s->attn_nch > 1 && attention_split_supported(a))
+            L2Z_HIP(launch_attention_split(a, sh.heads_loc, s->attn_nch, s->d_attn_part, s->d_attn_cnt, st, variant == ATTN_SPLIT_S));
+        else
+            L2Z_HIP(launch_attention(a, sh.heads_loc, st, (variant == ATTN_SHORT || s->attn_all256) ? 1 : 0));
+        L2Z_HIP(launch_engine(s->d_eng + l + 1, s->eng_grid, s->eng_xs_floats, st));
+    }
+    s->n_part = 2 * s->eng_grid;
+    if (with_step) {
+        ArgmaxArgs a = {};
+        a.logits = s->logits; a.vocab = c.vocab_size; a.token_ptr = s->d_token;
+        a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.n_part = s->n_part;
+        a.pos_ptr = s->d_pos; a.prompt = s->d_prompt; a.n_prompt_ptr = s->d_n_prompt;
+        a.out_tokens = s->d_out_tokens; a.argmax_out = s->d_argmax; a.tok_emb = w->tok_emb;
+        a.x = s->x; a.dim = c.dim; a.advance = 1;
+        a.epoch_ctl = s->self_comm->d_ctl; a.epoch_add = s->n_gathers;
+        L2Z_HIP(launch_argmax(a, st));
+    } else {
+        L2Z_HIP(launch_epoch_advance(s->self_comm->d_ctl, s->n_gathers, st));
+    }
+    return L2Z_OK;
+}
+
 int attn_variant(const l2z_runstate *s, int pos)
 {
     if (s->attn_nch > 1 && pos >= s->attn_split_pos) return pos < s->attn_split_wide_pos ? ATTN_SPLIT_S : ATTN_SPLIT;
@@ -380,6 +520,7 @@ int run_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, int pos)
               "l2z_comm_p2p_export/_connect), or drive emulated ranks with l2z_emu_transformer");
     L2Z_TRY(comm_check(s->comm));
     L2Z_TRY(comm_check(s->self_comm));
+    if (s->eng) L2Z_TRY(engine_prepare(s, w));  // (a synchronous upload: before any capture)
     L2Z_TRY(ensure_graph(s, w, variant, with_step));
     if (s->use_graphs) {
         L2Z_HIP(hipGraphLaunch(with_step ? s->g_step[variant] : s->g_forward[variant], s->stream));

@@ -125,6 +125,12 @@ struct l2z_runstate {
     l2z_comm *self_comm = nullptr; // owned: arena, epoch counter, error latch of the hand-overs
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_tail = nullptr;
+    // persistent decode launches (engine.hip): one chunk description per launch, in device memory, rebuilt when the
+    // weights object changes (they hold its pointers)
+    bool eng = false;
+    int eng_grid = 0, eng_xs_floats = 0;
+    l2z::EngChunk *d_eng = nullptr;   // [n_layers + 1]
+    uint64_t eng_w_uid = 0;
     int tl_seq = 0;                // mat-vec launches enqueued so far (MatvecArgs::tl_seq, measurement builds)
 };
 

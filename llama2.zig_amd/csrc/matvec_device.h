@@ -2,17 +2,25 @@
 // (engine.hip): the argument block copied into locals, the pair -> weight rows map, and the fused epilogues
 // (RoPE + KV write, residual, SwiGLU, store) with what they prefetch.  Anonymous namespace, like kernel_common.h.
 #pragma once
+#include <type_traits>
+
 #include "kernel_common.h"
 
 namespace l2z {
 namespace {
 
 // Kernel arguments copied into plain locals once (keeps them out of scratch).
-struct MvLocals {
-    const float *w0, *w1, *w2;
-    float *out0, *out1, *out2;
-    const float *resid;
-    const float2 *rope;
+// G: the pointers carry the device-memory address space explicitly (engine.hip reads them out of a structure in
+// memory, where the compiler cannot infer it and would emit flat loads / stores); !G: plain pointers (kernel arguments)
+template <bool G>
+struct MvLocalsT {
+    typedef typename std::conditional<G, const L2Z_G float *, const float *>::type CFP;
+    typedef typename std::conditional<G, L2Z_G float *, float *>::type FP;
+    typedef typename std::conditional<G, const L2Z_G float2 *, const float2 *>::type CF2P;
+    CFP w0, w1, w2;
+    FP out0, out1, out2;
+    CFP resid;
+    CF2P rope;
     int rows0, r01, total_rows, n_pairs, n, head_size, rope_segs, pos;
     size_t ps1, ps2;
     size_t kv_head_stride;  // != 0: out1 / out2 are head-major caches (MatvecArgs::kv_head_stride)
@@ -26,6 +34,7 @@ struct MvLocals {
     long long resid_timeout;
     bool resid_pre;  // duo kernel: the residual words of all the block's units were requested at entry (EpiIn::rw is filled from LDS)
 };
+typedef MvLocalsT<false> MvLocals;
 
 template <int EPI>
 __device__ __forceinline__ MvLocals mv_locals(const MatvecArgs &a)
@@ -55,9 +64,9 @@ __device__ __forceinline__ MvLocals mv_locals(const MatvecArgs &a)
 }
 
 // the two weight rows of pair p (clamped to the last pair for idle lane groups)
-template <int EPI>
-__device__ __forceinline__ void pair_rows(const MvLocals &m, int p, const float *&pa,
-                                          const float *&pb)
+template <int EPI, bool G>
+__device__ __forceinline__ void pair_rows(const MvLocalsT<G> &m, int p, typename MvLocalsT<G>::CFP &pa,
+                                          typename MvLocalsT<G>::CFP &pb)
 {
     if (p >= m.n_pairs) p = m.n_pairs - 1;
     if (EPI == EPI_SWIGLU) {  // w0: W1 | W3 row-interleaved (MatvecArgs): the pair is one contiguous run like any other
@@ -70,9 +79,9 @@ __device__ __forceinline__ void pair_rows(const MvLocals &m, int p, const float 
         const bool b1 = gb >= m.rows0, b2 = gb >= m.r01;
         const int row_a = ga - (a2 ? m.r01 : (a1 ? m.rows0 : 0));
         const int row_b = gb - (b2 ? m.r01 : (b1 ? m.rows0 : 0));
-        const float *wa = a1 ? m.w1 : m.w0;
+        typename MvLocalsT<G>::CFP wa = a1 ? m.w1 : m.w0;
         wa = a2 ? m.w2 : wa;
-        const float *wb = b1 ? m.w1 : m.w0;
+        typename MvLocalsT<G>::CFP wb = b1 ? m.w1 : m.w0;
         wb = b2 ? m.w2 : wb;
         pa = wa + (size_t)row_a * (size_t)m.n;
         pb = wb + (size_t)row_b * (size_t)m.n;
@@ -117,8 +126,8 @@ __device__ __forceinline__ EpiIn epi_prefetch(const MvLocals &m, int p, bool wri
 
 // stash != null (duo kernel of an overlapped chain): the values that would be pushed as LL words are left in
 // stash[0], stash[1] instead and pushed by the block when its units are done (matvec_duo_kernel)
-template <int EPI>
-__device__ __forceinline__ void pair_epilogue(const MvLocals &m, int p, float sa, float sb,
+template <int EPI, bool G>
+__device__ __forceinline__ void pair_epilogue(const MvLocalsT<G> &m, int p, float sa, float sb,
                                               bool writer, const EpiIn &in, float *stash = nullptr)
 {
     const bool valid_a = p < m.n_pairs;
@@ -139,9 +148,9 @@ __device__ __forceinline__ void pair_epilogue(const MvLocals &m, int p, float sa
     const bool b1 = gb >= m.rows0, b2 = gb >= m.r01;
     const int row_a = ga - (a2 ? m.r01 : (a1 ? m.rows0 : 0));
     const int row_b = gb - (b2 ? m.r01 : (b1 ? m.rows0 : 0));
-    float *oa = a1 ? m.out1 + m.ps1 : m.out0;
+    typename MvLocalsT<G>::FP oa = a1 ? m.out1 + m.ps1 : m.out0;
     oa = a2 ? m.out2 + m.ps2 : oa;
-    float *ob = b1 ? m.out1 + m.ps1 : m.out0;
+    typename MvLocalsT<G>::FP ob = b1 ? m.out1 + m.ps1 : m.out0;
     ob = b2 ? m.out2 + m.ps2 : ob;
     if (EPI == EPI_ROPE) {
         // rows (row_a, row_a+1) of one segment: the pair (i, i+1) of :346-349

@@ -132,7 +132,18 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
         aa.head_size = sh.hs; aa.kv_row = sh.hs; aa.kv_head = (size_t)c.seq_len * sh.hs;
         s->duo = attention_push_supported(aa);
     }
-    if (s->duo && tn.overlap != 0 && e == hipSuccess) {
+    // the persistent decode launches: wide-row model, every mat-vec's units fit the blocks' lanes
+    if (sh.world == 1 && tn.engine != 0 && !s->fused_qkv_attn && matvec_duo_supported(c.dim) && matvec_duo_supported(c.hidden_dim) &&
+        e == hipSuccess) {
+        const int grid = g_cus;
+        s->eng = engine_units_ok((c.dim + 2 * sh.kvd_loc + 1) / 2, grid) && engine_units_ok((c.dim + 1) / 2, grid) &&
+                 engine_units_ok(c.hidden_dim, grid) && engine_units_ok((c.vocab_size + 1) / 2, grid) && matvec_vector_width(c.dim);
+        s->eng_grid = grid;
+        s->eng_xs_floats = engine_xs_floats(std::max(c.dim, c.hidden_dim));
+        if (s->eng && engine_lds_bytes(s->eng_xs_floats) > 160 * 1024) s->eng = false;
+        if (s->eng) alloc((void **)&s->d_eng, (size_t)(c.n_layers + 1) * sizeof(EngChunk));
+    }
+    if (((s->duo && tn.overlap != 0) || s->eng) && e == hipSuccess) {
         // the overlapped chain: a second stream, fork / join events, and this process's own landing slots
         s->self_comm = comm_self_create(dev, (size_t)std::max(c.dim, c.hidden_dim));
         if (s->self_comm == nullptr) {
@@ -150,8 +161,9 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_tail, hipEventDisableTiming);
-        s->ovl = e == hipSuccess;
+        s->ovl = e == hipSuccess && s->duo && tn.overlap != 0 && !s->eng;
         s->ovl_edges = tn.overlap_edges & 15;
+        if (e != hipSuccess) s->eng = false;
     }
     if (e != hipSuccess) {
         set_error("RunState allocation failed: %s", hipGetErrorString(e));
@@ -196,7 +208,7 @@ extern "C" void l2z_runstate_free(l2z_runstate *s)
     void *ptrs[] = {s->x, s->xb, s->hb, s->q, s->logits, s->key_cache, s->value_cache, s->rope,
                     s->d_token, s->d_pos, s->d_prompt, s->d_n_prompt, s->d_out_tokens, s->d_argmax,
                     s->d_probs, s->d_part_val, s->d_part_idx, s->d_attn_part, s->d_attn_cnt, s->pf_x, s->pf_xn, s->pf_q,
-                    s->pf_att, s->pf_h1, s->pf_stage, s->pf_tokens, s->d_push, s->pf_sk.part, s->pf_sk.cnt};
+                    s->pf_att, s->pf_h1, s->pf_stage, s->pf_tokens, s->d_push, s->pf_sk.part, s->pf_sk.cnt, s->d_eng};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->h_stage) (void)hipHostFree(s->h_stage);

@@ -118,4 +118,15 @@ grep -E "passed|failed|^FAILED|rc=" $O/r04i_pytest_gpu.log | tail -n 8
 timeout 600 python bench.py > $O/r04i_bench.json 2> $O/r04i_bench.err
 tail -c 1500 $O/r04i_bench.json; tail -n 3 $O/r04i_bench.err
 ;;
+j)
+# round 4, GPU call J: the persistent decode launches (engine.hip): bits and speed against the launch chain
+export L2Z_P2P_TIMEOUT_S=3
+{
+timeout 300 python scripts/ab.py llama2-7b 128 3 "" "L2Z_ENGINE=1"
+echo "rc=$?"
+timeout 300 python scripts/ab.py llama2-7b 64 3 300 "" "L2Z_ENGINE=1"
+echo "rc=$?"
+} > $O/r04j_ab.txt 2>&1
+cat $O/r04j_ab.txt
+;;
 esac
