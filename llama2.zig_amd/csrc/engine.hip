@@ -90,6 +90,17 @@ __device__ __forceinline__ MvG eng_locals(const MatvecArgs &a, int epi)
 // allocates in these waves (every statement clobbers them all; scripts/check_engine_regs.py verifies the build).
 #include "engine_ring.inc"
 
+#ifdef L2Z_TIMELINE
+// measurement build (scripts/timeline_build.sh): per (launch, block) wall-clock stamps (100 MHz), stored at the end --
+// [0] entry; per mat-vec k: [1 + 6k] streaming waves start waiting for x, [2 + 6k] x ready, [3 + 6k] their last unit
+// done; [4 + 6k] gatherer past the gate, [5 + 6k] x staged, [6 + 6k] outputs published.  Read with l2z_engine_timeline_dump.
+constexpr int kEtlMax = 1024, kEtlBlocks = 256, kEtlSlots = 32;
+__device__ long long g_etl[kEtlMax * kEtlBlocks * kEtlSlots];
+#define L2Z_ETL(slot) do { if (tl_on) tl[(slot)] = wall_clock64(); } while (0)
+#else
+#define L2Z_ETL(slot) do { } while (0)
+#endif
+
 // units half 0 of block b has in a mat-vec of n_pairs pairs: the block's unit steps for that mat-vec
 __device__ __forceinline__ int eng_steps(int n_pairs, int b, int vgrid) { return (n_pairs - 2 * b + vgrid - 1) / vgrid; }
 
@@ -98,8 +109,15 @@ __device__ __forceinline__ int eng_steps(int n_pairs, int b, int vgrid) { return
 // duo form: x plain (first mat-vec of the chunk, written by the launch before this one) or xin (LL words written by
 // mat-vec k - 1 of this launch), resid plain or resid_in, push (outputs as LL words) for all but the last.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__restrict__ chunk, int xs_floats)
+__global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__restrict__ chunk, int xs_floats, int tl_seq)
 {
+#ifdef L2Z_TIMELINE
+    const bool tl_on = tl_seq >= 0 && tl_seq < kEtlMax && blockIdx.x < kEtlBlocks && (threadIdx.x == 0 || threadIdx.x == kEngStream);
+    long long *tl = g_etl + ((size_t)(tl_on ? tl_seq : 0) * kEtlBlocks + blockIdx.x) * kEtlSlots;
+    if (tl_on && threadIdx.x == 0) tl[0] = wall_clock64();
+#else
+    (void)tl_seq;
+#endif
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *xs_base = lds;                                   // [2][xs_floats] x of the running and of the next mat-vec
     volatile L2Z_S int *ctrl = (volatile L2Z_S int *)(lds + 2 * (size_t)xs_floats);  // EC_WORDS control words
@@ -163,6 +181,7 @@ __global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__r
                     if (bad) break;
                 }
             }
+            L2Z_ETL(4 + 6 * g);
             // ---- this lane's epilogue input: residual values (validated once, here) or the RoPE pair
             v4u ein = {0u, 0u, 0u, 0u};
             if (uk < n_pairs) {
@@ -270,6 +289,7 @@ __global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__r
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) ctrl[EC_READY] = g + 1;
+            L2Z_ETL(5 + 6 * g);
 
             // ---- the epilogues of this mat-vec's unit steps, as their partial sums arrive
             const MvG me = eng_locals(a, epi);
@@ -320,6 +340,7 @@ __global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__r
                     if (2 * uk + 1 < total_rows) p2p_ll_push(a.push, e, (size_t)(2 * uk + 1), hold_b);
                 }
             }
+            L2Z_ETL(6 + 6 * g);
             if (epi == EPI_ARGMAX) {  // one candidate per virtual block: its units in ascending order, strict >
                 float *gb = gbest + (gh * kEngUnits + gk) * 2;
                 gb[0] = hold_a; gb[1] = hold_b;
@@ -468,7 +489,9 @@ __global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__r
     int cop = 0, cu = vb, cb = 0, useq = 0;
     int c_nb = desc[0].nb, c_pairs = desc[0].n_pairs;
     int xs_off = 0;   // floats from xs_base to the running mat-vec's x
+    L2Z_ETL(1);
     wait_ge(EC_READY, 1);
+    L2Z_ETL(2);
     bool c_valid = true;
 
     auto unit_end = [&]() {
@@ -487,6 +510,7 @@ __global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__r
         if (tid == 0) ctrl[EC_UNITS] = useq;
         cu += vgrid;
         if (cu - half < c_pairs) return;
+        L2Z_ETL(3 + 6 * cop);
         cop++;                 // this block is done with the mat-vec
         if (cop >= n_ops) {
             c_valid = false;
@@ -495,7 +519,9 @@ __global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__r
         c_pairs = desc[cop].n_pairs; c_nb = desc[cop].nb;
         cu = vb;
         xs_off = (cop & 1) * xs_floats;
+        L2Z_ETL(1 + 6 * cop);
         wait_ge(EC_READY, cop + 1);   // x of this mat-vec staged
+        L2Z_ETL(2 + 6 * cop);
     };
     // LDS byte address of this thread's first float4 of the batch (the asm adds k * 4096)
     auto xaddr_of = [&]() { return (unsigned)(size_t)(L2Z_S float *)(xs_base + xs_off) + (unsigned)(cb * (kBlock * kEngU) + ht) * 16u; };
@@ -552,13 +578,22 @@ bool engine_units_ok(int n_pairs, int grid)
     return vgrid >= 2 && vgrid <= n_pairs && (n_pairs + vgrid - 1) / vgrid <= kEngUnits;
 }
 
-hipError_t launch_engine(const EngChunk *d_chunk, int grid, int xs_floats, hipStream_t st)
+hipError_t launch_engine(const EngChunk *d_chunk, int grid, int xs_floats, hipStream_t st, int tl_seq)
 {
     const size_t lds = engine_lds_bytes(xs_floats);
     hipError_t e = ensure_lds(engine_kernel, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(engine_kernel, dim3(grid), dim3(kEngThreads), lds, st, d_chunk, xs_floats);
+    hipLaunchKernelGGL(engine_kernel, dim3(grid), dim3(kEngThreads), lds, st, d_chunk, xs_floats, tl_seq);
     return hipGetLastError();
 }
 
 }  // namespace l2z
+
+#ifdef L2Z_TIMELINE
+extern "C" int l2z_engine_timeline_dump(long long *out, int max_launches)
+{
+    const int n = max_launches < l2z::kEtlMax ? max_launches : l2z::kEtlMax;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(l2z::g_etl), (size_t)n * l2z::kEtlBlocks * l2z::kEtlSlots * sizeof(long long)) != hipSuccess) return 1;
+    return 0;
+}
+#endif

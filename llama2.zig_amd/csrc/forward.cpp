@@ -414,7 +414,7 @@ static int enqueue_engine(l2z_runstate *s, const l2z_weights *w, bool with_step,
     const Shard &sh = s->sh;
     hipStream_t st = s->stream;
     const bool split = variant == ATTN_SPLIT || variant == ATTN_SPLIT_S;
-    L2Z_HIP(launch_engine(s->d_eng, s->eng_grid, s->eng_xs_floats, st));
+    L2Z_HIP(launch_engine(s->d_eng, s->eng_grid, s->eng_xs_floats, st, s->tl_seq++));
     for (int l = 0; l < c.n_layers; l++) {
         AttnArgs a = {};
         a.q = s->q;
@@ -426,7 +426,7 @@ static int enqueue_engine(l2z_runstate *s, const l2z_weights *w, bool with_step,
             L2Z_HIP(launch_attention_split(a, sh.heads_loc, s->attn_nch, s->d_attn_part, s->d_attn_cnt, st, variant == ATTN_SPLIT_S));
         else
             L2Z_HIP(launch_attention(a, sh.heads_loc, st, (variant == ATTN_SHORT || s->attn_all256) ? 1 : 0));
-        L2Z_HIP(launch_engine(s->d_eng + l + 1, s->eng_grid, s->eng_xs_floats, st));
+        L2Z_HIP(launch_engine(s->d_eng + l + 1, s->eng_grid, s->eng_xs_floats, st, s->tl_seq++));
     }
     s->n_part = 2 * s->eng_grid;
     if (with_step) {

@@ -161,7 +161,7 @@ size_t engine_lds_bytes(int xs_floats);
 int engine_xs_floats(int n_max);
 bool engine_units_ok(int n_pairs, int grid);
 // d_chunk: device memory.  grid blocks of 576 threads, all of which must be resident at once (grid <= CUs)
-hipError_t launch_engine(const EngChunk *d_chunk, int grid, int xs_floats, hipStream_t st);
+hipError_t launch_engine(const EngChunk *d_chunk, int grid, int xs_floats, hipStream_t st, int tl_seq = -1);  // tl_seq: measurement builds
 
 // main.zig:361-389: scores, softmax, att.V for the local heads of one layer
 struct AttnArgs {

@@ -129,4 +129,10 @@ echo "rc=$?"
 } > $O/r04j_ab.txt 2>&1
 cat $O/r04j_ab.txt
 ;;
+k)
+# round 4, GPU call K: where a persistent launch spends its time (measurement build)
+export L2Z_P2P_TIMEOUT_S=3
+L2Z_LIB=$PWD/llama2.zig_amd/libllama2_hip_tl.so L2Z_NO_GRAPH=1 L2Z_ENGINE=1 timeout 200 python scripts/engine_timeline.py 4 > $O/r04k_engine_timeline.md 2>&1
+cat $O/r04k_engine_timeline.md
+;;
 esac
