@@ -43,12 +43,13 @@ namespace {
 #define L2Z_S __attribute__((address_space(3)))
 
 constexpr int kEngStream = 512;               // streaming threads: two halves of kBlock
-constexpr int kEngThreads = kEngStream + 64;  // + the gatherer wave
+constexpr int kEngGather = 256;                // the gatherer: four waves (its leader, wave 8, also runs the epilogues and publishes)
+constexpr int kEngThreads = kEngStream + kEngGather;
 constexpr int kEngR = 3;                      // weight batches in flight per streaming wave
 constexpr int kEngU = 4;                      // float4 per row per thread per batch (as the row kernel)
 constexpr int kEngUnits = 32;                 // most units of one mat-vec a half may have (lanes of the gatherer: 2 x 32)
 
-enum { EC_BAR = 0, EC_READY, EC_UNITS, EC_EPI, EC_ERR, EC_DESC, EC_WORDS = 8 };  // control words in LDS
+enum { EC_BAR = 0, EC_READY, EC_UNITS, EC_EPI, EC_ERR, EC_DESC, EC_GO, EC_GBAR, EC_WORDS = 8 };  // control words in LDS
 constexpr int kEngSlots = 8;                  // units whose wave partials may wait in LDS for the gatherer's epilogue
 
 // what the streaming waves need to know of a mat-vec, in LDS (written once by the gatherer)
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__r
     float *part = lds + 2 * (size_t)xs_floats + EC_WORDS;   // [kEngSlots][half][2][kWaves] wave partials of a unit step
     EngDesc *desc = (EngDesc *)(part + kEngSlots * 2 * 2 * kWaves);  // [kEngMaxOps]
     float *gbest = (float *)(desc + kEngMaxOps);            // [2][kEngUnits][2] classifier: per-unit candidates (value, index bits)
+    float *gpart = gbest + 2 * kEngUnits * 2;               // [kWaves] the gatherer waves' partial sums of squares
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n_ops = chunk->n_ops;
@@ -132,15 +134,22 @@ __global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__r
     if (tid < EC_WORDS) ctrl[tid] = 0;
     __syncthreads();  // the only hardware barrier: all nine waves, before the roles part
 
-    if (wave == 8) {
+    if (wave >= 8) {
         // =========================================================================================================
         // The gatherer.  Per mat-vec k, in order: stage x (+ this block's per-unit epilogue inputs), then run the
         // epilogue of every unit step as its partial sums arrive, then publish the block's outputs.
         // =========================================================================================================
         asm volatile("; L2Z_GATHER_BEGIN (scripts/check_engine_regs.py)" ::: "memory");
+        // Four waves.  Wave 8 leads: it waits at the gate, runs the epilogues and publishes (lane = (half, k-th unit));
+        // all four sweep x -- gatherer lane t plays thread t of the 256-thread kernels' staging (float4 t, t + 256, ...;
+        // sum of squares per thread, wave sum, four partials in wave order: main.zig:432-468 in that order, bit for bit).
+        // One wave alone took 8-14 us per hand-over (profiles/r04_engine_timeline*.md): 16 KB ... 88 KB of words at one
+        // or two round trips per 16 loads.
         int *g_ctl = chunk->ctl;
         int *h_err = chunk->h_err;
-        if (lane < n_ops) {
+        const int gw = wave - 8, gl = tid - kEngStream;
+        const bool leader = gw == 0;
+        if (leader && lane < n_ops) {
             const MatvecArgs &a = chunk->op[lane].a;
             EngDesc d;
             d.w0 = (unsigned long long)a.w0; d.w1 = (unsigned long long)a.w1; d.w2 = (unsigned long long)a.w2;
@@ -149,10 +158,23 @@ __global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__r
             desc[lane] = d;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) ctrl[EC_DESC] = 1;
-        const int gh = lane >> 5, gk = lane & 31;          // this lane's (half, k-th unit)
+        if (leader && lane == 0) ctrl[EC_DESC] = 1;
+        const int gh = lane >> 5, gk = lane & 31;          // the leader's lanes: (half, k-th unit)
         int useq = 0;                                      // unit steps whose epilogue has run (all mat-vecs)
         bool bad = false;
+        int gbar_target = 0;
+        L2Z_S int *gbar = (L2Z_S int *)&ctrl[EC_GBAR];
+        auto gather_barrier = [&]() {   // among the four gatherer waves
+            gbar_target += kEngGather / 64;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_fetch_add(gbar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(gbar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gbar_target) {
+                if (ctrl[EC_ERR] || wall_clock64() - t0 > timeout) { ctrl[EC_ERR] = 1; bad = true; break; }
+                __builtin_amdgcn_s_sleep(0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        };
         for (int g = 0; g < n_ops && !bad; g++) {
             const MatvecArgs &a = chunk->op[g].a;
             const int pro = chunk->op[g].pro, epi = chunk->op[g].epi;
@@ -162,13 +184,13 @@ __global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__r
             const int n4_pad = ((n4 + kBlock * kEngU - 1) / (kBlock * kEngU)) * (kBlock * kEngU);
             v4f *xs4 = (v4f *)(xs_base + (size_t)(g & 1) * xs_floats);
             const v4f zero = {0.f, 0.f, 0.f, 0.f};
-            const int uk = 2 * blockIdx.x + gh + gk * vgrid;   // this lane's unit of this mat-vec (if < n_pairs)
+            const int uk = 2 * blockIdx.x + gh + gk * vgrid;   // the leader lane's unit of this mat-vec (if < n_pairs)
             const bool ll = a.xin.slots != nullptr;
             LLPoll lp = {};
-            // ---- the gate: 16 producer blocks' last words (this block's own outputs of mat-vec g - 1 are out: below)
-            if (ll) {
-                lp = ll_poll_init(a.xin);
-                if (a.xin.hint_n != 0) {
+            if (ll) lp = ll_poll_init(a.xin);
+            if (leader) {
+                // ---- the gate: 16 producer blocks' last words (this block's own outputs of mat-vec g - 1 are out: below)
+                if (ll && a.xin.hint_n != 0) {
                     const unsigned step = a.xin.hint_n >= kHintLanes ? a.xin.hint_n / kHintLanes : 1u;
                     const unsigned idx = a.xin.hint0 + ((blockIdx.x + (lane & (kHintLanes - 1)) * step) % a.xin.hint_n) * a.xin.hint_stride;
                     const long long t0 = wall_clock64();
@@ -178,13 +200,24 @@ __global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__r
                         if (ctrl[EC_ERR] || wall_clock64() - t0 > timeout) { bad = true; break; }
                         __builtin_amdgcn_s_sleep(8);
                     }
-                    if (bad) break;
                 }
+                if (bad) ctrl[EC_ERR] = 1;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) ctrl[EC_GO] = g + 1;
+                if (bad) break;
+            } else {
+                const long long t0 = wall_clock64();
+                while (ctrl[EC_GO] < g + 1) {
+                    if (ctrl[EC_ERR] || wall_clock64() - t0 > 4 * timeout) { bad = true; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (bad) break;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
             L2Z_ETL(4 + 6 * g);
             // ---- this lane's epilogue input: residual values (validated once, here) or the RoPE pair
             v4u ein = {0u, 0u, 0u, 0u};
-            if (uk < n_pairs) {
+            if (leader && uk < n_pairs) {
                 if (epi == EPI_RESID) {
                     const bool two = 2 * uk + 1 < total_rows;
                     if (a.resid_in.slots != nullptr) {
@@ -219,21 +252,21 @@ __global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__r
                 }
             }
             // ---- x into the buffer of this mat-vec's parity (free: the streaming waves finished mat-vec g - 2 before
-            // mat-vec g - 1, whose epilogues all ran above): lane L holds float4 L + 64 i
-            constexpr int RG = 8;   // float4 per lane per round (16 loads of 16 bytes in flight in the LL form)
-            for (int j0 = lane; j0 < n4_pad; j0 += 64 * RG) {
+            // mat-vec g - 1, whose epilogues all ran): gatherer lane t holds float4 t + 256 i
+            constexpr int RG = 11;  // float4 per lane per round: the longest vector here (11008 floats) in one round of 22 loads
+            for (int j0 = gl; j0 < n4_pad; j0 += kEngGather * RG) {
                 if (ll) {
                     v4u w[2 * RG];
 #pragma unroll
                     for (int i = 0; i < RG; i++) {
-                        const int j = j0 + 64 * i;
+                        const int j = j0 + kEngGather * i;
                         const int jc = j < n4 ? j : 0;
                         w[2 * i] = ll_load2(lp.slot, (size_t)4 * jc);
                         w[2 * i + 1] = ll_load2(lp.slot, (size_t)4 * jc + 2);
                     }
 #pragma unroll
                     for (int i = 0; i < RG; i++) {
-                        const int j = j0 + 64 * i;
+                        const int j = j0 + kEngGather * i;
                         if (j < n4_pad) {
                             const v4f v = ll_wait4(lp, j < n4 ? j : 0, w[2 * i], w[2 * i + 1]);
                             xs4[j] = j < n4 ? v : zero;
@@ -244,49 +277,50 @@ __global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__r
                     v4f v[RG];
 #pragma unroll
                     for (int i = 0; i < RG; i++) {
-                        const int j = j0 + 64 * i;
+                        const int j = j0 + kEngGather * i;
                         v[i] = j < n4 ? x4[j] : zero;
                     }
 #pragma unroll
                     for (int i = 0; i < RG; i++) {
-                        const int j = j0 + 64 * i;
+                        const int j = j0 + kEngGather * i;
                         if (j < n4_pad) xs4[j] = v[i];
                     }
                 }
             }
             if (pro == PRO_RMS) {
-                // main.zig:432-468 in the 256-thread kernels' order: thread t sums float4 t, t + 256, ... (fmaf per
-                // component), wave sum, the four wave partials added in wave order.  Lane L plays t = L + 64 v.
-                float pv[kWaves];
-#pragma unroll
-                for (int v = 0; v < kWaves; v++) {
-                    float ss = 0.0f;
-                    for (int j = lane + 64 * v; j < n4; j += kBlock) {
-                        const v4f x = xs4[j];
-                        ss = fmaf(x.x, x.x, ss);
-                        ss = fmaf(x.y, x.y, ss);
-                        ss = fmaf(x.z, x.z, ss);
-                        ss = fmaf(x.w, x.w, ss);
-                    }
-                    pv[v] = wave_sum(ss);
+                // main.zig:432-468 in the 256-thread kernels' order: thread t sums its float4 t, t + 256, ... (fmaf per
+                // component), wave sum, the four wave partials added in wave order
+                float ss = 0.0f;
+                for (int j = gl; j < n4; j += kEngGather) {
+                    const v4f x = xs4[j];   // this lane's own float4 (it wrote them)
+                    ss = fmaf(x.x, x.x, ss);
+                    ss = fmaf(x.y, x.y, ss);
+                    ss = fmaf(x.z, x.z, ss);
+                    ss = fmaf(x.w, x.w, ss);
                 }
-                float tot = pv[0];
+                ss = wave_sum(ss);
+                if (lane == 0) gpart[gw] = ss;
+                gather_barrier();
+                float tot = gpart[0];
 #pragma unroll
-                for (int v = 1; v < kWaves; v++) tot += pv[v];
-                float s = tot / (float)n;  // :452
-                s += 1e-5f;                // :453
-                s = 1.0f / sqrtf(s);       // :454
+                for (int v = 1; v < kWaves; v++) tot += gpart[v];
+                float sc = tot / (float)n;  // :452
+                sc += 1e-5f;                // :453
+                sc = 1.0f / sqrtf(sc);      // :454
                 const L2Z_G v4f *g4 = (const L2Z_G v4f *)a.rms_w;
-                for (int j = lane; j < n4; j += 64) {
+                for (int j = gl; j < n4; j += kEngGather) {
                     v4f x = xs4[j];
-                    const v4f gw = g4[j];
-                    x.x = (x.x * s) * gw.x;  // :462
-                    x.y = (x.y * s) * gw.y;
-                    x.z = (x.z * s) * gw.z;
-                    x.w = (x.w * s) * gw.w;
+                    const v4f gw4 = g4[j];
+                    x.x = (x.x * sc) * gw4.x;  // :462
+                    x.y = (x.y * sc) * gw4.y;
+                    x.z = (x.z * sc) * gw4.z;
+                    x.w = (x.w * sc) * gw4.w;
                     xs4[j] = x;
                 }
             }
+            gather_barrier();   // x (and, with the rmsnorm, every lane's share of it) is in LDS
+            if (bad) break;
+            if (!leader) continue;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) ctrl[EC_READY] = g + 1;
             L2Z_ETL(5 + 6 * g);
@@ -360,7 +394,7 @@ __global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__r
                 }
             }
         }
-        if ((bad || ctrl[EC_ERR]) && lane == 0) {  // a wait in this block gave up: latch it for every later wait, tell the host
+        if ((bad || ctrl[EC_ERR]) && leader && lane == 0) {  // a wait in this block gave up: latch it for every later wait, tell the host
             ctrl[EC_ERR] = 1;
             __hip_atomic_store(g_ctl + kCtlErr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *h_err = 1;

@@ -135,4 +135,14 @@ export L2Z_P2P_TIMEOUT_S=3
 L2Z_LIB=$PWD/llama2.zig_amd/libllama2_hip_tl.so L2Z_NO_GRAPH=1 L2Z_ENGINE=1 timeout 200 python scripts/engine_timeline.py 4 > $O/r04k_engine_timeline.md 2>&1
 cat $O/r04k_engine_timeline.md
 ;;
+l)
+# round 4, GPU call L: four gatherer waves -- bits, speed, timeline
+export L2Z_P2P_TIMEOUT_S=3
+{
+timeout 300 python scripts/ab.py llama2-7b 128 3 "" "L2Z_ENGINE=1"
+echo "rc=$?"
+L2Z_LIB=$PWD/llama2.zig_amd/libllama2_hip_tl.so L2Z_NO_GRAPH=1 L2Z_ENGINE=1 timeout 200 python scripts/engine_timeline.py 4
+} > $O/r04l_engine.txt 2>&1
+cat $O/r04l_engine.txt
+;;
 esac
