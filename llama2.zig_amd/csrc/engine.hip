@@ -126,13 +126,20 @@ __global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__r
     EngDesc *desc = (EngDesc *)(part + kEngSlots * 2 * 2 * kWaves);  // [kEngMaxOps]
     float *gbest = (float *)(desc + kEngMaxOps);            // [2][kEngUnits][2] classifier: per-unit candidates (value, index bits)
     float *gpart = gbest + 2 * kEngUnits * 2;               // [kWaves] the gatherer waves' partial sums of squares
+    EngChunk *lch = (EngChunk *)(gpart + 2 * kWaves);       // the chunk description, copied once: every field the gatherer reads from
+                                                            // device memory was a dependent ~1 us round trip (8 us per hand-over)
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n_ops = chunk->n_ops;
     const int vgrid = 2 * gridDim.x;
     const long long timeout = chunk->timeout_ticks;
     if (tid < EC_WORDS) ctrl[tid] = 0;
-    __syncthreads();  // the only hardware barrier: all nine waves, before the roles part
+    {   // the chunk description into LDS: one coalesced round trip by everybody
+        const L2Z_G unsigned *src = (const L2Z_G unsigned *)chunk;
+        unsigned *dst = (unsigned *)lch;
+        for (int i = tid; i < (int)(sizeof(EngChunk) / 4); i += kEngThreads) dst[i] = src[i];
+    }
+    __syncthreads();  // the only hardware barrier: all twelve waves, before the roles part
 
     if (wave >= 8) {
         // =========================================================================================================
@@ -145,16 +152,16 @@ __global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__r
         // sum of squares per thread, wave sum, four partials in wave order: main.zig:432-468 in that order, bit for bit).
         // One wave alone took 8-14 us per hand-over (profiles/r04_engine_timeline*.md): 16 KB ... 88 KB of words at one
         // or two round trips per 16 loads.
-        int *g_ctl = chunk->ctl;
-        int *h_err = chunk->h_err;
+        int *g_ctl = lch->ctl;
+        int *h_err = lch->h_err;
         const int gw = wave - 8, gl = tid - kEngStream;
         const bool leader = gw == 0;
         if (leader && lane < n_ops) {
-            const MatvecArgs &a = chunk->op[lane].a;
+            const MatvecArgs &a = lch->op[lane].a;
             EngDesc d;
             d.w0 = (unsigned long long)a.w0; d.w1 = (unsigned long long)a.w1; d.w2 = (unsigned long long)a.w2;
             d.rows0 = a.rows0; d.r01 = a.rows0 + a.rows1; d.total_rows = a.rows0 + a.rows1 + a.rows2;
-            d.n_pairs = chunk->op[lane].n_pairs; d.n4 = a.n >> 2; d.nb = chunk->op[lane].nb; d.epi = chunk->op[lane].epi; d.pad = 0;
+            d.n_pairs = lch->op[lane].n_pairs; d.n4 = a.n >> 2; d.nb = lch->op[lane].nb; d.epi = lch->op[lane].epi; d.pad = 0;
             desc[lane] = d;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -176,9 +183,9 @@ __global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__r
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         };
         for (int g = 0; g < n_ops && !bad; g++) {
-            const MatvecArgs &a = chunk->op[g].a;
-            const int pro = chunk->op[g].pro, epi = chunk->op[g].epi;
-            const int n_pairs = chunk->op[g].n_pairs;
+            const MatvecArgs &a = lch->op[g].a;
+            const int pro = lch->op[g].pro, epi = lch->op[g].epi;
+            const int n_pairs = lch->op[g].n_pairs;
             const int total_rows = a.rows0 + a.rows1 + a.rows2;
             const int n = a.n, n4 = n >> 2;
             const int n4_pad = ((n4 + kBlock * kEngU - 1) / (kBlock * kEngU)) * (kBlock * kEngU);
