@@ -601,8 +601,10 @@ __global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__r
 
 size_t engine_lds_bytes(int xs_floats)
 {
-    return (size_t)(2 * (size_t)xs_floats + EC_WORDS + kEngSlots * 2 * 2 * kWaves + 2 * kEngUnits * 2) * sizeof(float) +
-           kEngMaxOps * sizeof(EngDesc) + 64;
+    // the carve at the top of engine_kernel: x twice, control words, partial-sum slots, descriptions, classifier
+    // candidates, the gatherer's partials, the chunk description
+    return (size_t)(2 * (size_t)xs_floats + EC_WORDS + kEngSlots * 2 * 2 * kWaves + 2 * kEngUnits * 2 + 2 * kWaves) * sizeof(float) +
+           kEngMaxOps * sizeof(EngDesc) + sizeof(EngChunk) + 64;
 }
 
 // x buffer size (floats) for a chunk whose widest mat-vec has n columns

@@ -145,4 +145,9 @@ L2Z_LIB=$PWD/llama2.zig_amd/libllama2_hip_tl.so L2Z_NO_GRAPH=1 L2Z_ENGINE=1 time
 } > $O/r04l_engine.txt 2>&1
 cat $O/r04l_engine.txt
 ;;
+m)
+# debug: one engine pass with a short timeout
+L2Z_P2P_TIMEOUT_S=1 L2Z_ENGINE=1 L2Z_NO_GRAPH=1 timeout 100 python scripts/decode_steps.py llama2-7b 2 > $O/r04m_dbg.txt 2>&1
+tail -5 $O/r04m_dbg.txt
+;;
 esac
