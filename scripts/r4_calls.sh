@@ -150,4 +150,10 @@ m)
 L2Z_P2P_TIMEOUT_S=1 L2Z_ENGINE=1 L2Z_NO_GRAPH=1 timeout 100 python scripts/decode_steps.py llama2-7b 2 > $O/r04m_dbg.txt 2>&1
 tail -5 $O/r04m_dbg.txt
 ;;
+n)
+# round 4, GPU call N: the opt-in forms' test; the engine after the start-order fix
+export L2Z_P2P_TIMEOUT_S=3
+timeout 600 python -m pytest tests/test_gpu_chain_forms.py -m gpu -q -x 2>&1 | tail -5
+timeout 200 python scripts/ab.py llama2-7b 128 3 "" "L2Z_ENGINE=1" 2>&1 | tail -3
+;;
 esac
