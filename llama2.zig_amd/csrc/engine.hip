@@ -522,9 +522,9 @@ __global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__r
                          [ba0] "s"(ba[0]), [ba1] "s"(ba[1]), [ba2] "s"(ba[2]), [ba3] "s"(ba[3]), \
                          [bb0] "s"(bb[0]), [bb1] "s"(bb[1]), [bb2] "s"(bb[2]), [bb3] "s"(bb[3])
     asm volatile(L2Z_ENG_ACC_ZERO ::: "memory", L2Z_ENG_CLOBBERS);
-    // The first mat-vec's x is a plain buffer the gatherer loads at once: let its requests go out before this CU's
-    // queue holds 192 KB of weight requests (x came back behind them: staged 8 us into the launch instead of 3)
-    wait_ge(EC_GO, 1);
+    // (Measured, not kept: holding the ring back until the gatherer has requested the first mat-vec's plain x -- which
+    // otherwise comes back behind this CU's 192 KB of weight requests, staged 8 us into the launch instead of 3 -- cost
+    // more than it saved: 194.1 against 196.3 tok/s; the weights requested at entry are the shorter path.)
     issue_prep(); asm volatile(L2Z_ENG_ISSUE_0 :: L2Z_ENG_LOAD_OPS : "memory", L2Z_ENG_CLOBBERS);   // a chunk has more than R batches per half
     issue_prep(); asm volatile(L2Z_ENG_ISSUE_1 :: L2Z_ENG_LOAD_OPS : "memory", L2Z_ENG_CLOBBERS);
     issue_prep(); asm volatile(L2Z_ENG_ISSUE_2 :: L2Z_ENG_LOAD_OPS : "memory", L2Z_ENG_CLOBBERS);
