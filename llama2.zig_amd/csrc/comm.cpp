@@ -98,11 +98,8 @@ l2z_comm *comm_self_create(int device, size_t max_vector_floats)
     c->rank = 0; c->world = 1; c->device = device; c->nccl = nullptr;
     c->slot_floats = (max_vector_floats + 1023) & ~(size_t)1023;
     const size_t bytes = kP2pFlagBytes + 2 * c->slot_floats * 8;
-    // Ordinary (coarse-grained) device memory: one GPU writes and reads it, with system-scope stores (write-through) and
-    // loads that either name that scope (past the caches) or go through them and check the word's tag (ll_load2_cached);
-    // fine-grained memory -- what the peers' arenas must be -- is never cached, and 256 blocks sweeping a vector each
-    // then read all of it from the memory side.
-    hipError_t e = hipMalloc((void **)&c->arena, bytes);
+    // fine-grained like the peers' arenas: the words are written and polled inside running kernels
+    hipError_t e = hipExtMallocWithFlags((void **)&c->arena, bytes, hipDeviceMallocFinegrained);
     if (e == hipSuccess) e = hipMemset(c->arena, 0, bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_ctl, kCtlInts * sizeof(int));
     if (e == hipSuccess) e = hipMemset(c->d_ctl, 0, kCtlInts * sizeof(int));

@@ -260,7 +260,6 @@ __global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__r
             }
             // ---- x into the buffer of this mat-vec's parity (free: the streaming waves finished mat-vec g - 2 before
             // mat-vec g - 1, whose epilogues all ran): gatherer lane t holds float4 t + 256 i
-            const bool cached = lch->cached_sweep != 0;
             constexpr int RG = 11;  // float4 per lane per round: the longest vector here (11008 floats) in one round of 22 loads
             for (int j0 = gl; j0 < n4_pad; j0 += kEngGather * RG) {
                 if (ll) {
@@ -269,8 +268,8 @@ __global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__r
                     for (int i = 0; i < RG; i++) {
                         const int j = j0 + kEngGather * i;
                         const int jc = j < n4 ? j : 0;
-                        w[2 * i] = cached ? ll_load2_cached(lp.slot, (size_t)4 * jc) : ll_load2(lp.slot, (size_t)4 * jc);
-                        w[2 * i + 1] = cached ? ll_load2_cached(lp.slot, (size_t)4 * jc + 2) : ll_load2(lp.slot, (size_t)4 * jc + 2);
+                        w[2 * i] = ll_load2(lp.slot, (size_t)4 * jc);
+                        w[2 * i + 1] = ll_load2(lp.slot, (size_t)4 * jc + 2);
                     }
 #pragma unroll
                     for (int i = 0; i < RG; i++) {

@@ -360,7 +360,6 @@ static int engine_prepare(l2z_runstate *s, const l2z_weights *w)
         k.ctl = lc->d_ctl; k.h_err = lc->h_err;
         k.timeout_ticks = tn.p2p_timeout_s * 100000000LL;
         k.dummy = w->tok_emb;
-        k.cached_sweep = tn.engine_cached_sweep;
         if (i == 0) {
             k.n_ops = 1;
             qkv_op(k.op[0], 0, true);

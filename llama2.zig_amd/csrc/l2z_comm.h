@@ -121,16 +121,6 @@ __device__ __forceinline__ v4u ll_load2(const unsigned long long *slot_base, siz
         const_cast<unsigned long long *>(slot_base), 0, 0x7ffffff0, 0x00020000);
     return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(word_idx * 8), 0, 17 /* sc0 sc1 */);
 }
-// The same two words through the caches (engine.hip, this process's own coarse-grained slots): the first block of an XCD
-// to ask pulls the line into that XCD's L2, the other 31 hit it there -- 32x fewer reads of the handed-over vector at
-// the memory side than 256 blocks each reading all of it uncached.  A line that is stale (an older hand-over's words:
-// another tag) or half-written fails the tag check like any late word, and the caller re-reads it with ll_load2.
-__device__ __forceinline__ v4u ll_load2_cached(const unsigned long long *slot_base, size_t word_idx)
-{
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned long long *>(slot_base), 0, 0x7ffffff0, 0x00020000);
-    return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(word_idx * 8), 0, 0);
-}
 __device__ __forceinline__ bool ll_ready2(v4u w, unsigned e) { return w.y == e && w.w == e; }
 #endif
 }  // namespace l2z

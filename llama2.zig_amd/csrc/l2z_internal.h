@@ -155,8 +155,6 @@ struct EngChunk {
     int *ctl, *h_err;          // l2z_comm::d_ctl / h_err of the hand-overs
     long long timeout_ticks;
     const float *dummy;        // >= 2 KB of finite, cache-resident floats (what out-of-row steps read)
-    int cached_sweep;          // 1: the gatherers' first read of a handed-over vector goes through the caches (ll_load2_cached)
-    int pad;
     EngOp op[kEngMaxOps];
 };
 size_t engine_lds_bytes(int xs_floats);

@@ -33,7 +33,6 @@ struct Tunables {
     int overlap_hint_sleep = 2;  // L2Z_OVERLAP_HINT_SLEEP  s_sleep(8) instructions between polls of the hint word
     int engine = 0;            // L2Z_ENGINE          1: wide-row models run wo, w1|w3, w2 and the next layer's q|k|v as ONE persistent launch per layer
                                //                     (engine.hip: register-ring run-ahead, gatherer wave, in-launch hand-overs); same bits as the launch chain
-    int engine_cached_sweep = 1;  // L2Z_ENGINE_CACHED_SWEEP  0: the gatherers read handed-over vectors uncached (every block every word from the memory side)
     int duo = 0;               // L2Z_DUO             1: wide-row models (dim >= 4096) take the 512-thread duo mat-vecs, 256-thread attention forms at every
                                //                     position and -- with L2Z_OVERLAP -- the two-chain pass.  Measured slower than the default chain
                                //                     of round 3 (203 / 218 vs 225 tok/s at the 7B shape, profiles/r04_overlap_*): an experiment, off

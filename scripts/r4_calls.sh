@@ -156,13 +156,4 @@ export L2Z_P2P_TIMEOUT_S=3
 timeout 600 python -m pytest tests/test_gpu_chain_forms.py -m gpu -q -x 2>&1 | tail -5
 timeout 200 python scripts/ab.py llama2-7b 128 3 "" "L2Z_ENGINE=1" 2>&1 | tail -3
 ;;
-o)
-# round 4, GPU call O: handed-over vectors swept through the caches (coarse-grained slots) vs uncached
-export L2Z_P2P_TIMEOUT_S=3
-{
-timeout 200 python scripts/ab.py llama2-7b 128 3 "" "L2Z_ENGINE=1" "L2Z_ENGINE=1,L2Z_ENGINE_CACHED_SWEEP=0" "L2Z_DUO=1"
-L2Z_LIB=$PWD/llama2.zig_amd/libllama2_hip_tl.so L2Z_NO_GRAPH=1 L2Z_ENGINE=1 timeout 100 python scripts/engine_timeline.py 4
-} > $O/r04o_engine.txt 2>&1
-cat $O/r04o_engine.txt
-;;
 esac
