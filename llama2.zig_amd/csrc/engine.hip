@@ -358,7 +358,10 @@ __global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__r
                     if (epi == EPI_ROPE) pair_epilogue<EPI_ROPE>(me, uk, ta, tb, true, in, nullptr);
                     else if (epi == EPI_RESID) pair_epilogue<EPI_RESID>(me, uk, ta, tb, true, in, st);
                     else if (epi == EPI_SWIGLU) pair_epilogue<EPI_SWIGLU>(me, uk, ta, tb, true, in, st);
-                    else {
+                    else if (epi == EPI_STORE) {   // a shard's classifier rows: logits slice, published for the logits gather
+                        pair_epilogue<EPI_STORE>(me, uk, ta, tb, true, in, nullptr);
+                        st[0] = ta; st[1] = tb;
+                    } else {
                         pair_epilogue<EPI_ARGMAX>(me, uk, ta, tb, true, in, nullptr);
                         // the unit's candidate (rows 2 uk, 2 uk + 1: strict > keeps the first)
                         float bv = ta; int bi = 2 * uk;
@@ -372,13 +375,15 @@ __global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__r
             }
             if (bad) break;
             // ---- publish: every lane its unit's outputs (the {value, epoch} words the next mat-vec's gatherers sweep)
-            if (uk < n_pairs && a.push != nullptr && (epi == EPI_RESID || epi == EPI_SWIGLU)) {
+            // (row_offset: this rank's first element of the vector -- 0 unsharded)
+            if (uk < n_pairs && a.push != nullptr && (epi == EPI_RESID || epi == EPI_SWIGLU || epi == EPI_STORE)) {
                 const int e = a.push_ctl[kCtlEpoch] + a.push_gi;
+                const size_t base = (size_t)a.row_offset;
                 if (epi == EPI_SWIGLU) {
-                    p2p_ll_push(a.push, e, (size_t)uk, hold_a);
+                    p2p_ll_push(a.push, e, base + (size_t)uk, hold_a);
                 } else {
-                    p2p_ll_push(a.push, e, (size_t)(2 * uk), hold_a);
-                    if (2 * uk + 1 < total_rows) p2p_ll_push(a.push, e, (size_t)(2 * uk + 1), hold_b);
+                    p2p_ll_push(a.push, e, base + (size_t)(2 * uk), hold_a);
+                    if (2 * uk + 1 < total_rows) p2p_ll_push(a.push, e, base + (size_t)(2 * uk + 1), hold_b);
                 }
             }
             L2Z_ETL(6 + 6 * g);

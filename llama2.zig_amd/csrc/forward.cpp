@@ -319,7 +319,8 @@ static int engine_prepare(l2z_runstate *s, const l2z_weights *w)
     if (s->eng_w_uid == w->uid) return L2Z_OK;
     const l2z_config &c = s->cfg;
     const Shard &sh = s->sh;
-    const l2z_comm *lc = s->self_comm;
+    const bool sharded = sh.world > 1;
+    const l2z_comm *lc = sharded ? s->comm : s->self_comm;   // whose landing slots carry the hand-overs
     const size_t dim = c.dim, hid = c.hidden_dim;
     const int L = c.n_layers, vgrid = 2 * s->eng_grid;
     const Tunables &tn = tunables();
@@ -331,13 +332,18 @@ static int engine_prepare(l2z_runstate *s, const l2z_weights *w)
         o.n_pairs = epi == EPI_SWIGLU ? a.rows0 : (rows + 1) / 2;
         o.nb = nb_of(a.n);
     };
-    auto ll_in = [&](MatvecArgs &a, int g, size_t count, const Hint &h) {
+    // x of a mat-vec as the words of gather g (count floats per rank); the hint: elements THIS rank's producer writes in
+    // its last sweep (the other ranks' words are late words like any other: every word validates itself)
+    auto ll_in = [&](MatvecArgs &a, int g, size_t count, Hint h, size_t base) {
         a.xin = comm_ll_in(lc, g, count);
         if (tn.overlap_hint && h.n) {
-            a.xin.hint0 = h.h0; a.xin.hint_n = h.n; a.xin.hint_stride = h.stride; a.xin.hint_sleep = tn.overlap_hint_sleep;
+            a.xin.hint0 = (unsigned)base + h.h0; a.xin.hint_n = h.n; a.xin.hint_stride = h.stride; a.xin.hint_sleep = tn.overlap_hint_sleep;
         }
     };
     auto push = [&](MatvecArgs &a, int which, int g) { a.push = s->d_push + which; a.push_ctl = lc->d_ctl; a.push_gi = g; };
+    const Hint h_dim = mv_hint((sh.dim_loc + 1) / 2, vgrid, EPI_RESID), h_hid = mv_hint(sh.hid_loc, vgrid, EPI_SWIGLU);
+    Hint h_attn;   // the attention launch's outputs: a head's last element, this rank's heads
+    h_attn.h0 = (unsigned)(sh.hs - 1); h_attn.n = (unsigned)sh.heads_loc; h_attn.stride = (unsigned)sh.hs;
     auto qkv_op = [&](EngOp &o, int l, bool plain) {
         MatvecArgs a = {};
         a.w0 = w->wq + (size_t)l * sh.dim_loc * dim;
@@ -350,7 +356,7 @@ static int engine_prepare(l2z_runstate *s, const l2z_weights *w)
         a.pos_stride1 = sh.hs; a.pos_stride2 = sh.hs; a.kv_head_stride = (size_t)c.seq_len * sh.hs;
         a.n = c.dim; a.rms_w = w->rms_att + (size_t)l * dim;
         a.x = s->x;
-        if (!plain) ll_in(a, 4 * l, dim, mv_hint((c.dim + 1) / 2, vgrid, EPI_RESID));   // x as the previous layer's w2 handed it over
+        if (!plain) ll_in(a, 4 * l, sh.dim_loc, h_dim, sh.dim0);   // x as the previous layer's w2 handed it over
         a.pos_ptr = s->d_pos; a.rope = s->rope; a.head_size = sh.hs; a.rope_segs = 2;
         set_op(o, a, PRO_RMS, EPI_ROPE);
     };
@@ -362,45 +368,57 @@ static int engine_prepare(l2z_runstate *s, const l2z_weights *w)
         k.dummy = w->tok_emb;
         if (i == 0) {
             k.n_ops = 1;
-            qkv_op(k.op[0], 0, true);
+            qkv_op(k.op[0], 0, true);   // the embedding row: a plain buffer on every rank
             continue;
         }
         const int l = i - 1;
         k.n_ops = 4;
-        {   // wo (:392) + residual (:395): xb and x are plain buffers (the attention launch, the launch before it)
+        {   // wo (:392) + residual (:395).  xb: unsharded, the attention launch's plain buffer; sharded, every rank's heads as
+            // the words of gather 4l + 1 (the attention launch pushes them).  The residual: this rank's rows of x, plain
+            // (written by this rank's own w2 in the launch before)
             MatvecArgs a = {};
-            a.w0 = w->wo + (size_t)l * dim * dim;
-            a.out0 = s->x; a.resid = s->x; a.rows0 = c.dim; a.n = c.dim; a.x = s->xb;
+            a.w0 = w->wo + (size_t)l * sh.dim_loc * dim;
+            a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0; a.rows0 = sh.dim_loc; a.n = c.dim; a.x = s->xb;
+            a.row_offset = sh.dim0;
+            if (sharded) ll_in(a, 4 * l + 1, sh.dim_loc, h_attn, sh.dim0);
             push(a, 1, 4 * l + 2);
             set_op(k.op[0], a, PRO_NONE, EPI_RESID);
         }
         {   // rmsnorm (:398) + w1, w3 (:405-408) + SiLU * mul (:411-416)
             MatvecArgs a = {};
-            a.w0 = w->w1 + (size_t)l * hid * 2 * dim;
-            a.w1 = w->w3 + (size_t)l * hid * 2 * dim;
-            a.out0 = s->hb; a.rows0 = c.hidden_dim; a.rows1 = c.hidden_dim; a.n = c.dim;
+            a.w0 = w->w1 + (size_t)l * sh.hid_loc * 2 * dim;
+            a.w1 = w->w3 + (size_t)l * sh.hid_loc * 2 * dim;
+            a.out0 = s->hb + sh.hid0; a.rows0 = sh.hid_loc; a.rows1 = sh.hid_loc; a.n = c.dim;
             a.rms_w = w->rms_ffn + (size_t)l * dim; a.x = s->x;
-            ll_in(a, 4 * l + 2, dim, mv_hint((c.dim + 1) / 2, vgrid, EPI_RESID));
+            a.row_offset = sh.hid0;
+            ll_in(a, 4 * l + 2, sh.dim_loc, h_dim, sh.dim0);
             push(a, 2, 4 * l + 3);
             set_op(k.op[1], a, PRO_RMS, EPI_SWIGLU);
         }
-        {   // w2 (:419) + residual (:422): the residual is x as this launch's wo handed it over
+        {   // w2 (:419) + residual (:422): the residual is this rank's rows of x as this launch's wo handed them over
             MatvecArgs a = {};
-            a.w0 = w->w2 + (size_t)l * dim * hid;
-            a.out0 = s->x; a.resid = s->x; a.rows0 = c.dim; a.n = c.hidden_dim; a.x = s->hb;
-            ll_in(a, 4 * l + 3, hid, mv_hint(c.hidden_dim, vgrid, EPI_SWIGLU));
-            a.resid_in = comm_ll_in(lc, 4 * l + 2, dim);
+            a.w0 = w->w2 + (size_t)l * sh.dim_loc * hid;
+            a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0; a.rows0 = sh.dim_loc; a.n = c.hidden_dim; a.x = s->hb;
+            a.row_offset = sh.dim0;
+            ll_in(a, 4 * l + 3, sh.hid_loc, h_hid, sh.hid0);
+            a.resid_in = comm_ll_in(lc, 4 * l + 2, sh.dim_loc);
             push(a, 1, 4 * l + 4);
             set_op(k.op[2], a, PRO_NONE, EPI_RESID);
         }
         if (l + 1 < L) {
             qkv_op(k.op[3], l + 1, false);
-        } else {   // final rmsnorm (:426) + classifier (:429) + one argmax candidate per virtual block
+        } else {   // final rmsnorm (:426) + classifier (:429)
             MatvecArgs a = {};
-            a.w0 = w->wcls; a.out0 = s->logits; a.rows0 = c.vocab_size; a.n = c.dim; a.rms_w = w->rms_final; a.x = s->x;
-            ll_in(a, 4 * L, dim, mv_hint((c.dim + 1) / 2, vgrid, EPI_RESID));
-            a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.row_offset = 0;
-            set_op(k.op[3], a, PRO_RMS, EPI_ARGMAX);
+            a.w0 = w->wcls; a.out0 = s->logits + sh.v0; a.rows0 = sh.v_loc; a.n = c.dim; a.rms_w = w->rms_final; a.x = s->x;
+            ll_in(a, 4 * L, sh.dim_loc, h_dim, sh.dim0);
+            a.row_offset = sh.v0;
+            if (sharded) {   // a shard's rows of the logits, published for the pass-closing gather (which advances the epochs)
+                push(a, 3, 4 * L + 1);
+                set_op(k.op[3], a, PRO_RMS, EPI_STORE);
+            } else {         // + one argmax candidate per virtual block
+                a.part_val = s->d_part_val; a.part_idx = s->d_part_idx;
+                set_op(k.op[3], a, PRO_RMS, EPI_ARGMAX);
+            }
         }
     }
     L2Z_HIP(hipMemcpy(s->d_eng, ch.data(), ch.size() * sizeof(EngChunk), hipMemcpyHostToDevice));
@@ -412,6 +430,8 @@ static int enqueue_engine(l2z_runstate *s, const l2z_weights *w, bool with_step,
 {
     const l2z_config &c = s->cfg;
     const Shard &sh = s->sh;
+    const bool sharded = sh.world > 1;
+    const l2z_comm *lc = sharded ? s->comm : s->self_comm;
     hipStream_t st = s->stream;
     const bool split = variant == ATTN_SPLIT || variant == ATTN_SPLIT_S;
     L2Z_HIP(launch_engine(s->d_eng, s->eng_grid, s->eng_xs_floats, st, s->tl_seq++));
@@ -420,26 +440,34 @@ static int enqueue_engine(l2z_runstate *s, const l2z_weights *w, bool with_step,
         a.q = s->q;
         a.kcache = s->key_cache + (size_t)l * c.seq_len * sh.kvd_loc;
         a.vcache = s->value_cache + (size_t)l * c.seq_len * sh.kvd_loc;
-        a.xb = s->xb; a.pos_ptr = s->d_pos; a.head_size = sh.hs; a.kv_row = sh.hs; a.kv_head = (size_t)c.seq_len * sh.hs;
+        a.xb = s->xb + sh.dim0; a.pos_ptr = s->d_pos; a.head_size = sh.hs; a.kv_row = sh.hs; a.kv_head = (size_t)c.seq_len * sh.hs;
         a.kv_mul = c.n_heads / c.n_kv_heads; a.seq_len = c.seq_len;
+        if (sharded) {   // every rank's wo reads every rank's heads: out as the words of gather 4l + 1
+            a.push = s->d_push + 0; a.push_ctl = lc->d_ctl; a.push_gi = 4 * l + 1;
+        }
         if (split && s->attn_nch > 1 && attention_split_supported(a))
             L2Z_HIP(launch_attention_split(a, sh.heads_loc, s->attn_nch, s->d_attn_part, s->d_attn_cnt, st, variant == ATTN_SPLIT_S));
         else
             L2Z_HIP(launch_attention(a, sh.heads_loc, st, (variant == ATTN_SHORT || s->attn_all256) ? 1 : 0));
         L2Z_HIP(launch_engine(s->d_eng + l + 1, s->eng_grid, s->eng_xs_floats, st, s->tl_seq++));
     }
-    s->n_part = 2 * s->eng_grid;
+    if (sharded) {   // the logits: collected by the pass-closing gather launch (it also advances the group's epochs)
+        s->n_part = 0;
+        L2Z_TRY(comm_allgather_inplace(s->comm, s->logits, (size_t)sh.v_loc, s->n_gathers, s->n_gathers, true, st));
+    } else {
+        s->n_part = 2 * s->eng_grid;
+    }
     if (with_step) {
         ArgmaxArgs a = {};
         a.logits = s->logits; a.vocab = c.vocab_size; a.token_ptr = s->d_token;
-        a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.n_part = s->n_part;
+        if (s->n_part > 0) { a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.n_part = s->n_part; }
         a.pos_ptr = s->d_pos; a.prompt = s->d_prompt; a.n_prompt_ptr = s->d_n_prompt;
         a.out_tokens = s->d_out_tokens; a.argmax_out = s->d_argmax; a.tok_emb = w->tok_emb;
         a.x = s->x; a.dim = c.dim; a.advance = 1;
-        a.epoch_ctl = s->self_comm->d_ctl; a.epoch_add = s->n_gathers;
+        if (!sharded) { a.epoch_ctl = lc->d_ctl; a.epoch_add = s->n_gathers; }
         L2Z_HIP(launch_argmax(a, st));
-    } else {
-        L2Z_HIP(launch_epoch_advance(s->self_comm->d_ctl, s->n_gathers, st));
+    } else if (!sharded) {
+        L2Z_HIP(launch_epoch_advance(lc->d_ctl, s->n_gathers, st));
     }
     return L2Z_OK;
 }

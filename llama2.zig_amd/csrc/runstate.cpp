@@ -132,18 +132,21 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
         aa.head_size = sh.hs; aa.kv_row = sh.hs; aa.kv_head = (size_t)c.seq_len * sh.hs;
         s->duo = attention_push_supported(aa);
     }
-    // the persistent decode launches: wide-row model, every mat-vec's units fit the blocks' lanes
-    if (sh.world == 1 && tn.engine != 0 && !s->fused_qkv_attn && matvec_duo_supported(c.dim) && matvec_duo_supported(c.hidden_dim) &&
-        e == hipSuccess) {
-        const int grid = g_cus;
-        s->eng = engine_units_ok((c.dim + 2 * sh.kvd_loc + 1) / 2, grid) && engine_units_ok((c.dim + 1) / 2, grid) &&
-                 engine_units_ok(c.hidden_dim, grid) && engine_units_ok((c.vocab_size + 1) / 2, grid) && matvec_vector_width(c.dim);
+    // the persistent decode launches: wide-row model, every mat-vec's units fit the blocks' lanes; sharded runs: the
+    // peer-write transport in its consumer-side form (the launches hand their vectors over as its words)
+    if (tn.engine != 0 && !s->fused_qkv_attn && matvec_duo_supported(c.dim) && matvec_duo_supported(c.hidden_dim) &&
+        (sh.world == 1 || (comm_uses_p2p(comm) && s->ll_consume)) && e == hipSuccess) {
+        // several ranks on ONE GPU (tests): every rank's blocks must be resident at once (a block ~ a CU)
+        int grid = g_cus;
+        if (tn.grid_cap > 0 && grid > tn.grid_cap / 2) grid = tn.grid_cap / 2;
+        s->eng = grid >= 1 && engine_units_ok((sh.dim_loc + 2 * sh.kvd_loc + 1) / 2, grid) && engine_units_ok((sh.dim_loc + 1) / 2, grid) &&
+                 engine_units_ok(sh.hid_loc, grid) && engine_units_ok((sh.v_loc + 1) / 2, grid) && matvec_vector_width(c.dim);
         s->eng_grid = grid;
         s->eng_xs_floats = engine_xs_floats(std::max(c.dim, c.hidden_dim));
         if (s->eng && engine_lds_bytes(s->eng_xs_floats) > 160 * 1024) s->eng = false;
         if (s->eng) alloc((void **)&s->d_eng, (size_t)(c.n_layers + 1) * sizeof(EngChunk));
     }
-    if (((s->duo && tn.overlap != 0) || s->eng) && e == hipSuccess) {
+    if (((s->duo && tn.overlap != 0) || (s->eng && sh.world == 1)) && e == hipSuccess) {
         // the overlapped chain: a second stream, fork / join events, and this process's own landing slots
         s->self_comm = comm_self_create(dev, (size_t)std::max(c.dim, c.hidden_dim));
         if (s->self_comm == nullptr) {

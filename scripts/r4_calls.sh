@@ -156,4 +156,8 @@ export L2Z_P2P_TIMEOUT_S=3
 timeout 600 python -m pytest tests/test_gpu_chain_forms.py -m gpu -q -x 2>&1 | tail -5
 timeout 200 python scripts/ab.py llama2-7b 128 3 "" "L2Z_ENGINE=1" 2>&1 | tail -3
 ;;
+p)
+# round 4, GPU call P: the persistent launches on a shard group (2 and 4 processes on the one GPU), bit for bit
+timeout 900 python -m pytest tests/test_gpu_p2p.py -m gpu -q -x -k "engine or (row-kernel and x2-consume)" 2>&1 | tail -15
+;;
 esac

@@ -54,8 +54,11 @@ def run_ranks(tmp_path, world, spec, env_extra=None, timeout=300):
 
 # consume: consumers read the LL words from their own landing slot (no gather launches, default);
 # gather: one gather launch per gathered vector (L2Z_P2P_CONSUME=0); nopush: the gather launch also sends
-CASES = [(m, "consume") for m in MODELS] + [(MODELS[0], "gather"), (MODELS[4], "gather"), (MODELS[3], "nopush")]
-MODE_ENV = {"consume": {}, "gather": {"L2Z_P2P_CONSUME": "0"}, "nopush": {"L2Z_P2P_PUSH": "0"}}
+# engine: the ranks run the persistent decode launches (engine.hip, L2Z_ENGINE=1): wo, w1|w3, w2 and the next q|k|v as one
+# launch per layer whose mat-vecs hand their vectors over as the same words, across the ranks as inside one
+CASES = ([(m, "consume") for m in MODELS] + [(MODELS[0], "gather"), (MODELS[4], "gather"), (MODELS[3], "nopush")] +
+         [(MODELS[5], "engine"), (MODELS[4], "engine")])
+MODE_ENV = {"consume": {}, "gather": {"L2Z_P2P_CONSUME": "0"}, "nopush": {"L2Z_P2P_PUSH": "0"}, "engine": {"L2Z_ENGINE": "1"}}
 
 
 @pytest.mark.parametrize("model,mode", CASES, ids=[f"{m[0]}-x{m[3]}-{mode}" for m, mode in CASES])
