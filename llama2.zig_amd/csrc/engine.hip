@@ -230,12 +230,12 @@ __global__ __launch_bounds__(kEngThreads) void engine_kernel(const EngChunk *__r
                     if (a.resid_in.slots != nullptr) {
                         const unsigned e = (unsigned)(a.resid_in.ctl[kCtlEpoch] + a.resid_in.gi);
                         const unsigned long long *slot = a.resid_in.slots + (size_t)(e & 1) * a.resid_in.slot_floats;
-                        v4u w = ll_load2(slot, (size_t)(2 * uk));
+                        v4u w = ll_load2(slot, (size_t)(a.row_offset + 2 * uk));
                         const long long t0 = wall_clock64();
                         while (!(w.y == e && (w.w == e || !two))) {
                             if (wall_clock64() - t0 > timeout) { ctrl[EC_ERR] = 1; break; }
                             __builtin_amdgcn_s_sleep(16);
-                            w = ll_load2(slot, (size_t)(2 * uk));
+                            w = ll_load2(slot, (size_t)(a.row_offset + 2 * uk));
                         }
                         ein.x = w.x; ein.z = w.z;
                     } else {

@@ -160,4 +160,11 @@ p)
 # round 4, GPU call P: the persistent launches on a shard group (2 and 4 processes on the one GPU), bit for bit
 timeout 900 python -m pytest tests/test_gpu_p2p.py -m gpu -q -x -k "engine or (row-kernel and x2-consume)" 2>&1 | tail -15
 ;;
+q)
+timeout 600 python -m pytest tests/test_gpu_chain_forms.py -m gpu -q -k "engine" 2>&1 | tail -12
+;;
+r)
+timeout 200 python scripts/dbg_engine_shard.py 2 2>&1 | tail -6
+DBG_ENGINE=0 timeout 200 python scripts/dbg_engine_shard.py 2 2>&1 | tail -3
+;;
 esac

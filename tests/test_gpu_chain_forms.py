@@ -10,6 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 WIDE = dict(dim=4096, hidden_dim=11008, n_layers=2, n_heads=32, n_kv_heads=32, vocab_size=32000, seq_len=384)
+WIDE_GQA = dict(dim=4096, hidden_dim=8192, n_layers=3, n_heads=32, n_kv_heads=8, vocab_size=8192, seq_len=320)  # tests/test_gpu_p2p.py's wide shape
 RESET = {"L2Z_DUO": 0, "L2Z_OVERLAP": 1, "L2Z_ENGINE": 0, "L2Z_OVERLAP_EDGES": 15}
 
 
@@ -35,9 +36,10 @@ def _run(B, cfg, w, opts, n_tok, probe_pos):
 @pytest.mark.parametrize("opts", [{"L2Z_DUO": 1, "L2Z_OVERLAP": 0}, {"L2Z_DUO": 1, "L2Z_OVERLAP": 1},
                                   {"L2Z_DUO": 1, "L2Z_OVERLAP": 1, "L2Z_OVERLAP_EDGES": 9}, {"L2Z_ENGINE": 1}],
                          ids=["duo", "duo+overlap", "duo+overlap-edges-9", "engine"])
-def test_opt_in_forms_keep_the_chains_bits(gpu, ck, opts):
+@pytest.mark.parametrize("shape", [WIDE, WIDE_GQA], ids=["mha-11008", "gqa-8192"])
+def test_opt_in_forms_keep_the_chains_bits(gpu, ck, opts, shape):
     B = gpu
-    cfg = ck.Config(**WIDE)
+    cfg = ck.Config(**shape)
     w = B.Weights(cfg, None, False, seed=77)
     probe = [0, 5, 60, 127]          # the attention form is the default chain's below pos 128 in every mode
     ref_t, ref_l = _run(B, cfg, w, {}, 140, probe)
