@@ -46,8 +46,10 @@ import __graft_entry__ as ge  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E vendor peak (MI355X_MICROARCH.md); ~6300 measured copy
 MFMA_F32_PEAK_TF = 157.3  # dense fp32 matrix peak (256 CUs x 256 flop/clk x 2.4 GHz)
 
-LEGS = ["rccl", "p2p-gather", "p2p-consume"]  # run in this order: the library collective first
+LEGS = ["rccl", "p2p-gather", "p2p-consume", "p2p-engine"]  # run in this order: the library collective first
 LEG_TEXT = {
+    "p2p-engine": "peer writes of LL words over IPC-mapped memory (xGMI), polled by the persistent decode "
+                  "launches (wo, w1|w3, w2 and the next q|k|v in one launch: 2 launches per layer instead of 5)",
     "p2p-consume": "peer writes of LL words over IPC-mapped memory (xGMI), polled by the consuming "
                    "mat-vec (no gather launch)",
     "p2p-gather": "peer writes over IPC-mapped memory (xGMI) + a gather launch per vector",
@@ -582,8 +584,10 @@ def leg_main(args) -> int:
         dist.destroy_process_group()
         return 3
 
-    B.option_set("L2Z_P2P_CONSUME", 1 if kind == "p2p-consume" else 0)
-    B.option_set("L2Z_GRID_CAP", shared_cap if kind == "p2p-consume" else 0)
+    polling = kind in ("p2p-consume", "p2p-engine")  # launches that wait for the peers' words inside the kernel
+    B.option_set("L2Z_P2P_CONSUME", 1 if polling else 0)
+    B.option_set("L2Z_GRID_CAP", shared_cap if polling else 0)
+    B.option_set("L2Z_ENGINE", 1 if kind == "p2p-engine" else 0)
     B.option_set("L2Z_COMM_RCCL", 1 if kind == "rccl" else 0)
     comm = make_comm()
     if comm is None:
@@ -595,6 +599,15 @@ def leg_main(args) -> int:
     trs = [None] * world
     dist.all_gather_object(trs, tr)
     s = w = None
+    if kind == "p2p-engine":
+        # the persistent launches are refused by narrow shapes (csrc/runstate.cpp): without this check the leg would
+        # time the p2p-consume chain under another name
+        probe = B.RunState(cfg, comm=comm)
+        form = probe.form()
+        probe.close()
+        if not all_ok(form & 4):
+            comm.close()
+            return fail(f"this shape does not take the persistent launches (runstate form {form}): leg not run")
     try:
         n_tok, dt, s, w = run_once(B, cfg, shared, args.seed, steps, args.warmup, comm, all_ok)
         ran = True
@@ -604,6 +617,7 @@ def leg_main(args) -> int:
     if not all_ok(ran):
         return fail("run failed")
     agree = ranks_agree(s)
+    form_ran = s.form()  # bit 2: the persistent launches ran (p2p-engine leg)
     t = torch.tensor([dt], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
@@ -660,7 +674,7 @@ def leg_main(args) -> int:
            # step would take with free gathers; the rest of ms_per_step is gather + launch overhead
            "ms_per_step_at_stream_read_rate": ideal_ms,
            "overhead_ms_per_step": (dt / n_tok * 1e3 - ideal_ms) if ideal_ms else None,
-           "prefill_sharded": prefill_sharded}
+           "prefill_sharded": prefill_sharded, "runstate_form": form_ran}
     out = {
         "metric": "tokens/s (argmax, -t 0)", "value": n_tok / dt, "unit": "tokens/s",
         "n_gpus": args.gpus, "steps": n_tok, "warmup": args.warmup,
@@ -699,8 +713,8 @@ def multi_main(args) -> None:
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     want = os.environ.get("L2Z_COMM", "")
-    order = {"": LEGS, "p2p": ["p2p-gather", "p2p-consume"], "p2p-consume": ["p2p-consume"],
-             "p2p-gather": ["p2p-gather"], "rccl": ["rccl"]}[want]
+    order = {"": LEGS, "p2p": ["p2p-gather", "p2p-consume", "p2p-engine"], "p2p-consume": ["p2p-consume"],
+             "p2p-gather": ["p2p-gather"], "p2p-engine": ["p2p-engine"], "rccl": ["rccl"]}[want]
     if os.environ.get("L2Z_BENCH_FORCE_DIST") == "1":  # 1-rank RCCL + gloo, for testing
         order = ["rccl"]
     leg_timeout = float(os.environ.get("L2Z_BENCH_LEG_TIMEOUT_S", "150"))

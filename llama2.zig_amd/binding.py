@@ -109,6 +109,8 @@ def lib():
         L.l2z_comm_p2p_export_sized.argtypes = [vp, sz, sz, vp]
     L.l2z_comm_p2p_connect.argtypes = [vp, vp]
     L.l2z_comm_rank.argtypes = [vp, ip, ip]
+    if hasattr(L, "l2z_runstate_form"):
+        L.l2z_runstate_form.argtypes = [vp, ip]
     if hasattr(L, "l2z_comm_transports"):  # an older build loaded through L2Z_LIB (A/B runs) lacks the newer entry points
         L.l2z_comm_transports.argtypes = [vp, ip, ip]
     L.l2z_comm_free.argtypes = [vp]
@@ -304,6 +306,12 @@ class RunState:
         _chk(lib().l2z_profile_forward(token, pos, C.byref(self.cfg), self.h, w.h, ms, cnt,
                                        len(KINDS)))
         return {k: (ms[i], cnt[i]) for i, k in enumerate(KINDS)}
+
+    def form(self) -> int:
+        """The decode structure this state runs: bit 0 paired mat-vec blocks, bit 1 two chains, bit 2 persistent launches."""
+        f = C.c_int(0)
+        _chk(lib().l2z_runstate_form(self.h, C.byref(f)))
+        return f.value
 
     def time_kind(self, kind: str, pos: int, w: Weights, reps: int = 4):
         """(average ms per launch, launches) of one kind of launch, back to back between one event pair."""

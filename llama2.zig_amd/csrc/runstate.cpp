@@ -227,6 +227,16 @@ extern "C" void l2z_runstate_free(l2z_runstate *s)
     delete s;
 }
 
+// Which decode structure this runstate will run (the opt-in forms of tunables.h can be refused by the shape or
+// the transport; a test that asks for one checks here that it got it): bit 0 paired mat-vec blocks (L2Z_DUO),
+// bit 1 two overlapped chains (L2Z_OVERLAP), bit 2 the persistent launches (L2Z_ENGINE).
+extern "C" int l2z_runstate_form(const l2z_runstate *s, int *form)
+{
+    L2Z_CHECK(s != nullptr && form != nullptr, L2Z_ERR_INVALID, "l2z_runstate_form: bad arguments");
+    *form = (s->duo ? 1 : 0) | (s->ovl ? 2 : 0) | (s->eng ? 4 : 0);
+    return L2Z_OK;
+}
+
 extern "C" int l2z_runstate_read(l2z_runstate *s, const char *name, size_t offset, size_t count,
                                  float *out)
 {

@@ -167,4 +167,23 @@ r)
 timeout 200 python scripts/dbg_engine_shard.py 2 2>&1 | tail -6
 DBG_ENGINE=0 timeout 200 python scripts/dbg_engine_shard.py 2 2>&1 | tail -3
 ;;
+s)
+# round 4, GPU call S: the forms' tests with the runstate-form assertion, the peer-write tests with the fourth bench leg,
+# then bench.py --gpus 4 on the 7B shape with all four ranks on this one GPU (a proxy: the kernels share the chip)
+export L2Z_P2P_TIMEOUT_S=20
+timeout 600 python -m pytest tests/test_gpu_chain_forms.py -m gpu -q -x 2>&1 | tail -5
+timeout 1200 python -m pytest tests/test_gpu_p2p.py -m gpu -q -x 2>&1 | tail -8
+L2Z_BENCH_LEG_TIMEOUT_S=240 timeout 1100 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 \
+  --master-port 29533 bench.py --gpus 4 --steps 64 --warmup 1 > $O/r04_bench_4ranks_1gpu.json 2> $O/r04_bench_4ranks_1gpu.err
+echo "bench rc=$?"; tail -c 1500 $O/r04_bench_4ranks_1gpu.err
+python - <<'PY'
+import json
+for ln in open("gpurun_out/r04_bench_4ranks_1gpu.json"):
+    if ln.startswith("{"):
+        o = json.loads(ln)
+        print(o.get("value"), o.get("comm", {}).get("transport"))
+        for l in o["comm"]["legs"]:
+            print(l["transport"], l["ok"], l.get("tokens_per_s"), l.get("why"), l.get("runstate_form"), l.get("wall_s"))
+PY
+;;
 esac

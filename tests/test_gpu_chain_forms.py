@@ -14,6 +14,15 @@ WIDE_GQA = dict(dim=4096, hidden_dim=8192, n_layers=3, n_heads=32, n_kv_heads=8,
 RESET = {"L2Z_DUO": 0, "L2Z_OVERLAP": 1, "L2Z_ENGINE": 0, "L2Z_OVERLAP_EDGES": 15}
 
 
+def _want_form(opts):
+    """l2z_runstate_form's bits for a set of options (a form refused by the shape would pass the comparison trivially)."""
+    if opts.get("L2Z_ENGINE"):
+        return 4
+    if opts.get("L2Z_DUO"):
+        return 3 if opts.get("L2Z_OVERLAP", 1) else 1
+    return 0
+
+
 def _run(B, cfg, w, opts, n_tok, probe_pos):
     for k, v in opts.items():
         B.option_set(k, v)
@@ -22,6 +31,7 @@ def _run(B, cfg, w, opts, n_tok, probe_pos):
     finally:
         for k in opts:
             B.option_set(k, RESET[k])
+    assert s.form() == _want_form(opts), f"{opts}: the runstate runs form {s.form()}"
     B.option_set("L2Z_PREFILL", 0)
     s.greedy_begin([])
     toks = np.array(s.greedy_run(w, n_tok))

@@ -168,7 +168,8 @@ def test_bench_legs_on_one_gpu(gpu, tmp_path):
     """bench.py --gpus 2 with both ranks on the one GPU of this box: every transport runs as its own leg
     (child process per rank), all of them are reported, and the headline is the fastest leg whose ranks
     agree.  RCCL refuses two ranks on one device, so its leg must FAIL here -- and the line must say so
-    instead of the run dying with it; both peer-write legs must work."""
+    instead of the run dying with it; both peer-write legs must work.  The fourth leg (persistent launches) is
+    refused by this narrow shape and must be reported as not run."""
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(HERE)
@@ -181,7 +182,9 @@ def test_bench_legs_on_one_gpu(gpu, tmp_path):
     assert p.returncode == 0 and len(lines) == 1, p.stdout.decode()[-3000:] + p.stderr.decode()[-3000:]
     out = json.loads(lines[0])
     legs = {l["transport"]: l for l in out["comm"]["legs"]}
-    assert set(legs) == {"rccl", "p2p-gather", "p2p-consume"}
+    assert set(legs) == {"rccl", "p2p-gather", "p2p-consume", "p2p-engine"}
+    # dim 768 is too narrow for the persistent launches: the leg must say so instead of timing the consume chain twice
+    assert not legs["p2p-engine"]["ok"] and "persistent" in legs["p2p-engine"]["why"], legs["p2p-engine"]
     ok = [t for t, l in legs.items() if l["ok"]]
     assert "p2p-gather" in ok and "p2p-consume" in ok, legs
     for t in ok:
