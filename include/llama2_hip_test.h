@@ -131,7 +131,8 @@ int l2z_emu_prefill(int n_ranks, l2z_runstate *const *ss, const l2z_weights *con
 int l2z_comm_transports(const l2z_comm *c, int *rccl_ranks, int *p2p_connected);
 
 /* The decode structure a runstate runs: bit 0 = paired mat-vec blocks (L2Z_DUO), bit 1 = two overlapped
- * chains (L2Z_OVERLAP), bit 2 = the persistent launches (L2Z_ENGINE).  0 = the default chain.  An opt-in
+ * chains (L2Z_OVERLAP), bit 2 = the persistent launches (L2Z_ENGINE), bit 3 = sharding scheme B (L2Z_SCHEME_B:
+ * column-sharded Wo / W2 + all-reduces).  0 = the default chain.  An opt-in
  * form is refused silently when the shape or the transport cannot carry it; tests that ask for one check here. */
 int l2z_runstate_form(const l2z_runstate *s, int *form);
 

@@ -24,6 +24,8 @@ struct RcclApi {
     ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t,
                               hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                              hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -47,6 +49,7 @@ int load_rccl()
     SYM(CommDestroy, "ncclCommDestroy");
     SYM(CommCount, "ncclCommCount");
     SYM(AllGather, "ncclAllGather");
+    SYM(AllReduce, "ncclAllReduce");
     SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
     g_api.handle = h;
@@ -153,6 +156,24 @@ int comm_allgather_inplace(const l2z_comm *c, float *buf, size_t count_per_rank,
     ncclResult_t r = g_api.AllGather(buf + (size_t)c->rank * count_per_rank, buf, count_per_rank,
                                      ncclFloat, static_cast<ncclComm_t>(c->nccl), st);
     L2Z_CHECK(r == ncclSuccess, L2Z_ERR_COMM, "ncclAllGather failed: %s", g_api.GetErrorString(r));
+    return L2Z_OK;
+}
+
+int comm_allreduce(const l2z_comm *c, const float *part, float *out, size_t count, int gi, bool pushed, hipStream_t st)
+{
+    if (comm_uses_p2p(c)) {
+        L2Z_CHECK(count * (size_t)c->world <= c->slot_floats, L2Z_ERR_COMM,
+                  "peer-write all-reduce of %d x %zu floats exceeds the landing slot (%zu)", c->world, count, c->slot_floats);
+        P2pArgs a = {};
+        comm_p2p_args(c, const_cast<float *>(part), count, false, &a);
+        hipError_t e = launch_p2p_allreduce(a, out, gi, pushed, st);
+        L2Z_CHECK(e == hipSuccess, L2Z_ERR_HIP, "peer-write all-reduce launch failed: %s", hipGetErrorString(e));
+        return L2Z_OK;
+    }
+    L2Z_CHECK(!pushed, L2Z_ERR_STATE, "pushed all-reduce without the peer-write transport");
+    L2Z_CHECK(c != nullptr && c->nccl != nullptr, L2Z_ERR_COMM, "all-reduce: the shard group has no transport");
+    ncclResult_t r = g_api.AllReduce(part, out, count, ncclFloat, ncclSum, static_cast<ncclComm_t>(c->nccl), st);
+    L2Z_CHECK(r == ncclSuccess, L2Z_ERR_COMM, "ncclAllReduce failed: %s", g_api.GetErrorString(r));
     return L2Z_OK;
 }
 

@@ -41,6 +41,8 @@ int check_pair(const l2z_config *config, const l2z_runstate *s, const l2z_weight
               L2Z_ERR_INVALID, "config does not match the one RunState / Weights were built with");
     L2Z_CHECK(s->device == w->device && s->sh.rank == w->sh.rank && s->sh.world == w->sh.world,
               L2Z_ERR_INVALID, "RunState and Weights live on different devices / shards");
+    L2Z_CHECK(s->sh.scheme_b == w->sh.scheme_b, L2Z_ERR_INVALID,
+              "RunState and Weights were built under different sharding schemes (L2Z_SCHEME_B changed in between)");
     return L2Z_OK;
 }
 
@@ -56,6 +58,13 @@ int check_pair(const l2z_config *config, const l2z_runstate *s, const l2z_weight
 //   ll_consume  producers push LL words to every rank, consumers read them from their own landing
 //               slot while staging x: no launch per gather, 5 nodes per layer as at world == 1;
 //   gather launch after every producer (peer writes without consumer polling, or RCCL).
+// Scheme B (sh.scheme_b: L2Z_SCHEME_B=1 at world > 1; SURVEY.md 8e, the "all-reduce" half of north_star): Wo and W2 are
+// sharded by COLUMNS.  A rank's attention output and hidden activations stay local -- wo and w2 read just this rank's slice
+// against its columns of every row and leave a partial [dim] vector (rank 0 adds the residual, main.zig:395 / :422), and an
+// all-reduce sums the partials in rank order into x on every rank.  2 collectives per layer (+ the logits gather) instead
+// of 4; stages between collectives: [qkv, attention, wo], [w1|w3, w2] per layer, then the classifier.  The sum over a row
+// is split differently than in the unsharded pass: logits agree at the tolerance of the parity tests, not bit for bit
+// (ranks agree with each other exactly: same partials, same order).
 // Overlapped chain (s->ovl; world == 1, wide-row models).  The launches of a pass go out on TWO
 // streams with no edge between consecutive mat-vecs: a consumer whose input edge is overlapped runs in the other
 // chain than its producer, becomes resident while the producer still streams, issues its first weight batch and
@@ -108,6 +117,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
     // while the launch still runs).  With gather launches, not while profiling: the gather's share
     // would be hidden in the producer's time.
     const bool can_push = ovl || (p2p && tn.p2p_push && (consume || prof == nullptr));
+    const bool sb = sh.scheme_b;
     const int n_g = s->n_gathers;
     int gi = 0;           // gathers issued so far in this pass
     bool pushed = false;  // the launch just made pushed its outputs itself
@@ -147,6 +157,28 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         }
         return L2Z_OK;
     };
+    // scheme B: x = sum over ranks of their partial vectors (s->part), as its own launch
+    auto reduce = [&]() -> int {
+        stage++;
+        gi++;
+        if (only_stage >= 0 || only_kind >= 0) return L2Z_OK;
+        const bool was_pushed = pushed;
+        pushed = false;
+        hipEvent_t ea = nullptr, eb = nullptr;
+        if (prof != nullptr) {
+            L2Z_HIP(hipEventCreate(&ea));
+            L2Z_HIP(hipEventCreate(&eb));
+            L2Z_HIP(hipEventRecord(ea, st));
+        }
+        L2Z_TRY(comm_allreduce(s->comm, s->part, s->x, dim, gi, was_pushed, st));
+        if (prof != nullptr) {
+            L2Z_HIP(hipEventRecord(eb, st));
+            prof->ev.push_back(ea);
+            prof->ev.push_back(eb);
+            prof->kind.push_back(KIND_GATHER);
+        }
+        return L2Z_OK;
+    };
     // input of a consumer: the vector gathered as number g (consumer-side form), else the plain buffer.
     // Overlapped chain: `edge` = the bit of the edge this input arrives over; set -> the consumer runs in the
     // other chain than the producer and reads the words behind the producer's hint, clear -> same chain, plain.
@@ -173,6 +205,18 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         a.push = s->d_push + which;
         a.push_ctl = ctl;
         a.push_gi = gi + 1;
+    };
+    // a column-shard mat-vec of scheme B: the local slice x_loc (n_pad floats, zero beyond the slice) against this rank's
+    // columns of all `dim` rows -> s->part; rank 0 adds the residual
+    auto col_shard = [&](MatvecArgs &a, const float *wcols, const float *x_loc, int n_pad, int *epi) {
+        a.w0 = wcols;
+        a.x = x_loc;
+        a.n = n_pad;
+        a.rows0 = c.dim;
+        a.out0 = s->part;
+        a.resid = sh.rank == 0 ? s->x : nullptr;
+        *epi = sh.rank == 0 ? EPI_RESID : EPI_STORE;
+        push_to(a, 1);
     };
     for (int l = 0; l < c.n_layers; l++) {
         // :354 loff; inside a layer the device cache is head-major, [kv heads][seq_len][head_size]: the rows
@@ -210,7 +254,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.q = s->q; a.kcache = kc; a.vcache = vc; a.xb = s->xb + sh.dim0;
             a.pos_ptr = s->d_pos; a.head_size = sh.hs; a.kv_row = sh.hs; a.kv_head = kvh_stride;
             a.kv_mul = c.n_heads / c.n_kv_heads; a.seq_len = c.seq_len;
-            if (can_push && attention_push_supported(a)) {
+            if (!sb && can_push && attention_push_supported(a)) {
                 a.push = s->d_push + 0;
                 a.push_ctl = ctl;
                 a.push_gi = gi + 1;
@@ -223,47 +267,59 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             else
                 L2Z_LAUNCH(KIND_ATTN, launch_attention(a, sh.heads_loc, st, (variant == ATTN_SHORT || s->attn_all256) ? 1 : 0));
         }
-        L2Z_TRY(gather(s->xb, sh.dim_loc));
+        if (!sb) L2Z_TRY(gather(s->xb, sh.dim_loc));
         if (want() && kind(KIND_WO)) {   // wo (:392) + residual (:395)
             MatvecArgs a = {};
-            a.w0 = w->wo + (size_t)l * sh.dim_loc * dim;
-            a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0;
-            a.rows0 = sh.dim_loc; a.n = c.dim;
-            x_in(a, s->xb, gi, sh.dim_loc, 1u);
-            if (ovl && gi >= 2) a.resid_in = comm_ll_in(lc, gi - 1, sh.dim_loc);  // x as the previous layer's w2 handed it over
-            push_to(a, 1);
+            int epi = EPI_RESID;
+            if (sb) {
+                col_shard(a, w->wo + (size_t)l * dim * sh.dimc_pad, s->xb + sh.dim0, sh.dimc_pad, &epi);
+            } else {
+                a.w0 = w->wo + (size_t)l * sh.dim_loc * dim;
+                a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0;
+                a.rows0 = sh.dim_loc; a.n = c.dim;
+                x_in(a, s->xb, gi, sh.dim_loc, 1u);
+                if (ovl && gi >= 2) a.resid_in = comm_ll_in(lc, gi - 1, sh.dim_loc);  // x as the previous layer's w2 handed it over
+                push_to(a, 1);
+            }
             int vg = 0;
-            L2Z_LAUNCH(KIND_WO, launch_matvec(a, PRO_NONE, EPI_RESID, mb, g_cus, st, &vg, &pushed));
+            L2Z_LAUNCH(KIND_WO, launch_matvec(a, PRO_NONE, epi, mb, g_cus, st, &vg, &pushed));
             hint = mv_hint((sh.dim_loc + 1) / 2, vg, EPI_RESID);
         }
-        L2Z_TRY(gather(s->x, sh.dim_loc));
+        if (sb) L2Z_TRY(reduce());
+        else L2Z_TRY(gather(s->x, sh.dim_loc));
         if (want() && kind(KIND_FFN13)) {   // rmsnorm (:398) + w1,w3 (:405-408) + SiLU*mul (:411-416)
             MatvecArgs a = {};
             a.w0 = w->w1 + (size_t)l * sh.hid_loc * 2 * dim;  // W1 | W3 row-interleaved: one linear sweep
             a.w1 = w->w3 + (size_t)l * sh.hid_loc * 2 * dim;  // = a.w0 + dim; the kernels derive it from a.w0
-            a.out0 = s->hb + sh.hid0;
+            a.out0 = sb ? s->hb : s->hb + sh.hid0;  // scheme B: the slice stays local, w2's column shard reads it from the buffer's start
             a.rows0 = sh.hid_loc; a.rows1 = sh.hid_loc; a.n = c.dim;
             a.rms_w = w->rms_ffn + (size_t)l * dim;
             x_in(a, s->x, gi, sh.dim_loc, 2u);
-            push_to(a, 2);
+            if (!sb) push_to(a, 2);
             int vg = 0;
             L2Z_LAUNCH(KIND_FFN13, launch_matvec(a, PRO_RMS, EPI_SWIGLU, mb, g_cus, st, &vg, &pushed));
             hint = mv_hint(sh.hid_loc, vg, EPI_SWIGLU);
         }
-        L2Z_TRY(gather(s->hb, sh.hid_loc));
+        if (!sb) L2Z_TRY(gather(s->hb, sh.hid_loc));
         if (want() && kind(KIND_FFN2)) {   // w2 (:419) + residual (:422)
             MatvecArgs a = {};
-            a.w0 = w->w2 + (size_t)l * sh.dim_loc * hid;
-            a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0;
-            a.rows0 = sh.dim_loc; a.n = c.hidden_dim;
-            x_in(a, s->hb, gi, sh.hid_loc, 4u);
-            if (ovl) a.resid_in = comm_ll_in(lc, gi - 1, sh.dim_loc);  // x as this layer's wo handed it over
-            push_to(a, 1);
+            int epi = EPI_RESID;
+            if (sb) {
+                col_shard(a, w->w2 + (size_t)l * dim * sh.hidc_pad, s->hb, sh.hidc_pad, &epi);
+            } else {
+                a.w0 = w->w2 + (size_t)l * sh.dim_loc * hid;
+                a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0;
+                a.rows0 = sh.dim_loc; a.n = c.hidden_dim;
+                x_in(a, s->hb, gi, sh.hid_loc, 4u);
+                if (ovl) a.resid_in = comm_ll_in(lc, gi - 1, sh.dim_loc);  // x as this layer's wo handed it over
+                push_to(a, 1);
+            }
             int vg = 0;
-            L2Z_LAUNCH(KIND_FFN2, launch_matvec(a, PRO_NONE, EPI_RESID, mb, g_cus, st, &vg, &pushed));
+            L2Z_LAUNCH(KIND_FFN2, launch_matvec(a, PRO_NONE, epi, mb, g_cus, st, &vg, &pushed));
             hint = mv_hint((sh.dim_loc + 1) / 2, vg, EPI_RESID);
         }
-        L2Z_TRY(gather(s->x, sh.dim_loc));
+        if (sb) L2Z_TRY(reduce());
+        else L2Z_TRY(gather(s->x, sh.dim_loc));
     }
     if (want() && kind(KIND_CLS)) {   // final rmsnorm (:426) + classifier (:429)
         MatvecArgs a = {};
@@ -801,11 +857,21 @@ extern "C" int l2z_emu_transformer(int n_ranks, l2z_runstate *const *ss,
         L2Z_HIP(launch_set_state(token, pos, ss[r]->d_token, ss[r]->d_pos, ws[r]->tok_emb, ss[r]->x,
                                  c.dim, ss[r]->stream));
     }
-    const int n_stages = 4 * c.n_layers + 1;
+    const bool sb = ss[0]->sh.scheme_b;
+    const int n_stages = (sb ? 2 : 4) * c.n_layers + 1;
     for (int stage = 0; stage < n_stages; stage++) {
         for (int r = 0; r < n_ranks; r++)
             L2Z_TRY(enqueue_forward(ss[r], ws[r], false, nullptr, stage, attn_variant(ss[r], pos)));
         for (int r = 0; r < n_ranks; r++) L2Z_HIP(hipStreamSynchronize(ss[r]->stream));
+        if (sb && stage < n_stages - 1) {
+            // scheme B: the all-reduce -- every rank's x = the partials summed in rank order
+            const float *parts[kMaxWorld];
+            L2Z_CHECK(n_ranks <= kMaxWorld, L2Z_ERR_INVALID, "l2z_emu_transformer: more than %d ranks", kMaxWorld);
+            for (int r = 0; r < n_ranks; r++) parts[r] = ss[r]->part;
+            for (int r = 0; r < n_ranks; r++) L2Z_HIP(launch_sum_parts(ss[r]->x, parts, n_ranks, c.dim, nullptr));
+            L2Z_HIP(hipDeviceSynchronize());
+            continue;
+        }
         // which buffer this stage produced, and the per-rank slice length
         const Shard &sh0 = ss[0]->sh;
         size_t count;

@@ -39,6 +39,10 @@ namespace l2z {
 // No-op for a null comm or world == 1.
 int comm_allgather_inplace(const l2z_comm *c, float *buf, size_t count_per_rank, int gi, int n_gathers,
                            bool pushed, hipStream_t st);
+// Scheme B: out[i] = the sum over ranks, in rank order, of every rank's part[i] (count floats each), as its own launch:
+// the peer-write reduce kernel (p2p.hip; pushed: the producing mat-vec already stored this rank's words), or
+// ncclAllReduce (sum order RCCL's; every rank receives the same result).  gi as for the gathers.
+int comm_allreduce(const l2z_comm *c, const float *part, float *out, size_t count, int gi, bool pushed, hipStream_t st);
 // 0, or L2Z_ERR_COMM once a peer-write wait has timed out (checked after synchronising)
 int comm_check(const l2z_comm *c);
 
@@ -57,6 +61,7 @@ struct P2pArgs {
 
 // pushed: the producing kernel has already written this rank's words (MatvecArgs::push)
 hipError_t launch_p2p_allgather(const P2pArgs &a, int gi, int n_gathers, bool pushed, hipStream_t st);
+hipError_t launch_p2p_allreduce(const P2pArgs &a, float *out, int gi, bool pushed, hipStream_t st);
 bool comm_p2p_args(const l2z_comm *c, float *buf, size_t count_per_rank, bool self, P2pArgs *out);
 LLIn comm_ll_in(const l2z_comm *c, int gi, size_t count_per_rank);
 // the peer-write transport is connected and not overridden by L2Z_COMM=rccl

@@ -237,9 +237,13 @@ hipError_t launch_probs(float *probs, const float *logits, int n, float temperat
 hipError_t launch_dot(float *out, const float *x, const float *y, int n, hipStream_t st);
 hipError_t launch_weighted_sum_rows(float *xout, int xout_len, const float *rows, int row_stride,
                                     const float *weights, int n_weights, hipStream_t st);
-// row_len != 0: element i goes to dst[(i / row_len) * row_pitch + i % row_len] (rows of a strided matrix)
+// row_len != 0: element i goes to dst[(i / row_len) * row_pitch + i % row_len] (rows of a strided matrix); idx_pitch != 0:
+// its blob index is base_idx + (i / row_len) * idx_pitch + i % row_len (a column range of rows idx_pitch wide)
 hipError_t launch_synth_fill(float *dst, uint64_t base_idx, uint64_t count, uint64_t seed,
-                             float scale, float bias, hipStream_t st, uint64_t row_len = 0, uint64_t row_pitch = 0);
+                             float scale, float bias, hipStream_t st, uint64_t row_len = 0, uint64_t row_pitch = 0,
+                             uint64_t idx_pitch = 0);
+// out[i] = parts[0][i] + parts[1][i] + ... in that order (the emulated ranks' all-reduce of scheme B)
+hipError_t launch_sum_parts(float *out, const float *const *parts, int n_parts, int n, hipStream_t st);
 // dst row r (dpitch floats apart) = src row r (contiguous rows of cols floats); both on the device
 hipError_t launch_copy_rows(float *dst, size_t dpitch, const float *src, size_t rows, size_t cols, hipStream_t st);
 size_t attention_lds_bytes(int head_size, int seq_len, bool vec);

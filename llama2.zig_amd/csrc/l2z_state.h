@@ -20,7 +20,14 @@ struct Shard {
     int heads_loc = 0;
     int hid0 = 0, hid_loc = 0;   // rows of w1/w3, slice of hb
     int v0 = 0, v_loc = 0;       // rows of wcls, slice of logits
+    // Scheme B (L2Z_SCHEME_B, world > 1): Wo and W2 are sharded by COLUMNS -- this rank holds the
+    // columns its own heads / hidden rows feed, [dim][dimc_pad] and [dim][hidc_pad] per layer, the pad columns zero --
+    // and produces a partial [dim] vector that an all-reduce sums.  dimc_pad / hidc_pad: dim_loc / hid_loc rounded
+    // up to a width the vector mat-vec takes (pad_cols)
+    bool scheme_b = false;
+    int dimc_pad = 0, hidc_pad = 0;
 };
+int pad_cols(int n);  // widths above 768 floats: multiples of 256 (a row = whole 64-lane sweeps of 16 bytes); below: of 4
 int make_shard(const l2z_config &c, const l2z_comm *comm, Shard *out);
 
 // ----- the Weights.init pointer walk (main.zig:85-112) as a table -----
@@ -76,6 +83,7 @@ struct l2z_runstate {
     // main.zig:119-135 (k, v, xb2, hb2, logits_indexed have no device twin:
     // k/v go straight into the cache rows, xb2/hb2 are fused away)
     float *x = nullptr, *xb = nullptr, *hb = nullptr, *q = nullptr, *logits = nullptr;
+    float *part = nullptr;    // scheme B: this rank's partial [dim] output of wo / w2 (rank 0's includes the residual), summed by the all-reduce
     float *key_cache = nullptr, *value_cache = nullptr;
     float2 *rope = nullptr;  // (seq_len, head_size/2) {cos, sin}
     // loop state on the device
@@ -110,7 +118,7 @@ struct l2z_runstate {
     // peer-write transport: device copies of the four gathers' descriptions (xb, x, hb, logits) for
     // the kernels that push their outputs to the peers themselves (MatvecArgs::push)
     l2z::P2pArgs *d_push = nullptr;
-    int n_gathers = 0;        // gathers per forward pass at world > 1: 4 per layer + logits
+    int n_gathers = 0;        // collectives per forward pass at world > 1: 4 gathers per layer + logits (scheme B: 2 all-reduces per layer + logits)
     bool ll_consume = false;  // peer-write transport, consumer side: mat-vecs read their gathered input
                               // as LL words from the landing slot; no gather launch except the logits
     bool fused_qkv_attn = false;  // small models: qkv + RoPE + KV write + attention in one launch

@@ -135,13 +135,15 @@ __global__ __launch_bounds__(1024) void probs_kernel(float *probs, const float *
 
 // Seeded synthetic weights: value(idx) = bias + scale*r(idx,seed); must match
 // oracle/llama2_oracle.c orc_synth_value and checkpoint.py synth_values bit for bit.
-// row_len != 0: element i lands at dst[(i / row_len) * row_pitch + i % row_len] (rows of a strided matrix)
+// row_len != 0: element i lands at dst[(i / row_len) * row_pitch + i % row_len] (rows of a strided matrix);
+// idx_pitch != 0: its index in the blob is base_idx + (i / row_len) * idx_pitch + i % row_len (a column range of wider rows)
 __global__ void synth_fill_kernel(float *dst, uint64_t base_idx, uint64_t count, uint64_t seed,
-                                  float scale, float bias, uint64_t row_len, uint64_t row_pitch)
+                                  float scale, float bias, uint64_t row_len, uint64_t row_pitch, uint64_t idx_pitch)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-        uint64_t z = (base_idx + i) + seed * 0x9E3779B97F4A7C15ULL;
+        const uint64_t idx = idx_pitch ? (i / row_len) * idx_pitch + i % row_len : i;
+        uint64_t z = (base_idx + idx) + seed * 0x9E3779B97F4A7C15ULL;
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
         z = z ^ (z >> 31);
@@ -150,6 +152,16 @@ __global__ void synth_fill_kernel(float *dst, uint64_t base_idx, uint64_t count,
         const uint64_t at = row_len ? (i / row_len) * row_pitch + i % row_len : i;
         dst[at] = __fadd_rn(bias, __fmul_rn(scale, r));
     }
+}
+
+struct PartPtrs { const float *p[16]; };
+__global__ void sum_parts_kernel(float *out, const PartPtrs parts, int n_parts, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float acc = parts.p[0][i];
+    for (int r = 1; r < n_parts; r++) acc = __fadd_rn(acc, parts.p[r][i]);
+    out[i] = acc;
 }
 
 // dst row r (dpitch floats apart) = src row r (contiguous rows of cols floats)
@@ -212,13 +224,22 @@ hipError_t launch_softmax(float *x, int n, hipStream_t st)
 }
 
 hipError_t launch_synth_fill(float *dst, uint64_t base_idx, uint64_t count, uint64_t seed,
-                             float scale, float bias, hipStream_t st, uint64_t row_len, uint64_t row_pitch)
+                             float scale, float bias, hipStream_t st, uint64_t row_len, uint64_t row_pitch, uint64_t idx_pitch)
 {
     if (count == 0) return hipSuccess;
     uint64_t blocks = (count + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(synth_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dst, base_idx,
-                       count, seed, scale, bias, row_len, row_pitch);
+                       count, seed, scale, bias, row_len, row_pitch, idx_pitch);
+    return hipGetLastError();
+}
+
+hipError_t launch_sum_parts(float *out, const float *const *parts, int n_parts, int n, hipStream_t st)
+{
+    if (n_parts < 1 || n_parts > 16) return hipErrorInvalidValue;
+    PartPtrs pp = {};
+    for (int r = 0; r < n_parts; r++) pp.p[r] = parts[r];
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((n + 255) / 256), dim3(256), 0, st, out, pp, n_parts, n);
     return hipGetLastError();
 }
 

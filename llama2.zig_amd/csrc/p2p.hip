@@ -116,6 +116,72 @@ __global__ __launch_bounds__(256) void p2p_allgather_kernel(const P2pArgs a, int
     }
 }
 
+// ---- all-reduce (scheme B: column-sharded Wo / W2) ----
+// Every rank holds a partial [count] vector (rank 0's includes the residual); afterwards out[i] = part_0[i] + part_1[i] + ...
+// + part_{N-1}[i], summed in RANK order by every rank -- so all ranks end with the same bits, whatever the order the
+// words arrive in.  One hop: a rank's partial travels as LL words to word rank * count + i of every peer's slot (from the
+// producing mat-vec's epilogue, or from this launch when the producer could not push), and the thread that owns element
+// i polls the N - 1 peers' words for it.  Slot reuse and deadlock freedom: as for the gather launch above.
+__global__ __launch_bounds__(256) void p2p_allreduce_kernel(const P2pArgs a, float *out, int gi, int pushed)
+{
+    __shared__ int s_timeout;
+    if (threadIdx.x == 0) s_timeout = 0;
+    const int e = a.ctl[kCtlEpoch] + gi;
+    const bool dead = __hip_atomic_load(a.ctl + kCtlErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    __syncthreads();
+    const u64 tag = (u64)(unsigned)e << 32;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int late = -1;
+    if (i < a.count && !dead) {
+        const float own = a.buf[i];
+        if (!pushed)
+            for (int p = 0; p < a.world; p++)
+                if (p != a.rank)
+                    __hip_atomic_store(slot_words(a.peer_arena[p], e, a.slot_floats) + (size_t)a.rank * a.count + i,
+                                       tag | (u64)__float_as_uint(own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // all peers' words for element i in flight at once, re-polled until each carries the epoch
+        const u64 *mine = slot_words(a.peer_arena[a.rank], e, a.slot_floats) + i;
+        const long long t0 = wall_clock64();
+        u64 w[kMaxWorld];
+#pragma unroll
+        for (int p = 0; p < kMaxWorld; p++)
+            w[p] = (p < a.world && p != a.rank) ? __hip_atomic_load(mine + (size_t)p * a.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                                 : tag;
+        for (;;) {
+            bool ready = true;
+#pragma unroll
+            for (int p = 0; p < kMaxWorld; p++)
+                if ((unsigned)(w[p] >> 32) != (unsigned)e) {
+                    w[p] = __hip_atomic_load(mine + (size_t)p * a.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if ((unsigned)(w[p] >> 32) != (unsigned)e) {
+                        ready = false;
+                        late = p;
+                    }
+                }
+            if (ready) {
+                late = -1;
+                break;
+            }
+            if (wall_clock64() - t0 > a.timeout_ticks) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        float acc = 0.0f;
+#pragma unroll
+        for (int p = 0; p < kMaxWorld; p++)
+            if (p < a.world) {
+                const float v = p == a.rank ? own : __uint_as_float((unsigned)w[p]);
+                acc = p == 0 ? v : __fadd_rn(acc, v);
+            }
+        out[i] = acc;
+        if (late >= 0) s_timeout = 1 + late;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_timeout) {
+        __hip_atomic_store(a.ctl + kCtlErr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *a.err = s_timeout;
+    }
+}
+
 // ---- bulk form (sharded prefill): [P, n_loc] blocks of floats, plain stores, one flag per sender ----
 // A gather of a whole activation matrix is bandwidth-, not latency-bound: the LL form's 8 bytes per
 // float would double the xGMI traffic for nothing.  The sender stores its block into region (e & 1)
@@ -223,6 +289,12 @@ hipError_t launch_bulk_unpack(const BulkArgs &a, unsigned long long e, int wait,
     const int blocks = wait && tunables().grid_cap > 0 ? (tunables().grid_cap < 128 ? tunables().grid_cap : 128) : 512;
     const int parts = (blocks + a.world - 1) / a.world;
     hipLaunchKernelGGL(bulk_unpack_kernel, dim3(a.world, parts), dim3(256), 0, st, a, (u64)e, wait, dst, ldd);
+    return hipGetLastError();
+}
+
+hipError_t launch_p2p_allreduce(const P2pArgs &a, float *out, int gi, bool pushed, hipStream_t st)
+{
+    hipLaunchKernelGGL(p2p_allreduce_kernel, dim3((unsigned)((a.count + 255) / 256)), dim3(256), 0, st, a, out, gi, pushed ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -223,6 +223,7 @@ bool prefill_usable(const l2z_runstate *s)
     const l2z_config &c = s->cfg;
     if (c.dim % 4 != 0 || c.hidden_dim % 4 != 0 || s->sh.hs % 4 != 0 || s->sh.hs > 256) return false;
     if (s->sh.world == 1) return true;
+    if (s->sh.scheme_b) return false;  // column-sharded Wo / W2: the batched pass is built on row shards; prompts are stepped
     if (s->sh.dim_loc % 4 != 0 || s->sh.hid_loc % 4 != 0) return false;
     const size_t widest = (size_t)(c.dim > c.hidden_dim ? c.dim : c.hidden_dim);
     return comm_bulk_ok(s->comm, (size_t)kPrefillChunk * widest);
@@ -233,6 +234,8 @@ int prefill_check(const l2z_config *config, const l2z_runstate *s)
     L2Z_CHECK(config->dim % 4 == 0 && config->hidden_dim % 4 == 0 && s->sh.hs % 4 == 0 &&
                   s->sh.hs <= 256, L2Z_ERR_INVALID,
               "l2z_prefill: needs dim, hidden_dim, head_size multiples of 4 and head_size <= 256");
+    L2Z_CHECK(!s->sh.scheme_b, L2Z_ERR_INVALID,
+              "l2z_prefill: the batched pass is built on row shards; scheme-B runstates step their prompts");
     L2Z_CHECK(prefill_usable(s), L2Z_ERR_INVALID,
               "l2z_prefill: this sharded runstate has no transport for [%d, hidden_dim] matrices (RCCL "
               "communicator, or peer-write arena with bulk regions: L2Z_P2P_BULK_MB), or its row shards are "
@@ -310,6 +313,8 @@ extern "C" int l2z_emu_prefill(int n_ranks, l2z_runstate *const *ss, const l2z_w
         L2Z_CHECK(c.dim % 4 == 0 && c.hidden_dim % 4 == 0 && ss[r]->sh.hs % 4 == 0 && ss[r]->sh.hs <= 256 &&
                       ss[r]->sh.dim_loc % 4 == 0 && ss[r]->sh.hid_loc % 4 == 0,
                   L2Z_ERR_INVALID, "l2z_emu_prefill: shape not supported by the batched path");
+        L2Z_CHECK(!ss[r]->sh.scheme_b, L2Z_ERR_INVALID,
+                  "l2z_emu_prefill: the batched pass is built on row shards; scheme-B runstates step their prompts");
         L2Z_TRY(prefill_alloc(ss[r], n_tokens < kPrefillChunk ? n_tokens : kPrefillChunk));
     }
     auto sync_all = [&]() -> int {

@@ -45,7 +45,7 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
     if (comm && comm->nccl && !comm_uses_p2p(comm) && tn.comm_graph == 0) s->use_graphs = false;
     s->fused_qkv_attn = sh.world == 1 && tn.fuse_small != 0 &&
                         fused_qkv_attn_supported(c.dim, c.n_heads, c.n_kv_heads, c.seq_len, g_cus);
-    s->n_gathers = 4 * c.n_layers + 1;
+    s->n_gathers = (sh.scheme_b ? 2 : 4) * c.n_layers + 1;
     // Wide-row models (every mat-vec takes matvec_duo_kernel): 256-thread attention forms at every position -- what
     // lets a waiting launch of the overlapped chain share a CU with the attention it waits behind.
     // A function of the MODEL, not of the rank count or the mode, so sharded, unsharded, overlapped and
@@ -54,10 +54,13 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
                      matvec_duo_supported(c.hidden_dim);
     if (comm_uses_p2p(comm)) {
         // the producers store straight into the peers' landing slots: they must hold the longest vector
-        const size_t longest = (size_t)std::max(std::max(c.dim, c.hidden_dim), c.vocab_size);
+        // (scheme B: every rank's whole partial [dim] vector lands in every slot)
+        const size_t longest = std::max((size_t)std::max(std::max(c.dim, c.hidden_dim), c.vocab_size),
+                                        sh.scheme_b ? (size_t)sh.world * (size_t)c.dim : (size_t)0);
         if (comm->slot_floats < longest) {
             set_error("peer-write landing slots hold %zu floats, this config gathers up to %zu: pass "
-                      "max(dim, hidden_dim, vocab_size) to l2z_comm_p2p_export", comm->slot_floats, longest);
+                      "max(dim, hidden_dim, vocab_size%s) to l2z_comm_p2p_export", comm->slot_floats, longest,
+                      sh.scheme_b ? ", world * dim" : "");
             delete s;
             return L2Z_ERR_COMM;
         }
@@ -70,8 +73,10 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
         if (e == hipSuccess) e = hipMemset(*p, 0, bytes ? bytes : 4);
     };
     alloc((void **)&s->x, (size_t)c.dim * 4);
-    alloc((void **)&s->xb, (size_t)c.dim * 4);
-    alloc((void **)&s->hb, (size_t)c.hidden_dim * 4);
+    // (+ 256: scheme B's column-shard mat-vecs read their local slice padded to the shard's row width; the pad stays zero)
+    alloc((void **)&s->xb, ((size_t)c.dim + 256) * 4);
+    alloc((void **)&s->hb, ((size_t)c.hidden_dim + 256) * 4);
+    if (sh.scheme_b) alloc((void **)&s->part, (size_t)c.dim * 4);
     alloc((void **)&s->q, (size_t)c.dim * 4);
     alloc((void **)&s->logits, (size_t)c.vocab_size * 4);
     alloc((void **)&s->key_cache, kv * 4);
@@ -116,11 +121,12 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
         AttnArgs aa = {};
         aa.q = s->q; aa.kcache = s->key_cache; aa.vcache = s->value_cache;
         aa.head_size = sh.hs; aa.kv_row = sh.hs; aa.kv_head = (size_t)c.seq_len * sh.hs;
-        s->ll_consume = tn.p2p_push && tn.p2p_consume && matvec_ll_supported(c.dim) &&
+        s->ll_consume = !sh.scheme_b && tn.p2p_push && tn.p2p_consume && matvec_ll_supported(c.dim) &&
                         matvec_ll_supported(c.hidden_dim) && attention_push_supported(aa);
         P2pArgs t[4];
         comm_p2p_args(comm, s->xb, (size_t)sh.dim_loc, s->ll_consume, &t[0]);
-        comm_p2p_args(comm, s->x, (size_t)sh.dim_loc, s->ll_consume, &t[1]);
+        // (scheme B: the pushed vector is the rank's whole partial, element i of rank r at word r * dim + i)
+        comm_p2p_args(comm, sh.scheme_b ? s->part : s->x, sh.scheme_b ? (size_t)c.dim : (size_t)sh.dim_loc, s->ll_consume, &t[1]);
         comm_p2p_args(comm, s->hb, (size_t)sh.hid_loc, s->ll_consume, &t[2]);
         comm_p2p_args(comm, s->logits, (size_t)sh.v_loc, false, &t[3]);
         alloc((void **)&s->d_push, sizeof t);
@@ -134,7 +140,7 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
     }
     // the persistent decode launches: wide-row model, every mat-vec's units fit the blocks' lanes; sharded runs: the
     // peer-write transport in its consumer-side form (the launches hand their vectors over as its words)
-    if (tn.engine != 0 && !s->fused_qkv_attn && matvec_duo_supported(c.dim) && matvec_duo_supported(c.hidden_dim) &&
+    if (tn.engine != 0 && !sh.scheme_b && !s->fused_qkv_attn && matvec_duo_supported(c.dim) && matvec_duo_supported(c.hidden_dim) &&
         (sh.world == 1 || (comm_uses_p2p(comm) && s->ll_consume)) && e == hipSuccess) {
         // several ranks on ONE GPU (tests): every rank's blocks must be resident at once (a block ~ a CU)
         int grid = g_cus;
@@ -211,7 +217,7 @@ extern "C" void l2z_runstate_free(l2z_runstate *s)
     void *ptrs[] = {s->x, s->xb, s->hb, s->q, s->logits, s->key_cache, s->value_cache, s->rope,
                     s->d_token, s->d_pos, s->d_prompt, s->d_n_prompt, s->d_out_tokens, s->d_argmax,
                     s->d_probs, s->d_part_val, s->d_part_idx, s->d_attn_part, s->d_attn_cnt, s->pf_x, s->pf_xn, s->pf_q,
-                    s->pf_att, s->pf_h1, s->pf_stage, s->pf_tokens, s->d_push, s->pf_sk.part, s->pf_sk.cnt, s->d_eng};
+                    s->pf_att, s->pf_h1, s->pf_stage, s->pf_tokens, s->d_push, s->pf_sk.part, s->pf_sk.cnt, s->d_eng, s->part};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->h_stage) (void)hipHostFree(s->h_stage);
@@ -229,11 +235,12 @@ extern "C" void l2z_runstate_free(l2z_runstate *s)
 
 // Which decode structure this runstate will run (the opt-in forms of tunables.h can be refused by the shape or
 // the transport; a test that asks for one checks here that it got it): bit 0 paired mat-vec blocks (L2Z_DUO),
-// bit 1 two overlapped chains (L2Z_OVERLAP), bit 2 the persistent launches (L2Z_ENGINE).
+// bit 1 two overlapped chains (L2Z_OVERLAP), bit 2 the persistent launches (L2Z_ENGINE), bit 3 sharding scheme B
+// (L2Z_SCHEME_B: column-sharded Wo / W2, all-reduces).
 extern "C" int l2z_runstate_form(const l2z_runstate *s, int *form)
 {
     L2Z_CHECK(s != nullptr && form != nullptr, L2Z_ERR_INVALID, "l2z_runstate_form: bad arguments");
-    *form = (s->duo ? 1 : 0) | (s->ovl ? 2 : 0) | (s->eng ? 4 : 0);
+    *form = (s->duo ? 1 : 0) | (s->ovl ? 2 : 0) | (s->eng ? 4 : 0) | (s->sh.scheme_b ? 8 : 0);
     return L2Z_OK;
 }
 

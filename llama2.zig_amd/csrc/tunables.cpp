@@ -33,6 +33,7 @@ Tunables read_env()
     env_int("L2Z_OVERLAP_HINT_SLEEP", &t.overlap_hint_sleep);
     env_int("L2Z_DUO", &t.duo);
     env_int("L2Z_ENGINE", &t.engine);
+    env_int("L2Z_SCHEME_B", &t.scheme_b);
     env_int("L2Z_NO_GRAPH", &t.no_graph);
     env_int("L2Z_COMM_GRAPH", &t.comm_graph);
     if (const char *e = getenv("L2Z_COMM")) t.prefer_rccl = strcmp(e, "rccl") == 0;
@@ -98,7 +99,7 @@ bool tunables_set(const char *name, long long v)
         {"L2Z_ATTN_SPLIT_POS", &t.attn_split_pos}, {"L2Z_ATTN_SHORT_POS", &t.attn_short_pos}, {"L2Z_ATTN_SPLIT_WIDE_POS", &t.attn_split_wide_pos},
         {"L2Z_FUSE_SMALL", &t.fuse_small}, {"L2Z_NO_GRAPH", &t.no_graph},
         {"L2Z_OVERLAP", &t.overlap}, {"L2Z_OVERLAP_EDGES", &t.overlap_edges}, {"L2Z_OVERLAP_HINT", &t.overlap_hint},
-        {"L2Z_OVERLAP_HINT_SLEEP", &t.overlap_hint_sleep}, {"L2Z_DUO", &t.duo}, {"L2Z_ENGINE", &t.engine},
+        {"L2Z_OVERLAP_HINT_SLEEP", &t.overlap_hint_sleep}, {"L2Z_DUO", &t.duo}, {"L2Z_ENGINE", &t.engine}, {"L2Z_SCHEME_B", &t.scheme_b},
         {"L2Z_COMM_GRAPH", &t.comm_graph}, {"L2Z_COMM_RCCL", &t.prefer_rccl},
         {"L2Z_P2P_PUSH", &t.p2p_push}, {"L2Z_P2P_CONSUME", &t.p2p_consume},
         {"L2Z_P2P_BULK_MB", &t.p2p_bulk_mb},

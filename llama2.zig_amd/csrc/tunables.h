@@ -44,6 +44,10 @@ struct Tunables {
     int p2p_consume = 1;       // L2Z_P2P_CONSUME     0: keep a gather launch per gathered vector (consumers
                                //                     read plain buffers)
     long long p2p_timeout_s = 20;  // L2Z_P2P_TIMEOUT_S
+    int scheme_b = 0;          // L2Z_SCHEME_B        1: shard groups take scheme B: Wo / W2 sharded by COLUMNS, every rank's partial
+                               //                     [dim] vectors summed by an all-reduce -- 2 collectives per layer instead of 4 all-gathers, but the
+                               //                     sum order differs from the unsharded pass (logit tolerance, not bit identity).  Read when Weights /
+                               //                     RunState objects are created
     int p2p_bulk_mb = -1;      // L2Z_P2P_BULK_MB     MB per bulk landing region of the peer-write arena (two of
                                //                     them; sharded prefill); default: longest vector x chunk tokens
     // --- batched prefill (prefill_host.cpp, prefill_*.hip) ---

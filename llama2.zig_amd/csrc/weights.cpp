@@ -11,6 +11,7 @@
 #include <mutex>
 
 #include "l2z_state.h"
+#include "tunables.h"
 
 namespace l2z {
 
@@ -50,8 +51,18 @@ int make_shard(const l2z_config &c, const l2z_comm *comm, Shard *out)
     L2Z_TRY(l2z_shard_range(c.vocab_size, 1, s.rank, s.world, &a, &b));
     s.v0 = (int)a;
     s.v_loc = (int)(b - a);
+    // (a 1-rank RCCL communicator takes it too: the ncclAllReduce call path, testable on one GPU)
+    s.scheme_b = tunables().scheme_b != 0 && comm != nullptr && (s.world > 1 || comm->nccl != nullptr);
+    s.dimc_pad = pad_cols(s.dim_loc);
+    s.hidc_pad = pad_cols(s.hid_loc);
     *out = s;
     return L2Z_OK;
+}
+
+int pad_cols(int n)
+{
+    const int n4 = (n + 3) / 4;
+    return n > 768 ? ((n4 + 63) / 64) * 256 : n4 * 4;
 }
 
 std::vector<TensorDesc> tensor_table(const l2z_config &c, bool shared)
@@ -135,6 +146,17 @@ namespace {
 bool is_w1(const TensorDesc &d) { return strcmp(d.name, "w1") == 0; }
 bool is_w3(const TensorDesc &d) { return strcmp(d.name, "w3") == 0; }
 
+// scheme B: Wo / W2 live here as this rank's COLUMNS of every row, each row padded with zeros to cpad floats
+bool col_shard(const l2z_weights *w, const TensorDesc &d, size_t *c0, size_t *cl, size_t *cpad)
+{
+    if (!w->sh.scheme_b || d.kind != BY_DIM_ROWS) return false;
+    const bool is_wo = strcmp(d.name, "wo") == 0;
+    *c0 = is_wo ? w->sh.dim0 : w->sh.hid0;
+    *cl = is_wo ? w->sh.dim_loc : w->sh.hid_loc;
+    *cpad = is_wo ? w->sh.dimc_pad : w->sh.hidc_pad;
+    return true;
+}
+
 // floats a tensor takes in the device blob: this rank's rows; W1's slot also holds W3's rows (interleaved),
 // W3 has none of its own; the never-read freq_cis tables stay resident only in the unsharded layout (weights_read)
 size_t slot_floats(const l2z_weights *w, const TensorDesc &d)
@@ -143,6 +165,8 @@ size_t slot_floats(const l2z_weights *w, const TensorDesc &d)
     shard_rows(d, w->sh, &r0, &r1);
     if (d.kind == SKIP && !w->file_layout) return 0;
     if (is_w3(d)) return 0;
+    size_t c0, cl, cpad;
+    if (col_shard(w, d, &c0, &cl, &cpad)) return d.layers * d.rows * cpad;
     return d.layers * (r1 - r0) * d.cols * (is_w1(d) ? 2 : 1);
 }
 
@@ -213,7 +237,7 @@ int weights_alloc(const l2z_config *config, int shared_weights, const l2z_comm *
     w->shared = shared_weights ? 1 : 0;
     w->device = dev;
     w->sh = sh;
-    w->file_layout = sh.world == 1;
+    w->file_layout = sh.world == 1 && !sh.scheme_b;
     *tt_out = tensor_table(*config, w->shared != 0);
     w->blob_floats = local_floats(w, *tt_out);
     hipError_t e = hipMalloc(&w->blob, w->blob_floats * sizeof(float));
@@ -280,6 +304,15 @@ extern "C" int l2z_weights_init(const l2z_config *config, const float *data, siz
         shard_rows(d, w->sh, &r0, &r1);
         const size_t rl = r1 - r0;
         float *dst = w->blob + w->dev_off[i];
+        size_t c0, cl, cpad;
+        if (col_shard(w, d, &c0, &cl, &cpad)) {
+            // columns [c0, c0 + cl) of every row; the pad columns stay zero
+            e = hipMemset(dst, 0, d.layers * d.rows * cpad * sizeof(float));
+            for (size_t l = 0; l < d.layers && e == hipSuccess; l++)
+                e = hipMemcpy2D(dst + l * d.rows * cpad, cpad * sizeof(float), data + d.offset + l * d.rows * d.cols + c0,
+                                d.cols * sizeof(float), cl * sizeof(float), d.rows, hipMemcpyHostToDevice);
+            continue;
+        }
         if (is_w1(d) || is_w3(d)) {
             // in pieces of <= 64 MB through TWO staging buffers: a whole layer (180 MB at the 7B shape, ~1 GB at wider
             // ones) allocated after the blob could be the allocation that no longer fits, and a device-wide
@@ -328,6 +361,15 @@ extern "C" int l2z_weights_init_synthetic(const l2z_config *config, int shared_w
         shard_rows(d, w->sh, &r0, &r1);
         const size_t rl = r1 - r0;
         const bool pair = is_w1(d) || is_w3(d);  // rows 2 * cols apart in the shared slot
+        size_t c0, cl, cpad;
+        if (col_shard(w, d, &c0, &cl, &cpad)) {
+            float *dst = w->blob + w->dev_off[i];
+            e = hipMemsetAsync(dst, 0, d.layers * d.rows * cpad * sizeof(float), nullptr);
+            for (size_t l = 0; l < d.layers && e == hipSuccess; l++)
+                e = launch_synth_fill(dst + l * d.rows * cpad, d.offset + l * d.rows * d.cols + c0, d.rows * cl, seed, d.scale, d.bias,
+                                      nullptr, cl, cpad, d.cols);
+            continue;
+        }
         for (size_t l = 0; l < d.layers && e == hipSuccess; l++) {
             const uint64_t base = d.offset + (l * d.rows + r0) * d.cols;
             e = launch_synth_fill(w->blob + w->dev_off[i] + l * rl * d.cols * (pair ? 2 : 1), base, rl * d.cols, seed, d.scale,

@@ -302,7 +302,9 @@ int main(int argc, char **argv)
             return finish(die("comm_init"));
         }
         char handle[L2Z_COMM_IPC_BYTES];
-        const size_t longest = (size_t)std::max(std::max(cfg.dim, cfg.hidden_dim), cfg.vocab_size);
+        // (world * dim: under L2Z_SCHEME_B every rank's whole partial [dim] vector lands in every slot)
+        const size_t longest = std::max((size_t)std::max(std::max(cfg.dim, cfg.hidden_dim), cfg.vocab_size),
+                                        (size_t)g_world * (size_t)cfg.dim);
         const size_t widest = (size_t)std::max(cfg.dim, cfg.hidden_dim);  // bulk regions: [chunk, dim | hidden_dim]
         std::vector<char> all;
         if (l2z_comm_p2p_export_sized(comm, longest, widest, handle) != L2Z_OK) {

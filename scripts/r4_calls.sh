@@ -186,4 +186,29 @@ for ln in open("gpurun_out/r04_bench_4ranks_1gpu.json"):
             print(l["transport"], l["ok"], l.get("tokens_per_s"), l.get("why"), l.get("runstate_form"), l.get("wall_s"))
 PY
 ;;
+t)
+# round 4, GPU call T: scheme B (column-sharded Wo / W2, all-reduces) -- emulated ranks, then real processes, then the legs
+export L2Z_P2P_TIMEOUT_S=20
+timeout 900 python -m pytest tests/test_gpu_scheme_b.py -m gpu -q -x -s 2>&1 | tail -25
+timeout 900 python -m pytest tests/test_gpu_p2p.py -m gpu -q -x -s -k "scheme_b or bench_legs" 2>&1 | tail -25
+;;
+u)
+# round 4, GPU call U: scheme B after the parallel-poll reduce kernel, the 1-rank RCCL all-reduce path, the CLI under scheme B;
+# then bench.py --gpus 4 (7B shape, four ranks on this one GPU: a proxy) with all six legs
+export L2Z_P2P_TIMEOUT_S=20
+timeout 900 python -m pytest tests/test_gpu_scheme_b.py -m gpu -q -x 2>&1 | tail -5
+timeout 900 python -m pytest tests/test_gpu_p2p.py tests/test_host_cli.py -m gpu -q -x -k "scheme_b or bench_legs" 2>&1 | tail -8
+L2Z_BENCH_LEG_TIMEOUT_S=240 timeout 1100 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 \
+  --master-port 29533 bench.py --gpus 4 --steps 64 --warmup 1 > $O/r04_bench_4ranks_1gpu.json 2> $O/r04_bench_4ranks_1gpu.err
+echo "bench rc=$?"; tail -c 600 $O/r04_bench_4ranks_1gpu.err
+python - <<'PY'
+import json
+for ln in open("gpurun_out/r04_bench_4ranks_1gpu.json"):
+    if ln.startswith("{"):
+        o = json.loads(ln)
+        print(o.get("value"), o.get("comm", {}).get("transport"), o.get("comm", {}).get("scheme_b"))
+        for l in o["comm"]["legs"]:
+            print(l["transport"], l.get("scheme"), l["ok"], l.get("tokens_per_s"), l.get("why"), l.get("runstate_form"), l.get("wall_s"), l.get("us_per_gather"))
+PY
+;;
 esac

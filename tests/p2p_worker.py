@@ -26,6 +26,9 @@ def main() -> None:
     expect = spec.get("expect", "ok")
     comm = B.Comm(rank, world, None, 0)  # every rank on device 0: this is a one-GPU test
     longest = max(cfg.dim, cfg.hidden_dim, cfg.vocab_size)
+    scheme_b = os.environ.get("L2Z_SCHEME_B") == "1"
+    if scheme_b:  # every rank's whole partial [dim] vector lands in every slot
+        longest = max(longest, world * cfg.dim)
     h = comm.p2p_export(longest // 2 if expect == "slot_error" else longest, max(cfg.dim, cfg.hidden_dim))
     with open(os.path.join(d, f"h_{rank}.tmp"), "wb") as f:
         f.write(h)
@@ -66,6 +69,7 @@ def main() -> None:
     s = B.RunState(cfg, comm=comm)
     want_engine = os.environ.get("L2Z_ENGINE") == "1"  # a refused form would pass the comparison trivially
     assert (s.form() & 4 != 0) == want_engine, f"rank {rank}: runstate form {s.form()}, L2Z_ENGINE={want_engine}"
+    assert (s.form() & 8 != 0) == scheme_b, f"rank {rank}: runstate form {s.form()}, L2Z_SCHEME_B={scheme_b}"
     s.greedy_begin(spec["prompt"])
     if expect == "peer_dies":
         t0 = time.time()

@@ -86,6 +86,40 @@ def test_multiprocess_peer_write_gather_is_bit_identical(gpu, ck, tmp_path, mode
     s.close(); w.close()
 
 
+SCHEME_B = [(MODELS[0], "push"), (MODELS[1], "push"), (MODELS[3], "push"), (MODELS[3], "nopush"), (MODELS[5], "push"), (MODELS[4], "push")]
+
+
+@pytest.mark.parametrize("model,mode", SCHEME_B, ids=[f"{m[0]}-x{m[3]}-{mode}" for m, mode in SCHEME_B])
+def test_multiprocess_scheme_b_allreduce(gpu, ck, tmp_path, model, mode, options):
+    """Scheme B with real processes (L2Z_SCHEME_B=1: Wo / W2 sharded by columns, the ranks' partial [dim] vectors pushed as
+    LL words into every peer's slot and summed in rank order by the reduce launch, csrc/p2p.hip): 2 collectives per layer.
+    The ranks must agree with each other BIT FOR BIT; against the unsharded pass fed the same tokens the logits hold the
+    parity tests' tolerance (the row sums are split differently).  nopush: the reduce launch sends the partial itself."""
+    name, kw, shared, world = model
+    options(L2Z_FUSE_SMALL=0, L2Z_PREFILL=0)
+    cfg = ck.Config(**kw)
+    steps = min(cfg.seq_len - 2, 120)
+    on_device = cfg.dim >= 4096
+    spec = dict(cfg=kw, shared=shared, seed=33, prompt=[5, 9, 11], steps=steps, blob=not on_device)
+    run_ranks(tmp_path, world, spec, dict({"L2Z_SCHEME_B": "1"}, **({"L2Z_P2P_PUSH": "0"} if mode == "nopush" else {})))
+    outs = [np.load(tmp_path / f"out_{r}.npz") for r in range(world)]
+    for r in range(1, world):
+        for k in ("toks", "logits", "logits2"):
+            assert np.array_equal(outs[r][k], outs[0][k]), f"rank {r} {k} differs from rank 0"
+        assert int(outs[r]["am"]) == int(outs[0]["am"])
+    # the unsharded pass over the SAME token sequence (the sharded run's tokens forced as the prompt, main.zig:999-1000)
+    toks = outs[0]["toks"]
+    blob = None if on_device else ck.synth_blob(cfg, shared, 33)
+    w, s = gpu.Weights(cfg, blob, shared, seed=33), gpu.RunState(cfg)
+    s.greedy_begin(toks.tolist())
+    s.greedy_run(w, len(toks))
+    np.testing.assert_allclose(outs[0]["logits"], s.logits(), rtol=5e-5, atol=5e-5)
+    s.transformer(int(toks[-1]), len(toks) % cfg.seq_len, w)
+    np.testing.assert_allclose(outs[0]["logits2"], s.logits(), rtol=5e-5, atol=5e-5)
+    print(f"scheme B {name} x{world} {mode}: max |logit - unsharded| {np.abs(outs[0]['logits2'] - s.logits()).max():.2e}")
+    s.close(); w.close()
+
+
 def test_landing_slots_too_small_are_refused(gpu, tmp_path):
     kw = MODELS[2][1]  # vocab 32000: half of it rounds up to 16384 words, too few
     spec = dict(cfg=kw, shared=True, seed=1, prompt=[], steps=4, expect="slot_error")
@@ -182,14 +216,17 @@ def test_bench_legs_on_one_gpu(gpu, tmp_path):
     assert p.returncode == 0 and len(lines) == 1, p.stdout.decode()[-3000:] + p.stderr.decode()[-3000:]
     out = json.loads(lines[0])
     legs = {l["transport"]: l for l in out["comm"]["legs"]}
-    assert set(legs) == {"rccl", "p2p-gather", "p2p-consume", "p2p-engine"}
+    assert set(legs) == {"rccl", "p2p-gather", "p2p-consume", "p2p-engine", "rccl-allreduce", "p2p-allreduce"}
+    assert legs["p2p-allreduce"]["ok"] and legs["p2p-allreduce"]["scheme"] == "B" and legs["p2p-gather"]["scheme"] == "A"
+    assert legs["p2p-allreduce"]["gathers"] == 2 * 12 + 1 and legs["p2p-gather"]["gathers"] == 4 * 12 + 1
+    assert out["comm"]["scheme"] == "A" and out["comm"]["scheme_b"]["transport"] == "p2p-allreduce"
     # dim 768 is too narrow for the persistent launches: the leg must say so instead of timing the consume chain twice
     assert not legs["p2p-engine"]["ok"] and "persistent" in legs["p2p-engine"]["why"], legs["p2p-engine"]
     ok = [t for t, l in legs.items() if l["ok"]]
     assert "p2p-gather" in ok and "p2p-consume" in ok, legs
     for t in ok:
         assert legs[t]["ranks_agree"] and legs[t]["steps"] == 48 and legs[t]["tokens_per_s"] > 0
-    assert out["comm"]["transport"] == max(ok, key=lambda t: legs[t]["tokens_per_s"])
+    assert out["comm"]["transport"] == max([t for t in ok if legs[t]["scheme"] == "A"], key=lambda t: legs[t]["tokens_per_s"])
     assert out["value"] == legs[out["comm"]["transport"]]["tokens_per_s"] and out["n_gpus"] == 2
     if not legs["rccl"]["ok"]:
         assert legs["rccl"]["why"], legs["rccl"]

@@ -330,6 +330,29 @@ def test_cli_multi_gpu_mode_matches_single(gpu, n_gpus):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_gpus", [2, 4])
+def test_cli_multi_gpu_scheme_b(gpu, n_gpus):
+    """`-g N` under L2Z_SCHEME_B=1 (Wo / W2 sharded by columns, two all-reduces per layer, csrc/forward.cpp): the ranks
+    hold bit-identical logits among themselves -- which is what keeps the CLI's ranks in step, greedy and sampled -- and
+    logits within ~1e-6 of the single-GPU pass; these toys' argmax margins are far wider, so the greedy tokens are the
+    single-GPU run's."""
+    exe = os.path.join(HOST, "llama2")
+    ckpt = os.path.join(GOLDEN, "toy_gqa_unshared.bin" if n_gpus == 2 else "toy_mha_shared.bin")
+    env = dict(os.environ, L2Z_GRID_CAP=str(max(32, 512 // n_gpus)), L2Z_P2P_TIMEOUT_S="30", L2Z_FUSE_SMALL="0")
+    outs = []
+    for g, extra in ((1, {}), (n_gpus, {"L2Z_SCHEME_B": "1"})):
+        r = subprocess.run([exe, ckpt, "-t", "0", "-n", "20", "-z", TOK, "-i", "a b", "--tokens", "-g", str(g)],
+                           capture_output=True, timeout=180, env=dict(env, **extra))
+        assert r.returncode == 0, r.stderr.decode(errors="replace")
+        outs.append(([l for l in r.stderr.decode().splitlines() if l.startswith("tokens:")][0], r.stdout))
+    assert outs[0] == outs[1]
+    # sampled: every rank draws from its own copy of the distribution with the same seed; they finish together
+    r = subprocess.run([exe, ckpt, "-t", "1.0", "-p", "0.9", "-s", "99", "-n", "20", "-z", TOK, "-i", "a b", "--tokens", "-g", str(n_gpus)],
+                       capture_output=True, timeout=180, env=dict(env, L2Z_SCHEME_B="1"))
+    assert r.returncode == 0, r.stderr.decode(errors="replace")
+
+
+@pytest.mark.gpu
 def test_cli_multi_gpu_mode_ends_cleanly_on_bos(gpu, ck, orc, tmp_path):
     """`-g 2 -t 0` on a model whose greedy sequence ends with BOS (main.zig:1017) in the middle of a
     device call: the ranks share no control plane, so they only stay in step if every rank asks for the

@@ -29,7 +29,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, kw, shared, seed, toks, out_dir):
+def _worker(rank, world, port, kw, shared, seed, toks, out_dir, scheme="A"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
     import torch
@@ -51,10 +51,27 @@ def _worker(rank, world, port, kw, shared, seed, toks, out_dir):
     kc = np.zeros((cfg.n_layers, S, k1 - k0), np.float32)
     vc = np.zeros((cfg.n_layers, S, k1 - k0), np.float32)
 
+    n_coll = [0]
+
     def allgather(buf, lo, hi):
+        n_coll[0] += 1
         parts = [torch.zeros(hi - lo) for _ in range(world)]
         dist.all_gather(parts, torch.from_numpy(buf[lo:hi].copy()))
         return np.concatenate([p.numpy() for p in parts]).astype(np.float32)
+
+    def allreduce(part):
+        """Scheme B (csrc/p2p.hip p2p_allreduce_kernel): every rank's partial reaches every rank, each sums them in RANK
+        order.  Cross-checked against the library's own all_reduce (the RCCL leg: ncclAllReduce, its order)."""
+        n_coll[0] += 1
+        parts = [torch.zeros(part.size) for _ in range(world)]
+        dist.all_gather(parts, torch.from_numpy(part.copy()))
+        acc = parts[0].numpy().astype(np.float32)
+        for p in parts[1:]:
+            acc = acc + p.numpy()
+        lib = torch.from_numpy(part.copy())
+        dist.all_reduce(lib, op=dist.ReduceOp.SUM)
+        np.testing.assert_allclose(lib.numpy(), acc, rtol=1e-5, atol=1e-6)
+        return acc
 
     logits_all = []
     for pos, tok in enumerate(toks):
@@ -81,23 +98,34 @@ def _worker(rank, world, port, kw, shared, seed, toks, out_dir):
                 rows = np.ascontiguousarray(vc[l, :pos + 1].reshape(-1)[kh:])
                 xb_full[d0 + hl * hs:d0 + (hl + 1) * hs] = orc.vector_weighted_sum_rows(
                     hs, rows, k1 - k0, att)
-            xb_full = allgather(xb_full, d0, d1)
-            x[d0:d1] = x[d0:d1] + orc.matmul(xb_full, W["wo"][l][d0:d1])
-            x = allgather(x, d0, d1)
+            if scheme == "B":
+                # wo by columns: the local heads' outputs against this rank's columns of every row (main.zig:392);
+                # rank 0's partial carries the residual (:395)
+                part = orc.matmul(np.ascontiguousarray(xb_full[d0:d1]), np.ascontiguousarray(W["wo"][l][:, d0:d1]))
+                x = allreduce(x + part if rank == 0 else part)
+            else:
+                xb_full = allgather(xb_full, d0, d1)
+                x[d0:d1] = x[d0:d1] + orc.matmul(xb_full, W["wo"][l][d0:d1])
+                x = allgather(x, d0, d1)
             xb = orc.rmsnorm(x, W["rms_ffn_weight"][l])
             a = orc.matmul(xb, W["w1"][l][h0:h1])
             b = orc.matmul(xb, W["w3"][l][h0:h1])
             hb = np.zeros(cfg.hidden_dim, np.float32)
             one = np.float32(1.0)
             hb[h0:h1] = (a * (one / (one + np.exp(-a, dtype=np.float32)))) * b
-            hb = allgather(hb, h0, h1)
-            x[d0:d1] = x[d0:d1] + orc.matmul(hb, W["w2"][l][d0:d1])
-            x = allgather(x, d0, d1)
+            if scheme == "B":   # w2 by columns (:419), residual on rank 0 (:422)
+                part = orc.matmul(np.ascontiguousarray(hb[h0:h1]), np.ascontiguousarray(W["w2"][l][:, h0:h1]))
+                x = allreduce(x + part if rank == 0 else part)
+            else:
+                hb = allgather(hb, h0, h1)
+                x[d0:d1] = x[d0:d1] + orc.matmul(hb, W["w2"][l][d0:d1])
+                x = allgather(x, d0, d1)
         xf = orc.rmsnorm(x, W["rms_final_weight"])
         lg = np.zeros(cfg.vocab_size, np.float32)
         lg[v0:v1] = orc.matmul(xf, W["wcls"][v0:v1])
         logits_all.append(allgather(lg, v0, v1))
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.stack(logits_all))
+    np.save(os.path.join(out_dir, f"ncoll{rank}.npy"), np.array(n_coll))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -127,6 +155,27 @@ def test_sharded_schedule_is_bit_identical(world, tmp_path, ck, orc):
         np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5)
         assert got.argmax(1).tolist() == ref.argmax(1).tolist()
         assert np.array_equal(got, np.load(tmp_path / "rank0.npy"))  # all ranks agree bit for bit
+    m.close()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_scheme_b_schedule(world, tmp_path, ck, orc):
+    """Scheme B (L2Z_SCHEME_B; csrc/forward.cpp): Wo / W2 sharded by columns, 2 all-reduces per layer + the logits gather
+    instead of 4 all-gathers + it.  The row sums are split across ranks, so the logits hold the parity tolerance against
+    the oracle (not bit identity), the ranks agree with each other bit for bit, and a token costs 2L + 1 collectives."""
+    import torch.multiprocessing as mp
+
+    kw = _toy(world)
+    shared, seed, toks = False, 78, [1, 41, 299, 8, 10]
+    cfg = ck.Config(**kw)
+    mp.spawn(_worker, args=(world, _free_port(), kw, shared, seed, toks, str(tmp_path), "B"), nprocs=world, join=True)
+    m = orc.Model(cfg.as_i32(), ck.synth_blob(cfg, shared, seed), shared)
+    ref = np.stack([m.transformer(t, p) for p, t in enumerate(toks)])
+    for r in range(world):
+        got = np.load(tmp_path / f"rank{r}.npy")
+        np.testing.assert_allclose(got, ref, rtol=5e-5, atol=5e-5)
+        assert np.array_equal(got, np.load(tmp_path / "rank0.npy"))
+        assert int(np.load(tmp_path / f"ncoll{r}.npy")[0]) == len(toks) * (2 * cfg.n_layers + 1)
     m.close()
 
 
