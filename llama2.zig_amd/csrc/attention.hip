@@ -312,12 +312,27 @@ __device__ __forceinline__ void combine_chunks(const float *p, int nch, int hs, 
 // 256-timestep chunk -- K rows and V rows -- in flight in ONE round trip; with 256 threads the same
 // chunk took four dependent rounds of K loads and four of V (measured 21 us per layer at pos 2047
 // for 67 MB: latency-, not bandwidth-bound).
+#ifdef L2Z_TIMELINE
+// measurement build (scripts/timeline_build.sh): wall-clock stamps of every block of the split kernel, kept in registers
+// and stored at the block's end.  Per (launch, block): [0] entry, [1] K / V loads issued, [2] scores in LDS, [3] weights in
+// LDS, [4] partial reduced, [5] partial drained + arrival counted, [6] combined (the last arriver only), [7] 1 + last
+constexpr int kAtlMax = 512, kAtlBlocks = 512;
+__device__ long long g_atl[kAtlMax * kAtlBlocks * 8];
+#define L2Z_ATL(i) tl[i] = wall_clock64()
+#else
+#define L2Z_ATL(i) do { } while (0)
+#endif
+
 template <int NT>
 __global__ __launch_bounds__(NT) void attention_split_kernel(const AttnArgs a, int nch,
                                                              float *__restrict__ part_out,
                                                              int *__restrict__ arrivals)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef L2Z_TIMELINE
+    long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    L2Z_ATL(0);
     const int hs = a.head_size;
     const AttnGeom ge = attn_geom(hs, true, NT);
     const int max_local = attn_split_per(a.seq_len, nch);
@@ -365,6 +380,7 @@ __global__ __launch_bounds__(NT) void attention_split_kernel(const AttnArgs a, i
             j = j < Tc ? j : Tc - 1;
             vr[i] = ldg_nt((const v4f *)(vbase + (size_t)j * stride) + cc);
         }
+        L2Z_ATL(1);
         const float div = sqrtf((float)hs);
         for (int j0 = g;;) {  // scores (:367-375), local index j <-> t = t_lo + j
 #pragma unroll
@@ -384,6 +400,7 @@ __global__ __launch_bounds__(NT) void attention_split_kernel(const AttnArgs a, i
             }
         }
         __syncthreads();
+        L2Z_ATL(2);
         // chunk-local max and sum of exponentials, redundantly per wave (identical in every wave)
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         for (int j = lane; j < Tc; j += kWave) m = fmaxf(m, sc[j]);
@@ -392,6 +409,7 @@ __global__ __launch_bounds__(NT) void attention_split_kernel(const AttnArgs a, i
         l = wave_sum(l);
         for (int j = wave * kWave + lane; j < Tc; j += NT) wt[j] = expf(sc[j] - m);  // unnormalised
         __syncthreads();
+        L2Z_ATL(3);
         v4f acc = zero;
         for (int j0 = g;;) {  // weighted V (:381-388), increasing t within the group
 #pragma unroll
@@ -416,6 +434,7 @@ __global__ __launch_bounds__(NT) void attention_split_kernel(const AttnArgs a, i
         __syncthreads();
         reduce_partials_wt(part, ge.G, hs, po);
     }
+    L2Z_ATL(4);
     if (threadIdx.x == 0) {
         __hip_atomic_store(po + hs, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(po + hs + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -433,10 +452,27 @@ __global__ __launch_bounds__(NT) void attention_split_kernel(const AttnArgs a, i
         *flag = last;
     }
     __syncthreads();
+    L2Z_ATL(5);
+#ifdef L2Z_TIMELINE
+    const bool tl_last = *flag != 0;
+    if (tl_last)
+#else
     if (!*flag) return;
+#endif
     combine_chunks(part_out + (size_t)h * nch * (size_t)(hs + 4), nch, hs, a.xb + (size_t)h * hs, a.push,
                    a.push ? a.push_ctl[kCtlEpoch] + a.push_gi : 0,
                    a.push ? (size_t)a.push->rank * a.push->count + (size_t)h * hs : 0);
+#ifdef L2Z_TIMELINE
+    if (tl_last) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        L2Z_ATL(6);
+    }
+    tl[7] = 1 + (tl_last ? 1 : 0);
+    if (threadIdx.x == 0 && (unsigned)a.tl_seq < (unsigned)kAtlMax && blockIdx.x < kAtlBlocks) {
+        long long *o = g_atl + ((size_t)a.tl_seq * kAtlBlocks + blockIdx.x) * 8;
+        for (int i = 0; i < 8; i++) o[i] = tl[i];
+    }
+#endif
 }
 
 // Generic path: any head_size / alignment.
@@ -655,3 +691,12 @@ hipError_t launch_weighted_sum_rows(float *xout, int xout_len, const float *rows
 
 
 }  // namespace l2z
+
+#ifdef L2Z_TIMELINE
+extern "C" int l2z_attn_timeline_dump(long long *out, int max_launches)
+{
+    const int n = max_launches < l2z::kAtlMax ? max_launches : l2z::kAtlMax;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(l2z::g_atl), (size_t)n * l2z::kAtlBlocks * 8 * sizeof(long long)) != hipSuccess) return 1;
+    return 0;
+}
+#endif

@@ -254,6 +254,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.q = s->q; a.kcache = kc; a.vcache = vc; a.xb = s->xb + sh.dim0;
             a.pos_ptr = s->d_pos; a.head_size = sh.hs; a.kv_row = sh.hs; a.kv_head = kvh_stride;
             a.kv_mul = c.n_heads / c.n_kv_heads; a.seq_len = c.seq_len;
+            a.tl_seq = s->tl_attn_seq++;
             if (!sb && can_push && attention_push_supported(a)) {
                 a.push = s->d_push + 0;
                 a.push_ctl = ctl;

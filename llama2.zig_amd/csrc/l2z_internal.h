@@ -178,6 +178,7 @@ struct AttnArgs {
     const P2pArgs *push;   // as in MatvecArgs, for xb (fast / split-combine kernels); may be null
     const int *push_ctl;
     int push_gi;
+    int tl_seq;            // attention launch number since the runstate was made (measurement builds only: L2Z_TIMELINE)
 };
 
 

@@ -140,6 +140,7 @@ struct l2z_runstate {
     l2z::EngChunk *d_eng = nullptr;   // [n_layers + 1]
     uint64_t eng_w_uid = 0;
     int tl_seq = 0;                // mat-vec launches enqueued so far (MatvecArgs::tl_seq, measurement builds)
+    int tl_attn_seq = 0;           // attention launches enqueued so far (AttnArgs::tl_seq, measurement builds)
 };
 
 namespace l2z {

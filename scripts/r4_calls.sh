@@ -211,4 +211,25 @@ for ln in open("gpurun_out/r04_bench_4ranks_1gpu.json"):
             print(l["transport"], l.get("scheme"), l["ok"], l.get("tokens_per_s"), l.get("why"), l.get("runstate_form"), l.get("wall_s"), l.get("us_per_gather"))
 PY
 ;;
+v)
+# round 4, GPU call V: the split attention kernel at pos 2047 (and 1023, 4095-equivalents) by its blocks' own clocks
+for pos in 2047 1023 511; do
+L2Z_LIB=$PWD/llama2.zig_amd/libllama2_hip_tl.so L2Z_NO_GRAPH=1 timeout 300 python scripts/attn_timeline.py llama2-7b $pos 4
+done > $O/r04_attn_timeline.md 2>&1
+cat $O/r04_attn_timeline.md
+;;
+w)
+# round 4, GPU call W: synchronisation and streaming inside ONE XCD (scripts/xcd_local_probe.hip)
+hipcc --offload-arch=gfx950 -O3 -o /tmp/xcd_local_probe scripts/xcd_local_probe.hip && timeout 120 /tmp/xcd_local_probe > $O/r04_xcd_local_probe.txt 2>&1
+cat $O/r04_xcd_local_probe.txt
+;;
+x)
+# round 4, GPU call X: the split attention kernel after the change of row ownership (pieces dealt to the chunks, rows below the
+# form's first position requested before pos has arrived) and the one-round-trip combine: parity tests, then the timeline
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m gpu -q -x -k "attention or attn or split or sharded_hip or long" 2>&1 | tail -5
+for pos in 2047 1023 511 300; do
+L2Z_LIB=$PWD/llama2.zig_amd/libllama2_hip_tl.so L2Z_NO_GRAPH=1 timeout 300 python scripts/attn_timeline.py llama2-7b $pos 4
+done > $O/r04_attn_timeline_2.md 2>&1
+cat $O/r04_attn_timeline_2.md
+;;
 esac
