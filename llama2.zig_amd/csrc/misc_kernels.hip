@@ -25,6 +25,32 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const ArgmaxArgs a)
                 bi = id;
             }
         }
+    } else if ((a.vocab & 3) == 0 && ((unsigned long long)a.logits & 15ull) == 0) {
+        // the whole vocabulary in flight at once where it fits (32000 logits = 8 x 16 bytes per thread): the scan of a
+        // gathered logits vector -- every sharded token -- took 11 us as 32 dependent rounds of 4-byte loads
+        constexpr int kU = 8;
+        const int n4 = a.vocab >> 2;
+        for (int base = tid; base < n4; base += kU * (int)blockDim.x) {
+            v4f r[kU];
+#pragma unroll
+            for (int k = 0; k < kU; k++) {
+                const int j = base + k * (int)blockDim.x;
+                r[k] = ((const v4f *)a.logits)[j < n4 ? j : base];
+            }
+#pragma unroll
+            for (int k = 0; k < kU; k++) {  // increasing index inside a thread: strict '>' keeps the lowest (:720)
+                const int j = base + k * (int)blockDim.x;
+                if (j < n4) {
+                    const float e[4] = {r[k].x, r[k].y, r[k].z, r[k].w};
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (e[q] > best || bi == 0x7fffffff) {
+                            best = e[q];
+                            bi = 4 * j + q;
+                        }
+                }
+            }
+        }
     } else {
         for (int i = tid; i < a.vocab; i += blockDim.x) {
             const float v = a.logits[i];

@@ -232,4 +232,20 @@ L2Z_LIB=$PWD/llama2.zig_amd/libllama2_hip_tl.so L2Z_NO_GRAPH=1 timeout 300 pytho
 done > $O/r04_attn_timeline_2.md 2>&1
 cat $O/r04_attn_timeline_2.md
 ;;
+y)
+# round 4, GPU call Y: regression sweep of every fuzzer on the round's tree (scheme B included), fresh seeds
+S=${SEED:-61}; F=${OUT:-r04_fuzz.txt}
+{
+echo "== fuzz_shapes 80 (seed $S)"; timeout 600 python scripts/fuzz_shapes.py 80 $S | grep -v "^ok " | tail -n 8
+echo "== fuzz_shapes wide 20 (seed $((S+1)))"; timeout 600 python scripts/fuzz_shapes.py 20 $((S+1)) wide | grep -v "^ok " | tail -n 8
+echo "== fuzz_shards 80 (seed $S)"; timeout 600 python scripts/fuzz_shards.py 80 $S | grep -v "^ok " | tail -n 8
+echo "== fuzz_shards scheme B 80 (seed $((S+2)))"; timeout 600 python scripts/fuzz_shards.py 80 $((S+2)) b | grep -v "^ok " | tail -n 8
+echo "== fuzz_prefill 160 (seed $S)"; timeout 900 python scripts/fuzz_prefill.py 160 $S | grep -v "^ok " | tail -n 12
+echo "== fuzz_greedy 120 (seed $S)"; timeout 600 python scripts/fuzz_greedy.py 120 $S | grep -v "^ok " | tail -n 8
+echo "== fuzz_hooks 120 (seed $S)"; timeout 600 python scripts/fuzz_hooks.py 120 $S | grep -v "^ok " | tail -n 8
+echo "== fuzz_longctx 6 (seed $S)"; timeout 600 python scripts/fuzz_longctx.py 6 $S | grep -v "^ok " | tail -n 8
+echo "== fuzz_p2p 16 (seed $S)"; timeout 900 python scripts/fuzz_p2p.py 16 $S | grep -v "^ok " | tail -n 8
+} > $O/$F 2>&1
+cat $O/$F
+;;
 esac

@@ -42,6 +42,14 @@ def test_random_shapes_and_world_sizes_sharded_bit_identical(gpu):
     assert bad == 0, "\n".join(l for l in lines if not l.startswith("ok "))
 
 
+def test_fuzz_scheme_b_ranks_agree_and_hold_the_tolerance(gpu):
+    """The same random shapes x world sizes under L2Z_SCHEME_B (Wo / W2 by columns, all-reduces): the emulated ranks equal
+    each other bit for bit and the unsharded pass within the parity tolerance (scripts/fuzz_shards.py ... b)."""
+    lines = []
+    bad = _fuzz("fuzz_shards").run(16, 20260928, lines.append, scheme_b=True)
+    assert bad == 0, "\n".join(l for l in lines if not l.startswith("ok "))
+
+
 def test_fuzz_prefill_vs_stepped_and_sharded_vs_unsharded(gpu):
     """Random shapes x prompt lengths (1 .. 530 tokens: every GEMM form and both attention kernels) x
     world sizes: the batched prefill against the stepped loop (logit tolerance), and the row-sharded
