@@ -10,8 +10,11 @@
  * own known-answer tests (src/main.zig:1078-1150, see tests/golden/).  The
  * whole-pass function orc_transformer() is "parity unpinned": the reference
  * holds no golden vector for transformer(), there is no Zig 0.16 compiler and
- * no checkpoint in this image, so it can only be checked against an
- * independent float64 numpy restatement (tests/test_oracle_cpu.py).
+ * no checkpoint in this image, so it can only be checked against independent
+ * implementations of the same architecture: a float64 numpy restatement
+ * (tests/test_oracle_cpu.py) and Hugging Face's LlamaForCausalLM on the same
+ * seeded checkpoint (tests/test_oracle_vs_hf.py: logits equal to <= 1e-5 at
+ * every position) -- neither of which is the Zig binary.
  *
  * Every function cites the reference lines (src/main.zig) it restates.
  * The reference's arithmetic depends on the host through
