@@ -335,6 +335,59 @@ def test_weights_read_serves_file_order_across_the_interleaved_slot(gpu, ck):
         w.close()
 
 
+# ---------------------------------------------------------------- an implementation that is not ours
+HF_CONFIGS = [
+    ("gqa-toy", dict(TOY), False, 32),
+    ("stories15M-shape", dict(dim=288, hidden_dim=768, n_layers=6, n_heads=6, n_kv_heads=6, vocab_size=32000, seq_len=256), True, 64),
+    ("gqa-head-128", dict(dim=512, hidden_dim=1408, n_layers=2, n_heads=4, n_kv_heads=2, vocab_size=1024, seq_len=320), False, 300),
+]
+
+
+@pytest.mark.parametrize("name,kw,shared,n_pos", HF_CONFIGS, ids=[c[0] for c in HF_CONFIGS])
+def test_gpu_logits_agree_with_hf_llama(gpu, ck, name, kw, shared, n_pos):
+    """The HIP pass against Hugging Face's LlamaForCausalLM (CPU, fp32) holding the same seeded checkpoint -- an
+    implementation of the reference's architecture that shares no code or author with the oracle
+    (tests/test_oracle_vs_hf.py checks the oracle against it): logits at every position, stepped on the GPU (its KV
+    cache, the attention forms by position up to the split form at pos >= 256), one causal pass in HF."""
+    pytest.importorskip("transformers")
+    import hf_llama
+    cfg = ck.Config(**kw)
+    blob = ck.synth_blob(cfg, shared, seed=4243)
+    m = hf_llama.build(ck, cfg, blob, shared)
+    rng = np.random.default_rng(4)
+    toks = [1] + rng.integers(0, cfg.vocab_size, n_pos - 1).tolist()
+    hf = hf_llama.logits(m, toks)
+    w, s = gpu.Weights(cfg, blob, shared), gpu.RunState(cfg)
+    worst = 0.0
+    for pos, tok in enumerate(toks):
+        s.transformer(tok, pos, w)
+        got = s.logits()
+        np.testing.assert_allclose(got, hf[pos], rtol=LOGIT_RTOL, atol=LOGIT_ATOL, err_msg=f"{name} pos {pos}")
+        worst = max(worst, float(np.abs(got - hf[pos]).max()))
+    print(f"GPU vs HF LlamaForCausalLM {name}: max |logit diff| over {n_pos} positions {worst:.2e}")
+    s.close(); w.close()
+
+
+def test_gpu_prefill_agrees_with_hf_llama(gpu, ck):
+    """The batched prompt pass (MFMA GEMMs, prefill attention) against the same HF model: its logits after a 300-token
+    prompt and the KV cache it leaves -- checked through the next stepped token -- against HF's causal pass."""
+    pytest.importorskip("transformers")
+    import hf_llama
+    name, kw, shared, n_pos = HF_CONFIGS[2]
+    cfg = ck.Config(**kw)
+    blob = ck.synth_blob(cfg, shared, seed=4243)
+    m = hf_llama.build(ck, cfg, blob, shared)
+    toks = [1] + np.random.default_rng(4).integers(0, cfg.vocab_size, n_pos).tolist()
+    hf = hf_llama.logits(m, toks)
+    w, s = gpu.Weights(cfg, blob, shared), gpu.RunState(cfg)
+    s.prefill(toks[:n_pos], 0, w)
+    np.testing.assert_allclose(s.logits(), hf[n_pos - 1], rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
+    s.transformer(toks[n_pos], n_pos, w)   # reads every KV row the batched pass wrote
+    np.testing.assert_allclose(s.logits(), hf[n_pos], rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
+    print(f"GPU prefill vs HF: max |logit diff| {np.abs(s.logits() - hf[n_pos]).max():.2e}")
+    s.close(); w.close()
+
+
 # ---------------------------------------------------------------- whole forward pass
 CONFIGS = [
     ("toy-gqa-unshared", dict(TOY), False),

@@ -20,50 +20,22 @@ CONFIGS = [
     ("mqa", dict(dim=96, hidden_dim=256, n_layers=2, n_heads=6, n_kv_heads=1, vocab_size=1000, seq_len=40), True),
     ("head-size-6", dict(dim=36, hidden_dim=100, n_layers=2, n_heads=6, n_kv_heads=3, vocab_size=97, seq_len=16), False),
     ("head-size-128", dict(dim=256, hidden_dim=704, n_layers=2, n_heads=2, n_kv_heads=1, vocab_size=320, seq_len=48), False),
+    # BASELINE configs 1-2 at full shape (6 layers, 32000-word vocabulary, shared classifier), 96 positions
+    ("stories15M-shape", dict(dim=288, hidden_dim=768, n_layers=6, n_heads=6, n_kv_heads=6, vocab_size=32000, seq_len=256), True),
 ]
-
-
-def _to_hf(w: np.ndarray, n_heads: int) -> np.ndarray:
-    """rows of one head in the reference's order (pairs (2i, 2i+1) rotate together) -> HF's (i with i + hs/2)"""
-    rows, cols = w.shape
-    hs = rows // n_heads
-    return w.reshape(n_heads, hs // 2, 2, cols).transpose(0, 2, 1, 3).reshape(rows, cols)
 
 
 @pytest.mark.parametrize("name,kw,shared", CONFIGS, ids=[c[0] for c in CONFIGS])
 def test_oracle_forward_pass_agrees_with_hf_llama(ck, orc, name, kw, shared):
-    torch = pytest.importorskip("torch")
-    tf = pytest.importorskip("transformers")
+    pytest.importorskip("torch")
+    pytest.importorskip("transformers")
+    import hf_llama
     cfg = ck.Config(**kw)
     blob = ck.synth_blob(cfg, shared, seed=4242)
-    W = ck.carve(cfg, blob, shared)
-    hf_cfg = tf.LlamaConfig(hidden_size=cfg.dim, intermediate_size=cfg.hidden_dim, num_hidden_layers=cfg.n_layers,
-                            num_attention_heads=cfg.n_heads, num_key_value_heads=cfg.n_kv_heads, vocab_size=cfg.vocab_size,
-                            max_position_embeddings=cfg.seq_len, rms_norm_eps=1e-5, rope_theta=10000.0, hidden_act="silu",
-                            tie_word_embeddings=bool(shared), attention_bias=False, mlp_bias=False,
-                            head_dim=cfg.dim // cfg.n_heads, attn_implementation="eager")
-    torch.manual_seed(0)
-    m = tf.LlamaForCausalLM(hf_cfg).eval().float()
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
-    sd = {"model.embed_tokens.weight": t(W["token_embedding_table"]), "model.norm.weight": t(W["rms_final_weight"]),
-          "lm_head.weight": t(W["token_embedding_table"] if shared else W["wcls"])}
-    for l in range(cfg.n_layers):
-        p = f"model.layers.{l}."
-        sd[p + "input_layernorm.weight"] = t(W["rms_att_weight"][l])
-        sd[p + "self_attn.q_proj.weight"] = t(_to_hf(W["wq"][l], cfg.n_heads))
-        sd[p + "self_attn.k_proj.weight"] = t(_to_hf(W["wk"][l], cfg.n_kv_heads))
-        sd[p + "self_attn.v_proj.weight"] = t(W["wv"][l])
-        sd[p + "self_attn.o_proj.weight"] = t(W["wo"][l])
-        sd[p + "post_attention_layernorm.weight"] = t(W["rms_ffn_weight"][l])
-        sd[p + "mlp.gate_proj.weight"] = t(W["w1"][l])
-        sd[p + "mlp.down_proj.weight"] = t(W["w2"][l])
-        sd[p + "mlp.up_proj.weight"] = t(W["w3"][l])
-    missing, unexpected = m.load_state_dict(sd, strict=False)
-    assert not unexpected and all("rotary" in k or "inv_freq" in k for k in missing), (missing, unexpected)
+    m = hf_llama.build(ck, cfg, blob, shared)
     rng = np.random.default_rng(3)
-    toks = [1] + rng.integers(0, cfg.vocab_size, cfg.seq_len - 1).tolist()
-    with torch.no_grad():
-        hf = m(torch.tensor([toks])).logits[0].numpy()
+    toks = [1] + rng.integers(0, cfg.vocab_size, min(cfg.seq_len, 96) - 1).tolist()
+    hf = hf_llama.logits(m, toks)
     om = orc.Model(cfg.as_i32(), blob, shared)
     worst = 0.0
     for pos, tok in enumerate(toks):
