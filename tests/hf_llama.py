@@ -48,3 +48,27 @@ def logits(m, toks) -> np.ndarray:
     import torch
     with torch.no_grad():
         return m(torch.tensor([list(toks)])).logits[0].numpy()
+
+
+def logits_in_subprocess(kw: dict, shared: bool, seed: int, toks) -> np.ndarray:
+    """The same, computed by a CHILD process: importing torch (its own HIP runtime and RCCL copies) into a process that
+    also drives libllama2_hip.so breaks that library's RCCL initialisation later on -- GPU tests keep torch out."""
+    import json, os, subprocess, sys, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        spec = os.path.join(d, "spec.json")
+        json.dump(dict(kw=kw, shared=bool(shared), seed=int(seed), toks=[int(t) for t in toks], out=os.path.join(d, "hf.npy")), open(spec, "w"))
+        env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        subprocess.run([sys.executable, os.path.abspath(__file__), spec], check=True, env=env, timeout=600)
+        return np.load(os.path.join(d, "hf.npy"))
+
+
+if __name__ == "__main__":
+    import json, os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import __graft_entry__ as ge
+    spec = json.load(open(sys.argv[1]))
+    ck = ge.load_package().checkpoint
+    cfg = ck.Config(**spec["kw"])
+    m = build(ck, cfg, ck.synth_blob(cfg, spec["shared"], spec["seed"]), spec["shared"])
+    np.save(spec["out"], logits(m, spec["toks"]))
+
