@@ -697,7 +697,14 @@ def leg_main(args) -> int:
     launches = by_kind["gather"][1] // n_prof
     bytes_tok = weight_bytes_per_token(cfg, world)
     ideal_ms = bytes_tok / (rd_avg * 1e9) * 1e3 if rd_avg else None
+    rccl_lib = None
+    if kind in RCCL_LEGS:
+        try:  # which librccl this process got: torch was imported first, so its bundled copy (and HIP runtime) serve the leg
+            rccl_lib = B.rccl_info()
+        except Exception as e:  # noqa: BLE001
+            rccl_lib = {"error": str(e)}
     leg = {"transport": kind, "scheme": "B" if scheme_b else "A", "ok": bool(agree), "why": None if agree else "ranks disagree",
+           "rccl_library": rccl_lib,
            "tokens_per_s": n_tok / dt, "ms_per_step": dt / n_tok * 1e3, "steps": n_tok, "ranks_agree": bool(agree),
            "gathers": n_g, "collectives": (f"{n_g - 1} all-reduces of [dim] + the logits all-gather" if scheme_b else
                                            f"{n_g} all-gathers"), "gather_launches_per_token": launches,

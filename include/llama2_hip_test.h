@@ -130,6 +130,10 @@ int l2z_emu_prefill(int n_ranks, l2z_runstate *const *ss, const l2z_weights *con
  * are connected. */
 int l2z_comm_transports(const l2z_comm *c, int *rccl_ranks, int *p2p_connected);
 
+/* Loads RCCL (dlopen) now and reports the file the process got and ncclGetVersion's code.  A process that imports
+ * PyTorch afterwards keeps THIS copy (same SONAME); one that imported it before gets torch's bundled copy. */
+int l2z_comm_rccl_info(char *path_out, size_t cap, int *version);
+
 /* The decode structure a runstate runs: bit 0 = paired mat-vec blocks (L2Z_DUO), bit 1 = two overlapped
  * chains (L2Z_OVERLAP), bit 2 = the persistent launches (L2Z_ENGINE), bit 3 = sharding scheme B (L2Z_SCHEME_B:
  * column-sharded Wo / W2 + all-reduces).  0 = the default chain.  An opt-in

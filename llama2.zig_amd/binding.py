@@ -109,6 +109,8 @@ def lib():
         L.l2z_comm_p2p_export_sized.argtypes = [vp, sz, sz, vp]
     L.l2z_comm_p2p_connect.argtypes = [vp, vp]
     L.l2z_comm_rank.argtypes = [vp, ip, ip]
+    if hasattr(L, "l2z_comm_rccl_info"):
+        L.l2z_comm_rccl_info.argtypes = [C.c_char_p, sz, ip]
     if hasattr(L, "l2z_runstate_form"):
         L.l2z_runstate_form.argtypes = [vp, ip]
     if hasattr(L, "l2z_comm_transports"):  # an older build loaded through L2Z_LIB (A/B runs) lacks the newer entry points
@@ -461,6 +463,13 @@ def attention_decode(q, kcache, vcache, pos: int, n_heads: int, n_kv_heads: int,
     _chk(lib().l2z_attention_decode(ATTN_FORMS[form], nch, _fp(out), _fp(q), _fp(kcache), _fp(vcache),
                                     pos, n_heads, n_kv_heads, head_size, seq_len))
     return out
+
+
+def rccl_info() -> dict:
+    """Loads RCCL now; {'path': the file the process got, 'version': ncclGetVersion's code}."""
+    buf, v = C.create_string_buffer(512), C.c_int(0)
+    _chk(lib().l2z_comm_rccl_info(buf, 512, C.byref(v)))
+    return {"path": buf.value.decode(errors="replace"), "version": v.value}
 
 
 def option_set(name: str, value: int) -> None:

@@ -27,6 +27,7 @@ struct RcclApi {
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
                               hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
 };
 
 RcclApi g_api;
@@ -51,6 +52,7 @@ int load_rccl()
     SYM(AllGather, "ncclAllGather");
     SYM(AllReduce, "ncclAllReduce");
     SYM(GetErrorString, "ncclGetErrorString");
+    SYM(GetVersion, "ncclGetVersion");
 #undef SYM
     g_api.handle = h;
     return L2Z_OK;
@@ -359,6 +361,25 @@ extern "C" int l2z_comm_rank(const l2z_comm *c, int *rank, int *world)
     L2Z_CHECK(c != nullptr, L2Z_ERR_INVALID, "l2z_comm_rank: null comm");
     if (rank) *rank = c->rank;
     if (world) *world = c->world;
+    return L2Z_OK;
+}
+
+// Loads RCCL now (l2z_comm_init would on first use) and says WHICH library the process got: a process that has imported
+// PyTorch holds torch's own bundled copies of librccl / libamdhip64, and a dlopen by SONAME then resolves to whichever
+// copy was loaded first.  Callers that mix the two (bench.py's legs use torch's gloo for their control plane) call this
+// before importing torch, so that the collective library and the HIP runtime under it are the ones this library was
+// built against, and put the answer in their record.
+extern "C" int l2z_comm_rccl_info(char *path_out, size_t cap, int *version)
+{
+    L2Z_TRY(load_rccl());
+    if (version) {
+        *version = 0;
+        (void)g_api.GetVersion(version);
+    }
+    if (path_out && cap) {
+        Dl_info info;
+        snprintf(path_out, cap, "%s", dladdr(reinterpret_cast<void *>(g_api.AllGather), &info) && info.dli_fname ? info.dli_fname : "?");
+    }
     return L2Z_OK;
 }
 

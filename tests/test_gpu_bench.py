@@ -41,3 +41,24 @@ def test_bench_line_has_the_contract_fields(gpu):
     by_shape = out["extra"]["cpu_baseline_by_shape"]
     assert set(by_shape) == {"stories15M", "stories110M"} and all(v["value"] > 0 and v["cores"] == 1 for v in by_shape.values())
     assert out["extra"]["stories15M_tokens_per_s"] > 0 and out["extra"]["prefill"]["roofline"]["bound"] == "mfma"
+
+
+def test_rccl_leg_runs_with_one_rank(gpu):
+    """The RCCL leg of `bench.py --gpus N` as the driver would start it, with ONE rank (RCCL refuses two ranks on one
+    device): torch imported first (gloo control plane), then this library and its dlopen of RCCL -- the order the legs
+    use -- ncclCommInitRank, captured ncclAllGather per vector, the leg's record.  L2Z_BENCH_FORCE_DIST=1 makes the
+    single-GPU invocation take the multi-rank path."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, L2Z_BENCH_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "stories110M", "--steps", "16",
+                        "--warmup", "1", "--no-extra"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, p.stdout.decode()[-2000:] + p.stderr.decode()[-2000:]
+    out = json.loads(lines[0])
+    leg = out["comm"]["legs"][0]
+    assert leg["transport"] == "rccl" and leg["ok"] and leg["rccl_ranks"] == [1], leg
+    assert leg["rccl_library"]["version"] > 20000 and "rccl" in leg["rccl_library"]["path"], leg["rccl_library"]
+    assert out["comm"]["rccl"]["initialised"] and out["value"] > 0
+    print("RCCL library of the leg:", leg["rccl_library"])
