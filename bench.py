@@ -757,8 +757,8 @@ def multi_main(args) -> None:
     want = os.environ.get("L2Z_COMM", "")
     order = {"": LEGS, "p2p": ["p2p-gather", "p2p-consume", "p2p-engine", "p2p-allreduce"], "rccl": ["rccl", "rccl-allreduce"],
              **{k: [k] for k in LEGS if k != "rccl"}}[want]
-    if os.environ.get("L2Z_BENCH_FORCE_DIST") == "1":  # 1-rank RCCL + gloo, for testing
-        order = ["rccl"]
+    if os.environ.get("L2Z_BENCH_FORCE_DIST") == "1":  # 1-rank RCCL + gloo, for testing (L2Z_COMM picks the RCCL leg)
+        order = [want] if want in RCCL_LEGS else ["rccl"]
     leg_timeout = float(os.environ.get("L2Z_BENCH_LEG_TIMEOUT_S", "150"))
     legs, lines = [], {}
     for kind in order:

@@ -43,14 +43,15 @@ def test_bench_line_has_the_contract_fields(gpu):
     assert out["extra"]["stories15M_tokens_per_s"] > 0 and out["extra"]["prefill"]["roofline"]["bound"] == "mfma"
 
 
-def test_rccl_leg_runs_with_one_rank(gpu):
+@pytest.mark.parametrize("leg_name", ["rccl", "rccl-allreduce"])
+def test_rccl_leg_runs_with_one_rank(gpu, leg_name):
     """The RCCL leg of `bench.py --gpus N` as the driver would start it, with ONE rank (RCCL refuses two ranks on one
     device): torch imported first (gloo control plane), then this library and its dlopen of RCCL -- the order the legs
-    use -- ncclCommInitRank, captured ncclAllGather per vector, the leg's record.  L2Z_BENCH_FORCE_DIST=1 makes the
+    use -- ncclCommInitRank, captured ncclAllGather per vector (scheme B: ncclAllReduce of the partial vectors), the leg's record.  L2Z_BENCH_FORCE_DIST=1 makes the
     single-GPU invocation take the multi-rank path."""
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, L2Z_BENCH_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+    env = dict(os.environ, L2Z_BENCH_FORCE_DIST="1", L2Z_COMM=leg_name, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(port))
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "stories110M", "--steps", "16",
                         "--warmup", "1", "--no-extra"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
@@ -58,7 +59,8 @@ def test_rccl_leg_runs_with_one_rank(gpu):
     assert p.returncode == 0 and len(lines) == 1, p.stdout.decode()[-2000:] + p.stderr.decode()[-2000:]
     out = json.loads(lines[0])
     leg = out["comm"]["legs"][0]
-    assert leg["transport"] == "rccl" and leg["ok"] and leg["rccl_ranks"] == [1], leg
+    assert leg["transport"] == leg_name and leg["ok"] and leg["rccl_ranks"] == [1], leg
+    assert leg["scheme"] == ("B" if leg_name == "rccl-allreduce" else "A") and bool(leg["runstate_form"] & 8) == (leg["scheme"] == "B")
     assert leg["rccl_library"]["version"] > 20000 and "rccl" in leg["rccl_library"]["path"], leg["rccl_library"]
-    assert out["comm"]["rccl"]["initialised"] and out["value"] > 0
+    assert out["value"] > 0 and (leg_name != "rccl" or out["comm"]["rccl"]["initialised"])
     print("RCCL library of the leg:", leg["rccl_library"])
