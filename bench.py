@@ -344,6 +344,59 @@ def scaling_model(B, cfg, shared, seed, pos: int, worlds=(2, 4, 8)) -> dict:
     return out
 
 
+SOLO_FORMS = [("p2p-consume", {}), ("p2p-gather", {"L2Z_P2P_CONSUME": 0}), ("p2p-engine", {"L2Z_ENGINE": 1}),
+              ("p2p-allreduce", {"L2Z_SCHEME_B": 1})]
+
+
+def solo_rank_model(B, cfg, shared, seed, steps: int = 64, worlds=(2, 4, 8)) -> dict:
+    """What scaling_model's per-kind sums leave out: ONE rank of an N-rank group alone on this GPU running its WHOLE
+    sharded pass -- graph replay, every launch, the pushes of its outputs as LL words, the consumer-side polls, the
+    gather / reduce launches -- with free hand-overs (l2z_comm_p2p_connect_solo: every peer arena is the rank's own and
+    the zeroed landing slots satisfy every wait).  tokens/s of that rank = an upper bound on tokens/s at N GPUs for
+    each leg's structure; hand-over latency, rank skew and xGMI are still not in it (and its N stores per pushed word
+    land on one local address instead of N devices)."""
+    reset = {"L2Z_P2P_CONSUME": 1, "L2Z_ENGINE": 0, "L2Z_SCHEME_B": 0}
+    out = {}
+    for world in worlds:
+        if cfg.n_heads % world or cfg.n_kv_heads % world or cfg.hidden_dim % world or cfg.vocab_size % world:
+            continue
+        row = {}
+        for leg, opts in SOLO_FORMS:
+            comm = w = s = None
+            try:
+                for k, v in opts.items():
+                    B.option_set(k, v)
+                comm = B.Comm(0, world, None, 0)
+                comm.p2p_export(max(cfg.dim, cfg.hidden_dim, cfg.vocab_size, world * cfg.dim), max(cfg.dim, cfg.hidden_dim))
+                comm.p2p_connect_solo()
+                w = B.Weights(cfg, None, shared, seed=seed, comm=comm)
+                s = B.RunState(cfg, comm=comm)
+                form = s.form()
+                if (form & 12) != (4 if "L2Z_ENGINE" in opts else 8 if "L2Z_SCHEME_B" in opts else 0):
+                    row[leg] = {"refused": f"runstate form {form}"}
+                    continue
+                s.greedy_begin([]); s.greedy_run(w, 4); s.synchronize()
+                best = 0.0
+                for _ in range(2):
+                    s.greedy_begin([]); s.greedy_run(w, 2); s.synchronize()
+                    t0 = time.perf_counter()
+                    n = len(s.greedy_run(w, steps))
+                    s.synchronize()
+                    best = max(best, n / (time.perf_counter() - t0))
+                row[leg] = {"tokens_per_s_upper_bound": best}
+            except Exception as e:  # noqa: BLE001
+                row[leg] = {"error": str(e)}
+            finally:
+                for k in opts:
+                    B.option_set(k, reset[k])
+                for o in (s, w, comm):
+                    if o is not None:
+                        o.close()
+        out[str(world)] = row
+    out["note"] = ("rank 0 of N alone on ONE GPU, whole pass, hand-overs free: upper bounds per leg structure, not measurements of N GPUs")
+    return out
+
+
 def single_gpu(args) -> None:
     pkg = ge.load_package()
     B, ck = pkg.binding, pkg.checkpoint
@@ -472,6 +525,10 @@ def single_gpu(args) -> None:
                 sm = scaling_model(B, cfg, shared, args.seed, 8)
             except Exception as e:  # noqa: BLE001
                 sm = {"error": str(e)}
+            try:
+                sm["solo_rank"] = solo_rank_model(B, cfg, shared, args.seed)
+            except Exception as e:  # noqa: BLE001
+                sm["solo_rank"] = {"error": str(e)}
         out["extra"] = {"prefill": prefill, "repeats": repeats, "scaling_model": sm,
                         "stories110M": {"tokens_per_s": n110 / dt110, "steps": n110,
                                         "weight_bytes_per_token": bytes110,

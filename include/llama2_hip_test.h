@@ -130,6 +130,12 @@ int l2z_emu_prefill(int n_ranks, l2z_runstate *const *ss, const l2z_weights *con
  * are connected. */
 int l2z_comm_transports(const l2z_comm *c, int *rccl_ranks, int *p2p_connected);
 
+/* Measurement: after l2z_comm_p2p_export, connect this rank ALONE -- every peer's arena is its own, every hand-over's
+ * wait is satisfied by the zeroed slots -- so that ONE rank of an N-rank group runs its whole sharded pass (launches,
+ * pushes, polls, gather / reduce launches) on a GPU by itself: the per-rank time with free hand-overs.  Results are
+ * meaningless (the peers' slices read as zeros). */
+int l2z_comm_p2p_connect_solo(l2z_comm *c);
+
 /* Loads RCCL (dlopen) now and reports the file the process got and ncclGetVersion's code.  A process that imports
  * PyTorch afterwards keeps THIS copy (same SONAME); one that imported it before gets torch's bundled copy. */
 int l2z_comm_rccl_info(char *path_out, size_t cap, int *version);

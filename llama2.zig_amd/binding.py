@@ -109,6 +109,8 @@ def lib():
         L.l2z_comm_p2p_export_sized.argtypes = [vp, sz, sz, vp]
     L.l2z_comm_p2p_connect.argtypes = [vp, vp]
     L.l2z_comm_rank.argtypes = [vp, ip, ip]
+    if hasattr(L, "l2z_comm_p2p_connect_solo"):
+        L.l2z_comm_p2p_connect_solo.argtypes = [vp]
     if hasattr(L, "l2z_comm_rccl_info"):
         L.l2z_comm_rccl_info.argtypes = [C.c_char_p, sz, ip]
     if hasattr(L, "l2z_runstate_form"):
@@ -198,6 +200,10 @@ class Comm:
         assert len(handles) == COMM_IPC_BYTES * self.world
         buf = C.create_string_buffer(handles, len(handles))
         _chk(lib().l2z_comm_p2p_connect(self.h, buf))
+
+    def p2p_connect_solo(self) -> None:
+        """Measurement: this rank alone, every peer's arena its own, no wait ever blocks (l2z_comm_p2p_connect_solo)."""
+        _chk(lib().l2z_comm_p2p_connect_solo(self.h))
 
     def transports(self) -> dict:
         """{"rccl_ranks": ranks RCCL reports for the communicator (0: none), "p2p": arenas connected}"""

@@ -90,7 +90,7 @@ LLIn comm_ll_in(const l2z_comm *c, int gi, size_t count_per_rank)
     in.slots = reinterpret_cast<const unsigned long long *>(c->arena + kP2pFlagBytes);
     in.slot_floats = (unsigned)c->slot_floats;
     in.count = (unsigned)count_per_rank;
-    in.gi = gi;
+    in.gi = comm_gi(c, gi);
     in.ctl = c->d_ctl;
     in.h_err = c->h_err;
     in.timeout_ticks = tunables().p2p_timeout_s * 100000000LL;
@@ -148,7 +148,8 @@ int comm_allgather_inplace(const l2z_comm *c, float *buf, size_t count_per_rank,
                   count_per_rank * (size_t)c->world, c->slot_floats);
         P2pArgs a = {};
         comm_p2p_args(c, buf, count_per_rank, false, &a);
-        hipError_t e = launch_p2p_allgather(a, gi, n_gathers, pushed, st);
+        // (solo: index 0 and no pass-closing advance of the epoch counter)
+        hipError_t e = c->solo ? launch_p2p_allgather(a, 0, -1, pushed, st) : launch_p2p_allgather(a, gi, n_gathers, pushed, st);
         L2Z_CHECK(e == hipSuccess, L2Z_ERR_HIP, "peer-write gather launch failed: %s", hipGetErrorString(e));
         return L2Z_OK;
     }
@@ -168,7 +169,7 @@ int comm_allreduce(const l2z_comm *c, const float *part, float *out, size_t coun
                   "peer-write all-reduce of %d x %zu floats exceeds the landing slot (%zu)", c->world, count, c->slot_floats);
         P2pArgs a = {};
         comm_p2p_args(c, const_cast<float *>(part), count, false, &a);
-        hipError_t e = launch_p2p_allreduce(a, out, gi, pushed, st);
+        hipError_t e = launch_p2p_allreduce(a, out, comm_gi(c, gi), pushed, st);
         L2Z_CHECK(e == hipSuccess, L2Z_ERR_HIP, "peer-write all-reduce launch failed: %s", hipGetErrorString(e));
         return L2Z_OK;
     }
@@ -356,6 +357,17 @@ extern "C" int l2z_comm_p2p_connect(l2z_comm *c, const void *handles)
     return L2Z_OK;
 }
 
+// Measurement support (llama2_hip_test.h): this rank ALONE, every peer's arena mapped to its own -- see l2z_comm::solo.
+extern "C" int l2z_comm_p2p_connect_solo(l2z_comm *c)
+{
+    L2Z_CHECK(c != nullptr, L2Z_ERR_INVALID, "l2z_comm_p2p_connect_solo: null comm");
+    L2Z_CHECK(c->arena != nullptr && !c->p2p, L2Z_ERR_STATE, "l2z_comm_p2p_connect_solo: call l2z_comm_p2p_export first (once)");
+    for (int r = 0; r < c->world; r++) c->peer_arena[r] = c->arena;
+    c->p2p = true;
+    c->solo = true;
+    return L2Z_OK;
+}
+
 extern "C" int l2z_comm_rank(const l2z_comm *c, int *rank, int *world)
 {
     L2Z_CHECK(c != nullptr, L2Z_ERR_INVALID, "l2z_comm_rank: null comm");
@@ -402,7 +414,7 @@ extern "C" void l2z_comm_free(l2z_comm *c)
 {
     if (!c) return;
     for (int r = 0; r < c->world && r < kMaxWorld; r++)
-        if (r != c->rank && c->peer_arena[r]) (void)hipIpcCloseMemHandle(c->peer_arena[r]);
+        if (r != c->rank && c->peer_arena[r] && c->peer_arena[r] != c->arena) (void)hipIpcCloseMemHandle(c->peer_arena[r]);
     if (c->arena) (void)hipFree(c->arena);
     if (c->d_ctl) (void)hipFree(c->d_ctl);
     if (c->h_err) (void)hipHostFree(c->h_err);

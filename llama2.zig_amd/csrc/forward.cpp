@@ -204,7 +204,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         if (!can_push) return;
         a.push = s->d_push + which;
         a.push_ctl = ctl;
-        a.push_gi = gi + 1;
+        a.push_gi = comm_gi(lc, gi + 1);
     };
     // a column-shard mat-vec of scheme B: the local slice x_loc (n_pad floats, zero beyond the slice) against this rank's
     // columns of all `dim` rows -> s->part; rank 0 adds the residual
@@ -258,7 +258,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             if (!sb && can_push && attention_push_supported(a)) {
                 a.push = s->d_push + 0;
                 a.push_ctl = ctl;
-                a.push_gi = gi + 1;
+                a.push_gi = comm_gi(lc, gi + 1);
                 pushed = true;
                 hint.h0 = (unsigned)(sh.hs - 1); hint.n = (unsigned)sh.heads_loc; hint.stride = (unsigned)sh.hs;  // a head's last element
             }
@@ -397,7 +397,7 @@ static int engine_prepare(l2z_runstate *s, const l2z_weights *w)
             a.xin.hint0 = (unsigned)base + h.h0; a.xin.hint_n = h.n; a.xin.hint_stride = h.stride; a.xin.hint_sleep = tn.overlap_hint_sleep;
         }
     };
-    auto push = [&](MatvecArgs &a, int which, int g) { a.push = s->d_push + which; a.push_ctl = lc->d_ctl; a.push_gi = g; };
+    auto push = [&](MatvecArgs &a, int which, int g) { a.push = s->d_push + which; a.push_ctl = lc->d_ctl; a.push_gi = comm_gi(lc, g); };
     const Hint h_dim = mv_hint((sh.dim_loc + 1) / 2, vgrid, EPI_RESID), h_hid = mv_hint(sh.hid_loc, vgrid, EPI_SWIGLU);
     Hint h_attn;   // the attention launch's outputs: a head's last element, this rank's heads
     h_attn.h0 = (unsigned)(sh.hs - 1); h_attn.n = (unsigned)sh.heads_loc; h_attn.stride = (unsigned)sh.hs;
@@ -500,7 +500,7 @@ static int enqueue_engine(l2z_runstate *s, const l2z_weights *w, bool with_step,
         a.xb = s->xb + sh.dim0; a.pos_ptr = s->d_pos; a.head_size = sh.hs; a.kv_row = sh.hs; a.kv_head = (size_t)c.seq_len * sh.hs;
         a.kv_mul = c.n_heads / c.n_kv_heads; a.seq_len = c.seq_len;
         if (sharded) {   // every rank's wo reads every rank's heads: out as the words of gather 4l + 1
-            a.push = s->d_push + 0; a.push_ctl = lc->d_ctl; a.push_gi = 4 * l + 1;
+            a.push = s->d_push + 0; a.push_ctl = lc->d_ctl; a.push_gi = comm_gi(lc, 4 * l + 1);
         }
         if (split && s->attn_nch > 1 && attention_split_supported(a))
             L2Z_HIP(launch_attention_split(a, sh.heads_loc, s->attn_nch, s->d_attn_part, s->d_attn_cnt, st, variant == ATTN_SPLIT_S));

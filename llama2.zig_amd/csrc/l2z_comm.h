@@ -29,7 +29,15 @@ struct l2z_comm {
     // as plain 16-byte stores + one flag per sender in the arena's reserved head); 0: none
     size_t bulk_floats = 0;
     mutable unsigned long long bulk_epoch = 0;  // bulk gathers issued (every rank issues the same sequence)
+    // SOLO (measurement: l2z_comm_p2p_connect_solo): one rank of an N-rank group alone on a GPU, every "peer" arena
+    // mapped to its own.  Every hand-over of every pass gets index 0, so its epoch is the counter's initial value and
+    // the zeroed landing slots already "carry" it: no wait ever blocks, the peers' slices read as 0.0.  The rank's
+    // launches, pushes, polls and gather / reduce launches all run -- the per-rank time of a sharded pass with free
+    // hand-overs (bench.py extra.scaling_model); the results mean nothing.
+    bool solo = false;
 };
+// the index a hand-over is given on this group (solo: always 0)
+inline int comm_gi(const l2z_comm *c, int gi) { return c != nullptr && c->solo ? 0 : gi; }
 
 namespace l2z {
 // In-place all-gather of `count_per_rank` floats per rank over buf[0 .. world*count) as its own

@@ -145,8 +145,14 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
         // several ranks on ONE GPU (tests): every rank's blocks must be resident at once (a block ~ a CU)
         int grid = g_cus;
         if (tn.grid_cap > 0 && grid > tn.grid_cap / 2) grid = tn.grid_cap / 2;
-        s->eng = grid >= 1 && engine_units_ok((sh.dim_loc + 2 * sh.kvd_loc + 1) / 2, grid) && engine_units_ok((sh.dim_loc + 1) / 2, grid) &&
-                 engine_units_ok(sh.hid_loc, grid) && engine_units_ok((sh.v_loc + 1) / 2, grid) && matvec_vector_width(c.dim);
+        auto fits = [&](int g) {
+            return g >= 1 && engine_units_ok((sh.dim_loc + 2 * sh.kvd_loc + 1) / 2, g) && engine_units_ok((sh.dim_loc + 1) / 2, g) &&
+                   engine_units_ok(sh.hid_loc, g) && engine_units_ok((sh.v_loc + 1) / 2, g);
+        };
+        // a narrow shard (N = 8: 256 row pairs of wo / w2 per rank) has fewer units than a CU-filling grid has halves: fewer
+        // blocks then -- every half must own a unit of every mat-vec
+        while (grid > 1 && !fits(grid) && fits(grid / 2)) grid /= 2;
+        s->eng = fits(grid) && matvec_vector_width(c.dim);
         s->eng_grid = grid;
         s->eng_xs_floats = engine_xs_floats(std::max(c.dim, c.hidden_dim));
         if (s->eng && engine_lds_bytes(s->eng_xs_floats) > 160 * 1024) s->eng = false;

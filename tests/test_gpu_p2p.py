@@ -232,3 +232,36 @@ def test_bench_legs_on_one_gpu(gpu, tmp_path):
         assert legs["rccl"]["why"], legs["rccl"]
         assert out["comm"]["rccl"]["initialised"] is False
     print({t: (l["ok"], l.get("tokens_per_s"), l.get("why")) for t, l in legs.items()})
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_solo_rank_runs_every_structure(gpu, ck, world):
+    """l2z_comm_p2p_connect_solo (measurement support, bench.py extra.scaling_model.solo_rank): ONE rank of an N-rank group
+    alone, every peer arena its own, every hand-over's wait satisfied by the zeroed landing slots.  Every leg's structure
+    must run its whole pass that way -- no wait may block, nothing may time out -- and produce finite numbers (they mean
+    nothing: the peers' slices read as zeros)."""
+    kw = dict(dim=4096, hidden_dim=8192, n_layers=2, n_heads=32, n_kv_heads=8, vocab_size=8192, seq_len=320)
+    cfg = ck.Config(**kw)
+    forms = [({}, 0), ({"L2Z_P2P_CONSUME": 0}, 0), ({"L2Z_ENGINE": 1}, 4), ({"L2Z_SCHEME_B": 1}, 8)]
+    reset = {"L2Z_P2P_CONSUME": 1, "L2Z_ENGINE": 0, "L2Z_SCHEME_B": 0}
+    gpu.option_set("L2Z_P2P_TIMEOUT_S", 5)
+    try:
+        for opts, want in forms:
+            for k, v in opts.items():
+                gpu.option_set(k, v)
+            try:
+                comm = gpu.Comm(0, world, None, 0)
+                comm.p2p_export(max(cfg.dim, cfg.hidden_dim, cfg.vocab_size, world * cfg.dim), max(cfg.dim, cfg.hidden_dim))
+                comm.p2p_connect_solo()
+                w = gpu.Weights(cfg, None, False, seed=3, comm=comm)
+                s = gpu.RunState(cfg, comm=comm)
+            finally:
+                for k in opts:
+                    gpu.option_set(k, reset[k])
+            assert (s.form() & 12) == want, (opts, s.form())
+            s.greedy_begin([5, 6])
+            toks = s.greedy_run(w, 300)          # past pos 256: the split attention form as well
+            assert len(toks) >= 2 and np.isfinite(s.logits()).all(), opts
+            s.close(); w.close(); comm.close()
+    finally:
+        gpu.option_set("L2Z_P2P_TIMEOUT_S", 20)
