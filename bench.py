@@ -351,7 +351,7 @@ SOLO_FORMS = [("p2p-consume", {}), ("p2p-gather", {"L2Z_P2P_CONSUME": 0}), ("p2p
 def solo_rank_model(B, cfg, shared, seed, steps: int = 64, worlds=(2, 4, 8)) -> dict:
     """What scaling_model's per-kind sums leave out: ONE rank of an N-rank group alone on this GPU running its WHOLE
     sharded pass -- graph replay, every launch, the pushes of its outputs as LL words, the consumer-side polls, the
-    gather / reduce launches -- with free hand-overs (l2z_comm_p2p_connect_solo: every peer arena is the rank's own and
+    gather / reduce launches -- with free hand-overs (l2z_comm_p2p_connect_solo: the peers' arenas are a local sink and
     the zeroed landing slots satisfy every wait).  tokens/s of that rank = an upper bound on tokens/s at N GPUs for
     each leg's structure; hand-over latency, rank skew and xGMI are still not in it (and its N stores per pushed word
     land on one local address instead of N devices)."""

@@ -130,7 +130,7 @@ int l2z_emu_prefill(int n_ranks, l2z_runstate *const *ss, const l2z_weights *con
  * are connected. */
 int l2z_comm_transports(const l2z_comm *c, int *rccl_ranks, int *p2p_connected);
 
-/* Measurement: after l2z_comm_p2p_export, connect this rank ALONE -- every peer's arena is its own, every hand-over's
+/* Measurement: after l2z_comm_p2p_export, connect this rank ALONE -- every peer's arena is a local sink, this rank's own zeroed slots satisfy every hand-over's
  * wait is satisfied by the zeroed slots -- so that ONE rank of an N-rank group runs its whole sharded pass (launches,
  * pushes, polls, gather / reduce launches) on a GPU by itself: the per-rank time with free hand-overs.  Results are
  * meaningless (the peers' slices read as zeros). */

@@ -202,7 +202,7 @@ class Comm:
         _chk(lib().l2z_comm_p2p_connect(self.h, buf))
 
     def p2p_connect_solo(self) -> None:
-        """Measurement: this rank alone, every peer's arena its own, no wait ever blocks (l2z_comm_p2p_connect_solo)."""
+        """Measurement: this rank alone, peers' arenas a local sink, no wait ever blocks (l2z_comm_p2p_connect_solo)."""
         _chk(lib().l2z_comm_p2p_connect_solo(self.h))
 
     def transports(self) -> dict:

@@ -362,7 +362,17 @@ extern "C" int l2z_comm_p2p_connect_solo(l2z_comm *c)
 {
     L2Z_CHECK(c != nullptr, L2Z_ERR_INVALID, "l2z_comm_p2p_connect_solo: null comm");
     L2Z_CHECK(c->arena != nullptr && !c->p2p, L2Z_ERR_STATE, "l2z_comm_p2p_connect_solo: call l2z_comm_p2p_export first (once)");
-    for (int r = 0; r < c->world; r++) c->peer_arena[r] = c->arena;
+    // the peers' "arenas": a local sink with one reserved head + slot pair per peer, so that the N - 1 stores of a pushed
+    // word go to N - 1 different addresses as they would to N - 1 devices (they are never read); no bulk regions there:
+    // the batched prefill is refused on a solo group
+    const size_t per_peer = kP2pFlagBytes + 2 * c->slot_floats * 8;
+    L2Z_HIP(hipSetDevice(c->device));
+    if (c->world > 1) {
+        L2Z_HIP(hipExtMallocWithFlags((void **)&c->solo_sink, per_peer * (size_t)(c->world - 1), hipDeviceMallocFinegrained));
+        L2Z_HIP(hipMemset(c->solo_sink, 0, per_peer * (size_t)(c->world - 1)));
+    }
+    for (int r = 0, k = 0; r < c->world; r++) c->peer_arena[r] = r == c->rank ? c->arena : c->solo_sink + per_peer * (size_t)(k++);
+    c->bulk_floats = 0;
     c->p2p = true;
     c->solo = true;
     return L2Z_OK;
@@ -414,7 +424,8 @@ extern "C" void l2z_comm_free(l2z_comm *c)
 {
     if (!c) return;
     for (int r = 0; r < c->world && r < kMaxWorld; r++)
-        if (r != c->rank && c->peer_arena[r] && c->peer_arena[r] != c->arena) (void)hipIpcCloseMemHandle(c->peer_arena[r]);
+        if (r != c->rank && c->peer_arena[r] && !c->solo) (void)hipIpcCloseMemHandle(c->peer_arena[r]);
+    if (c->solo_sink) (void)hipFree(c->solo_sink);
     if (c->arena) (void)hipFree(c->arena);
     if (c->d_ctl) (void)hipFree(c->d_ctl);
     if (c->h_err) (void)hipHostFree(c->h_err);

@@ -811,8 +811,8 @@ extern "C" int l2z_time_kind(int kind, int pos, const l2z_config *config, l2z_ru
               "l2z_time_kind: bad arguments");
     // a shard's launches can be timed on an EMULATED rank (no transport: every input is a plain buffer, nothing waits):
     // the per-rank kernel time of a sharded pass, measured on one GPU (bench.py extra.scaling_model)
-    L2Z_CHECK(s->sh.world == 1 || (s->comm && !s->comm->nccl && !s->comm->p2p), L2Z_ERR_INVALID,
-              "l2z_time_kind: unsharded runstates or emulated ranks only (a connected shard would wait for its peers)");
+    L2Z_CHECK(s->sh.world == 1 || (s->comm && ((!s->comm->nccl && !s->comm->p2p) || s->comm->solo)), L2Z_ERR_INVALID,
+              "l2z_time_kind: unsharded runstates, emulated or solo ranks only (a connected shard would wait for its peers)");
     L2Z_CHECK(pos >= 0 && pos < config->seq_len, L2Z_ERR_STATE, "pos out of range");
     L2Z_HIP(hipSetDevice(s->device));
     L2Z_HIP(launch_set_state(1, pos, s->d_token, s->d_pos, w->tok_emb, s->x, config->dim, s->stream));

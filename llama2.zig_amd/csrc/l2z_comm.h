@@ -30,11 +30,12 @@ struct l2z_comm {
     size_t bulk_floats = 0;
     mutable unsigned long long bulk_epoch = 0;  // bulk gathers issued (every rank issues the same sequence)
     // SOLO (measurement: l2z_comm_p2p_connect_solo): one rank of an N-rank group alone on a GPU, every "peer" arena
-    // mapped to its own.  Every hand-over of every pass gets index 0, so its epoch is the counter's initial value and
+    // mapped to a local sink (peer stores hit distinct local addresses instead of N devices).  Every hand-over of every pass gets index 0, so its epoch is the counter's initial value and
     // the zeroed landing slots already "carry" it: no wait ever blocks, the peers' slices read as 0.0.  The rank's
     // launches, pushes, polls and gather / reduce launches all run -- the per-rank time of a sharded pass with free
     // hand-overs (bench.py extra.scaling_model); the results mean nothing.
     bool solo = false;
+    char *solo_sink = nullptr;        // solo: where the pushes "to the peers" land (one slot pair per peer, distinct addresses)
 };
 // the index a hand-over is given on this group (solo: always 0)
 inline int comm_gi(const l2z_comm *c, int gi) { return c != nullptr && c->solo ? 0 : gi; }

@@ -248,4 +248,16 @@ echo "== fuzz_p2p 16 (seed $S)"; timeout 900 python scripts/fuzz_p2p.py 16 $S | 
 } > $O/$F 2>&1
 cat $O/$F
 ;;
+z)
+# round 4, GPU call Z: rocprofv3 kernel tables of ONE rank of 8 alone on the GPU (solo connect), whole pass, per structure
+export L2Z_P2P_TIMEOUT_S=5
+( cd /tmp
+for k in ${FORMS:-0 3}; do
+  rm -rf /tmp/prof_solo$k
+  rocprofv3 --kernel-trace --stats -d /tmp/prof_solo$k -o p -- python $GRAFT_REPO_ROOT/scripts/solo_rank.py llama2-7b 12 8 $k > /tmp/prof_solo$k.log 2>&1 || tail -5 /tmp/prof_solo$k.log
+  grep "tok/s" /tmp/prof_solo$k.log
+  python $GRAFT_REPO_ROOT/scripts/rocprof_summary.py $(find /tmp/prof_solo$k -name "*.db" | head -1) "round 4: rocprofv3 --kernel-trace --stats -- python scripts/solo_rank.py llama2-7b 12 8 $k (one rank of 8 alone, hand-overs free)" > $GRAFT_REPO_ROOT/$O/r04_solo8_form${k}_kernel_stats.md
+  head -16 $GRAFT_REPO_ROOT/$O/r04_solo8_form${k}_kernel_stats.md | cut -c1-150
+done )
+;;
 esac

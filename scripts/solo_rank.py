@@ -1,8 +1,9 @@
 """ONE rank of an N-rank shard group alone on the GPU, its whole sharded decode pass with free hand-overs
-(l2z_comm_p2p_connect_solo: every peer arena is its own, the zeroed landing slots satisfy every wait): tokens/s of the
+(l2z_comm_p2p_connect_solo: the peers' arenas are a local sink, this rank's zeroed landing slots satisfy every wait): tokens/s of the
 rank = an UPPER bound on tokens/s at N GPUs for each structure -- launches, pushes, polls, gather / reduce launches and
 graph replay included (scaling_model's per-kind sums leave those out); hand-over latency, rank skew and xGMI are not.
-usage: solo_rank.py [workload] [steps]"""
+usage: solo_rank.py [workload] [steps]            the table, N = 2 / 4 / 8 x every structure
+       solo_rank.py <workload> <steps> <N> <k>    only structure number k (0 .. 3) at N (for rocprofv3 --kernel-trace --stats)"""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 import numpy as np, __graft_entry__ as ge
@@ -53,6 +54,11 @@ def run(world, opts):
             if o is not None: o.close()
 
 
+if len(sys.argv) > 4:
+    name, opts = FORMS[int(sys.argv[4])]
+    v, form = run(int(sys.argv[3]), opts)
+    print(f"{wl} N = {sys.argv[3]} {name}: {v:.1f} tok/s = {1e3 / v:.3f} ms per token, runstate form {form}")
+    sys.exit(0)
 base, _ = run(1, {})
 print(f"# {wl}: one rank of N alone on the GPU, hand-overs free (solo connect), best of 3 x {steps} greedy steps; N = 1: {base:.1f} tok/s\n")
 print("| structure | " + " | ".join(f"N = {n}: tok/s (x of N = 1)" for n in (2, 4, 8)) + " |\n|---|" + "---:|" * 3)

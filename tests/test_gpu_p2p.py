@@ -237,7 +237,7 @@ def test_bench_legs_on_one_gpu(gpu, tmp_path):
 @pytest.mark.parametrize("world", [2, 8])
 def test_solo_rank_runs_every_structure(gpu, ck, world):
     """l2z_comm_p2p_connect_solo (measurement support, bench.py extra.scaling_model.solo_rank): ONE rank of an N-rank group
-    alone, every peer arena its own, every hand-over's wait satisfied by the zeroed landing slots.  Every leg's structure
+    alone, the peers' arenas a local sink, every hand-over's wait satisfied by its own zeroed landing slots.  Every leg's structure
     must run its whole pass that way -- no wait may block, nothing may time out -- and produce finite numbers (they mean
     nothing: the peers' slices read as zeros)."""
     kw = dict(dim=4096, hidden_dim=8192, n_layers=2, n_heads=32, n_kv_heads=8, vocab_size=8192, seq_len=320)
