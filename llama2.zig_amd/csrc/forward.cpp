@@ -114,9 +114,12 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
     const bool p2p = ovl || (s->d_push != nullptr && only_stage < 0 && sh.world > 1);
     const bool consume = ovl || (p2p && s->ll_consume);
     // Producers push their outputs as LL words straight into the peers' slots (the values travel
-    // while the launch still runs).  With gather launches, not while profiling: the gather's share
-    // would be hidden in the producer's time.
-    const bool can_push = ovl || (p2p && tn.p2p_push && (consume || prof == nullptr));
+    // while the launch still runs) where the CONSUMERS read the words (consumer-side form, persistent launches).
+    // (Where a launch collects the vector anyway -- gather launches, scheme B's reduce launches -- that launch sends too:
+    // a store to a peer's arena from a mat-vec's epilogue holds up the wave's loads behind it (they return in order), which
+    // costs the launch more than the earlier departure saves: one rank of 8 alone with free hand-overs, profiles/
+    // r04_solo_rank.md: scheme B 580 -> 727 tok/s, gather launches 488 -> 649.  L2Z_P2P_PUSH=2 pushes there as well.)
+    const bool can_push = ovl || (p2p && (consume ? tn.p2p_push != 0 : (tn.p2p_push >= 2 && prof == nullptr)));
     const bool sb = sh.scheme_b;
     const int n_g = s->n_gathers;
     int gi = 0;           // gathers issued so far in this pass

@@ -40,7 +40,9 @@ struct Tunables {
     int no_graph = 0;          // L2Z_NO_GRAPH        1: launch eagerly
     int comm_graph = 1;        // L2Z_COMM_GRAPH      0: RCCL collectives are launched eagerly, not captured
     int prefer_rccl = 0;       // L2Z_COMM=rccl       use RCCL even when the peer-write transport is connected
-    int p2p_push = 1;          // L2Z_P2P_PUSH        0: producers do not push, the gather launch sends
+    int p2p_push = 1;          // L2Z_P2P_PUSH        1: producers push their outputs from their epilogues where consumers read the words
+                               //                     (consumer-side form, persistent launches); 2: also where a gather / reduce launch
+                               //                     collects them (slower, measured); 0: never (no consumer-side form then)
     int p2p_consume = 1;       // L2Z_P2P_CONSUME     0: keep a gather launch per gathered vector (consumers
                                //                     read plain buffers)
     long long p2p_timeout_s = 20;  // L2Z_P2P_TIMEOUT_S

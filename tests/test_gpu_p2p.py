@@ -53,12 +53,15 @@ def run_ranks(tmp_path, world, spec, env_extra=None, timeout=300):
 
 
 # consume: consumers read the LL words from their own landing slot (no gather launches, default);
-# gather: one gather launch per gathered vector (L2Z_P2P_CONSUME=0); nopush: the gather launch also sends
+# gather: one gather launch per gathered vector, which also sends (L2Z_P2P_CONSUME=0); gather-push: the producers' epilogues
+# send, the gather launch only collects (L2Z_P2P_PUSH=2); nopush: no pushes anywhere (L2Z_P2P_PUSH=0: gather launches)
 # engine: the ranks run the persistent decode launches (engine.hip, L2Z_ENGINE=1): wo, w1|w3, w2 and the next q|k|v as one
 # launch per layer whose mat-vecs hand their vectors over as the same words, across the ranks as inside one
 CASES = ([(m, "consume") for m in MODELS] + [(MODELS[0], "gather"), (MODELS[4], "gather"), (MODELS[3], "nopush")] +
+         [(MODELS[0], "gather-push"), (MODELS[4], "gather-push")] +
          [(MODELS[5], "engine"), (MODELS[4], "engine")])
-MODE_ENV = {"consume": {}, "gather": {"L2Z_P2P_CONSUME": "0"}, "nopush": {"L2Z_P2P_PUSH": "0"}, "engine": {"L2Z_ENGINE": "1"}}
+MODE_ENV = {"consume": {}, "gather": {"L2Z_P2P_CONSUME": "0"}, "gather-push": {"L2Z_P2P_CONSUME": "0", "L2Z_P2P_PUSH": "2"},
+            "nopush": {"L2Z_P2P_PUSH": "0"}, "engine": {"L2Z_ENGINE": "1"}}
 
 
 @pytest.mark.parametrize("model,mode", CASES, ids=[f"{m[0]}-x{m[3]}-{mode}" for m, mode in CASES])
@@ -86,7 +89,7 @@ def test_multiprocess_peer_write_gather_is_bit_identical(gpu, ck, tmp_path, mode
     s.close(); w.close()
 
 
-SCHEME_B = [(MODELS[0], "push"), (MODELS[1], "push"), (MODELS[3], "push"), (MODELS[3], "nopush"), (MODELS[5], "push"), (MODELS[4], "push")]
+SCHEME_B = [(MODELS[0], "push"), (MODELS[1], "nopush"), (MODELS[3], "push"), (MODELS[3], "nopush"), (MODELS[5], "nopush"), (MODELS[4], "push")]
 
 
 @pytest.mark.parametrize("model,mode", SCHEME_B, ids=[f"{m[0]}-x{m[3]}-{mode}" for m, mode in SCHEME_B])
@@ -94,14 +97,15 @@ def test_multiprocess_scheme_b_allreduce(gpu, ck, tmp_path, model, mode, options
     """Scheme B with real processes (L2Z_SCHEME_B=1: Wo / W2 sharded by columns, the ranks' partial [dim] vectors pushed as
     LL words into every peer's slot and summed in rank order by the reduce launch, csrc/p2p.hip): 2 collectives per layer.
     The ranks must agree with each other BIT FOR BIT; against the unsharded pass fed the same tokens the logits hold the
-    parity tests' tolerance (the row sums are split differently).  nopush: the reduce launch sends the partial itself."""
+    parity tests' tolerance (the row sums are split differently).  nopush (the default): the reduce launch sends the partial
+    itself; push (L2Z_P2P_PUSH=2): the mat-vec's epilogue does."""
     name, kw, shared, world = model
     options(L2Z_FUSE_SMALL=0, L2Z_PREFILL=0)
     cfg = ck.Config(**kw)
     steps = min(cfg.seq_len - 2, 120)
     on_device = cfg.dim >= 4096
     spec = dict(cfg=kw, shared=shared, seed=33, prompt=[5, 9, 11], steps=steps, blob=not on_device)
-    run_ranks(tmp_path, world, spec, dict({"L2Z_SCHEME_B": "1"}, **({"L2Z_P2P_PUSH": "0"} if mode == "nopush" else {})))
+    run_ranks(tmp_path, world, spec, dict({"L2Z_SCHEME_B": "1"}, **({"L2Z_P2P_PUSH": "2"} if mode == "push" else {})))
     outs = [np.load(tmp_path / f"out_{r}.npz") for r in range(world)]
     for r in range(1, world):
         for k in ("toks", "logits", "logits2"):
