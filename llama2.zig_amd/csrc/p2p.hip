@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void p2p_allgather_kernel(const P2pArgs a, int
 // words arrive in.  One hop: a rank's partial travels as LL words to word rank * count + i of every peer's slot (from the
 // producing mat-vec's epilogue, or from this launch when the producer could not push), and the thread that owns element
 // i polls the N - 1 peers' words for it.  Slot reuse and deadlock freedom: as for the gather launch above.
-__global__ __launch_bounds__(256) void p2p_allreduce_kernel(const P2pArgs a, float *out, int gi, int pushed)
+__global__ __launch_bounds__(1024) void p2p_allreduce_kernel(const P2pArgs a, float *out, int gi, int pushed)
 {
     __shared__ int s_timeout;
     if (threadIdx.x == 0) s_timeout = 0;
@@ -294,7 +294,9 @@ hipError_t launch_bulk_unpack(const BulkArgs &a, unsigned long long e, int wait,
 
 hipError_t launch_p2p_allreduce(const P2pArgs &a, float *out, int gi, bool pushed, hipStream_t st)
 {
-    hipLaunchKernelGGL(p2p_allreduce_kernel, dim3((unsigned)((a.count + 255) / 256)), dim3(256), 0, st, a, out, gi, pushed ? 1 : 0);
+    int nt = tunables().reduce_block;
+    nt = nt < 64 ? 64 : nt > 1024 ? 1024 : (nt / 64) * 64;
+    hipLaunchKernelGGL(p2p_allreduce_kernel, dim3((unsigned)((a.count + nt - 1) / nt)), dim3(nt), 0, st, a, out, gi, pushed ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -45,6 +45,7 @@ struct Tunables {
                                //                     collects them (slower, measured); 0: never (no consumer-side form then)
     int p2p_consume = 1;       // L2Z_P2P_CONSUME     0: keep a gather launch per gathered vector (consumers
                                //                     read plain buffers)
+XX
     long long p2p_timeout_s = 20;  // L2Z_P2P_TIMEOUT_S
     int scheme_b = 0;          // L2Z_SCHEME_B        1: shard groups take scheme B: Wo / W2 sharded by COLUMNS, every rank's partial
                                //                     [dim] vectors summed by an all-reduce -- 2 collectives per layer instead of 4 all-gathers, but the
