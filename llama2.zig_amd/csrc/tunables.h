@@ -45,7 +45,8 @@ struct Tunables {
                                //                     collects them (slower, measured); 0: never (no consumer-side form then)
     int p2p_consume = 1;       // L2Z_P2P_CONSUME     0: keep a gather launch per gathered vector (consumers
                                //                     read plain buffers)
-XX
+    int reduce_block = 128;    // L2Z_REDUCE_BLOCK    threads per block of scheme B's reduce launch (64 ... 1024; one element per thread;
+                               //                     one rank of 8 alone: 64 / 128 / 256 / 512 / 1024 threads -> 734 / 733 / 728 / 722 / 693 tok/s)
     long long p2p_timeout_s = 20;  // L2Z_P2P_TIMEOUT_S
     int scheme_b = 0;          // L2Z_SCHEME_B        1: shard groups take scheme B: Wo / W2 sharded by COLUMNS, every rank's partial
                                //                     [dim] vectors summed by an all-reduce -- 2 collectives per layer instead of 4 all-gathers, but the
