@@ -387,10 +387,9 @@ extern "C" int l2z_comm_rank(const l2z_comm *c, int *rank, int *world)
 }
 
 // Loads RCCL now (l2z_comm_init would on first use) and says WHICH library the process got: a process that has imported
-// PyTorch holds torch's own bundled copies of librccl / libamdhip64, and a dlopen by SONAME then resolves to whichever
-// copy was loaded first.  Callers that mix the two (bench.py's legs use torch's gloo for their control plane) call this
-// before importing torch, so that the collective library and the HIP runtime under it are the ones this library was
-// built against, and put the answer in their record.
+// PyTorch holds torch's own bundled copies of librccl / libamdhip64, and a dlopen by SONAME resolves to whichever copy
+// was loaded first.  bench.py's legs import torch first (gloo control plane; the other order leaves HIP without a visible
+// device on this image), so their RCCL is torch's bundled one: they put this answer in their record.
 extern "C" int l2z_comm_rccl_info(char *path_out, size_t cap, int *version)
 {
     L2Z_TRY(load_rccl());

@@ -119,9 +119,9 @@ __global__ __launch_bounds__(256) void p2p_allgather_kernel(const P2pArgs a, int
 // ---- all-reduce (scheme B: column-sharded Wo / W2) ----
 // Every rank holds a partial [count] vector (rank 0's includes the residual); afterwards out[i] = part_0[i] + part_1[i] + ...
 // + part_{N-1}[i], summed in RANK order by every rank -- so all ranks end with the same bits, whatever the order the
-// words arrive in.  One hop: a rank's partial travels as LL words to word rank * count + i of every peer's slot (from the
-// producing mat-vec's epilogue, or from this launch when the producer could not push), and the thread that owns element
-// i polls the N - 1 peers' words for it.  Slot reuse and deadlock freedom: as for the gather launch above.
+// words arrive in.  One hop: a rank's partial travels as LL words to word rank * count + i of every peer's slot -- sent by
+// this launch (the default: a peer store in a mat-vec's epilogue holds up the wave's loads behind it; L2Z_P2P_PUSH=2 makes
+// the producing mat-vec send instead) -- and the thread that owns element i polls the N - 1 peers' words for it.  Slot reuse and deadlock freedom: as for the gather launch above.
 __global__ __launch_bounds__(1024) void p2p_allreduce_kernel(const P2pArgs a, float *out, int gi, int pushed)
 {
     __shared__ int s_timeout;
