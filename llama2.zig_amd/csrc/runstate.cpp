@@ -151,7 +151,11 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
         };
         // a narrow shard (N = 8: 256 row pairs of wo / w2 per rank) has fewer units than a CU-filling grid has halves: fewer
         // blocks then -- every half must own a unit of every mat-vec
-        while (grid > 1 && !fits(grid) && fits(grid / 2)) grid /= 2;
+        for (int g2 = grid; g2 >= 1; g2 /= 2)
+            if (fits(g2)) {
+                grid = g2;
+                break;
+            }
         s->eng = fits(grid) && matvec_vector_width(c.dim);
         s->eng_grid = grid;
         s->eng_xs_floats = engine_xs_floats(std::max(c.dim, c.hidden_dim));
