@@ -344,7 +344,7 @@ def scaling_model(B, cfg, shared, seed, pos: int, worlds=(2, 4, 8)) -> dict:
     return out
 
 
-SOLO_FORMS = [("p2p-consume", {}), ("p2p-gather", {"L2Z_P2P_CONSUME": 0}), ("p2p-engine", {"L2Z_ENGINE": 1}),
+SOLO_FORMS = [("p2p-consume", {"L2Z_P2P_CONSUME": 1}), ("p2p-gather", {"L2Z_P2P_CONSUME": 0}), ("p2p-engine", {"L2Z_ENGINE": 1}),
               ("p2p-allreduce", {"L2Z_SCHEME_B": 1})]
 
 
@@ -355,7 +355,7 @@ def solo_rank_model(B, cfg, shared, seed, steps: int = 64, worlds=(2, 4, 8)) -> 
     the zeroed landing slots satisfy every wait).  tokens/s of that rank = an upper bound on tokens/s at N GPUs for
     each leg's structure; hand-over latency, rank skew and xGMI are still not in it (and its N stores per pushed word
     land on one local address instead of N devices)."""
-    reset = {"L2Z_P2P_CONSUME": 1, "L2Z_ENGINE": 0, "L2Z_SCHEME_B": 0}
+    reset = {"L2Z_P2P_CONSUME": -1, "L2Z_ENGINE": 0, "L2Z_SCHEME_B": 0}
     out = {}
     for world in worlds:
         if cfg.n_heads % world or cfg.n_kv_heads % world or cfg.hidden_dim % world or cfg.vocab_size % world:

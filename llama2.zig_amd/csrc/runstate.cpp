@@ -121,7 +121,8 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
         AttnArgs aa = {};
         aa.q = s->q; aa.kcache = s->key_cache; aa.vcache = s->value_cache;
         aa.head_size = sh.hs; aa.kv_row = sh.hs; aa.kv_head = (size_t)c.seq_len * sh.hs;
-        s->ll_consume = !sh.scheme_b && tn.p2p_push && tn.p2p_consume && matvec_ll_supported(c.dim) &&
+        const bool want_consume = tn.p2p_consume >= 0 ? tn.p2p_consume != 0 : (tn.engine != 0 || sh.world <= 2 || c.dim < 4096);
+        s->ll_consume = !sh.scheme_b && tn.p2p_push && want_consume && matvec_ll_supported(c.dim) &&
                         matvec_ll_supported(c.hidden_dim) && attention_push_supported(aa);
         P2pArgs t[4];
         comm_p2p_args(comm, s->xb, (size_t)sh.dim_loc, s->ll_consume, &t[0]);

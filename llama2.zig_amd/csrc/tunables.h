@@ -43,8 +43,11 @@ struct Tunables {
     int p2p_push = 1;          // L2Z_P2P_PUSH        1: producers push their outputs from their epilogues where consumers read the words
                                //                     (consumer-side form, persistent launches); 2: also where a gather / reduce launch
                                //                     collects them (slower, measured); 0: never (no consumer-side form then)
-    int p2p_consume = 1;       // L2Z_P2P_CONSUME     0: keep a gather launch per gathered vector (consumers
-                               //                     read plain buffers)
+    int p2p_consume = -1;      // L2Z_P2P_CONSUME     1: consumers read their gathered input as LL words while staging x (no gather launches);
+                               //                     0: a gather launch per gathered vector (consumers read plain buffers); -1 (default):
+                               //                     by shape -- the consumer-side form for up to 2 ranks or rows narrower than 4096, gather
+                               //                     launches beyond (one rank of N alone, 7B shape, profiles/r04_solo_rank.md: N = 2 equal,
+                               //                     N = 4 +13 %, N = 8 +27 % for the gather launches); the persistent launches imply 1
     int reduce_block = 128;    // L2Z_REDUCE_BLOCK    threads per block of scheme B's reduce launch (64 ... 1024; one element per thread;
                                //                     one rank of 8 alone: 64 / 128 / 256 / 512 / 1024 threads -> 734 / 733 / 728 / 722 / 693 tok/s)
     long long p2p_timeout_s = 20;  // L2Z_P2P_TIMEOUT_S

@@ -21,7 +21,7 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 8):
     cfg = ck.Config(**kw); shared = bool(rng.integers(0, 2))
     steps = cfg.seq_len - 2
     mode = str(rng.choice(["consume", "consume", "consume", "gather", "scheme-b", "scheme-b"]))
-    mode_env = {"consume": {}, "gather": {"L2Z_P2P_CONSUME": "0"}, "scheme-b": {"L2Z_SCHEME_B": "1"}}[mode]
+    mode_env = {"consume": {"L2Z_P2P_CONSUME": "1"}, "gather": {"L2Z_P2P_CONSUME": "0"}, "scheme-b": {"L2Z_SCHEME_B": "1"}}[mode]
     with tempfile.TemporaryDirectory() as d:
         # prompts of 4 tokens and more go through the row-sharded batched prefill (bulk regions of the arenas)
         n_prompt = int(rng.choice([2, 5, 40, min(100, cfg.seq_len - 8)]))

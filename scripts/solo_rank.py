@@ -11,11 +11,11 @@ pkg = ge.load_package(); B, ck = pkg.binding, pkg.checkpoint
 wl = sys.argv[1] if len(sys.argv) > 1 else "llama2-7b"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 cfg, shared = {n: (c, sh) for n, c, sh in ck.iter_configs()}[wl]
-FORMS = [("A: consumer-side words (p2p-consume)", {}),
+FORMS = [("A: consumer-side words (p2p-consume)", {"L2Z_P2P_CONSUME": 1}),
          ("A: gather launch per vector (p2p-gather)", {"L2Z_P2P_CONSUME": 0}),
          ("A: persistent launches (p2p-engine)", {"L2Z_ENGINE": 1}),
          ("B: column shards + reduce launches (p2p-allreduce)", {"L2Z_SCHEME_B": 1})]
-RESET = {"L2Z_P2P_CONSUME": 1, "L2Z_ENGINE": 0, "L2Z_SCHEME_B": 0}
+RESET = {"L2Z_P2P_CONSUME": -1, "L2Z_ENGINE": 0, "L2Z_SCHEME_B": 0}
 B.option_set("L2Z_PREFILL", 0)
 
 

@@ -52,7 +52,8 @@ def run_ranks(tmp_path, world, spec, env_extra=None, timeout=300):
     return outs
 
 
-# consume: consumers read the LL words from their own landing slot (no gather launches, default);
+# consume: consumers read the LL words from their own landing slot (no gather launches; the default up to 2 ranks or for
+# rows narrower than 4096, L2Z_P2P_CONSUME=1 here);
 # gather: one gather launch per gathered vector, which also sends (L2Z_P2P_CONSUME=0); gather-push: the producers' epilogues
 # send, the gather launch only collects (L2Z_P2P_PUSH=2); nopush: no pushes anywhere (L2Z_P2P_PUSH=0: gather launches)
 # engine: the ranks run the persistent decode launches (engine.hip, L2Z_ENGINE=1): wo, w1|w3, w2 and the next q|k|v as one
@@ -60,7 +61,7 @@ def run_ranks(tmp_path, world, spec, env_extra=None, timeout=300):
 CASES = ([(m, "consume") for m in MODELS] + [(MODELS[0], "gather"), (MODELS[4], "gather"), (MODELS[3], "nopush")] +
          [(MODELS[0], "gather-push"), (MODELS[4], "gather-push")] +
          [(MODELS[5], "engine"), (MODELS[4], "engine")])
-MODE_ENV = {"consume": {}, "gather": {"L2Z_P2P_CONSUME": "0"}, "gather-push": {"L2Z_P2P_CONSUME": "0", "L2Z_P2P_PUSH": "2"},
+MODE_ENV = {"consume": {"L2Z_P2P_CONSUME": "1"}, "gather": {"L2Z_P2P_CONSUME": "0"}, "gather-push": {"L2Z_P2P_CONSUME": "0", "L2Z_P2P_PUSH": "2"},
             "nopush": {"L2Z_P2P_PUSH": "0"}, "engine": {"L2Z_ENGINE": "1"}}
 
 
@@ -246,8 +247,8 @@ def test_solo_rank_runs_every_structure(gpu, ck, world):
     nothing: the peers' slices read as zeros)."""
     kw = dict(dim=4096, hidden_dim=8192, n_layers=2, n_heads=32, n_kv_heads=8, vocab_size=8192, seq_len=320)
     cfg = ck.Config(**kw)
-    forms = [({}, 0), ({"L2Z_P2P_CONSUME": 0}, 0), ({"L2Z_ENGINE": 1}, 4), ({"L2Z_SCHEME_B": 1}, 8)]
-    reset = {"L2Z_P2P_CONSUME": 1, "L2Z_ENGINE": 0, "L2Z_SCHEME_B": 0}
+    forms = [({"L2Z_P2P_CONSUME": 1}, 0), ({"L2Z_P2P_CONSUME": 0}, 0), ({"L2Z_ENGINE": 1}, 4), ({"L2Z_SCHEME_B": 1}, 8)]
+    reset = {"L2Z_P2P_CONSUME": -1, "L2Z_ENGINE": 0, "L2Z_SCHEME_B": 0}
     gpu.option_set("L2Z_P2P_TIMEOUT_S", 5)
     try:
         for opts, want in forms:
