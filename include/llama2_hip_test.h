@@ -98,6 +98,12 @@ int l2z_attention_decode(int form, int nch, float *out, const float *q, const fl
 int l2z_prefill_attention(int form, float *out, const float *q, const float *kcache, const float *vcache,
                           int pos0, int n_queries, int n_heads, int n_kv_heads, int head_size, int seq_len);
 
+/* Host-side shard geometry (no device needed): out[0..9] = dim0, dim_loc, kvd_loc, heads_loc, hid0, hid_loc, v0, v_loc of
+ * rank `rank` of `world` (scheme A: rows / heads owned), then dimc_pad, hidc_pad: the zero-padded row width of its Wo / W2
+ * column shards under scheme B (multiples of 256 floats above 768, of 4 below).  L2Z_ERR_INVALID when the shape does not
+ * split over `world` ranks. */
+int l2z_shard_plan(const l2z_config *config, int rank, int world, int *out, int cap);
+
 /* Host-side planning of the batched prefill (no device needed).  l2z_prefill_plan: the chunk lengths a
  * prompt of n_tokens is cut into (returns their number, writes up to cap of them).  l2z_prefill_tile: the
  * output tile of the direct-to-LDS GEMM for an [n_tokens, n_features] product -- 0: 128x64, 1: 64x64,

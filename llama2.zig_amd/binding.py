@@ -123,6 +123,8 @@ def lib():
     L.l2z_emu_transformer.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int]
     L.l2z_prefill_attention.argtypes = [C.c_int, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.l2z_prefill_plan.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int]
+    if hasattr(L, "l2z_shard_plan"):
+        L.l2z_shard_plan.argtypes = [cfgp, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
     L.l2z_prefill_tile.argtypes = [C.c_int, C.c_int, C.c_int]
     if hasattr(L, "l2z_prefill_split_k"):
         L.l2z_prefill_split_k.argtypes = [C.c_longlong, C.c_int, C.c_int, C.c_int]
@@ -369,6 +371,15 @@ def prefill_attention(form: int, q, kcache, vcache, pos0: int, n_heads: int, n_k
     _chk(lib().l2z_prefill_attention(form, _fp(out), _fp(q), _fp(kcache), _fp(vcache), pos0, q.shape[0], n_heads,
                                      n_kv_heads, head_size, kcache.shape[0]))
     return out
+
+
+def shard_plan(cfg, rank: int, world: int) -> dict:
+    """What rank `rank` of `world` owns (host logic, no device): scheme A's row / head ranges and scheme B's padded widths."""
+    buf = (C.c_int * 10)()
+    c = _cfg(cfg)
+    _chk(lib().l2z_shard_plan(C.byref(c), rank, world, buf, 10))
+    keys = ("dim0", "dim_loc", "kvd_loc", "heads_loc", "hid0", "hid_loc", "v0", "v_loc", "dimc_pad", "hidc_pad")
+    return dict(zip(keys, list(buf)))
 
 
 def prefill_plan(n_tokens: int) -> list[int]:

@@ -249,6 +249,22 @@ extern "C" int l2z_option_set(const char *env_name, long long value)
     return L2Z_OK;
 }
 
+// Host-side shard geometry (no device needed): what rank `rank` of `world` owns under scheme A (rows) and, for Wo / W2 under
+// scheme B, the padded width of its column shards.  out[0..9] = dim0, dim_loc, kvd_loc, heads_loc, hid0, hid_loc, v0, v_loc,
+// dimc_pad, hidc_pad.
+extern "C" int l2z_shard_plan(const l2z_config *config, int rank, int world, int *out, int cap)
+{
+    L2Z_CHECK(config != nullptr && out != nullptr && cap >= 10 && world >= 1 && rank >= 0 && rank < world, L2Z_ERR_INVALID,
+              "l2z_shard_plan: bad arguments");
+    l2z_comm c;
+    c.rank = rank; c.world = world; c.device = 0; c.nccl = nullptr;
+    Shard sh;
+    L2Z_TRY(make_shard(*config, &c, &sh));
+    const int v[10] = {sh.dim0, sh.dim_loc, sh.kvd_loc, sh.heads_loc, sh.hid0, sh.hid_loc, sh.v0, sh.v_loc, sh.dimc_pad, sh.hidc_pad};
+    for (int i = 0; i < 10; i++) out[i] = v[i];
+    return L2Z_OK;
+}
+
 // Host-side planning of the batched prefill, no device needed: how a prompt is cut into chunks, and which
 // output tile the direct-to-LDS GEMM takes for a [P, N] product (0: 128x64, 1: 64x64, 2: 32x64, 3: 32x32,
 // 4: 128x128; the CU count is the current device's, 256 without one).

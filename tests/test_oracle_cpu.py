@@ -238,6 +238,32 @@ def test_product_does_not_reference_the_oracle():
         assert "liboracle" not in needed
 
 
+def test_shard_plan_rows_and_scheme_b_widths(B, ck):
+    """Host-side shard geometry (l2z_shard_plan, no device): the row / head ranges of scheme A tile the model exactly, and
+    scheme B's column shards of Wo / W2 are padded to widths the vector mat-vecs take -- at least the shard, a multiple of 4,
+    and of 256 floats (whole 64-lane sweeps of 16 bytes) above 768."""
+    shapes = [dict(dim=4096, hidden_dim=11008, n_layers=2, n_heads=32, n_kv_heads=32, vocab_size=32000, seq_len=64),
+              dict(dim=4096, hidden_dim=8192, n_layers=2, n_heads=32, n_kv_heads=8, vocab_size=8192, seq_len=64),
+              dict(dim=768, hidden_dim=2048, n_layers=2, n_heads=12, n_kv_heads=12, vocab_size=32000, seq_len=64),
+              dict(dim=36, hidden_dim=102, n_layers=1, n_heads=6, n_kv_heads=3, vocab_size=96, seq_len=16)]
+    for kw in shapes:
+        cfg = ck.Config(**kw)
+        for world in (1, 2, 3, 4, 6, 8):
+            if cfg.n_kv_heads % world or cfg.hidden_dim % world or cfg.vocab_size % world:
+                with pytest.raises(B.L2ZError):
+                    B.shard_plan(cfg, 0, world)
+                continue
+            plans = [B.shard_plan(cfg, r, world) for r in range(world)]
+            assert [p["dim0"] for p in plans] == [r * cfg.dim // world for r in range(world)]
+            assert sum(p["dim_loc"] for p in plans) == cfg.dim and sum(p["hid_loc"] for p in plans) == cfg.hidden_dim
+            assert sum(p["v_loc"] for p in plans) == cfg.vocab_size and sum(p["kvd_loc"] for p in plans) == cfg.kv_dim
+            assert all(p["heads_loc"] * cfg.head_size == p["dim_loc"] for p in plans)
+            for p in plans:
+                for loc, pad in ((p["dim_loc"], p["dimc_pad"]), (p["hid_loc"], p["hidc_pad"])):
+                    assert loc <= pad < loc + 256 and pad % 4 == 0 and (pad <= 768 or pad % 256 == 0), (kw, world, loc, pad)
+    assert B.shard_plan(ck.Config(**shapes[0]), 7, 8)["hidc_pad"] == 1536   # 1376 -> 1536 (DESIGN.md 6)
+
+
 def test_shard_range(B):
     assert B.shard_range(4096, 128, 3, 8) == (1536, 2048)
     assert B.shard_range(11008, 1, 7, 8) == (9632, 11008)
