@@ -146,10 +146,9 @@ int l2z_comm_p2p_connect_solo(l2z_comm *c);
  * PyTorch afterwards keeps THIS copy (same SONAME); one that imported it before gets torch's bundled copy. */
 int l2z_comm_rccl_info(char *path_out, size_t cap, int *version);
 
-/* The decode structure a runstate runs: bit 0 = paired mat-vec blocks (L2Z_DUO), bit 1 = two overlapped
- * chains (L2Z_OVERLAP), bit 2 = the persistent launches (L2Z_ENGINE), bit 3 = sharding scheme B (L2Z_SCHEME_B:
- * column-sharded Wo / W2 + all-reduces).  0 = the default chain.  An opt-in
- * form is refused silently when the shape or the transport cannot carry it; tests that ask for one check here. */
+/* The structure a runstate runs: bit 3 = sharding scheme B (L2Z_SCHEME_B: column-sharded Wo / W2 + all-reduces);
+ * 0 = the default.  (Bits 0-2 named round 4's opt-in decode forms, removed in round 5: always 0.)  Tests that ask
+ * for an option check here that they got it. */
 int l2z_runstate_form(const l2z_runstate *s, int *form);
 
 /* Set one tuning knob by its environment-variable name (csrc/tunables.h), e.g. ("L2Z_P2P_CONSUME", 0).

@@ -542,13 +542,10 @@ size_t attention_lds_bytes(int head_size, int seq_len, bool vec)
 // geometry: 256 positions at head sizes <= 64 (stories110M: 7.3 -> ~4.5 us per layer at pos < 66), 128 at
 // head size 128 (7B: the forms cross there, profiles/r02_kind_scan.txt).  A function of the MODEL only, so
 // every rank of a shard group takes the same form at the same position.
-// all256 (wide-row models, runstate.cpp attn_all256): the 256-thread form at every position the split form does
-// not take -- the 1024-thread block would not fit a CU beside a waiting mat-vec block of the overlapped chain.
-int attention_short_pos(int head_size, int seq_len, bool all256)
+int attention_short_pos(int head_size, int seq_len)
 {
     const int forced = tunables().attn_short_pos;
     if (forced >= 0) return forced < seq_len ? forced : seq_len;
-    if (all256 && (head_size % 4) == 0 && head_size <= 256) return seq_len;  // clamped to the split position by the caller
     if (seq_len <= 512 || (head_size % 4) != 0 || head_size > 256) return 0;  // that form at every position anyway
     const AttnGeom ge = attn_geom(head_size, true, kBlock);
     const int two_rounds = 2 * ge.G * kFastUB;
@@ -575,11 +572,10 @@ size_t attention_split_part_floats(int n_heads_local, int head_size, int nch)
 // profiles/r03_attn_split_scan.txt, us per layer back to back): pos 256 10.0 vs 12.4, pos 511 11.1 vs 13.2, pos 1023
 // 14.9 vs 15.0, pos 2047 21.8 vs 19.9 -- a chunk of <= 128 timesteps is four rounds of a 256-thread block's rows and
 // a quarter of the waves to launch and to combine.  A function of the model and the position only.
-int attention_split_wide_pos(int seq_len, bool all256)
+int attention_split_wide_pos(int seq_len)
 {
     const int forced = tunables().attn_split_wide_pos;
     if (forced >= 0) return forced;
-    if (all256) return seq_len;  // never (see attention_short_pos)
     return seq_len > 512 ? 1024 : seq_len;  // small contexts: 256 threads throughout (as before)
 }
 

@@ -97,43 +97,6 @@ LLIn comm_ll_in(const l2z_comm *c, int gi, size_t count_per_rank)
     return in;
 }
 
-l2z_comm *comm_self_create(int device, size_t max_vector_floats)
-{
-    l2z_comm *c = new l2z_comm();
-    c->rank = 0; c->world = 1; c->device = device; c->nccl = nullptr;
-    c->slot_floats = (max_vector_floats + 1023) & ~(size_t)1023;
-    const size_t bytes = kP2pFlagBytes + 2 * c->slot_floats * 8;
-    // fine-grained like the peers' arenas: the words are written and polled inside running kernels
-    hipError_t e = hipExtMallocWithFlags((void **)&c->arena, bytes, hipDeviceMallocFinegrained);
-    if (e == hipSuccess) e = hipMemset(c->arena, 0, bytes);
-    if (e == hipSuccess) e = hipMalloc((void **)&c->d_ctl, kCtlInts * sizeof(int));
-    if (e == hipSuccess) e = hipMemset(c->d_ctl, 0, kCtlInts * sizeof(int));
-    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_err, sizeof(int), hipHostMallocDefault);
-    if (e == hipSuccess) {
-        *c->h_err = 0;
-        e = hipDeviceSynchronize();
-    }
-    if (e != hipSuccess) {
-        set_error("overlapped chain: arena allocation failed: %s", hipGetErrorString(e));
-        l2z_comm_free(c);
-        return nullptr;
-    }
-    c->peer_arena[0] = c->arena;
-    return c;
-}
-
-void comm_self_args(const l2z_comm *c, float *buf, size_t count, P2pArgs *out)
-{
-    P2pArgs a = {};
-    a.buf = buf; a.count = count; a.rank = 0; a.world = 1;
-    a.slot_floats = c->slot_floats;
-    a.peer_arena[0] = c->arena;
-    a.ctl = c->d_ctl; a.err = c->h_err;
-    a.timeout_ticks = tunables().p2p_timeout_s * 100000000LL;
-    a.self = 1;
-    *out = a;
-}
-
 bool comm_uses_p2p(const l2z_comm *c)
 {
     return c != nullptr && c->p2p && c->world > 1 && !(tunables().prefer_rccl && c->nccl);

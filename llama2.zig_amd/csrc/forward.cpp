@@ -65,81 +65,41 @@ int check_pair(const l2z_config *config, const l2z_runstate *s, const l2z_weight
 // of 4; stages between collectives: [qkv, attention, wo], [w1|w3, w2] per layer, then the classifier.  The sum over a row
 // is split differently than in the unsharded pass: logits agree at the tolerance of the parity tests, not bit for bit
 // (ranks agree with each other exactly: same partials, same order).
-// Overlapped chain (s->ovl; world == 1, wide-row models).  The launches of a pass go out on TWO
-// streams with no edge between consecutive mat-vecs: a consumer whose input edge is overlapped runs in the other
-// chain than its producer, becomes resident while the producer still streams, issues its first weight batch and
-// only then waits for its input vector, which the producer hands over as LL words {value, epoch} in this
-// process's own landing slots (the peer-write transport of sharded runs with one rank: p2p.hip).  Edges, per layer:
-// bit 0 attention -> wo, 1 wo -> w1|w3, 2 w1|w3 -> w2, 3 w2 -> next qkv / classifier.  qkv -> attention (q and the
-// new K / V row are plain buffers) and classifier -> argmax stay stream-ordered.  A kernel only ever reads plain
-// buffers written earlier in ITS OWN chain or before the pass began; the residual of wo / w2 comes as the LL words
-// of the previous hand-over of x.  Every mat-vec is the duo kernel (one 8-wave block per CU) and every attention
-// form a 256-thread one, so a waiting launch can never keep the launch it waits for from becoming resident.
-struct Hint { unsigned h0 = 0, n = 0, stride = 0; };
-static int enqueue_engine(l2z_runstate *s, const l2z_weights *w, bool with_step, int variant);
-
-// the elements a mat-vec producer writes in its last sweep over the units (virtual grid vgrid)
-static Hint mv_hint(int n_pairs, int vgrid, int epi)
-{
-    Hint h;
-    if (vgrid <= 0 || n_pairs <= 0) return h;
-    const int u0 = ((n_pairs - 1) / vgrid) * vgrid;
-    h.n = (unsigned)(n_pairs - u0);
-    if (epi == EPI_SWIGLU) { h.h0 = (unsigned)u0; h.stride = 1; }
-    else { h.h0 = (unsigned)(2 * u0 + 1); h.stride = 2; }
-    return h;
-}
-
 int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof *prof,
                     int only_stage, int variant, int only_kind)
 {
-    if (s->eng && only_stage < 0 && only_kind < 0 && prof == nullptr) return enqueue_engine(s, w, with_step, variant);
     const bool split = variant == ATTN_SPLIT || variant == ATTN_SPLIT_S;
     const l2z_config &c = s->cfg;
     const Shard &sh = s->sh;
     const Tunables &tn = tunables();
-    const bool duo = s->duo;  // such a runstate runs the duo mat-vecs in every mode (what is timed is what runs)
-    const bool ovl = s->ovl && only_stage < 0 && only_kind < 0 && prof == nullptr;
-    const unsigned emask = ovl ? (unsigned)s->ovl_edges : 0u;
-    hipStream_t sts[2] = {s->stream, ovl ? s->stream2 : s->stream};
-    int chain = 0;
-    hipStream_t st = sts[0];
-    const l2z_comm *lc = ovl ? s->self_comm : s->comm;
+    hipStream_t st = s->stream;
+    const l2z_comm *lc = s->comm;
     const size_t dim = c.dim, hid = c.hidden_dim;
     const int mb = s->max_blocks;
     int stage = 0;
     auto want = [&]() { return only_stage < 0 || only_stage == stage; };
     // only_kind >= 0: just the launches of one kind, back to back (l2z_time_kind: kernel duration)
     auto kind = [&](int k) { return only_kind < 0 || only_kind == k; };
-    const bool p2p = ovl || (s->d_push != nullptr && only_stage < 0 && sh.world > 1);
-    const bool consume = ovl || (p2p && s->ll_consume);
+    const bool p2p = s->d_push != nullptr && only_stage < 0 && sh.world > 1;
+    const bool consume = p2p && s->ll_consume;
     // Producers push their outputs as LL words straight into the peers' slots (the values travel
     // while the launch still runs) where the CONSUMERS read the words (consumer-side form, persistent launches).
     // (Where a launch collects the vector anyway -- gather launches, scheme B's reduce launches -- that launch sends too:
     // a store to a peer's arena from a mat-vec's epilogue holds up the wave's loads behind it (they return in order), which
     // costs the launch more than the earlier departure saves: one rank of 8 alone with free hand-overs, profiles/
     // r04_solo_rank.md: scheme B 580 -> 727 tok/s, gather launches 488 -> 649.  L2Z_P2P_PUSH=2 pushes there as well.)
-    const bool can_push = ovl || (p2p && (consume ? tn.p2p_push != 0 : (tn.p2p_push >= 2 && prof == nullptr)));
+    const bool can_push = p2p && (consume ? tn.p2p_push != 0 : (tn.p2p_push >= 2 && prof == nullptr));
     const bool sb = sh.scheme_b;
     const int n_g = s->n_gathers;
     int gi = 0;           // gathers issued so far in this pass
     bool pushed = false;  // the launch just made pushed its outputs itself
-    Hint hint;            // overlapped chain: where the launch just made writes last
     const int *ctl = lc ? lc->d_ctl : nullptr;
-    if (ovl) {  // fork: the second chain starts behind whatever precedes the pass on the runstate's stream
-        L2Z_HIP(hipEventRecord(s->ev_fork, sts[0]));
-        L2Z_HIP(hipStreamWaitEvent(sts[1], s->ev_fork, 0));
-    }
     auto gather = [&](float *buf, size_t count_per_rank) -> int {
         stage++;
         gi++;
         if (only_stage >= 0 || only_kind >= 0) return L2Z_OK;
         const bool was_pushed = pushed;
         pushed = false;
-        if (ovl) {  // nothing is collected: consumers read the words (or, stream-ordered edges, the plain buffer)
-            L2Z_CHECK(was_pushed || gi == n_g, L2Z_ERR_STATE, "overlapped chain, hand-over %d: the producer did not push", gi);
-            return L2Z_OK;
-        }
         if (consume) {
             L2Z_CHECK(was_pushed, L2Z_ERR_STATE, "consumer-side gather %d: the producer did not push", gi);
             if (gi < n_g) return L2Z_OK;  // the consumer collects; only the logits get a launch
@@ -182,25 +142,9 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         }
         return L2Z_OK;
     };
-    // input of a consumer: the vector gathered as number g (consumer-side form), else the plain buffer.
-    // Overlapped chain: `edge` = the bit of the edge this input arrives over; set -> the consumer runs in the
-    // other chain than the producer and reads the words behind the producer's hint, clear -> same chain, plain.
-    auto x_in = [&](MatvecArgs &a, const float *plain, int g, size_t count_per_rank, unsigned edge = 0) {
+    // input of a consumer: the vector gathered as number g (consumer-side form), else the plain buffer
+    auto x_in = [&](MatvecArgs &a, const float *plain, int g, size_t count_per_rank) {
         a.x = plain;
-        a.duo = duo ? 1 : 0;
-        a.tl_seq = s->tl_seq++;
-        if (ovl) {
-            if (g >= 1 && (emask & edge)) {
-                chain ^= 1;
-                a.xin = comm_ll_in(lc, g, count_per_rank);
-                if (tn.overlap_hint && hint.n) {
-                    a.xin.hint0 = hint.h0; a.xin.hint_n = hint.n; a.xin.hint_stride = hint.stride;
-                    a.xin.hint_sleep = tn.overlap_hint_sleep;
-                }
-            }
-            st = sts[chain];
-            return;
-        }
         if (consume && g >= 1) a.xin = comm_ll_in(s->comm, g, count_per_rank);
     };
     auto push_to = [&](MatvecArgs &a, int which) {
@@ -248,7 +192,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.rows0 = sh.dim_loc; a.rows1 = sh.kvd_loc; a.rows2 = sh.kvd_loc;
             a.pos_stride1 = sh.hs; a.pos_stride2 = sh.hs; a.kv_head_stride = kvh_stride;
             a.n = c.dim; a.rms_w = w->rms_att + (size_t)l * dim;
-            x_in(a, s->x, gi, sh.dim_loc, 8u);  // layer 0: the embedding row, a plain buffer (gi == 0)
+            x_in(a, s->x, gi, sh.dim_loc);  // layer 0: the embedding row, a plain buffer (gi == 0)
             a.pos_ptr = s->d_pos; a.rope = s->rope; a.head_size = sh.hs; a.rope_segs = 2;
             L2Z_LAUNCH(KIND_QKV, launch_matvec(a, PRO_RMS, EPI_ROPE, mb, g_cus, st));
         }
@@ -263,13 +207,12 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
                 a.push_ctl = ctl;
                 a.push_gi = comm_gi(lc, gi + 1);
                 pushed = true;
-                hint.h0 = (unsigned)(sh.hs - 1); hint.n = (unsigned)sh.heads_loc; hint.stride = (unsigned)sh.hs;  // a head's last element
             }
             if (split && s->attn_nch > 1 && attention_split_supported(a))
                 L2Z_LAUNCH(KIND_ATTN, launch_attention_split(a, sh.heads_loc, s->attn_nch,
                                                              s->d_attn_part, s->d_attn_cnt, st, variant == ATTN_SPLIT_S));
             else
-                L2Z_LAUNCH(KIND_ATTN, launch_attention(a, sh.heads_loc, st, (variant == ATTN_SHORT || s->attn_all256) ? 1 : 0));
+                L2Z_LAUNCH(KIND_ATTN, launch_attention(a, sh.heads_loc, st, variant == ATTN_SHORT ? 1 : 0));
         }
         if (!sb) L2Z_TRY(gather(s->xb, sh.dim_loc));
         if (want() && kind(KIND_WO)) {   // wo (:392) + residual (:395)
@@ -281,13 +224,10 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
                 a.w0 = w->wo + (size_t)l * sh.dim_loc * dim;
                 a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0;
                 a.rows0 = sh.dim_loc; a.n = c.dim;
-                x_in(a, s->xb, gi, sh.dim_loc, 1u);
-                if (ovl && gi >= 2) a.resid_in = comm_ll_in(lc, gi - 1, sh.dim_loc);  // x as the previous layer's w2 handed it over
+                x_in(a, s->xb, gi, sh.dim_loc);
                 push_to(a, 1);
             }
-            int vg = 0;
-            L2Z_LAUNCH(KIND_WO, launch_matvec(a, PRO_NONE, epi, mb, g_cus, st, &vg, &pushed));
-            hint = mv_hint((sh.dim_loc + 1) / 2, vg, EPI_RESID);
+            L2Z_LAUNCH(KIND_WO, launch_matvec(a, PRO_NONE, epi, mb, g_cus, st, nullptr, &pushed));
         }
         if (sb) L2Z_TRY(reduce());
         else L2Z_TRY(gather(s->x, sh.dim_loc));
@@ -298,11 +238,9 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.out0 = sb ? s->hb : s->hb + sh.hid0;  // scheme B: the slice stays local, w2's column shard reads it from the buffer's start
             a.rows0 = sh.hid_loc; a.rows1 = sh.hid_loc; a.n = c.dim;
             a.rms_w = w->rms_ffn + (size_t)l * dim;
-            x_in(a, s->x, gi, sh.dim_loc, 2u);
+            x_in(a, s->x, gi, sh.dim_loc);
             if (!sb) push_to(a, 2);
-            int vg = 0;
-            L2Z_LAUNCH(KIND_FFN13, launch_matvec(a, PRO_RMS, EPI_SWIGLU, mb, g_cus, st, &vg, &pushed));
-            hint = mv_hint(sh.hid_loc, vg, EPI_SWIGLU);
+            L2Z_LAUNCH(KIND_FFN13, launch_matvec(a, PRO_RMS, EPI_SWIGLU, mb, g_cus, st, nullptr, &pushed));
         }
         if (!sb) L2Z_TRY(gather(s->hb, sh.hid_loc));
         if (want() && kind(KIND_FFN2)) {   // w2 (:419) + residual (:422)
@@ -314,13 +252,10 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
                 a.w0 = w->w2 + (size_t)l * sh.dim_loc * hid;
                 a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0;
                 a.rows0 = sh.dim_loc; a.n = c.hidden_dim;
-                x_in(a, s->hb, gi, sh.hid_loc, 4u);
-                if (ovl) a.resid_in = comm_ll_in(lc, gi - 1, sh.dim_loc);  // x as this layer's wo handed it over
+                x_in(a, s->hb, gi, sh.hid_loc);
                 push_to(a, 1);
             }
-            int vg = 0;
-            L2Z_LAUNCH(KIND_FFN2, launch_matvec(a, PRO_NONE, epi, mb, g_cus, st, &vg, &pushed));
-            hint = mv_hint((sh.dim_loc + 1) / 2, vg, EPI_RESID);
+            L2Z_LAUNCH(KIND_FFN2, launch_matvec(a, PRO_NONE, epi, mb, g_cus, st, nullptr, &pushed));
         }
         if (sb) L2Z_TRY(reduce());
         else L2Z_TRY(gather(s->x, sh.dim_loc));
@@ -329,24 +264,17 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         MatvecArgs a = {};
         a.w0 = w->wcls; a.out0 = s->logits + sh.v0;
         a.rows0 = sh.v_loc; a.n = c.dim; a.rms_w = w->rms_final;
-        x_in(a, s->x, gi, sh.dim_loc, 8u);
+        x_in(a, s->x, gi, sh.dim_loc);
         a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.row_offset = sh.v0;
         // single GPU, vector path: the launch also leaves one argmax candidate per block
         const bool fuse = sh.world == 1 && matvec_vector_width(c.dim);
         int grid = 0;
-        if (!ovl) push_to(a, 3);
+        push_to(a, 3);
         L2Z_LAUNCH(KIND_CLS, launch_matvec(a, PRO_RMS, fuse ? EPI_ARGMAX : EPI_STORE, mb, g_cus, st,
                                            &grid, &pushed));
         s->n_part = fuse ? grid : 0;
     }
     L2Z_TRY(gather(s->logits, sh.v_loc));
-    if (ovl) {
-        // Join BEFORE the hand-over: the argmax launch writes the next step's x, token and pos -- plain buffers the
-        // launches of both chains read or wrote -- and closes the pass's epochs, so it runs behind every launch of
-        // the pass (the chain it is not in has long drained: the classifier consumed that chain's last vector).
-        L2Z_HIP(hipEventRecord(s->ev_join, sts[chain ^ 1]));
-        L2Z_HIP(hipStreamWaitEvent(sts[chain], s->ev_join, 0));
-    }
     if (with_step && want() && kind(KIND_ARGMAX)) {
         ArgmaxArgs a = {};
         a.logits = s->logits; a.vocab = c.vocab_size; a.token_ptr = s->d_token;
@@ -354,180 +282,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         a.pos_ptr = s->d_pos; a.prompt = s->d_prompt; a.n_prompt_ptr = s->d_n_prompt;
         a.out_tokens = s->d_out_tokens; a.argmax_out = s->d_argmax; a.tok_emb = w->tok_emb;
         a.x = s->x; a.dim = c.dim; a.advance = 1;
-        if (ovl) { a.epoch_ctl = lc->d_ctl; a.epoch_add = n_g; }  // the pass is over: its epochs are used up
         L2Z_LAUNCH(KIND_ARGMAX, launch_argmax(a, st));
-    } else if (ovl) {
-        L2Z_HIP(launch_epoch_advance(lc->d_ctl, n_g, st));
-    }
-    if (ovl && chain == 1) {  // the pass ended in the second chain: the runstate's stream continues behind it
-        L2Z_HIP(hipEventRecord(s->ev_tail, sts[1]));
-        L2Z_HIP(hipStreamWaitEvent(sts[0], s->ev_tail, 0));
-    }
-    return L2Z_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// The pass as persistent launches (engine.hip; world == 1, wide-row models, L2Z_ENGINE=1):
-//   launch 0: q|k|v of layer 0        then per layer l: attention(l) -- its own launch, plain buffers either side --
-//   launch l + 1: wo(l), w1|w3(l), w2(l) and q|k|v(l + 1) (the classifier after the last layer) as ONE launch whose
-//   mat-vecs hand x / hb / x over as LL words in this process's own landing slots (the gathers 4l+2, 4l+3, 4l+4 of
-//   the sharded pass's numbering; epochs advance with the argmax launch, as in the overlapped chain).
-// Same units, same summation order, same epilogues as the launch chain: the same bits.
-// ---------------------------------------------------------------------------------------------------------------
-static int engine_prepare(l2z_runstate *s, const l2z_weights *w)
-{
-    if (s->eng_w_uid == w->uid) return L2Z_OK;
-    const l2z_config &c = s->cfg;
-    const Shard &sh = s->sh;
-    const bool sharded = sh.world > 1;
-    const l2z_comm *lc = sharded ? s->comm : s->self_comm;   // whose landing slots carry the hand-overs
-    const size_t dim = c.dim, hid = c.hidden_dim;
-    const int L = c.n_layers, vgrid = 2 * s->eng_grid;
-    const Tunables &tn = tunables();
-    std::vector<EngChunk> ch((size_t)L + 1);
-    auto nb_of = [](int n) { return ((n >> 2) + 1023) / 1024; };
-    auto set_op = [&](EngOp &o, const MatvecArgs &a, int pro, int epi) {
-        o.a = a; o.pro = pro; o.epi = epi;
-        const int rows = a.rows0 + a.rows1 + a.rows2;
-        o.n_pairs = epi == EPI_SWIGLU ? a.rows0 : (rows + 1) / 2;
-        o.nb = nb_of(a.n);
-    };
-    // x of a mat-vec as the words of gather g (count floats per rank); the hint: elements THIS rank's producer writes in
-    // its last sweep (the other ranks' words are late words like any other: every word validates itself)
-    auto ll_in = [&](MatvecArgs &a, int g, size_t count, Hint h, size_t base) {
-        a.xin = comm_ll_in(lc, g, count);
-        if (tn.overlap_hint && h.n) {
-            a.xin.hint0 = (unsigned)base + h.h0; a.xin.hint_n = h.n; a.xin.hint_stride = h.stride; a.xin.hint_sleep = tn.overlap_hint_sleep;
-        }
-    };
-    auto push = [&](MatvecArgs &a, int which, int g) { a.push = s->d_push + which; a.push_ctl = lc->d_ctl; a.push_gi = comm_gi(lc, g); };
-    const Hint h_dim = mv_hint((sh.dim_loc + 1) / 2, vgrid, EPI_RESID), h_hid = mv_hint(sh.hid_loc, vgrid, EPI_SWIGLU);
-    Hint h_attn;   // the attention launch's outputs: a head's last element, this rank's heads
-    h_attn.h0 = (unsigned)(sh.hs - 1); h_attn.n = (unsigned)sh.heads_loc; h_attn.stride = (unsigned)sh.hs;
-    auto qkv_op = [&](EngOp &o, int l, bool plain) {
-        MatvecArgs a = {};
-        a.w0 = w->wq + (size_t)l * sh.dim_loc * dim;
-        a.w1 = w->wk + (size_t)l * sh.kvd_loc * dim;
-        a.w2 = w->wv + (size_t)l * sh.kvd_loc * dim;
-        a.out0 = s->q;
-        a.out1 = s->key_cache + (size_t)l * c.seq_len * sh.kvd_loc;
-        a.out2 = s->value_cache + (size_t)l * c.seq_len * sh.kvd_loc;
-        a.rows0 = sh.dim_loc; a.rows1 = sh.kvd_loc; a.rows2 = sh.kvd_loc;
-        a.pos_stride1 = sh.hs; a.pos_stride2 = sh.hs; a.kv_head_stride = (size_t)c.seq_len * sh.hs;
-        a.n = c.dim; a.rms_w = w->rms_att + (size_t)l * dim;
-        a.x = s->x;
-        if (!plain) ll_in(a, 4 * l, sh.dim_loc, h_dim, sh.dim0);   // x as the previous layer's w2 handed it over
-        a.pos_ptr = s->d_pos; a.rope = s->rope; a.head_size = sh.hs; a.rope_segs = 2;
-        set_op(o, a, PRO_RMS, EPI_ROPE);
-    };
-    for (int i = 0; i <= L; i++) {
-        EngChunk &k = ch[(size_t)i];
-        memset(&k, 0, sizeof k);
-        k.ctl = lc->d_ctl; k.h_err = lc->h_err;
-        k.timeout_ticks = tn.p2p_timeout_s * 100000000LL;
-        k.dummy = w->tok_emb;
-        if (i == 0) {
-            k.n_ops = 1;
-            qkv_op(k.op[0], 0, true);   // the embedding row: a plain buffer on every rank
-            continue;
-        }
-        const int l = i - 1;
-        k.n_ops = 4;
-        {   // wo (:392) + residual (:395).  xb: unsharded, the attention launch's plain buffer; sharded, every rank's heads as
-            // the words of gather 4l + 1 (the attention launch pushes them).  The residual: this rank's rows of x, plain
-            // (written by this rank's own w2 in the launch before)
-            MatvecArgs a = {};
-            a.w0 = w->wo + (size_t)l * sh.dim_loc * dim;
-            a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0; a.rows0 = sh.dim_loc; a.n = c.dim; a.x = s->xb;
-            a.row_offset = sh.dim0;
-            if (sharded) ll_in(a, 4 * l + 1, sh.dim_loc, h_attn, sh.dim0);
-            push(a, 1, 4 * l + 2);
-            set_op(k.op[0], a, PRO_NONE, EPI_RESID);
-        }
-        {   // rmsnorm (:398) + w1, w3 (:405-408) + SiLU * mul (:411-416)
-            MatvecArgs a = {};
-            a.w0 = w->w1 + (size_t)l * sh.hid_loc * 2 * dim;
-            a.w1 = w->w3 + (size_t)l * sh.hid_loc * 2 * dim;
-            a.out0 = s->hb + sh.hid0; a.rows0 = sh.hid_loc; a.rows1 = sh.hid_loc; a.n = c.dim;
-            a.rms_w = w->rms_ffn + (size_t)l * dim; a.x = s->x;
-            a.row_offset = sh.hid0;
-            ll_in(a, 4 * l + 2, sh.dim_loc, h_dim, sh.dim0);
-            push(a, 2, 4 * l + 3);
-            set_op(k.op[1], a, PRO_RMS, EPI_SWIGLU);
-        }
-        {   // w2 (:419) + residual (:422): the residual is this rank's rows of x as this launch's wo handed them over
-            MatvecArgs a = {};
-            a.w0 = w->w2 + (size_t)l * sh.dim_loc * hid;
-            a.out0 = s->x + sh.dim0; a.resid = s->x + sh.dim0; a.rows0 = sh.dim_loc; a.n = c.hidden_dim; a.x = s->hb;
-            a.row_offset = sh.dim0;
-            ll_in(a, 4 * l + 3, sh.hid_loc, h_hid, sh.hid0);
-            a.resid_in = comm_ll_in(lc, 4 * l + 2, sh.dim_loc);
-            push(a, 1, 4 * l + 4);
-            set_op(k.op[2], a, PRO_NONE, EPI_RESID);
-        }
-        if (l + 1 < L) {
-            qkv_op(k.op[3], l + 1, false);
-        } else {   // final rmsnorm (:426) + classifier (:429)
-            MatvecArgs a = {};
-            a.w0 = w->wcls; a.out0 = s->logits + sh.v0; a.rows0 = sh.v_loc; a.n = c.dim; a.rms_w = w->rms_final; a.x = s->x;
-            ll_in(a, 4 * L, sh.dim_loc, h_dim, sh.dim0);
-            a.row_offset = sh.v0;
-            if (sharded) {   // a shard's rows of the logits, published for the pass-closing gather (which advances the epochs)
-                push(a, 3, 4 * L + 1);
-                set_op(k.op[3], a, PRO_RMS, EPI_STORE);
-            } else {         // + one argmax candidate per virtual block
-                a.part_val = s->d_part_val; a.part_idx = s->d_part_idx;
-                set_op(k.op[3], a, PRO_RMS, EPI_ARGMAX);
-            }
-        }
-    }
-    L2Z_HIP(hipMemcpy(s->d_eng, ch.data(), ch.size() * sizeof(EngChunk), hipMemcpyHostToDevice));
-    s->eng_w_uid = w->uid;
-    return L2Z_OK;
-}
-
-static int enqueue_engine(l2z_runstate *s, const l2z_weights *w, bool with_step, int variant)
-{
-    const l2z_config &c = s->cfg;
-    const Shard &sh = s->sh;
-    const bool sharded = sh.world > 1;
-    const l2z_comm *lc = sharded ? s->comm : s->self_comm;
-    hipStream_t st = s->stream;
-    const bool split = variant == ATTN_SPLIT || variant == ATTN_SPLIT_S;
-    L2Z_HIP(launch_engine(s->d_eng, s->eng_grid, s->eng_xs_floats, st, s->tl_seq++));
-    for (int l = 0; l < c.n_layers; l++) {
-        AttnArgs a = {};
-        a.q = s->q;
-        a.kcache = s->key_cache + (size_t)l * c.seq_len * sh.kvd_loc;
-        a.vcache = s->value_cache + (size_t)l * c.seq_len * sh.kvd_loc;
-        a.xb = s->xb + sh.dim0; a.pos_ptr = s->d_pos; a.head_size = sh.hs; a.kv_row = sh.hs; a.kv_head = (size_t)c.seq_len * sh.hs;
-        a.kv_mul = c.n_heads / c.n_kv_heads; a.seq_len = c.seq_len;
-        if (sharded) {   // every rank's wo reads every rank's heads: out as the words of gather 4l + 1
-            a.push = s->d_push + 0; a.push_ctl = lc->d_ctl; a.push_gi = comm_gi(lc, 4 * l + 1);
-        }
-        if (split && s->attn_nch > 1 && attention_split_supported(a))
-            L2Z_HIP(launch_attention_split(a, sh.heads_loc, s->attn_nch, s->d_attn_part, s->d_attn_cnt, st, variant == ATTN_SPLIT_S));
-        else
-            L2Z_HIP(launch_attention(a, sh.heads_loc, st, (variant == ATTN_SHORT || s->attn_all256) ? 1 : 0));
-        L2Z_HIP(launch_engine(s->d_eng + l + 1, s->eng_grid, s->eng_xs_floats, st, s->tl_seq++));
-    }
-    if (sharded) {   // the logits: collected by the pass-closing gather launch (it also advances the group's epochs)
-        s->n_part = 0;
-        L2Z_TRY(comm_allgather_inplace(s->comm, s->logits, (size_t)sh.v_loc, s->n_gathers, s->n_gathers, true, st));
-    } else {
-        s->n_part = 2 * s->eng_grid;
-    }
-    if (with_step) {
-        ArgmaxArgs a = {};
-        a.logits = s->logits; a.vocab = c.vocab_size; a.token_ptr = s->d_token;
-        if (s->n_part > 0) { a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.n_part = s->n_part; }
-        a.pos_ptr = s->d_pos; a.prompt = s->d_prompt; a.n_prompt_ptr = s->d_n_prompt;
-        a.out_tokens = s->d_out_tokens; a.argmax_out = s->d_argmax; a.tok_emb = w->tok_emb;
-        a.x = s->x; a.dim = c.dim; a.advance = 1;
-        if (!sharded) { a.epoch_ctl = lc->d_ctl; a.epoch_add = s->n_gathers; }
-        L2Z_HIP(launch_argmax(a, st));
-    } else if (!sharded) {
-        L2Z_HIP(launch_epoch_advance(lc->d_ctl, s->n_gathers, st));
     }
     return L2Z_OK;
 }
@@ -607,8 +362,6 @@ int run_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, int pos)
               "sharded runstate without a transport: connect the group (RCCL id or "
               "l2z_comm_p2p_export/_connect), or drive emulated ranks with l2z_emu_transformer");
     L2Z_TRY(comm_check(s->comm));
-    L2Z_TRY(comm_check(s->self_comm));
-    if (s->eng) L2Z_TRY(engine_prepare(s, w));  // (a synchronous upload: before any capture)
     L2Z_TRY(ensure_graph(s, w, variant, with_step));
     if (s->use_graphs) {
         L2Z_HIP(hipGraphLaunch(with_step ? s->g_step[variant] : s->g_forward[variant], s->stream));
@@ -659,7 +412,6 @@ extern "C" int l2z_logits_read(l2z_runstate *s, float *out_logits)
                            hipMemcpyDeviceToHost, s->stream));
     L2Z_HIP(hipStreamSynchronize(s->stream));
     L2Z_TRY(comm_check(s->comm));
-    L2Z_TRY(comm_check(s->self_comm));
     return L2Z_OK;
 }
 
@@ -677,7 +429,6 @@ extern "C" int l2z_probs_read(l2z_runstate *s, float temperature, float *out_pro
     L2Z_HIP(hipMemcpyAsync(s->h_stage, s->d_probs, bytes, hipMemcpyDeviceToHost, s->stream));
     L2Z_HIP(hipStreamSynchronize(s->stream));
     L2Z_TRY(comm_check(s->comm));
-    L2Z_TRY(comm_check(s->self_comm));
     memcpy(out_probs, s->h_stage, bytes);
     return L2Z_OK;
 }
@@ -749,8 +500,7 @@ extern "C" int l2z_greedy_run(const l2z_config *config, l2z_runstate *s, const l
                                (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s->stream));
         L2Z_HIP(hipStreamSynchronize(s->stream));
         L2Z_TRY(comm_check(s->comm));
-        L2Z_TRY(comm_check(s->self_comm));
-        int got = n;
+            int got = n;
         for (int i = 0; i < n; i++) {
             if (out_tokens[produced + i] == 1) {  // BOS ends the sequence
                 got = i + 1;

@@ -16,21 +16,10 @@ constexpr int kWave = 64;
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / kWave;
 constexpr int kScratch = 32;  // floats of LDS scratch for block reductions
-constexpr int kDuo = 512;     // threads of a matvec_duo_kernel block (two halves of kBlock)
-
-
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-// Device-memory ("global") address space, spelled out.  The compiler infers it for pointers that arrive as kernel
-// arguments; a pointer read out of a structure in memory is generic to it -- flat_load / flat_store, which count on
-// both memory counters, so that every LDS wait also waits for the weight stream (engine.hip reads its mat-vec
-// descriptions from device memory).
-#define L2Z_G __attribute__((address_space(1)))
-template <typename T> __device__ __forceinline__ L2Z_G T *as_g(T *p) { return (L2Z_G T *)p; }
-
 __device__ __forceinline__ v4f ldg_nt(const v4f *p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ v4f ldg_nt(const L2Z_G v4f *p) { return __builtin_nontemporal_load(p); }
 
 // Cross-lane reductions.  Inside a 16-lane row the exchange is a DPP modifier on a VALU op
 // (a few cycles); ds_bpermute-based __shfl_xor (~100 cycles each, and the five steps of one
@@ -333,171 +322,6 @@ __device__ __forceinline__ void xstage_finish_ll(const LLPoll &p, const float *_
     xstage_tail<PRO, XC>(rms_w, n, n4_pad, xr, gr, xs, scratch, [&](int j) {
         return ll_wait4(p, j, ll_load2(p.slot, (size_t)4 * j), ll_load2(p.slot, (size_t)4 * j + 2));
     });
-}
-
-#ifdef L2Z_TIMELINE
-// Measurement build only (scripts/timeline_build.sh -> libllama2_hip_tl.so; never the product library): wall-clock
-// stamps (100 MHz) of every block of every duo launch, kept in registers and stored when the block is done (a stamp
-// written on the spot is a memory operation the block's next wait on its loads would wait behind).  Per (launch,
-// block): [0] kind (epi * 65536 + n / 4, bit 32: x handed over), [1] entry, [2] past the hint gate, [3] x staged,
-// [4] first unit done, [5] out of the unit loop, [6] hand-over stores acknowledged.  Read with l2z_timeline_dump.
-constexpr int kTlMax = 2048, kTlBlocks = 256;
-__device__ long long g_tl[kTlMax * kTlBlocks * 8];
-#define L2Z_TL(var) var = wall_clock64()
-#else
-#define L2Z_TL(var) do { } while (0)
-#endif
-
-// ---------------------------------------------------------------------------
-// x staging of the duo kernel (matvec.hip matvec_duo_kernel): 512 threads fill ONE copy of x per CU.
-// LL: x is a vector handed over by the previous launch of an overlapped chain, which may still be running
-// when this block becomes resident.  Every thread of every waiting block re-reading its
-// words for the whole life of the producer would be a second stream beside the producer's weights, so
-// the wait is gated: lane 0 polls ONE word -- the hint: an element a producer block writes in its LAST
-// sweep -- with s_sleep between polls, the other waves sit at the barrier; then all 512 threads sweep
-// the vector, four float4 (eight 16-byte loads) per thread in flight, and every word still validates
-// itself, so a hint that fires early only costs re-reads of the words that are late (ll_wait4).
-// hint_n == 0: no gate.
-// rmsnorm (main.zig:432-468): the sum of squares is formed by threads 0..255 over float4 t, t+256, ... in
-// increasing order, wave sum, four partials in wave order -- the 256-thread kernels' order, bit for bit.
-// ---------------------------------------------------------------------------
-constexpr int kHintLanes = 16;
-// called by lanes 0 .. kHintLanes-1 of the block's first wave: lane i polls the hint element of another producer
-// block (spread evenly over the producer's last sweep, so over its XCDs); all of them must carry the epoch.  One
-// producer block's word fired up to 14 us before the slowest block was done (the blocks' exits spread that much),
-// and a block that is let through early sweeps and then re-polls every late word beside the producer's tail.
-__device__ __forceinline__ void ll_hint_wait(const LLPoll &p, const LLIn &in)
-{
-    const unsigned step = in.hint_n >= kHintLanes ? in.hint_n / kHintLanes : 1u;
-    const unsigned idx = in.hint0 + ((blockIdx.x + threadIdx.x * step) % in.hint_n) * in.hint_stride;
-    const long long t0 = wall_clock64();
-    for (;;) {
-        const unsigned long long w =
-            __hip_atomic_load(p.slot + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (__all((unsigned)(w >> 32) == p.e)) break;
-        if (__hip_atomic_load(p.ctl + kCtlErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-        if (wall_clock64() - t0 > p.timeout_ticks) break;  // the sweep's own waits latch and report it
-        for (int i = 0; i < in.hint_sleep; i++) __builtin_amdgcn_s_sleep(8);  // 8 x 64 clocks each
-    }
-}
-
-// plain x: this thread's first GC float4 (zero past the end), issued ahead of the weight stream
-template <int GC>
-__device__ __forceinline__ void duo_xload(const float *__restrict__ x, int n4, v4f (&xr)[GC])
-{
-    const v4f *x4 = (const v4f *)x;
-#pragma unroll
-    for (int k = 0; k < GC; k++) {
-        const int j = threadIdx.x + kDuo * k;
-        xr[k] = (j < n4) ? x4[j] : v4f{0.f, 0.f, 0.f, 0.f};
-    }
-}
-
-// one lane: until *word carries id (bounded like every wait here; giving up only costs the pacing)
-__device__ __forceinline__ void ll_word_wait(const unsigned long long *word, unsigned id, const LLIn &in)
-{
-    const long long t0 = wall_clock64();
-    for (;;) {
-        const unsigned long long w = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if ((unsigned)(w >> 32) == id) break;
-        if (__hip_atomic_load(in.ctl + kCtlErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-        if (wall_clock64() - t0 > in.timeout_ticks) break;
-        for (int i = 0; i < in.hint_sleep; i++) __builtin_amdgcn_s_sleep(8);
-    }
-}
-
-template <int PRO, int GC, bool LL>
-__device__ __forceinline__ void duo_stage_x(const MatvecArgs &a, int n, int n4_pad, v4f (&gr)[GC], v4f (&xr)[LL ? 1 : GC],
-                                            float *xs, float *scratch)
-{
-    const int tid = threadIdx.x;
-    const int n4 = n >> 2;
-    v4f *xs4 = (v4f *)xs;
-    const v4f zero = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (LL) {
-        const LLPoll p = ll_poll_init(a.xin);
-        if (a.xin.hint_n != 0) {
-            if (tid < kHintLanes) ll_hint_wait(p, a.xin);
-            __syncthreads();
-        }
-#ifdef L2Z_TIMELINE
-        if (tid == 0) ((long long *)scratch)[8] = wall_clock64();  // scratch floats 16, 17: nothing else uses them
-#endif
-        constexpr int R = 4;
-        for (int j0 = tid; j0 < n4_pad; j0 += kDuo * R) {
-            v4u w[2 * R];
-#pragma unroll
-            for (int k = 0; k < R; k++) {
-                const int j = j0 + kDuo * k;
-                const int jc = j < n4 ? j : 0;  // past the end: any valid words, the value is dropped
-                w[2 * k] = ll_load2(p.slot, (size_t)4 * jc);
-                w[2 * k + 1] = ll_load2(p.slot, (size_t)4 * jc + 2);
-            }
-#pragma unroll
-            for (int k = 0; k < R; k++) {
-                const int j = j0 + kDuo * k;
-                if (j < n4_pad) {
-                    const v4f v = ll_wait4(p, j < n4 ? j : 0, w[2 * k], w[2 * k + 1]);
-                    xs4[j] = j < n4 ? v : zero;
-                }
-            }
-        }
-    } else {
-        // xr[]: this thread's float4 tid + 512 k of x, requested BEFORE the first weight batch (duo_xload: VMEM
-        // returns in order, x must not queue behind 8 KB of weights per wave)
-        const v4f *x4 = (const v4f *)a.x;
-#pragma unroll
-        for (int k = 0; k < (LL ? 1 : GC); k++) {
-            const int j = tid + kDuo * k;
-            if (j < n4_pad) xs4[j] = xr[k];
-        }
-        for (int j = tid + kDuo * GC; j < n4_pad; j += kDuo) xs4[j] = j < n4 ? x4[j] : zero;
-    }
-    __syncthreads();
-    if (PRO == PRO_RMS) {
-        if (tid < kBlock) {
-            float ss = 0.0f;
-            for (int j = tid; j < n4; j += kBlock) {
-                const v4f v = xs4[j];
-                ss = fmaf(v.x, v.x, ss);
-                ss = fmaf(v.y, v.y, ss);
-                ss = fmaf(v.z, v.z, ss);
-                ss = fmaf(v.w, v.w, ss);
-            }
-            ss = wave_sum(ss);
-            if ((tid & 63) == 0) scratch[tid >> 6] = ss;
-        }
-        __syncthreads();
-        float tot = scratch[0];
-#pragma unroll
-        for (int i = 1; i < kWaves; i++) tot += scratch[i];
-        float s = tot / (float)n;  // :452
-        s += 1e-5f;                // :453
-        s = 1.0f / sqrtf(s);       // :454
-        const v4f *g4 = (const v4f *)a.rms_w;
-#pragma unroll
-        for (int k = 0; k < GC; k++) {
-            const int j = tid + kDuo * k;
-            if (j < n4) {
-                v4f v = xs4[j];
-                v.x = (v.x * s) * gr[k].x;  // :462 values * scale * weights
-                v.y = (v.y * s) * gr[k].y;
-                v.z = (v.z * s) * gr[k].z;
-                v.w = (v.w * s) * gr[k].w;
-                xs4[j] = v;
-            }
-        }
-        for (int j = tid + kDuo * GC; j < n4; j += kDuo) {  // n > GC * 2048 floats
-            v4f v = xs4[j];
-            const v4f g = g4[j];
-            v.x = (v.x * s) * g.x;
-            v.y = (v.y * s) * g.y;
-            v.z = (v.z * s) * g.z;
-            v.w = (v.w * s) * g.w;
-            xs4[j] = v;
-        }
-        __syncthreads();
-    }
 }
 
 // in-place softmax over att[0..T)  (main.zig:687-706)

@@ -75,11 +75,6 @@ bool comm_p2p_args(const l2z_comm *c, float *buf, size_t count_per_rank, bool se
 LLIn comm_ll_in(const l2z_comm *c, int gi, size_t count_per_rank);
 // the peer-write transport is connected and not overridden by L2Z_COMM=rccl
 bool comm_uses_p2p(const l2z_comm *c);
-// A one-rank group whose arena is this process's own: the landing slots of the overlapped decode chain's
-// hand-overs (forward.cpp).  Freed with l2z_comm_free.  null + last error on failure.
-l2z_comm *comm_self_create(int device, size_t max_vector_floats);
-// its description for the producers (P2pArgs::self: they write this rank's own slot)
-void comm_self_args(const l2z_comm *c, float *buf, size_t count, P2pArgs *out);
 
 // ---- bulk all-gather of activation blocks (sharded prefill) ----
 // Every rank holds its [P, n_loc] block (contiguous) at stage + rank * P * n_loc; afterwards

@@ -28,11 +28,6 @@ struct LLIn {
     int *ctl;             // l2z_comm::d_ctl
     int *h_err;           // l2z_comm::h_err
     long long timeout_ticks;
-    // overlapped chain (matvec_duo_kernel): the word lane 0 of block b polls before the block sweeps the
-    // vector -- hint0 + (b % hint_n) * hint_stride, an element the producer writes in its last sweep.
-    // A hint only gates the polling traffic; every word still validates itself.  hint_n == 0: no gate.
-    unsigned hint0, hint_n, hint_stride;
-    int hint_sleep;       // s_sleep(8) instructions (512 clocks each) between polls of the hint word
 };
 
 void set_error(const char *fmt, ...);
@@ -90,7 +85,7 @@ struct ArgmaxArgs {
     float *x;
     int dim;
     int advance;             // 1: greedy step (write token/pos/x), 0: argmax only
-    int *epoch_ctl;          // overlapped chain: the pass ends here -- ctl[kCtlEpoch] += epoch_add (null: not)
+    int *epoch_ctl;          // this launch closes the pass of a shard group: ctl[kCtlEpoch] += epoch_add (null: not)
     int epoch_add;
 };
 
@@ -132,36 +127,8 @@ struct MatvecArgs {
     int push_gi;              // index of the gather the outputs belong to
     // x is a gathered vector that is read as LL words from this rank's landing slot (xin.slots != null)
     LLIn xin;
-    // EPI_RESID of an overlapped chain: the residual values are read as the LL words of an EARLIER hand-over
-    // (the launch that wrote the plain buffer may be in the other chain); slots == null: plain `resid`
-    LLIn resid_in;
-    int duo;                  // 1: matvec_duo_kernel (512-thread blocks, one per CU; wide rows only)
-    int tl_seq;               // launch number since the runstate was made (read by measurement builds only: L2Z_TIMELINE)
     int tail_skip;            // row kernel, n > 4096: out-of-row steps of a row's last batch load nothing (set by the launcher)
 };
-
-// engine.hip: a chunk of consecutive mat-vecs run by one persistent launch.  op[k].a is what launch_matvec would get
-// for mat-vec k (duo form): x plain for the first (written before the launch) or xin (LL words written by mat-vec
-// k - 1 of the same launch), resid or resid_in, push for every mat-vec whose output the next one reads.
-constexpr int kEngMaxOps = 4;
-struct EngOp {
-    MatvecArgs a;
-    int pro, epi;
-    int n_pairs;   // units (row pairs)
-    int nb;        // batches of 1024 float4 per row
-};
-struct EngChunk {
-    int n_ops;
-    int *ctl, *h_err;          // l2z_comm::d_ctl / h_err of the hand-overs
-    long long timeout_ticks;
-    const float *dummy;        // >= 2 KB of finite, cache-resident floats (what out-of-row steps read)
-    EngOp op[kEngMaxOps];
-};
-size_t engine_lds_bytes(int xs_floats);
-int engine_xs_floats(int n_max);
-bool engine_units_ok(int n_pairs, int grid);
-// d_chunk: device memory.  grid blocks of 576 threads, all of which must be resident at once (grid <= CUs)
-hipError_t launch_engine(const EngChunk *d_chunk, int grid, int xs_floats, hipStream_t st, int tl_seq = -1);  // tl_seq: measurement builds
 
 // main.zig:361-389: scores, softmax, att.V for the local heads of one layer
 struct AttnArgs {
@@ -207,8 +174,6 @@ hipError_t launch_matvec(const MatvecArgs &a, int pro, int epi, int max_blocks_p
                          hipStream_t st, int *out_grid = nullptr, bool *pushed = nullptr);
 // true if a launch with this width takes the vector kernels, which honour push and xin
 bool matvec_ll_supported(int n);
-// true if launch_matvec with MatvecArgs::duo set takes this width (matvec_duo_kernel: the overlapped decode chain)
-bool matvec_duo_supported(int n);
 // true if launch_attention / launch_attention_split will honour a.push (vector kernels only)
 bool attention_push_supported(const AttnArgs &a);
 int matvec_max_grid(int n_cus);
@@ -217,7 +182,7 @@ bool matvec_vector_width(int n);
 hipError_t launch_stream_read(const float *p, size_t n_floats, float *out, int n_cus, hipStream_t st);  // upper bound of the grid launch_matvec picks
 hipError_t launch_attention(const AttnArgs &a, int n_heads_local, hipStream_t st, int form = 0);
 // positions below this take the 256-thread speculative one-block-per-head form whatever seq_len is (attention.hip)
-int attention_short_pos(int head_size, int seq_len, bool all256 = false);
+int attention_short_pos(int head_size, int seq_len);
 // flash-decoding form: `nch` blocks per head, the last arriver combines (attention.hip)
 int attention_split_chunks(int n_heads_local, int n_cus);
 size_t attention_split_part_floats(int n_heads_local, int head_size, int nch);
@@ -226,10 +191,8 @@ bool attention_split_supported(const AttnArgs &a);
 // small: 256 threads per block instead of 1024 (positions below attention_split_wide_pos)
 hipError_t launch_attention_split(const AttnArgs &a, int n_heads_local, int nch, float *part,
                                   int *arrivals, hipStream_t st, bool small = false);
-int attention_split_wide_pos(int seq_len, bool all256 = false);
+int attention_split_wide_pos(int seq_len);
 hipError_t launch_argmax(const ArgmaxArgs &a, hipStream_t st);
-// ctl[0] += add by a one-thread launch (overlapped chain, passes that do not end in the argmax hand-over)
-hipError_t launch_epoch_advance(int *ctl, int add, hipStream_t st);
 hipError_t launch_set_state(int token, int pos, int *token_ptr, int *pos_ptr, const float *tok_emb,
                             float *x, int dim, hipStream_t st);
 hipError_t launch_rmsnorm(float *o, const float *x, const float *w, int n, hipStream_t st);

@@ -123,23 +123,6 @@ struct l2z_runstate {
                               // as LL words from the landing slot; no gather launch except the logits
     bool fused_qkv_attn = false;  // small models: qkv + RoPE + KV write + attention in one launch
     int max_blocks = 0;
-    // overlapped decode chain (world == 1, wide-row models; forward.cpp): the pass runs as two
-    // chains of launches on two streams, consecutive mat-vecs hand their vectors over as LL words in
-    // self_comm's landing slots (d_push then describes those)
-    bool attn_all256 = false;      // wide-row model: 256-thread attention forms at every position
-    bool duo = false;              // every mat-vec is matvec_duo_kernel (world == 1, attn_all256)
-    bool ovl = false;              // ... and the pass runs as two chains
-    int ovl_edges = 0;             // which hand-overs of a layer are overlapped (bit 0 attn->wo, 1 wo->w1|w3, 2 w1|w3->w2, 3 w2->qkv/cls)
-    l2z_comm *self_comm = nullptr; // owned: arena, epoch counter, error latch of the hand-overs
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_tail = nullptr;
-    // persistent decode launches (engine.hip): one chunk description per launch, in device memory, rebuilt when the
-    // weights object changes (they hold its pointers)
-    bool eng = false;
-    int eng_grid = 0, eng_xs_floats = 0;
-    l2z::EngChunk *d_eng = nullptr;   // [n_layers + 1]
-    uint64_t eng_w_uid = 0;
-    int tl_seq = 0;                // mat-vec launches enqueued so far (MatvecArgs::tl_seq, measurement builds)
     int tl_attn_seq = 0;           // attention launches enqueued so far (AttnArgs::tl_seq, measurement builds)
 };
 

@@ -356,193 +356,6 @@ __global__ __launch_bounds__(kBlock) void matvec_row_kernel(const MatvecArgs a)
     }
 }
 
-// ---------------------------------------------------------------------------
-// "Duo" form of the wide-row kernel, for the OVERLAPPED decode chain.  One 512-thread
-// block = two HALVES of four waves; half h of block b is exactly one matvec_row_kernel block with index
-// 2b + h of a grid of 2 * gridDim.x: the same units, the same thread -> column map, the same summation
-// order (so the same bits), the same linear sweep of the matrix.  What the halves share is the staged x:
-// one copy per CU instead of two -- half the LL words to sweep when x is a handed-over vector -- and the
-// footprint: every mat-vec of the chain is ONE 8-wave block per CU with <= 128 VGPRs and <= 48 KB of
-// LDS, so any two such blocks fit one CU and launch k + 1 can always become resident beside launch k
-// (and launch k can always finish becoming resident beside a waiting launch k + 1: no scheduling
-// deadlock, whatever the dispatcher's placement).
-//   LL: x arrives as {value, epoch} words written by the PREVIOUS launch of the chain, which may still
-//   be running (kernel_common.h duo_stage_x): the block issues its first weight batch, then lane 0 waits
-//   for the hint word, then everybody sweeps the vector.
-// rmsnorm: the sum of squares is formed by threads 0..255 in the 256-thread kernel's order.
-// ---------------------------------------------------------------------------
-constexpr int kDuoStash = 64;  // units per half whose outputs wait in LDS for the block's hand-over (more: pushed as they come)
-
-template <int PRO, int EPI, bool BIGX, bool LL>
-__global__ __launch_bounds__(kDuo, 4) void matvec_duo_kernel(const MatvecArgs a)
-{
-    constexpr int U = 4;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    MvLocals m = mv_locals<EPI>(a);
-    m.resid_pre = m.resid_slot != nullptr;
-    const int n4 = m.n >> 2;
-    const int n_batches = (n4 + kBlock * U - 1) / (kBlock * U);
-    const int n4_pad = n_batches * (kBlock * U);
-    float *xs = lds;
-    float *scratch = lds + 4 * n4_pad;            // kScratch floats
-    float *part = scratch + kScratch;             // [half][parity][2][kWaves] wave partials
-    const v4f *xs4 = (const v4f *)xs;
-    const int tid = threadIdx.x, half = tid >> 8, ht = tid & (kBlock - 1), lane = tid & 63, hw = ht >> 6;
-    const int n_units = m.n_pairs;
-    const int ustride = 2 * gridDim.x;            // virtual grid: 2 * gridDim.x <= n_units
-
-#ifdef L2Z_TIMELINE
-    long long tl_entry = wall_clock64(), tl_staged = 0, tl_first = 0, tl_done = 0, tl_acked = 0;
-#endif
-    constexpr int GC = BIGX ? 6 : 2;              // x / rmsnorm weights of this thread held in registers (n <= GC * 2048)
-    v4f gr[GC], xr[LL ? 1 : GC];
-    if constexpr (!LL) duo_xload<GC>(a.x, n4, xr);
-    if (PRO == PRO_RMS) {
-        const v4f *g4 = (const v4f *)a.rms_w;
-#pragma unroll
-        for (int k = 0; k < GC; k++) {
-            const int j = tid + kDuo * k;
-            gr[k] = (j < n4) ? g4[j] : v4f{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    int u = 2 * blockIdx.x + half;
-    const float *pa, *pb;
-    pair_rows<EPI>(m, u, pa, pb);   // clamped to the last pair when the half has no unit
-    v4f wa[U], wb[U];
-    auto load = [&](int cb) {  // columns cb + ht + 256k; validity is wave-uniform (n4 % 64 == 0)
-        const v4f *a4 = (const v4f *)pa + cb + ht, *b4 = (const v4f *)pb + cb + ht;
-        const int wbase = cb + (ht & ~63);
-#pragma unroll
-        for (int k = 0; k < U; k++) {
-            const bool in_row = wbase + kBlock * k < n4;  // wave-uniform
-            if (BIGX && a.tail_skip && !in_row) {  // as matvec_row_kernel: out-of-row steps load nothing
-                wa[k] = v4f{0.f, 0.f, 0.f, 0.f};
-                wb[k] = v4f{0.f, 0.f, 0.f, 0.f};
-                continue;
-            }
-            const int off = in_row ? kBlock * k : -(cb + (ht & ~63));
-            wa[k] = ldg_nt(a4 + off);
-            wb[k] = ldg_nt(b4 + off);
-        }
-    };
-    // the epilogue's own inputs: plain buffers of a launch that ended before this one began, or -- the
-    // residual of an overlapped chain -- LL words of an earlier hand-over (EpiIn::rw)
-    EpiIn ein = epi_prefetch<EPI>(m, u, ht == 0);
-    EpiIn ein_next = ein;
-    // LL residual: lane k of each half's first wave requests the two words of the half's k-th unit now -- one load
-    // instruction per half instead of an uncached load ahead of every unit's weight batch (loads return in order:
-    // the wave's weights waited behind it, and the block's per-unit barrier behind that wave)
-    v4u rs_mine = {0u, 0u, 0u, 0u};
-    if (EPI == EPI_RESID && m.resid_pre && ht < kDuoStash) {
-        const int uk = 2 * blockIdx.x + half + ht * ustride;
-        if (uk < n_units) rs_mine = ll_load2(m.resid_slot, (size_t)(2 * uk));
-    }
-    load(0);
-    duo_stage_x<PRO, GC, LL>(a, m.n, n4_pad, gr, xr, xs, scratch);
-    v4u *rsd = (v4u *)(part + 4 * (2 * kWaves) + 4 * kDuoStash);  // [half][kDuoStash] residual words as requested at entry
-    if (EPI == EPI_RESID && m.resid_pre && ht < kDuoStash) rsd[half * kDuoStash + ht] = rs_mine;  // read after >= 1 barrier
-    L2Z_TL(tl_staged);
-
-    // The loop is the row kernel's, with one difference: its trip count is half 0's (block-uniform: the
-    // barrier), so in the last sweep a half without a unit runs one unit's FMAs on whatever its registers
-    // hold and skips the epilogue -- no branch around the loads or the FMAs (a conditional consume kept
-    // hipcc from hoisting the next batch's loads above it: 72-82 VGPRs, one batch in flight, 4-9 % slower).
-    v4f acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
-    float best_v = -INFINITY;
-    int best_i = 0x7fffffff;
-    int b = 0, parity = 0, k_unit = 0;
-    float *stash = part + 4 * (2 * kWaves);       // [half][kDuoStash][2] outputs waiting for the hand-over
-    const bool stash_on = m.push != nullptr && (EPI == EPI_RESID || EPI == EPI_SWIGLU);
-    while (true) {
-#pragma unroll
-        for (int k = 0; k < U; k++) {
-            const v4f xv = xs4[b * (kBlock * U) + ht + kBlock * k];
-            acc_a = fma4(wa[k], xv, acc_a);
-            acc_b = fma4(wb[k], xv, acc_b);
-        }
-        const bool unit_done = (b + 1 == n_batches);
-        const int u_next = unit_done ? u + ustride : u;
-        const int b_next = unit_done ? 0 : b + 1;
-        const bool more = u_next < n_units;
-        const bool more0 = u_next - half < n_units;  // half 0 of this block
-        if (more) {
-            if (unit_done) {
-                pair_rows<EPI>(m, u_next, pa, pb);
-                ein_next = epi_prefetch<EPI>(m, u_next, ht == 0);
-            }
-            load(b_next * (kBlock * U));
-        }
-        if (unit_done) {
-            const float sa = wave_sum(hsum4(acc_a));
-            const float sb = wave_sum(hsum4(acc_b));
-            float *pp = part + (half * 2 + parity) * (2 * kWaves);
-            if (lane == 0) {
-                pp[hw] = sa;
-                pp[kWaves + hw] = sb;
-            }
-            __syncthreads();
-            if (ht == 0 && u < n_units) {
-                const float ta = ((pp[0] + pp[1]) + pp[2]) + pp[3];
-                const float tb = ((pp[kWaves] + pp[kWaves + 1]) + pp[kWaves + 2]) + pp[kWaves + 3];
-                float *st = (stash_on && k_unit < kDuoStash) ? stash + (half * kDuoStash + k_unit) * 2 : nullptr;
-                if (EPI == EPI_RESID && m.resid_pre)
-                    ein.rw = k_unit < kDuoStash ? rsd[half * kDuoStash + k_unit] : ll_load2(m.resid_slot, (size_t)(2 * u));
-                pair_epilogue<EPI>(m, u, ta, tb, true, ein, st);
-                if (EPI == EPI_ARGMAX) {
-                    const int ra_ = 2 * u, rb_ = ra_ + 1;
-                    if (ta > best_v || best_i == 0x7fffffff) { best_v = ta; best_i = ra_ + a.row_offset; }
-                    if (rb_ < m.total_rows && tb > best_v) { best_v = tb; best_i = rb_ + a.row_offset; }
-                }
-            }
-            if (k_unit == 0) L2Z_TL(tl_first);
-            k_unit++;
-            ein = ein_next;
-            parity ^= 1;
-            acc_a = v4f{0.f, 0.f, 0.f, 0.f};
-            acc_b = v4f{0.f, 0.f, 0.f, 0.f};
-        }
-        if (!more0) break;
-        u = u_next;
-        b = b_next;
-    }
-    L2Z_TL(tl_done);
-    if (stash_on) {
-        // The hand-over, once per block: lane k of each half's first wave stores the LL words of the half's k-th unit.
-        // Per-unit pushes sat in the streaming waves' own memory queue -- a system-scope store is acknowledged by the
-        // memory, microseconds under a saturated stream, and the wave's next wait on its weight loads is behind it.
-        __syncthreads();
-        const int u0 = 2 * blockIdx.x + half;
-        if (ht < kDuoStash) {
-            const int uk = u0 + ht * ustride;
-            if (uk < n_units) {
-                const float *sv = stash + (half * kDuoStash + ht) * 2;
-                if (EPI == EPI_SWIGLU) {
-                    p2p_ll_push(m.push, m.push_e, m.push_base + (size_t)uk, sv[0]);
-                } else {
-                    p2p_ll_push(m.push, m.push_e, m.push_base + (size_t)(2 * uk), sv[0]);
-                    if (2 * uk + 1 < m.total_rows) p2p_ll_push(m.push, m.push_e, m.push_base + (size_t)(2 * uk + 1), sv[1]);
-                }
-            }
-        }
-#ifdef L2Z_TIMELINE
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        L2Z_TL(tl_acked);
-#endif
-    }
-#ifdef L2Z_TIMELINE
-    if (threadIdx.x == 0 && (unsigned)a.tl_seq < (unsigned)kTlMax && blockIdx.x < kTlBlocks) {
-        long long *o = g_tl + ((size_t)a.tl_seq * kTlBlocks + blockIdx.x) * 8;
-        o[0] = (long long)EPI * 65536 + (m.n >> 2) + (LL ? (1LL << 32) : 0);
-        o[1] = tl_entry; o[2] = LL ? ((long long *)scratch)[8] : 0; o[3] = tl_staged; o[4] = tl_first; o[5] = tl_done; o[6] = tl_acked;
-        o[7] = gridDim.x;
-    }
-#endif
-    if (EPI == EPI_ARGMAX && ht == 0) {  // one candidate per virtual block (units ascend: first index kept)
-        a.part_val[2 * blockIdx.x + half] = best_v;
-        a.part_idx[2 * blockIdx.x + half] = best_i;
-    }
-}
-
 // Generic form: any n, any alignment (the reference's 3x3 / 2x12 known-answer
 // tests land here).  One pair per wave, scalar loads.
 template <int PRO, int EPI>
@@ -621,26 +434,6 @@ const void *mv_row_pick(int pro, int epi, bool big_x, bool ll)
     return nullptr;
 }
 
-template <int PRO, int EPI, bool LL>
-const void *mv_duo_fn(bool big_x)
-{
-    return big_x ? reinterpret_cast<const void *>(&matvec_duo_kernel<PRO, EPI, true, LL>)
-                 : reinterpret_cast<const void *>(&matvec_duo_kernel<PRO, EPI, false, LL>);
-}
-
-// the launches of the overlapped decode chain: qkv, wo / w2, w1|w3, classifier -- x plain or handed over
-const void *mv_duo_pick(int pro, int epi, bool big_x, bool ll)
-{
-#define L2Z_MVD(P, E)                                                  \
-    if (pro == P && epi == E) return ll ? mv_duo_fn<P, E, true>(big_x) : mv_duo_fn<P, E, false>(big_x);
-    L2Z_MVD(PRO_RMS, EPI_ROPE)
-    L2Z_MVD(PRO_NONE, EPI_RESID)
-    L2Z_MVD(PRO_RMS, EPI_SWIGLU)
-    L2Z_MVD(PRO_RMS, EPI_ARGMAX)
-#undef L2Z_MVD
-    return nullptr;
-}
-
 MvLaunch mv_pick_pe(int pro, int epi, int lpr, bool big_x, bool vec, bool ll)
 {
 #define L2Z_MV(P, E)                                                                      \
@@ -702,17 +495,6 @@ bool matvec_vector_width(int n)
 // vector kernels (16-byte aligned operands assumed: every buffer here is a hipMalloc or a row of one)
 bool matvec_ll_supported(int n) { return matvec_vector_width(n); }
 
-// widths matvec_duo_kernel takes: the wide-row kernel's, with x + scratch inside 48 KB of LDS (two such
-// blocks, or one beside any other kernel of the chain, always fit a CU)
-bool matvec_duo_supported(int n)
-{
-    if (n <= 0 || (n % 4) != 0) return false;
-    const int n4 = n >> 2;
-    if (n4 < 1024 || (n4 % 64) != 0 || !tunables().row_kernel) return false;
-    const int n4_pad = ((n4 + 1023) / 1024) * 1024;
-    return (size_t)(4 * n4_pad + kScratch + 8 * kWaves + 12 * kDuoStash) * sizeof(float) <= 64 * 1024;
-}
-
 hipError_t launch_stream_read(const float *p, size_t n_floats, float *out, int n_cus, hipStream_t st)
 {
     hipLaunchKernelGGL(stream_read_kernel, dim3(n_cus * 8), dim3(256), 0, st, (const v4f *)p, n_floats / 4, out);
@@ -740,29 +522,6 @@ hipError_t launch_matvec(const MatvecArgs &a_in, int pro, int epi, int max_block
     const bool use_row = vec && tn.row_kernel && n4 >= 1024 && (n4 % 64) == 0;
     const bool ll = a.xin.slots != nullptr;
     if (ll && !vec) return hipErrorNotSupported;  // callers ask matvec_ll_supported() first
-    if (a.duo) {  // overlapped decode chain: one 512-thread block per CU (callers ask matvec_duo_supported() first)
-        if (!vec || !matvec_duo_supported(a.n)) return hipErrorNotSupported;
-        const void *fn = mv_duo_pick(pro, epi, a.n > 4096, ll);
-        if (fn == nullptr) return hipErrorNotSupported;
-        const int n4_pad = ((n4 + 1023) / 1024) * 1024;
-        const size_t lds = (size_t)(4 * n4_pad + kScratch + 8 * kWaves + 12 * kDuoStash) * sizeof(float);
-        int resident = 2 * n_cus;  // virtual blocks (halves): one block of two per CU
-        if (tn.grid_cap > 0 && resident > tn.grid_cap) resident = tn.grid_cap;
-        int vgrid = n_pairs;
-        if (vgrid > resident) {
-            const int per_block = (n_pairs + resident - 1) / resident;
-            vgrid = (n_pairs + per_block - 1) / per_block;
-        }
-        // an even number of virtual blocks, every one with at least one unit
-        if (vgrid & 1) vgrid = (vgrid + 1 <= n_pairs && vgrid + 1 <= resident) ? vgrid + 1 : vgrid - 1;
-        if (vgrid < 2) return hipErrorNotSupported;
-        if (out_grid) *out_grid = vgrid;
-        if (epi == EPI_ROPE || a.rows2 != 0 || (epi != EPI_SWIGLU && a.rows1 != 0) || epi == EPI_ARGMAX) a.push = nullptr;
-        if (pushed) *pushed = a.push != nullptr;
-        a.tail_skip = tn.row_tail_skip;
-        void *args[] = {&a};
-        return hipLaunchKernel(fn, dim3(vgrid / 2), dim3(kDuo), args, lds, st);
-    }
     MvLaunch k = mv_pick_pe(pro, epi, lpr, a.n > 4096, vec, ll);
     if (use_row) k.fn = mv_row_pick(pro, epi, a.n > 4096, ll);
     if (k.fn == nullptr) return hipErrorInvalidValue;
@@ -827,12 +586,3 @@ hipError_t launch_matvec(const MatvecArgs &a_in, int pro, int epi, int max_block
 }
 
 }  // namespace l2z
-
-#ifdef L2Z_TIMELINE
-extern "C" int l2z_timeline_dump(long long *out, int max_launches)
-{
-    const int n = max_launches < l2z::kTlMax ? max_launches : l2z::kTlMax;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(l2z::g_tl), (size_t)n * l2z::kTlBlocks * 8 * sizeof(long long)) != hipSuccess) return 1;
-    return 0;
-}
-#endif

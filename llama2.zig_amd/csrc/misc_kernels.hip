@@ -105,8 +105,6 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const ArgmaxArgs a)
     }
 }
 
-__global__ void epoch_advance_kernel(int *ctl, int add) { ctl[0] += add; }
-
 // token/pos from the host + embedding copy (main.zig:295-296)
 __global__ void set_state_kernel(int token, int pos, int *token_ptr, int *pos_ptr,
                                  const float *tok_emb, float *x, int dim)
@@ -203,12 +201,6 @@ __global__ void copy_rows_kernel(float *dst, size_t dpitch, const float *src, si
 hipError_t launch_argmax(const ArgmaxArgs &a, hipStream_t st)
 {
     hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_epoch_advance(int *ctl, int add, hipStream_t st)
-{
-    hipLaunchKernelGGL(epoch_advance_kernel, dim3(1), dim3(1), 0, st, ctl, add);
     return hipGetLastError();
 }
 

@@ -222,8 +222,8 @@ bool prefill_usable(const l2z_runstate *s)
 {
     const l2z_config &c = s->cfg;
     if (c.dim % 4 != 0 || c.hidden_dim % 4 != 0 || s->sh.hs % 4 != 0 || s->sh.hs > 256) return false;
-    if (s->sh.world == 1) return true;
     if (s->sh.scheme_b) return false;  // column-sharded Wo / W2: the batched pass is built on row shards; prompts are stepped
+    if (s->sh.world == 1) return true;
     if (s->sh.dim_loc % 4 != 0 || s->sh.hid_loc % 4 != 0) return false;
     const size_t widest = (size_t)(c.dim > c.hidden_dim ? c.dim : c.hidden_dim);
     return comm_bulk_ok(s->comm, (size_t)kPrefillChunk * widest);

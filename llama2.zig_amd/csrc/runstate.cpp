@@ -46,12 +46,6 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
     s->fused_qkv_attn = sh.world == 1 && tn.fuse_small != 0 &&
                         fused_qkv_attn_supported(c.dim, c.n_heads, c.n_kv_heads, c.seq_len, g_cus);
     s->n_gathers = (sh.scheme_b ? 2 : 4) * c.n_layers + 1;
-    // Wide-row models (every mat-vec takes matvec_duo_kernel): 256-thread attention forms at every position -- what
-    // lets a waiting launch of the overlapped chain share a CU with the attention it waits behind.
-    // A function of the MODEL, not of the rank count or the mode, so sharded, unsharded, overlapped and
-    // single-chain passes pick the same form at the same position and keep the same bits.
-    s->attn_all256 = tn.duo != 0 && !s->fused_qkv_attn && matvec_duo_supported(c.dim) &&
-                     matvec_duo_supported(c.hidden_dim);
     if (comm_uses_p2p(comm)) {
         // the producers store straight into the peers' landing slots: they must hold the longest vector
         // (scheme B: every rank's whole partial [dim] vector lands in every slot)
@@ -106,8 +100,8 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
         s->attn_split_pos = mode > 0 ? 0 : 256;
         if (tn.attn_split_pos >= 0) s->attn_split_pos = tn.attn_split_pos;
         if (mode == 0 || c.seq_len <= s->attn_split_pos) nch = 0;
-        s->attn_split_wide_pos = attention_split_wide_pos(c.seq_len, s->attn_all256);
-        s->attn_short_pos = attention_short_pos(sh.hs, c.seq_len, s->attn_all256);
+        s->attn_split_wide_pos = attention_split_wide_pos(c.seq_len);
+        s->attn_short_pos = attention_short_pos(sh.hs, c.seq_len);
         if (nch > 1 && s->attn_short_pos > s->attn_split_pos) s->attn_short_pos = s->attn_split_pos;
         if (nch > 1) {
             s->attn_nch = nch;
@@ -121,7 +115,7 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
         AttnArgs aa = {};
         aa.q = s->q; aa.kcache = s->key_cache; aa.vcache = s->value_cache;
         aa.head_size = sh.hs; aa.kv_row = sh.hs; aa.kv_head = (size_t)c.seq_len * sh.hs;
-        const bool want_consume = tn.p2p_consume >= 0 ? tn.p2p_consume != 0 : (tn.engine != 0 || sh.world <= 2 || c.dim < 4096);
+        const bool want_consume = tn.p2p_consume >= 0 ? tn.p2p_consume != 0 : (sh.world <= 2 || c.dim < 4096);
         s->ll_consume = !sh.scheme_b && tn.p2p_push && want_consume && matvec_ll_supported(c.dim) &&
                         matvec_ll_supported(c.hidden_dim) && attention_push_supported(aa);
         P2pArgs t[4];
@@ -132,58 +126,6 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
         comm_p2p_args(comm, s->logits, (size_t)sh.v_loc, false, &t[3]);
         alloc((void **)&s->d_push, sizeof t);
         if (e == hipSuccess) e = hipMemcpy(s->d_push, t, sizeof t, hipMemcpyHostToDevice);
-    }
-    if (sh.world == 1 && s->attn_all256 && e == hipSuccess) {
-        AttnArgs aa = {};
-        aa.q = s->q; aa.kcache = s->key_cache; aa.vcache = s->value_cache;
-        aa.head_size = sh.hs; aa.kv_row = sh.hs; aa.kv_head = (size_t)c.seq_len * sh.hs;
-        s->duo = attention_push_supported(aa);
-    }
-    // the persistent decode launches: wide-row model, every mat-vec's units fit the blocks' lanes; sharded runs: the
-    // peer-write transport in its consumer-side form (the launches hand their vectors over as its words)
-    if (tn.engine != 0 && !sh.scheme_b && !s->fused_qkv_attn && matvec_duo_supported(c.dim) && matvec_duo_supported(c.hidden_dim) &&
-        (sh.world == 1 || (comm_uses_p2p(comm) && s->ll_consume)) && e == hipSuccess) {
-        // several ranks on ONE GPU (tests): every rank's blocks must be resident at once (a block ~ a CU)
-        int grid = g_cus;
-        if (tn.grid_cap > 0 && grid > tn.grid_cap / 2) grid = tn.grid_cap / 2;
-        auto fits = [&](int g) {
-            return g >= 1 && engine_units_ok((sh.dim_loc + 2 * sh.kvd_loc + 1) / 2, g) && engine_units_ok((sh.dim_loc + 1) / 2, g) &&
-                   engine_units_ok(sh.hid_loc, g) && engine_units_ok((sh.v_loc + 1) / 2, g);
-        };
-        // a narrow shard (N = 8: 256 row pairs of wo / w2 per rank) has fewer units than a CU-filling grid has halves: fewer
-        // blocks then -- every half must own a unit of every mat-vec
-        for (int g2 = grid; g2 >= 1; g2 /= 2)
-            if (fits(g2)) {
-                grid = g2;
-                break;
-            }
-        s->eng = fits(grid) && matvec_vector_width(c.dim);
-        s->eng_grid = grid;
-        s->eng_xs_floats = engine_xs_floats(std::max(c.dim, c.hidden_dim));
-        if (s->eng && engine_lds_bytes(s->eng_xs_floats) > 160 * 1024) s->eng = false;
-        if (s->eng) alloc((void **)&s->d_eng, (size_t)(c.n_layers + 1) * sizeof(EngChunk));
-    }
-    if (((s->duo && tn.overlap != 0) || (s->eng && sh.world == 1)) && e == hipSuccess) {
-        // the overlapped chain: a second stream, fork / join events, and this process's own landing slots
-        s->self_comm = comm_self_create(dev, (size_t)std::max(c.dim, c.hidden_dim));
-        if (s->self_comm == nullptr) {
-            l2z_runstate_free(s);
-            return L2Z_ERR_HIP;
-        }
-        P2pArgs t[4];
-        comm_self_args(s->self_comm, s->xb, (size_t)c.dim, &t[0]);
-        comm_self_args(s->self_comm, s->x, (size_t)c.dim, &t[1]);
-        comm_self_args(s->self_comm, s->hb, (size_t)c.hidden_dim, &t[2]);
-        comm_self_args(s->self_comm, s->logits, (size_t)c.vocab_size, &t[3]);  // never pushed: the slots do not hold it
-        alloc((void **)&s->d_push, sizeof t);
-        if (e == hipSuccess) e = hipMemcpy(s->d_push, t, sizeof t, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_tail, hipEventDisableTiming);
-        s->ovl = e == hipSuccess && s->duo && tn.overlap != 0 && !s->eng;
-        s->ovl_edges = tn.overlap_edges & 15;
-        if (e != hipSuccess) s->eng = false;
     }
     if (e != hipSuccess) {
         set_error("RunState allocation failed: %s", hipGetErrorString(e));
@@ -228,30 +170,21 @@ extern "C" void l2z_runstate_free(l2z_runstate *s)
     void *ptrs[] = {s->x, s->xb, s->hb, s->q, s->logits, s->key_cache, s->value_cache, s->rope,
                     s->d_token, s->d_pos, s->d_prompt, s->d_n_prompt, s->d_out_tokens, s->d_argmax,
                     s->d_probs, s->d_part_val, s->d_part_idx, s->d_attn_part, s->d_attn_cnt, s->pf_x, s->pf_xn, s->pf_q,
-                    s->pf_att, s->pf_h1, s->pf_stage, s->pf_tokens, s->d_push, s->pf_sk.part, s->pf_sk.cnt, s->d_eng, s->part};
+                    s->pf_att, s->pf_h1, s->pf_stage, s->pf_tokens, s->d_push, s->pf_sk.part, s->pf_sk.cnt, s->part};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->h_stage) (void)hipHostFree(s->h_stage);
-    if (s->stream2) {
-        (void)hipStreamSynchronize(s->stream2);
-        (void)hipStreamDestroy(s->stream2);
-    }
-    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
-    if (s->ev_join) (void)hipEventDestroy(s->ev_join);
-    if (s->ev_tail) (void)hipEventDestroy(s->ev_tail);
-    if (s->self_comm) l2z_comm_free(s->self_comm);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
 
-// Which decode structure this runstate will run (the opt-in forms of tunables.h can be refused by the shape or
-// the transport; a test that asks for one checks here that it got it): bit 0 paired mat-vec blocks (L2Z_DUO),
-// bit 1 two overlapped chains (L2Z_OVERLAP), bit 2 the persistent launches (L2Z_ENGINE), bit 3 sharding scheme B
-// (L2Z_SCHEME_B: column-sharded Wo / W2, all-reduces).
+// Which structure this runstate runs (a test that asks for an option checks here that it got it): bit 3 sharding
+// scheme B (L2Z_SCHEME_B: column-sharded Wo / W2, all-reduces).  Bits 0-2 named round 4's opt-in decode forms
+// (paired blocks, two chains, persistent launches), which were measured slower and removed: always 0.
 extern "C" int l2z_runstate_form(const l2z_runstate *s, int *form)
 {
     L2Z_CHECK(s != nullptr && form != nullptr, L2Z_ERR_INVALID, "l2z_runstate_form: bad arguments");
-    *form = (s->duo ? 1 : 0) | (s->ovl ? 2 : 0) | (s->eng ? 4 : 0) | (s->sh.scheme_b ? 8 : 0);
+    *form = s->sh.scheme_b ? 8 : 0;
     return L2Z_OK;
 }
 
@@ -390,6 +323,5 @@ extern "C" int l2z_synchronize(l2z_runstate *s)
     L2Z_HIP(hipSetDevice(s->device));
     L2Z_HIP(hipStreamSynchronize(s->stream));
     L2Z_TRY(comm_check(s->comm));
-    L2Z_TRY(comm_check(s->self_comm));
     return L2Z_OK;
 }

@@ -27,12 +27,6 @@ Tunables read_env()
     env_int("L2Z_ATTN_SHORT_POS", &t.attn_short_pos);
     env_int("L2Z_ATTN_SPLIT_WIDE_POS", &t.attn_split_wide_pos);
     env_int("L2Z_FUSE_SMALL", &t.fuse_small);
-    env_int("L2Z_OVERLAP", &t.overlap);
-    env_int("L2Z_OVERLAP_EDGES", &t.overlap_edges);
-    env_int("L2Z_OVERLAP_HINT", &t.overlap_hint);
-    env_int("L2Z_OVERLAP_HINT_SLEEP", &t.overlap_hint_sleep);
-    env_int("L2Z_DUO", &t.duo);
-    env_int("L2Z_ENGINE", &t.engine);
     env_int("L2Z_SCHEME_B", &t.scheme_b);
     env_int("L2Z_NO_GRAPH", &t.no_graph);
     env_int("L2Z_COMM_GRAPH", &t.comm_graph);
@@ -99,8 +93,8 @@ bool tunables_set(const char *name, long long v)
         {"L2Z_ATTN_BLOCK", &t.attn_block}, {"L2Z_ATTN_SPLIT", &t.attn_split},
         {"L2Z_ATTN_SPLIT_POS", &t.attn_split_pos}, {"L2Z_ATTN_SHORT_POS", &t.attn_short_pos}, {"L2Z_ATTN_SPLIT_WIDE_POS", &t.attn_split_wide_pos},
         {"L2Z_FUSE_SMALL", &t.fuse_small}, {"L2Z_NO_GRAPH", &t.no_graph},
-        {"L2Z_OVERLAP", &t.overlap}, {"L2Z_OVERLAP_EDGES", &t.overlap_edges}, {"L2Z_OVERLAP_HINT", &t.overlap_hint},
-        {"L2Z_OVERLAP_HINT_SLEEP", &t.overlap_hint_sleep}, {"L2Z_DUO", &t.duo}, {"L2Z_ENGINE", &t.engine}, {"L2Z_SCHEME_B", &t.scheme_b},
+        
+        {"L2Z_SCHEME_B", &t.scheme_b},
         {"L2Z_COMM_GRAPH", &t.comm_graph}, {"L2Z_COMM_RCCL", &t.prefer_rccl},
         {"L2Z_P2P_PUSH", &t.p2p_push}, {"L2Z_REDUCE_BLOCK", &t.reduce_block}, {"L2Z_P2P_CONSUME", &t.p2p_consume},
         {"L2Z_P2P_BULK_MB", &t.p2p_bulk_mb},

@@ -24,30 +24,18 @@ struct Tunables {
     int attn_short_pos = -1;   // L2Z_ATTN_SHORT_POS  positions below this take the 256-thread one-block-per-head kernel with the
                                //                     speculative first round whatever seq_len is (default: by head size, 0: never)
     int fuse_small = 1;        // L2Z_FUSE_SMALL      0: small models keep separate qkv / attention launches
-    // --- overlapped decode chain (forward.cpp, runstate.cpp) ---
-    int overlap = 1;           // L2Z_OVERLAP         0: one chain of launches on one stream (the duo mat-vecs and the attention
-                               //                     forms by position stay: same bits either way)
-    int overlap_edges = 15;    // L2Z_OVERLAP_EDGES   hand-overs of a layer that are overlapped: bit 0 attention -> wo, 1 wo -> w1|w3,
-                               //                     2 w1|w3 -> w2, 3 w2 -> next qkv / classifier
-    int overlap_hint = 1;      // L2Z_OVERLAP_HINT    0: waiting blocks poll their whole input vector instead of one hint word first
-    int overlap_hint_sleep = 2;  // L2Z_OVERLAP_HINT_SLEEP  s_sleep(8) instructions between polls of the hint word
-    int engine = 0;            // L2Z_ENGINE          1: wide-row models run wo, w1|w3, w2 and the next layer's q|k|v as ONE persistent launch per layer
-                               //                     (engine.hip: register-ring run-ahead, gatherer wave, in-launch hand-overs); same bits as the launch chain
-    int duo = 0;               // L2Z_DUO             1: wide-row models (dim >= 4096) take the 512-thread duo mat-vecs, 256-thread attention forms at every
-                               //                     position and -- with L2Z_OVERLAP -- the two-chain pass.  Measured slower than the default chain
-                               //                     of round 3 (203 / 218 vs 225 tok/s at the 7B shape, profiles/r04_overlap_*): an experiment, off
     // --- graphs / transport (runstate.cpp, comm.cpp, forward.cpp) ---
     int no_graph = 0;          // L2Z_NO_GRAPH        1: launch eagerly
     int comm_graph = 1;        // L2Z_COMM_GRAPH      0: RCCL collectives are launched eagerly, not captured
     int prefer_rccl = 0;       // L2Z_COMM=rccl       use RCCL even when the peer-write transport is connected
     int p2p_push = 1;          // L2Z_P2P_PUSH        1: producers push their outputs from their epilogues where consumers read the words
-                               //                     (consumer-side form, persistent launches); 2: also where a gather / reduce launch
+                               //                     (consumer-side form); 2: also where a gather / reduce launch
                                //                     collects them (slower, measured); 0: never (no consumer-side form then)
     int p2p_consume = -1;      // L2Z_P2P_CONSUME     1: consumers read their gathered input as LL words while staging x (no gather launches);
                                //                     0: a gather launch per gathered vector (consumers read plain buffers); -1 (default):
                                //                     by shape -- the consumer-side form for up to 2 ranks or rows narrower than 4096, gather
                                //                     launches beyond (one rank of N alone, 7B shape, profiles/r04_solo_rank.md: N = 2 equal,
-                               //                     N = 4 +13 %, N = 8 +27 % for the gather launches); the persistent launches imply 1
+                               //                     N = 4 +13 %, N = 8 +27 % for the gather launches)
     int reduce_block = 128;    // L2Z_REDUCE_BLOCK    threads per block of scheme B's reduce launch (64 ... 1024; one element per thread;
                                //                     one rank of 8 alone: 64 / 128 / 256 / 512 / 1024 threads -> 734 / 733 / 728 / 722 / 693 tok/s)
     long long p2p_timeout_s = 20;  // L2Z_P2P_TIMEOUT_S

@@ -3,7 +3,7 @@
 rank = an UPPER bound on tokens/s at N GPUs for each structure -- launches, pushes, polls, gather / reduce launches and
 graph replay included (scaling_model's per-kind sums leave those out); hand-over latency, rank skew and xGMI are not.
 usage: solo_rank.py [workload] [steps]            the table, N = 2 / 4 / 8 x every structure
-       solo_rank.py <workload> <steps> <N> <k>    only structure number k (0 .. 3) at N (for rocprofv3 --kernel-trace --stats)"""
+       solo_rank.py <workload> <steps> <N> <k>    only structure number k (0 .. 2) at N (for rocprofv3 --kernel-trace --stats)"""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 import numpy as np, __graft_entry__ as ge
@@ -13,9 +13,8 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 cfg, shared = {n: (c, sh) for n, c, sh in ck.iter_configs()}[wl]
 FORMS = [("A: consumer-side words (p2p-consume)", {"L2Z_P2P_CONSUME": 1}),
          ("A: gather launch per vector (p2p-gather)", {"L2Z_P2P_CONSUME": 0}),
-         ("A: persistent launches (p2p-engine)", {"L2Z_ENGINE": 1}),
          ("B: column shards + reduce launches (p2p-allreduce)", {"L2Z_SCHEME_B": 1})]
-RESET = {"L2Z_P2P_CONSUME": -1, "L2Z_ENGINE": 0, "L2Z_SCHEME_B": 0}
+RESET = {"L2Z_P2P_CONSUME": -1, "L2Z_SCHEME_B": 0}
 B.option_set("L2Z_PREFILL", 0)
 
 
@@ -40,7 +39,7 @@ def run(world, opts):
             t0 = time.perf_counter(); n = len(s.greedy_run(w, steps)); s.synchronize()
             best = max(best, n / (time.perf_counter() - t0))
         prof = None
-        if world == 8 and "L2Z_ENGINE" not in opts:   # in situ, an event pair around every launch (adds ~3 us to each)
+        if world == 8:   # in situ, an event pair around every launch (adds ~3 us to each)
             acc = {}
             for i in range(4):
                 for k, (ms, cnt) in s.profile_forward(1 + i, 8 + i, w).items():
@@ -67,8 +66,8 @@ for name, opts in FORMS:
     for world in (2, 4, 8):
         try:
             v, form = run(world, opts)
-            want = 4 if "L2Z_ENGINE" in opts else 8 if "L2Z_SCHEME_B" in opts else 0
-            cells.append(f"{v:.0f} ({v / base:.2f})" + ("" if (form & 12) == want else f" [form {form}!]"))
+            want = 8 if "L2Z_SCHEME_B" in opts else 0
+            cells.append(f"{v:.0f} ({v / base:.2f})" + ("" if (form & 8) == want else f" [form {form}!]"))
         except Exception as e:  # noqa: BLE001
             cells.append(f"failed: {str(e)[:40]}")
     print(f"| {name} | " + " | ".join(cells) + " |")

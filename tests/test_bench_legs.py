@@ -39,7 +39,7 @@ def test_multi_rank_bench_reports_every_leg_when_no_device_is_there(B):
     out = json.loads(lines[0])
     assert out["value"] is None and out["n_gpus"] == 2
     legs = out["comm"]["legs"]
-    assert [l["transport"] for l in legs] == ["rccl", "p2p-gather", "p2p-consume", "p2p-engine", "rccl-allreduce", "p2p-allreduce"]
+    assert [l["transport"] for l in legs] == ["rccl", "p2p-gather", "p2p-consume", "rccl-allreduce", "p2p-allreduce"]
     for l in legs:
         assert l["ok"] is False and l["exit_codes"] == [1, 1], l
     assert out["comm"]["rccl"]["initialised"] is False

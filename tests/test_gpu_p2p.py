@@ -56,13 +56,10 @@ def run_ranks(tmp_path, world, spec, env_extra=None, timeout=300):
 # rows narrower than 4096, L2Z_P2P_CONSUME=1 here);
 # gather: one gather launch per gathered vector, which also sends (L2Z_P2P_CONSUME=0); gather-push: the producers' epilogues
 # send, the gather launch only collects (L2Z_P2P_PUSH=2); nopush: no pushes anywhere (L2Z_P2P_PUSH=0: gather launches)
-# engine: the ranks run the persistent decode launches (engine.hip, L2Z_ENGINE=1): wo, w1|w3, w2 and the next q|k|v as one
-# launch per layer whose mat-vecs hand their vectors over as the same words, across the ranks as inside one
 CASES = ([(m, "consume") for m in MODELS] + [(MODELS[0], "gather"), (MODELS[4], "gather"), (MODELS[3], "nopush")] +
-         [(MODELS[0], "gather-push"), (MODELS[4], "gather-push")] +
-         [(MODELS[5], "engine"), (MODELS[4], "engine")])
+         [(MODELS[0], "gather-push"), (MODELS[4], "gather-push"), (MODELS[5], "gather")])
 MODE_ENV = {"consume": {"L2Z_P2P_CONSUME": "1"}, "gather": {"L2Z_P2P_CONSUME": "0"}, "gather-push": {"L2Z_P2P_CONSUME": "0", "L2Z_P2P_PUSH": "2"},
-            "nopush": {"L2Z_P2P_PUSH": "0"}, "engine": {"L2Z_ENGINE": "1"}}
+            "nopush": {"L2Z_P2P_PUSH": "0"}}
 
 
 @pytest.mark.parametrize("model,mode", CASES, ids=[f"{m[0]}-x{m[3]}-{mode}" for m, mode in CASES])
@@ -221,12 +218,10 @@ def test_bench_legs_on_one_gpu(gpu, tmp_path):
     assert p.returncode == 0 and len(lines) == 1, p.stdout.decode()[-3000:] + p.stderr.decode()[-3000:]
     out = json.loads(lines[0])
     legs = {l["transport"]: l for l in out["comm"]["legs"]}
-    assert set(legs) == {"rccl", "p2p-gather", "p2p-consume", "p2p-engine", "rccl-allreduce", "p2p-allreduce"}
+    assert set(legs) == {"rccl", "p2p-gather", "p2p-consume", "rccl-allreduce", "p2p-allreduce"}
     assert legs["p2p-allreduce"]["ok"] and legs["p2p-allreduce"]["scheme"] == "B" and legs["p2p-gather"]["scheme"] == "A"
     assert legs["p2p-allreduce"]["gathers"] == 2 * 12 + 1 and legs["p2p-gather"]["gathers"] == 4 * 12 + 1
     assert out["comm"]["scheme"] == "A" and out["comm"]["scheme_b"]["transport"] == "p2p-allreduce"
-    # dim 768 is too narrow for the persistent launches: the leg must say so instead of timing the consume chain twice
-    assert not legs["p2p-engine"]["ok"] and "persistent" in legs["p2p-engine"]["why"], legs["p2p-engine"]
     ok = [t for t, l in legs.items() if l["ok"]]
     assert "p2p-gather" in ok and "p2p-consume" in ok, legs
     for t in ok:
@@ -247,8 +242,8 @@ def test_solo_rank_runs_every_structure(gpu, ck, world):
     nothing: the peers' slices read as zeros)."""
     kw = dict(dim=4096, hidden_dim=8192, n_layers=2, n_heads=32, n_kv_heads=8, vocab_size=8192, seq_len=320)
     cfg = ck.Config(**kw)
-    forms = [({"L2Z_P2P_CONSUME": 1}, 0), ({"L2Z_P2P_CONSUME": 0}, 0), ({"L2Z_ENGINE": 1}, 4), ({"L2Z_SCHEME_B": 1}, 8)]
-    reset = {"L2Z_P2P_CONSUME": -1, "L2Z_ENGINE": 0, "L2Z_SCHEME_B": 0}
+    forms = [({"L2Z_P2P_CONSUME": 1}, 0), ({"L2Z_P2P_CONSUME": 0}, 0), ({"L2Z_SCHEME_B": 1}, 8)]
+    reset = {"L2Z_P2P_CONSUME": -1, "L2Z_SCHEME_B": 0}
     gpu.option_set("L2Z_P2P_TIMEOUT_S", 5)
     try:
         for opts, want in forms:
