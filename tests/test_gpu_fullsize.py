@@ -68,6 +68,24 @@ def test_7b_device_loop_equals_host_loop_and_is_deterministic(gpu, model7b):
     assert np.array_equal(s.logits(), lg1)
 
 
+def test_7b_decode_kernels_stay_at_their_perf_floor(gpu, model7b):
+    """Perf gate (round 5, after round 4's opt-in forms taxed the default chain by 1.3 % unnoticed): every kind of launch of
+    the 7B decode pass, its 32 launches back to back between one event pair (l2z_time_kind = rocprofv3's kernel durations),
+    must stay within `slack` of the durations committed in profiles/perf_floor.json.  Best of three passes: a kernel
+    that got slower is slower every time, a busy chip is not."""
+    import json, os
+    floor = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "perf_floor.json")))["llama2-7b"]
+    cfg, w, s = model7b
+    got, bad = {}, []
+    for kind, ref_us in floor["us_per_launch"].items():
+        us = min(s.time_kind(kind, floor["pos"], w, reps=4)[0] for _ in range(3)) * 1e3
+        got[kind] = round(us, 2)
+        if us > ref_us * (1.0 + floor["slack"]):
+            bad.append(f"{kind}: {us:.2f} us per launch, floor {ref_us} (+{floor['slack']:.0%})")
+    print("7B decode, us per launch back to back:", got)
+    assert not bad, "; ".join(bad)
+
+
 def test_7b_classifier_rows_vs_oracle(gpu, ck, orc, model7b):
     """logits[r] = wcls[r] . rmsnorm(x_final): re-derive sampled rows on the CPU from the
     device's own pre-classifier activations and the regenerated weight rows."""
