@@ -90,6 +90,10 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
     // r04_solo_rank.md: scheme B 580 -> 727 tok/s, gather launches 488 -> 649.  L2Z_P2P_PUSH=2 pushes there as well.)
     const bool can_push = p2p && (consume ? tn.p2p_push != 0 : (tn.p2p_push >= 2 && prof == nullptr));
     const bool sb = sh.scheme_b;
+    // greedy step of a shard group on the peer-write transport: the classifier leaves this rank's argmax candidates and
+    // the hand-over launch exchanges one pair per rank instead of the logits gather + 32000-logit scan (main.zig:715-726
+    // over the whole vocabulary all the same: larger value, then lower index)
+    const bool xchg = with_step && p2p && s->xchg_steps;
     const int n_g = s->n_gathers;
     int gi = 0;           // gathers issued so far in this pass
     bool pushed = false;  // the launch just made pushed its outputs itself
@@ -266,15 +270,26 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         a.rows0 = sh.v_loc; a.n = c.dim; a.rms_w = w->rms_final;
         x_in(a, s->x, gi, sh.dim_loc);
         a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.row_offset = sh.v0;
-        // single GPU, vector path: the launch also leaves one argmax candidate per block
-        const bool fuse = sh.world == 1 && matvec_vector_width(c.dim);
+        // vector path, single GPU or a shard's exchanging step: the launch also leaves one argmax candidate per block
+        // (an emulated rank timed kind by kind takes that form too: it is what a real rank's step launches)
+        const bool fuse = (sh.world == 1 || xchg || (only_kind >= 0 && with_step && s->comm && !s->comm->nccl && !s->comm->p2p)) &&
+                          matvec_vector_width(c.dim);
         int grid = 0;
-        push_to(a, 3);
+        if (!xchg) push_to(a, 3);
         L2Z_LAUNCH(KIND_CLS, launch_matvec(a, PRO_RMS, fuse ? EPI_ARGMAX : EPI_STORE, mb, g_cus, st,
                                            &grid, &pushed));
         s->n_part = fuse ? grid : 0;
+        // (a captured graph bakes its form in: run_forward restores the count that belongs to the graph it replays)
+        if (only_stage < 0 && only_kind < 0) (with_step ? s->n_part_step : s->n_part_fwd) = s->n_part;
     }
-    L2Z_TRY(gather(s->logits, sh.v_loc));
+    if (xchg) {  // hand-over n_g of the pass is the candidate exchange inside the argmax launch
+        stage++;
+        gi++;
+        pushed = false;
+        if (only_kind < 0) s->logits_partial = true;
+    } else {
+        L2Z_TRY(gather(s->logits, sh.v_loc));
+    }
     if (with_step && want() && kind(KIND_ARGMAX)) {
         ArgmaxArgs a = {};
         a.logits = s->logits; a.vocab = c.vocab_size; a.token_ptr = s->d_token;
@@ -282,6 +297,12 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
         a.pos_ptr = s->d_pos; a.prompt = s->d_prompt; a.n_prompt_ptr = s->d_n_prompt;
         a.out_tokens = s->d_out_tokens; a.argmax_out = s->d_argmax; a.tok_emb = w->tok_emb;
         a.x = s->x; a.dim = c.dim; a.advance = 1;
+        if (xchg && only_kind < 0) {
+            a.xchg = s->d_push + 3;
+            a.xchg_gi = comm_gi(lc, n_g);
+            a.epoch_ctl = lc->d_ctl;               // the exchange closes the pass: its epochs are used up
+            a.epoch_add = lc->solo ? 0 : n_g;      // (a solo rank's hand-overs all carry index 0)
+        }
         L2Z_LAUNCH(KIND_ARGMAX, launch_argmax(a, st));
     }
     return L2Z_OK;
@@ -363,11 +384,24 @@ int run_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, int pos)
               "l2z_comm_p2p_export/_connect), or drive emulated ranks with l2z_emu_transformer");
     L2Z_TRY(comm_check(s->comm));
     L2Z_TRY(ensure_graph(s, w, variant, with_step));
+    s->logits_partial = with_step && s->xchg_steps;
     if (s->use_graphs) {
+        s->n_part = with_step ? s->n_part_step : s->n_part_fwd;
         L2Z_HIP(hipGraphLaunch(with_step ? s->g_step[variant] : s->g_forward[variant], s->stream));
         return L2Z_OK;
     }
     return enqueue_forward(s, w, with_step, nullptr, -1, variant);
+}
+
+// After a greedy step that ended in the candidate exchange `logits` holds this rank's rows only: gather the rest, as a
+// pass of one hand-over (collective: every rank of the group calls whatever reads the whole vector, like every other call)
+int ensure_logits(l2z_runstate *s)
+{
+    if (!s->logits_partial) return L2Z_OK;
+    L2Z_TRY(comm_allgather_inplace(s->comm, s->logits, (size_t)s->sh.v_loc, 1, 1, false, s->stream));
+    s->logits_partial = false;
+    s->n_part = 0;  // the candidates named this rank's rows only
+    return L2Z_OK;
 }
 
 
@@ -395,6 +429,7 @@ extern "C" int l2z_argmax(l2z_runstate *s, int *out_token)
 {
     L2Z_CHECK(s && out_token, L2Z_ERR_INVALID, "l2z_argmax: null argument");
     L2Z_HIP(hipSetDevice(s->device));
+    L2Z_TRY(ensure_logits(s));
     ArgmaxArgs a = {};
     a.logits = s->logits; a.vocab = s->cfg.vocab_size; a.argmax_out = s->d_argmax; a.advance = 0;
     if (s->n_part > 0) { a.part_val = s->d_part_val; a.part_idx = s->d_part_idx; a.n_part = s->n_part; }
@@ -408,6 +443,7 @@ extern "C" int l2z_logits_read(l2z_runstate *s, float *out_logits)
 {
     L2Z_CHECK(s && out_logits, L2Z_ERR_INVALID, "l2z_logits_read: null argument");
     L2Z_HIP(hipSetDevice(s->device));
+    L2Z_TRY(ensure_logits(s));
     L2Z_HIP(hipMemcpyAsync(out_logits, s->logits, (size_t)s->cfg.vocab_size * sizeof(float),
                            hipMemcpyDeviceToHost, s->stream));
     L2Z_HIP(hipStreamSynchronize(s->stream));
@@ -421,6 +457,7 @@ extern "C" int l2z_probs_read(l2z_runstate *s, float temperature, float *out_pro
     L2Z_CHECK(s && out_probs, L2Z_ERR_INVALID, "l2z_probs_read: null argument");
     L2Z_CHECK(temperature > 0.0f, L2Z_ERR_INVALID, "l2z_probs_read: temperature %g (0 is the argmax path)", (double)temperature);
     L2Z_HIP(hipSetDevice(s->device));
+    L2Z_TRY(ensure_logits(s));
     if (s->d_probs == nullptr) L2Z_HIP(hipMalloc(&s->d_probs, (size_t)s->cfg.vocab_size * sizeof(float)));
     L2Z_HIP(launch_probs(s->d_probs, s->logits, s->cfg.vocab_size, temperature, s->stream));
     // through a pinned buffer: a copy into pageable memory is staged by the runtime anyway, slower

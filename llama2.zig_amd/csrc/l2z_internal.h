@@ -87,6 +87,12 @@ struct ArgmaxArgs {
     int advance;             // 1: greedy step (write token/pos/x), 0: argmax only
     int *epoch_ctl;          // this launch closes the pass of a shard group: ctl[kCtlEpoch] += epoch_add (null: not)
     int epoch_add;
+    // Shard group on the peer-write transport, greedy step ("a local-argmax + N-pair exchange"): the
+    // candidates are this rank's vocabulary rows only; the ranks exchange their (max, first index) pairs as LL words in the
+    // landing slots (hand-over xchg_gi of the pass, words 2r and 2r + 1 of rank r) and every rank picks the same winner --
+    // larger value, equal values: lower index (main.zig:720) -- instead of gathering 32000 logits to scan them.  null: not
+    const P2pArgs *xchg;
+    int xchg_gi;
 };
 
 // One fused mat-vec launch: up to 3 row-major (rowsJ, n) matrices sharing x.

@@ -101,6 +101,7 @@ struct l2z_runstate {
     float *d_part_val = nullptr;  // classifier launch's per-block argmax candidates
     int *d_part_idx = nullptr;
     int n_part = 0;               // 0: argmax scans the logits instead
+    int n_part_step = 0, n_part_fwd = 0;  // ... as left by the captured step / forward graphs (a shard's differ)
     float *d_attn_part = nullptr; // split attention: per (head, chunk) partials
     int *d_attn_cnt = nullptr;    // split attention: arrivals per local head (zero between launches)
     int attn_nch = 0;             // 0: one block per head at every position
@@ -121,6 +122,12 @@ struct l2z_runstate {
     int n_gathers = 0;        // collectives per forward pass at world > 1: 4 gathers per layer + logits (scheme B: 2 all-reduces per layer + logits)
     bool ll_consume = false;  // peer-write transport, consumer side: mat-vecs read their gathered input
                               // as LL words from the landing slot; no gather launch except the logits
+    // Greedy steps of a shard group on the peer-write transport end in a candidate exchange (ArgmaxArgs::xchg) instead
+    // of the logits gather: after such a step `logits` holds only this rank's rows, and the first call that reads the
+    // whole vector (l2z_logits_read, l2z_probs_read, l2z_argmax, l2z_runstate_read) gathers it -- a COLLECTIVE then:
+    // every rank of the group makes it, as every rank makes every other call
+    bool xchg_steps = false;
+    bool logits_partial = false;
     bool fused_qkv_attn = false;  // small models: qkv + RoPE + KV write + attention in one launch
     int max_blocks = 0;
     int tl_attn_seq = 0;           // attention launches enqueued so far (AttnArgs::tl_seq, measurement builds)
@@ -139,6 +146,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
                     int variant, int only_kind = -1);
 int attn_variant(const l2z_runstate *s, int pos);
 int run_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, int pos);
+int ensure_logits(l2z_runstate *s);  // gathers the logits if the last pass left only this rank's rows (see xchg_steps)
 void drop_graphs(l2z_runstate *s);
 
 // prefill_host.cpp

@@ -75,8 +75,11 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const ArgmaxArgs a)
         s_idx[tid >> 6] = bi;
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid < kWave) {
+        // every lane of the first wave forms the block's candidate (<= 16 wave candidates, in wave order)
         const int nw = blockDim.x >> 6;
+        best = s_val[0];
+        bi = s_idx[0];
         for (int w = 1; w < nw; w++) {
             if (s_idx[w] != 0x7fffffff &&
                 (bi == 0x7fffffff || s_val[w] > best || (s_val[w] == best && s_idx[w] < bi))) {
@@ -84,6 +87,62 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const ArgmaxArgs a)
                 bi = s_idx[w];
             }
         }
+        if (a.xchg != nullptr) {
+            // The ranks' candidates: lane p sends this rank's pair to rank p -- two LL words {bits, epoch}, each valid by
+            // itself -- and waits for rank p's pair in this rank's own slot; then the wave reduces the N pairs by the
+            // same rule.  Every rank sees the same N pairs, so every rank picks the same token.
+            const P2pArgs *x = a.xchg;
+            const int world = x->world, rank = x->rank;
+            const unsigned e = (unsigned)(x->ctl[kCtlEpoch] + a.xchg_gi);
+            const unsigned long long tag = (unsigned long long)e << 32;
+            const size_t off = (size_t)(e & 1u) * x->slot_floats;
+            float cv = -INFINITY;
+            int ci = 0x7fffffff;
+            bool late = false;
+            const bool dead = __hip_atomic_load(x->ctl + kCtlErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            if (tid == rank) {
+                cv = best;
+                ci = bi;
+            } else if (tid < world && !dead) {
+                unsigned long long *dst = (unsigned long long *)(x->peer_arena[tid] + kP2pFlagBytes) + off + 2 * (size_t)rank;
+                __hip_atomic_store(dst, tag | (unsigned long long)__float_as_uint(best), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(dst + 1, tag | (unsigned long long)(unsigned)bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned long long *src = (const unsigned long long *)(x->peer_arena[rank] + kP2pFlagBytes) + off + 2 * (size_t)tid;
+                const long long t0 = wall_clock64();
+                unsigned long long wv, wi;
+                for (;;) {
+                    wv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    wi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if ((unsigned)(wv >> 32) == e && (unsigned)(wi >> 32) == e) break;
+                    if (wall_clock64() - t0 > x->timeout_ticks ||
+                        __hip_atomic_load(x->ctl + kCtlErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                        late = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (!late) {
+                    cv = __uint_as_float((unsigned)wv);
+                    ci = (int)(unsigned)wi;
+                } else {
+                    __hip_atomic_store(x->ctl + kCtlErr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *x->err = 1 + tid;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(cv, o, 64);
+                const int oi = __shfl_xor(ci, o, 64);
+                if (oi != 0x7fffffff && (ci == 0x7fffffff || ov > cv || (ov == cv && oi < ci))) {
+                    cv = ov;
+                    ci = oi;
+                }
+            }
+            best = cv;
+            bi = ci;
+        }
+    }
+    if (tid == 0) {
         if (bi == 0x7fffffff) bi = 0;
         if (a.epoch_ctl) a.epoch_ctl[0] += a.epoch_add;  // every launch of the pass has read its epoch long ago
         if (a.argmax_out) *a.argmax_out = bi;

@@ -288,6 +288,7 @@ extern "C" int l2z_prefill(const int32_t *tokens, int n_tokens, int pos0, const 
     if (s->sh.world > 1)
         L2Z_TRY(comm_allgather_inplace(s->comm, s->logits, (size_t)s->sh.v_loc, s->n_gathers, s->n_gathers,
                                        false, s->stream));
+    s->logits_partial = false;
     L2Z_HIP(hipStreamSynchronize(s->stream));
     L2Z_TRY(comm_check(s->comm));
     s->host_pos = pos0 + n_tokens;

@@ -126,6 +126,9 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
         comm_p2p_args(comm, s->logits, (size_t)sh.v_loc, false, &t[3]);
         alloc((void **)&s->d_push, sizeof t);
         if (e == hipSuccess) e = hipMemcpy(s->d_push, t, sizeof t, hipMemcpyHostToDevice);
+        // greedy steps end in the candidate exchange where the classifier takes the vector kernels (their fused
+        // argmax epilogue) and the slots hold the 2 * world words
+        s->xchg_steps = tn.argmax_xchg != 0 && matvec_vector_width(c.dim) && sh.v_loc >= 2 && comm->slot_floats >= 2 * (size_t)sh.world;
     }
     if (e != hipSuccess) {
         set_error("RunState allocation failed: %s", hipGetErrorString(e));
@@ -207,6 +210,7 @@ extern "C" int l2z_runstate_read(l2z_runstate *s, const char *name, size_t offse
     L2Z_CHECK(p != nullptr, L2Z_ERR_INVALID, "l2z_runstate_read: unknown buffer '%s'", name);
     L2Z_CHECK(offset + count <= n, L2Z_ERR_INVALID, "l2z_runstate_read: out of range");
     L2Z_HIP(hipSetDevice(s->device));
+    if (k == "logits") L2Z_TRY(ensure_logits(s));
     L2Z_HIP(hipStreamSynchronize(s->stream));
     if (k == "key_cache" || k == "value_cache") {
         // offset / count address the REFERENCE's order (layer, pos, kv_dim) (main.zig:354); a layer of the

@@ -33,6 +33,7 @@ Tunables read_env()
     if (const char *e = getenv("L2Z_COMM")) t.prefer_rccl = strcmp(e, "rccl") == 0;
     env_int("L2Z_P2P_PUSH", &t.p2p_push);
     env_int("L2Z_REDUCE_BLOCK", &t.reduce_block);
+    env_int("L2Z_ARGMAX_XCHG", &t.argmax_xchg);
     env_int("L2Z_P2P_CONSUME", &t.p2p_consume);
     if (const char *e = getenv("L2Z_P2P_TIMEOUT_S"))
         if (*e) t.p2p_timeout_s = atoll(e);
@@ -96,7 +97,7 @@ bool tunables_set(const char *name, long long v)
         
         {"L2Z_SCHEME_B", &t.scheme_b},
         {"L2Z_COMM_GRAPH", &t.comm_graph}, {"L2Z_COMM_RCCL", &t.prefer_rccl},
-        {"L2Z_P2P_PUSH", &t.p2p_push}, {"L2Z_REDUCE_BLOCK", &t.reduce_block}, {"L2Z_P2P_CONSUME", &t.p2p_consume},
+        {"L2Z_P2P_PUSH", &t.p2p_push}, {"L2Z_REDUCE_BLOCK", &t.reduce_block}, {"L2Z_ARGMAX_XCHG", &t.argmax_xchg}, {"L2Z_P2P_CONSUME", &t.p2p_consume},
         {"L2Z_P2P_BULK_MB", &t.p2p_bulk_mb},
         {"L2Z_PREFILL", &t.prefill}, {"L2Z_PF_CHUNK", &t.pf_chunk},
         {"L2Z_PF_SKINNY_FORM", &t.pf_skinny_form}, {"L2Z_PF_TILE", &t.pf_tile},

@@ -36,6 +36,8 @@ struct Tunables {
                                //                     by shape -- the consumer-side form for up to 2 ranks or rows narrower than 4096, gather
                                //                     launches beyond (one rank of N alone, 7B shape, profiles/r04_solo_rank.md: N = 2 equal,
                                //                     N = 4 +13 %, N = 8 +27 % for the gather launches)
+    int argmax_xchg = 1;       // L2Z_ARGMAX_XCHG     0: greedy steps of a shard group gather all the logits and scan them (round 4's form)
+                               //                     instead of exchanging one (max, first index) candidate per rank (peer-write transport)
     int reduce_block = 128;    // L2Z_REDUCE_BLOCK    threads per block of scheme B's reduce launch (64 ... 1024; one element per thread;
                                //                     one rank of 8 alone: 64 / 128 / 256 / 512 / 1024 threads -> 734 / 733 / 728 / 722 / 693 tok/s)
     long long p2p_timeout_s = 20;  // L2Z_P2P_TIMEOUT_S

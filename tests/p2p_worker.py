@@ -17,6 +17,17 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
 
+def tie_classifier_rows(ck, cfg, blob, shared, rows) -> None:
+    """Classifier rows a, b (different ranks' shards) := 64 x row `base`, rows c, d := -64 x it: whichever sign the final
+    activations give, the largest logit is (at most steps) attained at TWO indices owned by different ranks, exactly (the
+    same row against the same x).  main.zig:720: the lower index must win -- across the ranks' candidate exchange as well."""
+    a, b, c, d, base = rows
+    assert not shared, "the tie is built in wcls (an unshared classifier)"
+    wcls = ck.carve(cfg, blob, shared)["wcls"]
+    v = np.float32(64.0) * wcls[base].copy()
+    wcls[a] = v; wcls[b] = v; wcls[c] = -v; wcls[d] = -v
+
+
 def main() -> None:
     rank, world, d, spec = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], json.load(open(sys.argv[4]))
     pkg = ge.load_package()
@@ -65,6 +76,8 @@ def main() -> None:
         comm.close()
         return
     blob = ck.synth_blob(cfg, shared, seed) if spec.get("blob", True) else None
+    if spec.get("tie_rows"):
+        tie_classifier_rows(ck, cfg, blob, shared, spec["tie_rows"])
     w = B.Weights(cfg, blob, shared, seed=seed, comm=comm)
     s = B.RunState(cfg, comm=comm)
     assert (s.form() & 8 != 0) == scheme_b, f"rank {rank}: runstate form {s.form()}, L2Z_SCHEME_B={scheme_b}"

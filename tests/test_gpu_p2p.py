@@ -87,6 +87,42 @@ def test_multiprocess_peer_write_gather_is_bit_identical(gpu, ck, tmp_path, mode
     s.close(); w.close()
 
 
+@pytest.mark.parametrize("world,mode", [(2, "consume"), (4, "gather"), (8, "gather"), (4, "scheme_b")])
+def test_argmax_tie_across_ranks_takes_the_lowest_index(gpu, ck, tmp_path, world, mode, options):
+    """main.zig:715-726 over a SHARDED vocabulary: greedy steps of a shard group exchange one (max, first index) candidate
+    per rank instead of gathering the logits (csrc/misc_kernels.hip argmax_kernel, ArgmaxArgs::xchg).  The classifier is
+    rigged so that the largest logit is attained at two indices that live on DIFFERENT ranks, bit for bit: every step must
+    produce the lower one, as the unsharded pass does (strict '>', :720), and the stepped API (full logits gather +
+    l2z_argmax) must agree."""
+    from p2p_worker import tie_classifier_rows
+    options(L2Z_FUSE_SMALL=0, L2Z_PREFILL=0)
+    kw = dict(dim=64, hidden_dim=176, n_layers=2, n_heads=8, n_kv_heads=8, vocab_size=512, seq_len=48)
+    cfg = ck.Config(**kw)
+    per = cfg.vocab_size // world
+    # a < b and c < d, each pair on two different ranks; the higher index sits on a LOWER... and on a higher rank both ways
+    rows = [per - 3, (world - 1) * per + 5, per + 7 if world > 2 else 9, (world - 1) * per + 1, 17]
+    spec = dict(cfg=kw, shared=False, seed=41, prompt=[], steps=40, tie_rows=rows)
+    env = {"consume": {"L2Z_P2P_CONSUME": "1"}, "gather": {"L2Z_P2P_CONSUME": "0"}, "scheme_b": {"L2Z_SCHEME_B": "1"}}[mode]
+    run_ranks(tmp_path, world, spec, env)
+    blob = ck.synth_blob(cfg, False, 41)
+    tie_classifier_rows(ck, cfg, blob, False, rows)
+    w, s = gpu.Weights(cfg, blob, False), gpu.RunState(cfg)
+    s.greedy_begin([])
+    toks = s.greedy_run(w, 40)
+    lg = s.logits()
+    tied = sum(int(t) in (rows[0], rows[2]) for t in toks)
+    assert tied >= 20 and not set(toks.tolist()) & {rows[1], rows[3]}, f"the rigged rows must win most steps, by their lower index: {toks}"
+    if int(toks[-1]) in (rows[0], rows[2]):
+        assert np.sum(lg == lg.max()) == 2, "the rigged classifier ties the maximum at exactly two indices"
+    for r in range(world):
+        o = np.load(tmp_path / f"out_{r}.npz")
+        assert np.array_equal(o["toks"], toks), f"rank {r}: {o['toks']} vs {toks}"
+        if mode != "scheme_b":
+            assert np.array_equal(o["logits"], lg), f"rank {r} logits (gathered on demand after the exchanging steps)"
+        assert int(o["am"]) == int(np.argmax(o["logits2"])), f"rank {r}: l2z_argmax after a full-logits pass"
+    s.close(); w.close()
+
+
 SCHEME_B = [(MODELS[0], "push"), (MODELS[1], "nopush"), (MODELS[3], "push"), (MODELS[3], "nopush"), (MODELS[5], "nopush"), (MODELS[4], "push")]
 
 
