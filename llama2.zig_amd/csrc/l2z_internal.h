@@ -261,6 +261,33 @@ hipError_t launch_prefill_attention(const float *q, int ldq, const float *kcache
                                     float *out, int ldo, int pos0, int P, int n_heads, int head_size,
                                     int kv_row, size_t kv_head, int kv_mul, int seq_len, hipStream_t st,
                                     int n_heads_model = 0);  // heads of the whole model when n_heads is a shard's
+// ---- prefill_panel.hip: chunks of <= 32 tokens of matrices that stream from HBM (K ranges with a resident X panel) ----
+enum PanelEpi { PANEL_STORE = 0, PANEL_RESID = 1, PANEL_SWIGLU = 2, PANEL_QKV = 3 };
+struct PanelProduct {
+    const float *x;      // [P, K]
+    int ldx;
+    const float *w0, *w1, *w2;   // up to three [rows, K] matrices sharing x (unused: null, 0 rows); W1 | W3 interleaved = one matrix
+    int rows0, rows1, rows2;
+    int P, K;
+    int mode;            // PanelEpi
+    float *out;          // STORE / RESID: [P, ldo]; SWIGLU: [P, ldo], rows / 2 gated values; QKV: q [P, ldo]
+    int ldo;
+    const float *res;    // RESID: out = res + product
+    int ldres;
+    float *xn;           // RESID, optional: xn[P, N] = rmsnorm(out) * rms_w in the same launch (prefill_panel_can_fuse_rms, ldo == N)
+    const float *rms_w;
+    float *outk, *outv;  // QKV: the layer's key / value caches (rows1 == rows2 features each)
+    int ldkv, head_size, pos0;
+    size_t kv_head_stride;
+    const float2 *rope;
+};
+// a function of the WHOLE model's matrix (n_whole rows) and the chunk length: a rank's shard takes what the unsharded pass takes
+bool prefill_panel_shape(long long n_whole, int P, int K);
+bool prefill_panel_can_fuse_rms(int n);
+int prefill_panel_max_tokens();
+// hipErrorNotSupported: this rank's rows / pointers / workspace do not take the kernel (rows % 16, alignment) -- callers that
+// asked prefill_panel_shape first treat that as an error on a shard (the unsharded pass would have taken it)
+hipError_t launch_prefill_panel(const PanelProduct &p, int n_cus, const SplitKWs *ws, hipStream_t st);
 int prefill_tile_form(int N, int P, int pair);  // 0: 128x64, 1: 64x64, 2: 32x64, 3: 32x32, 4: 128x128
 size_t matvec_lds_bytes(int n);
 

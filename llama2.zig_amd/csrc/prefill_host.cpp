@@ -111,8 +111,37 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
     const int sk_wo = prefill_split_k(dim, P, dim, false), sk_w2 = prefill_split_k(dim, P, hid, false);
     const int sk_h1 = prefill_split_k(hid, P, dim, true);
     const SplitKWs *ws = &s->pf_sk;
+    // Chunks of <= 32 tokens of matrices that stream from HBM: the K-range panel kernel (prefill_panel.hip), chosen from
+    // the WHOLE model's matrix so that a shard takes what the unsharded pass takes.  Its wo / W2 launches leave the next
+    // rmsnorm done as well (unsharded passes): pf_xn_ready.
+    const bool fuse_rms = !sharded && tunables().pf_panel_fuse != 0 && prefill_panel_can_fuse_rms(dim);
+    auto panel = [&](PanelProduct &pp, long long n_whole, bool *taken) -> int {
+        *taken = false;
+        if (!prefill_panel_shape(n_whole, P, pp.K)) return L2Z_OK;
+        pp.P = P;
+        const hipError_t e = launch_prefill_panel(pp, g_cus, ws, st);
+        if (e == hipErrorNotSupported) return L2Z_OK;  // this rank's rows / workspace do not take it: the forms below
+        L2Z_HIP(e);
+        *taken = true;
+        return L2Z_OK;
+    };
+    bool taken = false;
+    if (k == PF_ATT || k == PF_H1) {   // :305 / :398 (unless the launch before has left it: same arithmetic)
+        if (!s->pf_xn_ready)
+            L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, s->pf_x, (k == PF_ATT ? w->rms_att : w->rms_ffn) + (size_t)l * dim, dim, P, st));
+        s->pf_xn_ready = false;
+    }
     if (k == PF_ATT) {
-        L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, s->pf_x, w->rms_att + (size_t)l * dim, dim, P, st));  // :305
+        {
+            PanelProduct pp = {};
+            pp.x = s->pf_xn; pp.ldx = dim; pp.K = dim;
+            pp.w0 = w->wq + (size_t)l * sh.dim_loc * dim; pp.w1 = w->wk + (size_t)l * kvd * dim; pp.w2 = w->wv + (size_t)l * kvd * dim;
+            pp.rows0 = sh.dim_loc; pp.rows1 = kvd; pp.rows2 = kvd;
+            pp.mode = PANEL_QKV; pp.out = s->pf_q; pp.ldo = sh.dim_loc; pp.outk = kc; pp.outv = vc; pp.ldkv = kvd;
+            pp.head_size = hs; pp.pos0 = pos0; pp.kv_head_stride = kvh_stride; pp.rope = s->rope;
+            L2Z_TRY(panel(pp, (long long)dim + 2 * kvd_whole, &taken));
+        }
+        if (!taken) {
         // q of the local heads ([P, dim_loc]) and the k / v rows of the local kv heads: one launch where
         // the tile kernel takes the shape (:308-358), else three
         const float *wq = w->wq + (size_t)l * sh.dim_loc * dim, *wk = w->wk + (size_t)l * kvd * dim,
@@ -136,18 +165,34 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
         } else {
             L2Z_HIP(qe);
         }
+        }
         L2Z_HIP(launch_prefill_attention(s->pf_q, sh.dim_loc, kc, vc, out, ldo, pos0, P, sh.heads_loc, hs,
                                          hs, kvh_stride, c.n_heads / c.n_kv_heads, c.seq_len, st, c.n_heads));  // :361-389
     } else if (k == PF_WO) {
         const float *res = s->pf_x + sh.dim0;
+        {
+            PanelProduct pp = {};
+            pp.x = s->pf_att; pp.ldx = dim; pp.K = dim; pp.w0 = w->wo + (size_t)l * sh.dim_loc * dim; pp.rows0 = sh.dim_loc;
+            pp.mode = PANEL_RESID; pp.out = out; pp.ldo = ldo; pp.res = res; pp.ldres = dim;
+            if (fuse_rms) { pp.xn = s->pf_xn; pp.rms_w = w->rms_ffn + (size_t)l * dim; }  // :398 behind :395
+            L2Z_TRY(panel(pp, dim, &taken));
+            if (taken) s->pf_xn_ready = fuse_rms;
+        }
+        if (!taken)
         L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_att, dim, w->wo + (size_t)l * sh.dim_loc * dim, out, ldo,
                                     P, sh.dim_loc, dim, pos0, s->rope, hs, st, res, dim, sh.world, 0, sk_wo, ws));   // :392-395
     } else if (k == PF_H1) {
-        L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, s->pf_x, w->rms_ffn + (size_t)l * dim, dim, P, st));  // :398
         // :405-416: W1 and W3 in one launch with silu(a) * b as its epilogue where the tile kernel
         // takes the shape, else two GEMMs, the second one merging into the first one's output
         // W1 | W3 share one slot of the device blob, rows alternating: rows of either are 2 dim apart
         const float *w1 = w->w1 + (size_t)l * sh.hid_loc * 2 * dim, *w3 = w->w3 + (size_t)l * sh.hid_loc * 2 * dim;
+        {
+            PanelProduct pp = {};   // the shared slot as ONE matrix of 2 hid_loc rows: row 2p = W1 row p, 2p + 1 = W3 row p
+            pp.x = s->pf_xn; pp.ldx = dim; pp.K = dim; pp.w0 = w1; pp.rows0 = 2 * sh.hid_loc;
+            pp.mode = PANEL_SWIGLU; pp.out = out; pp.ldo = ldo;
+            L2Z_TRY(panel(pp, 2LL * hid, &taken));
+        }
+        if (taken) return L2Z_OK;
         const hipError_t pe = launch_prefill_gemm_swiglu_pair(s->pf_xn, dim, w1, w3, out, ldo, P, sh.hid_loc, dim, st, sh.world,
                                                               sk_h1, ws, 2 * dim);
         if (pe == hipErrorNotSupported) {
@@ -160,6 +205,16 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
         }
     } else {
         const float *res = s->pf_x + sh.dim0;
+        {
+            PanelProduct pp = {};
+            pp.x = s->pf_h1; pp.ldx = hid; pp.K = hid; pp.w0 = w->w2 + (size_t)l * sh.dim_loc * hid; pp.rows0 = sh.dim_loc;
+            pp.mode = PANEL_RESID; pp.out = out; pp.ldo = ldo; pp.res = res; pp.ldres = dim;
+            const bool fuse_next = fuse_rms && l + 1 < c.n_layers;   // the next layer's :305 behind :422
+            if (fuse_next) { pp.xn = s->pf_xn; pp.rms_w = w->rms_att + (size_t)(l + 1) * dim; }
+            L2Z_TRY(panel(pp, dim, &taken));
+            if (taken) s->pf_xn_ready = fuse_next;
+        }
+        if (!taken)
         L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_h1, hid, w->w2 + (size_t)l * sh.dim_loc * hid, out, ldo,
                                     P, sh.dim_loc, hid, pos0, s->rope, hs, st, res, dim, sh.world, 0, sk_w2, ws));   // :419-422
     }
@@ -172,6 +227,7 @@ int prefill_begin_chunk(l2z_runstate *s, const l2z_weights *w, const int32_t *to
     // cut short (a peer-write wait that timed out, a failed launch) must not leave a later one a half-counted tile
     if (s->pf_sk.cnt)
         L2Z_HIP(hipMemsetAsync(s->pf_sk.cnt, 0, (size_t)s->pf_sk.cnt_ints * sizeof(int), s->stream));
+    s->pf_xn_ready = false;
     L2Z_HIP(hipMemcpyAsync(s->pf_tokens, tokens, (size_t)P * 4, hipMemcpyHostToDevice, s->stream));
     L2Z_HIP(launch_prefill_embed(s->pf_x, w->tok_emb, s->pf_tokens, s->cfg.dim, P, s->stream));  // :295
     return L2Z_OK;

@@ -1,0 +1,384 @@
+// prefill_panel.hip -- the GEMM of the batched prompt pass for SHORT chunks (P <= 32 tokens) of matrices that stream from
+// HBM (round 5): weight-streaming bound like the decode mat-vec, so the kernel is built around the W stream and nothing
+// else comes into a CU twice.
+//
+// prefill_skinny.hip's forms give a block 16 (or 2 x 16) rows of W and ALL of K, so every block re-reads the whole X
+// ([P, K], from L2) beside its rows: 1 byte of X per 1-2 bytes of W into every CU, and the W stream stalls at 4.4-5.2 TB/s
+// (a CU takes in ~13-15 bytes per cycle of W + X together).  Here the product is cut the other way:
+//   * K is cut into RANGES of 512 (kPnRange; the last one of a row may be shorter: K % 128 == 0).  A block works on ONE
+//     range at a time and keeps that range of X -- the "panel", [16 TMS tokens][512] -- resident in LDS; what streams
+//     through the CU is W alone, rows of 512-byte pieces, 64 rows per work item.
+//   * A work item is (range, 64 rows): wave w of the block's four owns rows 16 w .. 16 w + 15 of it, brings their 128-k
+//     stages in through its OWN ring of three 8-KB LDS buffers (direct-to-LDS loads, non-temporal) and multiplies them
+//     against the panel on MFMA 16x16x4 (A = X: 16 tokens, B = W: 16 rows).  The waves share nothing but the panel: no
+//     barrier in the loop, a wave's loads run two stages (16 KB) ahead of its multiplies ACROSS item boundaries.
+//     Items are ordered range-major and dealt in equal contiguous spans to one persistent block per CU, so a block
+//     changes its panel at most a few times per launch (barrier, reload, barrier).
+//   * The block leaves the range's partial products in part[range][token][row]; a second launch (panel_reduce*) adds
+//     the ranges IN RANGE ORDER and runs the epilogue of the product -- RoPE + q / KV-cache rows (main.zig:336-358),
+//     residual (:395 / :422) with the NEXT rmsnorm fused behind it (:398 / :305: one launch instead of two), SiLU * mul
+//     (:411-416).  Partial traffic is P x N x ranges x 8 bytes: 1-6 % of the W bytes at 16-32 tokens.
+// Arithmetic: an output is the sum over ranges, in range order, of MFMA chains in (stage, u, c) order -- a function of K
+// alone: not of the rows a rank owns (row-sharded == unsharded, bit for bit), not of P or the token's place in its tile.
+//
+// LDS: panel 32 / 64 KB (TMS 1 / 2; rows unpadded, float4 slots XOR-swizzled by token & 7 on the SOURCE address of the
+// direct loads, like the tile GEMM) + 4 rings x 3 x 8 KB (rows of 128 floats, slots swizzled by row & 7): 128 / 160 KB,
+// one block per CU.  ds_read_b128 phases of 8 lanes (rows / tokens j .. j + 7) then touch 8 different 16-byte chunks.
+#include "prefill_common.h"
+
+namespace l2z {
+namespace {
+
+constexpr int kPnStage = 128;                 // k per ring stage: a row's piece is 512 bytes, a wave-wide load is two rows
+constexpr int kPnRange = 512;                 // k per range: four stages
+constexpr int kPnDepth = 3;                   // ring buffers per wave
+constexpr int kPnStageFloats = 16 * kPnStage; // one ring buffer: 16 rows x 128
+constexpr int kPnLoads = 8;                   // wave-wide loads per stage
+
+struct PanelArgs {
+    const float *x;   // [P, K], ldx floats per row
+    int ldx;
+    // up to three row-major [rows, K] matrices (K floats per row) sharing x: the launch's features are their rows, in
+    // order (q | k | v; W1 and W3 row-interleaved are ONE matrix of 2 hidden rows: the device layout)
+    const float *w0, *w1, *w2;
+    int rows0, rows1, rows2;
+    int P, K;
+    float *part;      // [ranges][16 TMS][N]
+    int n_groups;     // groups of 64 rows
+    int n_items;      // ranges * n_groups
+};
+
+__device__ __forceinline__ int pn_range_stages(int K, int r)
+{
+    const int left = K - r * kPnRange;
+    return (left < kPnRange ? left : kPnRange) / kPnStage;
+}
+
+template <int TMS>
+__global__ __launch_bounds__(256) void prefill_panel(const PanelArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    float *panel = smem;                                                       // [16 TMS][512], swizzled
+    float *ring = smem + 16 * TMS * kPnRange + wave * (kPnDepth * kPnStageFloats);
+    const int N = a.rows0 + a.rows1 + a.rows2;
+    const int i0 = (int)((long long)blockIdx.x * a.n_items / gridDim.x);
+    const int i1 = (int)((long long)(blockIdx.x + 1) * a.n_items / gridDim.x);
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+
+    // ---- producer side: this wave's loads, one stage at a time, running ahead of its multiplies ----
+    // Load i of a stage brings rows 2i, 2i + 1 of the wave's 16 (lane >> 5 picks the row, lane & 31 the PHYSICAL float4
+    // slot, which holds logical slot ^ (row & 7)).  The 16 rows lie in one matrix (rows % 16 == 0), so a lane's source is
+    // a wave-uniform row-0 pointer + a per-lane offset that never changes: no per-item pointer tables.
+    size_t loff[kPnLoads];
+#pragma unroll
+    for (int i = 0; i < kPnLoads; i++) {
+        const int jl = 2 * i + (lane >> 5);
+        loff[i] = (size_t)jl * (size_t)a.K + (size_t)(4 * ((lane & 31) ^ (jl & 7)));
+    }
+    int p_item = i0, p_st = 0, p_ns = 0, p_buf = 0, issued = 0;
+    const float *p_base = a.w0;  // row 0 of the wave's 16 at k = the range's start
+    auto producer_item = [&]() {
+        const int r = p_item / a.n_groups, g = p_item - r * a.n_groups;
+        p_ns = pn_range_stages(a.K, r);
+        int row = g * 64 + wave * 16;
+        row = row < N ? row : N - 16;                        // a wave past the end: the last 16 rows again (never stored)
+        const bool s1 = row >= a.rows0, s2 = row >= a.rows0 + a.rows1;
+        const float *base = s1 ? a.w1 : a.w0;
+        base = s2 ? a.w2 : base;
+        row -= s2 ? a.rows0 + a.rows1 : (s1 ? a.rows0 : 0);
+        p_base = base + (size_t)row * (size_t)a.K + (size_t)r * kPnRange;
+    };
+    auto issue_one = [&]() {
+        if (p_item >= i1) return;
+        float *dst = ring + p_buf * kPnStageFloats;
+        const float *src = p_base + p_st * kPnStage;
+#pragma unroll
+        for (int i = 0; i < kPnLoads; i++) lds_dma16_nt(src + loff[i], dst + i * 256);
+        p_buf = p_buf + 1 == kPnDepth ? 0 : p_buf + 1;
+        issued++;
+        if (++p_st == p_ns) {
+            p_st = 0;
+            if (++p_item < i1) producer_item();
+        }
+    };
+    // ---- the panel: range r of X, all 16 TMS token rows (tokens past P: the last token; never stored) ----
+    auto load_panel = [&](int r) {
+        const int klen = pn_range_stages(a.K, r) * kPnStage;
+        for (int t = wave; t < 32 * TMS; t += 4) {              // wave-wide load t: half h of token row t / 2
+            const int tok = t >> 1, h = t & 1;
+            const int logical = (64 * h + lane) ^ (tok & 7);
+            int kk = 4 * logical;
+            kk = kk < klen ? kk : klen - 4;                     // (a short last range: the piece past its end is never read)
+            const float *src = a.x + (size_t)(tok < a.P ? tok : a.P - 1) * (size_t)a.ldx + (size_t)r * kPnRange + kk;
+            lds_dma16(src, panel + tok * kPnRange + 256 * h);
+        }
+    };
+
+    v4f acc[TMS];
+#pragma unroll
+    for (int tm = 0; tm < TMS; tm++) acc[tm] = zero;
+    if (i0 < i1) producer_item();
+    issue_one();
+    issue_one();
+    int c_item = i0, c_st = 0, c_buf = 0, consumed = 0, cur_range = -1;
+    while (c_item < i1) {
+        const int r = c_item / a.n_groups;
+        const int ns = pn_range_stages(a.K, r);
+        if (c_st == 0 && r != cur_range) {  // block-uniform: every wave walks the same items
+            __syncthreads();                // nobody reads the old panel any more
+            load_panel(r);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the ring's loads in flight land with it)
+            __syncthreads();
+            cur_range = r;
+        } else {
+            // stage `consumed` of this wave has landed: what may still fly are the stages issued after it
+            const int younger = issued - consumed - 1;
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kPnLoads) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPnLoads) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the operand reads of the stage before have retired: its buffer is free
+        issue_one();                                        // two stages ahead, into that buffer
+        const v4f *wst = (const v4f *)(ring + c_buf * kPnStageFloats);
+        const v4f *xp = (const v4f *)panel;
+        const int sw = j & 7;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {  // k = 16 u + 4 q + c of the stage, A and B alike
+            const int slot = 4 * u + q;
+            const v4f b = wst[j * 32 + (slot ^ sw)];
+            v4f xa[TMS];
+#pragma unroll
+            for (int tm = 0; tm < TMS; tm++) xa[tm] = xp[(16 * tm + j) * (kPnRange / 4) + ((c_st * 32 + slot) ^ sw)];
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int tm = 0; tm < TMS; tm++)
+                    acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[tm][c], b[c], acc[tm], 0, 0, 0);
+        }
+        c_buf = c_buf + 1 == kPnDepth ? 0 : c_buf + 1;
+        consumed++;
+        if (++c_st == ns) {
+            // the item's partial products: lane (j, q), register i holds token 16 tm + 4 q + i of row j
+            const int g = c_item - r * a.n_groups;
+            const int row = g * 64 + wave * 16 + j;
+            if (row < N) {
+                float *po = a.part + ((size_t)r * (16 * TMS)) * (size_t)N + row;
+#pragma unroll
+                for (int tm = 0; tm < TMS; tm++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) po[(size_t)(16 * tm + 4 * q + i) * (size_t)N] = acc[tm][i];
+            }
+#pragma unroll
+            for (int tm = 0; tm < TMS; tm++) acc[tm] = zero;
+            c_st = 0;
+            c_item++;
+        }
+    }
+}
+
+// ---- second launch: ranges added in range order + the product's epilogue ----
+enum PanelMode { PN_STORE = 0, PN_RESID = 1, PN_SWIGLU = 2, PN_QKV = 3 };
+
+struct PanelReduceArgs {
+    const float *part;   // [ranges][P16][N]
+    int n_ranges, P16, N, P;
+    float *out;          // PN_STORE / PN_RESID: [P, ldo]; PN_SWIGLU: [P, ldo] of N / 2 gated values; PN_QKV: q [P, ldo]
+    int ldo;
+    const float *res;    // PN_RESID: out = res + product
+    int ldres;
+    float *xn;           // panel_reduce_resid_rms: rmsnorm of the new row, [P, N]
+    const float *rms_w;
+    // PN_QKV: features [0, nq) -> RoPE -> out; [nq, nq + nkv) -> RoPE -> key-cache row pos0 + token; then the value cache
+    int nq, nkv, ldkv, head_size, pos0;
+    float *outk, *outv;
+    size_t kv_head_stride;
+    const float2 *rope;
+};
+
+__device__ __forceinline__ v4f pn_sum_ranges(const PanelReduceArgs &a, int t, int f)
+{
+    const size_t stride = (size_t)a.P16 * (size_t)a.N;
+    const float *p = a.part + (size_t)t * (size_t)a.N + f;
+    v4f v = *(const v4f *)p;                       // range 0, then 1, ...: one fixed order
+    for (int r = 1; r < a.n_ranges; r++) {
+        const v4f u = *(const v4f *)(p + (size_t)r * stride);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    return v;
+}
+
+__device__ __forceinline__ size_t pn_kv_index(const PanelReduceArgs &a, int pos, int f)
+{
+    return a.kv_head_stride ? (size_t)(f / a.head_size) * a.kv_head_stride + (size_t)pos * (size_t)a.head_size + (size_t)(f % a.head_size)
+                            : (size_t)pos * (size_t)a.ldkv + (size_t)f;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void panel_reduce(const PanelReduceArgs a)
+{
+    const int t = blockIdx.y;
+    const int f = 4 * (blockIdx.x * 256 + threadIdx.x);
+    if (f >= a.N) return;
+    const v4f v = pn_sum_ranges(a, t, f);
+    if (MODE == PN_STORE) {
+        *(v4f *)(a.out + (size_t)t * a.ldo + f) = v;
+    } else if (MODE == PN_RESID) {
+        const v4f r = *(const v4f *)(a.res + (size_t)t * a.ldres + f);
+        v4f o;
+        o.x = r.x + v.x; o.y = r.y + v.y; o.z = r.z + v.z; o.w = r.w + v.w;   // main.zig:711
+        *(v4f *)(a.out + (size_t)t * a.ldo + f) = o;
+    } else if (MODE == PN_SWIGLU) {
+        // rows 2p, 2p + 1 = W1 row p, W3 row p (main.zig:405-416)
+        float2 o;
+        o.x = swiglu_merge(v.x, v.y);
+        o.y = swiglu_merge(v.z, v.w);
+        *(float2 *)(a.out + (size_t)t * a.ldo + (f >> 1)) = o;
+    } else {
+        const int seg = f >= a.nq + a.nkv ? 2 : f >= a.nq ? 1 : 0;
+        const int fl = f - (seg == 2 ? a.nq + a.nkv : seg == 1 ? a.nq : 0);
+        v4f o = v;
+        if (seg < 2) {  // RoPE on the pairs (fl, fl + 1), (fl + 2, fl + 3)  (main.zig:346-349)
+            const int hs = a.head_size, pos = a.pos0 + t;
+            const float2 c0 = a.rope[(size_t)pos * (size_t)(hs >> 1) + (size_t)((fl % hs) >> 1)];
+            const float2 c1 = a.rope[(size_t)pos * (size_t)(hs >> 1) + (size_t)(((fl + 2) % hs) >> 1)];
+            o.x = v.x * c0.x - v.y * c0.y;
+            o.y = v.x * c0.y + v.y * c0.x;
+            o.z = v.z * c1.x - v.w * c1.y;
+            o.w = v.z * c1.y + v.w * c1.x;
+        }
+        if (seg == 0) {
+            *(v4f *)(a.out + (size_t)t * a.ldo + fl) = o;
+        } else {  // :354-358 (four consecutive features of one head: head_size % 4 == 0)
+            float *c = seg == 1 ? a.outk : a.outv;
+            *(v4f *)(c + pn_kv_index(a, a.pos0 + t, fl)) = o;
+        }
+    }
+}
+
+// residual + the NEXT rmsnorm in one launch, one block per token: out = res + product (main.zig:395 / :422), then
+// xn = rmsnorm(out) * rms_w (:398 / :305) with exactly prefill_rmsnorm's arithmetic (a row-sharded pass runs the two
+// as separate launches and must get the same bits).  N <= 8192: the row stays in registers.
+__global__ __launch_bounds__(kPfBlock) void panel_reduce_resid_rms(const PanelReduceArgs a)
+{
+    __shared__ float red[8];
+    const int t = blockIdx.x;
+    const int n4 = a.N >> 2;
+    constexpr int R = 8;
+    v4f xv[R];
+    float ss = 0.0f;
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const int i = threadIdx.x + kPfBlock * k;
+        if (i < n4) {
+            const v4f v = pn_sum_ranges(a, t, 4 * i);
+            const v4f r = *(const v4f *)(a.res + (size_t)t * a.ldres + 4 * i);
+            v4f o;
+            o.x = r.x + v.x; o.y = r.y + v.y; o.z = r.z + v.z; o.w = r.w + v.w;
+            *(v4f *)(a.out + (size_t)t * a.ldo + 4 * i) = o;
+            xv[k] = o;
+        } else {
+            xv[k] = v4f{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        ss = fmaf(xv[k].x, xv[k].x, ss); ss = fmaf(xv[k].y, xv[k].y, ss);
+        ss = fmaf(xv[k].z, xv[k].z, ss); ss = fmaf(xv[k].w, xv[k].w, ss);
+    }
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    float tot = red[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); i++) tot += red[i];
+    float s = tot / (float)a.N;  // main.zig:452-455
+    s += 1e-5f;
+    s = 1.0f / sqrtf(s);
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const int i = threadIdx.x + kPfBlock * k;
+        if (i < n4) {
+            const v4f wv = ((const v4f *)a.rms_w)[i];
+            v4f r;
+            r.x = (xv[k].x * s) * wv.x; r.y = (xv[k].y * s) * wv.y;
+            r.z = (xv[k].z * s) * wv.z; r.w = (xv[k].w * s) * wv.w;
+            *(v4f *)(a.xn + (size_t)t * a.N + 4 * i) = r;
+        }
+    }
+}
+
+}  // namespace
+
+int prefill_panel_max_tokens()
+{
+    const int m = tunables().pf_panel_max;
+    return m < 0 ? 32 : (m > 32 ? 32 : m);
+}
+
+// Whether a [P, n_whole] x K product of the WHOLE model takes the panel kernel (a function of the model and the chunk
+// length only: a rank's share of the rows takes what the unsharded pass takes).  rows_mult16: every matrix of the
+// launch has a multiple of 16 rows ON THIS RANK (a wave's 16 rows lie in one matrix).
+bool prefill_panel_shape(long long n_whole, int P, int K)
+{
+    if (tunables().pf_panel == 0 || tunables().pf_dma == 0 || tunables().pf_tile != 0) return false;
+    if (P < 1 || P > prefill_panel_max_tokens() || K % kPnStage != 0 || K < kPnRange) return false;
+    return n_whole * (long long)K * 4 > ((long long)16 << 20);  // matrices that stream from HBM; cache-resident ones keep the short-prompt forms
+}
+
+hipError_t launch_prefill_panel(const PanelProduct &p, int n_cus, const SplitKWs *ws, hipStream_t st)
+{
+    const int N = p.rows0 + p.rows1 + p.rows2;
+    if ((p.rows0 % 16) || (p.rows1 % 16) || (p.rows2 % 16) || N <= 0 || (p.ldx % 4) || p.K % kPnStage != 0) return hipErrorNotSupported;
+    if (((uintptr_t)p.x & 15) || ((uintptr_t)p.w0 & 15) || ((uintptr_t)p.w1 & 15) || ((uintptr_t)p.w2 & 15)) return hipErrorNotSupported;
+    if (ws == nullptr || ws->part == nullptr) return hipErrorNotSupported;
+    const int tms = p.P <= 16 ? 1 : 2;
+    const int n_ranges = (p.K + kPnRange - 1) / kPnRange;
+    if ((size_t)n_ranges * (size_t)(16 * tms) * (size_t)N > ws->part_floats) return hipErrorNotSupported;
+    PanelArgs a = {};
+    a.x = p.x; a.ldx = p.ldx; a.w0 = p.w0; a.w1 = p.w1 ? p.w1 : p.w0; a.w2 = p.w2 ? p.w2 : p.w0;
+    a.rows0 = p.rows0; a.rows1 = p.rows1; a.rows2 = p.rows2; a.P = p.P; a.K = p.K;
+    a.part = ws->part;
+    a.n_groups = (N + 63) / 64;
+    a.n_items = n_ranges * a.n_groups;
+    const size_t lds = (size_t)(16 * tms * kPnRange + 4 * kPnDepth * kPnStageFloats) * sizeof(float);
+    const void *fn = tms == 1 ? (const void *)prefill_panel<1> : (const void *)prefill_panel<2>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return hipErrorNotSupported;
+    }
+    const int grid = a.n_items < n_cus ? a.n_items : n_cus;
+    void *params[] = {&a};
+    e = hipLaunchKernel(fn, dim3(grid), dim3(256), params, lds, st);
+    if (e != hipSuccess) return e;
+    // the ranges, in order, and the epilogue
+    PanelReduceArgs r = {};
+    r.part = ws->part; r.n_ranges = n_ranges; r.P16 = 16 * tms; r.N = N; r.P = p.P;
+    r.out = p.out; r.ldo = p.ldo; r.res = p.res; r.ldres = p.ldres; r.xn = p.xn; r.rms_w = p.rms_w;
+    r.nq = p.rows0; r.nkv = p.rows1; r.ldkv = p.ldkv; r.head_size = p.head_size; r.pos0 = p.pos0;
+    r.outk = p.outk; r.outv = p.outv; r.kv_head_stride = p.kv_head_stride; r.rope = p.rope;
+    const dim3 g2((unsigned)((N / 4 + 255) / 256), (unsigned)p.P);
+    switch (p.mode) {
+    case PANEL_STORE: hipLaunchKernelGGL(panel_reduce<PN_STORE>, g2, dim3(256), 0, st, r); break;
+    case PANEL_RESID:
+        if (p.xn != nullptr && N <= 8 * 4 * kPfBlock && p.ldo == N)
+            hipLaunchKernelGGL(panel_reduce_resid_rms, dim3(p.P), dim3(kPfBlock), 0, st, r);
+        else if (p.xn != nullptr)
+            return hipErrorInvalidValue;  // the caller asked for a fusion this row length does not take (it checks first)
+        else
+            hipLaunchKernelGGL(panel_reduce<PN_RESID>, g2, dim3(256), 0, st, r);
+        break;
+    case PANEL_SWIGLU: hipLaunchKernelGGL(panel_reduce<PN_SWIGLU>, g2, dim3(256), 0, st, r); break;
+    case PANEL_QKV:
+        if ((p.head_size % 4) != 0) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(panel_reduce<PN_QKV>, g2, dim3(256), 0, st, r);
+        break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+bool prefill_panel_can_fuse_rms(int n) { return n % 4 == 0 && n <= 8 * 4 * kPfBlock; }
+
+}  // namespace l2z

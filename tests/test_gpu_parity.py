@@ -899,6 +899,53 @@ def test_prefill_equals_token_by_token(gpu, ck, orc, name, kw, shared):
         o.close()
 
 
+@pytest.mark.parametrize("kv_heads", [24, 8])
+def test_prefill_panel_kernel_vs_oracle(gpu, ck, orc, options, kv_heads):
+    """prefill_panel.hip: chunks of <= 32 tokens of matrices that stream from HBM (K cut into ranges of 512 with a
+    resident X panel, the ranges added in order by a second launch that also runs the epilogue -- RoPE + cache rows,
+    residual + the next rmsnorm, SiLU * mul).  A wide two-layer shape whose hidden_dim leaves a SHORT last range (8448 =
+    16.5 x 512), MHA and GQA: logits and KV rows against the CPU oracle's stepped loop for chunks of 1 / 16 (one token
+    tile), 17 / 32 (two), and a second call continuing the context; against the short-prompt GEMMs (L2Z_PF_PANEL=0)
+    within the tolerance; and the fused residual + rmsnorm launch against the two separate ones, bit for bit."""
+    kw = dict(dim=3072, hidden_dim=8448, n_layers=2, n_heads=24, n_kv_heads=kv_heads, vocab_size=2048, seq_len=64)
+    cfg = ck.Config(**kw)
+    blob = ck.synth_blob(cfg, False, seed=55)
+    w, s = gpu.Weights(cfg, blob, False), gpu.RunState(cfg)
+    m = orc.Model(cfg.as_i32(), blob, False)
+    rng = np.random.default_rng(12)
+    toks = [1] + rng.integers(2, cfg.vocab_size, 39).tolist()
+    kvd, S = cfg.kv_dim, cfg.seq_len
+    worst = 0.0
+    for n in (1, 16, 17, 32):
+        for pos, t in enumerate(toks[:n]):
+            ref = m.transformer(t, pos)
+        s.prefill(toks[:n], 0, w)
+        got = s.logits()
+        worst = max(worst, float(np.abs(got - ref).max()))
+        np.testing.assert_allclose(got, ref, rtol=LOGIT_RTOL, atol=LOGIT_ATOL, err_msg=f"{n} tokens")
+        for l in range(cfg.n_layers):
+            for nm in ("key_cache", "value_cache"):
+                a = m.state(nm, cfg.n_layers * S * kvd).reshape(cfg.n_layers, S, kvd)[l, :n].ravel()
+                np.testing.assert_allclose(s.read(nm, l * S * kvd, n * kvd), a, rtol=2e-5, atol=2e-5, err_msg=f"{nm} l={l} n={n}")
+    # a second call continuing the context (pos0 = 32), 8 more tokens
+    for pos in range(32, 40):
+        ref = m.transformer(toks[pos], pos)
+    s.prefill(toks[32:40], 32, w)
+    np.testing.assert_allclose(s.logits(), ref, rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
+    panel = s.logits()
+    # the same two calls through the short-prompt GEMMs: another summation order, the same tolerance
+    options(L2Z_PF_PANEL=0)
+    s.prefill(toks[:32], 0, w); s.prefill(toks[32:40], 32, w)
+    np.testing.assert_allclose(s.logits(), ref, rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
+    assert not np.array_equal(s.logits(), panel), "L2Z_PF_PANEL=0 did not change the path"
+    # residual + rmsnorm as one launch == as two
+    options(L2Z_PF_PANEL=1, L2Z_PF_PANEL_FUSE=0)
+    s.prefill(toks[:32], 0, w); s.prefill(toks[32:40], 32, w)
+    assert np.array_equal(s.logits(), panel)
+    print(f"panel kernel, kv heads {kv_heads}: max |logit - oracle| {worst:.2e}")
+    m.close(); s.close(); w.close()
+
+
 @pytest.mark.parametrize("temp", [1.0, 0.7])
 def test_probs_read_vs_host_softmax(gpu, ck, orc, temp):
     """l2z_probs_read = main.zig:1005-1008 (logits / temperature, softmax) on the device, for the host

@@ -281,3 +281,52 @@ def test_sharded_prefill_schedule(world, tmp_path, ck, orc):
     assert full_k.shape == (cfg.n_layers, len(toks), cfg.kv_dim) and kvl * world == cfg.kv_dim
     assert np.isfinite(full_k).all() and float(np.abs(full_k).max()) > 0
     m.close()
+
+
+def _xchg_worker(rank, world, port, vocab, seed, out_dir):
+    """The greedy step's hand-over of a shard group (csrc/misc_kernels.hip argmax_kernel, ArgmaxArgs::xchg): every rank
+    reduces ITS vocabulary rows to one (max, first index) candidate, the ranks exchange the N pairs (here: gloo
+    all_gather; on the GPUs: two LL words per rank in every peer's landing slot) and every rank applies main.zig:720's
+    rule to them -- larger value, equal values: lower index."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B = ge.load_package().binding
+    v0, v1 = B.shard_range(vocab, 1, rank, world)
+    rng = np.random.default_rng(seed)
+    picks = []
+    for case in range(24):
+        lg = rng.standard_normal(vocab).astype(np.float32)
+        if case % 3 != 2:  # plant the maximum at several indices, on different ranks and inside one rank
+            hot = rng.choice(vocab, size=2 + case % 4, replace=False)
+            lg[hot] = np.float32(lg.max() + 1.0 if case % 3 == 0 else lg.max())
+        mine = lg[v0:v1]
+        loc = int(np.argmax(mine))  # first index of the maximum: strict '>' (main.zig:720)
+        pair = torch.tensor([float(mine[loc]), float(v0 + loc)], dtype=torch.float64)
+        pairs = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(pairs, pair)
+        best, bi = -np.inf, 0x7fffffff
+        for p in pairs:  # any order gives the same winner: the rule is a total order on (value desc, index asc)
+            v, i = np.float32(p[0].item()), int(p[1].item())
+            if v > best or (v == best and i < bi):
+                best, bi = v, i
+        assert bi == int(np.argmax(lg)), (case, bi, int(np.argmax(lg)))
+        picks.append(bi)
+    np.save(os.path.join(out_dir, f"picks{rank}.npy"), np.array(picks))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_greedy_candidate_exchange_rule(world, tmp_path):
+    """N pairs instead of 32000 logits: the winner equals the argmax of the whole vector, ties included, on every rank."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_xchg_worker, args=(world, _free_port(), 32000, 5, str(tmp_path)), nprocs=world, join=True)
+    p0 = np.load(tmp_path / "picks0.npy")
+    for r in range(1, world):
+        assert np.array_equal(np.load(tmp_path / f"picks{r}.npy"), p0)
