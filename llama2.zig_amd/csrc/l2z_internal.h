@@ -274,8 +274,6 @@ struct PanelProduct {
     int ldo;
     const float *res;    // RESID: out = res + product
     int ldres;
-    float *xn;           // RESID, optional: xn[P, N] = rmsnorm(out) * rms_w in the same launch (prefill_panel_can_fuse_rms, ldo == N)
-    const float *rms_w;
     float *outk, *outv;  // QKV: the layer's key / value caches (rows1 == rows2 features each)
     int ldkv, head_size, pos0;
     size_t kv_head_stride;
@@ -283,7 +281,6 @@ struct PanelProduct {
 };
 // a function of the WHOLE model's matrix (n_whole rows) and the chunk length: a rank's shard takes what the unsharded pass takes
 bool prefill_panel_shape(long long n_whole, int P, int K);
-bool prefill_panel_can_fuse_rms(int n);
 int prefill_panel_max_tokens();
 // hipErrorNotSupported: this rank's rows / pointers / workspace do not take the kernel (rows % 16, alignment) -- callers that
 // asked prefill_panel_shape first treat that as an error on a shard (the unsharded pass would have taken it)

@@ -96,7 +96,6 @@ struct l2z_runstate {
     int *pf_tokens = nullptr;
     l2z::SplitKWs pf_sk = {nullptr, nullptr, 0, 0};  // split-K workspace of the tile GEMM (chunks of <= 256 tokens)
     int pf_cap = 0;             // tokens per chunk the scratch above was allocated for
-    bool pf_xn_ready = false;   // pf_xn already holds the rmsnorm the next stage starts with (left by a fused wo / W2 launch of prefill_panel.hip)
     float *d_probs = nullptr;     // l2z_probs_read: softmax(logits / temperature), allocated on first use
     float *h_stage = nullptr;     // ... and its pinned host landing buffer
     float *d_part_val = nullptr;  // classifier launch's per-block argmax candidates

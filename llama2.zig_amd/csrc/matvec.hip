@@ -429,6 +429,7 @@ const void *mv_row_pick(int pro, int epi, bool big_x, bool ll)
     L2Z_MVR_LL(PRO_RMS, EPI_STORE)
     L2Z_MVR_LL(PRO_RMS, EPI_ROPE)
     L2Z_MVR_LL(PRO_RMS, EPI_SWIGLU)
+    L2Z_MVR_LL(PRO_RMS, EPI_ARGMAX)   // a shard's classifier on a gathered x: the candidate exchange of greedy steps
 #undef L2Z_MVR
 #undef L2Z_MVR_LL
     return nullptr;
@@ -453,6 +454,7 @@ MvLaunch mv_pick_pe(int pro, int epi, int lpr, bool big_x, bool vec, bool ll)
 #undef L2Z_MV
 #undef L2Z_MV_LL
     if (pro == PRO_RMS && epi == EPI_ARGMAX && vec && !ll) return mv_pick<PRO_RMS, EPI_ARGMAX, false>(lpr, big_x);
+    if (pro == PRO_RMS && epi == EPI_ARGMAX && vec && ll) return mv_pick<PRO_RMS, EPI_ARGMAX, true>(lpr, big_x);
     return {nullptr, 0, 0};
 }
 

@@ -112,9 +112,7 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
     const int sk_h1 = prefill_split_k(hid, P, dim, true);
     const SplitKWs *ws = &s->pf_sk;
     // Chunks of <= 32 tokens of matrices that stream from HBM: the K-range panel kernel (prefill_panel.hip), chosen from
-    // the WHOLE model's matrix so that a shard takes what the unsharded pass takes.  Its wo / W2 launches leave the next
-    // rmsnorm done as well (unsharded passes): pf_xn_ready.
-    const bool fuse_rms = !sharded && tunables().pf_panel_fuse != 0 && prefill_panel_can_fuse_rms(dim);
+    // the WHOLE model's matrix so that a shard takes what the unsharded pass takes.
     auto panel = [&](PanelProduct &pp, long long n_whole, bool *taken) -> int {
         *taken = false;
         if (!prefill_panel_shape(n_whole, P, pp.K)) return L2Z_OK;
@@ -126,11 +124,8 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
         return L2Z_OK;
     };
     bool taken = false;
-    if (k == PF_ATT || k == PF_H1) {   // :305 / :398 (unless the launch before has left it: same arithmetic)
-        if (!s->pf_xn_ready)
-            L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, s->pf_x, (k == PF_ATT ? w->rms_att : w->rms_ffn) + (size_t)l * dim, dim, P, st));
-        s->pf_xn_ready = false;
-    }
+    if (k == PF_ATT || k == PF_H1)   // :305 / :398
+        L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, s->pf_x, (k == PF_ATT ? w->rms_att : w->rms_ffn) + (size_t)l * dim, dim, P, st));
     if (k == PF_ATT) {
         {
             PanelProduct pp = {};
@@ -174,9 +169,7 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
             PanelProduct pp = {};
             pp.x = s->pf_att; pp.ldx = dim; pp.K = dim; pp.w0 = w->wo + (size_t)l * sh.dim_loc * dim; pp.rows0 = sh.dim_loc;
             pp.mode = PANEL_RESID; pp.out = out; pp.ldo = ldo; pp.res = res; pp.ldres = dim;
-            if (fuse_rms) { pp.xn = s->pf_xn; pp.rms_w = w->rms_ffn + (size_t)l * dim; }  // :398 behind :395
             L2Z_TRY(panel(pp, dim, &taken));
-            if (taken) s->pf_xn_ready = fuse_rms;
         }
         if (!taken)
         L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_att, dim, w->wo + (size_t)l * sh.dim_loc * dim, out, ldo,
@@ -209,10 +202,7 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
             PanelProduct pp = {};
             pp.x = s->pf_h1; pp.ldx = hid; pp.K = hid; pp.w0 = w->w2 + (size_t)l * sh.dim_loc * hid; pp.rows0 = sh.dim_loc;
             pp.mode = PANEL_RESID; pp.out = out; pp.ldo = ldo; pp.res = res; pp.ldres = dim;
-            const bool fuse_next = fuse_rms && l + 1 < c.n_layers;   // the next layer's :305 behind :422
-            if (fuse_next) { pp.xn = s->pf_xn; pp.rms_w = w->rms_att + (size_t)(l + 1) * dim; }
             L2Z_TRY(panel(pp, dim, &taken));
-            if (taken) s->pf_xn_ready = fuse_next;
         }
         if (!taken)
         L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_h1, hid, w->w2 + (size_t)l * sh.dim_loc * hid, out, ldo,
@@ -227,7 +217,6 @@ int prefill_begin_chunk(l2z_runstate *s, const l2z_weights *w, const int32_t *to
     // cut short (a peer-write wait that timed out, a failed launch) must not leave a later one a half-counted tile
     if (s->pf_sk.cnt)
         L2Z_HIP(hipMemsetAsync(s->pf_sk.cnt, 0, (size_t)s->pf_sk.cnt_ints * sizeof(int), s->stream));
-    s->pf_xn_ready = false;
     L2Z_HIP(hipMemcpyAsync(s->pf_tokens, tokens, (size_t)P * 4, hipMemcpyHostToDevice, s->stream));
     L2Z_HIP(launch_prefill_embed(s->pf_x, w->tok_emb, s->pf_tokens, s->cfg.dim, P, s->stream));  // :295
     return L2Z_OK;

@@ -16,8 +16,7 @@
 //     changes its panel at most a few times per launch (barrier, reload, barrier).
 //   * The block leaves the range's partial products in part[range][token][row]; a second launch (panel_reduce*) adds
 //     the ranges IN RANGE ORDER and runs the epilogue of the product -- RoPE + q / KV-cache rows (main.zig:336-358),
-//     residual (:395 / :422) with the NEXT rmsnorm fused behind it (:398 / :305: one launch instead of two), SiLU * mul
-//     (:411-416).  Partial traffic is P x N x ranges x 8 bytes: 1-6 % of the W bytes at 16-32 tokens.
+//     residual (:395 / :422), SiLU * mul (:411-416).  Partial traffic is P x N x ranges x 8 bytes: 1-6 % of the W bytes at 16-32 tokens.
 // Arithmetic: an output is the sum over ranges, in range order, of MFMA chains in (stage, u, c) order -- a function of K
 // alone: not of the rows a rank owns (row-sharded == unsharded, bit for bit), not of P or the token's place in its tile.
 //
@@ -30,10 +29,14 @@ namespace l2z {
 namespace {
 
 constexpr int kPnStage = 128;                 // k per ring stage: a row's piece is 512 bytes, a wave-wide load is two rows
-constexpr int kPnRange = 512;                 // k per range: four stages
-constexpr int kPnDepth = 3;                   // ring buffers per wave
+constexpr int kPnRange = 512;                 // k per range, chunks of <= 32 tokens: four stages (33 ... 64 tokens: 256, two)
 constexpr int kPnStageFloats = 16 * kPnStage; // one ring buffer: 16 rows x 128
 constexpr int kPnLoads = 8;                   // wave-wide loads per stage
+constexpr int kPanelDefaultMax = 32;          // longest chunk that takes the kernel by default
+// ... and the shortest: up to 16 tokens the short-prompt GEMMs of prefill_skinny.hip are ahead -- their products need no
+// second launch (7B shape, whole prefill of 8 / 16 / 24 / 32 tokens: 5.31 / 5.65 / 8.76 / 8.78 ms there, 6.02 / 6.16 /
+// 6.92 / 6.98 here; profiles/r05b_prefill_panel_ab.txt)
+constexpr int kPanelDefaultMin = 17;
 
 struct PanelArgs {
     const float *x;   // [P, K], ldx floats per row
@@ -48,20 +51,23 @@ struct PanelArgs {
     int n_items;      // ranges * n_groups
 };
 
+template <int KR>
 __device__ __forceinline__ int pn_range_stages(int K, int r)
 {
-    const int left = K - r * kPnRange;
-    return (left < kPnRange ? left : kPnRange) / kPnStage;
+    const int left = K - r * KR;
+    return (left < KR ? left : KR) / kPnStage;
 }
 
-template <int TMS>
+// TMS token tiles of 16; KR: k per range (the panel is [16 TMS][KR]: 64 KB at (2, 512) and (4, 256)); kPnDepth: ring
+// buffers per wave (its loads run kPnDepth - 1 stages ahead)
+template <int TMS, int KR, int kPnDepth>
 __global__ __launch_bounds__(256) void prefill_panel(const PanelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
     float *panel = smem;                                                       // [16 TMS][512], swizzled
-    float *ring = smem + 16 * TMS * kPnRange + wave * (kPnDepth * kPnStageFloats);
+    float *ring = smem + 16 * TMS * KR + wave * (kPnDepth * kPnStageFloats);
     const int N = a.rows0 + a.rows1 + a.rows2;
     const int i0 = (int)((long long)blockIdx.x * a.n_items / gridDim.x);
     const int i1 = (int)((long long)(blockIdx.x + 1) * a.n_items / gridDim.x);
@@ -81,14 +87,14 @@ __global__ __launch_bounds__(256) void prefill_panel(const PanelArgs a)
     const float *p_base = a.w0;  // row 0 of the wave's 16 at k = the range's start
     auto producer_item = [&]() {
         const int r = p_item / a.n_groups, g = p_item - r * a.n_groups;
-        p_ns = pn_range_stages(a.K, r);
+        p_ns = pn_range_stages<KR>(a.K, r);
         int row = g * 64 + wave * 16;
         row = row < N ? row : N - 16;                        // a wave past the end: the last 16 rows again (never stored)
         const bool s1 = row >= a.rows0, s2 = row >= a.rows0 + a.rows1;
         const float *base = s1 ? a.w1 : a.w0;
         base = s2 ? a.w2 : base;
         row -= s2 ? a.rows0 + a.rows1 : (s1 ? a.rows0 : 0);
-        p_base = base + (size_t)row * (size_t)a.K + (size_t)r * kPnRange;
+        p_base = base + (size_t)row * (size_t)a.K + (size_t)r * KR;
     };
     auto issue_one = [&]() {
         if (p_item >= i1) return;
@@ -105,14 +111,15 @@ __global__ __launch_bounds__(256) void prefill_panel(const PanelArgs a)
     };
     // ---- the panel: range r of X, all 16 TMS token rows (tokens past P: the last token; never stored) ----
     auto load_panel = [&](int r) {
-        const int klen = pn_range_stages(a.K, r) * kPnStage;
-        for (int t = wave; t < 32 * TMS; t += 4) {              // wave-wide load t: half h of token row t / 2
-            const int tok = t >> 1, h = t & 1;
+        const int klen = pn_range_stages<KR>(a.K, r) * kPnStage;
+        constexpr int HPR = KR / 256;                           // wave-wide loads (256 floats) per token row
+        for (int t = wave; t < 16 * TMS * HPR; t += 4) {        // wave-wide load t: piece h of token row t / HPR
+            const int tok = t / HPR, h = t % HPR;
             const int logical = (64 * h + lane) ^ (tok & 7);
             int kk = 4 * logical;
             kk = kk < klen ? kk : klen - 4;                     // (a short last range: the piece past its end is never read)
-            const float *src = a.x + (size_t)(tok < a.P ? tok : a.P - 1) * (size_t)a.ldx + (size_t)r * kPnRange + kk;
-            lds_dma16(src, panel + tok * kPnRange + 256 * h);
+            const float *src = a.x + (size_t)(tok < a.P ? tok : a.P - 1) * (size_t)a.ldx + (size_t)r * KR + kk;
+            lds_dma16(src, panel + tok * KR + 256 * h);
         }
     };
 
@@ -120,12 +127,12 @@ __global__ __launch_bounds__(256) void prefill_panel(const PanelArgs a)
 #pragma unroll
     for (int tm = 0; tm < TMS; tm++) acc[tm] = zero;
     if (i0 < i1) producer_item();
-    issue_one();
-    issue_one();
+#pragma unroll
+    for (int d = 0; d < kPnDepth - 1; d++) issue_one();
     int c_item = i0, c_st = 0, c_buf = 0, consumed = 0, cur_range = -1;
     while (c_item < i1) {
         const int r = c_item / a.n_groups;
-        const int ns = pn_range_stages(a.K, r);
+        const int ns = pn_range_stages<KR>(a.K, r);
         if (c_st == 0 && r != cur_range) {  // block-uniform: every wave walks the same items
             __syncthreads();                // nobody reads the old panel any more
             load_panel(r);
@@ -135,12 +142,12 @@ __global__ __launch_bounds__(256) void prefill_panel(const PanelArgs a)
         } else {
             // stage `consumed` of this wave has landed: what may still fly are the stages issued after it
             const int younger = issued - consumed - 1;
-            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kPnLoads) : "memory");
-            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPnLoads) : "memory");
+            if (kPnDepth >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kPnLoads) : "memory");
+            else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPnLoads) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the operand reads of the stage before have retired: its buffer is free
-        issue_one();                                        // two stages ahead, into that buffer
+        issue_one();                                        // kPnDepth - 1 stages ahead, into that buffer
         const v4f *wst = (const v4f *)(ring + c_buf * kPnStageFloats);
         const v4f *xp = (const v4f *)panel;
         const int sw = j & 7;
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(256) void prefill_panel(const PanelArgs a)
             const v4f b = wst[j * 32 + (slot ^ sw)];
             v4f xa[TMS];
 #pragma unroll
-            for (int tm = 0; tm < TMS; tm++) xa[tm] = xp[(16 * tm + j) * (kPnRange / 4) + ((c_st * 32 + slot) ^ sw)];
+            for (int tm = 0; tm < TMS; tm++) xa[tm] = xp[(16 * tm + j) * (KR / 4) + ((c_st * 32 + slot) ^ sw)];
 #pragma unroll
             for (int c = 0; c < 4; c++)
 #pragma unroll
@@ -188,8 +195,6 @@ struct PanelReduceArgs {
     int ldo;
     const float *res;    // PN_RESID: out = res + product
     int ldres;
-    float *xn;           // panel_reduce_resid_rms: rmsnorm of the new row, [P, N]
-    const float *rms_w;
     // PN_QKV: features [0, nq) -> RoPE -> out; [nq, nq + nkv) -> RoPE -> key-cache row pos0 + token; then the value cache
     int nq, nkv, ldkv, head_size, pos0;
     float *outk, *outv;
@@ -257,63 +262,12 @@ __global__ __launch_bounds__(256) void panel_reduce(const PanelReduceArgs a)
     }
 }
 
-// residual + the NEXT rmsnorm in one launch, one block per token: out = res + product (main.zig:395 / :422), then
-// xn = rmsnorm(out) * rms_w (:398 / :305) with exactly prefill_rmsnorm's arithmetic (a row-sharded pass runs the two
-// as separate launches and must get the same bits).  N <= 8192: the row stays in registers.
-__global__ __launch_bounds__(kPfBlock) void panel_reduce_resid_rms(const PanelReduceArgs a)
-{
-    __shared__ float red[8];
-    const int t = blockIdx.x;
-    const int n4 = a.N >> 2;
-    constexpr int R = 8;
-    v4f xv[R];
-    float ss = 0.0f;
-#pragma unroll
-    for (int k = 0; k < R; k++) {
-        const int i = threadIdx.x + kPfBlock * k;
-        if (i < n4) {
-            const v4f v = pn_sum_ranges(a, t, 4 * i);
-            const v4f r = *(const v4f *)(a.res + (size_t)t * a.ldres + 4 * i);
-            v4f o;
-            o.x = r.x + v.x; o.y = r.y + v.y; o.z = r.z + v.z; o.w = r.w + v.w;
-            *(v4f *)(a.out + (size_t)t * a.ldo + 4 * i) = o;
-            xv[k] = o;
-        } else {
-            xv[k] = v4f{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < R; k++) {
-        ss = fmaf(xv[k].x, xv[k].x, ss); ss = fmaf(xv[k].y, xv[k].y, ss);
-        ss = fmaf(xv[k].z, xv[k].z, ss); ss = fmaf(xv[k].w, xv[k].w, ss);
-    }
-    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
-    __syncthreads();
-    float tot = red[0];
-    for (int i = 1; i < (int)(blockDim.x >> 6); i++) tot += red[i];
-    float s = tot / (float)a.N;  // main.zig:452-455
-    s += 1e-5f;
-    s = 1.0f / sqrtf(s);
-#pragma unroll
-    for (int k = 0; k < R; k++) {
-        const int i = threadIdx.x + kPfBlock * k;
-        if (i < n4) {
-            const v4f wv = ((const v4f *)a.rms_w)[i];
-            v4f r;
-            r.x = (xv[k].x * s) * wv.x; r.y = (xv[k].y * s) * wv.y;
-            r.z = (xv[k].z * s) * wv.z; r.w = (xv[k].w * s) * wv.w;
-            *(v4f *)(a.xn + (size_t)t * a.N + 4 * i) = r;
-        }
-    }
-}
-
 }  // namespace
 
 int prefill_panel_max_tokens()
 {
     const int m = tunables().pf_panel_max;
-    return m < 0 ? 32 : (m > 32 ? 32 : m);
+    return m < 0 ? kPanelDefaultMax : (m > 64 ? 64 : m);
 }
 
 // Whether a [P, n_whole] x K product of the WHOLE model takes the panel kernel (a function of the model and the chunk
@@ -322,7 +276,9 @@ int prefill_panel_max_tokens()
 bool prefill_panel_shape(long long n_whole, int P, int K)
 {
     if (tunables().pf_panel == 0 || tunables().pf_dma == 0 || tunables().pf_tile != 0) return false;
-    if (P < 1 || P > prefill_panel_max_tokens() || K % kPnStage != 0 || K < kPnRange) return false;
+    const int p_min = tunables().pf_panel_min >= 0 ? tunables().pf_panel_min : kPanelDefaultMin;
+    if (P < p_min || P < 1 || P > prefill_panel_max_tokens() || K % kPnStage != 0 || K < kPnRange) return false;
+    // (33 ... 64 tokens: four token tiles against ranges of 256 -- an option, L2Z_PF_PANEL_MAX=64: MFMA-bound there)
     return n_whole * (long long)K * 4 > ((long long)16 << 20);  // matrices that stream from HBM; cache-resident ones keep the short-prompt forms
 }
 
@@ -332,8 +288,11 @@ hipError_t launch_prefill_panel(const PanelProduct &p, int n_cus, const SplitKWs
     if ((p.rows0 % 16) || (p.rows1 % 16) || (p.rows2 % 16) || N <= 0 || (p.ldx % 4) || p.K % kPnStage != 0) return hipErrorNotSupported;
     if (((uintptr_t)p.x & 15) || ((uintptr_t)p.w0 & 15) || ((uintptr_t)p.w1 & 15) || ((uintptr_t)p.w2 & 15)) return hipErrorNotSupported;
     if (ws == nullptr || ws->part == nullptr) return hipErrorNotSupported;
-    const int tms = p.P <= 16 ? 1 : 2;
-    const int n_ranges = (p.K + kPnRange - 1) / kPnRange;
+    const int tms = p.P <= 16 ? 1 : p.P <= 32 ? 2 : 4;
+    const int form = tunables().pf_panel_form;   // 1: deeper rings (experiments)
+    const int kr = tms == 4 || (tms == 2 && form == 1) ? 256 : kPnRange;
+    const int depth = form == 1 && tms <= 2 ? 4 : 3;
+    const int n_ranges = (p.K + kr - 1) / kr;
     if ((size_t)n_ranges * (size_t)(16 * tms) * (size_t)N > ws->part_floats) return hipErrorNotSupported;
     PanelArgs a = {};
     a.x = p.x; a.ldx = p.ldx; a.w0 = p.w0; a.w1 = p.w1 ? p.w1 : p.w0; a.w2 = p.w2 ? p.w2 : p.w0;
@@ -341,8 +300,10 @@ hipError_t launch_prefill_panel(const PanelProduct &p, int n_cus, const SplitKWs
     a.part = ws->part;
     a.n_groups = (N + 63) / 64;
     a.n_items = n_ranges * a.n_groups;
-    const size_t lds = (size_t)(16 * tms * kPnRange + 4 * kPnDepth * kPnStageFloats) * sizeof(float);
-    const void *fn = tms == 1 ? (const void *)prefill_panel<1> : (const void *)prefill_panel<2>;
+    const size_t lds = (size_t)(16 * tms * kr + 4 * depth * kPnStageFloats) * sizeof(float);
+    const void *fn = tms == 1 ? (depth == 4 ? (const void *)prefill_panel<1, kPnRange, 4> : (const void *)prefill_panel<1, kPnRange, 3>)
+                   : tms == 2 ? (depth == 4 ? (const void *)prefill_panel<2, 256, 4> : (const void *)prefill_panel<2, kPnRange, 3>)
+                              : (const void *)prefill_panel<4, 256, 3>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -355,20 +316,13 @@ hipError_t launch_prefill_panel(const PanelProduct &p, int n_cus, const SplitKWs
     // the ranges, in order, and the epilogue
     PanelReduceArgs r = {};
     r.part = ws->part; r.n_ranges = n_ranges; r.P16 = 16 * tms; r.N = N; r.P = p.P;
-    r.out = p.out; r.ldo = p.ldo; r.res = p.res; r.ldres = p.ldres; r.xn = p.xn; r.rms_w = p.rms_w;
+    r.out = p.out; r.ldo = p.ldo; r.res = p.res; r.ldres = p.ldres;
     r.nq = p.rows0; r.nkv = p.rows1; r.ldkv = p.ldkv; r.head_size = p.head_size; r.pos0 = p.pos0;
     r.outk = p.outk; r.outv = p.outv; r.kv_head_stride = p.kv_head_stride; r.rope = p.rope;
     const dim3 g2((unsigned)((N / 4 + 255) / 256), (unsigned)p.P);
     switch (p.mode) {
     case PANEL_STORE: hipLaunchKernelGGL(panel_reduce<PN_STORE>, g2, dim3(256), 0, st, r); break;
-    case PANEL_RESID:
-        if (p.xn != nullptr && N <= 8 * 4 * kPfBlock && p.ldo == N)
-            hipLaunchKernelGGL(panel_reduce_resid_rms, dim3(p.P), dim3(kPfBlock), 0, st, r);
-        else if (p.xn != nullptr)
-            return hipErrorInvalidValue;  // the caller asked for a fusion this row length does not take (it checks first)
-        else
-            hipLaunchKernelGGL(panel_reduce<PN_RESID>, g2, dim3(256), 0, st, r);
-        break;
+    case PANEL_RESID: hipLaunchKernelGGL(panel_reduce<PN_RESID>, g2, dim3(256), 0, st, r); break;
     case PANEL_SWIGLU: hipLaunchKernelGGL(panel_reduce<PN_SWIGLU>, g2, dim3(256), 0, st, r); break;
     case PANEL_QKV:
         if ((p.head_size % 4) != 0) return hipErrorInvalidValue;
@@ -378,7 +332,5 @@ hipError_t launch_prefill_panel(const PanelProduct &p, int n_cus, const SplitKWs
     }
     return hipGetLastError();
 }
-
-bool prefill_panel_can_fuse_rms(int n) { return n % 4 == 0 && n <= 8 * 4 * kPfBlock; }
 
 }  // namespace l2z

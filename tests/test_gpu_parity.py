@@ -903,20 +903,22 @@ def test_prefill_equals_token_by_token(gpu, ck, orc, name, kw, shared):
 def test_prefill_panel_kernel_vs_oracle(gpu, ck, orc, options, kv_heads):
     """prefill_panel.hip: chunks of <= 32 tokens of matrices that stream from HBM (K cut into ranges of 512 with a
     resident X panel, the ranges added in order by a second launch that also runs the epilogue -- RoPE + cache rows,
-    residual + the next rmsnorm, SiLU * mul).  A wide two-layer shape whose hidden_dim leaves a SHORT last range (8448 =
-    16.5 x 512), MHA and GQA: logits and KV rows against the CPU oracle's stepped loop for chunks of 1 / 16 (one token
-    tile), 17 / 32 (two), and a second call continuing the context; against the short-prompt GEMMs (L2Z_PF_PANEL=0)
-    within the tolerance; and the fused residual + rmsnorm launch against the two separate ones, bit for bit."""
-    kw = dict(dim=3072, hidden_dim=8448, n_layers=2, n_heads=24, n_kv_heads=kv_heads, vocab_size=2048, seq_len=64)
+    residual, SiLU * mul).  A wide two-layer shape whose hidden_dim leaves a SHORT last range (8448 = 16.5 x 512), MHA
+    and GQA: logits and KV rows against the CPU oracle's stepped loop for chunks of 1 / 16 (one token tile; below the
+    default switch-over, so forced: L2Z_PF_PANEL_MIN=1), 17 / 32 (two), 33 / 64 (four tiles against ranges of 256:
+    L2Z_PF_PANEL_MAX=64), a second call continuing the context, the deeper-ring forms; and against the short-prompt
+    GEMMs (L2Z_PF_PANEL=0) within the tolerance."""
+    kw = dict(dim=3072, hidden_dim=8448, n_layers=2, n_heads=24, n_kv_heads=kv_heads, vocab_size=2048, seq_len=80)
     cfg = ck.Config(**kw)
+    options(L2Z_PF_PANEL_MIN=1, L2Z_PF_PANEL_MAX=64)
     blob = ck.synth_blob(cfg, False, seed=55)
     w, s = gpu.Weights(cfg, blob, False), gpu.RunState(cfg)
     m = orc.Model(cfg.as_i32(), blob, False)
     rng = np.random.default_rng(12)
-    toks = [1] + rng.integers(2, cfg.vocab_size, 39).tolist()
+    toks = [1] + rng.integers(2, cfg.vocab_size, 71).tolist()
     kvd, S = cfg.kv_dim, cfg.seq_len
     worst = 0.0
-    for n in (1, 16, 17, 32):
+    for n in (1, 16, 17, 32, 33, 64):
         for pos, t in enumerate(toks[:n]):
             ref = m.transformer(t, pos)
         s.prefill(toks[:n], 0, w)
@@ -927,21 +929,23 @@ def test_prefill_panel_kernel_vs_oracle(gpu, ck, orc, options, kv_heads):
             for nm in ("key_cache", "value_cache"):
                 a = m.state(nm, cfg.n_layers * S * kvd).reshape(cfg.n_layers, S, kvd)[l, :n].ravel()
                 np.testing.assert_allclose(s.read(nm, l * S * kvd, n * kvd), a, rtol=2e-5, atol=2e-5, err_msg=f"{nm} l={l} n={n}")
-    # a second call continuing the context (pos0 = 32), 8 more tokens
-    for pos in range(32, 40):
+    # a second call continuing the context (pos0 = 64), 8 more tokens
+    for pos in range(64, 72):
         ref = m.transformer(toks[pos], pos)
-    s.prefill(toks[32:40], 32, w)
+    s.prefill(toks[64:72], 64, w)
     np.testing.assert_allclose(s.logits(), ref, rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
-    panel = s.logits()
-    # the same two calls through the short-prompt GEMMs: another summation order, the same tolerance
-    options(L2Z_PF_PANEL=0)
-    s.prefill(toks[:32], 0, w); s.prefill(toks[32:40], 32, w)
-    np.testing.assert_allclose(s.logits(), ref, rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
-    assert not np.array_equal(s.logits(), panel), "L2Z_PF_PANEL=0 did not change the path"
-    # residual + rmsnorm as one launch == as two
-    options(L2Z_PF_PANEL=1, L2Z_PF_PANEL_FUSE=0)
-    s.prefill(toks[:32], 0, w); s.prefill(toks[32:40], 32, w)
-    assert np.array_equal(s.logits(), panel)
+    # 32 + 8 tokens: the default form, the deeper rings (one tile: the same ranges, the same bits; two tiles: ranges
+    # of 256, other bits), and the short-prompt GEMMs: another summation order, the same tolerance
+    for pos in range(40):
+        ref = m.transformer(toks[pos], pos)
+    got = {}
+    for tag, opts in (("default", {}), ("deep", dict(L2Z_PF_PANEL_FORM=1)), ("skinny", dict(L2Z_PF_PANEL=0))):
+        options(**opts)
+        s.prefill(toks[:32], 0, w); s.prefill(toks[32:40], 32, w)
+        got[tag] = s.logits()
+        np.testing.assert_allclose(got[tag], ref, rtol=LOGIT_RTOL, atol=LOGIT_ATOL, err_msg=tag)
+        options(L2Z_PF_PANEL_FORM=0, L2Z_PF_PANEL=1)
+    assert not np.array_equal(got["skinny"], got["default"]), "L2Z_PF_PANEL=0 did not change the path"
     print(f"panel kernel, kv heads {kv_heads}: max |logit - oracle| {worst:.2e}")
     m.close(); s.close(); w.close()
 
