@@ -180,6 +180,34 @@ int comm_bulk_allgather(const l2z_comm *c, float *stage, int P, int n_loc, float
     return L2Z_OK;
 }
 
+int comm_bulk_allreduce(const l2z_comm *c, float *part, int P, int n, float *stage, float *dst, int ldd, hipStream_t st)
+{
+    L2Z_CHECK(c != nullptr, L2Z_ERR_STATE, "bulk all-reduce without a shard group");
+    L2Z_CHECK(n % c->world == 0, L2Z_ERR_INVALID, "bulk all-reduce: %d columns over %d ranks", n, c->world);
+    const int n_loc = n / c->world;
+    if (comm_uses_p2p(c)) {
+        L2Z_CHECK((size_t)P * (size_t)n <= c->bulk_floats, L2Z_ERR_COMM,
+                  "bulk all-reduce of %zu floats exceeds the bulk landing region (%zu)", (size_t)P * (size_t)n, c->bulk_floats);
+        BulkArgs a = {};
+        a.stage = part; a.P = P; a.n_loc = n_loc; a.rank = c->rank; a.world = c->world;
+        for (int r = 0; r < c->world; r++) a.peer_arena[r] = c->peer_arena[r];
+        a.bulk_off = kP2pFlagBytes + 2 * c->slot_floats * 8;
+        a.bulk_floats = c->bulk_floats;
+        a.ctl = c->d_ctl; a.err = c->h_err;
+        a.timeout_ticks = tunables().p2p_timeout_s * 100000000LL;
+        const unsigned long long e = ++c->bulk_epoch;
+        hipError_t he = launch_bulk_scatter_push(a, e, st);
+        if (he == hipSuccess) he = launch_bulk_reduce(a, e, stage + (size_t)c->rank * P * n_loc, st);
+        L2Z_CHECK(he == hipSuccess, L2Z_ERR_HIP, "bulk all-reduce launch failed: %s", hipGetErrorString(he));
+        return comm_bulk_allgather(c, stage, P, n_loc, dst, ldd, st);
+    }
+    L2Z_CHECK(c->nccl != nullptr, L2Z_ERR_COMM, "bulk all-reduce: the shard group has no transport");
+    L2Z_CHECK(ldd == n, L2Z_ERR_INVALID, "bulk all-reduce over RCCL: the destination rows must be contiguous");
+    ncclResult_t r = g_api.AllReduce(part, dst, (size_t)P * (size_t)n, ncclFloat, ncclSum, static_cast<ncclComm_t>(c->nccl), st);
+    L2Z_CHECK(r == ncclSuccess, L2Z_ERR_COMM, "ncclAllReduce failed: %s", g_api.GetErrorString(r));
+    return L2Z_OK;
+}
+
 }  // namespace l2z
 
 using namespace l2z;

@@ -83,6 +83,11 @@ bool comm_uses_p2p(const l2z_comm *c);
 // bulk region and then one flag per peer; the unpack launch waits for each sender's flag.  RCCL: an
 // in-place ncclAllGather over the staging buffer, then the same unpack without waits.
 int comm_bulk_allgather(const l2z_comm *c, float *stage, int P, int n_loc, float *dst, int ldd, hipStream_t st);
+// Scheme B's batched prefill: dst[P, n] (ldd floats per row) = the sum over ranks, in rank order, of every rank's partial
+// [P, n] (contiguous rows of n).  Peer-write transport: reduce-scatter through the bulk regions (launch_bulk_scatter_push,
+// launch_bulk_reduce into stage + rank * P * n / world), then comm_bulk_allgather of the summed slices; RCCL: ncclAllReduce
+// (ldd == n).  Every rank ends with the same bits.
+int comm_bulk_allreduce(const l2z_comm *c, float *part, int P, int n, float *stage, float *dst, int ldd, hipStream_t st);
 // whether comm_bulk_allgather can carry P x n_total floats (a transport is there and, peer-write, the
 // bulk regions are large enough)
 bool comm_bulk_ok(const l2z_comm *c, size_t floats);
@@ -98,6 +103,10 @@ struct BulkArgs {
     long long timeout_ticks;
 };
 hipError_t launch_bulk_push(const BulkArgs &a, unsigned long long e, hipStream_t st);
+// scheme B's bulk all-reduce, first half (p2p.hip): a.stage = this rank's partial [P, world * n_loc]; every peer gets the
+// columns of ITS slice; then the owner's sum over ranks, in rank order, into out [P, n_loc]
+hipError_t launch_bulk_scatter_push(const BulkArgs &a, unsigned long long e, hipStream_t st);
+hipError_t launch_bulk_reduce(const BulkArgs &a, unsigned long long e, float *out, hipStream_t st);
 // wait != 0: blocks of peers' data come from this rank's bulk region (e & 1) once the sender's flag
 // says e; else every block is read from the staging buffer
 hipError_t launch_bulk_unpack(const BulkArgs &a, unsigned long long e, int wait, float *dst, int ldd,

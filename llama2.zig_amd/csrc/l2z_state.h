@@ -93,6 +93,7 @@ struct l2z_runstate {
     float *pf_x = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_att = nullptr;
     float *pf_h1 = nullptr;
     float *pf_stage = nullptr;  // sharded: [world][P, n_loc] blocks of the matrix being gathered
+    float *pf_part = nullptr;   // scheme B: this rank's partial [P, dim] product of its column shard of Wo / W2
     int *pf_tokens = nullptr;
     l2z::SplitKWs pf_sk = {nullptr, nullptr, 0, 0};  // split-K workspace of the tile GEMM (chunks of <= 256 tokens)
     int pf_cap = 0;             // tokens per chunk the scratch above was allocated for

@@ -272,7 +272,103 @@ __global__ __launch_bounds__(256) void bulk_unpack_kernel(const BulkArgs a, u64 
     }
 }
 
+// ---- bulk all-reduce (scheme B's batched prefill): reduce-scatter here, then the bulk all-gather above ----
+// Every rank holds a partial [P, n] matrix (n = world * n_loc; rank 0's carries the residual).  Rank r sends the columns of
+// peer p's slice to peer p -- a [P, n_loc] block into block `rank` of p's region (e & 1) -- and flags as bulk_push_kernel
+// does; the owner of a slice then adds the world blocks IN RANK ORDER (its own straight from its partial), so every rank
+// that later receives the slice holds the same bits.  Region reuse: as for the gathers (every bulk operation is a push
+// followed by a wait for every peer's push).
+__global__ __launch_bounds__(256) void bulk_scatter_push_kernel(const BulkArgs a, u64 e)
+{
+    const int pi = blockIdx.x / kBulkBlocksPerPeer, part = blockIdx.x % kBulkBlocksPerPeer;
+    const int p = (a.rank + 1 + pi) % a.world;
+    const int n_loc = a.n_loc, n = n_loc * a.world;
+    const size_t count = (size_t)a.P * n_loc;
+    float *dst = bulk_region(a.peer_arena[p], a, e) + (size_t)a.rank * count;
+    const float *src = a.stage + (size_t)p * n_loc;   // columns of p's slice, rows n floats apart
+    if ((n_loc & 3) == 0) {
+        const int n4 = n_loc >> 2;
+        const size_t total = (size_t)a.P * n4;
+        for (size_t i = (size_t)part * 256 + threadIdx.x; i < total; i += (size_t)kBulkBlocksPerPeer * 256) {
+            const size_t t = i / n4, j = i - t * n4;
+            ((float4 *)(dst + t * n_loc))[j] = ((const float4 *)(src + t * n))[j];
+        }
+    } else {
+        for (size_t i = (size_t)part * 256 + threadIdx.x; i < count; i += (size_t)kBulkBlocksPerPeer * 256) {
+            const size_t t = i / n_loc, j = i - t * n_loc;
+            dst[t * n_loc + j] = src[t * n + j];
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0 &&
+        __hip_atomic_fetch_add(a.ctl + kCtlBulkDone, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+        __hip_atomic_store(a.ctl + kCtlBulkDone, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_system();
+        for (int q = 0; q < a.world; q++)
+            if (q != a.rank)
+                __hip_atomic_store((u64 *)a.peer_arena[q] + a.rank, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// out[t][j] = sum over ranks, in rank order, of their blocks of THIS rank's slice; out: [P, n_loc] contiguous
+__global__ __launch_bounds__(256) void bulk_reduce_kernel(const BulkArgs a, u64 e, int wait, float *out)
+{
+    __shared__ int s_fail;
+    if (threadIdx.x == 0) {
+        s_fail = 0;
+        for (int p = 0; p < a.world && wait && !s_fail; p++) {
+            if (p == a.rank) continue;
+            const u64 *flag = (const u64 *)a.peer_arena[a.rank] + p;
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < e) {
+                if (__hip_atomic_load(a.ctl + kCtlErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                    wall_clock64() - t0 > a.timeout_ticks) {
+                    s_fail = 1 + p;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        if (s_fail) {
+            __hip_atomic_store(a.ctl + kCtlErr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *a.err = s_fail;
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: the senders' stores, not a stale line
+    const int n_loc = a.n_loc, n = n_loc * a.world;
+    const size_t count = (size_t)a.P * n_loc;
+    // wait == 0 (emulated ranks, tests): the peers' blocks already lie in a.stage-style buffers the caller copied
+    const float *region = bulk_region(a.peer_arena[a.rank], a, e);
+    const float *own = a.stage + (size_t)a.rank * n_loc;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        const size_t t = i / n_loc, j = i - t * n_loc;
+        float acc = 0.0f;
+        for (int p = 0; p < a.world; p++) {
+            const float v = p == a.rank ? own[t * n + j] : region[(size_t)p * count + i];
+            acc = p == 0 ? v : __fadd_rn(acc, v);
+        }
+        out[i] = acc;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_bulk_scatter_push(const BulkArgs &a, unsigned long long e, hipStream_t st)
+{
+    if (a.world < 2) return hipSuccess;
+    hipLaunchKernelGGL(bulk_scatter_push_kernel, dim3((a.world - 1) * kBulkBlocksPerPeer), dim3(256), 0, st, a, (u64)e);
+    return hipGetLastError();
+}
+
+hipError_t launch_bulk_reduce(const BulkArgs &a, unsigned long long e, float *out, hipStream_t st)
+{
+    const int cap = tunables().grid_cap;
+    const int blocks = cap > 0 ? (cap < 64 ? cap : 64) : 128;
+    hipLaunchKernelGGL(bulk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a, (u64)e, 1, out);
+    return hipGetLastError();
+}
 
 hipError_t launch_bulk_push(const BulkArgs &a, unsigned long long e, hipStream_t st)
 {

@@ -25,7 +25,7 @@ int prefill_alloc(l2z_runstate *s, int need)
     // l2z_option_set): start over, in steps of 512 tokens
     const size_t P = (size_t)(need + 511) / 512 * 512;
     L2Z_HIP(hipStreamSynchronize(s->stream));
-    float **bufs[] = {&s->pf_x, &s->pf_xn, &s->pf_q, &s->pf_att, &s->pf_h1, &s->pf_stage};
+    float **bufs[] = {&s->pf_x, &s->pf_xn, &s->pf_q, &s->pf_att, &s->pf_h1, &s->pf_stage, &s->pf_part};
     for (float **b : bufs)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     if (s->pf_tokens) { (void)hipFree(s->pf_tokens); s->pf_tokens = nullptr; }
@@ -37,6 +37,8 @@ int prefill_alloc(l2z_runstate *s, int need)
         {(void **)&s->pf_h1, P * c.hidden_dim * 4},
         // sharded: [world][P, n / world] blocks of the matrix being gathered
         {(void **)&s->pf_stage, s->sh.world > 1 ? P * widest * 4 : 0},
+        // scheme B: this rank's partial [P, dim] products of its column shards of Wo / W2 (summed by the bulk all-reduce)
+        {(void **)&s->pf_part, s->sh.scheme_b ? P * c.dim * 4 : 0},
         {(void **)&s->pf_tokens, P * 4}};
     for (auto &b : want) {
         if (b.bytes == 0) continue;
@@ -48,6 +50,12 @@ int prefill_alloc(l2z_runstate *s, int need)
         }
     }
     s->pf_cap = (int)P;
+    if (s->sh.scheme_b) {
+        // the local attention / hidden blocks are read as rows of the column shards' PADDED width: the pad columns are
+        // never written, and must be zeros (finite) against the shards' zero columns
+        L2Z_HIP(hipMemsetAsync(s->pf_att, 0, P * c.dim * 4, s->stream));
+        L2Z_HIP(hipMemsetAsync(s->pf_h1, 0, P * c.hidden_dim * 4, s->stream));
+    }
     if (s->pf_sk.part == nullptr) {
         // split-K family of the tile GEMM (chunks of 33 ... 256 tokens): accumulator dumps of up to 4 K ranges of
         // the widest launch of a layer (q | k | v, or W1 | W3 side by side), one arrival counter per output tile
@@ -211,6 +219,69 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
     return L2Z_OK;
 }
 
+// Scheme B (L2Z_SCHEME_B: Wo and W2 sharded by COLUMNS; forward.cpp): a layer is two halves, each ending in a partial
+// [P, dim] product of this rank's column shard -- pf_part, rank 0's with the residual (main.zig:395 / :422) -- that the
+// bulk all-reduce sums over the ranks in rank order into pf_x.  The attention output and the gated hidden rows of the
+// rank's own heads / hidden rows never leave it: they are the K-slices the column shards multiply.
+//   half 0: rmsnorm, q | k | v of the local heads, attention -> pf_att [P, dimc_pad]; Wo columns -> pf_part
+//   half 1: rmsnorm, W1 | W3 of the local rows -> pf_h1 [P, hidc_pad]; W2 columns -> pf_part
+// The products are split across ranks differently than in the unsharded pass: logits at the parity tolerance, the ranks
+// bit-identical to each other (tests/test_gpu_scheme_b.py).
+int prefill_half_b(l2z_runstate *s, const l2z_weights *w, int l, int half, int P, int pos0)
+{
+    const l2z_config &c = s->cfg;
+    const Shard &sh = s->sh;
+    hipStream_t st = s->stream;
+    const int dim = c.dim, kvd = sh.kvd_loc, hs = sh.hs;
+    float *kc = s->key_cache + (size_t)l * c.seq_len * kvd;
+    float *vc = s->value_cache + (size_t)l * c.seq_len * kvd;
+    const size_t kvh_stride = (size_t)c.seq_len * hs;
+    const SplitKWs *ws = &s->pf_sk;
+    // kernel forms are chosen from what every rank sees alike: the whole matrices' row counts and the shards' widths
+    const int kvd_whole = c.n_kv_heads * hs;
+    const int epi = sh.rank == 0 ? PG_RESID : PG_STORE;
+    if (half == 0) {
+        L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, s->pf_x, w->rms_att + (size_t)l * dim, dim, P, st));  // :305
+        const int sk_qkv = prefill_split_k((long long)dim + 2 * kvd_whole, P, dim, false);
+        const float *wq = w->wq + (size_t)l * sh.dim_loc * dim, *wk = w->wk + (size_t)l * kvd * dim, *wv = w->wv + (size_t)l * kvd * dim;
+        const hipError_t qe = launch_prefill_gemm_qkv(s->pf_xn, dim, wq, wk, wv, s->pf_q, sh.dim_loc, kc, vc, kvd, P, sh.dim_loc, kvd,
+                                                      dim, pos0, s->rope, hs, st, kvh_stride, sh.world, sk_qkv, ws);
+        if (qe == hipErrorNotSupported) {
+            L2Z_HIP(launch_prefill_gemm(PG_ROPE, s->pf_xn, dim, wq, s->pf_q, sh.dim_loc, P, sh.dim_loc, dim, pos0, s->rope, hs, st,
+                                        nullptr, 0, sh.world, 0, sk_qkv, ws));
+            L2Z_HIP(launch_prefill_gemm(PG_ROPE_CACHE, s->pf_xn, dim, wk, kc, kvd, P, kvd, dim, pos0, s->rope, hs, st, nullptr, 0,
+                                        sh.world, kvh_stride, sk_qkv, ws));
+            L2Z_HIP(launch_prefill_gemm(PG_CACHE, s->pf_xn, dim, wv, vc, kvd, P, kvd, dim, pos0, s->rope, hs, st, nullptr, 0,
+                                        sh.world, kvh_stride, sk_qkv, ws));
+        } else {
+            L2Z_HIP(qe);
+        }
+        L2Z_HIP(launch_prefill_attention(s->pf_q, sh.dim_loc, kc, vc, s->pf_att, sh.dimc_pad, pos0, P, sh.heads_loc, hs, hs,
+                                         kvh_stride, c.n_heads / c.n_kv_heads, c.seq_len, st, c.n_heads));   // :361-389
+        const int sk = prefill_split_k(dim, P, sh.dimc_pad, false);
+        L2Z_HIP(launch_prefill_gemm(epi, s->pf_att, sh.dimc_pad, w->wo + (size_t)l * dim * sh.dimc_pad, s->pf_part, dim, P, dim,
+                                    sh.dimc_pad, pos0, s->rope, hs, st, s->pf_x, dim, 1, 0, sk, ws));        // :392-395
+    } else {
+        L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, s->pf_x, w->rms_ffn + (size_t)l * dim, dim, P, st));  // :398
+        const int sk_h1 = prefill_split_k(c.hidden_dim, P, dim, true);
+        const float *w1 = w->w1 + (size_t)l * sh.hid_loc * 2 * dim, *w3 = w->w3 + (size_t)l * sh.hid_loc * 2 * dim;
+        const hipError_t pe = launch_prefill_gemm_swiglu_pair(s->pf_xn, dim, w1, w3, s->pf_h1, sh.hidc_pad, P, sh.hid_loc, dim, st,
+                                                              sh.world, sk_h1, ws, 2 * dim);
+        if (pe == hipErrorNotSupported) {
+            L2Z_HIP(launch_prefill_gemm(PG_STORE, s->pf_xn, dim, w1, s->pf_h1, sh.hidc_pad, P, sh.hid_loc, dim, pos0, s->rope, hs, st,
+                                        nullptr, 0, sh.world, 0, sk_h1, ws, 2 * dim));                     // :405
+            L2Z_HIP(launch_prefill_gemm(PG_SWIGLU, s->pf_xn, dim, w3, s->pf_h1, sh.hidc_pad, P, sh.hid_loc, dim, pos0, s->rope, hs,
+                                        st, nullptr, 0, sh.world, 0, sk_h1, ws, 2 * dim));                 // :408-416
+        } else {
+            L2Z_HIP(pe);
+        }
+        const int sk = prefill_split_k(dim, P, sh.hidc_pad, false);
+        L2Z_HIP(launch_prefill_gemm(epi, s->pf_h1, sh.hidc_pad, w->w2 + (size_t)l * dim * sh.hidc_pad, s->pf_part, dim, P, dim,
+                                    sh.hidc_pad, pos0, s->rope, hs, st, s->pf_x, dim, 1, 0, sk, ws));        // :419-422
+    }
+    return L2Z_OK;
+}
+
 int prefill_begin_chunk(l2z_runstate *s, const l2z_weights *w, const int32_t *tokens, int P)
 {
     // the split forms' arrival counters and flags are left at zero by every launch that completes; a pass that was
@@ -225,6 +296,14 @@ int prefill_begin_chunk(l2z_runstate *s, const l2z_weights *w, const int32_t *to
 int prefill_chunk(l2z_runstate *s, const l2z_weights *w, const int32_t *tokens, int P, int pos0)
 {
     L2Z_TRY(prefill_begin_chunk(s, w, tokens, P));
+    if (s->sh.scheme_b) {
+        for (int l = 0; l < s->cfg.n_layers; l++)
+            for (int half = 0; half < 2; half++) {
+                L2Z_TRY(prefill_half_b(s, w, l, half, P, pos0));
+                L2Z_TRY(comm_bulk_allreduce(s->comm, s->pf_part, P, s->cfg.dim, s->pf_stage, s->pf_x, s->cfg.dim, s->stream));
+            }
+        return L2Z_OK;
+    }
     for (int l = 0; l < s->cfg.n_layers; l++)
         for (int k = 0; k < PF_STAGES; k++) {
             L2Z_TRY(prefill_stage(s, w, l, k, P, pos0));
@@ -267,7 +346,13 @@ bool prefill_usable(const l2z_runstate *s)
 {
     const l2z_config &c = s->cfg;
     if (c.dim % 4 != 0 || c.hidden_dim % 4 != 0 || s->sh.hs % 4 != 0 || s->sh.hs > 256) return false;
-    if (s->sh.scheme_b) return false;  // column-sharded Wo / W2: the batched pass is built on row shards; prompts are stepped
+    if (s->sh.scheme_b) {
+        // column-sharded Wo / W2: two bulk all-reduces of [chunk, dim] per layer (a 1-rank RCCL group included)
+        if (c.dim % s->sh.world != 0 || (c.dim / s->sh.world) % 4 != 0 || s->sh.dim_loc % 4 != 0 || s->sh.hid_loc % 4 != 0) return false;
+        if (s->comm == nullptr) return false;
+        if (s->comm->world == 1) return s->comm->nccl != nullptr;
+        return comm_bulk_ok(s->comm, (size_t)kPrefillChunk * (size_t)c.dim);
+    }
     if (s->sh.world == 1) return true;
     if (s->sh.dim_loc % 4 != 0 || s->sh.hid_loc % 4 != 0) return false;
     const size_t widest = (size_t)(c.dim > c.hidden_dim ? c.dim : c.hidden_dim);
@@ -279,8 +364,6 @@ int prefill_check(const l2z_config *config, const l2z_runstate *s)
     L2Z_CHECK(config->dim % 4 == 0 && config->hidden_dim % 4 == 0 && s->sh.hs % 4 == 0 &&
                   s->sh.hs <= 256, L2Z_ERR_INVALID,
               "l2z_prefill: needs dim, hidden_dim, head_size multiples of 4 and head_size <= 256");
-    L2Z_CHECK(!s->sh.scheme_b, L2Z_ERR_INVALID,
-              "l2z_prefill: the batched pass is built on row shards; scheme-B runstates step their prompts");
     L2Z_CHECK(prefill_usable(s), L2Z_ERR_INVALID,
               "l2z_prefill: this sharded runstate has no transport for [%d, hidden_dim] matrices (RCCL "
               "communicator, or peer-write arena with bulk regions: L2Z_P2P_BULK_MB), or its row shards are "
@@ -359,8 +442,7 @@ extern "C" int l2z_emu_prefill(int n_ranks, l2z_runstate *const *ss, const l2z_w
         L2Z_CHECK(c.dim % 4 == 0 && c.hidden_dim % 4 == 0 && ss[r]->sh.hs % 4 == 0 && ss[r]->sh.hs <= 256 &&
                       ss[r]->sh.dim_loc % 4 == 0 && ss[r]->sh.hid_loc % 4 == 0,
                   L2Z_ERR_INVALID, "l2z_emu_prefill: shape not supported by the batched path");
-        L2Z_CHECK(!ss[r]->sh.scheme_b, L2Z_ERR_INVALID,
-                  "l2z_emu_prefill: the batched pass is built on row shards; scheme-B runstates step their prompts");
+        L2Z_CHECK(ss[r]->sh.scheme_b == ss[0]->sh.scheme_b, L2Z_ERR_INVALID, "l2z_emu_prefill: the ranks' sharding schemes differ");
         L2Z_TRY(prefill_alloc(ss[r], n_tokens < kPrefillChunk ? n_tokens : kPrefillChunk));
     }
     auto sync_all = [&]() -> int {
@@ -381,6 +463,21 @@ extern "C" int l2z_emu_prefill(int n_ranks, l2z_runstate *const *ss, const l2z_w
     while (done < n_tokens) {
         const int P = prefill_next_chunk(n_tokens - done);
         for (int r = 0; r < n_ranks; r++) L2Z_TRY(prefill_begin_chunk(ss[r], ws[r], tokens + done, P));
+        if (ss[0]->sh.scheme_b) {
+            // scheme B: every rank's half layer, then the all-reduce -- every rank's pf_x = the partials summed in rank order
+            L2Z_CHECK(n_ranks <= kMaxWorld, L2Z_ERR_INVALID, "l2z_emu_prefill: more than %d ranks", kMaxWorld);
+            for (int l = 0; l < c.n_layers; l++)
+                for (int half = 0; half < 2; half++) {
+                    const float *parts[kMaxWorld];
+                    for (int r = 0; r < n_ranks; r++) {
+                        L2Z_TRY(prefill_half_b(ss[r], ws[r], l, half, P, pos0 + done));
+                        L2Z_HIP(hipStreamSynchronize(ss[r]->stream));
+                        parts[r] = ss[r]->pf_part;
+                    }
+                    for (int r = 0; r < n_ranks; r++) L2Z_HIP(launch_sum_parts(ss[r]->pf_x, parts, n_ranks, P * c.dim, nullptr));
+                    L2Z_HIP(hipDeviceSynchronize());
+                }
+        } else
         for (int l = 0; l < c.n_layers; l++)
             for (int k = 0; k < PF_STAGES; k++) {
                 // one rank at a time: on hardware every rank has a GPU to itself, so kernel times taken from

@@ -1,12 +1,13 @@
-// prefill_panel.hip -- the GEMM of the batched prompt pass for SHORT chunks (P <= 32 tokens) of matrices that stream from
+// prefill_panel.hip -- the GEMM of the batched prompt pass for SHORT chunks (17 ... 64 tokens) of matrices that stream from
 // HBM (round 5): weight-streaming bound like the decode mat-vec, so the kernel is built around the W stream and nothing
 // else comes into a CU twice.
 //
 // prefill_skinny.hip's forms give a block 16 (or 2 x 16) rows of W and ALL of K, so every block re-reads the whole X
 // ([P, K], from L2) beside its rows: 1 byte of X per 1-2 bytes of W into every CU, and the W stream stalls at 4.4-5.2 TB/s
 // (a CU takes in ~13-15 bytes per cycle of W + X together).  Here the product is cut the other way:
-//   * K is cut into RANGES of 512 (kPnRange; the last one of a row may be shorter: K % 128 == 0).  A block works on ONE
-//     range at a time and keeps that range of X -- the "panel", [16 TMS tokens][512] -- resident in LDS; what streams
+//   * K is cut into RANGES of 512 (kPnRange; 256 for chunks of 33 ... 64 tokens; the last one of a row may be shorter:
+//     K % 128 == 0).  A block works on ONE range at a time and keeps that range of X -- the "panel", [16 TMS tokens][512]
+//     (TMS = 1, 2; [64][256] at TMS = 4) -- resident in LDS; what streams
 //     through the CU is W alone, rows of 512-byte pieces, 64 rows per work item.
 //   * A work item is (range, 64 rows): wave w of the block's four owns rows 16 w .. 16 w + 15 of it, brings their 128-k
 //     stages in through its OWN ring of three 8-KB LDS buffers (direct-to-LDS loads, non-temporal) and multiplies them
@@ -32,7 +33,9 @@ constexpr int kPnStage = 128;                 // k per ring stage: a row's piece
 constexpr int kPnRange = 512;                 // k per range, chunks of <= 32 tokens: four stages (33 ... 64 tokens: 256, two)
 constexpr int kPnStageFloats = 16 * kPnStage; // one ring buffer: 16 rows x 128
 constexpr int kPnLoads = 8;                   // wave-wide loads per stage
-constexpr int kPanelDefaultMax = 32;          // longest chunk that takes the kernel by default
+// longest chunk that takes the kernel: 33 ... 64 tokens run four token tiles against ranges of 256 (MFMA-bound there: the
+// tile GEMM's split-K family took 12.5 ms for 40 ... 64 tokens at the 7B shape, this 10.8 ... 11.2)
+constexpr int kPanelDefaultMax = 64;
 // ... and the shortest: up to 16 tokens the short-prompt GEMMs of prefill_skinny.hip are ahead -- their products need no
 // second launch (7B shape, whole prefill of 8 / 16 / 24 / 32 tokens: 5.31 / 5.65 / 8.76 / 8.78 ms there, 6.02 / 6.16 /
 // 6.92 / 6.98 here; profiles/r05b_prefill_panel_ab.txt)
@@ -278,7 +281,6 @@ bool prefill_panel_shape(long long n_whole, int P, int K)
     if (tunables().pf_panel == 0 || tunables().pf_dma == 0 || tunables().pf_tile != 0) return false;
     const int p_min = tunables().pf_panel_min >= 0 ? tunables().pf_panel_min : kPanelDefaultMin;
     if (P < p_min || P < 1 || P > prefill_panel_max_tokens() || K % kPnStage != 0 || K < kPnRange) return false;
-    // (33 ... 64 tokens: four token tiles against ranges of 256 -- an option, L2Z_PF_PANEL_MAX=64: MFMA-bound there)
     return n_whole * (long long)K * 4 > ((long long)16 << 20);  // matrices that stream from HBM; cache-resident ones keep the short-prompt forms
 }
 
@@ -289,9 +291,10 @@ hipError_t launch_prefill_panel(const PanelProduct &p, int n_cus, const SplitKWs
     if (((uintptr_t)p.x & 15) || ((uintptr_t)p.w0 & 15) || ((uintptr_t)p.w1 & 15) || ((uintptr_t)p.w2 & 15)) return hipErrorNotSupported;
     if (ws == nullptr || ws->part == nullptr) return hipErrorNotSupported;
     const int tms = p.P <= 16 ? 1 : p.P <= 32 ? 2 : 4;
-    const int form = tunables().pf_panel_form;   // 1: deeper rings (experiments)
-    const int kr = tms == 4 || (tms == 2 && form == 1) ? 256 : kPnRange;
-    const int depth = form == 1 && tms <= 2 ? 4 : 3;
+    // (four ring buffers per wave -- for two token tiles against ranges of 256 -- measured slower: 20 / 32 tokens 6.72 /
+    // 6.82 ms with three, 7.55 / 7.66 with four; profiles/r05c_prefill_panel_ab.txt)
+    const int kr = tms == 4 ? 256 : kPnRange;
+    const int depth = 3;
     const int n_ranges = (p.K + kr - 1) / kr;
     if ((size_t)n_ranges * (size_t)(16 * tms) * (size_t)N > ws->part_floats) return hipErrorNotSupported;
     PanelArgs a = {};
@@ -301,9 +304,8 @@ hipError_t launch_prefill_panel(const PanelProduct &p, int n_cus, const SplitKWs
     a.n_groups = (N + 63) / 64;
     a.n_items = n_ranges * a.n_groups;
     const size_t lds = (size_t)(16 * tms * kr + 4 * depth * kPnStageFloats) * sizeof(float);
-    const void *fn = tms == 1 ? (depth == 4 ? (const void *)prefill_panel<1, kPnRange, 4> : (const void *)prefill_panel<1, kPnRange, 3>)
-                   : tms == 2 ? (depth == 4 ? (const void *)prefill_panel<2, 256, 4> : (const void *)prefill_panel<2, kPnRange, 3>)
-                              : (const void *)prefill_panel<4, 256, 3>;
+    const void *fn = tms == 1 ? (const void *)prefill_panel<1, kPnRange, 3> : tms == 2 ? (const void *)prefill_panel<2, kPnRange, 3>
+                                                                                       : (const void *)prefill_panel<4, 256, 3>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
         (void)hipGetLastError();

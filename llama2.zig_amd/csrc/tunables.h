@@ -64,9 +64,8 @@ struct Tunables {
                                //                     0 never, 10 + f: always, on tile form f (0 128x64, 1 64x64, 2 32x64, 4 128x128)
     int pf_panel = 1;          // L2Z_PF_PANEL        0: chunks of <= 32 tokens keep the short-prompt GEMMs (prefill_skinny.hip) instead of the
                                //                     K-range panel kernel (prefill_panel.hip; changes rounding: the ranges are part of the arithmetic)
-    int pf_panel_max = -1;     // L2Z_PF_PANEL_MAX    longest chunk that takes the panel kernel (default 32 tokens; up to 64: four token tiles against ranges of 256)
+    int pf_panel_max = -1;     // L2Z_PF_PANEL_MAX    longest chunk that takes the panel kernel (default and maximum 64 tokens)
     int pf_panel_min = -1;     // L2Z_PF_PANEL_MIN    shortest chunk that takes it (default 17: up to 16 tokens the short-prompt GEMMs are ahead)
-    int pf_panel_form = 0;     // L2Z_PF_PANEL_FORM   1: four ring buffers per wave (two token tiles: against ranges of 256) -- experiments
     int pf_splitk = -1;        // L2Z_PF_SPLITK       K ranges per output tile of the tile GEMM for chunks of <= 256 tokens: -1 by shape,
                                //                     1 none, 2 / 4 forced (changes rounding: the range partials are added in range order)
 };

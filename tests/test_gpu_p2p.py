@@ -158,6 +158,37 @@ def test_multiprocess_scheme_b_allreduce(gpu, ck, tmp_path, model, mode, options
     s.close(); w.close()
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_multiprocess_scheme_b_batched_prefill(gpu, ck, tmp_path, world, options):
+    """Scheme B's batched prompt pass with REAL processes: per layer two bulk all-reduces of the ranks' partial [tokens,
+    dim] products -- reduce-scatter through the arenas' bulk regions (every peer gets the columns of ITS slice, adds the
+    blocks in rank order), then the bulk all-gather of the summed slices (csrc/p2p.hip, comm.cpp comm_bulk_allreduce).
+    The greedy loop takes it for its 150-token prompt; l2z_prefill in two calls.  Ranks bit-identical to each other;
+    against the unsharded pass fed the same tokens: the logit tolerance."""
+    options(L2Z_FUSE_SMALL=0)
+    kw = dict(dim=512, hidden_dim=1408, n_layers=2, n_heads=16, n_kv_heads=8, vocab_size=1024, seq_len=256)
+    cfg = ck.Config(**kw)
+    rng = np.random.default_rng(3)
+    prompt = rng.integers(2, cfg.vocab_size, 150).tolist()
+    pf = [1] + prompt[:149]
+    spec = dict(cfg=kw, shared=False, seed=41, prompt=prompt, steps=170, blob=False, prefill=pf, prefill_split=9)
+    run_ranks(tmp_path, world, spec, {"L2Z_SCHEME_B": "1"})
+    outs = [np.load(tmp_path / f"out_{r}.npz") for r in range(world)]
+    for r in range(1, world):
+        for k in ("toks", "logits", "pf_logits"):
+            assert np.array_equal(outs[r][k], outs[0][k]), f"rank {r} {k} differs from rank 0"
+    toks = outs[0]["toks"]
+    assert toks[:150].tolist() == prompt
+    w, s = gpu.Weights(cfg, None, False, seed=41), gpu.RunState(cfg)
+    s.greedy_begin(toks.tolist())          # the sharded run's tokens forced (main.zig:999-1000)
+    s.greedy_run(w, len(toks))
+    np.testing.assert_allclose(outs[0]["logits"], s.logits(), rtol=5e-5, atol=5e-5)
+    s.prefill(pf[:9], 0, w); s.prefill(pf[9:], 9, w)
+    np.testing.assert_allclose(outs[0]["pf_logits"], s.logits(), rtol=5e-5, atol=5e-5)
+    print(f"scheme B batched prefill x{world} processes: max |logit - unsharded| {np.abs(outs[0]['pf_logits'] - s.logits()).max():.2e}")
+    s.close(); w.close()
+
+
 def test_landing_slots_too_small_are_refused(gpu, tmp_path):
     kw = MODELS[2][1]  # vocab 32000: half of it rounds up to 16384 words, too few
     spec = dict(cfg=kw, shared=True, seed=1, prompt=[], steps=4, expect="slot_error")

@@ -905,12 +905,11 @@ def test_prefill_panel_kernel_vs_oracle(gpu, ck, orc, options, kv_heads):
     resident X panel, the ranges added in order by a second launch that also runs the epilogue -- RoPE + cache rows,
     residual, SiLU * mul).  A wide two-layer shape whose hidden_dim leaves a SHORT last range (8448 = 16.5 x 512), MHA
     and GQA: logits and KV rows against the CPU oracle's stepped loop for chunks of 1 / 16 (one token tile; below the
-    default switch-over, so forced: L2Z_PF_PANEL_MIN=1), 17 / 32 (two), 33 / 64 (four tiles against ranges of 256:
-    L2Z_PF_PANEL_MAX=64), a second call continuing the context, the deeper-ring forms; and against the short-prompt
-    GEMMs (L2Z_PF_PANEL=0) within the tolerance."""
+    default switch-over, so forced: L2Z_PF_PANEL_MIN=1), 17 / 32 (two), 33 / 64 (four tiles against ranges of 256), a
+    second call continuing the context; and against the short-prompt GEMMs (L2Z_PF_PANEL=0) within the tolerance."""
     kw = dict(dim=3072, hidden_dim=8448, n_layers=2, n_heads=24, n_kv_heads=kv_heads, vocab_size=2048, seq_len=80)
     cfg = ck.Config(**kw)
-    options(L2Z_PF_PANEL_MIN=1, L2Z_PF_PANEL_MAX=64)
+    options(L2Z_PF_PANEL_MIN=1)
     blob = ck.synth_blob(cfg, False, seed=55)
     w, s = gpu.Weights(cfg, blob, False), gpu.RunState(cfg)
     m = orc.Model(cfg.as_i32(), blob, False)
@@ -934,17 +933,16 @@ def test_prefill_panel_kernel_vs_oracle(gpu, ck, orc, options, kv_heads):
         ref = m.transformer(toks[pos], pos)
     s.prefill(toks[64:72], 64, w)
     np.testing.assert_allclose(s.logits(), ref, rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
-    # 32 + 8 tokens: the default form, the deeper rings (one tile: the same ranges, the same bits; two tiles: ranges
-    # of 256, other bits), and the short-prompt GEMMs: another summation order, the same tolerance
+    # 32 + 8 tokens: the panel kernel and the short-prompt GEMMs: another summation order, the same tolerance
     for pos in range(40):
         ref = m.transformer(toks[pos], pos)
     got = {}
-    for tag, opts in (("default", {}), ("deep", dict(L2Z_PF_PANEL_FORM=1)), ("skinny", dict(L2Z_PF_PANEL=0))):
+    for tag, opts in (("default", {}), ("skinny", dict(L2Z_PF_PANEL=0))):
         options(**opts)
         s.prefill(toks[:32], 0, w); s.prefill(toks[32:40], 32, w)
         got[tag] = s.logits()
         np.testing.assert_allclose(got[tag], ref, rtol=LOGIT_RTOL, atol=LOGIT_ATOL, err_msg=tag)
-        options(L2Z_PF_PANEL_FORM=0, L2Z_PF_PANEL=1)
+        options(L2Z_PF_PANEL=1)
     assert not np.array_equal(got["skinny"], got["default"]), "L2Z_PF_PANEL=0 did not change the path"
     print(f"panel kernel, kv heads {kv_heads}: max |logit - oracle| {worst:.2e}")
     m.close(); s.close(); w.close()

@@ -88,15 +88,58 @@ def test_scheme_b_objects_must_match(gpu, ck):
     comm.close(); comm1.close()
 
 
-def test_scheme_b_refuses_the_batched_prefill(gpu, ck, scheme_b):
-    """The batched prompt pass is built on row shards; a scheme-B runstate says so (its prompts are stepped)."""
-    cfg = ck.Config(dim=128, hidden_dim=352, n_layers=1, n_heads=16, n_kv_heads=8, vocab_size=512, seq_len=64)
-    comms = [gpu.Comm(r, 2, None, 0, emulated=True) for r in range(2)]
-    ws = [gpu.Weights(cfg, None, False, seed=1, comm=c) for c in comms]
+PREFILL_SHAPES = [
+    # shards narrower than a tile, 45 tokens: the short-prompt GEMMs on K = 16 ... 64-column shards
+    ("toy-gqa", dict(dim=128, hidden_dim=352, n_layers=2, n_heads=16, n_kv_heads=8, vocab_size=512, seq_len=64), 45),
+    # hidden shards of 1376 floats padded to 1536 (N = 2); 150 tokens: the tile GEMMs, flash attention
+    ("pad-1376", dict(dim=1024, hidden_dim=2752, n_layers=2, n_heads=16, n_kv_heads=8, vocab_size=2048, seq_len=192), 150),
+    # the 7B widths, one layer, 70 tokens: column shards of 2048 ... 512 (Wo) and 5632 ... 1536 (W2) floats as the GEMMs' K
+    ("7B-width", dict(dim=4096, hidden_dim=11008, n_layers=1, n_heads=32, n_kv_heads=32, vocab_size=4096, seq_len=96), 70),
+]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("name,kw,n_tok", PREFILL_SHAPES, ids=[s[0] for s in PREFILL_SHAPES])
+def test_scheme_b_batched_prefill_emulated_ranks(gpu, ck, options, scheme_b, world, name, kw, n_tok):
+    """The batched prompt pass on column-sharded Wo / W2 (prefill_host.cpp prefill_half_b; main.zig:999-1000 over :392 /
+    :419): per layer two partial [tokens, dim] products per rank, summed over the ranks in rank order (here by the
+    emulated-rank driver; real groups: the bulk all-reduce).  Two calls (pos0 > 0 for the second).  Every rank's logits
+    equal rank 0's bit for bit; against the UNSHARDED batched pass they hold the logit tolerance (the products are split
+    across ranks differently), KV rows likewise; decoding continues from the sharded state."""
+    options(L2Z_FUSE_SMALL=0)
+    cfg = ck.Config(**kw)
+    gpu.option_set("L2Z_SCHEME_B", 0)
+    w0, s0 = gpu.Weights(cfg, None, False, seed=29), gpu.RunState(cfg)
+    gpu.option_set("L2Z_SCHEME_B", 1)
+    comms = [gpu.Comm(r, world, None, 0, emulated=True) for r in range(world)]
+    ws = [gpu.Weights(cfg, None, False, seed=29, comm=c) for c in comms]
     ss = [gpu.RunState(cfg, comm=c) for c in comms]
-    with pytest.raises(gpu.L2ZError):
-        gpu.emu_prefill(ss, ws, [1] + list(range(2, 40)), 0)
-    for o in ss + ws:
+    assert all(s.form() & 8 for s in ss)
+    rng = np.random.default_rng(8)
+    toks = [1] + rng.integers(2, cfg.vocab_size, n_tok - 1).tolist()
+    worst = 0.0
+    for lo, hi in ((0, 9), (9, n_tok)):
+        s0.prefill(toks[lo:hi], lo, w0)
+        gpu.emu_prefill(ss, ws, toks[lo:hi], lo)
+        ref, got = s0.logits(), ss[0].logits()
+        for r in range(1, world):
+            assert np.array_equal(ss[r].logits(), got), f"{name} x{world}: rank {r} differs from rank 0 after tokens {lo}..{hi}"
+        np.testing.assert_allclose(got, ref, rtol=LOGIT_RTOL, atol=LOGIT_ATOL, err_msg=f"{name} x{world} tokens {lo}..{hi}")
+        worst = max(worst, float(np.abs(got - ref).max()))
+    kvd, S = cfg.kv_dim, cfg.seq_len
+    kvl = kvd // world
+    for l in range(cfg.n_layers):
+        for nm in ("key_cache", "value_cache"):
+            full = s0.read(nm, l * S * kvd, n_tok * kvd).reshape(n_tok, kvd)
+            for r in range(world):
+                mine = ss[r].read(nm, l * S * kvl, n_tok * kvl).reshape(n_tok, kvl)
+                np.testing.assert_allclose(mine, full[:, r * kvl:(r + 1) * kvl], rtol=2e-5, atol=2e-5, err_msg=f"{nm} layer {l} rank {r}")
+    nxt = s0.argmax()
+    s0.transformer(nxt, n_tok, w0)
+    gpu.emu_transformer(ss, ws, nxt, n_tok)
+    np.testing.assert_allclose(ss[0].logits(), s0.logits(), rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
+    print(f"scheme B batched prefill {name} x{world}: max |logit - unsharded| {worst:.2e}")
+    for o in ss + ws + [s0, w0]:
         o.close()
     for c in comms:
         c.close()
@@ -122,6 +165,11 @@ def test_rccl_allreduce_call_path_world1(gpu, ck, scheme_b):
     assert np.array_equal(got, ref)
     s1.transformer(1, 0, w1)
     s0.transformer(1, 0, w0)
+    np.testing.assert_allclose(s1.logits(), s0.logits(), rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
+    # the batched prompt pass on the same group: its all-reduce is ncclAllReduce over the [tokens, dim] partial
+    prompt = [1] + list(range(5, 24))
+    s1.prefill(prompt, 0, w1)
+    s0.prefill(prompt, 0, w0)
     np.testing.assert_allclose(s1.logits(), s0.logits(), rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
     for o in (s0, s1, w0, w1):
         o.close()
