@@ -449,11 +449,11 @@ def single_gpu(args) -> None:
                                     "unit": "TFLOP/s", "frac": flops_tok * n_p / dtp / 1e12 / MFMA_F32_PEAK_TF,
                                     "note": "whole prefill (GEMMs + attention + norms), GEMM flops only "
                                             "in the numerator; v_mfma_f32_32x32x2_f32"}}
-            # shorter prompts: other kernels (<= 64 tokens: weight-streaming bound short-prompt GEMMs; 65-256:
-            # smaller tiles so that every CU has a block) -- ms per prompt length, with the bound that applies
+            # shorter prompts: other kernels (<= 16 tokens: the weight-streaming bound short-prompt GEMMs; 17-64: the
+            # K-range panel kernel; 65-256: smaller tiles / split K) -- ms per prompt length, with the bound that applies
             by_len, frac_by_len = {}, {}
             bytes_tok = weight_bytes_per_token(cfg)
-            for n_s in (16, 64, 128):
+            for n_s in (16, 32, 64, 128):
                 if n_s < cfg.seq_len:
                     d = time_prefill(n_s)
                     by_len[str(n_s)] = d * 1e3
@@ -710,9 +710,7 @@ def leg_main(args) -> int:
     # the arena's bulk regions on the p2p legs, ncclAllGather on the RCCL leg): a diagnostic beside the
     # decode figure
     prefill_sharded = None
-    if scheme_b:
-        prefill_sharded = {"skipped": "the batched prompt pass is built on row shards; scheme-B runstates step their prompts"}
-    elif not args.no_extra and os.environ.get("L2Z_BENCH_NO_SHARDED_PREFILL", "") != "1":
+    if not args.no_extra and os.environ.get("L2Z_BENCH_NO_SHARDED_PREFILL", "") != "1":
         err = None
         dtp = 0.0
         n_p = min(512, cfg.seq_len - 1)
@@ -733,8 +731,10 @@ def leg_main(args) -> int:
             t = torch.tensor([dtp], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             prefill_sharded = {"prompt_tokens": n_p, "ms": float(t.item()) * 1e3, "tokens_per_s": n_p / float(t.item()),
-                               "exchange": "ncclAllGather + unpack" if kind in RCCL_LEGS else
-                                           "bulk regions of the peer-write arena (plain 16-byte peer stores + a flag per sender)",
+                               "exchange": ("ncclAllReduce of the [tokens, dim] partials" if kind == "rccl-allreduce" else
+                                            "ncclAllGather + unpack" if kind in RCCL_LEGS else
+                                            "bulk all-reduce: reduce-scatter + all-gather through the peer-write arena's bulk regions" if scheme_b else
+                                            "bulk regions of the peer-write arena (plain 16-byte peer stores + a flag per sender)"),
                                "ranks_agree": ranks_agree(s)}
         else:
             prefill_sharded = {"error": str(err) if err else "failed on another rank"}

@@ -143,7 +143,9 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const ArgmaxArgs a)
         }
     }
     if (tid == 0) {
-        if (bi == 0x7fffffff) bi = 0;
+        // (an index outside the vocabulary can only come from a corrupted exchange -- a solo rank's collapsed epochs, a
+        // peer that died mid-word: never let it address the embedding table)
+        if (bi == 0x7fffffff || (unsigned)bi >= (unsigned)a.vocab) bi = 0;
         if (a.epoch_ctl) a.epoch_ctl[0] += a.epoch_add;  // every launch of the pass has read its epoch long ago
         if (a.argmax_out) *a.argmax_out = bi;
         int next = bi;

@@ -811,6 +811,7 @@ hipError_t gemm_launch_kgs(const GemmArgs &a, int n_feat, TileForm tile, const S
 // where the short-prompt kernels would read W twice -- and the block-starved ones 2 ranges at 65 ... 128;
 // everything else stays as it was.  The hand-off (accumulator dump, counter, the last arriver's re-read) costs 6-8 us per launch, which is
 // why 4 ranges of a 30-60 us product lose what the larger tile wins.
+constexpr long long kRefCus = 256;  // the part the split-K rule was measured on; see prefill_split_k
 int prefill_split_k(long long n_whole, int P, int K, bool pair)
 {
     (void)pair;
@@ -829,9 +830,11 @@ int prefill_split_k(long long n_whole, int P, int K, bool pair)
         // two ranges (rocprofv3, 128 tokens: wo 61 -> 54 us, W2 162 -> 130, but q|k|v 126 -> 133, W1|W3 237 -> 256)
         const long long unsplit_blocks = ((n_whole + 63) / 64) * ((P + 31) / 32);
         if (streams && P >= 49 && P <= 64) sk = 4;
-        // (1.5 blocks per CU of a 256-CU part, as a constant: the split is part of the arithmetic and must not depend
-        // on the device a rank happens to run on)
-        else if (streams && P > 64 && P <= 128 && 2 * unsplit_blocks <= 3 * 256) sk = 2;
+        // 1.5 blocks per CU of the REFERENCE part (kRefCus = 256: MI355X), as a constant: the split is part of the
+        // arithmetic, so it must not depend on the device a rank happens to run on.  (Until round 3 this compared with
+        // the running device's CU count: on a part with another CU count the shapes that take two ranges -- and with
+        // them the low-order bits of 65 ... 128-token prefills -- differ from results recorded before that change.)
+        else if (streams && P > 64 && P <= 128 && 2 * unsplit_blocks <= 3 * kRefCus) sk = 2;
     }
     while (sk > 1 && K % (64 * sk) != 0) sk >>= 1;
     return sk;

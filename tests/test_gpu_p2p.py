@@ -158,7 +158,7 @@ def test_multiprocess_scheme_b_allreduce(gpu, ck, tmp_path, model, mode, options
     s.close(); w.close()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_multiprocess_scheme_b_batched_prefill(gpu, ck, tmp_path, world, options):
     """Scheme B's batched prompt pass with REAL processes: per layer two bulk all-reduces of the ranks' partial [tokens,
     dim] products -- reduce-scatter through the arenas' bulk regions (every peer gets the columns of ITS slice, adds the
@@ -180,6 +180,7 @@ def test_multiprocess_scheme_b_batched_prefill(gpu, ck, tmp_path, world, options
     toks = outs[0]["toks"]
     assert toks[:150].tolist() == prompt
     w, s = gpu.Weights(cfg, None, False, seed=41), gpu.RunState(cfg)
+    options(L2Z_PREFILL=0)                 # the reference steps through: a loop that is all prompt would compute no logits
     s.greedy_begin(toks.tolist())          # the sharded run's tokens forced (main.zig:999-1000)
     s.greedy_run(w, len(toks))
     np.testing.assert_allclose(outs[0]["logits"], s.logits(), rtol=5e-5, atol=5e-5)

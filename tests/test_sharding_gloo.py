@@ -179,7 +179,7 @@ def test_scheme_b_schedule(world, tmp_path, ck, orc):
     m.close()
 
 
-def _prefill_worker(rank, world, port, kw, shared, seed, toks, out_dir):
+def _prefill_worker(rank, world, port, kw, shared, seed, toks, out_dir, scheme="A"):
     """The row-sharded BATCHED prefill (csrc/prefill_host.cpp: prefill_stage / comm_bulk_allgather /
     bulk_unpack_kernel) for one chunk: every stage ends in a [P, n] matrix whose columns are split over
     the ranks; a rank's [P, n_loc] block sits contiguously at stage[rank], the blocks are all-gathered and
@@ -214,6 +214,20 @@ def _prefill_worker(rank, world, port, kw, shared, seed, toks, out_dir):
             out[:, p * n_loc:(p + 1) * n_loc] = stage[p].numpy().reshape(P, n_loc)
         return out
 
+    def bulk_allreduce(part):
+        """Scheme B (comm.cpp comm_bulk_allreduce): part [P, n] -> the sum over ranks IN RANK ORDER, on every rank: every
+        peer gets the columns of ITS slice (reduce-scatter; here an all_gather of whole partials, each rank reading its
+        slice of every block), adds the world blocks in rank order, and the summed slices are all-gathered and unpacked."""
+        n = part.shape[1]
+        n_loc = n // world
+        blocks = [torch.zeros(P * n) for _ in range(world)]
+        dist.all_gather(blocks, torch.from_numpy(np.ascontiguousarray(part).reshape(-1).copy()))
+        mine = None
+        for p in range(world):                                           # bulk_reduce_kernel: rank order
+            blk = blocks[p].numpy().reshape(P, n)[:, rank * n_loc:(rank + 1) * n_loc].astype(np.float32)
+            mine = blk.copy() if mine is None else (mine + blk).astype(np.float32)
+        return gather_unpack(mine)
+
     rows = lambda X, Wm: np.stack([orc.matmul(X[t], Wm) for t in range(P)])   # the oracle's dot products per token
     x = np.stack([W["token_embedding_table"][t] for t in toks]).astype(np.float32)
     for l in range(cfg.n_layers):
@@ -237,11 +251,22 @@ def _prefill_worker(rank, world, port, kw, shared, seed, toks, out_dir):
                 a = orc.softmax(a)
                 att[t, hl * hs:(hl + 1) * hs] = orc.vector_weighted_sum_rows(
                     hs, np.ascontiguousarray(vc[l, :t + 1].reshape(-1)[kh:]), k1 - k0, a)
+        one = np.float32(1.0)
+        if scheme == "B":
+            # prefill_half_b: the local heads' output against this rank's COLUMNS of every row of Wo (:392), rank 0's
+            # partial with the residual (:395); likewise the local hidden rows against W2's columns (:419-422)
+            part = rows(att, np.ascontiguousarray(W["wo"][l][:, d0:d1]))
+            x = bulk_allreduce((x + part).astype(np.float32) if rank == 0 else part)
+            xn = np.stack([orc.rmsnorm(x[t], W["rms_ffn_weight"][l]) for t in range(P)])
+            a, b = rows(xn, W["w1"][l][h0:h1]), rows(xn, W["w3"][l][h0:h1])
+            hloc = ((a * (one / (one + np.exp(-a, dtype=np.float32)))) * b).astype(np.float32)
+            part = rows(hloc, np.ascontiguousarray(W["w2"][l][:, h0:h1]))
+            x = bulk_allreduce((x + part).astype(np.float32) if rank == 0 else part)
+            continue
         att_full = gather_unpack(att)                                                    # PF_ATT
         x = gather_unpack(x[:, d0:d1] + rows(att_full, W["wo"][l][d0:d1]))               # PF_WO (res = x[:, d0:d1])
         xn = np.stack([orc.rmsnorm(x[t], W["rms_ffn_weight"][l]) for t in range(P)])
         a, b = rows(xn, W["w1"][l][h0:h1]), rows(xn, W["w3"][l][h0:h1])
-        one = np.float32(1.0)
         h1m = gather_unpack((a * (one / (one + np.exp(-a, dtype=np.float32)))) * b)      # PF_H1
         x = gather_unpack(x[:, d0:d1] + rows(h1m, W["w2"][l][d0:d1]))                    # PF_W2
     xf = orc.rmsnorm(x[P - 1], W["rms_final_weight"])
@@ -253,6 +278,29 @@ def _prefill_worker(rank, world, port, kw, shared, seed, toks, out_dir):
     np.save(os.path.join(out_dir, f"pf_k_rank{rank}.npy"), kc[:, :P])
     dist.barrier()
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_scheme_b_prefill_schedule(world, tmp_path, ck, orc):
+    """Scheme B's batched prefill (prefill_host.cpp prefill_half_b + comm_bulk_allreduce) on gloo ranks: column shards of
+    Wo / W2, partial [tokens, dim] products summed in rank order by the slice owners and re-gathered.  The last
+    position's logits hold the parity tolerance against the oracle's stepped pass (the row sums are split across ranks),
+    and every rank holds the same bits."""
+    import torch.multiprocessing as mp
+
+    kw = _toy(world)
+    shared, seed, toks = False, 79, [1, 40, 300, 7, 9, 11, 500]
+    cfg = ck.Config(**kw)
+    mp.spawn(_prefill_worker, args=(world, _free_port(), kw, shared, seed, toks, str(tmp_path), "B"), nprocs=world, join=True)
+    m = orc.Model(cfg.as_i32(), ck.synth_blob(cfg, shared, seed), shared)
+    ref = None
+    for p, t in enumerate(toks):
+        ref = m.transformer(t, p)
+    for r in range(world):
+        got = np.load(tmp_path / f"pf_rank{r}.npy")
+        np.testing.assert_allclose(got, ref, rtol=5e-5, atol=5e-5)
+        assert np.array_equal(got, np.load(tmp_path / "pf_rank0.npy"))
+    m.close()
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
