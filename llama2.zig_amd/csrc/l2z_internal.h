@@ -280,7 +280,8 @@ struct PanelProduct {
     const float2 *rope;
 };
 // a function of the WHOLE model's matrix (n_whole rows) and the chunk length: a rank's shard takes what the unsharded pass takes
-bool prefill_panel_shape(long long n_whole, int P, int K);
+// (widest_whole: rows of the whole model's widest launch + 128, what sizes the split-K / partial-product workspace)
+bool prefill_panel_shape(long long n_whole, int P, int K, long long widest_whole);
 int prefill_panel_max_tokens();
 // hipErrorNotSupported: this rank's rows / pointers / workspace do not take the kernel (rows % 16, alignment) -- callers that
 // asked prefill_panel_shape first treat that as an error on a shard (the unsharded pass would have taken it)

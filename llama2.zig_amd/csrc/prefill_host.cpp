@@ -123,7 +123,8 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
     // the WHOLE model's matrix so that a shard takes what the unsharded pass takes.
     auto panel = [&](PanelProduct &pp, long long n_whole, bool *taken) -> int {
         *taken = false;
-        if (!prefill_panel_shape(n_whole, P, pp.K)) return L2Z_OK;
+        const long long widest_whole = std::max((long long)dim + 2 * kvd_whole, 2LL * hid) + 128;
+        if (!prefill_panel_shape(n_whole, P, pp.K, widest_whole)) return L2Z_OK;
         pp.P = P;
         const hipError_t e = launch_prefill_panel(pp, g_cus, ws, st);
         if (e == hipErrorNotSupported) return L2Z_OK;  // this rank's rows / workspace do not take it: the forms below

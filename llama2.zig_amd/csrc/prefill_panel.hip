@@ -276,12 +276,18 @@ int prefill_panel_max_tokens()
 // Whether a [P, n_whole] x K product of the WHOLE model takes the panel kernel (a function of the model and the chunk
 // length only: a rank's share of the rows takes what the unsharded pass takes).  rows_mult16: every matrix of the
 // launch has a multiple of 16 rows ON THIS RANK (a wave's 16 rows lie in one matrix).
-bool prefill_panel_shape(long long n_whole, int P, int K)
+bool prefill_panel_shape(long long n_whole, int P, int K, long long widest_whole)
 {
     if (tunables().pf_panel == 0 || tunables().pf_dma == 0 || tunables().pf_tile != 0) return false;
     const int p_min = tunables().pf_panel_min >= 0 ? tunables().pf_panel_min : kPanelDefaultMin;
     if (P < p_min || P < 1 || P > prefill_panel_max_tokens() || K % kPnStage != 0 || K < kPnRange) return false;
-    return n_whole * (long long)K * 4 > ((long long)16 << 20);  // matrices that stream from HBM; cache-resident ones keep the short-prompt forms
+    if (n_whole * (long long)K * 4 <= ((long long)16 << 20)) return false;  // cache-resident matrices keep the short-prompt forms
+    // the partial products of the WHOLE model's launch must fit the workspace an unsharded runstate allocates
+    // (prefill_host.cpp prefill_alloc: 4 * kSplitKMaxTokens rows of its widest launch) -- decided on the whole model, so
+    // that a shard, whose share always fits then, never takes a kernel the unsharded pass could not
+    const int tms = (P + 15) / 16, kr = tms >= 3 ? 256 : kPnRange;
+    const long long n_ranges = (K + kr - 1) / kr;
+    return n_ranges * 16 * tms * n_whole <= 4LL * kSplitKMaxTokens * widest_whole;
 }
 
 hipError_t launch_prefill_panel(const PanelProduct &p, int n_cus, const SplitKWs *ws, hipStream_t st)
@@ -290,10 +296,10 @@ hipError_t launch_prefill_panel(const PanelProduct &p, int n_cus, const SplitKWs
     if ((p.rows0 % 16) || (p.rows1 % 16) || (p.rows2 % 16) || N <= 0 || (p.ldx % 4) || p.K % kPnStage != 0) return hipErrorNotSupported;
     if (((uintptr_t)p.x & 15) || ((uintptr_t)p.w0 & 15) || ((uintptr_t)p.w1 & 15) || ((uintptr_t)p.w2 & 15)) return hipErrorNotSupported;
     if (ws == nullptr || ws->part == nullptr) return hipErrorNotSupported;
-    const int tms = p.P <= 16 ? 1 : p.P <= 32 ? 2 : 4;
+    const int tms = (p.P + 15) / 16;   // token tiles: 1, 2 (ranges of 512), 3, 4 (ranges of 256)
     // (four ring buffers per wave -- for two token tiles against ranges of 256 -- measured slower: 20 / 32 tokens 6.72 /
     // 6.82 ms with three, 7.55 / 7.66 with four; profiles/r05c_prefill_panel_ab.txt)
-    const int kr = tms == 4 ? 256 : kPnRange;
+    const int kr = tms >= 3 ? 256 : kPnRange;
     const int depth = 3;
     const int n_ranges = (p.K + kr - 1) / kr;
     if ((size_t)n_ranges * (size_t)(16 * tms) * (size_t)N > ws->part_floats) return hipErrorNotSupported;
@@ -305,7 +311,7 @@ hipError_t launch_prefill_panel(const PanelProduct &p, int n_cus, const SplitKWs
     a.n_items = n_ranges * a.n_groups;
     const size_t lds = (size_t)(16 * tms * kr + 4 * depth * kPnStageFloats) * sizeof(float);
     const void *fn = tms == 1 ? (const void *)prefill_panel<1, kPnRange, 3> : tms == 2 ? (const void *)prefill_panel<2, kPnRange, 3>
-                                                                                       : (const void *)prefill_panel<4, 256, 3>;
+                   : tms == 3 ? (const void *)prefill_panel<3, 256, 3> : (const void *)prefill_panel<4, 256, 3>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
         (void)hipGetLastError();

@@ -905,7 +905,7 @@ def test_prefill_panel_kernel_vs_oracle(gpu, ck, orc, options, kv_heads):
     resident X panel, the ranges added in order by a second launch that also runs the epilogue -- RoPE + cache rows,
     residual, SiLU * mul).  A wide two-layer shape whose hidden_dim leaves a SHORT last range (8448 = 16.5 x 512), MHA
     and GQA: logits and KV rows against the CPU oracle's stepped loop for chunks of 1 / 16 (one token tile; below the
-    default switch-over, so forced: L2Z_PF_PANEL_MIN=1), 17 / 32 (two), 33 / 64 (four tiles against ranges of 256), a
+    default switch-over, so forced: L2Z_PF_PANEL_MIN=1), 17 / 32 (two), 33 / 48 / 64 (three and four tiles against ranges of 256), a
     second call continuing the context; and against the short-prompt GEMMs (L2Z_PF_PANEL=0) within the tolerance."""
     kw = dict(dim=3072, hidden_dim=8448, n_layers=2, n_heads=24, n_kv_heads=kv_heads, vocab_size=2048, seq_len=80)
     cfg = ck.Config(**kw)
@@ -917,7 +917,7 @@ def test_prefill_panel_kernel_vs_oracle(gpu, ck, orc, options, kv_heads):
     toks = [1] + rng.integers(2, cfg.vocab_size, 71).tolist()
     kvd, S = cfg.kv_dim, cfg.seq_len
     worst = 0.0
-    for n in (1, 16, 17, 32, 33, 64):
+    for n in (1, 16, 17, 32, 33, 48, 64):
         for pos, t in enumerate(toks[:n]):
             ref = m.transformer(t, pos)
         s.prefill(toks[:n], 0, w)
