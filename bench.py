@@ -571,6 +571,7 @@ def leg_main(args) -> int:
     # each other after the handshake)
     os.environ.setdefault("L2Z_P2P_TIMEOUT_S", "8")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (the only kind the host driver has)
+    out_fd = quiet_stdout()
     # torch is imported BEFORE libllama2_hip.so is loaded: the other order leaves HIP without a visible
     # device on this image (measured on the MI355X box)
     import torch
@@ -668,7 +669,7 @@ def leg_main(args) -> int:
 
     def fail(why: str) -> int:
         if rank == 0:
-            print(json.dumps({"leg": {"transport": kind, "ok": False, "why": why}}), flush=True)
+            emit(out_fd, json.dumps({"leg": {"transport": kind, "ok": False, "why": why}}))
         dist.destroy_process_group()
         return 3
 
@@ -778,10 +779,24 @@ def leg_main(args) -> int:
         "leg": leg,
     }
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out_fd, json.dumps(out))
     comm.close()
     dist.destroy_process_group()
     return 0 if agree else 4
+
+
+def quiet_stdout() -> int:
+    """The contract is ONE JSON line on stdout; gloo's C++ side reports its mesh there ("[Gloo] Rank 0 is connected to
+    3 peer ranks ...").  From here on fd 1 goes where stderr goes; the line is written to the returned copy of the
+    original stdout (emit)."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    return saved
+
+
+def emit(fd: int, text: str) -> None:
+    os.write(fd, (text + "\n").encode())
 
 
 def free_port() -> int:
@@ -800,6 +815,7 @@ def multi_main(args) -> None:
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with "
                          "python -m torch.distributed.run --nproc-per-node N ...)")
+    out_fd = quiet_stdout()
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     want = os.environ.get("L2Z_COMM", "")
@@ -862,9 +878,9 @@ def multi_main(args) -> None:
                      "why": rccl.get("why")} if rccl else {"initialised": False, "why": "leg not run (L2Z_COMM)"})
         ok = [l for l in legs if l["ok"]]
         if not ok:
-            print(json.dumps({"metric": "tokens/s (argmax, -t 0)", "value": None, "unit": "tokens/s",
-                              "n_gpus": args.gpus, "error": "no transport produced agreeing ranks",
-                              "comm": {"legs": legs, "rccl": rccl_rec}}), flush=True)
+            emit(out_fd, json.dumps({"metric": "tokens/s (argmax, -t 0)", "value": None, "unit": "tokens/s",
+                                     "n_gpus": args.gpus, "error": "no transport produced agreeing ranks",
+                                     "comm": {"legs": legs, "rccl": rccl_rec}}))
             final_rc[0] = 1
         else:
             # the headline is a scheme-A leg (BASELINE config 5: "row/head-sharded", bit-identical to the unsharded pass);
@@ -887,7 +903,7 @@ def multi_main(args) -> None:
                            "note": "every leg times the same steps between the same barriers; kernel times in "
                                    "roofline.by_kind of a p2p-consume leg include the consumer-side polling of the "
                                    "gathered input -- compare with the N=1 line"}
-            print(json.dumps(out), flush=True)
+            emit(out_fd, json.dumps(out))
     dist.broadcast_object_list(final_rc, src=0)
     dist.destroy_process_group()
     if final_rc[0]:

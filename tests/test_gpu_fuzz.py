@@ -58,3 +58,13 @@ def test_fuzz_prefill_vs_stepped_and_sharded_vs_unsharded(gpu):
     lines = []
     bad = _fuzz("fuzz_prefill").run(28, 20260927, lines.append)
     assert bad == 0, "\n".join(l for l in lines if not l.startswith("ok "))
+
+
+def test_fuzz_prefill_wide_shapes_panel_kernel_and_scheme_b(gpu):
+    """The same harness on matrices that stream from HBM (dim 1024 ... 3072, hidden_dim multiples of 128) and chunks of
+    9 ... 80 tokens: the K-range panel kernel (csrc/prefill_panel.hip) on both sides of each of its switch-overs,
+    row-sharded bit-identical to the unsharded pass, and a third of the sharded cases under scheme B (column-sharded Wo /
+    W2 + the bulk all-reduce: ranks identical to each other, logits at the tolerance)."""
+    lines = []
+    bad = _fuzz("fuzz_prefill").run(10, 20260929, lines.append, wide=True)
+    assert bad == 0, "\n".join(l for l in lines if not l.startswith("ok "))
