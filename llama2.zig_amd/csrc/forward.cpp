@@ -187,20 +187,6 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.kv_row = sh.hs; a.kv_head = kvh_stride;
             L2Z_LAUNCH(KIND_QKV, launch_fused_qkv_attn(a, c.n_heads, st));
         }
-        // attention (:361-389) over the local heads: its own launch, or -- short contexts of wide-row models -- the tail of
-        // the q | k | v launch (s->fold_attn)
-        AttnArgs at = {};
-        at.q = s->q; at.kcache = kc; at.vcache = vc; at.xb = s->xb + sh.dim0;
-        at.pos_ptr = s->d_pos; at.head_size = sh.hs; at.kv_row = sh.hs; at.kv_head = kvh_stride;
-        at.kv_mul = c.n_heads / c.n_kv_heads; at.seq_len = c.seq_len;
-        bool attn_pushes = false;
-        if (!fused && !sb && can_push && attention_push_supported(at)) {
-            at.push = s->d_push + 0;
-            at.push_ctl = ctl;
-            at.push_gi = comm_gi(lc, gi + 1);
-            attn_pushes = true;
-        }
-        bool folded = false;
         if (!fused && want() && kind(KIND_QKV)) {   // rmsnorm (:305) + q,k,v (:308-320) + RoPE (:336-351) + KV write (:354-358)
             MatvecArgs a = {};
             a.w0 = w->wq + (size_t)l * sh.dim_loc * dim;
@@ -212,35 +198,20 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.n = c.dim; a.rms_w = w->rms_att + (size_t)l * dim;
             x_in(a, s->x, gi, sh.dim_loc);  // layer 0: the embedding row, a plain buffer (gi == 0)
             a.pos_ptr = s->d_pos; a.rope = s->rope; a.head_size = sh.hs; a.rope_segs = 2;
-            if (s->fold_attn && variant == ATTN_SHORT && attention_push_supported(at)) {
-                a.attn = at; a.attn_cnt = s->d_fold_cnt; a.attn_heads = sh.heads_loc; a.attn_lds_seq = s->attn_short_pos;
-                hipEvent_t ea = nullptr, eb = nullptr;
-                if (prof) {
-                    L2Z_HIP(hipEventCreate(&ea));
-                    L2Z_HIP(hipEventCreate(&eb));
-                    L2Z_HIP(hipEventRecord(ea, st));
-                }
-                const hipError_t fe = launch_matvec(a, PRO_RMS, EPI_ROPE_ATTN, mb, g_cus, st);
-                if (fe == hipSuccess) {
-                    folded = true;
-                    if (prof) {
-                        L2Z_HIP(hipEventRecord(eb, st));
-                        prof->ev.push_back(ea); prof->ev.push_back(eb); prof->kind.push_back(KIND_QKV);
-                    }
-                } else {
-                    if (prof) { (void)hipEventDestroy(ea); (void)hipEventDestroy(eb); }
-                    if (fe != hipErrorNotSupported) L2Z_HIP(fe);
-                    (void)hipGetLastError();
-                }
-            }
-            if (!folded) L2Z_LAUNCH(KIND_QKV, launch_matvec(a, PRO_RMS, EPI_ROPE, mb, g_cus, st));
-            if (folded && attn_pushes) pushed = true;
+            L2Z_LAUNCH(KIND_QKV, launch_matvec(a, PRO_RMS, EPI_ROPE, mb, g_cus, st));
         }
-        if (!fused && !folded && want() && kind(KIND_ATTN) &&
-            !(s->fold_attn && variant == ATTN_SHORT && only_kind == KIND_ATTN && attention_push_supported(at))) {
-            AttnArgs a = at;
+        if (!fused && want() && kind(KIND_ATTN)) {   // attention (:361-389) over the local heads
+            AttnArgs a = {};
+            a.q = s->q; a.kcache = kc; a.vcache = vc; a.xb = s->xb + sh.dim0;
+            a.pos_ptr = s->d_pos; a.head_size = sh.hs; a.kv_row = sh.hs; a.kv_head = kvh_stride;
+            a.kv_mul = c.n_heads / c.n_kv_heads; a.seq_len = c.seq_len;
             a.tl_seq = s->tl_attn_seq++;
-            if (attn_pushes) pushed = true;
+            if (!sb && can_push && attention_push_supported(a)) {
+                a.push = s->d_push + 0;
+                a.push_ctl = ctl;
+                a.push_gi = comm_gi(lc, gi + 1);
+                pushed = true;
+            }
             if (split && s->attn_nch > 1 && attention_split_supported(a))
                 L2Z_LAUNCH(KIND_ATTN, launch_attention_split(a, sh.heads_loc, s->attn_nch,
                                                              s->d_attn_part, s->d_attn_cnt, st, variant == ATTN_SPLIT_S));

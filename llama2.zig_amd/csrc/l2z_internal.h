@@ -64,8 +64,7 @@ void set_error(const char *fmt, ...);
 // ---------------------------------------------------------------------------
 
 enum Prologue { PRO_NONE = 0, PRO_RMS = 1 };
-// EPI_ROPE_ATTN: EPI_ROPE with the attention of the local heads in the launch's tail (short contexts, wide rows)
-enum Epilogue { EPI_STORE = 0, EPI_ROPE = 1, EPI_RESID = 2, EPI_SWIGLU = 3, EPI_ARGMAX = 4, EPI_ROPE_ATTN = 5 };
+enum Epilogue { EPI_STORE = 0, EPI_ROPE = 1, EPI_RESID = 2, EPI_SWIGLU = 3, EPI_ARGMAX = 4 };
 
 constexpr int kMaxSeg = 3;
 
@@ -94,24 +93,6 @@ struct ArgmaxArgs {
     // larger value, equal values: lower index (main.zig:720) -- instead of gathering 32000 logits to scan them.  null: not
     const P2pArgs *xchg;
     int xchg_gi;
-};
-
-// main.zig:361-389: scores, softmax, att.V for the local heads of one layer
-struct AttnArgs {
-    const float *q;        // (n_heads_local * head_size)
-    const float *kcache;   // this layer: [kv_heads_local][seq_len][head_size] (head-major, DESIGN.md 2)
-    const float *vcache;
-    float *xb;             // (n_heads_local * head_size)
-    const int *pos_ptr;
-    int head_size;
-    int kv_row;            // floats between consecutive timesteps of one kv head (head-major: head_size)
-    size_t kv_head;        // floats between kv heads (head-major: seq_len * head_size)
-    int kv_mul;
-    int seq_len;
-    const P2pArgs *push;   // as in MatvecArgs, for xb (fast / split-combine kernels); may be null
-    const int *push_ctl;
-    int push_gi;
-    int tl_seq;            // attention launch number since the runstate was made (measurement builds only: L2Z_TIMELINE)
 };
 
 // One fused mat-vec launch: up to 3 row-major (rowsJ, n) matrices sharing x.
@@ -152,19 +133,26 @@ struct MatvecArgs {
     int push_gi;              // index of the gather the outputs belong to
     // x is a gathered vector that is read as LL words from this rank's landing slot (xin.slots != null)
     LLIn xin;
-    // EPI_ROPE_ATTN (round 5): the launch ends in the attention of the local heads (main.zig:361-389) instead of handing
-    // q and the new cache rows to a separate launch.  q / K / V values leave write-through; a block that has finished its
-    // rows drains them and draws a ticket from attn_cnt[0]; the LAST attn_heads blocks to draw wait until every block
-    // has drawn (all blocks of a mat-vec grid are resident: nobody waits for a block that cannot run), acquire, and take
-    // one head each (attention_device.h: the body of the separate launch, the same bits); the last one to leave zeroes
-    // the counters for the next launch.
-    AttnArgs attn;
-    int *attn_cnt;            // [2]: tickets drawn, heads done; zero between launches
-    int attn_heads;           // local heads (<= the grid: the launcher checks)
-    int attn_lds_seq;         // positions the tail's score buffers are carved for (> pos: the short-context bound)
     int tail_skip;            // row kernel, n > 4096: out-of-row steps of a row's last batch load nothing (set by the launcher)
 };
 
+// main.zig:361-389: scores, softmax, att.V for the local heads of one layer
+struct AttnArgs {
+    const float *q;        // (n_heads_local * head_size)
+    const float *kcache;   // this layer: [kv_heads_local][seq_len][head_size] (head-major, DESIGN.md 2)
+    const float *vcache;
+    float *xb;             // (n_heads_local * head_size)
+    const int *pos_ptr;
+    int head_size;
+    int kv_row;            // floats between consecutive timesteps of one kv head (head-major: head_size)
+    size_t kv_head;        // floats between kv heads (head-major: seq_len * head_size)
+    int kv_mul;
+    int seq_len;
+    const P2pArgs *push;   // as in MatvecArgs, for xb (fast / split-combine kernels); may be null
+    const int *push_ctl;
+    int push_gi;
+    int tl_seq;            // attention launch number since the runstate was made (measurement builds only: L2Z_TIMELINE)
+};
 
 
 // fused_small.hip: rmsnorm + q/k/v rows + RoPE + KV write + attention of one head per block
@@ -188,8 +176,6 @@ hipError_t launch_fused_qkv_attn(const FusedQkvAttnArgs &a, int n_heads, hipStre
 // Launchers (matvec.hip, attention.hip, misc_kernels.hip).  All return a hipError_t from the launch.
 // pushed: set to whether a.push was honoured (row kernel only)
 // (a.push / a.xin are all-or-nothing: matvec_ll_supported tells beforehand whether they will be)
-// (epi EPI_ROPE_ATTN: hipErrorNotSupported when the shape does not take the fused form -- rows narrower than 4096, a grid
-// of fewer blocks than heads: the caller launches EPI_ROPE and the attention separately)
 hipError_t launch_matvec(const MatvecArgs &a, int pro, int epi, int max_blocks_per_cu, int n_cus,
                          hipStream_t st, int *out_grid = nullptr, bool *pushed = nullptr);
 // true if a launch with this width takes the vector kernels, which honour push and xin

@@ -130,10 +130,6 @@ struct l2z_runstate {
     bool xchg_steps = false;
     bool logits_partial = false;
     bool fused_qkv_attn = false;  // small models: qkv + RoPE + KV write + attention in one launch
-    // wide-row models, short contexts (ATTN_SHORT positions): the q | k | v launch ends in the attention of the local heads
-    // (MatvecArgs::attn, EPI_ROPE_ATTN): 4 launches per layer instead of 5.  A function of the model, not of the rank count
-    bool fold_attn = false;
-    int *d_fold_cnt = nullptr;    // [2] tickets / heads done of the running fused launch (zero between launches)
     int max_blocks = 0;
     int tl_attn_seq = 0;           // attention launches enqueued so far (AttnArgs::tl_seq, measurement builds)
 };

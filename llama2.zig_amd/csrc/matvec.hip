@@ -17,7 +17,6 @@
 //  * token and position live in device memory so one captured hipGraph per
 //    step can be replayed without host involvement.
 // matvec.hip: the fused mat-vec kernels (narrow rows, wide rows, generic scalar) and their launcher.
-#include "attention_device.h"
 #include "matvec_device.h"
 
 namespace l2z {
@@ -355,34 +354,6 @@ __global__ __launch_bounds__(kBlock) void matvec_row_kernel(const MatvecArgs a)
         a.part_val[blockIdx.x] = best_v;
         a.part_idx[blockIdx.x] = best_i;
     }
-    if constexpr (EPI == EPI_ROPE_ATTN) {
-        // The attention tail (MatvecArgs::attn).  Only the writer thread stored anything: it drains its write-through
-        // stores and draws the block's ticket; the last attn_heads tickets are the heads.
-        int *role = (int *)scratch;
-        __syncthreads();  // the last unit's partials have been read
-        if (tid == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            *role = __hip_atomic_fetch_add(a.attn_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ((int)gridDim.x - a.attn_heads);
-        }
-        __syncthreads();
-        const int head = *role;
-        if (head < 0) return;
-        if (tid == 0) {
-            const long long t0 = wall_clock64();
-            while (__hip_atomic_load(a.attn_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x) {
-                if (wall_clock64() - t0 > 2000000000LL) break;  // 20 s: never in practice (every block is resident)
-                __builtin_amdgcn_s_sleep(1);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this CU's stale lines of q and the new cache rows
-        }
-        __syncthreads();
-        attn_fast_head<kBlock, false>(a.attn, head, lds, a.attn_lds_seq);
-        if (tid == 0 &&
-            __hip_atomic_fetch_add(a.attn_cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.attn_heads - 1) {
-            __hip_atomic_store(a.attn_cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch: every
-            __hip_atomic_store(a.attn_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // head block has passed its wait
-        }
-    }
 }
 
 // Generic form: any n, any alignment (the reference's 3x3 / 2x12 known-answer
@@ -459,8 +430,6 @@ const void *mv_row_pick(int pro, int epi, bool big_x, bool ll)
     L2Z_MVR_LL(PRO_RMS, EPI_ROPE)
     L2Z_MVR_LL(PRO_RMS, EPI_SWIGLU)
     L2Z_MVR_LL(PRO_RMS, EPI_ARGMAX)   // a shard's classifier on a gathered x: the candidate exchange of greedy steps
-    L2Z_MVR(PRO_RMS, EPI_ROPE_ATTN)
-    L2Z_MVR_LL(PRO_RMS, EPI_ROPE_ATTN)
 #undef L2Z_MVR
 #undef L2Z_MVR_LL
     return nullptr;
@@ -555,8 +524,7 @@ hipError_t launch_matvec(const MatvecArgs &a_in, int pro, int epi, int max_block
     const bool use_row = vec && tn.row_kernel && n4 >= 1024 && (n4 % 64) == 0;
     const bool ll = a.xin.slots != nullptr;
     if (ll && !vec) return hipErrorNotSupported;  // callers ask matvec_ll_supported() first
-    if (epi == EPI_ROPE_ATTN && (!use_row || a.attn_cnt == nullptr || a.attn_heads < 1)) return hipErrorNotSupported;
-    MvLaunch k = epi == EPI_ROPE_ATTN ? MvLaunch{nullptr, 0, 0} : mv_pick_pe(pro, epi, lpr, a.n > 4096, vec, ll);
+    MvLaunch k = mv_pick_pe(pro, epi, lpr, a.n > 4096, vec, ll);
     if (use_row) k.fn = mv_row_pick(pro, epi, a.n > 4096, ll);
     if (k.fn == nullptr) return hipErrorInvalidValue;
     size_t lds;
@@ -565,11 +533,6 @@ hipError_t launch_matvec(const MatvecArgs &a_in, int pro, int epi, int max_block
         const int batch = kBlock * 4;
         const int n4_pad = ((n4 + batch - 1) / batch) * batch;
         lds = (size_t)(4 * n4_pad + kScratch + 4 * kWaves) * sizeof(float);
-        if (epi == EPI_ROPE_ATTN) {  // the tail's score buffers and group partials reuse the staged x's space
-            const AttnGeom ge = attn_geom(a.attn.head_size, true, kBlock);
-            const size_t tail = (size_t)(2 * ((a.attn_lds_seq + 3) & ~3) + ge.G * a.attn.head_size) * sizeof(float);
-            if (tail > lds) lds = tail;
-        }
         n_units = n_pairs;
     } else if (vec) {
         const int batch = k.lpr * k.u;
@@ -616,9 +579,8 @@ hipError_t launch_matvec(const MatvecArgs &a_in, int pro, int epi, int max_block
         }
     }
     if (out_grid) *out_grid = grid;
-    if (epi == EPI_ROPE_ATTN && grid < a.attn_heads) return hipErrorNotSupported;  // (ranks sharing a GPU under a grid cap)
     // only single-segment epilogues of the vector kernels push (wo, ffn13, ffn2, classifier)
-    if (!vec || epi == EPI_ROPE || epi == EPI_ROPE_ATTN || a.rows2 != 0 || (epi != EPI_SWIGLU && a.rows1 != 0)) a.push = nullptr;
+    if (!vec || epi == EPI_ROPE || a.rows2 != 0 || (epi != EPI_SWIGLU && a.rows1 != 0)) a.push = nullptr;
     if (pushed) *pushed = a.push != nullptr;
     a.tail_skip = tn.row_tail_skip;
     void *args[] = {&a};

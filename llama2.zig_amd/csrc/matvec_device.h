@@ -8,8 +8,6 @@ namespace l2z {
 namespace {
 
 // Kernel arguments copied into plain locals once (keeps them out of scratch).
-constexpr bool epi_is_rope(int e) { return e == EPI_ROPE || e == EPI_ROPE_ATTN; }
-
 struct MvLocals {
     const float *w0, *w1, *w2;
     float *out0, *out1, *out2;
@@ -33,10 +31,10 @@ __device__ __forceinline__ MvLocals mv_locals(const MatvecArgs &a)
     m.rows0 = a.rows0; m.r01 = a.rows0 + a.rows1; m.total_rows = a.rows0 + a.rows1 + a.rows2;
     m.n_pairs = (EPI == EPI_SWIGLU) ? a.rows0 : (m.total_rows + 1) >> 1;
     m.n = a.n; m.head_size = a.head_size; m.rope_segs = a.rope_segs;
-    m.pos = epi_is_rope(EPI) ? *a.pos_ptr : 0;
+    m.pos = (EPI == EPI_ROPE) ? *a.pos_ptr : 0;
     m.ps1 = (size_t)m.pos * (size_t)a.pos_stride1;
     m.ps2 = (size_t)m.pos * (size_t)a.pos_stride2;
-    m.kv_head_stride = epi_is_rope(EPI) ? a.kv_head_stride : 0;
+    m.kv_head_stride = (EPI == EPI_ROPE) ? a.kv_head_stride : 0;
     m.push = a.push;
     m.push_e = m.push ? a.push_ctl[kCtlEpoch] + a.push_gi : 0;
     m.push_base = m.push ? (size_t)m.push->rank * m.push->count : 0;
@@ -85,7 +83,7 @@ __device__ __forceinline__ EpiIn epi_prefetch(const MvLocals &m, int p, bool wri
         const int ga = 2 * p, gb = ga + 1;
         e.ra = m.resid[ga];
         if (gb < m.total_rows) e.rb = m.resid[gb];
-    } else if (epi_is_rope(EPI)) {
+    } else if (EPI == EPI_ROPE) {
         const int ga = 2 * p;
         const bool a1 = ga >= m.rows0, a2 = ga >= m.r01;
         const int seg_a = a2 ? 2 : (a1 ? 1 : 0);
@@ -122,7 +120,7 @@ __device__ __forceinline__ void pair_epilogue(const MvLocals &m, int p, float sa
     oa = a2 ? m.out2 + m.ps2 : oa;
     float *ob = b1 ? m.out1 + m.ps1 : m.out0;
     ob = b2 ? m.out2 + m.ps2 : ob;
-    if (epi_is_rope(EPI)) {
+    if (EPI == EPI_ROPE) {
         // rows (row_a, row_a+1) of one segment: the pair (i, i+1) of :346-349
         float o0 = sa, o1 = sb;
         const int seg_a = a2 ? 2 : (a1 ? 1 : 0);
@@ -138,13 +136,8 @@ __device__ __forceinline__ void pair_epilogue(const MvLocals &m, int p, float sa
                 if (a1) ia = (size_t)(row_a / hs) * m.kv_head_stride + (size_t)(row_a % hs);
                 if (b1) ib = (size_t)(row_b / hs) * m.kv_head_stride + (size_t)(row_b % hs);
             }
-            if (EPI == EPI_ROPE_ATTN) {  // read by ANOTHER block of this launch (the attention tail): write-through
-                __hip_atomic_store(oa + ia, o0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (valid_b) __hip_atomic_store(ob + ib, o1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                oa[ia] = o0;
-                if (valid_b) ob[ib] = o1;
-            }
+            oa[ia] = o0;
+            if (valid_b) ob[ib] = o1;
         }
     } else if (EPI == EPI_RESID) {
         if (writer && valid_a) {

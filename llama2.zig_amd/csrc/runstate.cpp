@@ -82,7 +82,6 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
     alloc((void **)&s->d_argmax, 4);
     alloc((void **)&s->d_prompt, (size_t)c.seq_len * 4);
     alloc((void **)&s->d_out_tokens, (size_t)c.seq_len * 4);
-    alloc((void **)&s->d_fold_cnt, 2 * sizeof(int));
     alloc((void **)&s->d_part_val, (size_t)matvec_max_grid(g_cus) * 4);
     alloc((void **)&s->d_part_idx, (size_t)matvec_max_grid(g_cus) * 4);
     {   // Attention form by position.  One block per head is fastest while the
@@ -104,10 +103,6 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
         s->attn_split_wide_pos = attention_split_wide_pos(c.seq_len);
         s->attn_short_pos = attention_short_pos(sh.hs, c.seq_len);
         if (nch > 1 && s->attn_short_pos > s->attn_split_pos) s->attn_short_pos = s->attn_split_pos;
-        // short contexts of wide-row models: the attention rides in the q | k | v launch's tail (forward.cpp; the launcher
-        // still refuses shapes whose grid has fewer blocks than heads)
-        s->fold_attn = tn.fold_attn != 0 && !s->fused_qkv_attn && s->attn_short_pos > 0 && c.dim >= 4096 && (c.dim % 256) == 0 &&
-                       tn.row_kernel != 0 && (sh.hs % 4) == 0 && sh.hs <= 256;
         if (nch > 1) {
             s->attn_nch = nch;
             alloc((void **)&s->d_attn_part, attention_split_part_floats(sh.heads_loc, sh.hs, nch) * 4);
@@ -177,7 +172,7 @@ extern "C" void l2z_runstate_free(l2z_runstate *s)
     }
     void *ptrs[] = {s->x, s->xb, s->hb, s->q, s->logits, s->key_cache, s->value_cache, s->rope,
                     s->d_token, s->d_pos, s->d_prompt, s->d_n_prompt, s->d_out_tokens, s->d_argmax,
-                    s->d_probs, s->d_fold_cnt, s->d_part_val, s->d_part_idx, s->d_attn_part, s->d_attn_cnt, s->pf_x, s->pf_xn, s->pf_q,
+                    s->d_probs, s->d_part_val, s->d_part_idx, s->d_attn_part, s->d_attn_cnt, s->pf_x, s->pf_xn, s->pf_q,
                     s->pf_att, s->pf_h1, s->pf_stage, s->pf_part, s->pf_tokens, s->d_push, s->pf_sk.part, s->pf_sk.cnt, s->part};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);

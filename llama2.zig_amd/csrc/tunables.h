@@ -24,8 +24,6 @@ struct Tunables {
     int attn_short_pos = -1;   // L2Z_ATTN_SHORT_POS  positions below this take the 256-thread one-block-per-head kernel with the
                                //                     speculative first round whatever seq_len is (default: by head size, 0: never)
     int fuse_small = 1;        // L2Z_FUSE_SMALL      0: small models keep separate qkv / attention launches
-    int fold_attn = 1;         // L2Z_FOLD_ATTN       0: wide-row models keep the attention of short contexts a launch of its own instead of
-                               //                     the tail of the q | k | v launch (same bits either way)
     // --- graphs / transport (runstate.cpp, comm.cpp, forward.cpp) ---
     int no_graph = 0;          // L2Z_NO_GRAPH        1: launch eagerly
     int comm_graph = 1;        // L2Z_COMM_GRAPH      0: RCCL collectives are launched eagerly, not captured

@@ -31,7 +31,7 @@ for v in variants:
     for k in kv:  # back to the default for the next variant (options apply at RunState creation)
         B.option_set(k, {"L2Z_ATTN_SPLIT": -1, "L2Z_ATTN_SPLIT_POS": -1, "L2Z_ATTN_SHORT_POS": -1, "L2Z_ATTN_SPLIT_WIDE_POS": -1, "L2Z_ROW_TAIL_SKIP": 1, "L2Z_ROW_BLOCKS": 2, "L2Z_ATTN_BLOCK": 0,
                          "L2Z_FUSE_SMALL": 1, "L2Z_NO_GRAPH": 0, "L2Z_ROW_KERNEL": 1,
-                         "L2Z_MAX_BLOCKS_PER_CU": 8, "L2Z_FOLD_ATTN": 1, "L2Z_ARGMAX_XCHG": 1}.get(k, 0))
+                         "L2Z_MAX_BLOCKS_PER_CU": 8}.get(k, 0))
 # the variants' arithmetic side by side: logits of one pass at pos0 and the first greedy tokens, against variant 0
 ref_logits = ref_toks = None
 for v, s in zip(variants, states):

@@ -899,49 +899,6 @@ def test_prefill_equals_token_by_token(gpu, ck, orc, name, kw, shared):
         o.close()
 
 
-@pytest.mark.parametrize("kv_heads", [32, 8])
-def test_attention_in_the_qkv_launch_keeps_the_bits(gpu, ck, options, kv_heads):
-    """Wide-row models run the attention of short contexts (pos < 128 at head size 128) in the TAIL of the q | k | v
-    launch (csrc/matvec.hip EPI_ROPE_ATTN: the last blocks to finish their rows wait for the rest and take a head each;
-    attention_device.h is the body of the separate launch).  Same arithmetic, so logits and greedy tokens must be
-    IDENTICAL to the five-launch chain (L2Z_FOLD_ATTN=0), MHA and GQA, across the switch to the longer forms at pos 128,
-    unsharded and on emulated ranks (2 and 4: the tail runs over a shard's local heads)."""
-    kw = dict(dim=4096, hidden_dim=5632, n_layers=2, n_heads=32, n_kv_heads=kv_heads, vocab_size=4096, seq_len=160)
-    cfg = ck.Config(**kw)
-    w = gpu.Weights(cfg, None, False, seed=61)
-    out = {}
-    for tag, fold in (("chain", 0), ("folded", 1)):
-        options(L2Z_FOLD_ATTN=fold, L2Z_PREFILL=0)
-        s = gpu.RunState(cfg)
-        s.greedy_begin([7, 8, 9])
-        toks = s.greedy_run(w, 140)
-        lg = []
-        for pos in (0, 1, 60, 127, 128):
-            s.transformer(int(toks[pos - 1]) if pos else 1, pos, w)
-            lg.append(s.logits().copy())
-        out[tag] = (toks, lg)
-        s.close()
-    assert np.array_equal(out["chain"][0], out["folded"][0]), "greedy tokens differ"
-    for a, b in zip(out["chain"][1], out["folded"][1]):
-        assert np.array_equal(a, b), f"logits differ by {np.abs(a - b).max():.3g}"
-    options(L2Z_FOLD_ATTN=1, L2Z_FUSE_SMALL=0)
-    for world in (2, 4):
-        comms = [gpu.Comm(r, world, None, 0, emulated=True) for r in range(world)]
-        ws = [gpu.Weights(cfg, None, False, seed=61, comm=c) for c in comms]
-        ss = [gpu.RunState(cfg, comm=c) for c in comms]
-        for pos in (0, 1, 60):
-            tok = int(out["chain"][0][pos - 1]) if pos else 1
-            gpu.emu_transformer(ss, ws, tok, pos)
-            ref = out["chain"][1][(0, 1, 60).index(pos)]
-            for r in range(world):
-                assert np.array_equal(ss[r].logits(), ref), f"world {world} rank {r} pos {pos}"
-        for o in ss + ws:
-            o.close()
-        for c_ in comms:
-            c_.close()
-    w.close()
-
-
 @pytest.mark.parametrize("kv_heads", [24, 8])
 def test_prefill_panel_kernel_vs_oracle(gpu, ck, orc, options, kv_heads):
     """prefill_panel.hip: chunks of <= 32 tokens of matrices that stream from HBM (K cut into ranges of 512 with a
