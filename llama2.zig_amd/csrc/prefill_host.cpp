@@ -31,10 +31,14 @@ int prefill_alloc(l2z_runstate *s, int need)
     if (s->pf_tokens) { (void)hipFree(s->pf_tokens); s->pf_tokens = nullptr; }
     s->pf_cap = 0;
     const size_t widest = (size_t)(c.dim > c.hidden_dim ? c.dim : c.hidden_dim);
+    // (scheme B reads the local attention / hidden blocks as rows of the column shards' PADDED width: a 1-rank group's
+    // padded width can exceed the model's)
+    const size_t att_w = std::max((size_t)c.dim, s->sh.scheme_b ? (size_t)s->sh.dimc_pad : (size_t)0);
+    const size_t h1_w = std::max((size_t)c.hidden_dim, s->sh.scheme_b ? (size_t)s->sh.hidc_pad : (size_t)0);
     struct { void **p; size_t bytes; } want[] = {
         {(void **)&s->pf_x, P * c.dim * 4},   {(void **)&s->pf_xn, P * c.dim * 4},
-        {(void **)&s->pf_q, P * c.dim * 4},   {(void **)&s->pf_att, P * c.dim * 4},
-        {(void **)&s->pf_h1, P * c.hidden_dim * 4},
+        {(void **)&s->pf_q, P * c.dim * 4},   {(void **)&s->pf_att, P * att_w * 4},
+        {(void **)&s->pf_h1, P * h1_w * 4},
         // sharded: [world][P, n / world] blocks of the matrix being gathered
         {(void **)&s->pf_stage, s->sh.world > 1 ? P * widest * 4 : 0},
         // scheme B: this rank's partial [P, dim] products of its column shards of Wo / W2 (summed by the bulk all-reduce)
@@ -53,8 +57,8 @@ int prefill_alloc(l2z_runstate *s, int need)
     if (s->sh.scheme_b) {
         // the local attention / hidden blocks are read as rows of the column shards' PADDED width: the pad columns are
         // never written, and must be zeros (finite) against the shards' zero columns
-        L2Z_HIP(hipMemsetAsync(s->pf_att, 0, P * c.dim * 4, s->stream));
-        L2Z_HIP(hipMemsetAsync(s->pf_h1, 0, P * c.hidden_dim * 4, s->stream));
+        L2Z_HIP(hipMemsetAsync(s->pf_att, 0, P * att_w * 4, s->stream));
+        L2Z_HIP(hipMemsetAsync(s->pf_h1, 0, P * h1_w * 4, s->stream));
     }
     if (s->pf_sk.part == nullptr) {
         // split-K family of the tile GEMM (chunks of 33 ... 256 tokens): accumulator dumps of up to 4 K ranges of
