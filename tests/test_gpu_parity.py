@@ -390,6 +390,31 @@ def test_gpu_prefill_agrees_with_hf_llama(gpu, ck):
     s.close(); w.close()
 
 
+def test_gpu_panel_prefill_agrees_with_hf_llama(gpu, ck):
+    """The K-range panel kernel (csrc/prefill_panel.hip: chunks of 17 ... 64 tokens of matrices that stream) against the
+    HF model as well: a wide two-layer GQA shape, prompts of 20, 33 and 64 tokens (two, three and four token tiles), the
+    logits after each prompt and -- through the next stepped token -- the KV rows it left."""
+    import importlib.util
+    if importlib.util.find_spec("transformers") is None:
+        pytest.skip("no transformers")
+    import hf_llama
+    kw = dict(dim=3072, hidden_dim=8448, n_layers=2, n_heads=24, n_kv_heads=8, vocab_size=2048, seq_len=80)
+    cfg = ck.Config(**kw)
+    blob = ck.synth_blob(cfg, False, seed=4244)
+    toks = [1] + np.random.default_rng(6).integers(0, cfg.vocab_size, 65).tolist()
+    hf = hf_llama.logits_in_subprocess(kw, False, 4244, toks)
+    w, s = gpu.Weights(cfg, blob, False), gpu.RunState(cfg)
+    worst = 0.0
+    for n in (20, 33, 64):
+        s.prefill(toks[:n], 0, w)
+        np.testing.assert_allclose(s.logits(), hf[n - 1], rtol=LOGIT_RTOL, atol=LOGIT_ATOL, err_msg=f"{n} tokens")
+        worst = max(worst, float(np.abs(s.logits() - hf[n - 1]).max()))
+        s.transformer(toks[n], n, w)   # reads every KV row the batched pass wrote
+        np.testing.assert_allclose(s.logits(), hf[n], rtol=LOGIT_RTOL, atol=LOGIT_ATOL, err_msg=f"step after {n} tokens")
+    print(f"GPU panel prefill vs HF: max |logit diff| {worst:.2e}")
+    s.close(); w.close()
+
+
 # ---------------------------------------------------------------- whole forward pass
 CONFIGS = [
     ("toy-gqa-unshared", dict(TOY), False),
