@@ -29,10 +29,8 @@
 namespace l2z {
 namespace {
 
-constexpr int kPnStage = 128;                 // k per ring stage: a row's piece is 512 bytes, a wave-wide load is two rows
-constexpr int kPnRange = 512;                 // k per range, chunks of <= 32 tokens: four stages (33 ... 64 tokens: 256, two)
-constexpr int kPnStageFloats = 16 * kPnStage; // one ring buffer: 16 rows x 128
-constexpr int kPnLoads = 8;                   // wave-wide loads per stage
+constexpr int kPnStage = 128;                 // k per ring stage, one / two token tiles: a row's piece is 512 bytes (three / four tiles: 64)
+constexpr int kPnRange = 512;                 // k per range, chunks of <= 32 tokens: four stages (33 ... 64 tokens: 256)
 // longest chunk that takes the kernel: 33 ... 64 tokens run four token tiles against ranges of 256 (MFMA-bound there: the
 // tile GEMM's split-K family took 12.5 ms for 40 ... 64 tokens at the 7B shape, this 10.8 ... 11.2)
 constexpr int kPanelDefaultMax = 64;
@@ -54,44 +52,51 @@ struct PanelArgs {
     int n_items;      // ranges * n_groups
 };
 
-template <int KR>
+template <int KR, int SK>
 __device__ __forceinline__ int pn_range_stages(int K, int r)
 {
     const int left = K - r * KR;
-    return (left < KR ? left : KR) / kPnStage;
+    return (left < KR ? left : KR) / SK;
 }
 
 // TMS token tiles of 16; KR: k per range (the panel is [16 TMS][KR]: 64 KB at (2, 512) and (4, 256)); kPnDepth: ring
-// buffers per wave (its loads run kPnDepth - 1 stages ahead)
-template <int TMS, int KR, int kPnDepth>
-__global__ __launch_bounds__(256) void prefill_panel(const PanelArgs a)
+// buffers per wave (its loads run kPnDepth - 1 stages ahead); NW waves per block, each with 16 rows of the item's
+// 16 NW; SK: k per ring stage.  Two forms: (4 waves, stages of 128 k) where the W stream is the bound -- one and two
+// token tiles -- and (8 waves, stages of 64 k: the same LDS, two waves per SIMD) where the MFMA pipe is -- three and
+// four tiles: a lone wave per SIMD leaves it idle whenever that wave waits for a stage or an operand read.
+template <int TMS, int KR, int kPnDepth, int NW, int SK>
+__global__ __launch_bounds__(64 * NW) void prefill_panel(const PanelArgs a)
 {
+    constexpr int SLOTS = SK / 4;             // float4 slots per row of a stage
+    constexpr int RPL = 64 / SLOTS;           // rows per wave-wide load (1 KB)
+    constexpr int LOADS = 16 / RPL;           // wave-wide loads per stage
+    constexpr int STAGE_FLOATS = 16 * SK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
-    float *panel = smem;                                                       // [16 TMS][512], swizzled
-    float *ring = smem + 16 * TMS * KR + wave * (kPnDepth * kPnStageFloats);
+    float *panel = smem;                                                       // [16 TMS][KR], swizzled
+    float *ring = smem + 16 * TMS * KR + wave * (kPnDepth * STAGE_FLOATS);
     const int N = a.rows0 + a.rows1 + a.rows2;
     const int i0 = (int)((long long)blockIdx.x * a.n_items / gridDim.x);
     const int i1 = (int)((long long)(blockIdx.x + 1) * a.n_items / gridDim.x);
     const v4f zero = {0.f, 0.f, 0.f, 0.f};
 
     // ---- producer side: this wave's loads, one stage at a time, running ahead of its multiplies ----
-    // Load i of a stage brings rows 2i, 2i + 1 of the wave's 16 (lane >> 5 picks the row, lane & 31 the PHYSICAL float4
+    // Load i of a stage brings RPL rows of the wave's 16 (lane / SLOTS picks the row, lane % SLOTS the PHYSICAL float4
     // slot, which holds logical slot ^ (row & 7)).  The 16 rows lie in one matrix (rows % 16 == 0), so a lane's source is
     // a wave-uniform row-0 pointer + a per-lane offset that never changes: no per-item pointer tables.
-    size_t loff[kPnLoads];
+    size_t loff[LOADS];
 #pragma unroll
-    for (int i = 0; i < kPnLoads; i++) {
-        const int jl = 2 * i + (lane >> 5);
-        loff[i] = (size_t)jl * (size_t)a.K + (size_t)(4 * ((lane & 31) ^ (jl & 7)));
+    for (int i = 0; i < LOADS; i++) {
+        const int jl = RPL * i + lane / SLOTS;
+        loff[i] = (size_t)jl * (size_t)a.K + (size_t)(4 * ((lane % SLOTS) ^ (jl & 7)));
     }
     int p_item = i0, p_st = 0, p_ns = 0, p_buf = 0, issued = 0;
     const float *p_base = a.w0;  // row 0 of the wave's 16 at k = the range's start
     auto producer_item = [&]() {
         const int r = p_item / a.n_groups, g = p_item - r * a.n_groups;
-        p_ns = pn_range_stages<KR>(a.K, r);
-        int row = g * 64 + wave * 16;
+        p_ns = pn_range_stages<KR, SK>(a.K, r);
+        int row = g * (16 * NW) + wave * 16;
         row = row < N ? row : N - 16;                        // a wave past the end: the last 16 rows again (never stored)
         const bool s1 = row >= a.rows0, s2 = row >= a.rows0 + a.rows1;
         const float *base = s1 ? a.w1 : a.w0;
@@ -101,10 +106,10 @@ __global__ __launch_bounds__(256) void prefill_panel(const PanelArgs a)
     };
     auto issue_one = [&]() {
         if (p_item >= i1) return;
-        float *dst = ring + p_buf * kPnStageFloats;
-        const float *src = p_base + p_st * kPnStage;
+        float *dst = ring + p_buf * STAGE_FLOATS;
+        const float *src = p_base + p_st * SK;
 #pragma unroll
-        for (int i = 0; i < kPnLoads; i++) lds_dma16_nt(src + loff[i], dst + i * 256);
+        for (int i = 0; i < LOADS; i++) lds_dma16_nt(src + loff[i], dst + i * 256);
         p_buf = p_buf + 1 == kPnDepth ? 0 : p_buf + 1;
         issued++;
         if (++p_st == p_ns) {
@@ -114,9 +119,9 @@ __global__ __launch_bounds__(256) void prefill_panel(const PanelArgs a)
     };
     // ---- the panel: range r of X, all 16 TMS token rows (tokens past P: the last token; never stored) ----
     auto load_panel = [&](int r) {
-        const int klen = pn_range_stages<KR>(a.K, r) * kPnStage;
+        const int klen = pn_range_stages<KR, SK>(a.K, r) * SK;
         constexpr int HPR = KR / 256;                           // wave-wide loads (256 floats) per token row
-        for (int t = wave; t < 16 * TMS * HPR; t += 4) {        // wave-wide load t: piece h of token row t / HPR
+        for (int t = wave; t < 16 * TMS * HPR; t += NW) {       // wave-wide load t: piece h of token row t / HPR
             const int tok = t / HPR, h = t % HPR;
             const int logical = (64 * h + lane) ^ (tok & 7);
             int kk = 4 * logical;
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(256) void prefill_panel(const PanelArgs a)
     int c_item = i0, c_st = 0, c_buf = 0, consumed = 0, cur_range = -1;
     while (c_item < i1) {
         const int r = c_item / a.n_groups;
-        const int ns = pn_range_stages<KR>(a.K, r);
+        const int ns = pn_range_stages<KR, SK>(a.K, r);
         if (c_st == 0 && r != cur_range) {  // block-uniform: every wave walks the same items
             __syncthreads();                // nobody reads the old panel any more
             load_panel(r);
@@ -145,22 +150,22 @@ __global__ __launch_bounds__(256) void prefill_panel(const PanelArgs a)
         } else {
             // stage `consumed` of this wave has landed: what may still fly are the stages issued after it
             const int younger = issued - consumed - 1;
-            if (kPnDepth >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kPnLoads) : "memory");
-            else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPnLoads) : "memory");
+            if (kPnDepth >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+            else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the operand reads of the stage before have retired: its buffer is free
         issue_one();                                        // kPnDepth - 1 stages ahead, into that buffer
-        const v4f *wst = (const v4f *)(ring + c_buf * kPnStageFloats);
+        const v4f *wst = (const v4f *)(ring + c_buf * STAGE_FLOATS);
         const v4f *xp = (const v4f *)panel;
         const int sw = j & 7;
 #pragma unroll
-        for (int u = 0; u < 8; u++) {  // k = 16 u + 4 q + c of the stage, A and B alike
+        for (int u = 0; u < SK / 16; u++) {  // k = 16 u + 4 q + c of the stage, A and B alike
             const int slot = 4 * u + q;
-            const v4f b = wst[j * 32 + (slot ^ sw)];
+            const v4f b = wst[j * SLOTS + (slot ^ sw)];
             v4f xa[TMS];
 #pragma unroll
-            for (int tm = 0; tm < TMS; tm++) xa[tm] = xp[(16 * tm + j) * (KR / 4) + ((c_st * 32 + slot) ^ sw)];
+            for (int tm = 0; tm < TMS; tm++) xa[tm] = xp[(16 * tm + j) * (KR / 4) + ((c_st * SLOTS + slot) ^ sw)];
 #pragma unroll
             for (int c = 0; c < 4; c++)
 #pragma unroll
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(256) void prefill_panel(const PanelArgs a)
         if (++c_st == ns) {
             // the item's partial products: lane (j, q), register i holds token 16 tm + 4 q + i of row j
             const int g = c_item - r * a.n_groups;
-            const int row = g * 64 + wave * 16 + j;
+            const int row = g * (16 * NW) + wave * 16 + j;
             if (row < N) {
                 float *po = a.part + ((size_t)r * (16 * TMS)) * (size_t)N + row;
 #pragma unroll
@@ -293,7 +298,7 @@ bool prefill_panel_shape(long long n_whole, int P, int K, long long widest_whole
 hipError_t launch_prefill_panel(const PanelProduct &p, int n_cus, const SplitKWs *ws, hipStream_t st)
 {
     const int N = p.rows0 + p.rows1 + p.rows2;
-    if ((p.rows0 % 16) || (p.rows1 % 16) || (p.rows2 % 16) || N <= 0 || (p.ldx % 4) || p.K % kPnStage != 0) return hipErrorNotSupported;
+    if ((p.rows0 % 16) || (p.rows1 % 16) || (p.rows2 % 16) || N < 16 || (p.ldx % 4) || p.K % kPnStage != 0) return hipErrorNotSupported;
     if (((uintptr_t)p.x & 15) || ((uintptr_t)p.w0 & 15) || ((uintptr_t)p.w1 & 15) || ((uintptr_t)p.w2 & 15)) return hipErrorNotSupported;
     if (ws == nullptr || ws->part == nullptr) return hipErrorNotSupported;
     const int tms = (p.P + 15) / 16;   // token tiles: 1, 2 (ranges of 512), 3, 4 (ranges of 256)
@@ -307,11 +312,16 @@ hipError_t launch_prefill_panel(const PanelProduct &p, int n_cus, const SplitKWs
     a.x = p.x; a.ldx = p.ldx; a.w0 = p.w0; a.w1 = p.w1 ? p.w1 : p.w0; a.w2 = p.w2 ? p.w2 : p.w0;
     a.rows0 = p.rows0; a.rows1 = p.rows1; a.rows2 = p.rows2; a.P = p.P; a.K = p.K;
     a.part = ws->part;
-    a.n_groups = (N + 63) / 64;
+    // one / two tiles: 4 waves, stages of 128 k; three / four: 8 waves, stages of 64 k (L2Z_PF_PANEL_WAVES=4 keeps four)
+    const bool eight = tms >= 3 && tunables().pf_panel_waves != 4;
+    const int nw = eight ? 8 : 4, sk = eight ? 64 : kPnStage;
+    a.n_groups = (N + 16 * nw - 1) / (16 * nw);
     a.n_items = n_ranges * a.n_groups;
-    const size_t lds = (size_t)(16 * tms * kr + 4 * depth * kPnStageFloats) * sizeof(float);
-    const void *fn = tms == 1 ? (const void *)prefill_panel<1, kPnRange, 3> : tms == 2 ? (const void *)prefill_panel<2, kPnRange, 3>
-                   : tms == 3 ? (const void *)prefill_panel<3, 256, 3> : (const void *)prefill_panel<4, 256, 3>;
+    const size_t lds = (size_t)(16 * tms * kr + nw * depth * 16 * sk) * sizeof(float);
+    const void *fn = tms == 1 ? (const void *)prefill_panel<1, kPnRange, 3, 4, kPnStage>
+                   : tms == 2 ? (const void *)prefill_panel<2, kPnRange, 3, 4, kPnStage>
+                   : tms == 3 ? (eight ? (const void *)prefill_panel<3, 256, 3, 8, 64> : (const void *)prefill_panel<3, 256, 3, 4, kPnStage>)
+                              : (eight ? (const void *)prefill_panel<4, 256, 3, 8, 64> : (const void *)prefill_panel<4, 256, 3, 4, kPnStage>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -319,7 +329,7 @@ hipError_t launch_prefill_panel(const PanelProduct &p, int n_cus, const SplitKWs
     }
     const int grid = a.n_items < n_cus ? a.n_items : n_cus;
     void *params[] = {&a};
-    e = hipLaunchKernel(fn, dim3(grid), dim3(256), params, lds, st);
+    e = hipLaunchKernel(fn, dim3(grid), dim3(64 * nw), params, lds, st);
     if (e != hipSuccess) return e;
     // the ranges, in order, and the epilogue
     PanelReduceArgs r = {};
