@@ -312,16 +312,16 @@ hipError_t launch_prefill_panel(const PanelProduct &p, int n_cus, const SplitKWs
     a.x = p.x; a.ldx = p.ldx; a.w0 = p.w0; a.w1 = p.w1 ? p.w1 : p.w0; a.w2 = p.w2 ? p.w2 : p.w0;
     a.rows0 = p.rows0; a.rows1 = p.rows1; a.rows2 = p.rows2; a.P = p.P; a.K = p.K;
     a.part = ws->part;
-    // one / two tiles: 4 waves, stages of 128 k; three / four: 8 waves, stages of 64 k (L2Z_PF_PANEL_WAVES=4 keeps four)
-    const bool eight = tms >= 3 && tunables().pf_panel_waves != 4;
+    // one / two tiles: 4 waves, stages of 128 k; three / four: 8 waves, stages of 64 k (the same k order: the same bits
+    // as four waves would give; 40 / 48 / 64 tokens 9.04 / 9.16 / 11.11 -> 8.86 / 9.02 / 11.09 ms, r05j_panel_waves_ab.txt)
+    const bool eight = tms >= 3;
     const int nw = eight ? 8 : 4, sk = eight ? 64 : kPnStage;
     a.n_groups = (N + 16 * nw - 1) / (16 * nw);
     a.n_items = n_ranges * a.n_groups;
     const size_t lds = (size_t)(16 * tms * kr + nw * depth * 16 * sk) * sizeof(float);
     const void *fn = tms == 1 ? (const void *)prefill_panel<1, kPnRange, 3, 4, kPnStage>
                    : tms == 2 ? (const void *)prefill_panel<2, kPnRange, 3, 4, kPnStage>
-                   : tms == 3 ? (eight ? (const void *)prefill_panel<3, 256, 3, 8, 64> : (const void *)prefill_panel<3, 256, 3, 4, kPnStage>)
-                              : (eight ? (const void *)prefill_panel<4, 256, 3, 8, 64> : (const void *)prefill_panel<4, 256, 3, 4, kPnStage>);
+                   : tms == 3 ? (const void *)prefill_panel<3, 256, 3, 8, 64> : (const void *)prefill_panel<4, 256, 3, 8, 64>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
         (void)hipGetLastError();

@@ -65,7 +65,6 @@ struct Tunables {
     int pf_panel = 1;          // L2Z_PF_PANEL        0: chunks of <= 32 tokens keep the short-prompt GEMMs (prefill_skinny.hip) instead of the
                                //                     K-range panel kernel (prefill_panel.hip; changes rounding: the ranges are part of the arithmetic)
     int pf_panel_max = -1;     // L2Z_PF_PANEL_MAX    longest chunk that takes the panel kernel (default and maximum 64 tokens)
-    int pf_panel_waves = 8;    // L2Z_PF_PANEL_WAVES  4: three / four token tiles keep the 4-wave form (stages of 128 k) -- same bits, A/B only
     int pf_panel_min = -1;     // L2Z_PF_PANEL_MIN    shortest chunk that takes it (default 17: up to 16 tokens the short-prompt GEMMs are ahead)
     int pf_splitk = -1;        // L2Z_PF_SPLITK       K ranges per output tile of the tile GEMM for chunks of <= 256 tokens: -1 by shape,
                                //                     1 none, 2 / 4 forced (changes rounding: the range partials are added in range order)

@@ -969,14 +969,6 @@ def test_prefill_panel_kernel_vs_oracle(gpu, ck, orc, options, kv_heads):
         np.testing.assert_allclose(got[tag], ref, rtol=LOGIT_RTOL, atol=LOGIT_ATOL, err_msg=tag)
         options(L2Z_PF_PANEL=1)
     assert not np.array_equal(got["skinny"], got["default"]), "L2Z_PF_PANEL=0 did not change the path"
-    # three / four token tiles: the 8-wave form (stages of 64 k) and the 4-wave form (128 k) walk k in the same order
-    for n in (33, 64):
-        s.prefill(toks[:n], 0, w)
-        eight = s.logits()
-        options(L2Z_PF_PANEL_WAVES=4)
-        s.prefill(toks[:n], 0, w)
-        options(L2Z_PF_PANEL_WAVES=8)
-        assert np.array_equal(s.logits(), eight), f"{n} tokens: the two forms' bits differ"
     print(f"panel kernel, kv heads {kv_heads}: max |logit - oracle| {worst:.2e}")
     m.close(); s.close(); w.close()
 
