@@ -21,9 +21,11 @@
 // Arithmetic: an output is the sum over ranges, in range order, of MFMA chains in (stage, u, c) order -- a function of K
 // alone: not of the rows a rank owns (row-sharded == unsharded, bit for bit), not of P or the token's place in its tile.
 //
-// LDS: panel 32 / 64 KB (TMS 1 / 2; rows unpadded, float4 slots XOR-swizzled by token & 7 on the SOURCE address of the
-// direct loads, like the tile GEMM) + 4 rings x 3 x 8 KB (rows of 128 floats, slots swizzled by row & 7): 128 / 160 KB,
-// one block per CU.  ds_read_b128 phases of 8 lanes (rows / tokens j .. j + 7) then touch 8 different 16-byte chunks.
+// LDS: panel 32 / 64 KB (TMS 1 / 2; rows unpadded, float4 slots XOR-swizzled by token & 15 on the SOURCE address of the
+// direct loads, like the tile GEMM) + 4 rings x 3 x 8 KB (rows of 128 floats, slots swizzled by row & 15): 128 / 160 KB,
+// one block per CU.  A ds_read_b128 is served in four groups of 16 lanes -- {0-3, 12-15, 20-27}, ... : rows j = 0-3, 12-15
+// at k slot q and 4-11 at q + 1 -- and slot ^ (row & 15) puts those 16 lanes on the 16 different 16-byte chunks of the
+// 256-byte bank row (row & 7, the first form, met each chunk twice: every operand read took 8 LDS cycles, not 4).
 #include "prefill_common.h"
 
 namespace l2z {
@@ -38,6 +40,10 @@ constexpr int kPanelDefaultMax = 64;
 // second launch (7B shape, whole prefill of 8 / 16 / 24 / 32 tokens: 5.31 / 5.65 / 8.76 / 8.78 ms there, 6.02 / 6.16 /
 // 6.92 / 6.98 here; profiles/r05b_prefill_panel_ab.txt)
 constexpr int kPanelDefaultMin = 17;
+#ifndef L2Z_PN_EXP
+#define L2Z_PN_EXP 0   // experiment builds (scripts/panel_exp.sh): 1 no W loads, 2 no MFMA, 4 no operand reads, 8 the round-5a swizzle
+#endif
+constexpr int kPnSwz = (L2Z_PN_EXP & 8) ? 7 : 15;
 
 struct PanelArgs {
     const float *x;   // [P, K], ldx floats per row
@@ -83,13 +89,13 @@ __global__ __launch_bounds__(64 * NW) void prefill_panel(const PanelArgs a)
 
     // ---- producer side: this wave's loads, one stage at a time, running ahead of its multiplies ----
     // Load i of a stage brings RPL rows of the wave's 16 (lane / SLOTS picks the row, lane % SLOTS the PHYSICAL float4
-    // slot, which holds logical slot ^ (row & 7)).  The 16 rows lie in one matrix (rows % 16 == 0), so a lane's source is
+    // slot, which holds logical slot ^ (row & 15)).  The 16 rows lie in one matrix (rows % 16 == 0), so a lane's source is
     // a wave-uniform row-0 pointer + a per-lane offset that never changes: no per-item pointer tables.
     size_t loff[LOADS];
 #pragma unroll
     for (int i = 0; i < LOADS; i++) {
         const int jl = RPL * i + lane / SLOTS;
-        loff[i] = (size_t)jl * (size_t)a.K + (size_t)(4 * ((lane % SLOTS) ^ (jl & 7)));
+        loff[i] = (size_t)jl * (size_t)a.K + (size_t)(4 * ((lane % SLOTS) ^ (jl & kPnSwz)));
     }
     int p_item = i0, p_st = 0, p_ns = 0, p_buf = 0, issued = 0;
     const float *p_base = a.w0;  // row 0 of the wave's 16 at k = the range's start
@@ -109,7 +115,8 @@ __global__ __launch_bounds__(64 * NW) void prefill_panel(const PanelArgs a)
         float *dst = ring + p_buf * STAGE_FLOATS;
         const float *src = p_base + p_st * SK;
 #pragma unroll
-        for (int i = 0; i < LOADS; i++) lds_dma16_nt(src + loff[i], dst + i * 256);
+        for (int i = 0; i < LOADS; i++)
+            if (!(L2Z_PN_EXP & 1)) lds_dma16_nt(src + loff[i], dst + i * 256);
         p_buf = p_buf + 1 == kPnDepth ? 0 : p_buf + 1;
         issued++;
         if (++p_st == p_ns) {
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(64 * NW) void prefill_panel(const PanelArgs a)
         constexpr int HPR = KR / 256;                           // wave-wide loads (256 floats) per token row
         for (int t = wave; t < 16 * TMS * HPR; t += NW) {       // wave-wide load t: piece h of token row t / HPR
             const int tok = t / HPR, h = t % HPR;
-            const int logical = (64 * h + lane) ^ (tok & 7);
+            const int logical = (64 * h + lane) ^ (tok & kPnSwz);
             int kk = 4 * logical;
             kk = kk < klen ? kk : klen - 4;                     // (a short last range: the piece past its end is never read)
             const float *src = a.x + (size_t)(tok < a.P ? tok : a.P - 1) * (size_t)a.ldx + (size_t)r * KR + kk;
@@ -158,19 +165,26 @@ __global__ __launch_bounds__(64 * NW) void prefill_panel(const PanelArgs a)
         issue_one();                                        // kPnDepth - 1 stages ahead, into that buffer
         const v4f *wst = (const v4f *)(ring + c_buf * STAGE_FLOATS);
         const v4f *xp = (const v4f *)panel;
-        const int sw = j & 7;
+        const int sw = j & kPnSwz;
 #pragma unroll
         for (int u = 0; u < SK / 16; u++) {  // k = 16 u + 4 q + c of the stage, A and B alike
             const int slot = 4 * u + q;
-            const v4f b = wst[j * SLOTS + (slot ^ sw)];
+            v4f b = wst[j * SLOTS + (slot ^ sw)];
             v4f xa[TMS];
 #pragma unroll
             for (int tm = 0; tm < TMS; tm++) xa[tm] = xp[(16 * tm + j) * (KR / 4) + ((c_st * SLOTS + slot) ^ sw)];
+            if (L2Z_PN_EXP & 4) {
+                b = (v4f){(float)lane, 1.f, 2.f, (float)u};
+#pragma unroll
+                for (int tm = 0; tm < TMS; tm++) xa[tm] = (v4f){(float)tm, (float)lane, 3.f, (float)c_st};
+            }
 #pragma unroll
             for (int c = 0; c < 4; c++)
 #pragma unroll
-                for (int tm = 0; tm < TMS; tm++)
-                    acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[tm][c], b[c], acc[tm], 0, 0, 0);
+                for (int tm = 0; tm < TMS; tm++) {
+                    if (L2Z_PN_EXP & 2) acc[tm][c] = fmaf(xa[tm][c], b[c], acc[tm][c]);
+                    else acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[tm][c], b[c], acc[tm], 0, 0, 0);
+                }
         }
         c_buf = c_buf + 1 == kPnDepth ? 0 : c_buf + 1;
         consumed++;
