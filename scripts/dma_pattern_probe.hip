@@ -110,6 +110,48 @@ __global__ __launch_bounds__(64 * W) void pat_rows_reg(const float *w, int n_row
     if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = acc.x;
 }
 
+
+// Pattern D (round 5): the panel kernel's walk -- items (k range, group of R x W rows) range-major, dealt in equal
+// contiguous spans to one persistent block per CU; wave w streams R rows of the item, a stage is R rows x SKB bytes,
+// a private ring of DEPTH stages, no barrier.  (R, SKB) = (16, 512): prefill_panel at one / two token tiles;
+// (4, 1024): what a 4x4x1-MFMA form (4 rows per wave) would read.
+template <int W, int R, int SKB, int DEPTH>
+__global__ __launch_bounds__(64 * W) void pat_panel(const float *w, int n_rows, int kr)
+{
+    extern __shared__ float smem[];
+    constexpr int LPR = SKB / 1024 > 0 ? SKB / 1024 : 1;       // wave loads per row and stage
+    constexpr int RPL = SKB >= 1024 ? 1 : 1024 / SKB;           // rows per wave load
+    constexpr int LOADS = R * SKB / 1024;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *ring = smem + wave * DEPTH * (R * SKB / 4);
+    const int n_groups = n_rows / (R * W), n_ranges = K / kr, n_items = n_ranges * n_groups, nst = kr * 4 / SKB;
+    const int i0 = (int)((long long)blockIdx.x * n_items / gridDim.x), i1 = (int)((long long)(blockIdx.x + 1) * n_items / gridDim.x);
+    const int total = (i1 - i0) * nst;
+    int issued = 0, item = i0, st = 0, buf = 0;
+    auto issue = [&]() {
+        const int r = item / n_groups, g = item - r * n_groups;
+        const float *base = w + (size_t)(g * R * W + wave * R) * K + (size_t)r * kr + (size_t)st * (SKB / 4);
+        float *dst = ring + buf * (R * SKB / 4);
+#pragma unroll
+        for (int i = 0; i < LOADS; i++) {
+            const int row = SKB >= 1024 ? i / LPR : RPL * i + lane / (SKB / 16);
+            const int off = SKB >= 1024 ? (i % LPR) * 256 + 4 * lane : 4 * (lane % (SKB / 16));
+            dma16(base + (size_t)row * K + off, dst + i * 256, true);
+        }
+        buf = buf + 1 == DEPTH ? 0 : buf + 1;
+        issued++;
+        if (++st == nst) { st = 0; item++; }
+    };
+    for (int p = 0; p < DEPTH - 1 && issued < total; p++) issue();
+    for (int done = 0; done < total; done++) {
+        const int younger = issued - done - 1;
+        if (younger >= 2 && DEPTH >= 4) wait_vm<2 * LOADS>();
+        else if (younger >= 1) wait_vm<LOADS>();
+        else wait_vm<0>();
+        if (issued < total) issue();
+    }
+}
+
 int main(int argc, char **argv)
 {
     const int only = argc > 1 ? atoi(argv[1]) : -1;
@@ -154,6 +196,18 @@ int main(int argc, char **argv)
         char nm[96]; snprintf(nm, 96, "row streams through registers: %d waves x %d loads, %d x %d blocks", W, U, nbx, S);   \
         run(nm, [&](const float *p) { hipLaunchKernelGGL((pat_rows_reg<W, U>), dim3(nbx, S), dim3(64 * W), 0, 0, p, N, K / S, out); }); \
     }
-    REG(4, 8, 256, 1) REG(4, 8, 512, 1) REG(8, 8, 256, 1) REG(4, 16, 256, 1) REG(4, 8, 1024, 1) REG(8, 8, 64, 4) REG(4, 4, 1024, 1)
+    REG(4, 8, 256, 1) REG(4, 8, 512, 1) REG(8, 8, 256, 1) REG(4, 16, 256, 1) REG(4, 8, 1024, 1) REG(4, 4, 1024, 1)
+#define PANEL(W, R, SKB, DEPTH, KR)                                                                                      \
+    {                                                                                                                     \
+        auto k = pat_panel<W, R, SKB, DEPTH>;                                                                             \
+        const int lds = W * DEPTH * R * SKB;                                                                              \
+        hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                            \
+        char nm[96]; snprintf(nm, 96, "panel walk: %d waves x %d rows x %d B stages, ring %d, ranges of %d k", W, R, SKB, DEPTH, KR); \
+        run(nm, [&](const float *p) { hipLaunchKernelGGL(k, dim3(256), dim3(64 * W), lds, 0, p, N, KR); });            \
+    }
+    PANEL(4, 16, 512, 3, 512) PANEL(4, 16, 512, 3, 2048) PANEL(4, 16, 512, 3, 4096) PANEL(8, 16, 256, 3, 256)
+    PANEL(4, 4, 1024, 3, 1024) PANEL(4, 4, 1024, 3, 2048) PANEL(4, 4, 1024, 3, 4096) PANEL(8, 4, 1024, 3, 2048) PANEL(8, 4, 1024, 3, 4096)
+    PANEL(4, 4, 2048, 3, 2048) PANEL(4, 4, 2048, 3, 4096) PANEL(16, 4, 512, 3, 4096) PANEL(4, 4, 1024, 6, 4096) PANEL(8, 2, 1024, 4, 4096)
+    PANEL(4, 8, 1024, 3, 4096) PANEL(4, 1, 4096, 3, 4096) PANEL(8, 1, 4096, 3, 4096) PANEL(16, 1, 2048, 3, 4096)
     return 0;
 }
