@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64 * W) void pat_rows_reg(const float *w, int n_row
 // contiguous spans to one persistent block per CU; wave w streams R rows of the item, a stage is R rows x SKB bytes,
 // a private ring of DEPTH stages, no barrier.  (R, SKB) = (16, 512): prefill_panel at one / two token tiles;
 // (4, 1024): what a 4x4x1-MFMA form (4 rows per wave) would read.
-template <int W, int R, int SKB, int DEPTH>
+template <int W, int R, int SKB, int DEPTH, int ORDER = 0>
 __global__ __launch_bounds__(64 * W) void pat_panel(const float *w, int n_rows, int kr)
 {
     extern __shared__ float smem[];
@@ -129,7 +129,11 @@ __global__ __launch_bounds__(64 * W) void pat_panel(const float *w, int n_rows, 
     const int total = (i1 - i0) * nst;
     int issued = 0, item = i0, st = 0, buf = 0;
     auto issue = [&]() {
-        const int r = item / n_groups, g = item - r * n_groups;
+        // ORDER 0: range-major (the shipped walk); 1: row-group-major, ranges 0, 1, ...; 2: row-group-major, group g
+        // starting at range g % n_ranges and wrapping (what a no-partials form with a double-buffered panel would read)
+        int r = item / n_groups, g = item - r * n_groups;
+        if (ORDER >= 1) { g = item / n_ranges; r = item - g * n_ranges; }
+        if (ORDER == 2) r = (r + g) % n_ranges;
         const float *base = w + (size_t)(g * R * W + wave * R) * K + (size_t)r * kr + (size_t)st * (SKB / 4);
         float *dst = ring + buf * (R * SKB / 4);
 #pragma unroll
@@ -205,6 +209,15 @@ int main(int argc, char **argv)
         char nm[96]; snprintf(nm, 96, "panel walk: %d waves x %d rows x %d B stages, ring %d, ranges of %d k", W, R, SKB, DEPTH, KR); \
         run(nm, [&](const float *p) { hipLaunchKernelGGL(k, dim3(256), dim3(64 * W), lds, 0, p, N, KR); });            \
     }
+#define PANELO(W, R, SKB, DEPTH, KR, ORD)                                                                                \
+    {                                                                                                                     \
+        auto k = pat_panel<W, R, SKB, DEPTH, ORD>;                                                                        \
+        const int lds = W * DEPTH * R * SKB;                                                                              \
+        hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                            \
+        char nm[120]; snprintf(nm, 120, "panel walk, row-group-major%s: %d waves x %d rows x %d B stages, ring %d, ranges of %d k", ORD == 2 ? " skewed" : "", W, R, SKB, DEPTH, KR); \
+        run(nm, [&](const float *p) { hipLaunchKernelGGL(k, dim3(256), dim3(64 * W), lds, 0, p, N, KR); });            \
+    }
+    PANELO(4, 16, 512, 3, 512, 1) PANELO(4, 16, 512, 3, 512, 2) PANELO(4, 16, 512, 3, 1024, 2) PANELO(4, 16, 512, 3, 256, 2) PANELO(8, 16, 256, 3, 256, 2)
     PANEL(4, 16, 512, 3, 512) PANEL(4, 16, 512, 3, 2048) PANEL(4, 16, 512, 3, 4096) PANEL(8, 16, 256, 3, 256)
     PANEL(4, 4, 1024, 3, 1024) PANEL(4, 4, 1024, 3, 2048) PANEL(4, 4, 1024, 3, 4096) PANEL(8, 4, 1024, 3, 2048) PANEL(8, 4, 1024, 3, 4096)
     PANEL(4, 4, 2048, 3, 2048) PANEL(4, 4, 2048, 3, 4096) PANEL(16, 4, 512, 3, 4096) PANEL(4, 4, 1024, 6, 4096) PANEL(8, 2, 1024, 4, 4096)
