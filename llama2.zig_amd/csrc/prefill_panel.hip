@@ -229,7 +229,15 @@ __device__ __forceinline__ v4f pn_sum_ranges(const PanelReduceArgs &a, int t, in
     const size_t stride = (size_t)a.P16 * (size_t)a.N;
     const float *p = a.part + (size_t)t * (size_t)a.N + f;
     v4f v = *(const v4f *)p;                       // range 0, then 1, ...: one fixed order
-    for (int r = 1; r < a.n_ranges; r++) {
+    int r = 1;
+    for (; r + 8 <= a.n_ranges; r += 8) {          // eight loads in flight, added in range order
+        v4f u[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) u[i] = *(const v4f *)(p + (size_t)(r + i) * stride);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { v.x += u[i].x; v.y += u[i].y; v.z += u[i].z; v.w += u[i].w; }
+    }
+    for (; r < a.n_ranges; r++) {
         const v4f u = *(const v4f *)(p + (size_t)r * stride);
         v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
     }
