@@ -62,7 +62,7 @@ struct Tunables {
     int pf_fuse = 1;           // L2Z_PF_FUSE         0: separate Q / K / V and W1 / W3 GEMMs
     int pf_kgs = -1;           // L2Z_PF_KGS          the tile GEMM's two k-groups on two blocks (same bits, twice the blocks): -1 by grid fill,
                                //                     0 never, 10 + f: always, on tile form f (0 128x64, 1 64x64, 2 32x64, 4 128x128)
-    int pf_panel = 1;          // L2Z_PF_PANEL        0: chunks of <= 32 tokens keep the short-prompt GEMMs (prefill_skinny.hip) instead of the
+    int pf_panel = 1;          // L2Z_PF_PANEL        0: chunks of 17 ... 64 tokens keep the short-prompt / tile GEMMs instead of the
                                //                     K-range panel kernel (prefill_panel.hip; changes rounding: the ranges are part of the arithmetic)
     int pf_panel_max = -1;     // L2Z_PF_PANEL_MAX    longest chunk that takes the panel kernel (default and maximum 64 tokens)
     int pf_panel_min = -1;     // L2Z_PF_PANEL_MIN    shortest chunk that takes it (default 17: up to 16 tokens the short-prompt GEMMs are ahead)
