@@ -41,7 +41,7 @@ constexpr int kPanelDefaultMax = 64;
 // 6.92 / 6.98 here; profiles/r05b_prefill_panel_ab.txt)
 constexpr int kPanelDefaultMin = 17;
 #ifndef L2Z_PN_EXP
-#define L2Z_PN_EXP 0   // experiment builds (scripts/panel_exp.sh): 1 no W loads, 2 no MFMA, 4 no operand reads, 8 the round-5a swizzle, 32 / 64 / 128 operand-read placements
+#define L2Z_PN_EXP 0   // experiment builds (scripts/panel_exp.sh): 1 no W loads, 2 no MFMA, 4 no operand reads, 8 the round-5a swizzle, 32 operand reads after the step's MFMAs
 #endif
 constexpr int kPnSwz = (L2Z_PN_EXP & 8) ? 7 : 15;
 
@@ -57,36 +57,6 @@ struct PanelArgs {
     int n_groups;     // groups of 64 rows
     int n_items;      // ranges * n_groups
 };
-
-// LDS reads the compiler does not schedule or count: a 16-byte read per lane, the wait for all but the N youngest of
-// them, and a zero-instruction use that keeps the consumers of a register behind that wait.
-__device__ __forceinline__ unsigned lds_addr(const void *p)
-{
-    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
-}
-__device__ __forceinline__ v4f lds_read16(unsigned addr)
-{
-    v4f v;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
-    return v;
-}
-template <int OFF>
-__device__ __forceinline__ v4f lds_read16_off(unsigned addr)
-{
-    static_assert(OFF >= 0 && OFF < 65536 && OFF % 16 == 0, "ds_read_b128 offset field");
-    v4f v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return v;
-}
-template <int N>
-__device__ __forceinline__ void lds_wait()
-{
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-}
-__device__ __forceinline__ void lds_landed(v4f &v)
-{
-    asm volatile("" : "+v"(v));
-}
 
 template <int KR, int SK>
 __device__ __forceinline__ int pn_range_stages(int K, int r)
@@ -199,23 +169,15 @@ __global__ __launch_bounds__(64 * NW) void prefill_panel(const PanelArgs a)
         // Operands of step u + 1 are requested BEFORE the MFMAs of step u (two register sets; the barrier keeps hipcc from
         // sinking them behind those MFMAs again, where it waited for them at once).  What hipcc makes of it -- the reads under
         // the last MFMA of the step before, one wait per two steps -- measured 3-5 % faster than the reads after the MFMAs
-        // AND than hand-placed reads with exact waits (L2Z_PN_EXP 32 / 64; EXPERIMENTS R5.2).
+        // AND than reads pinned elsewhere among the MFMAs or hand-placed with exact waits (L2Z_PN_EXP 32; EXPERIMENTS R5.2).
         constexpr int U = SK / 16;  // k = 16 u + 4 q + c of the stage, A and B alike
         v4f bq[2], xq[2][TMS];
-        const unsigned b_addr = lds_addr(wst + j * SLOTS), x_addr = lds_addr(xp + j * (KR / 4));
         auto operands = [&](int u, v4f &b, v4f (&xa)[TMS]) {
             const int slot = 4 * u + q;
             if (L2Z_PN_EXP & 4) {
                 b = (v4f){(float)lane, 1.f, 2.f, (float)u};
 #pragma unroll
                 for (int tm = 0; tm < TMS; tm++) xa[tm] = (v4f){(float)tm, (float)lane, 3.f, (float)c_st};
-            } else if (L2Z_PN_EXP & (64 | 128)) {  // inline-asm reads, waits written by hand
-                b = lds_read16(b_addr + 16u * (unsigned)(slot ^ sw));
-                const unsigned xo = x_addr + 16u * (unsigned)((c_st * SLOTS + slot) ^ sw);
-                xa[0] = lds_read16_off<0>(xo);  // token tile tm: 16 tm rows of KR floats further on
-                if constexpr (TMS > 1) xa[1] = lds_read16_off<1 * 16 * KR * 4>(xo);
-                if constexpr (TMS > 2) xa[2] = lds_read16_off<2 * 16 * KR * 4>(xo);
-                if constexpr (TMS > 3) xa[3] = lds_read16_off<3 * 16 * KR * 4>(xo);
             } else {
                 b = wst[j * SLOTS + (slot ^ sw)];
 #pragma unroll
@@ -231,36 +193,10 @@ __global__ __launch_bounds__(64 * NW) void prefill_panel(const PanelArgs a)
                     else acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq[u & 1][tm][c], bq[u & 1][c], acc[tm], 0, 0, 0);
                 }
         };
-        auto landed = [&](int u) {
-            lds_landed(bq[u & 1]);
-#pragma unroll
-            for (int tm = 0; tm < TMS; tm++) lds_landed(xq[u & 1][tm]);
-        };
         operands(0, bq[0], xq[0]);
-        if (L2Z_PN_EXP & (64 | 128)) { lds_wait<0>(); landed(0); }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            if (L2Z_PN_EXP & 128) {        // hand-placed: the next step's reads in the MIDDLE of this step's MFMAs
-                __builtin_amdgcn_sched_barrier(0);
-                mfmas(u, 0, 2);
-                __builtin_amdgcn_sched_barrier(0);
-                if (u + 1 < U) operands(u + 1, bq[(u + 1) & 1], xq[(u + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-                mfmas(u, 2, 4);
-                __builtin_amdgcn_sched_barrier(0);
-                if (u + 1 < U) { lds_wait<0>(); landed(u + 1); }
-            } else if (L2Z_PN_EXP & 64) {  // hand-placed: reads, exact wait, MFMAs back to back
-                if (u + 1 < U) {
-                    operands(u + 1, bq[(u + 1) & 1], xq[(u + 1) & 1]);
-                    lds_wait<TMS + 1>();
-                } else {
-                    lds_wait<0>();
-                }
-                landed(u);
-                __builtin_amdgcn_sched_barrier(0);
-                mfmas(u, 0, 4);
-                __builtin_amdgcn_sched_barrier(0);
-            } else if (L2Z_PN_EXP & 32) {  // the first form: reads after the MFMAs
+            if (L2Z_PN_EXP & 32) {  // the first form: reads after the MFMAs
                 mfmas(u, 0, 4);
                 if (u + 1 < U) operands(u + 1, bq[(u + 1) & 1], xq[(u + 1) & 1]);
             } else {
