@@ -123,6 +123,7 @@ def lib():
     L.l2z_emu_transformer.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int]
     L.l2z_prefill_attention.argtypes = [C.c_int, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.l2z_prefill_plan.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int]
+    L.l2z_prefill_plan_model.argtypes = [cfgp, C.c_int, C.POINTER(C.c_int), C.c_int]
     if hasattr(L, "l2z_shard_plan"):
         L.l2z_shard_plan.argtypes = [cfgp, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
     L.l2z_prefill_tile.argtypes = [C.c_int, C.c_int, C.c_int]
@@ -382,10 +383,14 @@ def shard_plan(cfg, rank: int, world: int) -> dict:
     return dict(zip(keys, list(buf)))
 
 
-def prefill_plan(n_tokens: int) -> list[int]:
-    """Chunk lengths of a batched prefill of n_tokens (host logic, no device)."""
+def prefill_plan(n_tokens: int, cfg=None) -> list[int]:
+    """Chunk lengths of a batched prefill of n_tokens (host logic, no device); with a config: of that model's."""
     buf = (C.c_int * 64)()
-    n = lib().l2z_prefill_plan(n_tokens, buf, 64)
+    if cfg is not None:
+        c = _cfg(cfg)
+        n = lib().l2z_prefill_plan_model(C.byref(c), n_tokens, buf, 64)
+    else:
+        n = lib().l2z_prefill_plan(n_tokens, buf, 64)
     if n < 0:
         raise L2ZError(n, lib().l2z_last_error().decode(errors="replace"))
     return list(buf[:n])

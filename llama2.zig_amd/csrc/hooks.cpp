@@ -268,6 +268,19 @@ extern "C" int l2z_shard_plan(const l2z_config *config, int rank, int world, int
 // Host-side planning of the batched prefill, no device needed: how a prompt is cut into chunks, and which
 // output tile the direct-to-LDS GEMM takes for a [P, N] product (0: 128x64, 1: 64x64, 2: 32x64, 3: 32x32,
 // 4: 128x128; the CU count is the current device's, 256 without one).
+extern "C" int l2z_prefill_plan_model(const l2z_config *config, int n_tokens, int *chunks, int cap)
+{
+    L2Z_CHECK(config != nullptr && n_tokens >= 0 && (chunks != nullptr || cap == 0), L2Z_ERR_INVALID, "l2z_prefill_plan_model: bad arguments");
+    L2Z_CHECK(config->n_heads > 0 && config->dim > 0, L2Z_ERR_INVALID, "l2z_prefill_plan_model: bad config");
+    int n = 0;
+    for (int done = 0; done < n_tokens; n++) {
+        const int P = prefill_next_chunk_of(*config, n_tokens - done);
+        if (n < cap) chunks[n] = P;
+        done += P;
+    }
+    return n;
+}
+
 extern "C" int l2z_prefill_plan(int n_tokens, int *chunks, int cap)
 {
     L2Z_CHECK(n_tokens >= 0 && (chunks != nullptr || cap == 0), L2Z_ERR_INVALID, "l2z_prefill_plan: bad arguments");

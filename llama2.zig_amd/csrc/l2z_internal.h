@@ -283,6 +283,11 @@ struct PanelProduct {
 // (widest_whole: rows of the whole model's widest launch + 128, what sizes the split-K / partial-product workspace)
 bool prefill_panel_shape(long long n_whole, int P, int K, long long widest_whole);
 int prefill_panel_max_tokens();
+// The next chunk of THIS model's batched prompt pass: the planner's (tunables.cpp prefill_next_chunk), except that a tail
+// of 65 ... 96 tokens on a model whose matrices take the panel kernel is cut in two chunks inside that kernel's range
+// (7B shape: one chunk of 65 ... 128 tokens costs 17.4 ... 17.8 ms whatever its length, 48 + 32 tokens 8.7 + 6.5 ms).
+// A function of the WHOLE model's shape and the tokens left: every rank of a shard group cuts the same chunks.
+int prefill_next_chunk_of(const l2z_config &c, int remaining);
 // hipErrorNotSupported: this rank's rows / pointers / workspace do not take the kernel (rows % 16, alignment) -- callers that
 // asked prefill_panel_shape first treat that as an error on a shard (the unsharded pass would have taken it)
 hipError_t launch_prefill_panel(const PanelProduct &p, int n_cus, const SplitKWs *ws, hipStream_t st);

@@ -376,6 +376,19 @@ int prefill_check(const l2z_config *config, const l2z_runstate *s)
     return L2Z_OK;
 }
 
+int prefill_next_chunk_of(const l2z_config &c, int remaining)
+{
+    const int P = prefill_next_chunk(remaining);
+    if (tunables().pf_chunk > 0 || P != remaining || remaining <= prefill_panel_max_tokens() || remaining > 96) return P;
+    const long long kvd = (long long)c.dim / c.n_heads * c.n_kv_heads;
+    const long long widest_whole = std::max((long long)c.dim + 2 * kvd, 2LL * c.hidden_dim) + 128;
+    const int first = remaining <= 80 ? 48 : 64;  // 65 ... 80: 48 + 17 ... 32; 81 ... 96: 64 + 17 ... 32
+    // Wo stands for the model's matrices: both pieces must take the panel kernel there (stream from HBM, K % 128 == 0)
+    if (!prefill_panel_shape(c.dim, first, c.dim, widest_whole) || !prefill_panel_shape(c.dim, remaining - first, c.dim, widest_whole))
+        return P;
+    return first;
+}
+
 // positions pos0 .. pos0+n-1 in chunks; leaves the last position's residual row in RunState.x
 int prefill_tokens(l2z_runstate *s, const l2z_weights *w, const int32_t *tokens, int n_tokens,
                           int pos0)
@@ -383,7 +396,7 @@ int prefill_tokens(l2z_runstate *s, const l2z_weights *w, const int32_t *tokens,
     const l2z_config *config = &s->cfg;
     int done = 0;
     while (done < n_tokens) {
-        const int P = prefill_next_chunk(n_tokens - done);
+        const int P = prefill_next_chunk_of(*config, n_tokens - done);
         L2Z_TRY(prefill_alloc(s, P));
         L2Z_TRY(prefill_chunk(s, w, tokens + done, P, pos0 + done));
         if (done + P == n_tokens)
@@ -466,7 +479,7 @@ extern "C" int l2z_emu_prefill(int n_ranks, l2z_runstate *const *ss, const l2z_w
     };
     int done = 0;
     while (done < n_tokens) {
-        const int P = prefill_next_chunk(n_tokens - done);
+        const int P = prefill_next_chunk_of(c, n_tokens - done);
         for (int r = 0; r < n_ranks; r++) L2Z_TRY(prefill_begin_chunk(ss[r], ws[r], tokens + done, P));
         if (ss[0]->sh.scheme_b) {
             // scheme B: every rank's half layer, then the all-reduce -- every rank's pf_x = the partials summed in rank order

@@ -64,7 +64,7 @@ def test_c_host_runs_the_golden_toy_checkpoints(gpu, tmp_path):
         assert np.array_equal(got, exp[:len(got)]) and len(got) == len(exp), (m["checkpoint"], got, exp)
 
 
-def test_prefill_planning_is_pinned(B):
+def test_prefill_planning_is_pinned(B, ck):
     """Host logic behind the batched prefill, no device needed (the library loads on a CPU-only machine):
     a prompt is cut into 1024-token chunks while that many tokens remain, then 512, then the rest; the
     direct-to-LDS GEMM's output tile follows the grid (256 CUs assumed without a device).  The tile never
@@ -72,6 +72,11 @@ def test_prefill_planning_is_pinned(B):
     assert B.prefill_plan(0) == [] and B.prefill_plan(5) == [5] and B.prefill_plan(512) == [512]
     assert B.prefill_plan(600) == [512, 88] and B.prefill_plan(1024) == [1024]
     assert B.prefill_plan(1500) == [1024, 476] and B.prefill_plan(2047) == [1024, 512, 511]
+    # a model whose matrices take the K-range panel kernel (they stream from HBM): a tail of 65 ... 96 tokens is cut in
+    # two chunks of that kernel's range; small models and other lengths keep the plain plan
+    c7b, c110 = ck.Config(4096, 11008, 32, 32, 32, 32000, 2048), ck.Config(768, 2048, 12, 12, 12, 32000, 1024)
+    assert [B.prefill_plan(n, c7b) for n in (64, 65, 80, 81, 96, 97, 600)] == [[64], [48, 17], [48, 32], [64, 17], [64, 32], [97], [512, 64, 24]]
+    assert [B.prefill_plan(n, c110) for n in (65, 96, 600)] == [[65], [96], [512, 88]]
     want = {(4096, 512, False): "128x64",    # 7B q / k / v / wo / W2: one 128 x 64 tile per CU
             (4096, 1024, False): "128x128",  # a 1024-token chunk: fewer bytes per flop into the CU
             (4096, 256, False): "64x64", (4096, 128, False): "32x64", (4096, 80, False): "32x64",
