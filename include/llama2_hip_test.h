@@ -110,7 +110,8 @@ int l2z_shard_plan(const l2z_config *config, int rank, int world, int *out, int 
  * 2: 32x64, 3: 32x32, 4: 128x128 (all forms give the same bits; the choice fills the CUs). */
 int l2z_prefill_plan(int n_tokens, int *chunks, int cap);
 /* The same for a given model: where the model's matrices take the K-range panel kernel (chunks of 17 ... 64 tokens of
- * matrices that stream from HBM) a tail of 65 ... 96 tokens is cut in two chunks of that range (48 | 64 tokens first). */
+ * matrices that stream from HBM) a tail of 65 ... 96 tokens is cut in two chunks of that range (48 | 64 tokens first),
+ * and a tail of 129 ... 160 / 257 ... 288 tokens into 128 / 256 + the rest. */
 int l2z_prefill_plan_model(const l2z_config *config, int n_tokens, int *chunks, int cap);
 int l2z_prefill_tile(int n_features, int n_tokens, int paired);
 /* K ranges per output tile of the tile GEMM's split-K family for an [n_tokens, k] x [n_features_whole, k]^T

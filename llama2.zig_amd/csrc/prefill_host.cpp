@@ -379,14 +379,20 @@ int prefill_check(const l2z_config *config, const l2z_runstate *s)
 int prefill_next_chunk_of(const l2z_config &c, int remaining)
 {
     const int P = prefill_next_chunk(remaining);
-    if (tunables().pf_chunk > 0 || P != remaining || remaining <= prefill_panel_max_tokens() || remaining > 96) return P;
+    if (tunables().pf_chunk > 0 || P != remaining || remaining <= prefill_panel_max_tokens()) return P;
     const long long kvd = (long long)c.dim / c.n_heads * c.n_kv_heads;
     const long long widest_whole = std::max((long long)c.dim + 2 * kvd, 2LL * c.hidden_dim) + 128;
-    const int first = remaining <= 80 ? 48 : 64;  // 65 ... 80: 48 + 17 ... 32; 81 ... 96: 64 + 17 ... 32
-    // Wo stands for the model's matrices: both pieces must take the panel kernel there (stream from HBM, K % 128 == 0)
-    if (!prefill_panel_shape(c.dim, first, c.dim, widest_whole) || !prefill_panel_shape(c.dim, remaining - first, c.dim, widest_whole))
-        return P;
-    return first;
+    // Wo stands for the model's matrices: a piece "takes the panel kernel" if Wo does at that length (streams from HBM, K % 128 == 0)
+    auto panel = [&](int n) { return prefill_panel_shape(c.dim, n, c.dim, widest_whole); };
+    if (remaining <= 96) {
+        const int first = remaining <= 80 ? 48 : 64;  // 65 ... 80: 48 + 17 ... 32; 81 ... 96: 64 + 17 ... 32
+        return panel(first) && panel(remaining - first) ? first : P;
+    }
+    // just past a step of the tile GEMM's cost (7B: 128 tokens 17.8 ms, 129 ... 160 25.4; 256 tokens 31.6, 288 40.2): the
+    // step's worth first, the <= 32 tokens left on the short-chunk kernels (5.5 ... 6.5 ms)
+    for (int q : {128, 256})
+        if (remaining > q && remaining <= q + 32) return panel(32) ? q : P;
+    return P;
 }
 
 // positions pos0 .. pos0+n-1 in chunks; leaves the last position's residual row in RunState.x

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 repo=$GRAFT_REPO_ROOT
 {
-for n in 65 72 80 81 96 97 600; do python $repo/scripts/prefill_ab.py llama2-7b $n 5 "" 2>&1 | grep prefill; done
+for n in 129 144 160 161 257 272 288 650; do python $repo/scripts/prefill_ab.py llama2-7b $n 5 "" 2>&1 | grep prefill; done
 python $repo/scripts/prefill_ab.py stories110M 80 10 "" 2>&1 | grep prefill
 } > $repo/gpurun_out/r05z_prefill_tail_split.txt 2>&1
 cat $repo/gpurun_out/r05z_prefill_tail_split.txt
