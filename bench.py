@@ -82,9 +82,76 @@ def weight_bytes_per_token(cfg, world: int = 1) -> int:
     return sum(wb[k] * (1 if k == "cls" else cfg.n_layers) for k in wb)
 
 
+def host_cpu_model() -> str:
+    """model name of the host CPU the baseline runs on ("report the box's CPU model")"""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine() or "unknown"
+
+
+_CPU_BUILD = None
+
+
+def cpu_oracle():
+    """The CPU checker as the timed baseline: rebuilt `-O3 -march=native` on THIS host when it has a C
+    compiler (BASELINE.md's plan) and kept if it is not slower than the library shipped with the tree on a
+    32-token probe of the stories15M shape (AVX-512 hosts can clock the native build down); the faster of the
+    two is what gets timed.  Returns (module, description of what ran) -- it goes into cpu_baseline.sample / .build."""
+    global _CPU_BUILD
+    orc = ge.load_oracle()
+    if _CPU_BUILD is not None:
+        return orc, _CPU_BUILD
+    shipped = orc.build()
+    if os.environ.get("L2Z_BENCH_CPU_NATIVE", "1") == "0":
+        _CPU_BUILD = f"shipped library (L2Z_BENCH_CPU_NATIVE=0): {orc.SHIPPED_FLAGS}"
+        return orc, _CPU_BUILD
+    built = orc.build_native()
+    if not built:
+        _CPU_BUILD = f"shipped library (no usable C compiler on the bench host): {orc.SHIPPED_FLAGS}"
+        return orc, _CPU_BUILD
+    ck = ge.load_package().checkpoint
+    cfg = ck.STORIES15M
+    rate = {}
+    for label, path in (("shipped", shipped), ("native", built[0])):
+        orc.use_library(path)
+        orc.set_mode(8, True, True)
+        m = orc.Model(cfg.as_i32(), orc.synth_fill(cfg.as_i32(), True, 1, 1), True)
+        m.transformer(1, 0)
+        best = 0.0
+        for _ in range(2):
+            t0 = time.perf_counter()
+            toks, _m = m.generate_greedy([], 32)
+            best = max(best, len(toks) / (time.perf_counter() - t0))
+        rate[label] = best
+        m.close()
+    probe = f"stories15M probe {rate['native']:.0f} vs {rate['shipped']:.0f} tok/s shipped x86-64-v3"
+    if rate["native"] >= rate["shipped"]:
+        orc.use_library(built[0])
+        _CPU_BUILD = f"rebuilt on the bench host: {built[1]} ({probe})"
+    else:
+        orc.use_library(shipped)
+        _CPU_BUILD = f"shipped library, {orc.SHIPPED_FLAGS}: faster here than the rebuild with {built[1]} ({probe})"
+    orc.lib()
+    return orc, _CPU_BUILD
+
+
+def cpu_record(value, sample: str, build: str) -> dict:
+    ncpu = os.cpu_count() or 1
+    cpu = host_cpu_model()
+    return {"value": value, "unit": "tokens/s", "cores": 1, "kind": "port",
+            "sample": f"{sample}; host CPU: {cpu}, 1 thread of {ncpu}; {build}",
+            "cpu_model": cpu, "host_threads": ncpu, "build": build}
+
+
 def cpu_baseline_small(ck, cfg, shared, name: str, n_tok: int = 64) -> dict:
     """The C oracle (port of src/main.zig, 1 thread) on a whole small model: n_tok greedy tokens."""
-    orc = ge.load_oracle()
+    orc, build = cpu_oracle()
     orc.set_mode(8, True, True)  # AVX2 width, fused -- the fastest reading of the reference
     ncpu = os.cpu_count() or 1
     blob = orc.synth_fill(cfg.as_i32(), shared, 1, ncpu)
@@ -94,14 +161,13 @@ def cpu_baseline_small(ck, cfg, shared, name: str, n_tok: int = 64) -> dict:
     toks, _ = m.generate_greedy([], n_tok)
     dt = time.perf_counter() - t0
     m.close()
-    return {"value": len(toks) / dt, "unit": "tokens/s", "cores": 1, "kind": "port",
-            "sample": f"{name}: full model, {len(toks)} greedy tokens from BOS, C oracle "
-                      f"(oracle/llama2_oracle.c, gcc -O3 AVX2+FMA), 1 thread of {ncpu}"}
+    return cpu_record(len(toks) / dt, f"{name}: full model, {len(toks)} greedy tokens from BOS, C oracle "
+                                      f"(oracle/llama2_oracle.c, the reference's 8-wide fused reading)", build)
 
 
 def cpu_baseline(ck, cfg, shared, name: str) -> dict:
     """Time the C oracle (port of src/main.zig, 1 thread) on a bounded sample."""
-    orc = ge.load_oracle()
+    orc, build = cpu_oracle()
     orc.set_mode(8, True, True)
     ncpu = os.cpu_count() or 1
     if cfg.n_layers <= 12 and ck.weights_count(cfg, shared) * 4 < (1 << 30):
@@ -124,9 +190,9 @@ def cpu_baseline(ck, cfg, shared, name: str) -> dict:
         dt = time.perf_counter() - t0
         m.close()
         del blob
-        return {"value": len(toks) / dt, "unit": "tokens/s", "cores": 1, "kind": "port",
-                "sample": f"{name}: full model ({need / 1e9:.1f} GB of weights on the host), {len(toks)} greedy "
-                          f"tokens from BOS, C oracle (oracle/llama2_oracle.c, gcc -O3 AVX2+FMA), 1 thread of {ncpu}"}
+        return cpu_record(len(toks) / dt, f"{name}: full model ({need / 1e9:.1f} GB of weights on the host), {len(toks)} "
+                                          f"greedy tokens from BOS, C oracle (oracle/llama2_oracle.c, the reference's "
+                                          f"8-wide fused reading)", build)
     # big shape, small host: time 1-layer and 3-layer models of the same dims, extrapolate layers linearly
     times = {}
     n_tok = 3
@@ -145,10 +211,9 @@ def cpu_baseline(ck, cfg, shared, name: str) -> dict:
     t_layer = (times[3] - times[1]) / 2
     t_rest = max(times[1] - t_layer, 0.0)
     t_full = t_rest + cfg.n_layers * t_layer
-    return {"value": 1.0 / t_full, "unit": "tokens/s", "cores": 1, "kind": "port",
-            "sample": f"{name}: same dims with 1 and 3 layers, {n_tok} tokens each, C oracle 1 thread "
-                      f"of {ncpu}; per-layer {t_layer*1e3:.1f} ms, classifier+rest {t_rest*1e3:.1f} ms, "
-                      f"extrapolated to {cfg.n_layers} layers"}
+    return cpu_record(1.0 / t_full, f"{name}: same dims with 1 and 3 layers, {n_tok} tokens each, C oracle; per-layer "
+                                    f"{t_layer*1e3:.1f} ms, classifier+rest {t_rest*1e3:.1f} ms, extrapolated to "
+                                    f"{cfg.n_layers} layers", build)
 
 
 def run_once(B, cfg, shared, seed, steps, warmup, comm=None, sync_ok=None):

@@ -9,7 +9,7 @@ Layout (cited against /root/reference/src/main.zig):
 No real checkpoint exists in the build image, so this module also produces
 seeded synthetic blobs.  The generator is specified in DESIGN.md ("Synthetic
 checkpoints") and implemented three times -- here (numpy), in the CPU oracle
-(oracle/llama2_oracle.c: orc_synth_*) and on the device (csrc/synth.hip) --
+(oracle/llama2_oracle.c: orc_synth_*) and on the device (csrc/misc_kernels.hip: synth_fill_kernel) --
 tests check the three agree bit for bit.
 """
 from __future__ import annotations

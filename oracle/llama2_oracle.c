@@ -238,6 +238,25 @@ void orc_runstate_free(orc_runstate *s)
     memset(s, 0, sizeof *s);
 }
 
+/* RoPE, main.zig:336-351 (inline in transformer()): adjacent pairs (i, i+1), freq from pow, cos,
+ * sin in f32, recomputed per pair; k is rotated only where i < kv_dim (:343). */
+void orc_rope(float *q, float *k, size_t pos, size_t dim, size_t kv_dim, size_t head_size)
+{
+    for (size_t i = 0; i < dim; i += 2) {
+        const float head_dim = (float)(i % head_size);                        /* :338 */
+        const float freq = 1.0f / powf(10000.0f, head_dim / (float)head_size); /* :339 */
+        const float val = (float)pos * freq;                                  /* :340 */
+        const float fcr = cosf(val), fci = sinf(val);                         /* :341-342 */
+        const int rotn = i < kv_dim ? 2 : 1;                                  /* :343 */
+        for (int v = 0; v < rotn; v++) {
+            float *vec = v == 0 ? q : k;
+            const float v0 = vec[i], v1 = vec[i + 1];
+            vec[i] = v0 * fcr - v1 * fci;                                     /* :348 */
+            vec[i + 1] = v0 * fci + v1 * fcr;                                 /* :349 */
+        }
+    }
+}
+
 /* main.zig:285-430 */
 void orc_transformer(size_t token, size_t pos, const orc_config *c, orc_runstate *s,
                      const orc_weights *w)
@@ -266,20 +285,7 @@ void orc_transformer(size_t token, size_t pos, const orc_config *c, orc_runstate
             orc_matmul_fused(2, outs, s->xb, ws, dim, kv_dim);
         }
 
-        /* RoPE, :336-351: adjacent pairs, freq from pow, cos, sin in f32 */
-        for (size_t i = 0; i < dim; i += 2) {
-            const float head_dim = (float)(i % head_size);                        /* :338 */
-            const float freq = 1.0f / powf(10000.0f, head_dim / (float)head_size); /* :339 */
-            const float val = (float)pos * freq;                                  /* :340 */
-            const float fcr = cosf(val), fci = sinf(val);                         /* :341-342 */
-            const int rotn = i < kv_dim ? 2 : 1;                                  /* :343 */
-            for (int v = 0; v < rotn; v++) {
-                float *vec = v == 0 ? s->q : s->k;
-                const float v0 = vec[i], v1 = vec[i + 1];
-                vec[i] = v0 * fcr - v1 * fci;                                     /* :348 */
-                vec[i + 1] = v0 * fci + v1 * fcr;                                 /* :349 */
-            }
-        }
+        orc_rope(s->q, s->k, pos, dim, kv_dim, head_size);      /* :336-351 */
 
         const size_t loff = l * seq_len * kv_dim;               /* :354 */
         memcpy(s->key_cache + loff + pos * kv_dim, s->k, kv_dim * sizeof(float));   /* :357 */
@@ -411,7 +417,7 @@ static void fill_parallel(float *dst, uint64_t base, uint64_t count, uint64_t se
     for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
 }
 
-/* Per-tensor (scale,bias); keep in sync with csrc/synth.hip and checkpoint.py:
+/* Per-tensor (scale,bias); keep in sync with csrc/misc_kernels.hip: synth_fill_kernel and checkpoint.py:
  *   matrices (d,n)         : uniform +-sqrt(3/n)  -> unit-variance outputs
  *   token_embedding / wcls : uniform +-2*sqrt(3/dim)
  *   rmsnorm weights        : 1 + 0.1*r

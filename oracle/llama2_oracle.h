@@ -94,6 +94,8 @@ void orc_vector_weighted_sum_rows(float *xout, size_t xout_len, const float *row
 void orc_softmax(float *x, size_t n);                                             /* :687-706 */
 void orc_accum(float *a, const float *b, size_t n);                               /* :708-713 */
 size_t orc_argmax(const float *x, size_t n);                                      /* :715-726 */
+/* the inline RoPE of transformer(), :336-351, in place on q [dim] and k [kv_dim] */
+void orc_rope(float *q, float *k, size_t pos, size_t dim, size_t kv_dim, size_t head_size);
 
 /* ---- checkpoint / state, main.zig:73-115, :137-154 ---- */
 /* number of f32 in the weight blob (after the 28-byte header) */
@@ -121,7 +123,7 @@ size_t orc_generate_greedy(const orc_config *c, orc_runstate *s, const orc_weigh
 /* ---- seeded synthetic checkpoints (no real .bin exists in the image) ----
  * value(idx) = bias + scale * r(idx, seed), r uniform on a 2^-22 grid in
  * [-1, 1); idx is the flat f32 index in the blob.  The same generator is
- * implemented on the device (csrc/synth.hip) and in numpy (checkpoint.py);
+ * implemented on the device (csrc/misc_kernels.hip: synth_fill_kernel) and in numpy (checkpoint.py);
  * tests check all three agree bit-for-bit.
  */
 float orc_synth_value(uint64_t idx, uint64_t seed, float scale, float bias);

@@ -43,6 +43,34 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
+NATIVE_FLAGS = ["-O3", "-march=native", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-std=c11", "-D_GNU_SOURCE"]
+SHIPPED_FLAGS = "-O3 -march=x86-64-v3 -ffp-contract=off (oracle/Makefile, built where the tree was built)"
+
+
+def build_native():
+    """BASELINE.md's CPU-baseline plan: the port at `-O3 -march=native` on the host that is timed.  Compiles
+    oracle/liboracle_native.so with this host's gcc and returns (path, flags); None when there is no compiler
+    or the build fails (the caller then times the shipped library and says so).  Same source, same
+    -ffp-contract=off: only the instruction selection changes, the arithmetic is still orc_set_mode's."""
+    import shutil
+    cc = shutil.which(os.environ.get("CC", "gcc"))
+    if not cc:
+        return None
+    out = os.path.join(_HERE, "liboracle_native.so")
+    cmd = [cc, *NATIVE_FLAGS, "-shared", "-o", out, os.path.join(_HERE, "llama2_oracle.c"), "-lm", "-lpthread"]
+    try:
+        subprocess.run(cmd, check=True, capture_output=True, timeout=300)
+    except (subprocess.SubprocessError, OSError):
+        return None
+    return out, f"{os.path.basename(cc)} " + " ".join(NATIVE_FLAGS[:-1])
+
+
+def use_library(path: str) -> None:
+    """Load the oracle from `path` from now on (bench.py's cpu_baseline: the -march=native build)."""
+    global _LIB_PATH, _lib
+    _LIB_PATH, _lib = path, None
+
+
 _lib = None
 
 
@@ -65,6 +93,7 @@ def lib():
         L.orc_accum.argtypes = [fp, fp, sz]
         L.orc_argmax.argtypes = [fp, sz]
         L.orc_argmax.restype = sz
+        L.orc_rope.argtypes = [fp, fp, sz, sz, sz, sz]
         L.orc_weights_count.argtypes = [C.POINTER(OrcConfig), C.c_int]
         L.orc_weights_count.restype = sz
         L.orc_weights_init.argtypes = [C.POINTER(OrcWeights), C.POINTER(OrcConfig), fp, C.c_int]
@@ -152,6 +181,13 @@ def softmax(x):
     o = np.array(x, np.float32, copy=True)
     lib().orc_softmax(_fp(o), o.size)
     return o
+
+
+def rope(q, k, pos: int, head_size: int):
+    """main.zig:336-351 on copies of q [dim] and k [kv_dim]; returns (q, k) rotated for `pos`"""
+    q = np.array(q, np.float32, copy=True); k = np.array(k, np.float32, copy=True)
+    lib().orc_rope(_fp(q), _fp(k), pos, q.size, k.size, head_size)
+    return q, k
 
 
 def argmax(x):

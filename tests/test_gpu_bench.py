@@ -38,6 +38,8 @@ def test_bench_line_has_the_contract_fields(gpu):
     assert r["d2d_copy_probe"]["copied_avg"] and r["d2d_copy_probe"]["copied_avg"] > 100.0  # GB/s copied; traffic is twice that
     c = out["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "oracle" in c["sample"]
+    # round 6: the line names the host CPU and the build of the port that was timed (BASELINE.md's plan)
+    assert c["cpu_model"] and c["cpu_model"] in c["sample"] and "-march=" in c["build"] and c["build"] in c["sample"]
     by_shape = out["extra"]["cpu_baseline_by_shape"]
     assert set(by_shape) == {"stories15M", "stories110M"} and all(v["value"] > 0 and v["cores"] == 1 for v in by_shape.values())
     assert out["extra"]["stories15M_tokens_per_s"] > 0 and out["extra"]["prefill"]["roofline"]["bound"] == "mfma"

@@ -1006,3 +1006,52 @@ def test_probs_read_vs_host_softmax(gpu, ck, orc, temp):
         assert int(np.argmax(got)) == int(np.argmax(ref))
         assert np.array_equal(s.logits(), lg)   # the logits themselves are left untouched
     s.close(); w.close()
+
+
+# ---------------------------------------------------------------- RoPE, driven directly (main.zig:336-351)
+ROPE_SHAPES = [("hs48-mha", 288, 6, 6), ("hs48-gqa", 288, 6, 2), ("hs64-gqa", 512, 8, 2),
+               ("hs128-gqa", 1024, 8, 4), ("hs128-rowkernel-gqa", 4096, 32, 8)]
+
+
+@pytest.mark.parametrize("name,dim,H,KV", ROPE_SHAPES, ids=[c[0] for c in ROPE_SHAPES])
+def test_rope_epilogue_at_positions_vs_oracle(gpu, ck, orc, options, name, dim, H, KV):
+    """the EPI_ROPE epilogue of the q|k|v launch (matvec_device.h; fused_small.hip for small MHA
+    models) at pos > 0, up to the last row of a 2048-row cache, head sizes 48 / 64 / 128, MHA and GQA (pairs
+    with i >= kv_dim rotate q only, main.zig:343).  Two bars on a one-layer model (so RunState.q is layer 0's):
+      * the rotation ALONE: the device's own pos-0 q / k rows (cos 1, sin 0: un-rotated) run through the
+        oracle's inline RoPE for `pos` must give the device's q / K-cache row at `pos` to an ulp of the pair's
+        magnitude -- same inputs, only the rotation differs; V rows do not change with pos at all;
+      * the whole launch: q and the K row against the oracle's own pass at `pos`, one dot product deep."""
+    hs, kv_dim = dim // H, (dim // H) * KV
+    cfg = ck.Config(dim=dim, hidden_dim=64, n_layers=1, n_heads=H, n_kv_heads=KV, vocab_size=64, seq_len=2048)
+    blob = ck.synth_blob(cfg, True, seed=77)
+    m = orc.Model(cfg.as_i32(), blob, True)
+    tok = 5
+    forms = (1, 0) if KV == H else (0,)   # the fused small-model launch only exists for MHA shapes
+    for fuse in forms:
+        options(L2Z_FUSE_SMALL=fuse)
+        w, s = gpu.Weights(cfg, blob, True), gpu.RunState(cfg)
+        s.transformer(tok, 0, w)
+        q0 = s.read("q", 0, dim)
+        k0 = s.read("key_cache", 0, kv_dim)
+        v0 = s.read("value_cache", 0, kv_dim)
+        m.transformer(tok, 0)
+        assert np.allclose(q0, m.state("q", dim), rtol=2e-5, atol=2e-5)
+        for pos in (1, 2, 7, 300, 1023, 2047):
+            s.transformer(tok, pos, w)
+            q = s.read("q", 0, dim)
+            k = s.read("key_cache", pos * kv_dim, kv_dim)
+            v = s.read("value_cache", pos * kv_dim, kv_dim)
+            assert np.array_equal(v, v0), (name, fuse, pos)
+            want_q, want_k = orc.rope(q0, k0, pos, hs)
+            for got, want, src in ((q, want_q, q0), (k, want_k, k0)):
+                pair_mag = np.repeat(np.abs(src.reshape(-1, 2)).sum(axis=1), 2)
+                assert np.all(np.abs(got - want) <= 2.4e-7 * pair_mag + 1e-12), \
+                    (name, fuse, pos, float(np.max(np.abs(got - want) / (pair_mag + 1e-30))))
+            assert not np.array_equal(q, q0) and not np.array_equal(k, k0)
+            m.transformer(tok, pos)
+            assert np.allclose(q, m.state("q", dim), rtol=2e-5, atol=2e-5), (name, fuse, pos)
+            assert np.allclose(k, m.state("key_cache", 2048 * kv_dim)[pos * kv_dim:(pos + 1) * kv_dim],
+                               rtol=2e-5, atol=2e-5), (name, fuse, pos)
+        s.close(); w.close()
+    m.close()

@@ -272,3 +272,33 @@ def test_shard_range(B):
         B.shard_range(288, 48, 0, 4)   # 6 heads do not split over 4 ranks
     with pytest.raises(B.L2ZError):
         B.shard_range(10, 1, 5, 4)
+
+
+def test_rope_function_is_the_pass_inline_rope(orc, ck):
+    """orc_rope is transformer()'s inline RoPE (main.zig:336-351) factored out for the GPU test of the
+    EPI_ROPE epilogue: identity at pos 0, equal to the float64 formula to f32 rounding elsewhere, k pairs
+    beyond kv_dim untouched (GQA), and the pass's own q / K row at pos p equals rope(pos-0 q / K row)."""
+    rng = np.random.default_rng(5)
+    for dim, kv_dim, hs in ((96, 96, 48), (128, 32, 64), (256, 128, 128)):
+        q, k = rng.standard_normal(dim).astype(np.float32), rng.standard_normal(kv_dim).astype(np.float32)
+        q0, k0 = orc.rope(q, k, 0, hs)
+        assert np.array_equal(q0, q) and np.array_equal(k0, k)
+        for pos in (1, 17, 2047):
+            qr, kr = orc.rope(q, k, pos, hs)
+            tol = 3e-6 + 1e-6 * pos   # an ulp of freq (powf vs numpy's pow) is an angle error of pos * 6e-8
+            i = np.arange(0, dim, 2)
+            ang = pos * (1.0 / np.power(10000.0, (i % hs) / hs).astype(np.float32)).astype(np.float32)
+            c, s_ = np.cos(ang.astype(np.float64)), np.sin(ang.astype(np.float64))
+            wq = np.empty(dim); wq[0::2] = q[0::2] * c - q[1::2] * s_; wq[1::2] = q[0::2] * s_ + q[1::2] * c
+            assert np.allclose(qr, wq, atol=tol)
+            half = kv_dim // 2
+            wk = np.empty(kv_dim); wk[0::2] = k[0::2] * c[:half] - k[1::2] * s_[:half]; wk[1::2] = k[0::2] * s_[:half] + k[1::2] * c[:half]
+            assert np.allclose(kr, wk, atol=tol)
+    cfg = ck.Config(dim=64, hidden_dim=32, n_layers=1, n_heads=4, n_kv_heads=2, vocab_size=32, seq_len=64)
+    m = orc.Model(cfg.as_i32(), ck.synth_blob(cfg, True, seed=3), True)
+    m.transformer(3, 0)
+    q0, k0 = m.state("q", 64), m.state("key_cache", 32)
+    m.transformer(3, 41)
+    wq, wk = orc.rope(q0, k0, 41, 16)
+    assert np.array_equal(m.state("q", 64), wq) and np.array_equal(m.state("key_cache", 64 * 32)[41 * 32:42 * 32], wk)
+    m.close()
