@@ -54,6 +54,9 @@ class Config:
 # The shapes BASELINE.json names.
 STORIES15M = Config(288, 768, 6, 6, 6, 32000, 256)
 STORIES110M = Config(768, 2048, 12, 12, 12, 32000, 1024)
+# llama2.c's public stories42M checkpoint: not a BASELINE config, but a model the reference runs whose hidden_dim
+# (1376 = 4 * 344, 344 = 5 * 64 + 24) is not a whole number of 64-lane float4 steps: the mat-vec's partial last step
+STORIES42M = Config(512, 1376, 8, 8, 8, 32000, 1024)
 LLAMA2_7B = Config(4096, 11008, 32, 32, 32, 32000, 2048)
 
 
@@ -182,4 +185,5 @@ def read_checkpoint(path, mmap: bool = True):
 def iter_configs() -> Iterator[tuple[str, Config, bool]]:
     yield "stories15M", STORIES15M, True
     yield "stories110M", STORIES110M, True
+    yield "stories42M", STORIES42M, True
     yield "llama2-7b", LLAMA2_7B, False

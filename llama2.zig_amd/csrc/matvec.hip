@@ -79,24 +79,16 @@ __device__ __forceinline__ void mv_load(const float *pa, const float *pb, int c0
 {
     constexpr int U = MvGeom<LPR>::U;
     const v4f *a4 = (const v4f *)pa, *b4 = (const v4f *)pb;
-    if (LPR == 64) {
-        // n4 % 64 == 0 (checked by the launcher): whether step k of the batch that starts
-        // at column cb is inside the row is the same for every lane.  Out-of-row steps
-        // re-read step 0 (their x entries are the zero padding).
+    // Per lane: n4 need not be a multiple of the lane count -- the last step of a row like hidden_dim 1376
+    // (n4 = 344 = 5 * 64 + 24) is a partial one, the vector form of the reference's scalar tail
+    // (main.zig:589-594).
+    (void)cb;
 #pragma unroll
-        for (int k = 0; k < U; k++) {
-            const int off = (cb + 64 * k < n4) ? 64 * k : 0;  // wave-uniform
-            wa[k] = ldg_nt(a4 + c0 + off);
-            wb[k] = ldg_nt(b4 + c0 + off);
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < U; k++) {
-            int c = c0 + LPR * k;
-            c = c < n4 ? c : n4 - 1;
-            wa[k] = ldg_nt(a4 + c);
-            wb[k] = ldg_nt(b4 + c);
-        }
+    for (int k = 0; k < U; k++) {
+        int c = c0 + LPR * k;
+        c = c < n4 ? c : n4 - 1;
+        wa[k] = ldg_nt(a4 + c);
+        wb[k] = ldg_nt(b4 + c);
     }
 }
 
@@ -485,14 +477,10 @@ size_t matvec_lds_bytes(int n) { return (size_t)(4 * ((n >> 2) + 1024) + kScratc
 
 int matvec_max_grid(int n_cus) { return n_cus * 8; }
 
-// widths the vector kernels take (16-byte aligned operands assumed); the rest goes to the generic
-// scalar kernel, which has no fused-argmax epilogue
-bool matvec_vector_width(int n)
-{
-    if (n <= 0 || (n % 4) != 0) return false;
-    const int n4 = n >> 2;
-    return !(lpr_for(n4) == 64 && (n4 % 64) != 0);
-}
+// widths the vector kernels take (16-byte aligned operands assumed): every multiple of 4 floats -- a row whose
+// float4 count is not a multiple of the lane count ends in a partial step (mv_load).  The rest (n % 4 != 0: the
+// reference's 3x3 / 2x12 known-answer tests) goes to the generic scalar kernel, which has no fused-argmax epilogue
+bool matvec_vector_width(int n) { return n > 0 && (n % 4) == 0; }
 
 // vector kernels (16-byte aligned operands assumed: every buffer here is a hipMalloc or a row of one)
 bool matvec_ll_supported(int n) { return matvec_vector_width(n); }
@@ -518,7 +506,6 @@ hipError_t launch_matvec(const MatvecArgs &a_in, int pro, int epi, int max_block
     if (n_pairs <= 0 || a.n <= 0) return hipErrorInvalidValue;
     const int n4 = a.n >> 2;
     const int lpr = lpr_for(n4);
-    if (lpr == 64 && (n4 % 64) != 0) vec = false;  // rare odd widths: generic scalar kernel
     if (epi == EPI_ARGMAX && (!vec || a.rows1 != 0 || a.rows2 != 0)) return hipErrorNotSupported;
     const Tunables &tn = tunables();
     const bool use_row = vec && tn.row_kernel && n4 >= 1024 && (n4 % 64) == 0;

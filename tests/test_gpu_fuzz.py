@@ -25,13 +25,15 @@ def test_random_shapes_against_oracle(gpu, ck, orc):
     assert bad == 0, "\n".join(l for l in lines if not l.startswith("ok "))
 
 
-def test_width_that_takes_the_scalar_kernel_with_classifier(gpu, ck, orc):
-    """dim 1152: (dim/4) % 64 != 0 above the narrow-row range -> generic scalar mat-vec kernel,
-    which has no fused-argmax epilogue; the classifier launch must fall back, not fail."""
+def test_width_with_a_partial_last_step_and_width_that_takes_the_scalar_kernel(gpu, ck, orc):
+    """dim 1152: (dim/4) % 64 != 0 above the narrow-row range -- the generic scalar kernel until round 5, since
+    round 6 the 64-lane vector kernel with a partial last float4 step (the reference handles any n with a scalar
+    TAIL, main.zig:589-594, not a scalar kernel) and the fused-argmax classifier.  dim 1150 (n % 4 != 0) still takes
+    the generic scalar kernel, which has no fused-argmax epilogue: the classifier launch must fall back, not fail."""
     f = _fuzz()
-    cfg = ck.Config(1152, 2304, 1, 12, 3, 1000, 96)
-    lines = []
-    assert f.check_config(gpu, ck, orc, np.random.default_rng(5), cfg, False, 77, lines.append), lines
+    for cfg in (ck.Config(1152, 2304, 1, 12, 3, 1000, 96), ck.Config(1150, 2302, 1, 25, 5, 1000, 96)):
+        lines = []
+        assert f.check_config(gpu, ck, orc, np.random.default_rng(5), cfg, False, 77, lines.append), lines
 
 
 def test_random_shapes_and_world_sizes_sharded_bit_identical(gpu):
