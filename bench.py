@@ -410,7 +410,7 @@ def scaling_model(B, cfg, shared, seed, pos: int, worlds=(2, 4, 8)) -> dict:
 SOLO_FORMS = [("p2p-consume", {"L2Z_P2P_CONSUME": 1}), ("p2p-gather", {"L2Z_P2P_CONSUME": 0}), ("p2p-allreduce", {"L2Z_SCHEME_B": 1})]
 
 
-def solo_rank_model(B, cfg, shared, seed, steps: int = 64, worlds=(2, 4, 8)) -> dict:
+def solo_rank_model(B, cfg, shared, seed, steps: int = 64, worlds=(2, 4, 8), forms=None) -> dict:
     """What scaling_model's per-kind sums leave out: ONE rank of an N-rank group alone on this GPU running its WHOLE
     sharded pass -- graph replay, every launch, the pushes of its outputs as LL words, the consumer-side polls, the
     gather / reduce launches -- with free hand-overs (l2z_comm_p2p_connect_solo: the peers' arenas are a local sink and
@@ -423,7 +423,7 @@ def solo_rank_model(B, cfg, shared, seed, steps: int = 64, worlds=(2, 4, 8)) -> 
         if cfg.n_heads % world or cfg.n_kv_heads % world or cfg.hidden_dim % world or cfg.vocab_size % world:
             continue
         row = {}
-        for leg, opts in SOLO_FORMS:
+        for leg, opts in (forms or SOLO_FORMS):
             comm = w = s = None
             try:
                 for k, v in opts.items():
@@ -760,6 +760,39 @@ def leg_main(args) -> int:
     tr = comm.transports()
     trs = [None] * world
     dist.all_gather_object(trs, tr)
+    # Cross-device diagnostics, measured in THIS run before the timed steps (peer-write legs; round 6): what one
+    # hand-over costs between rank 0 and each peer over the IPC-mapped arenas -- the number the leg's tokens/s has to be
+    # read against (a rank's token makes `gathers` hand-overs; SURVEY.md 8e: latency, not bandwidth, is the bound).
+    cross = None
+    if kind not in RCCL_LEGS and all(x["p2p"] for x in trs):
+        cross = {"ll_word_round_trip_us": {}, "peer_copy_16KB_us": {}, "devices": None,
+                 "note": "rank 0 <-> rank p: one 8-byte {value, epoch} word each way per round trip (2000 trips, device "
+                         "clock, one polling thread per side: l2z_comm_p2p_pingpong); hipMemcpyAsync of 16 KB into rank "
+                         "p's arena + stream sync (200 copies, host clock).  Ranks on ONE GPU (tests) measure the chip's "
+                         "own fine-grained memory, not xGMI"}
+        devs = [None] * world
+        dist.all_gather_object(devs, device)
+        cross["devices"] = devs
+        for p in range(1, world):
+            err = None
+            v = c16 = None
+            try:
+                if rank == 0:
+                    v = comm.p2p_pingpong(p, True)
+                elif rank == p:
+                    comm.p2p_pingpong(0, False)
+            except Exception as e:  # noqa: BLE001
+                err = str(e)
+            dist.barrier()
+            try:
+                if rank == 0 and err is None:
+                    c16 = comm.peer_copy_probe(p, 16384, 200)
+            except Exception as e:  # noqa: BLE001
+                err = str(e)
+            if rank == 0:
+                cross["ll_word_round_trip_us"][str(p)] = v if err is None else {"error": err}
+                cross["peer_copy_16KB_us"][str(p)] = c16
+            dist.barrier()
     s = w = None
     try:
         n_tok, dt, s, w = run_once(B, cfg, shared, args.seed, steps, args.warmup, comm, all_ok)
@@ -815,6 +848,28 @@ def leg_main(args) -> int:
     s.close()
     w.close()
 
+    # Predicted vs measured, in the same process: rank 0 alone re-runs ITS OWN whole sharded pass with free hand-overs
+    # (extra.scaling_model.solo_rank's bed: the peers' arenas a local sink, no wait ever blocks) for this leg's structure;
+    # measured / predicted < 1 is what the hand-overs (latency above, rank skew, xGMI) cost on this box.
+    predicted = None
+    if not args.no_extra and world > 1 and os.environ.get("L2Z_BENCH_NO_SOLO", "") != "1":
+        solo_leg = kind if kind in dict(SOLO_FORMS) else ("p2p-allreduce" if scheme_b else "p2p-gather")
+        if rank == 0:
+            try:
+                forms = [f for f in SOLO_FORMS if f[0] == solo_leg]
+                row = solo_rank_model(B, cfg, shared, args.seed, 64, (world,), forms).get(str(world), {}).get(solo_leg, {})
+                ub = row.get("tokens_per_s_upper_bound")
+                predicted = {"structure": solo_leg, "tokens_per_s_free_handovers": ub,
+                             "measured_tokens_per_s": n_tok / dt,
+                             "measured_over_predicted": (n_tok / dt) / ub if ub else None,
+                             "handover_cost_ms_per_token": (dt / n_tok - 1.0 / ub) * 1e3 if ub else None,
+                             "detail": row if not ub else None,
+                             "note": ("rank 0 of the group alone on its GPU, whole pass, hand-overs free (l2z_comm_p2p_connect_solo)"
+                                      + ("" if kind == solo_leg else f"; this leg's transport is RCCL: the bed's nearest structure ({solo_leg}) stands in"))}
+            except Exception as e:  # noqa: BLE001
+                predicted = {"error": str(e)}
+        dist.barrier()
+
     n_g = (2 if scheme_b else 4) * cfg.n_layers + 1
     launches = by_kind["gather"][1] // n_prof
     bytes_tok = weight_bytes_per_token(cfg, world)
@@ -837,7 +892,12 @@ def leg_main(args) -> int:
            # step would take with free gathers; the rest of ms_per_step is gather + launch overhead
            "ms_per_step_at_stream_read_rate": ideal_ms,
            "overhead_ms_per_step": (dt / n_tok * 1e3 - ideal_ms) if ideal_ms else None,
-           "prefill_sharded": prefill_sharded, "runstate_form": form_ran}
+           "prefill_sharded": prefill_sharded, "runstate_form": form_ran,
+           "cross_device": cross, "predicted_vs_measured": predicted}
+    if cross and launches is not None:
+        rt = [v for v in cross["ll_word_round_trip_us"].values() if isinstance(v, float)]
+        if rt:  # one way = half a round trip; a token makes n_g hand-overs in sequence
+            leg["handover_latency_floor_ms_per_token"] = n_g * (max(rt) / 2) * 1e-3
     out = {
         "metric": "tokens/s (argmax, -t 0)", "value": n_tok / dt, "unit": "tokens/s",
         "n_gpus": args.gpus, "steps": n_tok, "warmup": args.warmup,

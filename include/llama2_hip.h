@@ -104,9 +104,14 @@ void l2z_runstate_free(l2z_runstate *s);
  * Asynchronous on the runstate's stream; l2z_argmax / l2z_logits_read sync. */
 int l2z_transformer(int token, int pos, const l2z_config *config, l2z_runstate *s,
                     const l2z_weights *w);
-/* src/main.zig:715 argmax over s.logits, on device (strict '>' : lowest index wins ties) */
+/* src/main.zig:715 argmax over s.logits, on device (strict '>' : lowest index wins ties).
+ * SHARDED runstates: l2z_argmax, l2z_logits_read and l2z_probs_read are COLLECTIVE after greedy steps
+ * (l2z_greedy_run) on the peer-write transport -- those steps exchange one argmax candidate per rank instead of
+ * gathering the logits, so the first call that needs the whole vector gathers it, and every rank of the group
+ * must make that call (as every rank makes every other call); a rank that calls alone waits L2Z_P2P_TIMEOUT_S
+ * and gets L2Z_ERR_COMM.  After l2z_transformer / l2z_prefill the logits are already whole: plain reads. */
 int l2z_argmax(l2z_runstate *s, int *out_token);
-/* copy s.logits (vocab_size floats) to the host */
+/* copy s.logits (vocab_size floats) to the host (sharded: see l2z_argmax) */
 int l2z_logits_read(l2z_runstate *s, float *out_logits);
 /* src/main.zig:1005-1008 on the device: out_probs[i] = softmax(logits / temperature)[i] (temperature > 0),
  * then the device-to-host copy of vocab_size floats; the caller goes on with sample / sample_top_p

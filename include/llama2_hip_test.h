@@ -146,6 +146,15 @@ int l2z_comm_transports(const l2z_comm *c, int *rccl_ranks, int *p2p_connected);
  * meaningless (the peers' slices read as zeros). */
 int l2z_comm_p2p_connect_solo(l2z_comm *c);
 
+/* Diagnostics of the peer-write transport, for bench.py's N > 1 legs (what a hand-over costs between two ranks of
+ * THIS group on THIS box -- xGMI when they sit on two GPUs).  Both are made by two ranks at once, like every call of a
+ * shard group: l2z_comm_p2p_pingpong by `other` and by this rank with opposite `initiator` flags and the same iters --
+ * *rtt_us = microseconds per round trip of one 8-byte LL word each way (device clock, one polling thread per side);
+ * l2z_comm_peer_copy_probe by one rank only: `bytes` into the other's arena by the runtime's device-to-device copy,
+ * each copy synchronised: microseconds per copy (host clock). */
+int l2z_comm_p2p_pingpong(l2z_comm *c, int other, int initiator, int iters, double *rtt_us);
+int l2z_comm_peer_copy_probe(l2z_comm *c, int other, size_t bytes, int iters, double *us_per_copy);
+
 /* Loads RCCL (dlopen) now and reports the file the process got and ncclGetVersion's code.  A process that imports
  * PyTorch afterwards keeps THIS copy (same SONAME); one that imported it before gets torch's bundled copy. */
 int l2z_comm_rccl_info(char *path_out, size_t cap, int *version);

@@ -115,6 +115,9 @@ def lib():
         L.l2z_comm_rccl_info.argtypes = [C.c_char_p, sz, ip]
     if hasattr(L, "l2z_runstate_form"):
         L.l2z_runstate_form.argtypes = [vp, ip]
+    if hasattr(L, "l2z_comm_p2p_pingpong"):
+        L.l2z_comm_p2p_pingpong.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.l2z_comm_peer_copy_probe.argtypes = [vp, C.c_int, sz, C.c_int, C.POINTER(C.c_double)]
     if hasattr(L, "l2z_comm_transports"):  # an older build loaded through L2Z_LIB (A/B runs) lacks the newer entry points
         L.l2z_comm_transports.argtypes = [vp, ip, ip]
     L.l2z_comm_free.argtypes = [vp]
@@ -207,6 +210,18 @@ class Comm:
     def p2p_connect_solo(self) -> None:
         """Measurement: this rank alone, peers' arenas a local sink, no wait ever blocks (l2z_comm_p2p_connect_solo)."""
         _chk(lib().l2z_comm_p2p_connect_solo(self.h))
+
+    def p2p_pingpong(self, other: int, initiator: bool, iters: int = 2000) -> float:
+        """microseconds per round trip of one LL word each way between this rank and `other` (both ranks call)"""
+        v = C.c_double(0)
+        _chk(lib().l2z_comm_p2p_pingpong(self.h, other, 1 if initiator else 0, iters, C.byref(v)))
+        return v.value
+
+    def peer_copy_probe(self, other: int, nbytes: int = 16384, iters: int = 200) -> float:
+        """microseconds per synchronised device-to-device copy of `nbytes` into rank `other`'s arena (one rank calls)"""
+        v = C.c_double(0)
+        _chk(lib().l2z_comm_peer_copy_probe(self.h, other, nbytes, iters, C.byref(v)))
+        return v.value
 
     def transports(self) -> dict:
         """{"rccl_ranks": ranks RCCL reports for the communicator (0: none), "p2p": arenas connected}"""

@@ -348,7 +348,7 @@ __global__ __launch_bounds__(NT) void attention_split_kernel(const AttnArgs a, i
     const int step = ge.G * kFastUB;
     const v4f zero = {0.f, 0.f, 0.f, 0.f};
 
-    const int T = *a.pos_ptr + 1;                      // :367
+    const int T = a.pos_plus1 ? a.pos_plus1 : *a.pos_ptr + 1;   // :367
     // chunk c owns the CONTIGUOUS timesteps [c * per, c * per + Tc): in the head-major cache that is one
     // run of Tc * head_size floats of K and one of V -- a linear stream per block (the (seq_len, kv_dim)
     // order gave 512-byte pieces 16 KB apart at the 7B shape).  per is even: a wave's two rows stay

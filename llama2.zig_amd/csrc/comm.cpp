@@ -8,6 +8,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 
 #include "l2z_comm.h"
@@ -366,6 +367,63 @@ extern "C" int l2z_comm_p2p_connect_solo(l2z_comm *c)
     c->bulk_floats = 0;
     c->p2p = true;
     c->solo = true;
+    return L2Z_OK;
+}
+
+// Diagnostics of the peer-write transport (include/llama2_hip_test.h): what a hand-over costs between two ranks.
+extern "C" int l2z_comm_p2p_pingpong(l2z_comm *c, int other, int initiator, int iters, double *rtt_us)
+{
+    L2Z_CHECK(c != nullptr && rtt_us != nullptr && iters >= 1, L2Z_ERR_INVALID, "l2z_comm_p2p_pingpong: bad arguments");
+    L2Z_CHECK(c->p2p && !c->solo, L2Z_ERR_STATE, "l2z_comm_p2p_pingpong: the peer-write arenas are not connected");
+    L2Z_CHECK(other >= 0 && other < c->world && other != c->rank, L2Z_ERR_INVALID, "l2z_comm_p2p_pingpong: peer %d", other);
+    L2Z_HIP(hipSetDevice(c->device));
+    long long *d_ticks = nullptr;
+    L2Z_HIP(hipMalloc((void **)&d_ticks, sizeof(long long)));
+    const unsigned long long base = c->probe_seq[other];
+    c->probe_seq[other] += (unsigned long long)iters;
+    hipError_t e = launch_p2p_pingpong(c->arena, c->peer_arena[other], c->rank, other, initiator != 0, iters, base,
+                                       tunables().p2p_timeout_s * 100000000LL, d_ticks, c->h_err, nullptr);
+    long long ticks = -1;
+    if (e == hipSuccess) e = hipMemcpy(&ticks, d_ticks, sizeof ticks, hipMemcpyDeviceToHost);
+    (void)hipFree(d_ticks);
+    L2Z_HIP(e);
+    L2Z_CHECK(ticks >= 0, L2Z_ERR_COMM, "l2z_comm_p2p_pingpong: rank %d did not answer within %lld s", other,
+              tunables().p2p_timeout_s);
+    *rtt_us = (double)ticks / 100.0 / (double)iters;   // wall_clock64: 100 MHz
+    return L2Z_OK;
+}
+
+// `bytes` from a local buffer into rank `other`'s arena (bulk region 1, which only the sharded prefill uses and
+// rewrites before it flags) by the runtime's device-to-device copy: `iters` copies, each synchronised -- the latency
+// of ONE small peer copy (the transport RCCL-free hosts would reach for) beside the LL word's.
+extern "C" int l2z_comm_peer_copy_probe(l2z_comm *c, int other, size_t bytes, int iters, double *us_per_copy)
+{
+    L2Z_CHECK(c != nullptr && us_per_copy != nullptr && iters >= 1 && bytes >= 4, L2Z_ERR_INVALID,
+              "l2z_comm_peer_copy_probe: bad arguments");
+    L2Z_CHECK(c->p2p && !c->solo, L2Z_ERR_STATE, "l2z_comm_peer_copy_probe: the peer-write arenas are not connected");
+    L2Z_CHECK(other >= 0 && other < c->world && other != c->rank, L2Z_ERR_INVALID, "l2z_comm_peer_copy_probe: peer %d", other);
+    L2Z_CHECK(bytes <= c->bulk_floats * 4, L2Z_ERR_INVALID, "l2z_comm_peer_copy_probe: %zu bytes do not fit the bulk region", bytes);
+    L2Z_HIP(hipSetDevice(c->device));
+    char *dst = c->peer_arena[other] + kP2pFlagBytes + 2 * c->slot_floats * 8 + c->bulk_floats * 4;
+    void *src = nullptr;
+    L2Z_HIP(hipMalloc(&src, bytes));
+    hipError_t e = hipMemset(src, 0, bytes);
+    hipStream_t st = nullptr;
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    for (int i = 0; i < 3 && e == hipSuccess; i++) {  // warm-up
+        e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < iters && e == hipSuccess; i++) {
+        e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    if (st) (void)hipStreamDestroy(st);
+    (void)hipFree(src);
+    L2Z_HIP(e);
+    *us_per_copy = us / (double)iters;
     return L2Z_OK;
 }
 

@@ -206,6 +206,7 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.pos_ptr = s->d_pos; a.head_size = sh.hs; a.kv_row = sh.hs; a.kv_head = kvh_stride;
             a.kv_mul = c.n_heads / c.n_kv_heads; a.seq_len = c.seq_len;
             a.tl_seq = s->tl_attn_seq++;
+            if (tn.attn_pos_arg && only_kind >= 0) a.pos_plus1 = s->time_pos + 1;
             if (!sb && can_push && attention_push_supported(a)) {
                 a.push = s->d_push + 0;
                 a.push_ctl = ctl;
@@ -384,7 +385,7 @@ int run_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, int pos)
               "l2z_comm_p2p_export/_connect), or drive emulated ranks with l2z_emu_transformer");
     L2Z_TRY(comm_check(s->comm));
     L2Z_TRY(ensure_graph(s, w, variant, with_step));
-    s->logits_partial = with_step && s->xchg_steps;
+    s->logits_partial = with_step && s->xchg_steps && s->d_push != nullptr && s->sh.world > 1;  // enqueue_forward's `xchg`
     if (s->use_graphs) {
         s->n_part = with_step ? s->n_part_step : s->n_part_fwd;
         L2Z_HIP(hipGraphLaunch(with_step ? s->g_step[variant] : s->g_forward[variant], s->stream));
@@ -605,6 +606,7 @@ extern "C" int l2z_time_kind(int kind, int pos, const l2z_config *config, l2z_ru
               "l2z_time_kind: unsharded runstates, emulated or solo ranks only (a connected shard would wait for its peers)");
     L2Z_CHECK(pos >= 0 && pos < config->seq_len, L2Z_ERR_STATE, "pos out of range");
     L2Z_HIP(hipSetDevice(s->device));
+    s->time_pos = pos;
     L2Z_HIP(launch_set_state(1, pos, s->d_token, s->d_pos, w->tok_emb, s->x, config->dim, s->stream));
     hipEvent_t e0, e1;
     L2Z_HIP(hipEventCreate(&e0));

@@ -4,7 +4,8 @@
 #include "l2z_internal.h"
 
 constexpr int kMaxWorld = 16;
-constexpr size_t kP2pFlagBytes = 4096;  // reserved head of every arena
+constexpr size_t kP2pFlagBytes = 4096;  // reserved head of every arena: bulk flags [kMaxWorld] u64 at 0, probe words [kMaxWorld] u64 at kP2pProbeOff
+constexpr size_t kP2pProbeOff = 2048;   // l2z_comm_p2p_pingpong's words (one per sender)
 
 // ints of l2z_comm::d_ctl (device memory, shared by every runstate of the group)
 constexpr int kCtlEpoch = 0;  // epochs used up by completed passes: gather gi of the running pass is ctl[0] + gi
@@ -36,6 +37,7 @@ struct l2z_comm {
     // hand-overs (bench.py extra.scaling_model); the results mean nothing.
     bool solo = false;
     char *solo_sink = nullptr;        // solo: where the pushes "to the peers" land (one slot pair per peer, distinct addresses)
+    unsigned long long probe_seq[kMaxWorld] = {};  // round trips exchanged with each rank so far (l2z_comm_p2p_pingpong)
 };
 // the index a hand-over is given on this group (solo: always 0)
 inline int comm_gi(const l2z_comm *c, int gi) { return c != nullptr && c->solo ? 0 : gi; }
@@ -70,6 +72,9 @@ struct P2pArgs {
 
 // pushed: the producing kernel has already written this rank's words (MatvecArgs::push)
 hipError_t launch_p2p_allgather(const P2pArgs &a, int gi, int n_gathers, bool pushed, hipStream_t st);
+hipError_t launch_p2p_pingpong(char *mine, char *theirs, int me, int other, bool initiator, int iters,
+                               unsigned long long base, long long timeout_ticks, long long *ticks_out, int *err,
+                               hipStream_t st);
 hipError_t launch_p2p_allreduce(const P2pArgs &a, float *out, int gi, bool pushed, hipStream_t st);
 bool comm_p2p_args(const l2z_comm *c, float *buf, size_t count_per_rank, bool self, P2pArgs *out);
 LLIn comm_ll_in(const l2z_comm *c, int gi, size_t count_per_rank);

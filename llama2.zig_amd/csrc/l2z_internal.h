@@ -152,6 +152,7 @@ struct AttnArgs {
     const int *push_ctl;
     int push_gi;
     int tl_seq;            // attention launch number since the runstate was made (measurement builds only: L2Z_TIMELINE)
+    int pos_plus1;         // != 0: the position + 1 by value (split kernel; experiment L2Z_ATTN_POS_ARG), 0: read *pos_ptr
 };
 
 

@@ -131,6 +131,7 @@ struct l2z_runstate {
     bool logits_partial = false;
     bool fused_qkv_attn = false;  // small models: qkv + RoPE + KV write + attention in one launch
     int max_blocks = 0;
+    int time_pos = 0;              // l2z_time_kind's position (experiment L2Z_ATTN_POS_ARG)
     int tl_attn_seq = 0;           // attention launches enqueued so far (AttnArgs::tl_seq, measurement builds)
 };
 
@@ -154,6 +155,7 @@ void drop_graphs(l2z_runstate *s);
 constexpr int kPrefillMinPrompt = L2Z_PREFILL_MIN_PROMPT;  // shorter prompts: the stepped loop is as fast
 bool prefill_enabled();
 bool prefill_usable(const l2z_runstate *s);
+bool prefill_shard_takes_the_unsharded_kernels(const l2z_config &c, const Shard &sh);
 int prefill_check(const l2z_config *config, const l2z_runstate *s);
 int prefill_tokens(l2z_runstate *s, const l2z_weights *w, const int32_t *tokens, int n_tokens, int pos0);
 

@@ -8,6 +8,8 @@ namespace {
 // ---------------------------------------------------------------------------
 // argmax (main.zig:715-726) + the loop's hand-over (main.zig:999-1003, :1036)
 // ---------------------------------------------------------------------------
+constexpr int kArgmaxFailed = -2;  // the candidate exchange of a shard group did not complete (a peer timed out)
+
 __global__ __launch_bounds__(1024) void argmax_kernel(const ArgmaxArgs a)
 {
     __shared__ float s_val[16];
@@ -140,9 +142,19 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const ArgmaxArgs a)
             }
             best = cv;
             bi = ci;
+            // a candidate that never arrived (or a group already marked dead): the N pairs are not what the other ranks
+            // see, so this rank must not hand a token over as if they were -- mark the step invalid instead of diverging
+            if (__any(late ? 1 : 0) || dead) bi = kArgmaxFailed;
         }
     }
-    if (tid == 0) {
+    if (tid == 0 && bi == kArgmaxFailed) {
+        // failed candidate exchange: token, pos, x and the group's epochs stay as they are (every replay that follows
+        // finds the error latched and ends at once), the step's output slot gets -1; the host's comm_check after the
+        // stream sync turns the latch into L2Z_ERR_COMM before any token is consumed
+        if (a.argmax_out) *a.argmax_out = -1;
+        if (a.advance) a.out_tokens[*a.pos_ptr] = -1;
+        s_next = -1;
+    } else if (tid == 0) {
         // (an index outside the vocabulary can only come from a corrupted exchange -- a solo rank's collapsed epochs, a
         // peer that died mid-word: never let it address the embedding table)
         if (bi == 0x7fffffff || (unsigned)bi >= (unsigned)a.vocab) bi = 0;
@@ -159,7 +171,7 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const ArgmaxArgs a)
         s_next = next;
     }
     __syncthreads();
-    if (a.advance) {
+    if (a.advance && s_next >= 0) {
         // next step's embedding row -> x (main.zig:295-296), saves a launch
         const float *row = a.tok_emb + (size_t)s_next * (size_t)a.dim;
         for (int i = tid; i < a.dim; i += blockDim.x) a.x[i] = row[i];

@@ -396,6 +396,38 @@ hipError_t launch_p2p_allreduce(const P2pArgs &a, float *out, int gi, bool pushe
     return hipGetLastError();
 }
 
+// ---- diagnostic: LL-word round trips between two ranks (include/llama2_hip_test.h l2z_comm_p2p_pingpong) ----
+// One thread per side.  The initiator stores word base + i into the other side's probe word (reserved head of its arena,
+// kP2pProbeOff + 8 * sender), the responder answers with the same value into the initiator's; `iters` round trips
+// between two reads of the 100-MHz wall clock.  The words are the gathers' own kind of traffic: one 8-byte system-scope
+// store to the peer's fine-grained memory, polled by a system-scope load -- over xGMI when the ranks sit on two GPUs.
+__global__ void p2p_pingpong_kernel(char *mine, char *theirs, int me, int other, int initiator, int iters, u64 base,
+                                    long long timeout_ticks, long long *ticks_out, int *err)
+{
+    u64 *out = (u64 *)(theirs + kP2pProbeOff) + me;
+    const u64 *in = (const u64 *)(mine + kP2pProbeOff) + other;
+    const long long t0 = wall_clock64();
+    bool dead = false;
+    for (int i = 1; i <= iters && !dead; i++) {
+        const u64 v = base + (u64)i;
+        if (initiator) __hip_atomic_store(out, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        while (__hip_atomic_load(in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < v)
+            if (wall_clock64() - t0 > timeout_ticks) { dead = true; break; }
+        if (!initiator && !dead) __hip_atomic_store(out, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    *ticks_out = dead ? -1 : wall_clock64() - t0;
+    if (dead) *err = 1 + other;
+}
+
+hipError_t launch_p2p_pingpong(char *mine, char *theirs, int me, int other, bool initiator, int iters,
+                               unsigned long long base, long long timeout_ticks, long long *ticks_out, int *err,
+                               hipStream_t st)
+{
+    hipLaunchKernelGGL(p2p_pingpong_kernel, dim3(1), dim3(1), 0, st, mine, theirs, me, other, initiator ? 1 : 0, iters,
+                       (u64)base, timeout_ticks, ticks_out, err);
+    return hipGetLastError();
+}
+
 hipError_t launch_p2p_allgather(const P2pArgs &a, int gi, int n_gathers, bool pushed, hipStream_t st)
 {
     hipLaunchKernelGGL(p2p_allgather_kernel, dim3(a.world), dim3(256), 0, st, a, gi, n_gathers,

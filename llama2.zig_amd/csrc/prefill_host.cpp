@@ -131,7 +131,16 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
         if (!prefill_panel_shape(n_whole, P, pp.K, widest_whole)) return L2Z_OK;
         pp.P = P;
         const hipError_t e = launch_prefill_panel(pp, g_cus, ws, st);
-        if (e == hipErrorNotSupported) return L2Z_OK;  // this rank's rows / workspace do not take it: the forms below
+        if (e == hipErrorNotSupported) {
+            // The WHOLE model's product takes the panel kernel but this launch cannot (rows not a multiple of 16,
+            // alignment, workspace).  Unsharded: the forms below, consistently.  On a shard the unsharded pass takes
+            // the panel kernel's summation order and this rank would take another: refuse rather than break
+            // "row-sharded == unsharded, bit for bit" silently (prefill_usable keeps such shards off this path).
+            L2Z_CHECK(!sharded, L2Z_ERR_INVALID,
+                      "batched prefill: this rank's share of a [%lld, %d] product does not take the kernel the unsharded "
+                      "pass takes (rows per rank must be multiples of 16)", n_whole, pp.K);
+            return L2Z_OK;
+        }
         L2Z_HIP(e);
         *taken = true;
         return L2Z_OK;
@@ -340,6 +349,29 @@ int prefill_classifier(l2z_runstate *s, const l2z_weights *w)
 
 namespace l2z {
 
+// Row-sharded == unsharded bit for bit needs every rank to take the kernel -- the summation order -- the unsharded
+// pass takes.  The one kernel with a per-rank shape condition is the K-range panel kernel (a wave's 16 rows lie in one
+// matrix: every matrix of a launch must have a multiple of 16 rows ON THE RANK): where some chunk length sends one of
+// the WHOLE model's products there and this group's share of its rows is not a multiple of 16, the group keeps off the
+// batched path (its prompts are stepped).  A function of the model and the group size: the same on every rank.
+bool prefill_shard_takes_the_unsharded_kernels(const l2z_config &c, const Shard &sh)
+{
+    if (sh.world == 1 || sh.scheme_b) return true;  // (scheme B never takes the panel kernel)
+    const long long kvd = (long long)c.dim / c.n_heads * c.n_kv_heads;
+    const long long widest_whole = std::max((long long)c.dim + 2 * kvd, 2LL * c.hidden_dim) + 128;
+    struct { long long n_whole; int K; bool rows_ok; } prod[4] = {
+        {(long long)c.dim + 2 * kvd, c.dim, sh.dim_loc % 16 == 0 && sh.kvd_loc % 16 == 0},
+        {c.dim, c.dim, sh.dim_loc % 16 == 0},
+        {2LL * c.hidden_dim, c.dim, (2 * sh.hid_loc) % 16 == 0},
+        {c.dim, c.hidden_dim, sh.dim_loc % 16 == 0}};
+    for (const auto &p : prod) {
+        if (p.rows_ok) continue;
+        for (int P = 1; P <= prefill_panel_max_tokens(); P++)
+            if (prefill_panel_shape(p.n_whole, P, p.K, widest_whole)) return false;
+    }
+    return true;
+}
+
 bool prefill_enabled()
 {
     return tunables().prefill != 0;
@@ -360,6 +392,7 @@ bool prefill_usable(const l2z_runstate *s)
     }
     if (s->sh.world == 1) return true;
     if (s->sh.dim_loc % 4 != 0 || s->sh.hid_loc % 4 != 0) return false;
+    if (!prefill_shard_takes_the_unsharded_kernels(c, s->sh)) return false;
     const size_t widest = (size_t)(c.dim > c.hidden_dim ? c.dim : c.hidden_dim);
     return comm_bulk_ok(s->comm, (size_t)kPrefillChunk * widest);
 }
@@ -467,6 +500,8 @@ extern "C" int l2z_emu_prefill(int n_ranks, l2z_runstate *const *ss, const l2z_w
                       ss[r]->sh.dim_loc % 4 == 0 && ss[r]->sh.hid_loc % 4 == 0,
                   L2Z_ERR_INVALID, "l2z_emu_prefill: shape not supported by the batched path");
         L2Z_CHECK(ss[r]->sh.scheme_b == ss[0]->sh.scheme_b, L2Z_ERR_INVALID, "l2z_emu_prefill: the ranks' sharding schemes differ");
+        L2Z_CHECK(prefill_shard_takes_the_unsharded_kernels(c, ss[r]->sh), L2Z_ERR_INVALID,
+                  "l2z_emu_prefill: a rank's rows are not multiples of 16 where the unsharded pass takes the panel kernel");
         L2Z_TRY(prefill_alloc(ss[r], n_tokens < kPrefillChunk ? n_tokens : kPrefillChunk));
     }
     auto sync_all = [&]() -> int {

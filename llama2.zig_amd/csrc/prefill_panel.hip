@@ -155,7 +155,12 @@ __global__ __launch_bounds__(64 * NW) void prefill_panel(const PanelArgs a)
             __syncthreads();
             cur_range = r;
         } else {
-            // stage `consumed` of this wave has landed: what may still fly are the stages issued after it
+            // stage `consumed` of this wave has landed: what may still fly are the stages issued after it.
+            // (vmcnt counts the item-end stores of the partial products as well, and a wave's memory operations
+            // return IN ORDER on gfx9: right after an item end the immediates below also wait for those 4 TMS stores
+            // and for the stage loads issued before them -- correct, and once per item (64 rows x one range) the
+            // run-ahead is shorter by it.  The in-order return is the documented behaviour of loads AND stores that
+            // share vmcnt on gfx9 / CDNA; the cost of the item-end stall has not been measured on its own.)
             const int younger = issued - consumed - 1;
             if (kPnDepth >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
             else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");

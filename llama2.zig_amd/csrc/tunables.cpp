@@ -27,6 +27,7 @@ Tunables read_env()
     env_int("L2Z_ATTN_SHORT_POS", &t.attn_short_pos);
     env_int("L2Z_ATTN_SPLIT_WIDE_POS", &t.attn_split_wide_pos);
     env_int("L2Z_FUSE_SMALL", &t.fuse_small);
+    env_int("L2Z_ATTN_POS_ARG", &t.attn_pos_arg);
     env_int("L2Z_SCHEME_B", &t.scheme_b);
     env_int("L2Z_NO_GRAPH", &t.no_graph);
     env_int("L2Z_COMM_GRAPH", &t.comm_graph);
@@ -96,7 +97,7 @@ bool tunables_set(const char *name, long long v)
         {"L2Z_MAX_BLOCKS_PER_CU", &t.max_blocks_per_cu}, {"L2Z_GRID_CAP", &t.grid_cap},
         {"L2Z_ATTN_BLOCK", &t.attn_block}, {"L2Z_ATTN_SPLIT", &t.attn_split},
         {"L2Z_ATTN_SPLIT_POS", &t.attn_split_pos}, {"L2Z_ATTN_SHORT_POS", &t.attn_short_pos}, {"L2Z_ATTN_SPLIT_WIDE_POS", &t.attn_split_wide_pos},
-        {"L2Z_FUSE_SMALL", &t.fuse_small}, {"L2Z_NO_GRAPH", &t.no_graph},
+        {"L2Z_FUSE_SMALL", &t.fuse_small}, {"L2Z_ATTN_POS_ARG", &t.attn_pos_arg}, {"L2Z_NO_GRAPH", &t.no_graph},
         
         {"L2Z_SCHEME_B", &t.scheme_b},
         {"L2Z_COMM_GRAPH", &t.comm_graph}, {"L2Z_COMM_RCCL", &t.prefer_rccl},

@@ -23,6 +23,7 @@ struct Tunables {
     int attn_split_wide_pos = -1;  // L2Z_ATTN_SPLIT_WIDE_POS  first position at which the split form runs 1024 threads per block (256 below; default 1024)
     int attn_short_pos = -1;   // L2Z_ATTN_SHORT_POS  positions below this take the 256-thread one-block-per-head kernel with the
                                //                     speculative first round whatever seq_len is (default: by head size, 0: never)
+    int attn_pos_arg = 0;      // L2Z_ATTN_POS_ARG    experiment (l2z_time_kind only): the split kernel gets pos by value, not from device memory
     int fuse_small = 1;        // L2Z_FUSE_SMALL      0: small models keep separate qkv / attention launches
     // --- graphs / transport (runstate.cpp, comm.cpp, forward.cpp) ---
     int no_graph = 0;          // L2Z_NO_GRAPH        1: launch eagerly

@@ -277,10 +277,10 @@ def test_bench_legs_on_one_gpu(gpu, tmp_path):
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(HERE)
-    env = dict(os.environ, L2Z_BENCH_LEG_TIMEOUT_S="200", L2Z_P2P_TIMEOUT_S="20")
+    env = dict(os.environ, L2Z_BENCH_LEG_TIMEOUT_S="200", L2Z_P2P_TIMEOUT_S="20", L2Z_BENCH_NO_SHARDED_PREFILL="1")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-                        "--gpus", "2", "--steps", "48", "--warmup", "1", "--workload", "stories110M", "--no-extra"],
+                        "--gpus", "2", "--steps", "48", "--warmup", "1", "--workload", "stories110M"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
     assert p.returncode == 0 and len(lines) == 1, p.stdout.decode()[-3000:] + p.stderr.decode()[-3000:]
@@ -294,6 +294,16 @@ def test_bench_legs_on_one_gpu(gpu, tmp_path):
     assert "p2p-gather" in ok and "p2p-consume" in ok, legs
     for t in ok:
         assert legs[t]["ranks_agree"] and legs[t]["steps"] == 48 and legs[t]["tokens_per_s"] > 0
+    # round 6: every peer-write leg carries the cross-device diagnostics measured in its own run (here both ranks sit on
+    # one GPU: the numbers are the chip's own fine-grained memory, and say so) and the predicted-vs-measured row
+    for t in ("p2p-gather", "p2p-consume", "p2p-allreduce"):
+        if t not in ok:
+            continue
+        cd, pm = legs[t]["cross_device"], legs[t]["predicted_vs_measured"]
+        assert 0.0 < cd["ll_word_round_trip_us"]["1"] < 1000.0 and 0.0 < cd["peer_copy_16KB_us"]["1"] < 10000.0, cd
+        assert cd["devices"] == [0, 0] and "ONE GPU" in cd["note"]
+        assert pm["structure"] == t and pm["tokens_per_s_free_handovers"] > 0 and pm["measured_over_predicted"] > 0, pm
+        assert legs[t]["handover_latency_floor_ms_per_token"] > 0
     assert out["comm"]["transport"] == max([t for t in ok if legs[t]["scheme"] == "A"], key=lambda t: legs[t]["tokens_per_s"])
     assert out["value"] == legs[out["comm"]["transport"]]["tokens_per_s"] and out["n_gpus"] == 2
     if not legs["rccl"]["ok"]:
