@@ -229,6 +229,7 @@ struct SplitKWs {
     int cnt_ints;
 };
 constexpr int kSplitKMaxTokens = 256;  // longest chunk the split-K family takes
+constexpr int kPanelWsRows = 6 * kSplitKMaxTokens;  // rows of the widest launch the partial-product workspace holds (panel kernel: ranges x 16 tms)
 // K ranges per output tile for a [P, K] x [n_whole, K]^T product (1: the unsplit family).  Part of the
 // arithmetic, so a function of the chunk length and the WHOLE model's matrix only -- never of a rank's share.
 int prefill_split_k(long long n_whole, int P, int K, bool pair);

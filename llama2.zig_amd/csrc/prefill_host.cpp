@@ -65,7 +65,7 @@ int prefill_alloc(l2z_runstate *s, int need)
         // the widest launch of a layer (q | k | v, or W1 | W3 side by side), one arrival counter per output tile
         const Shard &sh = s->sh;
         const size_t widest_launch = std::max((size_t)sh.dim_loc + 2 * (size_t)sh.kvd_loc, 2 * (size_t)sh.hid_loc) + 128;
-        const size_t floats = (size_t)kSplitKMaxTokens * widest_launch * 4;
+        const size_t floats = (size_t)kPanelWsRows * widest_launch;  // (the split-K family needs 4 kSplitKMaxTokens rows of it)
         const int n_cnt = 1 << 16;
         hipError_t e = hipMalloc((void **)&s->pf_sk.part, floats * 4);
         if (e == hipSuccess) e = hipMalloc((void **)&s->pf_sk.cnt, (size_t)n_cnt * 4);

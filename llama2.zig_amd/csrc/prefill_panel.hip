@@ -35,7 +35,7 @@ constexpr int kPnStage = 128;                 // k per ring stage, one / two tok
 constexpr int kPnRange = 512;                 // k per range, chunks of <= 32 tokens: four stages (33 ... 64 tokens: 256)
 // longest chunk that takes the kernel: 33 ... 64 tokens run four token tiles against ranges of 256 (MFMA-bound there: the
 // tile GEMM's split-K family took 12.5 ms for 40 ... 64 tokens at the 7B shape, this 10.8 ... 11.2)
-constexpr int kPanelDefaultMax = 64;
+constexpr int kPanelDefaultMax = 96;   // round 6: five and six token tiles (65 ... 96 tokens; the tile GEMM took 15.0 ... 17.4 ms there, 7B)
 // ... and the shortest: up to 16 tokens the short-prompt GEMMs of prefill_skinny.hip are ahead -- their products need no
 // second launch (7B shape, whole prefill of 8 / 16 / 24 / 32 tokens: 5.31 / 5.65 / 8.76 / 8.78 ms there, 6.02 / 6.16 /
 // 6.92 / 6.98 here; profiles/r05b_prefill_panel_ab.txt)
@@ -127,14 +127,18 @@ __global__ __launch_bounds__(64 * NW) void prefill_panel(const PanelArgs a)
     // ---- the panel: range r of X, all 16 TMS token rows (tokens past P: the last token; never stored) ----
     auto load_panel = [&](int r) {
         const int klen = pn_range_stages<KR, SK>(a.K, r) * SK;
-        constexpr int HPR = KR / 256;                           // wave-wide loads (256 floats) per token row
-        for (int t = wave; t < 16 * TMS * HPR; t += NW) {       // wave-wide load t: piece h of token row t / HPR
-            const int tok = t / HPR, h = t % HPR;
-            const int logical = (64 * h + lane) ^ (tok & kPnSwz);
+        constexpr int SPR = KR / 4;                             // float4 slots per token row
+        static_assert((16 * TMS * SPR) % 64 == 0, "whole wave-wide loads");
+        // wave-wide load t fills float4 slots 64 t .. 64 t + 63 of the panel taken as one flat array (a token row is SPR
+        // slots: a load may straddle two rows when KR is not a multiple of 256); lane -> (token row, physical slot)
+        for (int t = wave; t < 16 * TMS * SPR / 64; t += NW) {
+            const int flat = 64 * t + lane;
+            const int tok = flat / SPR, slot = flat - tok * SPR;
+            const int logical = slot ^ (tok & kPnSwz);          // (stays inside the row: SPR % 16 == 0)
             int kk = 4 * logical;
             kk = kk < klen ? kk : klen - 4;                     // (a short last range: the piece past its end is never read)
             const float *src = a.x + (size_t)(tok < a.P ? tok : a.P - 1) * (size_t)a.ldx + (size_t)r * KR + kk;
-            lds_dma16(src, panel + tok * KR + 256 * h);
+            lds_dma16(src, panel + 256 * t);
         }
     };
 
@@ -323,7 +327,15 @@ __global__ __launch_bounds__(256) void panel_reduce(const PanelReduceArgs a)
 int prefill_panel_max_tokens()
 {
     const int m = tunables().pf_panel_max;
-    return m < 0 ? kPanelDefaultMax : (m > 64 ? 64 : m);
+    return m < 0 ? kPanelDefaultMax : (m > 96 ? 96 : m);
+}
+
+// k per range for a chunk of tms token tiles -- part of the arithmetic (the ranges are added in range order): a function
+// of the chunk's length class only
+static int panel_range(int tms)
+{
+    if (tunables().pf_panel_form == 9 && tms <= 4) return tms >= 3 ? 256 : kPnRange;   // round 5's
+    return tms <= 3 ? kPnRange : 256;
 }
 
 // Whether a [P, n_whole] x K product of the WHOLE model takes the panel kernel (a function of the model and the chunk
@@ -336,11 +348,11 @@ bool prefill_panel_shape(long long n_whole, int P, int K, long long widest_whole
     if (P < p_min || P < 1 || P > prefill_panel_max_tokens() || K % kPnStage != 0 || K < kPnRange) return false;
     if (n_whole * (long long)K * 4 <= ((long long)16 << 20)) return false;  // cache-resident matrices keep the short-prompt forms
     // the partial products of the WHOLE model's launch must fit the workspace an unsharded runstate allocates
-    // (prefill_host.cpp prefill_alloc: 4 * kSplitKMaxTokens rows of its widest launch) -- decided on the whole model, so
+    // (prefill_host.cpp prefill_alloc: kPanelWsRows rows of its widest launch) -- decided on the whole model, so
     // that a shard, whose share always fits then, never takes a kernel the unsharded pass could not
-    const int tms = (P + 15) / 16, kr = tms >= 3 ? 256 : kPnRange;
+    const int tms = (P + 15) / 16, kr = panel_range(tms);
     const long long n_ranges = (K + kr - 1) / kr;
-    return n_ranges * 16 * tms * n_whole <= 4LL * kSplitKMaxTokens * widest_whole;
+    return n_ranges * 16 * tms * n_whole <= (long long)kPanelWsRows * widest_whole;
 }
 
 hipError_t launch_prefill_panel(const PanelProduct &p, int n_cus, const SplitKWs *ws, hipStream_t st)
@@ -349,11 +361,12 @@ hipError_t launch_prefill_panel(const PanelProduct &p, int n_cus, const SplitKWs
     if ((p.rows0 % 16) || (p.rows1 % 16) || (p.rows2 % 16) || N < 16 || (p.ldx % 4) || p.K % kPnStage != 0) return hipErrorNotSupported;
     if (((uintptr_t)p.x & 15) || ((uintptr_t)p.w0 & 15) || ((uintptr_t)p.w1 & 15) || ((uintptr_t)p.w2 & 15)) return hipErrorNotSupported;
     if (ws == nullptr || ws->part == nullptr) return hipErrorNotSupported;
-    const int tms = (p.P + 15) / 16;   // token tiles: 1, 2 (ranges of 512), 3, 4 (ranges of 256)
+    const int tms = (p.P + 15) / 16;   // token tiles of 16: 1 ... 6
     // (four ring buffers per wave -- for two token tiles against ranges of 256 -- measured slower: 20 / 32 tokens 6.72 /
     // 6.82 ms with three, 7.55 / 7.66 with four; profiles/r05c_prefill_panel_ab.txt)
-    const int kr = tms >= 3 ? 256 : kPnRange;
-    const int depth = 3;
+    const int kr = panel_range(tms);
+    const bool r5 = tunables().pf_panel_form == 9 && tms <= 4;   // round 5's forms (A/B): ranges of 256, three buffers
+    const int depth = tms <= 2 || tms == 4 || r5 ? 3 : 2;
     const int n_ranges = (p.K + kr - 1) / kr;
     if ((size_t)n_ranges * (size_t)(16 * tms) * (size_t)N > ws->part_floats) return hipErrorNotSupported;
     PanelArgs a = {};
@@ -367,9 +380,26 @@ hipError_t launch_prefill_panel(const PanelProduct &p, int n_cus, const SplitKWs
     a.n_groups = (N + 16 * nw - 1) / (16 * nw);
     a.n_items = n_ranges * a.n_groups;
     const size_t lds = (size_t)(16 * tms * kr + nw * depth * 16 * sk) * sizeof(float);
-    const void *fn = tms == 1 ? (const void *)prefill_panel<1, kPnRange, 3, 4, kPnStage>
-                   : tms == 2 ? (const void *)prefill_panel<2, kPnRange, 3, 4, kPnStage>
-                   : tms == 3 ? (const void *)prefill_panel<3, 256, 3, 8, 64> : (const void *)prefill_panel<4, 256, 3, 8, 64>;
+    // Forms (LDS = panel + rings, one block per CU of 160 KB):
+    //   1, 2 tiles   [32 | 64 KB panel of 512 k] + 4 waves x 3 x 8 KB   the W stream is the bound
+    //   3 tiles      [96 KB of 512 k]  + 8 waves x 2 x 4 KB              round 6: half the partial products of round 5's ranges
+    //                                                                    of 256 (40 / 48 tokens 8.51 / 8.75 -> 8.06 / 8.27 ms)
+    //   4 tiles      [64 KB of 256 k]  + 8 x 3 x 4 KB                    (ranges of 384 with two buffers -- 96 + 64 KB, 31 % fewer
+    //                                                                    partials -- measured SLOWER: 56 / 64 tokens 10.40 / 10.56 ->
+    //                                                                    10.99 / 11.11 ms; ranges of 512 on four waves 11.10)
+    //   5, 6 tiles   [80 | 96 KB of 256 k] + 8 x 2 x 4 KB                round 6: 65 ... 96 tokens (72 / 80 / 88 / 96 tokens 14.7 /
+    //                                                                    14.8 / 17.7 / 17.8 -> 12.4 / 12.5 / 14.4 / 14.6 ms;
+    //                                                                    profiles/r06_panel_forms.txt)
+    const void *fn = nullptr;
+    switch (tms) {
+    case 1: fn = (const void *)prefill_panel<1, kPnRange, 3, 4, kPnStage>; break;
+    case 2: fn = (const void *)prefill_panel<2, kPnRange, 3, 4, kPnStage>; break;
+    case 3: fn = r5 ? (const void *)prefill_panel<3, 256, 3, 8, 64> : (const void *)prefill_panel<3, 512, 2, 8, 64>; break;
+    case 4: fn = (const void *)prefill_panel<4, 256, 3, 8, 64>; break;
+    case 5: fn = (const void *)prefill_panel<5, 256, 2, 8, 64>; break;
+    case 6: fn = (const void *)prefill_panel<6, 256, 2, 8, 64>; break;
+    default: return hipErrorNotSupported;
+    }
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
         (void)hipGetLastError();

@@ -51,6 +51,7 @@ Tunables read_env()
     env_int("L2Z_PF_SPLITK", &t.pf_splitk);
     env_int("L2Z_PF_PANEL", &t.pf_panel);
     env_int("L2Z_PF_PANEL_MAX", &t.pf_panel_max);
+    env_int("L2Z_PF_PANEL_FORM", &t.pf_panel_form);
     env_int("L2Z_PF_PANEL_MIN", &t.pf_panel_min);
     env_int("L2Z_PF_KGS", &t.pf_kgs);
     env_int("L2Z_PF_DMA", &t.pf_dma);
@@ -107,7 +108,7 @@ bool tunables_set(const char *name, long long v)
         {"L2Z_PF_SKINNY_FORM", &t.pf_skinny_form}, {"L2Z_PF_TILE", &t.pf_tile},
         {"L2Z_PF_SKINNY_MAX", &t.pf_skinny_max}, {"L2Z_PF_SKINNY_SPREAD", &t.pf_skinny_spread}, {"L2Z_PF_SKINNY_TMS", &t.pf_skinny_tms},
         {"L2Z_PF_ATTN", &t.pf_attn}, {"L2Z_PF_FUSE", &t.pf_fuse}, {"L2Z_PF_DMA", &t.pf_dma}, {"L2Z_PF_ORDER", &t.pf_order},
-        {"L2Z_PF_SPLITK", &t.pf_splitk}, {"L2Z_PF_PANEL", &t.pf_panel}, {"L2Z_PF_PANEL_MAX", &t.pf_panel_max}, {"L2Z_PF_PANEL_MIN", &t.pf_panel_min}, {"L2Z_PF_KGS", &t.pf_kgs}};
+        {"L2Z_PF_SPLITK", &t.pf_splitk}, {"L2Z_PF_PANEL", &t.pf_panel}, {"L2Z_PF_PANEL_MAX", &t.pf_panel_max}, {"L2Z_PF_PANEL_FORM", &t.pf_panel_form}, {"L2Z_PF_PANEL_MIN", &t.pf_panel_min}, {"L2Z_PF_KGS", &t.pf_kgs}};
     for (auto &e : ints)
         if (strcmp(e.n, name) == 0) {
             *e.p = (int)v;

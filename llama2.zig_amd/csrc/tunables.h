@@ -63,9 +63,10 @@ struct Tunables {
     int pf_fuse = 1;           // L2Z_PF_FUSE         0: separate Q / K / V and W1 / W3 GEMMs
     int pf_kgs = -1;           // L2Z_PF_KGS          the tile GEMM's two k-groups on two blocks (same bits, twice the blocks): -1 by grid fill,
                                //                     0 never, 10 + f: always, on tile form f (0 128x64, 1 64x64, 2 32x64, 4 128x128)
-    int pf_panel = 1;          // L2Z_PF_PANEL        0: chunks of 17 ... 64 tokens keep the short-prompt / tile GEMMs instead of the
+    int pf_panel = 1;          // L2Z_PF_PANEL        0: chunks of 17 ... 96 tokens keep the short-prompt / tile GEMMs instead of the
                                //                     K-range panel kernel (prefill_panel.hip; changes rounding: the ranges are part of the arithmetic)
-    int pf_panel_max = -1;     // L2Z_PF_PANEL_MAX    longest chunk that takes the panel kernel (default and maximum 64 tokens)
+    int pf_panel_form = 0;     // L2Z_PF_PANEL_FORM   9: round 5's forms at three / four token tiles (ranges of 256, three ring buffers; changes rounding), for A/B
+    int pf_panel_max = -1;     // L2Z_PF_PANEL_MAX    longest chunk that takes the panel kernel (default and maximum 96 tokens)
     int pf_panel_min = -1;     // L2Z_PF_PANEL_MIN    shortest chunk that takes it (default 17: up to 16 tokens the short-prompt GEMMs are ahead)
     int pf_splitk = -1;        // L2Z_PF_SPLITK       K ranges per output tile of the tile GEMM for chunks of <= 256 tokens: -1 by shape,
                                //                     1 none, 2 / 4 forced (changes rounding: the range partials are added in range order)

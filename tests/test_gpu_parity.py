@@ -730,6 +730,34 @@ def test_sharded_prefill_emulated_ranks_bit_identical(gpu, ck, world, name, kw, 
         c.close()
 
 
+def test_shard_that_cannot_take_the_unsharded_kernel_is_refused_not_rerouted(gpu, ck, options):
+    """which prefill kernel a product takes is decided from the WHOLE model (so a shard sums in the order the
+    unsharded pass sums in), but the K-range panel kernel also needs a multiple of 16 rows per matrix ON THE RANK.  Here
+    W1 | W3 of the whole model (2 x 2056 rows x 1152: 18.9 MB, streams from HBM) takes the panel kernel at 20 tokens and
+    a rank of 2 holds 2 x 1028 = 2056 rows, 2056 % 16 = 8: until round 5 that rank silently fell back to another kernel
+    (another summation order).  Now the group keeps off the batched path: l2z_emu_prefill refuses, and the world that
+    does split into multiples of 16 (hidden_dim 2048) still agrees bit for bit."""
+    options(L2Z_FUSE_SMALL=0)
+    toks = [1] + np.random.default_rng(8).integers(2, 500, 19).tolist()
+    for hidden, ok in ((2056, False), (2048, True)):
+        cfg = ck.Config(dim=1152, hidden_dim=hidden, n_layers=1, n_heads=18, n_kv_heads=18, vocab_size=512, seq_len=64)
+        w0, s0 = gpu.Weights(cfg, None, True, seed=5), gpu.RunState(cfg)
+        comms = [gpu.Comm(r, 2, None, 0, emulated=True) for r in range(2)]
+        ws = [gpu.Weights(cfg, None, True, seed=5, comm=c) for c in comms]
+        ss = [gpu.RunState(cfg, comm=c) for c in comms]
+        s0.prefill(toks, 0, w0)   # the unsharded pass takes the panel kernel either way (4112 and 4096 rows: % 16 == 0)
+        if ok:
+            gpu.emu_prefill(ss, ws, toks, 0)
+            assert all(np.array_equal(s.logits(), s0.logits()) for s in ss)
+        else:
+            with pytest.raises(gpu.L2ZError, match="multiples of 16"):
+                gpu.emu_prefill(ss, ws, toks, 0)
+        for o in ss + ws + [s0, w0]:
+            o.close()
+        for c in comms:
+            c.close()
+
+
 @pytest.mark.parametrize("nch", [2, 3, 16])
 def test_split_attention_matches_oracle(gpu, ck, orc, nch, options):
     """The flash-decoding attention (nch blocks per head, the last arriver combines) is forced on
