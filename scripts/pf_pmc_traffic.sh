@@ -15,10 +15,11 @@ n = int(sys.argv[1])
 dim, hid = 4096, 11008
 names = ["q|k|v", "Wo", "W1|W3", "W2"]
 wbytes = [4 * 3 * dim * dim, 4 * dim * dim, 4 * 2 * hid * dim, 4 * dim * hid]
-tms = (n + 15) // 16; kr = 256 if tms >= 3 else 512
+tms = (n + 15) // 16; kr = 512 if tms <= 3 else 256      # round 6: three tiles against ranges of 512
 ranges = [-(-dim // kr), -(-dim // kr), -(-dim // kr), -(-hid // kr)]
 rows_n = [3 * dim, dim, 2 * hid, dim]
 part = [4 * r * 16 * tms * N for r, N in zip(ranges, rows_n)]     # partial products written by the panel launch, read by the reduce
+xbytes = [4 * 16 * tms * k for k in (dim, dim, dim, hid)]         # the activation matrix [16 tms, K] the product multiplies
 acc = {c: collections.defaultdict(float) for c in ("FETCH_SIZE", "WRITE_SIZE")}; cnt = collections.Counter()
 for c in acc:
     f = glob.glob(f"/tmp/pfpmc_{c}/**/*counter_collection.csv", recursive=True)
@@ -35,11 +36,13 @@ for c in acc:
 print(f"# PMC HBM traffic per launch, panel prefill of {n} tokens, llama2-7b shape\n")
 print("FETCH_SIZE (KB) x 1024 x 2 (gfx950: half of a wide coalesced stream is reported, MI355X_MICROARCH.md HBM section) + WRITE_SIZE (KB) x 1024; "
       "separate --pmc passes, kernel-trace only (scripts/pf_pmc_traffic.sh).  W = the product's weight bytes; partials = ranges x 16 TMS x N x 4 bytes.\n")
-print("| launch | product | launches | read bytes | written bytes | W bytes | partial bytes | read / W | written / partials |\n|---|---|---:|---:|---:|---:|---:|---:|---:|")
+print("X = the activation matrix [16 tms, K]: every block keeps ITS range of it in LDS, so each of the 8 XCDs' L2s fetches it once -- "
+      "(read - W) / X is how many times X came in (<= 8: nothing else is read twice).\n")
+print("| launch | product | launches | read bytes | written bytes | W bytes | X bytes | partial bytes | read / W | (read - W) / X | written / partials |\n|---|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
 for kind in ("panel", "reduce"):
     for p in range(4):
         key = (kind, p); c = max(cnt[key], 1)
         rd = acc["FETCH_SIZE"][key] / c * 1024 * 2; wr = acc["WRITE_SIZE"][key] / c * 1024
-        if kind == "panel": print(f"| prefill_panel | {names[p]} | {cnt[key]} | {rd:.0f} | {wr:.0f} | {wbytes[p]} | {part[p]} | {rd / wbytes[p]:.3f} | {wr / part[p]:.3f} |")
-        else: print(f"| panel_reduce | {names[p]} | {cnt[key]} | {rd:.0f} | {wr:.0f} | - | {part[p]} | (read / partials {rd / part[p]:.3f}) | - |")
+        if kind == "panel": print(f"| prefill_panel | {names[p]} | {cnt[key]} | {rd:.0f} | {wr:.0f} | {wbytes[p]} | {xbytes[p]} | {part[p]} | {rd / wbytes[p]:.3f} | {(rd - wbytes[p]) / xbytes[p]:.2f} | {wr / part[p]:.3f} |")
+        else: print(f"| panel_reduce | {names[p]} | {cnt[key]} | {rd:.0f} | {wr:.0f} | - | - | {part[p]} | (read / partials {rd / part[p]:.3f}) | - | - |")
 PY

@@ -68,29 +68,6 @@ def test_7b_device_loop_equals_host_loop_and_is_deterministic(gpu, model7b):
     assert np.array_equal(s.logits(), lg1)
 
 
-def test_7b_decode_kernels_stay_at_their_perf_floor(gpu, model7b):
-    """Perf gate (round 5, after round 4's opt-in forms taxed the default chain by 1.3 % unnoticed): every kind of launch of
-    the 7B decode pass, its 32 launches back to back between one event pair (l2z_time_kind = rocprofv3's kernel durations),
-    against the durations committed in profiles/perf_floor.json.  Best of three passes: a kernel that got slower is slower
-    every time, a busy chip is not.  Two bars:
-      * every kind within `slack` (3 %) of its floor AFTER dividing out the process's common factor -- the median over
-        the kinds of measured / floor: some processes run every launch ~3 % slower (where the 27-GB allocation lands:
-        profiles/r03_process_variance.txt), which is not a kernel's doing -- what round 4 did to wo (+12 % beside an
-        unchanged ffn13) fails this at once;
-      * that common factor itself within `common_slack` (6 %): everything getting slower together is caught too."""
-    import json, os
-    floor = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "perf_floor.json")))["llama2-7b"]
-    cfg, w, s = model7b
-    got = {kind: min(s.time_kind(kind, floor["pos"], w, reps=4)[0] for _ in range(3)) * 1e3 for kind in floor["us_per_launch"]}
-    ratio = {k: got[k] / floor["us_per_launch"][k] for k in got}
-    common = float(np.median([ratio[k] for k in ratio if k != "attn"]))  # (the 5-us attention launch is the noisiest)
-    print("7B decode, us per launch back to back:", {k: round(v, 2) for k, v in got.items()}, f"common factor {common:.3f}")
-    bad = [f"{k}: {got[k]:.2f} us per launch = {ratio[k] / common:.3f} x its floor {floor['us_per_launch'][k]} after the common factor {common:.3f}"
-           for k in got if ratio[k] / common > 1.0 + floor.get("slack_by_kind", {}).get(k, floor["slack"])]
-    assert not bad, "; ".join(bad)
-    assert common <= 1.0 + floor["common_slack"], f"every kind of launch is {common:.3f} x its floor"
-
-
 def test_7b_classifier_rows_vs_oracle(gpu, ck, orc, model7b):
     """logits[r] = wcls[r] . rmsnorm(x_final): re-derive sampled rows on the CPU from the
     device's own pre-classifier activations and the regenerated weight rows."""
