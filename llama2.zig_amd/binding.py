@@ -1,4 +1,5 @@
-"""ctypes binding over libllama2_hip.so (include/llama2_hip.h).
+"""ctypes binding over libllama2_hip_test.so (include/llama2_hip.h + include/llama2_hip_test.h; the product library
+libllama2_hip.so exports the first header only).
 
 This is what tests/ and bench.py call: every compute path goes through the
 C ABI into the hand-written HIP kernels.  There is no Python or CPU fallback
@@ -14,7 +15,10 @@ import re
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("L2Z_LIB") or os.path.join(_HERE, "libllama2_hip.so")  # L2Z_LIB: A/B builds
+# The product library (exports include/llama2_hip.h only: what a host links) and the library this binding loads: the same
+# objects with the test / measurement entry points of include/llama2_hip_test.h exported as well (csrc/Makefile).
+PRODUCT_LIB_PATH = os.path.join(_HERE, "libllama2_hip.so")
+LIB_PATH = os.environ.get("L2Z_LIB") or os.path.join(_HERE, "libllama2_hip_test.so")  # L2Z_LIB: A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "llama2_hip.h")
 TEST_HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "llama2_hip_test.h")
 

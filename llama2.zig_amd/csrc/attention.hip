@@ -348,7 +348,10 @@ __global__ __launch_bounds__(NT) void attention_split_kernel(const AttnArgs a, i
     const int step = ge.G * kFastUB;
     const v4f zero = {0.f, 0.f, 0.f, 0.f};
 
-    const int T = a.pos_plus1 ? a.pos_plus1 : *a.pos_ptr + 1;   // :367
+    // (pos as a kernel ARGUMENT instead of this dependent read -- what a per-replay hipGraphExecKernelNodeSetParams would
+    // buy -- measured 19.68 -> 19.48 us per layer at pos 2047, 14.69 -> 14.54 at 1023: 0.13 % of a token; not built.
+    // profiles/r06_attn_pos_arg.txt)
+    const int T = *a.pos_ptr + 1;                      // :367
     // chunk c owns the CONTIGUOUS timesteps [c * per, c * per + Tc): in the head-major cache that is one
     // run of Tc * head_size floats of K and one of V -- a linear stream per block (the (seq_len, kv_dim)
     // order gave 512-byte pieces 16 KB apart at the 7B shape).  per is even: a wave's two rows stay
@@ -544,8 +547,6 @@ size_t attention_lds_bytes(int head_size, int seq_len, bool vec)
 // every rank of a shard group takes the same form at the same position.
 int attention_short_pos(int head_size, int seq_len)
 {
-    const int forced = tunables().attn_short_pos;
-    if (forced >= 0) return forced < seq_len ? forced : seq_len;
     if (seq_len <= 512 || (head_size % 4) != 0 || head_size > 256) return 0;  // that form at every position anyway
     const AttnGeom ge = attn_geom(head_size, true, kBlock);
     const int two_rounds = 2 * ge.G * kFastUB;
@@ -574,8 +575,6 @@ size_t attention_split_part_floats(int n_heads_local, int head_size, int nch)
 // a quarter of the waves to launch and to combine.  A function of the model and the position only.
 int attention_split_wide_pos(int seq_len)
 {
-    const int forced = tunables().attn_split_wide_pos;
-    if (forced >= 0) return forced;
     return seq_len > 512 ? 1024 : seq_len;  // small contexts: 256 threads throughout (as before)
 }
 
@@ -584,8 +583,7 @@ hipError_t launch_attention_split(const AttnArgs &a_in, int n_heads_local, int n
                                   int *arrivals, hipStream_t st, bool small)
 {
     const AttnArgs &a = a_in;
-    const int forced = tunables().attn_block;
-    const int nt = forced ? forced : (small ? kBlock : kAttnFastBlock);
+    const int nt = small ? kBlock : kAttnFastBlock;
     const AttnGeom ge = attn_geom(a.head_size, true, nt);
     const int max_local = attn_split_per(a.seq_len, nch);  // the kernel's own bound on a chunk's length
     const size_t lds = (size_t)(2 * ((max_local + 3) & ~3) + ge.G * a.head_size) * sizeof(float);
@@ -624,9 +622,7 @@ hipError_t launch_attention(const AttnArgs &a_in, int n_heads_local, hipStream_t
                      aligned16(a.kcache) && aligned16(a.vcache);
     const size_t lds = attention_lds_bytes(a.head_size, a.seq_len, vec);
     if (vec && a.head_size <= 256 && form != 4) {
-        // L2Z_ATTN_BLOCK, when set, overrides the form the caller picked by position as well
-        const int tb = tunables().attn_block;
-        const int forced = tb ? tb : form == 1 ? kBlock : form == 2 ? kAttnFastBlock : 0;
+        const int forced = form == 1 ? kBlock : form == 2 ? kAttnFastBlock : 0;
         const int nt = forced ? forced : (a.seq_len > 512 ? kAttnFastBlock : kBlock);
         const AttnGeom gf = attn_geom(a.head_size, true, nt);
         const size_t lds_fast = (size_t)(2 * ((a.seq_len + 3) & ~3) + gf.G * a.head_size) * sizeof(float);

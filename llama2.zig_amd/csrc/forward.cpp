@@ -71,7 +71,6 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
     const bool split = variant == ATTN_SPLIT || variant == ATTN_SPLIT_S;
     const l2z_config &c = s->cfg;
     const Shard &sh = s->sh;
-    const Tunables &tn = tunables();
     hipStream_t st = s->stream;
     const l2z_comm *lc = s->comm;
     const size_t dim = c.dim, hid = c.hidden_dim;
@@ -82,13 +81,13 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
     auto kind = [&](int k) { return only_kind < 0 || only_kind == k; };
     const bool p2p = s->d_push != nullptr && only_stage < 0 && sh.world > 1;
     const bool consume = p2p && s->ll_consume;
-    // Producers push their outputs as LL words straight into the peers' slots (the values travel
-    // while the launch still runs) where the CONSUMERS read the words (consumer-side form, persistent launches).
-    // (Where a launch collects the vector anyway -- gather launches, scheme B's reduce launches -- that launch sends too:
-    // a store to a peer's arena from a mat-vec's epilogue holds up the wave's loads behind it (they return in order), which
-    // costs the launch more than the earlier departure saves: one rank of 8 alone with free hand-overs, profiles/
-    // r04_solo_rank.md: scheme B 580 -> 727 tok/s, gather launches 488 -> 649.  L2Z_P2P_PUSH=2 pushes there as well.)
-    const bool can_push = p2p && (consume ? tn.p2p_push != 0 : (tn.p2p_push >= 2 && prof == nullptr));
+    // Producers push their outputs as LL words straight into the peers' slots (the values travel while the launch still
+    // runs) only where the CONSUMERS read the words (consumer-side form).  Where a launch collects the vector anyway --
+    // gather launches, scheme B's reduce launches -- that launch sends too: a store to a peer's arena from a mat-vec's
+    // epilogue holds up the wave's loads behind it (they return in order), which costs the launch more than the earlier
+    // departure saves (one rank of 8 alone with free hand-overs, profiles/r04_solo_rank.md: scheme B 580 -> 727 tok/s,
+    // gather launches 488 -> 649; that form and its knob are gone since round 6).
+    const bool can_push = p2p && consume;
     const bool sb = sh.scheme_b;
     // greedy step of a shard group on the peer-write transport: the classifier leaves this rank's argmax candidates and
     // the hand-over launch exchanges one pair per rank instead of the logits gather + 32000-logit scan (main.zig:715-726
@@ -206,7 +205,6 @@ int enqueue_forward(l2z_runstate *s, const l2z_weights *w, bool with_step, Prof 
             a.pos_ptr = s->d_pos; a.head_size = sh.hs; a.kv_row = sh.hs; a.kv_head = kvh_stride;
             a.kv_mul = c.n_heads / c.n_kv_heads; a.seq_len = c.seq_len;
             a.tl_seq = s->tl_attn_seq++;
-            if (tn.attn_pos_arg && only_kind >= 0) a.pos_plus1 = s->time_pos + 1;
             if (!sb && can_push && attention_push_supported(a)) {
                 a.push = s->d_push + 0;
                 a.push_ctl = ctl;
@@ -606,7 +604,6 @@ extern "C" int l2z_time_kind(int kind, int pos, const l2z_config *config, l2z_ru
               "l2z_time_kind: unsharded runstates, emulated or solo ranks only (a connected shard would wait for its peers)");
     L2Z_CHECK(pos >= 0 && pos < config->seq_len, L2Z_ERR_STATE, "pos out of range");
     L2Z_HIP(hipSetDevice(s->device));
-    s->time_pos = pos;
     L2Z_HIP(launch_set_state(1, pos, s->d_token, s->d_pos, w->tok_emb, s->x, config->dim, s->stream));
     hipEvent_t e0, e1;
     L2Z_HIP(hipEventCreate(&e0));

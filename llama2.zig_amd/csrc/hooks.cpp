@@ -153,14 +153,14 @@ static std::vector<float> to_head_major(const float *src, int seq_len, int n_kv_
 
 // src/main.zig:361-389 for the P queries of a prompt chunk at positions pos0 .. pos0 + P - 1, through the
 // batched prefill's attention kernels (prefill_attention.hip).  form: 0 as l2z_prefill picks, 1 block per
-// (head, query), 2 tiled with the softmax in LDS, 3 flash form with one key part, 4 flash form with two.
+// (head, query), 2 tiled with the softmax in LDS, 3 flash form (head sizes 64 and 128).
 extern "C" int l2z_prefill_attention(int form, float *out, const float *q, const float *kcache, const float *vcache,
                                      int pos0, int n_queries, int n_heads, int n_kv_heads, int head_size, int seq_len)
 {
     L2Z_CHECK(out && q && kcache && vcache && n_heads > 0 && n_kv_heads > 0 && head_size > 0 && head_size % 4 == 0 &&
                   n_heads % n_kv_heads == 0 && n_queries > 0 && pos0 >= 0 && pos0 + n_queries <= seq_len,
               L2Z_ERR_INVALID, "l2z_prefill_attention: bad arguments");
-    L2Z_CHECK(form >= 0 && form <= 4, L2Z_ERR_INVALID, "l2z_prefill_attention: form %d", form);
+    L2Z_CHECK(form >= 0 && form <= 3, L2Z_ERR_INVALID, "l2z_prefill_attention: form %d", form);
     L2Z_CHECK(form < 3 || head_size == 64 || head_size == 128, L2Z_ERR_INVALID,
               "l2z_prefill_attention: the flash form takes head sizes 64 and 128");
     L2Z_TRY(ensure_device(current_device_for(nullptr)));
@@ -171,14 +171,9 @@ extern "C" int l2z_prefill_attention(int form, float *out, const float *q, const
     const std::vector<float> hk = to_head_major(kcache, seq_len, n_kv_heads, head_size),
                              hv = to_head_major(vcache, seq_len, n_kv_heads, head_size);
     L2Z_TRY(dq.up(q, n_queries * dim)); L2Z_TRY(dk.up(hk.data(), seq_len * kvd)); L2Z_TRY(dv.up(hv.data(), seq_len * kvd));
-    // the launcher reads L2Z_PF_ATTN and a block-count threshold: force the form through both
-    const int saved = tunables().pf_attn;
-    const int knob[5] = {saved, 0, 2, 3, 1};
-    tunables_set("L2Z_PF_ATTN", knob[form]);
     const hipError_t e = launch_prefill_attention(dq.p, (int)dim, dk.p, dv.p, dout.p, (int)dim, pos0, n_queries, n_heads,
                                                   head_size, head_size, (size_t)seq_len * head_size, n_heads / n_kv_heads,
-                                                  seq_len, nullptr, form >= 2 ? (1 << 20) : n_heads);
-    tunables_set("L2Z_PF_ATTN", saved);
+                                                  seq_len, nullptr, n_heads, form);
     L2Z_HIP(e);
     L2Z_HIP(hipDeviceSynchronize());
     L2Z_TRY(dout.down(out, n_queries * dim));

@@ -133,7 +133,6 @@ struct MatvecArgs {
     int push_gi;              // index of the gather the outputs belong to
     // x is a gathered vector that is read as LL words from this rank's landing slot (xin.slots != null)
     LLIn xin;
-    int tail_skip;            // row kernel, n > 4096: out-of-row steps of a row's last batch load nothing (set by the launcher)
 };
 
 // main.zig:361-389: scores, softmax, att.V for the local heads of one layer
@@ -152,7 +151,6 @@ struct AttnArgs {
     const int *push_ctl;
     int push_gi;
     int tl_seq;            // attention launch number since the runstate was made (measurement builds only: L2Z_TIMELINE)
-    int pos_plus1;         // != 0: the position + 1 by value (split kernel; experiment L2Z_ATTN_POS_ARG), 0: read *pos_ptr
 };
 
 
@@ -262,7 +260,8 @@ hipError_t launch_prefill_embed(float *x, const float *tok_emb, const int *token
 hipError_t launch_prefill_attention(const float *q, int ldq, const float *kcache, const float *vcache,
                                     float *out, int ldo, int pos0, int P, int n_heads, int head_size,
                                     int kv_row, size_t kv_head, int kv_mul, int seq_len, hipStream_t st,
-                                    int n_heads_model = 0);  // heads of the whole model when n_heads is a shard's
+                                    int n_heads_model = 0,   // heads of the whole model when n_heads is a shard's
+                                    int form = 0);           // tests: 1 block per (head, query), 2 tiled, 3 flash; 0 by shape
 // ---- prefill_panel.hip: chunks of <= 32 tokens of matrices that stream from HBM (K ranges with a resident X panel) ----
 enum PanelEpi { PANEL_STORE = 0, PANEL_RESID = 1, PANEL_SWIGLU = 2, PANEL_QKV = 3 };
 struct PanelProduct {

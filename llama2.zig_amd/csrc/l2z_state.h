@@ -131,7 +131,6 @@ struct l2z_runstate {
     bool logits_partial = false;
     bool fused_qkv_attn = false;  // small models: qkv + RoPE + KV write + attention in one launch
     int max_blocks = 0;
-    int time_pos = 0;              // l2z_time_kind's position (experiment L2Z_ATTN_POS_ARG)
     int tl_attn_seq = 0;           // attention launches enqueued so far (AttnArgs::tl_seq, measurement builds)
 };
 

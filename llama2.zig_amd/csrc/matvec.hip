@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kBlock) void matvec_row_kernel(const MatvecArgs a)
 #pragma unroll
         for (int k = 0; k < U; k++) {
             const bool in_row = wbase + kBlock * k < n4;  // wave-uniform
-            if (XC == 12 && a.tail_skip && !in_row) {
+            if (XC == 12 && !in_row) {
                 // rows that do not fill their last batch (n = 11008: 704 of 1024 float4): the out-of-row steps
                 // load NOTHING (their x is the zero padding) -- the re-reads of the row start were 11.6 % of
                 // W2's load instructions and, the nt lines long evicted, 2.7 % extra HBM traffic (PMC 1.027x)
@@ -508,7 +508,7 @@ hipError_t launch_matvec(const MatvecArgs &a_in, int pro, int epi, int max_block
     const int lpr = lpr_for(n4);
     if (epi == EPI_ARGMAX && (!vec || a.rows1 != 0 || a.rows2 != 0)) return hipErrorNotSupported;
     const Tunables &tn = tunables();
-    const bool use_row = vec && tn.row_kernel && n4 >= 1024 && (n4 % 64) == 0;
+    const bool use_row = vec && n4 >= 1024 && (n4 % 64) == 0;
     const bool ll = a.xin.slots != nullptr;
     if (ll && !vec) return hipErrorNotSupported;  // callers ask matvec_ll_supported() first
     MvLaunch k = mv_pick_pe(pro, epi, lpr, a.n > 4096, vec, ll);
@@ -544,7 +544,7 @@ hipError_t launch_matvec(const MatvecArgs &a_in, int pro, int epi, int max_block
     // The row kernel streams best with few blocks per CU in lock step (fewer concurrent DRAM
     // streams).  Measured at 7B, whole-token rate: 2 blocks/CU 219 tok/s, 1 -> 208, 3 -> 213,
     // 4-8 -> 208-211 (single launches shift against each other under the power cap, so the
-    // choice is made on the whole-token rate).  L2Z_ROW_BLOCKS overrides.
+    // choice is made on the whole-token rate).
     if (use_row && occ > tn.row_blocks) occ = tn.row_blocks;
     int resident = occ * n_cus;
     // several ranks sharing ONE GPU (tests): a launch must leave room for the peers' kernels it
@@ -569,7 +569,6 @@ hipError_t launch_matvec(const MatvecArgs &a_in, int pro, int epi, int max_block
     // only single-segment epilogues of the vector kernels push (wo, ffn13, ffn2, classifier)
     if (!vec || epi == EPI_ROPE || a.rows2 != 0 || (epi != EPI_SWIGLU && a.rows1 != 0)) a.push = nullptr;
     if (pushed) *pushed = a.push != nullptr;
-    a.tail_skip = tn.row_tail_skip;
     void *args[] = {&a};
     return hipLaunchKernel(k.fn, dim3(grid), dim3(kBlock), args, lds, st);
 }

@@ -450,31 +450,33 @@ hipError_t launch_prefill_embed(float *x, const float *tok_emb, const int *token
 
 hipError_t launch_prefill_attention(const float *q, int ldq, const float *kcache, const float *vcache,
                                     float *out, int ldo, int pos0, int P, int n_heads, int head_size,
-                                    int kv_dim, size_t kv_head, int kv_mul, int seq_len, hipStream_t st, int n_heads_model)
+                                    int kv_dim, size_t kv_head, int kv_mul, int seq_len, hipStream_t st, int n_heads_model,
+                                    int form)
 {
     // kv_dim here: floats between consecutive timesteps of one kv head (head-major cache: head_size)
-    // the two kernels round differently; a shard must take the one the unsharded pass takes
+    // the kernels round differently; a shard must take the one the unsharded pass takes
+    // form (the test hook l2z_prefill_attention): 0 by shape, 1 block per (head, query), 2 tiled, 3 flash
     if (n_heads_model <= 0) n_heads_model = n_heads;
-    const bool naive = tunables().pf_attn == 0;
+    const bool naive = form == 1;
     const size_t lds_t = (size_t)(3 * 64 * (head_size + 1) + 64 * 65 + 3 * 64) * sizeof(float);
     const int n_ct = (head_size + 31) / 32;  // O column tiles; 2 n_ct tiles over 4 waves
     // one block per (head, 64 queries): worth it once that fills half the CUs (7B: from 256 tokens);
     // below, and for models with few heads, the block-per-(head, query) kernel has more parallelism
-    const bool enough_blocks = n_heads_model * ((P + 63) / 64) >= 128;
+    const bool enough_blocks = form == 2 || n_heads_model * ((P + 63) / 64) >= 128;
     // the flash form is ahead of the block-per-(head, query) kernel from far fewer blocks (12 heads x 4 query
     // tiles, stories110M at 256 tokens: 22 -> 16 us)
     // ... but not for chunks of <= 32 tokens: 32 heads x one query tile of mostly masked rows is a 12.5 us latency
     // chain, the per-query blocks (heads x tokens of them) take ~8 (7B shape, 16-token prompt: 5.74 -> 5.60 ms,
     // 4 tokens 5.89 -> 5.73; profiles/r03_prefill_short_ab.txt)
-    const bool flash_blocks = n_heads_model * ((P + 63) / 64) >= 32 && P > 32;
-    if (!naive && flash_blocks && tunables().pf_attn != 2 && (head_size == 64 || head_size == 128) && (kv_dim % 4) == 0 &&
+    const bool flash_blocks = form == 3 || (n_heads_model * ((P + 63) / 64) >= 32 && P > 32);
+    if (!naive && form != 2 && flash_blocks && (head_size == 64 || head_size == 128) && (kv_dim % 4) == 0 &&
         (ldq % 4) == 0 && (ldo % 4) == 0 && (((uintptr_t)q | (uintptr_t)out | (uintptr_t)kcache | (uintptr_t)vcache) & 15) == 0) {
-        // flash form (L2Z_PF_ATTN=2 keeps the LDS-softmax tiled kernel below)
+        // flash form: head sizes 64 and 128 (other head sizes: the LDS-softmax tiled kernel below)
         const size_t lds_f = (size_t)2 * 2 * 64 * head_size * sizeof(float);  // two buffers of a K and a V tile
-        // two key parts per tile (8 waves: two per SIMD cover each other's latencies); L2Z_PF_ATTN=3: one
-        const bool two = tunables().pf_attn != 3;
-        const void *fn = head_size == 128 ? (two ? (const void *)prefill_attention_flash<8, 2> : (const void *)prefill_attention_flash<8, 1>)
-                                          : (two ? (const void *)prefill_attention_flash<4, 2> : (const void *)prefill_attention_flash<4, 1>);
+        // two key parts per tile (8 waves: two per SIMD cover each other's latencies; one part, 4 waves, measured
+        // slower at every length and removed in round 6)
+        constexpr bool two = true;
+        const void *fn = head_size == 128 ? (const void *)prefill_attention_flash<8, 2> : (const void *)prefill_attention_flash<4, 2>;
         if (lds_f > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
             if (e != hipSuccess) return e;

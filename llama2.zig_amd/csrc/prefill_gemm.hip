@@ -67,11 +67,11 @@ static TileForm choose_tile(int N, int P, bool pair)
 }
 
 // 1-D grid of the direct-to-LDS tile kernel for ntx feature tiles x nty token tiles (see the kernel's
-// block -> tile comment); L2Z_PF_ORDER=0 keeps the 2-D grid
+// block -> tile comment); grids of more than 64 token tiles keep the 2-D form
 static dim3 dma_grid(int ntx, int nty, GemmArgs *a)
 {
     const unsigned z = a->sk > 1 ? (unsigned)a->sk : 1u;  // split-K family: blockIdx.z = the block's K range
-    if (tunables().pf_order == 0 || nty > 64) {
+    if (nty > 64) {
         a->ntx = 0; a->nty = 0;
         return dim3(ntx, nty, z);
     }
@@ -612,7 +612,7 @@ hipError_t gemm_launch_t(const GemmArgs &a, hipStream_t st)
     dim3 grid((a.N + BNt - 1) / BNt, (a.P + BMt - 1) / BMt);
     if constexpr (BK == 64 && (BMt / 4) % (4 * KS) == 0 && (BNt / 4) % (4 * KS) == 0) {
         // direct-to-LDS operand loads: whole 64-float stages only, 16-byte aligned rows
-        if (tunables().pf_dma != 0 && a.K % 64 == 0 && a.ldx % 4 == 0) {
+        if (a.K % 64 == 0 && a.ldx % 4 == 0) {
             size_t lds2 = 2 * (size_t)(BMt + BNt) * 64 * sizeof(float);
             if (red > lds2) lds2 = red;
             const void *fn = (const void *)prefill_gemm_dma<EPI, TM, TN, KS, false>;
@@ -630,11 +630,11 @@ hipError_t gemm_launch_t(const GemmArgs &a, hipStream_t st)
 
 // the direct-to-LDS tile kernel with fewer waves per block -- 32 x 64 (1 x 2 waves per k-group) and
 // 32 x 32 (1 x 1) output tiles: same k split and order as the 2 x 2 forms (bit-identical results), more
-// blocks for grids that would leave CUs idle.  false: shape not taken (K % 64, alignment, L2Z_PF_DMA=0).
+// blocks for grids that would leave CUs idle.  false: shape not taken (K % 64, alignment).
 template <int EPI, int WM, int WN>
 bool gemm_launch_small(const GemmArgs &a, hipStream_t st, hipError_t *err)
 {
-    if (tunables().pf_dma == 0 || a.K % 64 != 0 || a.ldx % 4 != 0) return false;
+    if (a.K % 64 != 0 || a.ldx % 4 != 0) return false;
     constexpr int KS = 2, BMt = 32 * WM, BNt = 32 * WN;
     const size_t lds = 2 * (size_t)(BMt + BNt) * 64 * sizeof(float);
     const void *fn = (const void *)prefill_gemm_dma<EPI, 1, 1, KS, false, WM, WN>;
@@ -649,20 +649,6 @@ bool gemm_launch_small(const GemmArgs &a, hipStream_t st, hipError_t *err)
 template <int EPI>
 hipError_t gemm_launch(const GemmArgs &a, hipStream_t st)
 {
-    const Tunables &tn = tunables();
-    const int tile = tn.pf_tile;
-    switch (tile) {  // L2Z_PF_TILE: experiments
-    case 1: return gemm_launch_t<EPI, 1, 1, 64, 1>(a, st);
-    case 2: return gemm_launch_t<EPI, 1, 1, 64, 2>(a, st);
-    case 3: return gemm_launch_t<EPI, 1, 1, 64, 4>(a, st);
-    case 6: return gemm_launch_t<EPI, 1, 2, 64, 2>(a, st);
-    case 7: return gemm_launch_t<EPI, 2, 2, 32, 2>(a, st);
-    case 8: return gemm_launch_t<EPI, 2, 1, 64, 2>(a, st);
-    case 11: return gemm_launch_t<EPI, 2, 2, 64, 2>(a, st);
-    case 9: { hipError_t e; if (gemm_launch_small<EPI, 1, 2>(a, st, &e)) return e; break; }
-    case 10: { hipError_t e; if (gemm_launch_small<EPI, 1, 1>(a, st, &e)) return e; break; }
-    default: break;
-    }
     // 64 x 64 tiles fill the 256 CUs from N = 4096 at 256 tokens; beyond that 128 x 64 halves
     // the LDS operand reads per MFMA (measured on the 7B shape: 94.7 vs 89.5 TFLOP/s at 512)
     hipError_t e;
@@ -752,18 +738,8 @@ hipError_t dma_launch_kgs(GemmArgs a, int n_feat, const SplitKWs *ws, hipStream_
 struct KgsChoice { bool use; TileForm tile; };
 static KgsChoice choose_kgs(int N, int P, int K, bool pair, const SplitKWs *ws)
 {
-    const Tunables &tn = tunables();
     KgsChoice none = {false, TILE_64x64};
-    if (ws == nullptr || ws->part == nullptr || tn.pf_kgs == 0 || tn.pf_dma == 0 || tn.pf_tile != 0 || tn.pf_fuse == 0 ||
-        K % 64 != 0)
-        return none;
-    static const struct { int tok, feat; double eff; } form[5] = {{128, 64, 1.0}, {64, 64, 0.87}, {32, 64, 0.80}, {32, 32, 0.65},
-                                                                   {128, 128, 1.12}};
-    if (tn.pf_kgs >= 10) {  // forced (experiments): 10 + tile form
-        const int f = tn.pf_kgs - 10;
-        if (f < 0 || f > 4 || f == TILE_32x32 || (pair && f == TILE_128x128)) return none;
-        return {true, (TileForm)f};  // (experiments: a grid beyond the workspace is reported by the launch)
-    }
+    if (ws == nullptr || ws->part == nullptr || K % 64 != 0) return none;
     // Measured (7B shape, whole prefill, interleaved; profiles/r03_prefill_kgs_ab.txt): the form pays where the
     // unsplit family runs ONE 8-wave block of a 128-token tile per CU -- two independent 4-wave blocks of half
     // the LDS hide each other's stage barriers: 512 tokens 58.56 -> 57.32 ms on 128 x 64 tiles -- and loses or
@@ -771,7 +747,6 @@ static KgsChoice choose_kgs(int N, int P, int K, bool pair, const SplitKWs *ws)
     // 110M shape: +10 %).  A cost model of the choose_tile kind picked it for q | k | v and W1 | W3 at 256
     // tokens and lost 5 %: so the rule is the measured one -- chunks of >= 512 tokens, on the 128-token tile the
     // unsplit family takes.
-    (void)form;
     if (P < 512) return none;
     const TileForm tu = choose_tile(N, P, pair);
     if (tu != TILE_128x64 && tu != TILE_128x128) return none;
@@ -815,15 +790,9 @@ constexpr long long kRefCus = 256;  // the part the split-K rule was measured on
 int prefill_split_k(long long n_whole, int P, int K, bool pair)
 {
     (void)pair;
-    const Tunables &tn = tunables();
-    const int skinny_max = tn.pf_skinny_max >= 0 ? tn.pf_skinny_max : 64;
-    if (P > kSplitKMaxTokens || tn.pf_dma == 0 || tn.pf_tile != 0 || tn.pf_fuse == 0) return 1;
+    if (P > kSplitKMaxTokens) return 1;
     int sk = 1;
-    if (tn.pf_splitk >= 0) {  // forced (experiments): beyond the short-prompt kernels' range only
-        if (P <= skinny_max) return 1;
-        sk = tn.pf_splitk >= 4 ? 4 : tn.pf_splitk >= 2 ? 2 : 1;
-    } else {
-        if (tn.pf_skinny_max >= 0 && P <= tn.pf_skinny_max) return 1;  // that range was set by hand
+    {
         const bool streams = n_whole * (long long)K * 4 > ((long long)16 << 20);
         // 65 ... 128 tokens: only the launches the unsplit family leaves block-starved (wo, W2: N = 4096 is 256
         // blocks of 32 x 64, one per CU); q | k | v and W1 | W3 already have ~3 blocks per CU there and LOSE with
@@ -846,11 +815,10 @@ hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float 
                                            float *out, int ldo, int P, int N, int K, hipStream_t st, int n_scale,
                                            int sk, const SplitKWs *ws, int ldw)
 {
-    if (tunables().pf_fuse == 0 || tunables().pf_dma == 0 || tunables().pf_tile != 0) return hipErrorNotSupported;
     if (((uintptr_t)x & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w3 & 15)) return hipErrorInvalidValue;
     GemmArgs a = {x, w3, w1, out, out, P, N, K, ldx, ldo, ldo, 0, nullptr, 0, n_scale > 0 ? n_scale : 1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
     a.ldw = ldw > 0 ? ldw : K;
-    const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
+    constexpr int skinny_max = Tunables::pf_skinny_max;
     if (P <= skinny_max && sk <= 1) return launch_prefill_skinny_pair(G_SWIGLU, a, st);  // prefill_skinny.hip (or not supported)
     if (K % 64 != 0 || ldx % 4 != 0) return hipErrorNotSupported;
     if (sk > 1) return gemm_launch_sk<G_STORE, true>(a, N, sk, ws, st);
@@ -885,8 +853,7 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
                                    int nkv, int K, int pos0, const float2 *rope, int head_size, hipStream_t st,
                                    size_t kv_head_stride, int n_scale, int sk, const SplitKWs *ws)
 {
-    if (tunables().pf_fuse == 0 || tunables().pf_dma == 0 || tunables().pf_tile != 0) return hipErrorNotSupported;
-    const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
+    constexpr int skinny_max = Tunables::pf_skinny_max;
     if ((P <= skinny_max && sk <= 1) || K % 64 != 0 || ldx % 4 != 0) return hipErrorNotSupported;
     if (((uintptr_t)x & 15) || ((uintptr_t)wq & 15) || ((uintptr_t)wk & 15) || ((uintptr_t)wv & 15)) return hipErrorInvalidValue;
     const int N = nq + 2 * nkv;
@@ -943,7 +910,7 @@ hipError_t launch_prefill_gemm_kv_pair(const float *x, int ldx, const float *wk,
                                        float *vcache, int ldkv, int P, int nkv, int K, int pos0, const float2 *rope,
                                        int head_size, hipStream_t st, int n_scale, size_t kv_head_stride, int sk)
 {
-    const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
+    constexpr int skinny_max = Tunables::pf_skinny_max;
     if (P > skinny_max || sk > 1) return hipErrorNotSupported;  // sk > 1: the tile kernel's split-K family takes it
     if (((uintptr_t)x & 15) || ((uintptr_t)wk & 15) || ((uintptr_t)wv & 15)) return hipErrorInvalidValue;
     GemmArgs a = {x, wv, wk, kcache, kcache, P, nkv, K, ldx, ldkv, ldkv, pos0, rope, head_size, n_scale > 0 ? n_scale : 1,
@@ -963,7 +930,7 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
     if (res == nullptr) { res = out; ldres = ldo; }  // PG_RESID in place
     GemmArgs a = {x, nullptr, w, out, res, P, N, K, ldx, ldo, ldres, pos0, rope, head_size, n_scale > 0 ? n_scale : 1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, kv_head_stride, 0, 0};
     a.ldw = ldw > 0 ? ldw : K;
-    const int skinny_max = tunables().pf_skinny_max >= 0 ? tunables().pf_skinny_max : 64;
+    constexpr int skinny_max = Tunables::pf_skinny_max;
     if (P <= skinny_max && sk <= 1) return launch_prefill_skinny(epi, a, st);  // prefill_skinny.hip
     if (sk > 1) {
         if (K % (64 * sk) != 0) return hipErrorInvalidValue;

@@ -334,7 +334,6 @@ int prefill_panel_max_tokens()
 // of the chunk's length class only
 static int panel_range(int tms)
 {
-    if (tunables().pf_panel_form == 9 && tms <= 4) return tms >= 3 ? 256 : kPnRange;   // round 5's
     return tms <= 3 ? kPnRange : 256;
 }
 
@@ -343,8 +342,8 @@ static int panel_range(int tms)
 // launch has a multiple of 16 rows ON THIS RANK (a wave's 16 rows lie in one matrix).
 bool prefill_panel_shape(long long n_whole, int P, int K, long long widest_whole)
 {
-    if (tunables().pf_panel == 0 || tunables().pf_dma == 0 || tunables().pf_tile != 0) return false;
-    const int p_min = tunables().pf_panel_min >= 0 ? tunables().pf_panel_min : kPanelDefaultMin;
+    if (tunables().pf_panel == 0) return false;
+    const int p_min = kPanelDefaultMin;
     if (P < p_min || P < 1 || P > prefill_panel_max_tokens() || K % kPnStage != 0 || K < kPnRange) return false;
     if (n_whole * (long long)K * 4 <= ((long long)16 << 20)) return false;  // cache-resident matrices keep the short-prompt forms
     // the partial products of the WHOLE model's launch must fit the workspace an unsharded runstate allocates
@@ -361,12 +360,11 @@ hipError_t launch_prefill_panel(const PanelProduct &p, int n_cus, const SplitKWs
     if ((p.rows0 % 16) || (p.rows1 % 16) || (p.rows2 % 16) || N < 16 || (p.ldx % 4) || p.K % kPnStage != 0) return hipErrorNotSupported;
     if (((uintptr_t)p.x & 15) || ((uintptr_t)p.w0 & 15) || ((uintptr_t)p.w1 & 15) || ((uintptr_t)p.w2 & 15)) return hipErrorNotSupported;
     if (ws == nullptr || ws->part == nullptr) return hipErrorNotSupported;
-    const int tms = (p.P + 15) / 16;   // token tiles of 16: 1 ... 6
+    const int tms = (p.P + 15) / 16;   // token tiles of 16: 2 ... 6 (up to 16 tokens the short-prompt GEMMs are ahead: kPanelDefaultMin)
     // (four ring buffers per wave -- for two token tiles against ranges of 256 -- measured slower: 20 / 32 tokens 6.72 /
     // 6.82 ms with three, 7.55 / 7.66 with four; profiles/r05c_prefill_panel_ab.txt)
     const int kr = panel_range(tms);
-    const bool r5 = tunables().pf_panel_form == 9 && tms <= 4;   // round 5's forms (A/B): ranges of 256, three buffers
-    const int depth = tms <= 2 || tms == 4 || r5 ? 3 : 2;
+    const int depth = tms <= 2 || tms == 4 ? 3 : 2;
     const int n_ranges = (p.K + kr - 1) / kr;
     if ((size_t)n_ranges * (size_t)(16 * tms) * (size_t)N > ws->part_floats) return hipErrorNotSupported;
     PanelArgs a = {};
@@ -381,7 +379,8 @@ hipError_t launch_prefill_panel(const PanelProduct &p, int n_cus, const SplitKWs
     a.n_items = n_ranges * a.n_groups;
     const size_t lds = (size_t)(16 * tms * kr + nw * depth * 16 * sk) * sizeof(float);
     // Forms (LDS = panel + rings, one block per CU of 160 KB):
-    //   1, 2 tiles   [32 | 64 KB panel of 512 k] + 4 waves x 3 x 8 KB   the W stream is the bound
+    //   2 tiles      [64 KB panel of 512 k] + 4 waves x 3 x 8 KB        the W stream is the bound (one tile: never ahead of the
+    //                                                                    short-prompt GEMMs, 6.0 vs 5.3-5.6 ms: removed in round 6)
     //   3 tiles      [96 KB of 512 k]  + 8 waves x 2 x 4 KB              round 6: half the partial products of round 5's ranges
     //                                                                    of 256 (40 / 48 tokens 8.51 / 8.75 -> 8.06 / 8.27 ms)
     //   4 tiles      [64 KB of 256 k]  + 8 x 3 x 4 KB                    (ranges of 384 with two buffers -- 96 + 64 KB, 31 % fewer
@@ -392,9 +391,8 @@ hipError_t launch_prefill_panel(const PanelProduct &p, int n_cus, const SplitKWs
     //                                                                    profiles/r06_panel_forms.txt)
     const void *fn = nullptr;
     switch (tms) {
-    case 1: fn = (const void *)prefill_panel<1, kPnRange, 3, 4, kPnStage>; break;
     case 2: fn = (const void *)prefill_panel<2, kPnRange, 3, 4, kPnStage>; break;
-    case 3: fn = r5 ? (const void *)prefill_panel<3, 256, 3, 8, 64> : (const void *)prefill_panel<3, 512, 2, 8, 64>; break;
+    case 3: fn = (const void *)prefill_panel<3, 512, 2, 8, 64>; break;
     case 4: fn = (const void *)prefill_panel<4, 256, 3, 8, 64>; break;
     case 5: fn = (const void *)prefill_panel<5, 256, 2, 8, 64>; break;
     case 6: fn = (const void *)prefill_panel<6, 256, 2, 8, 64>; break;

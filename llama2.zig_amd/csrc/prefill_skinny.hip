@@ -352,18 +352,17 @@ __global__ __launch_bounds__(kPfBlock) void prefill_skinny_dma(const GemmArgs a)
 bool skinny_spread(const GemmArgs &a)
 {
     const bool streams = (size_t)a.N * (size_t)a.n_scale * (size_t)a.K * sizeof(float) > ((size_t)16 << 20);
-    return tunables().pf_skinny_spread != 0 && streams && a.N >= 16 * 64;
+    return streams && a.N >= 16 * 64;
 }
 
 template <int EPI, int TMS>
 hipError_t skinny_launch_t(const GemmArgs &a, hipStream_t st)
 {
-    const int form = tunables().pf_skinny_form;
     dim3 grid((a.N + 15) / 16, (a.P + 16 * TMS - 1) / (16 * TMS));
     // LDS-staged forms (1-KB row reads), up to two token tiles (at 64 tokens the stage would take 83 KB).
-    // Direct-to-LDS ring where K is whole 256-k stages and rows are 16-byte aligned;
-    // L2Z_PF_SKINNY_FORM=2 keeps the register-staged form (same sums, another order)
-    if (form == 1 && a.K % kSkBK == 0 && a.K / kSkBK >= 3 && a.ldx % 4 == 0 && TMS <= 2 && tunables().pf_dma != 0) {
+    // Direct-to-LDS ring where K is whole 256-k stages and rows are 16-byte aligned; the register-staged LDS form for
+    // other K >= 256 (same sums, another order); no LDS below that
+    if (a.K % kSkBK == 0 && a.K / kSkBK >= 3 && a.ldx % 4 == 0 && TMS <= 2) {
         constexpr int SW = TMS == 1 ? 4 : 3;
         const size_t lds = (size_t)SW * (16 + 16 * TMS) * kSkLD2 * sizeof(float);
         const void *fn = (const void *)prefill_skinny_dma<EPI, TMS, SW>;
@@ -383,7 +382,7 @@ hipError_t skinny_launch_t(const GemmArgs &a, hipStream_t st)
         void *params[] = {&args};
         return hipLaunchKernel(fn, g1, dim3(kPfBlock), params, lds, st);
     }
-    if ((form == 1 || form == 2) && a.K >= kSkBK && TMS <= 2) {
+    if (a.K >= kSkBK && TMS <= 2) {
         const size_t stage = (size_t)(16 + 16 * TMS) * kSkLD * sizeof(float);
         const size_t red = (size_t)4 * TMS * 4 * 64 * sizeof(float);
         const size_t lds = stage > red ? stage : red;
@@ -405,9 +404,8 @@ hipError_t skinny_launch_t(const GemmArgs &a, hipStream_t st)
 // one token tile per block?  (see skinny_launch)
 bool skinny_one_tile(const GemmArgs &a)
 {
-    const int forced = tunables().pf_skinny_tms;
     const bool cached = (size_t)a.N * (size_t)a.n_scale * (size_t)a.K * sizeof(float) <= ((size_t)16 << 20);
-    return forced == 1 || (forced != 2 && forced != 4 && (a.P <= 16 || cached || (a.P > 32 && a.P <= 48)));
+    return a.P <= 16 || cached || (a.P > 32 && a.P <= 48);
 }
 
 template <int EPI>
@@ -417,10 +415,8 @@ hipError_t skinny_launch(const GemmArgs &a, hipStream_t st)
     // re-read per 16 tokens (more blocks, more waves per CU) -- the WHOLE matrix counts: a row shard takes
     // what the unsharded pass takes.  One that streams from HBM: one or two token tiles per block, and
     // from 33 tokens several blocks per 16 rows of W, paired on one XCD by the 1-D grid (64 tokens: 17.4 ms
-    // with four token tiles in registers, L2Z_PF_SKINNY_TMS=4, -> 15.8; 40 tokens 15.4 -> 14.0).  The one-
+    // with four token tiles in registers -> 15.8; 40 tokens 15.4 -> 14.0: that form is gone).  The one-
     // and two-tile forms sum in the same order.
-    const int forced = tunables().pf_skinny_tms;
-    if (forced == 4) return skinny_launch_t<EPI, 4>(a, st);
     const bool one = skinny_one_tile(a);
     return one ? skinny_launch_t<EPI, 1>(a, st) : skinny_launch_t<EPI, 2>(a, st);
 }
@@ -432,7 +428,6 @@ hipError_t skinny_launch(const GemmArgs &a, hipStream_t st)
 // the shape takes another short-prompt form: the caller launches the two products separately.
 hipError_t launch_prefill_skinny_pair(int epi, const GemmArgs &a, hipStream_t st)
 {
-    if (tunables().pf_fuse == 0 || tunables().pf_skinny_form != 1 || tunables().pf_dma == 0) return hipErrorNotSupported;
     if (a.K % kSkBK != 0 || a.K / kSkBK >= 3 == false || a.ldx % 4 != 0 || !skinny_one_tile(a)) return hipErrorNotSupported;
     constexpr int SW = 3;
     const size_t lds = (size_t)SW * (32 + 16) * kSkLD2 * sizeof(float);

@@ -39,10 +39,9 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
     s->use_graphs = tn.no_graph == 0;
     // Peer-write gathers are plain kernels (or no launch at all): captured with the rest of the
     // step.  RCCL collectives are captured too (stream capture of ncclAllGather; if the capture
-    // fails the step is launched eagerly, ensure_graph); L2Z_COMM_GRAPH=0 keeps them eager.
+    // fails the step is launched eagerly, ensure_graph).
     // Emulated ranks are driven stage by stage, never captured.
     if (comm && comm->world > 1 && !comm->nccl && !comm->p2p) s->use_graphs = false;
-    if (comm && comm->nccl && !comm_uses_p2p(comm) && tn.comm_graph == 0) s->use_graphs = false;
     s->fused_qkv_attn = sh.world == 1 && tn.fuse_small != 0 &&
                         fused_qkv_attn_supported(c.dim, c.n_heads, c.n_kv_heads, c.seq_len, g_cus);
     s->n_gathers = (sh.scheme_b ? 2 : 4) * c.n_layers + 1;
@@ -116,7 +115,7 @@ extern "C" int l2z_runstate_init(const l2z_config *config, const l2z_comm *comm,
         aa.q = s->q; aa.kcache = s->key_cache; aa.vcache = s->value_cache;
         aa.head_size = sh.hs; aa.kv_row = sh.hs; aa.kv_head = (size_t)c.seq_len * sh.hs;
         const bool want_consume = tn.p2p_consume >= 0 ? tn.p2p_consume != 0 : (sh.world <= 2 || c.dim < 4096);
-        s->ll_consume = !sh.scheme_b && tn.p2p_push && want_consume && matvec_ll_supported(c.dim) &&
+        s->ll_consume = !sh.scheme_b && want_consume && matvec_ll_supported(c.dim) &&
                         matvec_ll_supported(c.hidden_dim) && attention_push_supported(aa);
         P2pArgs t[4];
         comm_p2p_args(comm, s->xb, (size_t)sh.dim_loc, s->ll_consume, &t[0]);

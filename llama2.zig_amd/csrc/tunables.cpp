@@ -16,24 +16,13 @@ void env_int(const char *name, int *v)
 Tunables read_env()
 {
     Tunables t;
-    env_int("L2Z_ROW_KERNEL", &t.row_kernel);
-    env_int("L2Z_ROW_BLOCKS", &t.row_blocks);
-    env_int("L2Z_ROW_TAIL_SKIP", &t.row_tail_skip);
-    env_int("L2Z_MAX_BLOCKS_PER_CU", &t.max_blocks_per_cu);
     env_int("L2Z_GRID_CAP", &t.grid_cap);
-    env_int("L2Z_ATTN_BLOCK", &t.attn_block);
     env_int("L2Z_ATTN_SPLIT", &t.attn_split);
     env_int("L2Z_ATTN_SPLIT_POS", &t.attn_split_pos);
-    env_int("L2Z_ATTN_SHORT_POS", &t.attn_short_pos);
-    env_int("L2Z_ATTN_SPLIT_WIDE_POS", &t.attn_split_wide_pos);
     env_int("L2Z_FUSE_SMALL", &t.fuse_small);
-    env_int("L2Z_ATTN_POS_ARG", &t.attn_pos_arg);
     env_int("L2Z_SCHEME_B", &t.scheme_b);
     env_int("L2Z_NO_GRAPH", &t.no_graph);
-    env_int("L2Z_COMM_GRAPH", &t.comm_graph);
     if (const char *e = getenv("L2Z_COMM")) t.prefer_rccl = strcmp(e, "rccl") == 0;
-    env_int("L2Z_P2P_PUSH", &t.p2p_push);
-    env_int("L2Z_REDUCE_BLOCK", &t.reduce_block);
     env_int("L2Z_ARGMAX_XCHG", &t.argmax_xchg);
     env_int("L2Z_P2P_CONSUME", &t.p2p_consume);
     if (const char *e = getenv("L2Z_P2P_TIMEOUT_S"))
@@ -41,23 +30,8 @@ Tunables read_env()
     env_int("L2Z_P2P_BULK_MB", &t.p2p_bulk_mb);
     env_int("L2Z_PREFILL", &t.prefill);
     env_int("L2Z_PF_CHUNK", &t.pf_chunk);
-    env_int("L2Z_PF_SKINNY_FORM", &t.pf_skinny_form);
-    env_int("L2Z_PF_TILE", &t.pf_tile);
-    env_int("L2Z_PF_SKINNY_MAX", &t.pf_skinny_max);
-    env_int("L2Z_PF_SKINNY_SPREAD", &t.pf_skinny_spread);
-    env_int("L2Z_PF_SKINNY_TMS", &t.pf_skinny_tms);
-    env_int("L2Z_PF_ATTN", &t.pf_attn);
-    env_int("L2Z_PF_FUSE", &t.pf_fuse);
-    env_int("L2Z_PF_SPLITK", &t.pf_splitk);
     env_int("L2Z_PF_PANEL", &t.pf_panel);
     env_int("L2Z_PF_PANEL_MAX", &t.pf_panel_max);
-    env_int("L2Z_PF_PANEL_FORM", &t.pf_panel_form);
-    env_int("L2Z_PF_PANEL_MIN", &t.pf_panel_min);
-    env_int("L2Z_PF_KGS", &t.pf_kgs);
-    env_int("L2Z_PF_DMA", &t.pf_dma);
-    env_int("L2Z_PF_ORDER", &t.pf_order);
-    if (t.row_blocks < 1) t.row_blocks = 1;
-    if (t.max_blocks_per_cu < 1) t.max_blocks_per_cu = 8;
     return t;
 }
 
@@ -94,21 +68,11 @@ bool tunables_set(const char *name, long long v)
 {
     Tunables &t = mutable_tunables();
     struct { const char *n; int *p; } ints[] = {
-        {"L2Z_ROW_KERNEL", &t.row_kernel}, {"L2Z_ROW_BLOCKS", &t.row_blocks}, {"L2Z_ROW_TAIL_SKIP", &t.row_tail_skip},
-        {"L2Z_MAX_BLOCKS_PER_CU", &t.max_blocks_per_cu}, {"L2Z_GRID_CAP", &t.grid_cap},
-        {"L2Z_ATTN_BLOCK", &t.attn_block}, {"L2Z_ATTN_SPLIT", &t.attn_split},
-        {"L2Z_ATTN_SPLIT_POS", &t.attn_split_pos}, {"L2Z_ATTN_SHORT_POS", &t.attn_short_pos}, {"L2Z_ATTN_SPLIT_WIDE_POS", &t.attn_split_wide_pos},
-        {"L2Z_FUSE_SMALL", &t.fuse_small}, {"L2Z_ATTN_POS_ARG", &t.attn_pos_arg}, {"L2Z_NO_GRAPH", &t.no_graph},
-        
-        {"L2Z_SCHEME_B", &t.scheme_b},
-        {"L2Z_COMM_GRAPH", &t.comm_graph}, {"L2Z_COMM_RCCL", &t.prefer_rccl},
-        {"L2Z_P2P_PUSH", &t.p2p_push}, {"L2Z_REDUCE_BLOCK", &t.reduce_block}, {"L2Z_ARGMAX_XCHG", &t.argmax_xchg}, {"L2Z_P2P_CONSUME", &t.p2p_consume},
-        {"L2Z_P2P_BULK_MB", &t.p2p_bulk_mb},
-        {"L2Z_PREFILL", &t.prefill}, {"L2Z_PF_CHUNK", &t.pf_chunk},
-        {"L2Z_PF_SKINNY_FORM", &t.pf_skinny_form}, {"L2Z_PF_TILE", &t.pf_tile},
-        {"L2Z_PF_SKINNY_MAX", &t.pf_skinny_max}, {"L2Z_PF_SKINNY_SPREAD", &t.pf_skinny_spread}, {"L2Z_PF_SKINNY_TMS", &t.pf_skinny_tms},
-        {"L2Z_PF_ATTN", &t.pf_attn}, {"L2Z_PF_FUSE", &t.pf_fuse}, {"L2Z_PF_DMA", &t.pf_dma}, {"L2Z_PF_ORDER", &t.pf_order},
-        {"L2Z_PF_SPLITK", &t.pf_splitk}, {"L2Z_PF_PANEL", &t.pf_panel}, {"L2Z_PF_PANEL_MAX", &t.pf_panel_max}, {"L2Z_PF_PANEL_FORM", &t.pf_panel_form}, {"L2Z_PF_PANEL_MIN", &t.pf_panel_min}, {"L2Z_PF_KGS", &t.pf_kgs}};
+        {"L2Z_GRID_CAP", &t.grid_cap}, {"L2Z_ATTN_SPLIT", &t.attn_split}, {"L2Z_ATTN_SPLIT_POS", &t.attn_split_pos},
+        {"L2Z_FUSE_SMALL", &t.fuse_small}, {"L2Z_NO_GRAPH", &t.no_graph}, {"L2Z_SCHEME_B", &t.scheme_b},
+        {"L2Z_COMM_RCCL", &t.prefer_rccl}, {"L2Z_ARGMAX_XCHG", &t.argmax_xchg}, {"L2Z_P2P_CONSUME", &t.p2p_consume},
+        {"L2Z_P2P_BULK_MB", &t.p2p_bulk_mb}, {"L2Z_PREFILL", &t.prefill}, {"L2Z_PF_CHUNK", &t.pf_chunk},
+        {"L2Z_PF_PANEL", &t.pf_panel}, {"L2Z_PF_PANEL_MAX", &t.pf_panel_max}};
     for (auto &e : ints)
         if (strcmp(e.n, name) == 0) {
             *e.p = (int)v;

@@ -25,13 +25,12 @@ for v in variants:
         B.option_set(k, int(val))
     s = B.RunState(cfg)
     # graphs are captured at the first run, with the options in force THEN (launch-time knobs such as
-    # L2Z_ROW_BLOCKS are read while the launches are enqueued): capture both graph kinds now
+    # the attention split are read while the launches are enqueued): capture both graph kinds now
     s.greedy_begin([]); s.greedy_run(w, 2); s.transformer(1, 0, w); s.synchronize()
     states.append(s)
     for k in kv:  # back to the default for the next variant (options apply at RunState creation)
-        B.option_set(k, {"L2Z_ATTN_SPLIT": -1, "L2Z_ATTN_SPLIT_POS": -1, "L2Z_ATTN_SHORT_POS": -1, "L2Z_ATTN_SPLIT_WIDE_POS": -1, "L2Z_ROW_TAIL_SKIP": 1, "L2Z_ROW_BLOCKS": 2, "L2Z_ATTN_BLOCK": 0,
-                         "L2Z_FUSE_SMALL": 1, "L2Z_NO_GRAPH": 0, "L2Z_ROW_KERNEL": 1,
-                         "L2Z_MAX_BLOCKS_PER_CU": 8}.get(k, 0))
+        B.option_set(k, {"L2Z_ATTN_SPLIT": -1, "L2Z_ATTN_SPLIT_POS": -1, "L2Z_FUSE_SMALL": 1, "L2Z_NO_GRAPH": 0, "L2Z_P2P_CONSUME": -1,
+                         "L2Z_ARGMAX_XCHG": 1}.get(k, 0))
 # the variants' arithmetic side by side: logits of one pass at pos0 and the first greedy tokens, against variant 0
 ref_logits = ref_toks = None
 for v, s in zip(variants, states):

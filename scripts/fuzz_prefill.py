@@ -39,16 +39,12 @@ def run(n_cfg, seed, log=print, wide=False):
             if n_kv % world:
                 n_kv = n_heads
             hidden = 128 * world * int(rng.integers(2048 // (128 * world) + 1, 9216 // (128 * world) + 1))
-            n_tok = int(rng.choice([9, 16, 17, 20, 31, 32, 33, 40, 48, 49, 63, 64, 65, 80]))
+            n_tok = int(rng.choice([9, 16, 17, 20, 31, 32, 33, 40, 48, 49, 63, 64, 65, 72, 80, 81, 96, 97]))
             scheme_b = world > 1 and bool(rng.integers(0, 3) == 0)
         seq = n_tok + 8
         cfg = ck.Config(dim, hidden, int(rng.integers(1, 3)), n_heads, n_kv, vocab, seq)
         toks = [1] + rng.integers(2, vocab, n_tok - 1).tolist()
-        # the tile GEMM's split-K family: as the shape picks it (-1), or forced for 65 ... 256-token chunks -- the
-        # same setting for the unsharded pass and the shards, which must stay bit-identical in every family
-        sk = int(rng.choice([-1, -1, 2, 4]))
-        B.option_set("L2Z_PF_SPLITK", sk)
-        tag = f"world {world}{' scheme B' if scheme_b else ''} dim {dim} hs {hs} H {n_heads} kv {n_kv} hid {hidden} V {vocab} L {cfg.n_layers} tokens {n_tok} splitk {sk}"
+        tag = f"world {world}{' scheme B' if scheme_b else ''} dim {dim} hs {hs} H {n_heads} kv {n_kv} hid {hidden} V {vocab} L {cfg.n_layers} tokens {n_tok}"
         try:
             w0 = B.Weights(cfg, None, False, seed=70 + it)
             s0, s1 = B.RunState(cfg), B.RunState(cfg)
@@ -102,7 +98,6 @@ def run(n_cfg, seed, log=print, wide=False):
         except Exception as e:  # noqa: BLE001
             log(f"ERR {tag}: {e}")
             bad += 1
-    B.option_set("L2Z_PF_SPLITK", -1)
     B.option_set("L2Z_SCHEME_B", 0)
     return bad
 

@@ -8,7 +8,7 @@ wl = sys.argv[1]
 variants = sys.argv[2:] or [""]
 cfg, shared = {n: (c, sh) for n, c, sh in ck.iter_configs()}[wl]
 w = B.Weights(cfg, None, shared, seed=2024)
-DEF = {"L2Z_ROW_TAIL_SKIP": 1, "L2Z_ROW_BLOCKS": 2, "L2Z_MAX_BLOCKS_PER_CU": 8, "L2Z_ROW_KERNEL": 1, "L2Z_ATTN_BLOCK": 0}
+DEF = {"L2Z_ATTN_SPLIT": -1, "L2Z_ATTN_SPLIT_POS": -1, "L2Z_FUSE_SMALL": 1}   # (round 6: the mat-vec launch knobs this scanned are constants now)
 s = B.RunState(cfg)
 res = {}
 for rnd in range(3):

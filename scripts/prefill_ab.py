@@ -8,8 +8,7 @@ variants = sys.argv[4:] or [""]
 cfg, shared = {k: (c, sh) for k, c, sh in ck.iter_configs()}[shape]
 w = B.Weights(cfg, None, shared, seed=1); s = B.RunState(cfg)
 toks = [1] + np.random.default_rng(1).integers(2, cfg.vocab_size, n - 1).tolist()
-DEF = {"L2Z_PF_ATTN": 1, "L2Z_PF_SKINNY_TMS": 0, "L2Z_PF_ORDER": 1, "L2Z_PF_SKINNY_FORM": 1, "L2Z_PF_SKINNY_MAX": -1, "L2Z_PF_DMA": 1, "L2Z_PF_TILE": 0, "L2Z_PF_FUSE": 1, "L2Z_PF_ATTN": 1, "L2Z_PF_CHUNK": 0, "L2Z_PF_SPLITK": -1, "L2Z_PF_KGS": -1, "L2Z_PF_SKINNY_SPREAD": 1,
-       "L2Z_PF_PANEL": 1, "L2Z_PF_PANEL_MAX": -1, "L2Z_PF_PANEL_MIN": -1, "L2Z_PF_PANEL_FORM": 0}
+DEF = {"L2Z_PF_CHUNK": 0, "L2Z_PF_PANEL": 1, "L2Z_PF_PANEL_MAX": -1, "L2Z_PREFILL": 1}   # (round 6: the other prefill knobs are gone)
 res = [[] for _ in variants]
 logits = [None for _ in variants]
 flops = 2.0 * n * (cfg.n_layers * (2 * cfg.dim * cfg.dim + 2 * cfg.dim * cfg.kv_dim + 3 * cfg.dim * cfg.hidden_dim))

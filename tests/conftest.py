@@ -55,10 +55,9 @@ def gpu(B):
 def options(gpu):
     """Set tuning knobs of csrc/tunables.h for one test (they are read from the environment once,
     at first use, so tests go through l2z_option_set) and put the defaults back afterwards."""
-    defaults = {"L2Z_ATTN_SPLIT": -1, "L2Z_ATTN_SPLIT_POS": -1, "L2Z_ATTN_SHORT_POS": -1, "L2Z_ATTN_SPLIT_WIDE_POS": -1, "L2Z_FUSE_SMALL": 1,
-                "L2Z_PREFILL": 1, "L2Z_NO_GRAPH": 0, "L2Z_PF_FUSE": 1, "L2Z_PF_DMA": 1, "L2Z_ROW_KERNEL": 1,
-                "L2Z_PF_CHUNK": 0, "L2Z_PF_SKINNY_FORM": 1, "L2Z_PF_TILE": 0, "L2Z_PF_SPLITK": -1, "L2Z_PF_SKINNY_MAX": -1, "L2Z_PF_KGS": -1, "L2Z_PF_SKINNY_SPREAD": 1,
-                "L2Z_PF_PANEL": 1, "L2Z_PF_PANEL_MAX": -1, "L2Z_PF_PANEL_MIN": -1, "L2Z_ARGMAX_XCHG": 1}
+    defaults = {"L2Z_ATTN_SPLIT": -1, "L2Z_ATTN_SPLIT_POS": -1, "L2Z_FUSE_SMALL": 1, "L2Z_PREFILL": 1, "L2Z_NO_GRAPH": 0,
+                "L2Z_PF_CHUNK": 0, "L2Z_PF_PANEL": 1, "L2Z_PF_PANEL_MAX": -1, "L2Z_ARGMAX_XCHG": 1, "L2Z_GRID_CAP": 0,
+                "L2Z_P2P_CONSUME": -1, "L2Z_SCHEME_B": 0}
     touched = []
 
     def set_options(**kw):

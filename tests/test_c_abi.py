@@ -49,6 +49,27 @@ def test_product_and_test_headers_do_not_overlap(B):
             "l2z_matmul", "l2z_option_set"} <= test
 
 
+def exported_l2z(so):
+    out = subprocess.run(["nm", "-D", "--defined-only", so], check=True, capture_output=True, text=True).stdout
+    return {ln.split()[-1] for ln in out.splitlines() if ln.split()[-1].startswith("l2z_")}
+
+
+def test_product_library_exports_the_boundary_and_nothing_else(B):
+    """round 6: `nm -D libllama2_hip.so | grep l2z_` is EXACTLY include/llama2_hip.h (csrc/llama2_hip.map) -- the test and
+    measurement entry points (emulated ranks, solo connect, kernel hooks, l2z_option_set, ...) are not in the library a
+    host links; libllama2_hip_test.so, the same objects, exports both headers and is what tests / bench load."""
+    prod, test = set(B.declared_symbols("product")), set(B.declared_symbols("test"))
+    assert exported_l2z(B.PRODUCT_LIB_PATH) == prod
+    assert exported_l2z(os.path.join(os.path.dirname(B.PRODUCT_LIB_PATH), "libllama2_hip_test.so")) >= prod | test
+    # the version script is the header: a function added to one and not the other fails here before it fails a link
+    mp = open(os.path.join(ROOT, "llama2.zig_amd", "csrc", "llama2_hip.map")).read()
+    import re
+    assert set(re.findall(r"^\s+(l2z_\w+);", mp, flags=re.M)) == prod
+    # and nothing but the C ABI leaks out of the product library (no C++ symbols of namespace l2z)
+    out = subprocess.run(["nm", "-D", "--defined-only", B.PRODUCT_LIB_PATH], check=True, capture_output=True, text=True).stdout
+    assert not [ln for ln in out.splitlines() if "l2z" in ln and not ln.split()[-1].startswith("l2z_")], out[:2000]
+
+
 @pytest.mark.gpu
 def test_c_host_runs_the_golden_toy_checkpoints(gpu, tmp_path):
     """init -> l2z_transformer -> l2z_argmax -> free from C on the committed toy checkpoints:

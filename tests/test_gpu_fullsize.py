@@ -410,22 +410,9 @@ def test_stories110M_prefill_paths_vs_oracle(gpu, ck, orc, options):
         return got
 
     base = {n: check(n, "as chosen") for n in lens}
-    for tile, name in ((8, "128x64"), (11, "128x128"), (2, "64x64")):
-        options(L2Z_PF_TILE=tile)
-        assert np.array_equal(check(300, f"forced {name}"), base[300]), f"tile form {name} changed the bits"
-    options(L2Z_PF_TILE=0)
-    # the two k-groups of a stage on two blocks (csrc/prefill_gemm.hip SPLIT == 2): kg0 + kg1 is the sum the
-    # one-block forms form in LDS, so every tile of this form must give the SAME bits as well
-    for f, name in ((10, "128x64"), (11, "64x64"), (12, "32x64"), (14, "128x128")):
-        options(L2Z_PF_KGS=f)
-        assert np.array_equal(check(300, f"two-block form {name}"), base[300]), f"two-block form on {name} changed the bits"
-    options(L2Z_PF_KGS=-1)
-    # the split-K family (K cut into 2 / 4 ranges per output tile, the last arriver adds the range partials in
-    # order): this shape's matrices are cache resident, so it is forced here; another rounding, same tolerance
-    for sk in (2, 4):
-        options(L2Z_PF_SPLITK=sk)
-        got = check(100, f"split-K {sk}")
-        assert not np.array_equal(got, base[100]), f"split-K {sk}: identical bits, the split family did not run"
-    options(L2Z_PF_SPLITK=-1)
+    # (until round 5 this test also forced every tile form, the two-block form and the split-K family through knobs and
+    # compared bits; the knobs are gone with the forms nobody's cost model picked -- what remains is reached by shape:
+    # tests/test_gpu_parity.py PREFILL_CONFIGS "streams-2048", the fuzzers, and the sharded-vs-unsharded bit identity,
+    # where a rank's narrower matrices take other tiles than the whole model's)
     w.close()
 

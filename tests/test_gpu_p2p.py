@@ -54,12 +54,12 @@ def run_ranks(tmp_path, world, spec, env_extra=None, timeout=300):
 
 # consume: consumers read the LL words from their own landing slot (no gather launches; the default up to 2 ranks or for
 # rows narrower than 4096, L2Z_P2P_CONSUME=1 here);
-# gather: one gather launch per gathered vector, which also sends (L2Z_P2P_CONSUME=0); gather-push: the producers' epilogues
-# send, the gather launch only collects (L2Z_P2P_PUSH=2); nopush: no pushes anywhere (L2Z_P2P_PUSH=0: gather launches)
-CASES = ([(m, "consume") for m in MODELS] + [(MODELS[0], "gather"), (MODELS[4], "gather"), (MODELS[3], "nopush")] +
-         [(MODELS[0], "gather-push"), (MODELS[4], "gather-push"), (MODELS[5], "gather")])
-MODE_ENV = {"consume": {"L2Z_P2P_CONSUME": "1"}, "gather": {"L2Z_P2P_CONSUME": "0"}, "gather-push": {"L2Z_P2P_CONSUME": "0", "L2Z_P2P_PUSH": "2"},
-            "nopush": {"L2Z_P2P_PUSH": "0"}}
+# gather: one gather launch per gathered vector, which also sends (L2Z_P2P_CONSUME=0); default: what the library picks by
+# shape.  (Until round 5 also "gather-push" -- producers' epilogues send where a gather launch collects, L2Z_P2P_PUSH=2 --
+# and "nopush": the form measured slower on every bed and its knob are gone.)
+CASES = ([(m, "consume") for m in MODELS] + [(MODELS[0], "gather"), (MODELS[4], "gather"), (MODELS[3], "default")] +
+         [(MODELS[5], "gather")])
+MODE_ENV = {"consume": {"L2Z_P2P_CONSUME": "1"}, "gather": {"L2Z_P2P_CONSUME": "0"}, "default": {}}
 
 
 @pytest.mark.parametrize("model,mode", CASES, ids=[f"{m[0]}-x{m[3]}-{mode}" for m, mode in CASES])
@@ -123,7 +123,7 @@ def test_argmax_tie_across_ranks_takes_the_lowest_index(gpu, ck, tmp_path, world
     s.close(); w.close()
 
 
-SCHEME_B = [(MODELS[0], "push"), (MODELS[1], "nopush"), (MODELS[3], "push"), (MODELS[3], "nopush"), (MODELS[5], "nopush"), (MODELS[4], "push")]
+SCHEME_B = [(MODELS[0], "reduce"), (MODELS[1], "reduce"), (MODELS[3], "reduce"), (MODELS[5], "reduce"), (MODELS[4], "reduce")]
 
 
 @pytest.mark.parametrize("model,mode", SCHEME_B, ids=[f"{m[0]}-x{m[3]}-{mode}" for m, mode in SCHEME_B])
@@ -131,15 +131,14 @@ def test_multiprocess_scheme_b_allreduce(gpu, ck, tmp_path, model, mode, options
     """Scheme B with real processes (L2Z_SCHEME_B=1: Wo / W2 sharded by columns, the ranks' partial [dim] vectors pushed as
     LL words into every peer's slot and summed in rank order by the reduce launch, csrc/p2p.hip): 2 collectives per layer.
     The ranks must agree with each other BIT FOR BIT; against the unsharded pass fed the same tokens the logits hold the
-    parity tests' tolerance (the row sums are split differently).  nopush (the default): the reduce launch sends the partial
-    itself; push (L2Z_P2P_PUSH=2): the mat-vec's epilogue does."""
+    parity tests' tolerance (the row sums are split differently).  The reduce launch sends the rank's partial itself."""
     name, kw, shared, world = model
     options(L2Z_FUSE_SMALL=0, L2Z_PREFILL=0)
     cfg = ck.Config(**kw)
     steps = min(cfg.seq_len - 2, 120)
     on_device = cfg.dim >= 4096
     spec = dict(cfg=kw, shared=shared, seed=33, prompt=[5, 9, 11], steps=steps, blob=not on_device)
-    run_ranks(tmp_path, world, spec, dict({"L2Z_SCHEME_B": "1"}, **({"L2Z_P2P_PUSH": "2"} if mode == "push" else {})))
+    run_ranks(tmp_path, world, spec, {"L2Z_SCHEME_B": "1"})
     outs = [np.load(tmp_path / f"out_{r}.npz") for r in range(world)]
     for r in range(1, world):
         for k in ("toks", "logits", "logits2"):

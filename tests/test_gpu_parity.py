@@ -206,7 +206,7 @@ def test_attention_kernels_vs_oracle(gpu, orc, shape, form, nch, positions):
     print(f"attention {shape} {form}{nch or ''}: max |diff| {worst:.2e}")
 
 
-PF_ATTN_FORMS = {"per-query": 1, "tiled": 2, "flash1": 3, "flash2": 4}
+PF_ATTN_FORMS = {"per-query": 1, "tiled": 2, "flash": 3}
 
 
 @pytest.mark.parametrize("H,KV,hs", [(4, 2, 64), (4, 4, 128), (6, 6, 48)], ids=["gqa-hs64", "mha-hs128", "hs48"])
@@ -214,7 +214,7 @@ PF_ATTN_FORMS = {"per-query": 1, "tiled": 2, "flash1": 3, "flash2": 4}
 def test_prefill_attention_kernels_vs_softmax_reference(gpu, orc, H, KV, hs, form):
     """The batched prefill's attention kernels driven directly (l2z_prefill_attention): block per (head,
     query); tiled with the softmax in LDS; the flash form (S^T / O^T on MFMA 16x16x4, P kept in the
-    accumulators' registers) with one and two key parts.  150 queries at positions 37 .. 186 (three query
+    accumulators' registers; two key parts per tile).  150 queries at positions 37 .. 186 (three query
     tiles, the last one partial, key tiles that start before the chunk) against main.zig:361-389 in
     float64, and a few (query, head) pairs against the oracle's own dot / softmax / weighted sum.  Outputs
     are convex combinations of V entries (|v| <= 2): bound 3e-6."""
@@ -869,31 +869,10 @@ PREFILL_CONFIGS = [
     ("32-heads-hs16-gqa", dict(dim=512, hidden_dim=1024, n_layers=2, n_heads=32, n_kv_heads=8, vocab_size=1024, seq_len=560), False),
     ("16-heads-hs48", dict(dim=768, hidden_dim=1024, n_layers=2, n_heads=16, n_kv_heads=16, vocab_size=1024, seq_len=560), True),
     ("16-heads-hs64-gqa", dict(dim=1024, hidden_dim=1536, n_layers=2, n_heads=16, n_kv_heads=4, vocab_size=1024, seq_len=560), False),
+    # matrices that stream from HBM (> 16 MB): the K-range panel kernel at 17 ... 96 tokens, the split-K family at 65 / 79
+    # (wo, W2: 96 blocks of 32 x 64), and at 523 tokens 128 x 64 tiles with the two k-groups on two blocks
+    ("streams-2048", dict(dim=2048, hidden_dim=5632, n_layers=2, n_heads=16, n_kv_heads=16, vocab_size=1024, seq_len=560), False),
 ]
-
-
-def test_prefill_gemm_direct_to_lds_equals_register_staged(gpu, ck, options):
-    """The two forms of the tile GEMM (operands by global_load_lds vs staged through registers) pair
-    the k values differently inside an MFMA, and the paired W1|W3 launch (L2Z_PF_FUSE) computes
-    silu(a) * b in its epilogue instead of merging into the first GEMM's output -- nothing else:
-    logits and cache rows of a prefill agree within the logit tolerance, for 64-token (P <= 256)
-    and 128-token (P > 256) tiles."""
-    cfg = ck.Config(dim=512, hidden_dim=1536, n_layers=2, n_heads=8, n_kv_heads=4, vocab_size=2048, seq_len=400)
-    w = gpu.Weights(cfg, None, False, seed=5)
-    rng = np.random.default_rng(3)
-    for n in (100, 300):
-        toks = [1] + rng.integers(2, cfg.vocab_size, n - 1).tolist()
-        res = []
-        for dma, fuse in ((1, 1), (0, 1), (1, 0)):
-            options(L2Z_PF_DMA=dma, L2Z_PF_FUSE=fuse)
-            s = gpu.RunState(cfg)
-            s.prefill(toks, 0, w)
-            res.append((s.logits(), s.read("key_cache", 0, n * cfg.kv_dim), s.read("value_cache", cfg.seq_len * cfg.kv_dim, n * cfg.kv_dim)))
-            s.close()
-        for other in res[1:]:
-            for a, b in zip(res[0], other):
-                np.testing.assert_allclose(a, b, rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
-    w.close()
 
 
 @pytest.mark.parametrize("name,kw,shared", PREFILL_CONFIGS, ids=[c[0] for c in PREFILL_CONFIGS])
@@ -954,49 +933,56 @@ def test_prefill_equals_token_by_token(gpu, ck, orc, name, kw, shared):
 
 @pytest.mark.parametrize("kv_heads", [24, 8])
 def test_prefill_panel_kernel_vs_oracle(gpu, ck, orc, options, kv_heads):
-    """prefill_panel.hip: chunks of <= 32 tokens of matrices that stream from HBM (K cut into ranges of 512 with a
-    resident X panel, the ranges added in order by a second launch that also runs the epilogue -- RoPE + cache rows,
-    residual, SiLU * mul).  A wide two-layer shape whose hidden_dim leaves a SHORT last range (8448 = 16.5 x 512), MHA
-    and GQA: logits and KV rows against the CPU oracle's stepped loop for chunks of 1 / 16 (one token tile; below the
-    default switch-over, so forced: L2Z_PF_PANEL_MIN=1), 17 / 32 (two), 33 / 48 / 64 (three and four tiles against ranges of 256), a
-    second call continuing the context; and against the short-prompt GEMMs (L2Z_PF_PANEL=0) within the tolerance."""
-    kw = dict(dim=3072, hidden_dim=8448, n_layers=2, n_heads=24, n_kv_heads=kv_heads, vocab_size=2048, seq_len=80)
+    """prefill_panel.hip: chunks of 17 ... 96 tokens of matrices that stream from HBM (K cut into ranges with a resident X
+    panel, the ranges added in order by a second launch that also runs the epilogue -- RoPE + cache rows, residual,
+    SiLU * mul).  A wide two-layer shape whose hidden_dim leaves a SHORT last range (8448 = 16.5 x 512 = 33 x 256), MHA and
+    GQA: logits and KV rows against the CPU oracle's stepped loop for chunks of 16 (short-prompt GEMMs: below the panel
+    kernel's range), 17 / 32 (two token tiles, ranges of 512), 33 / 48 (three, 512), 49 / 64 (four, 256), 65 / 80 / 81 / 96
+    (five and six, 256: round 6), a second call continuing the context; and against the short-prompt GEMMs
+    (L2Z_PF_PANEL=0) within the tolerance."""
+    kw = dict(dim=3072, hidden_dim=8448, n_layers=2, n_heads=24, n_kv_heads=kv_heads, vocab_size=2048, seq_len=112)
     cfg = ck.Config(**kw)
-    options(L2Z_PF_PANEL_MIN=1)
     blob = ck.synth_blob(cfg, False, seed=55)
     w, s = gpu.Weights(cfg, blob, False), gpu.RunState(cfg)
     m = orc.Model(cfg.as_i32(), blob, False)
     rng = np.random.default_rng(12)
-    toks = [1] + rng.integers(2, cfg.vocab_size, 71).tolist()
+    toks = [1] + rng.integers(2, cfg.vocab_size, 103).tolist()
     kvd, S = cfg.kv_dim, cfg.seq_len
+    lens = (16, 17, 32, 33, 48, 49, 64, 65, 80, 81, 96)
+    ref = {}
+    for pos, t in enumerate(toks):       # ONE pass of the oracle: its logits after position n - 1 are the n-token prompt's
+        lg = m.transformer(t, pos)
+        if pos + 1 in lens or pos + 1 in (40, 104):
+            ref[pos + 1] = lg
+    ref_cache = {nm: m.state(nm, cfg.n_layers * S * kvd).reshape(cfg.n_layers, S, kvd) for nm in ("key_cache", "value_cache")}
     worst = 0.0
-    for n in (1, 16, 17, 32, 33, 48, 64):
-        for pos, t in enumerate(toks[:n]):
-            ref = m.transformer(t, pos)
+    for n in lens:
         s.prefill(toks[:n], 0, w)
         got = s.logits()
-        worst = max(worst, float(np.abs(got - ref).max()))
-        np.testing.assert_allclose(got, ref, rtol=LOGIT_RTOL, atol=LOGIT_ATOL, err_msg=f"{n} tokens")
+        worst = max(worst, float(np.abs(got - ref[n]).max()))
+        np.testing.assert_allclose(got, ref[n], rtol=LOGIT_RTOL, atol=LOGIT_ATOL, err_msg=f"{n} tokens")
         for l in range(cfg.n_layers):
             for nm in ("key_cache", "value_cache"):
-                a = m.state(nm, cfg.n_layers * S * kvd).reshape(cfg.n_layers, S, kvd)[l, :n].ravel()
-                np.testing.assert_allclose(s.read(nm, l * S * kvd, n * kvd), a, rtol=2e-5, atol=2e-5, err_msg=f"{nm} l={l} n={n}")
-    # a second call continuing the context (pos0 = 64), 8 more tokens
-    for pos in range(64, 72):
-        ref = m.transformer(toks[pos], pos)
-    s.prefill(toks[64:72], 64, w)
-    np.testing.assert_allclose(s.logits(), ref, rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
+                np.testing.assert_allclose(s.read(nm, l * S * kvd, n * kvd), ref_cache[nm][l, :n].ravel(), rtol=2e-5, atol=2e-5,
+                                           err_msg=f"{nm} l={l} n={n}")
+    # a second call continuing the context (pos0 = 96), 8 more tokens
+    s.prefill(toks[96:104], 96, w)
+    np.testing.assert_allclose(s.logits(), ref[104], rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
     # 32 + 8 tokens: the panel kernel and the short-prompt GEMMs: another summation order, the same tolerance
-    for pos in range(40):
-        ref = m.transformer(toks[pos], pos)
     got = {}
     for tag, opts in (("default", {}), ("skinny", dict(L2Z_PF_PANEL=0))):
         options(**opts)
         s.prefill(toks[:32], 0, w); s.prefill(toks[32:40], 32, w)
         got[tag] = s.logits()
-        np.testing.assert_allclose(got[tag], ref, rtol=LOGIT_RTOL, atol=LOGIT_ATOL, err_msg=tag)
+        np.testing.assert_allclose(got[tag], ref[40], rtol=LOGIT_RTOL, atol=LOGIT_ATOL, err_msg=tag)
         options(L2Z_PF_PANEL=1)
     assert not np.array_equal(got["skinny"], got["default"]), "L2Z_PF_PANEL=0 did not change the path"
+    # ... and the two sides of the upper switch-over: 96 tokens on the tile GEMM (L2Z_PF_PANEL_MAX=64)
+    options(L2Z_PF_PANEL_MAX=64)
+    s.prefill(toks[:96], 0, w)
+    tile = s.logits()
+    options(L2Z_PF_PANEL_MAX=-1)
+    np.testing.assert_allclose(tile, ref[96], rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
     print(f"panel kernel, kv heads {kv_heads}: max |logit - oracle| {worst:.2e}")
     m.close(); s.close(); w.close()
 

@@ -6,7 +6,7 @@ attention and a rank's whole sharded pass are measured inside `pytest -m gpu` wi
 (which also wrote the floors) and held to the committed figures.
 
 Noise: some processes run EVERY launch ~3 % slower (where the big allocations land, clock state).  So groups of figures
-are compared after dividing out the group's common factor (the best-behaved figure's measured / floor): one kernel falling behind
+are compared after dividing out the group's common factor (the lower quartile of measured / floor): one kernel falling behind
 fails at `slack`, everything drifting together only at `common_slack`.  The floors belong to ONE part: on another device
 name / CU count the gates skip -- they are regression tests of this code on the machine it is tuned for, not
 portability tests."""
@@ -37,9 +37,11 @@ def check_group(what, got, floor, slack, common_slack, higher_is_better=False, s
     """got / floor: dicts with the same keys.  ratio > 1 = worse."""
     ratio = {k: (floor[k] / got[k] if higher_is_better else got[k] / floor[k]) for k in floor}
     keys = [k for k in ratio if common_over is None or k in common_over]
-    # the common factor is the BEST-behaved figure's ratio: a process-wide slowdown lifts every ratio alike, a regression
-    # lifts some -- even most -- of them above the rest (a median would swallow a kernel that serves most of the group)
-    common = float(min(ratio[k] for k in keys)) if len(keys) >= 3 else 1.0
+    # the common factor is the LOWER QUARTILE of the ratios: a process-wide slowdown lifts every ratio alike, a regression
+    # lifts some -- even most -- of them above the rest (a median would swallow a kernel that serves most of the group;
+    # the minimum is one noisy reading: the 19-us classifier launch of a small model came in 3 % under its floor and
+    # failed everybody else)
+    common = float(np.percentile([ratio[k] for k in keys], 25)) if len(keys) >= 3 else 1.0
     print(what, {k: round(v, 3) for k, v in got.items()}, f"common factor {common:.3f}")
     bad = [f"{k}: {got[k]:.3f} vs its floor {floor[k]} = {ratio[k] / common:.3f} x after the common factor {common:.3f}"
            for k in ratio if ratio[k] / common > 1.0 + (slack_by_key or {}).get(k, slack)]
@@ -55,7 +57,7 @@ def test_decode_launches_stay_at_their_floor(gpu, ck, pf, shape):
     g = FLOOR["decode_us_per_launch"]
     got = pf.decode_kinds(gpu, ck, shape, g["pos"])
     assert set(got) == set(g["floors"][shape]), (sorted(got), sorted(g["floors"][shape]))
-    check_group(f"{shape} decode, us per launch", got, g["floors"][shape], g["slack"], g["common_slack"],
+    check_group(f"{shape} decode, us per launch", got, g["floors"][shape], g.get("slack_by_shape", {}).get(shape, g["slack"]), g["common_slack"],
                 slack_by_key=g.get("slack_by_kind"), common_over=[k for k in got if k != "attn"])
 
 

@@ -231,11 +231,11 @@ def test_product_does_not_reference_the_oracle():
                     assert needle not in txt, f"{f} references the oracle ({needle})"
                 import re
                 assert not re.search(r"\borc_[a-z_0-9]+\s*\(", txt), f"{f} calls an oracle function"
-    so = os.path.join(pkg, "libllama2_hip.so")
-    if os.path.exists(so):
-        import subprocess
-        needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
-        assert "liboracle" not in needed
+    for so in (os.path.join(pkg, "libllama2_hip.so"), os.path.join(pkg, "libllama2_hip_test.so")):
+        if os.path.exists(so):
+            import subprocess
+            needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
+            assert "liboracle" not in needed
 
 
 def test_shard_plan_rows_and_scheme_b_widths(B, ck):
