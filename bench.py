@@ -1016,17 +1016,24 @@ def multi_main(args) -> None:
                                      "comm": {"legs": legs, "rccl": rccl_rec}}))
             final_rc[0] = 1
         else:
-            # the headline is a scheme-A leg (BASELINE config 5: "row/head-sharded", bit-identical to the unsharded pass);
-            # scheme B (logit tolerance) is reported beside it, and only stands in when no scheme-A leg ran
+            # The headline is the FASTEST leg whose ranks agree, of either scheme (round 6; until round 5 a scheme-A leg).
+            # BASELINE config 5 / north_star name both ("RCCL all-gather / all-reduce"): scheme A's logits are bit-identical
+            # to the unsharded pass, scheme B's within the parity tests' fp32 tolerance (3e-6 observed) and identical on all
+            # ranks -- both inside north_star's correctness bar.  The best leg of each scheme is reported beside it.
             ok_a = [l for l in ok if l.get("scheme") != "B"]
             ok_b = [l for l in ok if l.get("scheme") == "B"]
-            best = max(ok_a or ok_b, key=lambda l: l["tokens_per_s"])
+            best = max(ok, key=lambda l: l["tokens_per_s"])
+            best_a = max(ok_a, key=lambda l: l["tokens_per_s"]) if ok_a else None
             best_b = max(ok_b, key=lambda l: l["tokens_per_s"]) if ok_b else None
             out = lines[best["transport"]]
             out.pop("leg", None)
             out["comm"] = {"transport": best["transport"], "scheme": best.get("scheme"),
-                           "selection": "fastest scheme-A leg whose ranks hold bit-identical logits (scheme-B legs: "
-                                        "reported in scheme_b, headline only if no scheme-A leg ran)",
+                           "selection": "fastest leg whose ranks agree, either scheme (scheme A: logits bit-identical to the "
+                                        "unsharded pass; scheme B: within the fp32 tolerance, ranks bit-identical to each other)",
+                           "scheme_a": ({"transport": best_a["transport"], "tokens_per_s": best_a["tokens_per_s"],
+                                         "vs_headline": best_a["tokens_per_s"] / best["tokens_per_s"],
+                                         "parity": "logits bit-identical to the unsharded pass (SHA-256 of the bytes on every rank)"}
+                                        if best_a else None),
                            "scheme_b": ({"transport": best_b["transport"], "tokens_per_s": best_b["tokens_per_s"],
                                          "vs_headline": best_b["tokens_per_s"] / best["tokens_per_s"],
                                          "parity": "logits within 5e-5 + 5e-5 |x| of the unsharded pass "

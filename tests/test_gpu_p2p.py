@@ -288,7 +288,7 @@ def test_bench_legs_on_one_gpu(gpu, tmp_path):
     assert set(legs) == {"rccl", "p2p-gather", "p2p-consume", "rccl-allreduce", "p2p-allreduce"}
     assert legs["p2p-allreduce"]["ok"] and legs["p2p-allreduce"]["scheme"] == "B" and legs["p2p-gather"]["scheme"] == "A"
     assert legs["p2p-allreduce"]["gathers"] == 2 * 12 + 1 and legs["p2p-gather"]["gathers"] == 4 * 12 + 1
-    assert out["comm"]["scheme"] == "A" and out["comm"]["scheme_b"]["transport"] == "p2p-allreduce"
+    assert out["comm"]["scheme_b"]["transport"] == "p2p-allreduce" and out["comm"]["scheme_a"]["transport"] in ("p2p-gather", "p2p-consume")
     ok = [t for t, l in legs.items() if l["ok"]]
     assert "p2p-gather" in ok and "p2p-consume" in ok, legs
     for t in ok:
@@ -303,7 +303,10 @@ def test_bench_legs_on_one_gpu(gpu, tmp_path):
         assert cd["devices"] == [0, 0] and "ONE GPU" in cd["note"]
         assert pm["structure"] == t and pm["tokens_per_s_free_handovers"] > 0 and pm["measured_over_predicted"] > 0, pm
         assert legs[t]["handover_latency_floor_ms_per_token"] > 0
-    assert out["comm"]["transport"] == max([t for t in ok if legs[t]["scheme"] == "A"], key=lambda t: legs[t]["tokens_per_s"])
+    # round 6: the headline is the fastest agreeing leg of EITHER scheme; the best of each scheme is reported beside it
+    assert out["comm"]["transport"] == max(ok, key=lambda t: legs[t]["tokens_per_s"])
+    assert out["comm"]["scheme"] == legs[out["comm"]["transport"]]["scheme"]
+    assert out["comm"]["scheme_a"]["transport"] == max([t for t in ok if legs[t]["scheme"] == "A"], key=lambda t: legs[t]["tokens_per_s"])
     assert out["value"] == legs[out["comm"]["transport"]]["tokens_per_s"] and out["n_gpus"] == 2
     if not legs["rccl"]["ok"]:
         assert legs["rccl"]["why"], legs["rccl"]
