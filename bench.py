@@ -514,16 +514,19 @@ def single_gpu(args) -> None:
                                     "unit": "TFLOP/s", "frac": flops_tok * n_p / dtp / 1e12 / MFMA_F32_PEAK_TF,
                                     "note": "whole prefill (GEMMs + attention + norms), GEMM flops only "
                                             "in the numerator; v_mfma_f32_32x32x2_f32"}}
-            # shorter prompts: other kernels (<= 16 tokens: the weight-streaming bound short-prompt GEMMs; 17-64: the
-            # K-range panel kernel; 65-256: smaller tiles / split K) -- ms per prompt length, with the bound that applies
+            # shorter prompts: other kernels (<= 16 tokens: the weight-streaming bound short-prompt GEMMs; 17-96: the
+            # K-range panel kernel; 97-256: smaller tiles / split K) -- ms per prompt length, with the bound that applies
             by_len, frac_by_len = {}, {}
             bytes_tok = weight_bytes_per_token(cfg)
-            for n_s in (16, 32, 64, 128):
+            for n_s in (16, 32, 48, 64, 96, 128):   # (48 / 96: the panel kernel's three- and six-tile forms, round 6)
                 if n_s < cfg.seq_len:
                     d = time_prefill(n_s)
                     by_len[str(n_s)] = d * 1e3
-                    frac_by_len[str(n_s)] = ({"bound": "hbm", "frac": bytes_tok / d / 1e9 / HBM_PEAK_GBS} if n_s <= 64 else
-                                             {"bound": "mfma", "frac": flops_tok * n_s / d / 1e12 / MFMA_F32_PEAK_TF})
+                    # both bounds: a chunk of <= ~64 tokens is nearer the weight stream's, a longer one the matrix cores'
+                    frac_by_len[str(n_s)] = {"bound": "hbm" if n_s <= 48 else "mfma",
+                                             "hbm_frac": bytes_tok / d / 1e9 / HBM_PEAK_GBS,
+                                             "mfma_frac": flops_tok * n_s / d / 1e12 / MFMA_F32_PEAK_TF}
+                    frac_by_len[str(n_s)]["frac"] = frac_by_len[str(n_s)]["hbm_frac" if n_s <= 48 else "mfma_frac"]
             prefill["ms_by_prompt_tokens"] = by_len
             prefill["frac_by_prompt_tokens"] = frac_by_len
         except Exception as e:  # noqa: BLE001
