@@ -14,11 +14,11 @@ struct Tunables {
                                //                     leave the peer's kernels room to run; never set with a GPU per rank
     int attn_split = -1;       // L2Z_ATTN_SPLIT      0: never split the decode attention; n > 0: n chunks per head at every position (changes
                                //                     rounding: the chunk count is part of the arithmetic).  Tests drive the split form on toy
-                               //                     contexts with it; default min(8, CUs / heads): pos 2047 at 7B 19.7 us per layer vs 61 unsplit
+                               //                     contexts with it; default min(8, CUs / heads): 19.7 us per layer at pos 2047 of the 7B shape
     int attn_split_pos = -1;   // L2Z_ATTN_SPLIT_POS  first position that takes the split form (default 256: below, one block per head wins by 1-3 us)
-    int fuse_small = 1;        // L2Z_FUSE_SMALL      0: small MHA models keep separate qkv / attention launches (fused: stories15M 6,900 -> 7,700 tok/s;
+    int fuse_small = 1;        // L2Z_FUSE_SMALL      0: small MHA models keep separate qkv / attention launches (fused: 5 -> 4 launches per layer;
                                //                     rounds differently from the unfused launches, so tests that compare with a shard group set 0)
-    int no_graph = 0;          // L2Z_NO_GRAPH        1: launch eagerly (debugging, rocprof of single launches; graphs: +9 % tok/s at 7B, 3x at 15M)
+    int no_graph = 0;          // L2Z_NO_GRAPH        1: launch eagerly (debugging, per-launch PMC passes; a graph replay is one host call per token)
     int prefer_rccl = 0;       // L2Z_COMM=rccl       use RCCL even when the peer-write transport is connected (bench's rccl legs)
     int p2p_consume = -1;      // L2Z_P2P_CONSUME     1: consumers read their gathered input as LL words while staging x (no gather launches);
                                //                     0: a gather launch per gathered vector; -1 (default): by shape -- the consumer-side form for

@@ -31,7 +31,7 @@ def test_gate_rule_on_synthetic_readings():
         check_group("prefill", {k: v * 1.08 for k, v in f.items()}, f, g["slack"], g["common_slack"])
     d = FLOOR["decode_us_per_launch"]
     f15 = d["floors"]["stories15M"]
-    fused = dict(f15, qkv=f15["qkv"] * 1.07)                        # fused_qkv_attn_kernel + 7 % (launch-floor launches: 6 %)
+    fused = dict(f15, qkv=f15["qkv"] * 1.2)                         # fused_qkv_attn_kernel + 20 % (launch-floor launches: 15 % per launch; tok/s: 4 %)
     with pytest.raises(AssertionError, match="qkv"):
         check_group("15M", fused, f15, d["slack_by_shape"]["stories15M"], d["common_slack"], slack_by_key=d["slack_by_kind"])
     noisy = dict(f15, cls=f15["cls"] * 0.97, wo=f15["wo"] * 1.03)   # one reading 3 % under its floor must not fail the others
