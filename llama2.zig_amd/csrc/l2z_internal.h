@@ -252,8 +252,8 @@ hipError_t launch_prefill_gemm_kv_pair(const float *x, int ldx, const float *wk,
                                        float *vcache, int ldkv, int P, int nkv, int K, int pos0, const float2 *rope,
                                        int head_size, hipStream_t st, int n_scale = 1, size_t kv_head_stride = 0,
                                        int sk = 1);
-hipError_t launch_prefill_rmsnorm(float *o, const float *x, const float *w, int n, int P,
-                                  hipStream_t st);
+hipError_t launch_prefill_rmsnorm(float *o, int ldo, const float *x, const float *w, int n, int P,
+                                  hipStream_t st);   // o: rows of ldo floats (the pad columns are left alone)
 hipError_t launch_prefill_embed(float *x, const float *tok_emb, const int *tokens, int dim, int P,
                                 hipStream_t st);
 // kv_row / kv_head: floats between timesteps of one kv head / between kv heads (AttnArgs)

@@ -92,6 +92,7 @@ struct l2z_runstate {
     // batched prefill scratch (allocated on first l2z_prefill): [kPrefillChunk, dim|hidden]
     float *pf_x = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_att = nullptr;
     float *pf_h1 = nullptr;
+    int pf_ld_xn = 0, pf_ld_att = 0, pf_ld_h1 = 0;   // row pitches of pf_xn / pf_att / pf_h1 (prefill_host.cpp pf_ld: zero-padded)
     float *pf_stage = nullptr;  // sharded: [world][P, n_loc] blocks of the matrix being gathered
     float *pf_part = nullptr;   // scheme B: this rank's partial [P, dim] product of its column shard of Wo / W2
     int *pf_tokens = nullptr;

@@ -7,7 +7,7 @@ namespace l2z {
 namespace {
 
 // rows of x -> rmsnorm rows (main.zig:432-468), one block per token
-__global__ __launch_bounds__(kPfBlock) void prefill_rmsnorm(float *o, const float *x, const float *w,
+__global__ __launch_bounds__(kPfBlock) void prefill_rmsnorm(float *o, int ldo, const float *x, const float *w,
                                                             int n, int P)
 {
     __shared__ float red[8];
@@ -49,11 +49,11 @@ __global__ __launch_bounds__(kPfBlock) void prefill_rmsnorm(float *o, const floa
                 v4f r;
                 r.x = (xv[k].x * s) * wv.x; r.y = (xv[k].y * s) * wv.y;
                 r.z = (xv[k].z * s) * wv.z; r.w = (xv[k].w * s) * wv.w;
-                ((v4f *)(o + (size_t)t * n))[i] = r;
+                ((v4f *)(o + (size_t)t * ldo))[i] = r;
             }
         }
     } else {
-        for (int i = threadIdx.x; i < n; i += blockDim.x) o[(size_t)t * n + i] = (xr[i] * s) * w[i];
+        for (int i = threadIdx.x; i < n; i += blockDim.x) o[(size_t)t * ldo + i] = (xr[i] * s) * w[i];
     }
 }
 
@@ -434,10 +434,10 @@ __global__ __launch_bounds__(kPfBlock) void prefill_attention_tiled(const float 
 
 }  // namespace
 
-hipError_t launch_prefill_rmsnorm(float *o, const float *x, const float *w, int n, int P,
+hipError_t launch_prefill_rmsnorm(float *o, int ldo, const float *x, const float *w, int n, int P,
                                   hipStream_t st)
 {
-    hipLaunchKernelGGL(prefill_rmsnorm, dim3(P), dim3(kPfBlock), 0, st, o, x, w, n, P);
+    hipLaunchKernelGGL(prefill_rmsnorm, dim3(P), dim3(kPfBlock), 0, st, o, ldo, x, w, n, P);
     return hipGetLastError();
 }
 

@@ -79,6 +79,17 @@ __device__ __forceinline__ void lds_dma16_nt(const float *g, float *lds)
     __builtin_amdgcn_global_load_lds(g, lds, 16, 0, 2);
 }
 
+// Loop bound of a kernel that multiplies whole `granule`-k stages (round 6): the product's K rounded up.  The columns
+// past K are ZEROS in every activation matrix of the batched pass (prefill_host.cpp pf_ld: rows padded to a multiple of
+// 256 floats, >= 768), and whatever follows the row in W -- the next row, the next tensor, the zeroed slack behind the
+// blob (weights.cpp kBlobSlackFloats) -- is finite: the extra products are exact zeros.  -1: the activation rows are
+// not padded that far (a caller that did not come through prefill_host.cpp).
+inline int pad_k(int K, int granule, int ldx)
+{
+    const int ke = (K + granule - 1) / granule * granule;
+    return ke <= ldx ? ke : -1;
+}
+
 // prefill_skinny.hip: the short-prompt (P <= 64 tokens) GEMM forms; picks the form and the token tiling
 hipError_t launch_prefill_skinny(int epi, const GemmArgs &a, hipStream_t st);
 hipError_t launch_prefill_skinny_pair(int epi, const GemmArgs &a, hipStream_t st);  // G_SWIGLU: w | w2 gated; G_QKV: wk | wv

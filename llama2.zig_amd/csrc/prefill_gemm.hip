@@ -141,154 +141,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, v16f (&acc)[TM]
         }
 }
 
-// Block tile (64 TM tokens) x (64 TN features), 4 waves as 2 x 2, each wave TM x TN MFMA tiles of
-// 32 x 32.  MFMA 32x32x2 f32: D[i][j] += A[i][k] B[k][j] with
+// MFMA 32x32x2 f32: D[i][j] += A[i][k] B[k][j] with
 //   A operand: lane l holds A[i = l & 31][k = l >> 5]      -> X[token i][k]
 //   B operand: lane l holds B[k = l >> 5][j = l & 31]      -> W[feature j][k]
 //   D: lane l, reg r holds D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31]
-// KS groups of 4 waves split each stage's k range (two waves per SIMD at KS = 2) and are summed
-// through LDS at the end.  Stages are double buffered in LDS (see the loop), weights non-temporal.
-template <int EPI, int TM, int TN, int BK, int KS>
-__global__ __launch_bounds__(256 * KS) void prefill_gemm(const GemmArgs a)
-{
-    constexpr int LDK = BK + 1;  // padded row: 32 rows hit 32 distinct banks
-    constexpr int RF = BK / 4;   // float4 per tile row
-    constexpr int BMt = 64 * TM, BNt = 64 * TN;
-    constexpr int NT = 256 * KS;  // KS groups of 4 waves; group g multiplies its 1/KS of each stage's k
-    constexpr int XL = BMt * BK / 4 / NT, WL = BNt * BK / 4 / NT;  // float4 per thread
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *xs = smem, *ws = smem + BMt * LDK;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) & 1, wn = wave & 1, kg = wave >> 2;
-    const int n0 = blockIdx.x * BNt, m0 = blockIdx.y * BMt;
-    const v4f zero = {0.f, 0.f, 0.f, 0.f};
-    // float4 slot f of a tile: row f / 8, columns 4 (f % 8)
-    v4f xv[XL], wv[WL];
-    // clamped addresses: every load is legal, out-of-range values are zeroed when the stage is
-    // written to LDS (a select right after the load would wait for it)
-    // piece p < XL: float4 p of the X tile; p >= XL: float4 p - XL of the W tile
-    auto gload_piece = [&](int p, int k0) {
-        if (p < XL) {
-            const int f = tid + NT * p, r = f / RF, c = (f % RF) * 4;
-            xv[p] = *(const v4f *)(a.x + (size_t)min(m0 + r, a.P - 1) * a.ldx + min(k0 + c, a.K - 4));
-        } else {
-            const int f = tid + NT * (p - XL), r = f / RF, c = (f % RF) * 4;
-            wv[p - XL] = __builtin_nontemporal_load(
-                (const v4f *)(a.w + (size_t)min(n0 + r, a.N - 1) * a.ldw + min(k0 + c, a.K - 4)));
-        }
-    };
-    auto sstore_piece = [&](int p, int k0) {
-        if (p < XL) {
-            const int f = tid + NT * p, r = f / RF, c = (f % RF) * 4;
-            const bool ok = m0 + r < a.P && k0 + c < a.K;  // K % 4 == 0: a float4 is all in or out
-            const v4f v = ok ? xv[p] : zero;
-            float *d = xs + r * LDK + c;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-        } else {
-            const int f = tid + NT * (p - XL), r = f / RF, c = (f % RF) * 4;
-            const bool ok = n0 + r < a.N && k0 + c < a.K;
-            const v4f v = ok ? wv[p - XL] : zero;
-            float *d = ws + r * LDK + c;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-        }
-    };
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int p = 0; p < XL + WL; p++) gload_piece(p, k0);
-    };
-    auto sstore = [&](int k0) {
-#pragma unroll
-        for (int p = 0; p < XL + WL; p++) sstore_piece(p, k0);
-    };
-    v16f acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
-    // MFMA step t of a stage multiplies the k pair (t, t + BK/2): lanes 32..63 then read LDS banks
-    // 32 away from lanes 0..31 (row stride BK+1 words), conflict-free; (t, t+1) collides 2-way
-    const int arow = (wm * 32 * TM + (lane & 31)) * LDK + (lane >> 5) * (BK / 2);
-    const int brow = (wn * 32 * TN + (lane & 31)) * LDK + (lane >> 5) * (BK / 2);
-    // two LDS buffers: stage s+1 is written (from registers) and stage s+2 requested from HBM
-    // before stage s is multiplied; one barrier per stage
-    constexpr int STAGE = (BMt + BNt) * LDK;
-    gload(0);
-    sstore(0);
-    if (BK < a.K) gload(BK);
-    __syncthreads();
-    int buf = 0;
-    constexpr int STEPS = BK / 2 / KS;  // MFMA steps of this wave group per stage
-    constexpr int PIECES = XL + WL;     // float4 per thread per stage
-    constexpr int AH = 3;               // LDS operand reads run this many MFMA steps ahead
-    for (int k0 = 0; k0 < a.K; k0 += BK) {
-        // Stage s is multiplied while stage s+1 goes from registers into the other LDS buffer and
-        // stage s+2 is requested from HBM into the registers just freed -- piece by piece between
-        // the MFMA steps: LDS operations keep their program order, so the interleaving has to be
-        // in the source.  (Copy first, then all MFMAs, costs a fifth of the run time: one wave per
-        // SIMD, and the barrier puts all waves in the same phase.)  No branch in the body: the
-        // last stages store / load clamped data nobody reads.
-        xs = smem + (buf ^ 1) * STAGE; ws = xs + BMt * LDK;
-        const float *xr = smem + buf * STAGE, *wr = xr + BMt * LDK;
-        float av[STEPS][TM], bv[STEPS][TN];
-        auto lds_read = [&](int t) {
-#pragma unroll
-            for (int i = 0; i < TM; i++) av[t][i] = xr[arow + i * 32 * LDK + kg * STEPS + t];
-#pragma unroll
-            for (int j = 0; j < TN; j++) bv[t][j] = wr[brow + j * 32 * LDK + kg * STEPS + t];
-        };
-#pragma unroll
-        for (int t = 0; t < AH && t < STEPS; t++) lds_read(t);
-#pragma unroll
-        for (int t = 0; t < STEPS; t++) {
-            if (t + AH < STEPS) lds_read(t + AH);
-#pragma unroll
-            for (int p = (t * PIECES) / STEPS; p < ((t + 1) * PIECES) / STEPS; p++) {
-                sstore_piece(p, k0 + BK);
-                gload_piece(p, k0 + 2 * BK);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][i], bv[t][j], acc[i][j], 0, 0, 0);
-            // pin the step: the scheduler otherwise gathers all selects (and their vmcnt waits) at
-            // the top of the stage and sinks the global loads to its end
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
-        buf ^= 1;
-    }
-    if (KS > 1) {
-        // partial sums of wave groups 1.. -> LDS -> added by group 0 in group order (the last
-        // barrier of the loop has already retired every read of the stage buffers)
-        float *red = smem;  // [KS-1][4 waves][TM*TN*16][64 lanes]
-        if (kg > 0) {
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        red[((((kg - 1) * 4 + (wave & 3)) * TM * TN + i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
-        }
-        __syncthreads();
-        if (kg > 0) return;
-#pragma unroll
-        for (int g = 1; g < KS; g++)
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        acc[i][j][r] += red[((((g - 1) * 4 + wave) * TM * TN + i * TN + j) * 16 + r) * 64 + lane];
-    }
-    gemm_epilogue<EPI, TM, TN>(a, acc, n0, m0, wm, wn, lane);
-}
+// (Rounds 1-5 also carried a register-staged form of the tile kernel -- operands through VGPRs and ds_write, any
+// K % 4 == 0 -- as the fallback for K % 64 != 0; since round 6 such products run the kernel below over K rounded up to
+// whole stages against zero-padded activation rows: pad_k, prefill_common.h.)
 
-// The same tile product with the operands brought in by DIRECT-TO-LDS loads
+// The tile product with the operands brought in by DIRECT-TO-LDS loads
 // (global_load_lds_dwordx4, gfx950): no VGPR round trip and no LDS-write instructions -- in the
 // register-staged kernel above the copy (6 float4 loads -> 24 ds_write_b32 per thread and stage,
 // the row padding forbids wider writes) costs 13 % of the run time (ablation).
@@ -594,38 +455,21 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
     }
 }
 
-template <int EPI, int TM, int TN, int BK, int KS>
+template <int EPI, int TM, int TN, int KS>
 hipError_t gemm_launch_t(const GemmArgs &a, hipStream_t st)
 {
     constexpr int BMt = 64 * TM, BNt = 64 * TN;
-    static_assert((BMt * BK / 4) % (256 * KS) == 0 && (BNt * BK / 4) % (256 * KS) == 0, "tile copy");
-    static_assert((BK / 2) % KS == 0 && ((BK / 2 / KS) % 8 == 0 || BK / 2 / KS < 8), "k steps");
-    size_t lds = 2 * (size_t)(BMt + BNt) * (BK + 1) * sizeof(float);
+    static_assert((BMt / 4) % (4 * KS) == 0 && (BNt / 4) % (4 * KS) == 0, "tile rows per wave");
+    if (a.K % 64 != 0 || a.ldx % 4 != 0) return hipErrorInvalidValue;   // (the launchers round K up: pad_k)
     const size_t red = (size_t)(KS - 1) * 4 * TM * TN * 16 * 64 * sizeof(float);
+    size_t lds = 2 * (size_t)(BMt + BNt) * 64 * sizeof(float);
     if (red > lds) lds = red;
-    static bool attr = false;
-    if (!attr && lds > 48 * 1024) {
-        (void)hipFuncSetAttribute((const void *)prefill_gemm<EPI, TM, TN, BK, KS>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
-    dim3 grid((a.N + BNt - 1) / BNt, (a.P + BMt - 1) / BMt);
-    if constexpr (BK == 64 && (BMt / 4) % (4 * KS) == 0 && (BNt / 4) % (4 * KS) == 0) {
-        // direct-to-LDS operand loads: whole 64-float stages only, 16-byte aligned rows
-        if (a.K % 64 == 0 && a.ldx % 4 == 0) {
-            size_t lds2 = 2 * (size_t)(BMt + BNt) * 64 * sizeof(float);
-            if (red > lds2) lds2 = red;
-            const void *fn = (const void *)prefill_gemm_dma<EPI, TM, TN, KS, false>;
-            if (lds2 > 48 * 1024)
-                (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-            GemmArgs args = a;
-            const dim3 grid1 = dma_grid((int)grid.x, (int)grid.y, &args);
-            void *params[] = {&args};
-            return hipLaunchKernel(fn, grid1, dim3(256 * KS), params, lds2, st);
-        }
-    }
-    hipLaunchKernelGGL((prefill_gemm<EPI, TM, TN, BK, KS>), grid, dim3(256 * KS), lds, st, a);
-    return hipGetLastError();
+    const void *fn = (const void *)prefill_gemm_dma<EPI, TM, TN, KS, false>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    GemmArgs args = a;
+    const dim3 grid1 = dma_grid((a.N + BNt - 1) / BNt, (a.P + BMt - 1) / BMt, &args);
+    void *params[] = {&args};
+    return hipLaunchKernel(fn, grid1, dim3(256 * KS), params, lds, st);
 }
 
 // the direct-to-LDS tile kernel with fewer waves per block -- 32 x 64 (1 x 2 waves per k-group) and
@@ -653,13 +497,13 @@ hipError_t gemm_launch(const GemmArgs &a, hipStream_t st)
     // the LDS operand reads per MFMA (measured on the 7B shape: 94.7 vs 89.5 TFLOP/s at 512)
     hipError_t e;
     switch (choose_tile(a.N, a.P, false)) {
-    case TILE_128x128: return gemm_launch_t<EPI, 2, 2, 64, 2>(a, st);
-    case TILE_128x64: return gemm_launch_t<EPI, 2, 1, 64, 2>(a, st);
+    case TILE_128x128: return gemm_launch_t<EPI, 2, 2, 2>(a, st);
+    case TILE_128x64: return gemm_launch_t<EPI, 2, 1, 2>(a, st);
     case TILE_32x64: if (gemm_launch_small<EPI, 1, 2>(a, st, &e)) return e; break;
     case TILE_32x32: if (gemm_launch_small<EPI, 1, 1>(a, st, &e)) return e; break;
     default: break;
     }
-    return gemm_launch_t<EPI, 1, 1, 64, 2>(a, st);
+    return gemm_launch_t<EPI, 1, 1, 2>(a, st);
 }
 
 // ---- the split-K family (prefill_gemm_dma SPLIT) ----
@@ -820,7 +664,8 @@ hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float 
     a.ldw = ldw > 0 ? ldw : K;
     constexpr int skinny_max = Tunables::pf_skinny_max;
     if (P <= skinny_max && sk <= 1) return launch_prefill_skinny_pair(G_SWIGLU, a, st);  // prefill_skinny.hip (or not supported)
-    if (K % 64 != 0 || ldx % 4 != 0) return hipErrorNotSupported;
+    K = a.K = pad_k(K, 64, ldx);   // whole 64-k stages (see pad_k)
+    if (K < 0 || ldx % 4 != 0) return hipErrorInvalidValue;
     if (sk > 1) return gemm_launch_sk<G_STORE, true>(a, N, sk, ws, st);
     {
         const KgsChoice c = choose_kgs(N, P, K, true, ws);
@@ -854,14 +699,17 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
                                    size_t kv_head_stride, int n_scale, int sk, const SplitKWs *ws)
 {
     constexpr int skinny_max = Tunables::pf_skinny_max;
-    if ((P <= skinny_max && sk <= 1) || K % 64 != 0 || ldx % 4 != 0) return hipErrorNotSupported;
+    if (P <= skinny_max && sk <= 1) return hipErrorNotSupported;
     if (((uintptr_t)x & 15) || ((uintptr_t)wq & 15) || ((uintptr_t)wk & 15) || ((uintptr_t)wv & 15)) return hipErrorInvalidValue;
+    const int ldw_true = K;        // W rows are K floats apart; the loop runs over whole 64-k stages (see pad_k)
+    K = pad_k(K, 64, ldx);
+    if (K < 0 || ldx % 4 != 0) return hipErrorInvalidValue;
     const int N = nq + 2 * nkv;
     if (sk > 1) {  // the split family: 64-feature tiles (a tile must not straddle q | k | v)
         if (nq % 64 != 0 || nkv % 64 != 0) return hipErrorNotSupported;
         GemmArgs as = {x, nullptr, wq, q_out, q_out, P, N, K, ldx, ldq, ldq, pos0, rope, head_size, n_scale > 0 ? n_scale : 1,
                        wk, wv, kcache, vcache, nq, nkv, ldkv, kv_head_stride, 0, 0};
-        as.ldw = K;
+        as.ldw = ldw_true;
         return gemm_launch_sk<G_QKV, false>(as, N, sk, ws, st);
     }
     {
@@ -870,7 +718,7 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
         if (c.use && nq % feat_k == 0 && nkv % feat_k == 0) {
             GemmArgs ak = {x, nullptr, wq, q_out, q_out, P, N, K, ldx, ldq, ldq, pos0, rope, head_size, n_scale > 0 ? n_scale : 1,
                            wk, wv, kcache, vcache, nq, nkv, ldkv, kv_head_stride, 0, 0};
-            ak.ldw = K;
+            ak.ldw = ldw_true;
             return gemm_launch_kgs<G_QKV, false>(ak, N, c.tile, ws, st);
         }
     }
@@ -887,7 +735,7 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
     }
     GemmArgs a = {x, nullptr, wq, q_out, q_out, P, N, K, ldx, ldq, ldq, pos0, rope, head_size, 1,
                   wk, wv, kcache, vcache, nq, nkv, ldkv, kv_head_stride, 0, 0};
-    a.ldw = K;
+    a.ldw = ldw_true;
     constexpr int KS = 2;
     const int tok = tf == TILE_128x64 ? 128 : tf == TILE_64x64 ? 64 : 32;
     const void *fn = tf == TILE_128x64 ? (const void *)prefill_gemm_dma<G_QKV, 2, 1, KS, false>
@@ -932,6 +780,8 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
     a.ldw = ldw > 0 ? ldw : K;
     constexpr int skinny_max = Tunables::pf_skinny_max;
     if (P <= skinny_max && sk <= 1) return launch_prefill_skinny(epi, a, st);  // prefill_skinny.hip
+    K = a.K = pad_k(K, 64, ldx);   // whole 64-k stages (see pad_k)
+    if (K < 0) return hipErrorInvalidValue;
     if (sk > 1) {
         if (K % (64 * sk) != 0) return hipErrorInvalidValue;
         switch (epi) {

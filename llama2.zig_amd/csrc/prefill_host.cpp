@@ -17,6 +17,17 @@ using namespace l2z;
 namespace {
 #define kPrefillChunk prefill_chunk_tokens()
 
+// Row pitch of the activation matrices the GEMMs read (pf_xn, pf_att, pf_h1): the width rounded up to a multiple of 256
+// floats, at least 768, the pad columns ZERO and never written.  Every GEMM kernel of the pass multiplies whole stages of
+// K (64 / 128 / 256 floats): it runs over K rounded up (pad_k), reads zeros from these rows and, past the end of a W row,
+// whatever finite floats follow -- so any K that is a multiple of 4 takes the direct-to-LDS kernels (until round 5
+// K % 64 != 0 fell back to register-staged forms: stories15M's dim 288, stories42M's hidden_dim 1376).
+int pf_ld(int n)
+{
+    const int r = (n + 255) / 256 * 256;
+    return r < 768 ? 768 : r;
+}
+
 int prefill_alloc(l2z_runstate *s, int need)
 {
     const l2z_config &c = s->cfg;
@@ -33,10 +44,12 @@ int prefill_alloc(l2z_runstate *s, int need)
     const size_t widest = (size_t)(c.dim > c.hidden_dim ? c.dim : c.hidden_dim);
     // (scheme B reads the local attention / hidden blocks as rows of the column shards' PADDED width: a 1-rank group's
     // padded width can exceed the model's)
-    const size_t att_w = std::max((size_t)c.dim, s->sh.scheme_b ? (size_t)s->sh.dimc_pad : (size_t)0);
-    const size_t h1_w = std::max((size_t)c.hidden_dim, s->sh.scheme_b ? (size_t)s->sh.hidc_pad : (size_t)0);
+    const size_t att_w = (size_t)pf_ld(std::max(c.dim, s->sh.scheme_b ? s->sh.dimc_pad : 0));
+    const size_t h1_w = (size_t)pf_ld(std::max(c.hidden_dim, s->sh.scheme_b ? s->sh.hidc_pad : 0));
+    const size_t xn_w = (size_t)pf_ld(c.dim);
+    s->pf_ld_xn = (int)xn_w; s->pf_ld_att = (int)att_w; s->pf_ld_h1 = (int)h1_w;
     struct { void **p; size_t bytes; } want[] = {
-        {(void **)&s->pf_x, P * c.dim * 4},   {(void **)&s->pf_xn, P * c.dim * 4},
+        {(void **)&s->pf_x, P * c.dim * 4},   {(void **)&s->pf_xn, P * xn_w * 4},
         {(void **)&s->pf_q, P * c.dim * 4},   {(void **)&s->pf_att, P * att_w * 4},
         {(void **)&s->pf_h1, P * h1_w * 4},
         // sharded: [world][P, n / world] blocks of the matrix being gathered
@@ -54,12 +67,11 @@ int prefill_alloc(l2z_runstate *s, int need)
         }
     }
     s->pf_cap = (int)P;
-    if (s->sh.scheme_b) {
-        // the local attention / hidden blocks are read as rows of the column shards' PADDED width: the pad columns are
-        // never written, and must be zeros (finite) against the shards' zero columns
-        L2Z_HIP(hipMemsetAsync(s->pf_att, 0, P * att_w * 4, s->stream));
-        L2Z_HIP(hipMemsetAsync(s->pf_h1, 0, P * h1_w * 4, s->stream));
-    }
+    // the pad columns are never written and must be zeros: the GEMMs multiply them against whatever follows a W row
+    // (scheme B: against the column shards' own zero columns)
+    L2Z_HIP(hipMemsetAsync(s->pf_xn, 0, P * xn_w * 4, s->stream));
+    L2Z_HIP(hipMemsetAsync(s->pf_att, 0, P * att_w * 4, s->stream));
+    L2Z_HIP(hipMemsetAsync(s->pf_h1, 0, P * h1_w * 4, s->stream));
     if (s->pf_sk.part == nullptr) {
         // split-K family of the tile GEMM (chunks of 33 ... 256 tokens): accumulator dumps of up to 4 K ranges of
         // the widest launch of a layer (q | k | v, or W1 | W3 side by side), one arrival counter per output tile
@@ -94,8 +106,8 @@ StageOut stage_out(const l2z_runstate *s, int k)
     const l2z_config &c = s->cfg;
     const Shard &sh = s->sh;
     switch (k) {
-        case PF_ATT: return {s->pf_att, sh.dim_loc, c.dim};
-        case PF_H1: return {s->pf_h1, sh.hid_loc, c.hidden_dim};
+        case PF_ATT: return {s->pf_att, sh.dim_loc, s->pf_ld_att};
+        case PF_H1: return {s->pf_h1, sh.hid_loc, s->pf_ld_h1};
         default: return {s->pf_x, sh.dim_loc, c.dim};  // PF_WO, PF_W2
     }
 }
@@ -119,9 +131,11 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
     // K ranges per output tile (split-K family, prefill_gemm.hip): part of the arithmetic, so taken from the WHOLE
     // model's matrices -- q | k | v as one launch's width whether or not they go out as one launch
     const int kvd_whole = c.n_kv_heads * hs;
-    const int sk_qkv = prefill_split_k((long long)dim + 2 * kvd_whole, P, dim, false);
-    const int sk_wo = prefill_split_k(dim, P, dim, false), sk_w2 = prefill_split_k(dim, P, hid, false);
-    const int sk_h1 = prefill_split_k(hid, P, dim, true);
+    const int ldxn = s->pf_ld_xn, ldatt = s->pf_ld_att, ldh1 = s->pf_ld_h1;   // padded rows of the GEMM inputs (pf_ld)
+    const int dim64 = (dim + 63) / 64 * 64, hid64 = (hid + 63) / 64 * 64;     // K as the tile GEMM walks it
+    const int sk_qkv = prefill_split_k((long long)dim + 2 * kvd_whole, P, dim64, false);
+    const int sk_wo = prefill_split_k(dim, P, dim64, false), sk_w2 = prefill_split_k(dim, P, hid64, false);
+    const int sk_h1 = prefill_split_k(hid, P, dim64, true);
     const SplitKWs *ws = &s->pf_sk;
     // Chunks of <= 32 tokens of matrices that stream from HBM: the K-range panel kernel (prefill_panel.hip), chosen from
     // the WHOLE model's matrix so that a shard takes what the unsharded pass takes.
@@ -147,11 +161,11 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
     };
     bool taken = false;
     if (k == PF_ATT || k == PF_H1)   // :305 / :398
-        L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, s->pf_x, (k == PF_ATT ? w->rms_att : w->rms_ffn) + (size_t)l * dim, dim, P, st));
+        L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, ldxn, s->pf_x, (k == PF_ATT ? w->rms_att : w->rms_ffn) + (size_t)l * dim, dim, P, st));
     if (k == PF_ATT) {
         {
             PanelProduct pp = {};
-            pp.x = s->pf_xn; pp.ldx = dim; pp.K = dim;
+            pp.x = s->pf_xn; pp.ldx = ldxn; pp.K = dim;
             pp.w0 = w->wq + (size_t)l * sh.dim_loc * dim; pp.w1 = w->wk + (size_t)l * kvd * dim; pp.w2 = w->wv + (size_t)l * kvd * dim;
             pp.rows0 = sh.dim_loc; pp.rows1 = kvd; pp.rows2 = kvd;
             pp.mode = PANEL_QKV; pp.out = s->pf_q; pp.ldo = sh.dim_loc; pp.outk = kc; pp.outv = vc; pp.ldkv = kvd;
@@ -163,18 +177,18 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
         // the tile kernel takes the shape (:308-358), else three
         const float *wq = w->wq + (size_t)l * sh.dim_loc * dim, *wk = w->wk + (size_t)l * kvd * dim,
                     *wv = w->wv + (size_t)l * kvd * dim;
-        const hipError_t qe = launch_prefill_gemm_qkv(s->pf_xn, dim, wq, wk, wv, s->pf_q, sh.dim_loc, kc, vc, kvd, P,
+        const hipError_t qe = launch_prefill_gemm_qkv(s->pf_xn, ldxn, wq, wk, wv, s->pf_q, sh.dim_loc, kc, vc, kvd, P,
                                                       sh.dim_loc, kvd, dim, pos0, s->rope, hs, st, kvh_stride, sh.world,
                                                       sk_qkv, ws);
         if (qe == hipErrorNotSupported) {
-            L2Z_HIP(launch_prefill_gemm(PG_ROPE, s->pf_xn, dim, wq, s->pf_q, sh.dim_loc, P, sh.dim_loc, dim, pos0,
+            L2Z_HIP(launch_prefill_gemm(PG_ROPE, s->pf_xn, ldxn, wq, s->pf_q, sh.dim_loc, P, sh.dim_loc, dim, pos0,
                                         s->rope, hs, st, nullptr, 0, sh.world, 0, sk_qkv, ws));  // :308-351
-            const hipError_t ke = launch_prefill_gemm_kv_pair(s->pf_xn, dim, wk, wv, kc, vc, kvd, P, kvd, dim, pos0,
+            const hipError_t ke = launch_prefill_gemm_kv_pair(s->pf_xn, ldxn, wk, wv, kc, vc, kvd, P, kvd, dim, pos0,
                                                               s->rope, hs, st, sh.world, kvh_stride, sk_qkv);  // short prompts: k | v together
             if (ke == hipErrorNotSupported) {
-                L2Z_HIP(launch_prefill_gemm(PG_ROPE_CACHE, s->pf_xn, dim, wk, kc, kvd, P, kvd, dim, pos0, s->rope, hs,
+                L2Z_HIP(launch_prefill_gemm(PG_ROPE_CACHE, s->pf_xn, ldxn, wk, kc, kvd, P, kvd, dim, pos0, s->rope, hs,
                                             st, nullptr, 0, sh.world, kvh_stride, sk_qkv, ws));   // :354-357
-                L2Z_HIP(launch_prefill_gemm(PG_CACHE, s->pf_xn, dim, wv, vc, kvd, P, kvd, dim, pos0, s->rope, hs, st,
+                L2Z_HIP(launch_prefill_gemm(PG_CACHE, s->pf_xn, ldxn, wv, vc, kvd, P, kvd, dim, pos0, s->rope, hs, st,
                                             nullptr, 0, sh.world, kvh_stride, sk_qkv, ws));       // :358
             } else {
                 L2Z_HIP(ke);
@@ -189,12 +203,12 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
         const float *res = s->pf_x + sh.dim0;
         {
             PanelProduct pp = {};
-            pp.x = s->pf_att; pp.ldx = dim; pp.K = dim; pp.w0 = w->wo + (size_t)l * sh.dim_loc * dim; pp.rows0 = sh.dim_loc;
+            pp.x = s->pf_att; pp.ldx = ldatt; pp.K = dim; pp.w0 = w->wo + (size_t)l * sh.dim_loc * dim; pp.rows0 = sh.dim_loc;
             pp.mode = PANEL_RESID; pp.out = out; pp.ldo = ldo; pp.res = res; pp.ldres = dim;
             L2Z_TRY(panel(pp, dim, &taken));
         }
         if (!taken)
-        L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_att, dim, w->wo + (size_t)l * sh.dim_loc * dim, out, ldo,
+        L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_att, ldatt, w->wo + (size_t)l * sh.dim_loc * dim, out, ldo,
                                     P, sh.dim_loc, dim, pos0, s->rope, hs, st, res, dim, sh.world, 0, sk_wo, ws));   // :392-395
     } else if (k == PF_H1) {
         // :405-416: W1 and W3 in one launch with silu(a) * b as its epilogue where the tile kernel
@@ -203,17 +217,17 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
         const float *w1 = w->w1 + (size_t)l * sh.hid_loc * 2 * dim, *w3 = w->w3 + (size_t)l * sh.hid_loc * 2 * dim;
         {
             PanelProduct pp = {};   // the shared slot as ONE matrix of 2 hid_loc rows: row 2p = W1 row p, 2p + 1 = W3 row p
-            pp.x = s->pf_xn; pp.ldx = dim; pp.K = dim; pp.w0 = w1; pp.rows0 = 2 * sh.hid_loc;
+            pp.x = s->pf_xn; pp.ldx = ldxn; pp.K = dim; pp.w0 = w1; pp.rows0 = 2 * sh.hid_loc;
             pp.mode = PANEL_SWIGLU; pp.out = out; pp.ldo = ldo;
             L2Z_TRY(panel(pp, 2LL * hid, &taken));
         }
         if (taken) return L2Z_OK;
-        const hipError_t pe = launch_prefill_gemm_swiglu_pair(s->pf_xn, dim, w1, w3, out, ldo, P, sh.hid_loc, dim, st, sh.world,
+        const hipError_t pe = launch_prefill_gemm_swiglu_pair(s->pf_xn, ldxn, w1, w3, out, ldo, P, sh.hid_loc, dim, st, sh.world,
                                                               sk_h1, ws, 2 * dim);
         if (pe == hipErrorNotSupported) {
-            L2Z_HIP(launch_prefill_gemm(PG_STORE, s->pf_xn, dim, w1, out, ldo, P, sh.hid_loc, dim, pos0, s->rope,
+            L2Z_HIP(launch_prefill_gemm(PG_STORE, s->pf_xn, ldxn, w1, out, ldo, P, sh.hid_loc, dim, pos0, s->rope,
                                         hs, st, nullptr, 0, sh.world, 0, sk_h1, ws, 2 * dim));                      // :405
-            L2Z_HIP(launch_prefill_gemm(PG_SWIGLU, s->pf_xn, dim, w3, out, ldo, P, sh.hid_loc, dim, pos0, s->rope,
+            L2Z_HIP(launch_prefill_gemm(PG_SWIGLU, s->pf_xn, ldxn, w3, out, ldo, P, sh.hid_loc, dim, pos0, s->rope,
                                         hs, st, nullptr, 0, sh.world, 0, sk_h1, ws, 2 * dim));  // :408 + :411-416 in the epilogue
         } else {
             L2Z_HIP(pe);
@@ -222,12 +236,12 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
         const float *res = s->pf_x + sh.dim0;
         {
             PanelProduct pp = {};
-            pp.x = s->pf_h1; pp.ldx = hid; pp.K = hid; pp.w0 = w->w2 + (size_t)l * sh.dim_loc * hid; pp.rows0 = sh.dim_loc;
+            pp.x = s->pf_h1; pp.ldx = ldh1; pp.K = hid; pp.w0 = w->w2 + (size_t)l * sh.dim_loc * hid; pp.rows0 = sh.dim_loc;
             pp.mode = PANEL_RESID; pp.out = out; pp.ldo = ldo; pp.res = res; pp.ldres = dim;
             L2Z_TRY(panel(pp, dim, &taken));
         }
         if (!taken)
-        L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_h1, hid, w->w2 + (size_t)l * sh.dim_loc * hid, out, ldo,
+        L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_h1, ldh1, w->w2 + (size_t)l * sh.dim_loc * hid, out, ldo,
                                     P, sh.dim_loc, hid, pos0, s->rope, hs, st, res, dim, sh.world, 0, sk_w2, ws));   // :419-422
     }
     return L2Z_OK;
@@ -254,43 +268,45 @@ int prefill_half_b(l2z_runstate *s, const l2z_weights *w, int l, int half, int P
     // kernel forms are chosen from what every rank sees alike: the whole matrices' row counts and the shards' widths
     const int kvd_whole = c.n_kv_heads * hs;
     const int epi = sh.rank == 0 ? PG_RESID : PG_STORE;
+    const int ldxn = s->pf_ld_xn, ldatt = s->pf_ld_att, ldh1 = s->pf_ld_h1;   // padded rows of the GEMM inputs (pf_ld)
+    const int dim64 = (dim + 63) / 64 * 64;
     if (half == 0) {
-        L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, s->pf_x, w->rms_att + (size_t)l * dim, dim, P, st));  // :305
-        const int sk_qkv = prefill_split_k((long long)dim + 2 * kvd_whole, P, dim, false);
+        L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, ldxn, s->pf_x, w->rms_att + (size_t)l * dim, dim, P, st));  // :305
+        const int sk_qkv = prefill_split_k((long long)dim + 2 * kvd_whole, P, dim64, false);
         const float *wq = w->wq + (size_t)l * sh.dim_loc * dim, *wk = w->wk + (size_t)l * kvd * dim, *wv = w->wv + (size_t)l * kvd * dim;
-        const hipError_t qe = launch_prefill_gemm_qkv(s->pf_xn, dim, wq, wk, wv, s->pf_q, sh.dim_loc, kc, vc, kvd, P, sh.dim_loc, kvd,
+        const hipError_t qe = launch_prefill_gemm_qkv(s->pf_xn, ldxn, wq, wk, wv, s->pf_q, sh.dim_loc, kc, vc, kvd, P, sh.dim_loc, kvd,
                                                       dim, pos0, s->rope, hs, st, kvh_stride, sh.world, sk_qkv, ws);
         if (qe == hipErrorNotSupported) {
-            L2Z_HIP(launch_prefill_gemm(PG_ROPE, s->pf_xn, dim, wq, s->pf_q, sh.dim_loc, P, sh.dim_loc, dim, pos0, s->rope, hs, st,
+            L2Z_HIP(launch_prefill_gemm(PG_ROPE, s->pf_xn, ldxn, wq, s->pf_q, sh.dim_loc, P, sh.dim_loc, dim, pos0, s->rope, hs, st,
                                         nullptr, 0, sh.world, 0, sk_qkv, ws));
-            L2Z_HIP(launch_prefill_gemm(PG_ROPE_CACHE, s->pf_xn, dim, wk, kc, kvd, P, kvd, dim, pos0, s->rope, hs, st, nullptr, 0,
+            L2Z_HIP(launch_prefill_gemm(PG_ROPE_CACHE, s->pf_xn, ldxn, wk, kc, kvd, P, kvd, dim, pos0, s->rope, hs, st, nullptr, 0,
                                         sh.world, kvh_stride, sk_qkv, ws));
-            L2Z_HIP(launch_prefill_gemm(PG_CACHE, s->pf_xn, dim, wv, vc, kvd, P, kvd, dim, pos0, s->rope, hs, st, nullptr, 0,
+            L2Z_HIP(launch_prefill_gemm(PG_CACHE, s->pf_xn, ldxn, wv, vc, kvd, P, kvd, dim, pos0, s->rope, hs, st, nullptr, 0,
                                         sh.world, kvh_stride, sk_qkv, ws));
         } else {
             L2Z_HIP(qe);
         }
-        L2Z_HIP(launch_prefill_attention(s->pf_q, sh.dim_loc, kc, vc, s->pf_att, sh.dimc_pad, pos0, P, sh.heads_loc, hs, hs,
+        L2Z_HIP(launch_prefill_attention(s->pf_q, sh.dim_loc, kc, vc, s->pf_att, ldatt, pos0, P, sh.heads_loc, hs, hs,
                                          kvh_stride, c.n_heads / c.n_kv_heads, c.seq_len, st, c.n_heads));   // :361-389
-        const int sk = prefill_split_k(dim, P, sh.dimc_pad, false);
-        L2Z_HIP(launch_prefill_gemm(epi, s->pf_att, sh.dimc_pad, w->wo + (size_t)l * dim * sh.dimc_pad, s->pf_part, dim, P, dim,
+        const int sk = prefill_split_k(dim, P, (sh.dimc_pad + 63) / 64 * 64, false);
+        L2Z_HIP(launch_prefill_gemm(epi, s->pf_att, ldatt, w->wo + (size_t)l * dim * sh.dimc_pad, s->pf_part, dim, P, dim,
                                     sh.dimc_pad, pos0, s->rope, hs, st, s->pf_x, dim, 1, 0, sk, ws));        // :392-395
     } else {
-        L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, s->pf_x, w->rms_ffn + (size_t)l * dim, dim, P, st));  // :398
-        const int sk_h1 = prefill_split_k(c.hidden_dim, P, dim, true);
+        L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, ldxn, s->pf_x, w->rms_ffn + (size_t)l * dim, dim, P, st));  // :398
+        const int sk_h1 = prefill_split_k(c.hidden_dim, P, dim64, true);
         const float *w1 = w->w1 + (size_t)l * sh.hid_loc * 2 * dim, *w3 = w->w3 + (size_t)l * sh.hid_loc * 2 * dim;
-        const hipError_t pe = launch_prefill_gemm_swiglu_pair(s->pf_xn, dim, w1, w3, s->pf_h1, sh.hidc_pad, P, sh.hid_loc, dim, st,
+        const hipError_t pe = launch_prefill_gemm_swiglu_pair(s->pf_xn, ldxn, w1, w3, s->pf_h1, ldh1, P, sh.hid_loc, dim, st,
                                                               sh.world, sk_h1, ws, 2 * dim);
         if (pe == hipErrorNotSupported) {
-            L2Z_HIP(launch_prefill_gemm(PG_STORE, s->pf_xn, dim, w1, s->pf_h1, sh.hidc_pad, P, sh.hid_loc, dim, pos0, s->rope, hs, st,
+            L2Z_HIP(launch_prefill_gemm(PG_STORE, s->pf_xn, ldxn, w1, s->pf_h1, ldh1, P, sh.hid_loc, dim, pos0, s->rope, hs, st,
                                         nullptr, 0, sh.world, 0, sk_h1, ws, 2 * dim));                     // :405
-            L2Z_HIP(launch_prefill_gemm(PG_SWIGLU, s->pf_xn, dim, w3, s->pf_h1, sh.hidc_pad, P, sh.hid_loc, dim, pos0, s->rope, hs,
+            L2Z_HIP(launch_prefill_gemm(PG_SWIGLU, s->pf_xn, ldxn, w3, s->pf_h1, ldh1, P, sh.hid_loc, dim, pos0, s->rope, hs,
                                         st, nullptr, 0, sh.world, 0, sk_h1, ws, 2 * dim));                 // :408-416
         } else {
             L2Z_HIP(pe);
         }
-        const int sk = prefill_split_k(dim, P, sh.hidc_pad, false);
-        L2Z_HIP(launch_prefill_gemm(epi, s->pf_h1, sh.hidc_pad, w->w2 + (size_t)l * dim * sh.hidc_pad, s->pf_part, dim, P, dim,
+        const int sk = prefill_split_k(dim, P, (sh.hidc_pad + 63) / 64 * 64, false);
+        L2Z_HIP(launch_prefill_gemm(epi, s->pf_h1, ldh1, w->w2 + (size_t)l * dim * sh.hidc_pad, s->pf_part, dim, P, dim,
                                     sh.hidc_pad, pos0, s->rope, hs, st, s->pf_x, dim, 1, 0, sk, ws));        // :419-422
     }
     return L2Z_OK;

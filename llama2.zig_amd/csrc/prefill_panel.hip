@@ -52,7 +52,8 @@ struct PanelArgs {
     // order (q | k | v; W1 and W3 row-interleaved are ONE matrix of 2 hidden rows: the device layout)
     const float *w0, *w1, *w2;
     int rows0, rows1, rows2;
-    int P, K;
+    int P, K;         // K: whole 128-k stages (the product's K rounded up: pad_k)
+    int ldw;          // floats between rows of the matrices (the product's own K)
     float *part;      // [ranges][16 TMS][N]
     int n_groups;     // groups of 64 rows
     int n_items;      // ranges * n_groups
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(64 * NW) void prefill_panel(const PanelArgs a)
 #pragma unroll
     for (int i = 0; i < LOADS; i++) {
         const int jl = RPL * i + lane / SLOTS;
-        loff[i] = (size_t)jl * (size_t)a.K + (size_t)(4 * ((lane % SLOTS) ^ (jl & kPnSwz)));
+        loff[i] = (size_t)jl * (size_t)a.ldw + (size_t)(4 * ((lane % SLOTS) ^ (jl & kPnSwz)));
     }
     int p_item = i0, p_st = 0, p_ns = 0, p_buf = 0, issued = 0;
     const float *p_base = a.w0;  // row 0 of the wave's 16 at k = the range's start
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(64 * NW) void prefill_panel(const PanelArgs a)
         const float *base = s1 ? a.w1 : a.w0;
         base = s2 ? a.w2 : base;
         row -= s2 ? a.rows0 + a.rows1 : (s1 ? a.rows0 : 0);
-        p_base = base + (size_t)row * (size_t)a.K + (size_t)r * KR;
+        p_base = base + (size_t)row * (size_t)a.ldw + (size_t)r * KR;
     };
     auto issue_one = [&]() {
         if (p_item >= i1) return;
@@ -344,7 +345,8 @@ bool prefill_panel_shape(long long n_whole, int P, int K, long long widest_whole
 {
     if (tunables().pf_panel == 0) return false;
     const int p_min = kPanelDefaultMin;
-    if (P < p_min || P < 1 || P > prefill_panel_max_tokens() || K % kPnStage != 0 || K < kPnRange) return false;
+    K = (K + kPnStage - 1) / kPnStage * kPnStage;   // the kernel walks whole 128-k stages (pad_k)
+    if (P < p_min || P < 1 || P > prefill_panel_max_tokens() || K < kPnRange) return false;
     if (n_whole * (long long)K * 4 <= ((long long)16 << 20)) return false;  // cache-resident matrices keep the short-prompt forms
     // the partial products of the WHOLE model's launch must fit the workspace an unsharded runstate allocates
     // (prefill_host.cpp prefill_alloc: kPanelWsRows rows of its widest launch) -- decided on the whole model, so
@@ -357,7 +359,8 @@ bool prefill_panel_shape(long long n_whole, int P, int K, long long widest_whole
 hipError_t launch_prefill_panel(const PanelProduct &p, int n_cus, const SplitKWs *ws, hipStream_t st)
 {
     const int N = p.rows0 + p.rows1 + p.rows2;
-    if ((p.rows0 % 16) || (p.rows1 % 16) || (p.rows2 % 16) || N < 16 || (p.ldx % 4) || p.K % kPnStage != 0) return hipErrorNotSupported;
+    const int Ke = pad_k(p.K, kPnStage, p.ldx);
+    if ((p.rows0 % 16) || (p.rows1 % 16) || (p.rows2 % 16) || N < 16 || (p.ldx % 4) || Ke < 0) return hipErrorNotSupported;
     if (((uintptr_t)p.x & 15) || ((uintptr_t)p.w0 & 15) || ((uintptr_t)p.w1 & 15) || ((uintptr_t)p.w2 & 15)) return hipErrorNotSupported;
     if (ws == nullptr || ws->part == nullptr) return hipErrorNotSupported;
     const int tms = (p.P + 15) / 16;   // token tiles of 16: 2 ... 6 (up to 16 tokens the short-prompt GEMMs are ahead: kPanelDefaultMin)
@@ -365,11 +368,11 @@ hipError_t launch_prefill_panel(const PanelProduct &p, int n_cus, const SplitKWs
     // 6.82 ms with three, 7.55 / 7.66 with four; profiles/r05c_prefill_panel_ab.txt)
     const int kr = panel_range(tms);
     const int depth = tms <= 2 || tms == 4 ? 3 : 2;
-    const int n_ranges = (p.K + kr - 1) / kr;
+    const int n_ranges = (Ke + kr - 1) / kr;
     if ((size_t)n_ranges * (size_t)(16 * tms) * (size_t)N > ws->part_floats) return hipErrorNotSupported;
     PanelArgs a = {};
     a.x = p.x; a.ldx = p.ldx; a.w0 = p.w0; a.w1 = p.w1 ? p.w1 : p.w0; a.w2 = p.w2 ? p.w2 : p.w0;
-    a.rows0 = p.rows0; a.rows1 = p.rows1; a.rows2 = p.rows2; a.P = p.P; a.K = p.K;
+    a.rows0 = p.rows0; a.rows1 = p.rows1; a.rows2 = p.rows2; a.P = p.P; a.K = Ke; a.ldw = p.K;
     a.part = ws->part;
     // one / two tiles: 4 waves, stages of 128 k; three / four: 8 waves, stages of 64 k (the same k order: the same bits
     // as four waves would give; 40 / 48 / 64 tokens 9.04 / 9.16 / 11.11 -> 8.86 / 9.02 / 11.09 ms, r05j_panel_waves_ab.txt)

@@ -7,191 +7,16 @@ namespace {
 
 // Short prompts (P <= 64): the product is bound by streaming W once, like the decode mat-vec, and
 // a 64 x 64 tile leaves most CUs without a block (N / 64 blocks).  Here a block owns 16 features
-// and 16 TMS tokens; its 8 waves split K in chunks of 64 and every lane feeds MFMA 16x16x4 straight
-// from global memory -- no LDS staging: each W element is loaded by exactly one lane, X (P x K,
-// L2 resident) by one lane per block.  MFMA 16x16x4 f32 operands:
+// and 16 TMS tokens and feeds MFMA 16x16x4.  MFMA 16x16x4 f32 operands:
 //   A: lane l holds A[i = l & 15][k = l >> 4]   B: lane l holds B[k = l >> 4][j = l & 15]
 //   D: lane l, reg r holds D[i = 4 (l >> 4) + r][j = l & 15]
-// Lane (., q) loads the float4 at k = chunk base + 16 u + 4 q; component t of it is "k = q" of MFMA
-// (c, u, t) for both operands, which is all the instruction needs (a sum over k is unordered in
-// exact arithmetic; the fp32 order is fixed by (c, u, t), then the waves in order: deterministic).
+// (Rounds 1-5 carried three forms: no LDS, a register-staged LDS form, and the direct-to-LDS ring below, the first two
+// as fallbacks for K that is not whole 256-k stages.  Since round 6 every product runs the ring over K rounded up to
+// whole stages -- at least three -- against zero-padded activation rows: pad_k, prefill_common.h.)
+constexpr int kSkBK = 256;
 
-template <int EPI, int TMS, int kSkWaves, int CU, bool KTAIL>
-__global__ __launch_bounds__(64 * kSkWaves) void prefill_skinny(const GemmArgs a)
-{
-    // CU float4 loads per lane and chunk (a chunk is 16 CU values of k); KTAIL: K % (16 CU) != 0
-    __shared__ float red[kSkWaves][TMS][4][64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 15, q = lane >> 4;
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * TMS;
-    const v4f zero = {0.f, 0.f, 0.f, 0.f};
-    // rows / tokens past the end are clamped: their products land in outputs nobody stores.
-    // No branch and no select around the loads (either would make the loop wait for them early).
-    const float *wrow = a.w + (size_t)min(n0 + j, a.N - 1) * a.ldw + 4 * q;
-    const float *xrow[TMS];
-#pragma unroll
-    for (int tm = 0; tm < TMS; tm++) xrow[tm] = a.x + (size_t)min(m0 + 16 * tm + j, a.P - 1) * a.ldx + 4 * q;
-    v4f acc[TMS];
-#pragma unroll
-    for (int tm = 0; tm < TMS; tm++) acc[tm] = zero;
-    constexpr int CK = 16 * CU;
-    const int nchunk = (a.K + CK - 1) / CK;
-    v4f wc[CU], wn[CU], xc[TMS][CU], xn[TMS][CU];
-    auto load = [&](int c, v4f (&wv)[CU], v4f (&xv)[TMS][CU]) {
-#pragma unroll
-        for (int u = 0; u < CU; u++) {
-            int k = CK * c + 16 * u;
-            if (KTAIL && k + 4 * q >= a.K) k = a.K - 4 - 4 * q;  // a lane past the row end re-reads the
-                                                                 // row's last float4; zeroed at use
-            wv[u] = __builtin_nontemporal_load((const v4f *)(wrow + k));
-#pragma unroll
-            for (int tm = 0; tm < TMS; tm++) xv[tm][u] = *(const v4f *)(xrow[tm] + k);
-        }
-    };
-    int c = wave;
-    if (c < nchunk) load(c, wc, xc);
-    for (; c < nchunk; c += kSkWaves) {
-        if (c + kSkWaves < nchunk) load(c + kSkWaves, wn, xn);
-#pragma unroll
-        for (int u = 0; u < CU; u++) {
-            const bool dead = KTAIL && CK * c + 16 * u + 4 * q >= a.K;  // K % 4 == 0
-#pragma unroll
-            for (int t = 0; t < 4; t++)
-#pragma unroll
-                for (int tm = 0; tm < TMS; tm++)
-                    acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(dead ? 0.0f : xc[tm][u][t], wc[u][t], acc[tm], 0, 0, 0);
-        }
-#pragma unroll
-        for (int u = 0; u < CU; u++) {
-            wc[u] = wn[u];
-#pragma unroll
-            for (int tm = 0; tm < TMS; tm++) xc[tm][u] = xn[tm][u];
-        }
-    }
-#pragma unroll
-    for (int tm = 0; tm < TMS; tm++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) red[wave][tm][r][lane] = acc[tm][r];
-    __syncthreads();
-    // TMS * 4 * 64 results; a wave of threads shares (tm, r), lanes are the MFMA lanes
-    for (int idx = tid; idx < TMS * 256; idx += 64 * kSkWaves) {
-        const int tm = idx >> 8, r = (idx >> 6) & 3, l = idx & 63;
-        float v = red[0][tm][r][l];
-#pragma unroll
-        for (int w = 1; w < kSkWaves; w++) v += red[w][tm][r][l];
-        const int tok = m0 + 16 * tm + 4 * (l >> 4) + r;
-        const int f = n0 + (l & 15);
-        if (EPI == G_ROPE || EPI == G_ROPE_CACHE) {
-            const float partner = __shfl_xor(v, 1, 64);  // feature f ^ 1, same token (main.zig:346-349)
-            const int hs = a.head_size;
-            const int pos = a.pos0 + (tok < a.P ? tok : 0);
-            const float2 cs = a.rope[(size_t)pos * (size_t)(hs >> 1) + (size_t)(((f < a.N ? f : 0) % hs) >> 1)];
-            v = (f & 1) ? partner * cs.y + v * cs.x : v * cs.x - partner * cs.y;
-        }
-        if (tok < a.P && f < a.N) {
-            if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + f] = v;
-            else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + f] = a.res[(size_t)tok * a.ldres + f] + v;
-            else if (EPI == G_SWIGLU) a.out[(size_t)tok * a.ldo + f] = swiglu_merge(a.out[(size_t)tok * a.ldo + f], v);
-            else a.out[kv_index(a, a.ldo, a.pos0 + tok, f)] = v;
-        }
-    }
-}
-
-// The same 16-feature x 16 TMS-token block as prefill_skinny, but W and X are staged through LDS
-// in chunks of 256 k: every wave-wide global load then reads 1 KB of ONE row instead of 16 rows x
-// 64 bytes, and the MFMA operands come from LDS rows of 260 floats (bank = 4 j + q: conflict-free).
-// Both forms stream W at ~3.4 TB/s, half the decode kernel's rate: N/16 blocks x 16 rows are
-// thousands of concurrent DRAM row streams, where the decode kernel sweeps 2 rows per block in
-// 16-KB bursts -- the price of having 16 features in flight per MFMA.
-// Stage s+1 travels global -> registers while stage s is multiplied; the 4 waves split each
-// stage's 64 k-steps and are summed through LDS at the end (order fixed: deterministic).
-constexpr int kSkBK = 256, kSkLD = kSkBK + 4;
-
-template <int EPI, int TMS>
-__global__ __launch_bounds__(kPfBlock) void prefill_skinny_lds(const GemmArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *ws = smem;                    // 16 x kSkLD
-    float *xs = smem + 16 * kSkLD;       // 16 TMS x kSkLD
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 15, q = lane >> 4;
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * TMS;
-    const v4f zero = {0.f, 0.f, 0.f, 0.f};
-    // float4 slot f = tid + 256 i of a tile: row f / 64, k = 4 (f % 64): a wave reads 1 KB of a row
-    v4f wv[4], xv[TMS][4];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int f = tid + kPfBlock * i, r = f >> 6, k = k0 + 4 * (f & 63);
-            const int kc = min(k, a.K - 4);  // clamped: legal address, zeroed at the LDS store
-            wv[i] = __builtin_nontemporal_load((const v4f *)(a.w + (size_t)min(n0 + r, a.N - 1) * a.ldw + kc));
-#pragma unroll
-            for (int tm = 0; tm < TMS; tm++)
-                xv[tm][i] = *(const v4f *)(a.x + (size_t)min(m0 + 16 * tm + r, a.P - 1) * a.ldx + kc);
-        }
-    };
-    auto sstore = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int f = tid + kPfBlock * i, r = f >> 6, c = 4 * (f & 63);
-            const bool ok = k0 + c < a.K;  // K % 4 == 0; rows / tokens past the end: junk nobody stores
-            *(v4f *)(ws + r * kSkLD + c) = ok ? wv[i] : zero;
-#pragma unroll
-            for (int tm = 0; tm < TMS; tm++) *(v4f *)(xs + (16 * tm + r) * kSkLD + c) = ok ? xv[tm][i] : zero;
-        }
-    };
-    v4f acc[TMS];
-#pragma unroll
-    for (int tm = 0; tm < TMS; tm++) acc[tm] = zero;
-    gload(0);
-    for (int k0 = 0; k0 < a.K; k0 += kSkBK) {
-        __syncthreads();  // the previous stage has been multiplied
-        sstore(k0);
-        __syncthreads();
-        if (k0 + kSkBK < a.K) gload(k0 + kSkBK);  // flies while this stage is multiplied
-        const float *wr = ws + j * kSkLD + 64 * wave + q;
-        const float *xr = xs + j * kSkLD + 64 * wave + q;
-#pragma unroll
-        for (int st = 0; st < 16; st++) {  // this wave's quarter of the stage: k = 64 wave + 4 st + q
-            const float b = wr[4 * st];
-#pragma unroll
-            for (int tm = 0; tm < TMS; tm++)
-                acc[tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[16 * tm * kSkLD + 4 * st], b, acc[tm], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-    float *red = smem;  // [4 waves][TMS][4][64]
-#pragma unroll
-    for (int tm = 0; tm < TMS; tm++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) red[((wave * TMS + tm) * 4 + r) * 64 + lane] = acc[tm][r];
-    __syncthreads();
-    for (int idx = tid; idx < TMS * 256; idx += kPfBlock) {
-        const int tm = idx >> 8, r = (idx >> 6) & 3, l = idx & 63;
-        float v = red[((0 * TMS + tm) * 4 + r) * 64 + l];
-#pragma unroll
-        for (int w = 1; w < 4; w++) v += red[((w * TMS + tm) * 4 + r) * 64 + l];
-        const int tok = m0 + 16 * tm + 4 * (l >> 4) + r;
-        const int f = n0 + (l & 15);
-        if (EPI == G_ROPE || EPI == G_ROPE_CACHE) {
-            const float partner = __shfl_xor(v, 1, 64);  // feature f ^ 1, same token (main.zig:346-349)
-            const int hs = a.head_size;
-            const int pos = a.pos0 + (tok < a.P ? tok : 0);
-            const float2 cs = a.rope[(size_t)pos * (size_t)(hs >> 1) + (size_t)(((f < a.N ? f : 0) % hs) >> 1)];
-            v = (f & 1) ? partner * cs.y + v * cs.x : v * cs.x - partner * cs.y;
-        }
-        if (tok < a.P && f < a.N) {
-            if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + f] = v;
-            else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + f] = a.res[(size_t)tok * a.ldres + f] + v;
-            else if (EPI == G_SWIGLU) a.out[(size_t)tok * a.ldo + f] = swiglu_merge(a.out[(size_t)tok * a.ldo + f], v);
-            else a.out[kv_index(a, a.ldo, a.pos0 + tok, f)] = v;
-        }
-    }
-}
-
-// Short prompts, third form (round 2): prefill_skinny_lds with the operands brought in by
-// direct-to-LDS loads and a ring of SW stages.  The register-staged form keeps one 16-KB stage of W in
-// flight per block, and N = 4096 gives one block per CU: 4 MB on the wire chip-wide where the memory
+// The operands are brought in by direct-to-LDS loads through a ring of SW stages.  (The register-staged form of
+// round 1 kept one 16-KB stage of W in flight per block, and N = 4096 gives one block per CU: 4 MB on the wire chip-wide where the memory
 // system needs ~13 MB (8 TB/s x latency) -- W streamed at 3.1 TB/s.  Here every wave-wide load still
 // reads 1 KB of ONE row, but it lands in LDS without passing through VGPRs, so SW - 1 stages (48 KB of
 // W per CU at SW = 4) are in flight.  X rides in the same ring: vmcnt retires loads in issue order, so
@@ -208,8 +33,7 @@ __global__ __launch_bounds__(kPfBlock) void prefill_skinny_lds(const GemmArgs a)
 // W byte (the paired form below: 4.4 -> 5.2 TB/s of W) -- every CU takes in ~13-15 bytes per cycle of
 // W + X together, on all 256 CUs (32 rows of one matrix per block on 128 CUs: 15.6 -> 21.8 us; skipping
 // the X rows past a 4-token prompt, duplicates that hit the L1: no change).
-// Needs K % 256 == 0 (whole stages: the 7B and 110M shapes); otherwise the launcher keeps the
-// register-staged form (same sums, another order).
+// Whole 256-k stages, at least three: the launcher rounds K up (skinny_k).
 constexpr int kSkLD2 = kSkBK + 8;
 
 // NW = 2: TWO weight matrices share the X stage -- w1 | w3 with silu(a) * b as the epilogue (EPI =
@@ -355,50 +179,38 @@ bool skinny_spread(const GemmArgs &a)
     return streams && a.N >= 16 * 64;
 }
 
+// K as the ring kernel multiplies it: whole 256-k stages, at least three (its ring runs two stages ahead)
+int skinny_k(const GemmArgs &a)
+{
+    const int ke = pad_k(a.K < 3 * kSkBK ? 3 * kSkBK : a.K, kSkBK, a.ldx);
+    return (a.ldx % 4) != 0 ? -1 : ke;
+}
+
 template <int EPI, int TMS>
 hipError_t skinny_launch_t(const GemmArgs &a, hipStream_t st)
 {
+    static_assert(TMS <= 2, "one or two token tiles (at 64 tokens the stage would take 83 KB)");
     dim3 grid((a.N + 15) / 16, (a.P + 16 * TMS - 1) / (16 * TMS));
-    // LDS-staged forms (1-KB row reads), up to two token tiles (at 64 tokens the stage would take 83 KB).
-    // Direct-to-LDS ring where K is whole 256-k stages and rows are 16-byte aligned; the register-staged LDS form for
-    // other K >= 256 (same sums, another order); no LDS below that
-    if (a.K % kSkBK == 0 && a.K / kSkBK >= 3 && a.ldx % 4 == 0 && TMS <= 2) {
-        constexpr int SW = TMS == 1 ? 4 : 3;
-        const size_t lds = (size_t)SW * (16 + 16 * TMS) * kSkLD2 * sizeof(float);
-        const void *fn = (const void *)prefill_skinny_dma<EPI, TMS, SW>;
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        GemmArgs args = a;
-        dim3 g1 = grid;
-        args.ntx = 0; args.nty = 0;
-        if (grid.y == 1 && skinny_spread(a)) {
-            args.ntx = (int)grid.x;
-            g1 = dim3((grid.x + 7) / 8 * 8);
-        }
-        if (grid.y > 1) {
-            args.ntx = (int)grid.x; args.nty = (int)grid.y;
-            g1 = dim3((grid.x + 7) / 8 * 8 * grid.y);
-        }
-        void *params[] = {&args};
-        return hipLaunchKernel(fn, g1, dim3(kPfBlock), params, lds, st);
+    GemmArgs args = a;
+    args.K = skinny_k(a);
+    if (args.K < 0) return hipErrorInvalidValue;
+    constexpr int SW = TMS == 1 ? 4 : 3;
+    const size_t lds = (size_t)SW * (16 + 16 * TMS) * kSkLD2 * sizeof(float);
+    const void *fn = (const void *)prefill_skinny_dma<EPI, TMS, SW>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    dim3 g1 = grid;
+    args.ntx = 0; args.nty = 0;
+    if (grid.y == 1 && skinny_spread(a)) {
+        args.ntx = (int)grid.x;
+        g1 = dim3((grid.x + 7) / 8 * 8);
     }
-    if (a.K >= kSkBK && TMS <= 2) {
-        const size_t stage = (size_t)(16 + 16 * TMS) * kSkLD * sizeof(float);
-        const size_t red = (size_t)4 * TMS * 4 * 64 * sizeof(float);
-        const size_t lds = stage > red ? stage : red;
-        static bool attr = false;
-        if (!attr && lds > 48 * 1024) {
-            (void)hipFuncSetAttribute((const void *)prefill_skinny_lds<EPI, TMS>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr = true;
-        }
-        hipLaunchKernelGGL((prefill_skinny_lds<EPI, TMS>), grid, dim3(kPfBlock), lds, st, a);
-    } else if (a.K % 64 == 0) {
-        hipLaunchKernelGGL((prefill_skinny<EPI, TMS, 8, 4, false>), grid, dim3(512), 0, st, a);
-    } else {
-        hipLaunchKernelGGL((prefill_skinny<EPI, TMS, 8, 4, true>), grid, dim3(512), 0, st, a);
+    if (grid.y > 1) {
+        args.ntx = (int)grid.x; args.nty = (int)grid.y;
+        g1 = dim3((grid.x + 7) / 8 * 8 * grid.y);
     }
-    return hipGetLastError();
+    void *params[] = {&args};
+    return hipLaunchKernel(fn, g1, dim3(kPfBlock), params, lds, st);
 }
 
 // one token tile per block?  (see skinny_launch)
@@ -428,7 +240,7 @@ hipError_t skinny_launch(const GemmArgs &a, hipStream_t st)
 // the shape takes another short-prompt form: the caller launches the two products separately.
 hipError_t launch_prefill_skinny_pair(int epi, const GemmArgs &a, hipStream_t st)
 {
-    if (a.K % kSkBK != 0 || a.K / kSkBK >= 3 == false || a.ldx % 4 != 0 || !skinny_one_tile(a)) return hipErrorNotSupported;
+    if (!skinny_one_tile(a)) return hipErrorNotSupported;
     constexpr int SW = 3;
     const size_t lds = (size_t)SW * (32 + 16) * kSkLD2 * sizeof(float);
     const void *fn = epi == G_SWIGLU ? (const void *)prefill_skinny_dma<G_SWIGLU, 1, SW, 2>
@@ -437,6 +249,8 @@ hipError_t launch_prefill_skinny_pair(int epi, const GemmArgs &a, hipStream_t st
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     GemmArgs args = a;
+    args.K = skinny_k(a);
+    if (args.K < 0) return hipErrorInvalidValue;
     dim3 grid((a.N + 15) / 16, (a.P + 15) / 16), g1 = grid;
     args.ntx = 0; args.nty = 0;
     if (grid.y == 1 && skinny_spread(a)) {

@@ -143,6 +143,7 @@ using namespace l2z;
 
 namespace {
 
+constexpr size_t kBlobSlackFloats = 1024;
 bool is_w1(const TensorDesc &d) { return strcmp(d.name, "w1") == 0; }
 bool is_w3(const TensorDesc &d) { return strcmp(d.name, "w3") == 0; }
 
@@ -240,7 +241,11 @@ int weights_alloc(const l2z_config *config, int shared_weights, const l2z_comm *
     w->file_layout = sh.world == 1 && !sh.scheme_b;
     *tt_out = tensor_table(*config, w->shared != 0);
     w->blob_floats = local_floats(w, *tt_out);
-    hipError_t e = hipMalloc(&w->blob, w->blob_floats * sizeof(float));
+    // + a zeroed slack: the batched prefill's GEMMs multiply whole stages of K and read up to 3 x 256 floats past the
+    // end of a W row against zero activation columns (prefill_common.h pad_k); past the LAST row of the LAST tensor
+    // that is here (everywhere else it is the next row or the next tensor: finite)
+    hipError_t e = hipMalloc(&w->blob, (w->blob_floats + kBlobSlackFloats) * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(w->blob + w->blob_floats, 0, kBlobSlackFloats * sizeof(float));
     if (e != hipSuccess) {
         set_error("hipMalloc(%zu bytes) for weights failed: %s", w->blob_floats * sizeof(float),
                   hipGetErrorString(e));
