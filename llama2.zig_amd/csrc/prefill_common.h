@@ -79,6 +79,51 @@ __device__ __forceinline__ void lds_dma16_nt(const float *g, float *lds)
     __builtin_amdgcn_global_load_lds(g, lds, 16, 0, 2);
 }
 
+// ---- f32 products on the bf16 matrix cores (round 6): x = x1 + x2 + x3, three bf16 terms ----
+// A float is split into three bf16 terms, each the round-to-nearest-even bf16 of what the terms before it left
+// (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 3 x 8 significand bits, the subtractions exact, so
+// x1 + x2 + x3 == x for every finite float whose last term does not underflow).  A product x w is then the sum of
+// nine bf16 x bf16 products, each EXACT in f32; the six of order <= 2^-16 are summed into the f32 accumulator by
+// v_mfma_f32_32x32x16_bf16 (the three left out are <= 2^-24 |x w| each: below the rounding of ONE f32 product).
+// The matrix cores run bf16 at 16 x the f32 rate: six instructions of 32 cycles replace eight of 64 per 16 k.
+#if defined(__HIPCC__)
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct Bf3 { v8bf t1, t2, t3; };
+
+// eight consecutive floats of a row (two float4) -> their three bf16 terms, element e of each = float e
+__device__ __forceinline__ Bf3 split3(const v4f lo, const v4f hi)
+{
+    Bf3 o;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const v2f f = {e < 4 ? lo[e] : hi[e - 4], e < 4 ? lo[e + 1] : hi[e - 3]};
+        const v2bf p1 = __builtin_convertvector(f, v2bf);           // v_cvt_pk_bf16_f32: round to nearest even
+        const v2f r1 = f - __builtin_convertvector(p1, v2f);        // exact
+        const v2bf p2 = __builtin_convertvector(r1, v2bf);
+        const v2f r2 = r1 - __builtin_convertvector(p2, v2f);       // exact
+        const v2bf p3 = __builtin_convertvector(r2, v2bf);
+        o.t1[e] = p1[0]; o.t1[e + 1] = p1[1];
+        o.t2[e] = p2[0]; o.t2[e + 1] = p2[1];
+        o.t3[e] = p3[0]; o.t3[e + 1] = p3[1];
+    }
+    return o;
+}
+
+// acc += sum over the lanes' 16 k of a b, smallest terms first (one fixed order: part of the arithmetic)
+__device__ __forceinline__ v16f x3_mfma(const Bf3 &a, const Bf3 &b, v16f acc)
+{
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t3, b.t1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t1, b.t3, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t2, b.t2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t2, b.t1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t1, b.t2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t1, b.t1, acc, 0, 0, 0);
+    return acc;
+}
+#endif
+
 // Loop bound of a kernel that multiplies whole `granule`-k stages (round 6): the product's K rounded up.  The columns
 // past K are ZEROS in every activation matrix of the batched pass (prefill_host.cpp pf_ld: rows padded to a multiple of
 // 256 floats, >= 768), and whatever follows the row in W -- the next row, the next tensor, the zeroed slack behind the

@@ -211,7 +211,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, v16f (&acc)[TM]
 //    accumulators and runs the epilogue.  kg0 + kg1 is exactly the sum the one-block forms form in LDS, and
 //    a + b == b + a: THE SAME BITS as every other form of the unsplit family -- so this one is chosen by grid
 //    fill alone, shards included.
-template <int EPI, int TM, int TN, int KS, bool PAIR = false, int WM = 2, int WN = 2, int SPLIT = 0>
+template <int EPI, int TM, int TN, int KS, bool PAIR = false, int WM = 2, int WN = 2, int SPLIT = 0, bool X3 = false>
 __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const GemmArgs a)
 {
     static_assert(!PAIR || TN == 2, "paired form: one W1 tile and one W3 tile per wave column");
@@ -324,13 +324,34 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
         }                                                                                                 \
     } while (0)
 
+    // X3: the same product on the bf16 matrix cores.  A k-step is 16 k: lane (row, k-half hl) holds the row's 8
+    // consecutive floats of slots 4 u + 2 hl, 4 u + 2 hl + 1 (two conflict-free b128 reads), splits them into three
+    // bf16 terms (split3) and feeds the six products of x3_mfma to ONE accumulator.
+    auto multiply_stage_x3 = [&](int buf_) {
+        const v4f *xr = (const v4f *)(smem + buf_ * STAGE), *wr = xr + BMt * SLOTS;
+#pragma unroll
+        for (int u = 0; u < SS / 2; u++) {
+            const int slot = (KGS ? 0 : kg * SPG) + 4 * u + 2 * hl;
+            Bf3 av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) av[i] = split3(xr[arow[i] + (slot ^ asw[i])], xr[arow[i] + ((slot + 1) ^ asw[i])]);
+#pragma unroll
+            for (int j = 0; j < TN; j++) bv[j] = split3(wr[brow[j] + (slot ^ bsw[j])], wr[brow[j] + ((slot + 1) ^ bsw[j])]);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) acc[i][j] = x3_mfma(av[i], bv[j], acc[i][j]);
+        }
+    };
+
     L2Z_DMA_ISSUE(kbeg, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int buf = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         if (k0 + BK < kend) L2Z_DMA_ISSUE(k0 + BK, buf ^ 1);
-        L2Z_MULTIPLY_STAGE(buf);
+        if constexpr (X3) multiply_stage_x3(buf);
+        else L2Z_MULTIPLY_STAGE(buf);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's loads of the next stage have landed
         __syncthreads();                                  // everyone's have, and nobody still reads this one
         buf ^= 1;
@@ -455,6 +476,14 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
     }
 }
 
+// the kernel of a form: on the f32 matrix cores, or (L2Z_PF_X3, default) the same form on the bf16 ones
+template <int EPI, int TM, int TN, int KS, bool PAIR = false, int WM = 2, int WN = 2, int SPLIT = 0>
+const void *dma_fn()
+{
+    return tunables().pf_x3 ? (const void *)prefill_gemm_dma<EPI, TM, TN, KS, PAIR, WM, WN, SPLIT, true>
+                            : (const void *)prefill_gemm_dma<EPI, TM, TN, KS, PAIR, WM, WN, SPLIT, false>;
+}
+
 template <int EPI, int TM, int TN, int KS>
 hipError_t gemm_launch_t(const GemmArgs &a, hipStream_t st)
 {
@@ -464,7 +493,7 @@ hipError_t gemm_launch_t(const GemmArgs &a, hipStream_t st)
     const size_t red = (size_t)(KS - 1) * 4 * TM * TN * 16 * 64 * sizeof(float);
     size_t lds = 2 * (size_t)(BMt + BNt) * 64 * sizeof(float);
     if (red > lds) lds = red;
-    const void *fn = (const void *)prefill_gemm_dma<EPI, TM, TN, KS, false>;
+    const void *fn = dma_fn<EPI, TM, TN, KS, false>();
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     GemmArgs args = a;
     const dim3 grid1 = dma_grid((a.N + BNt - 1) / BNt, (a.P + BMt - 1) / BMt, &args);
@@ -481,7 +510,7 @@ bool gemm_launch_small(const GemmArgs &a, hipStream_t st, hipError_t *err)
     if (a.K % 64 != 0 || a.ldx % 4 != 0) return false;
     constexpr int KS = 2, BMt = 32 * WM, BNt = 32 * WN;
     const size_t lds = 2 * (size_t)(BMt + BNt) * 64 * sizeof(float);
-    const void *fn = (const void *)prefill_gemm_dma<EPI, 1, 1, KS, false, WM, WN>;
+    const void *fn = dma_fn<EPI, 1, 1, KS, false, WM, WN>();
     dim3 grid((a.N + BNt - 1) / BNt, (a.P + BMt - 1) / BMt);
     GemmArgs args = a;
     const dim3 grid1 = dma_grid((int)grid.x, (int)grid.y, &args);
@@ -540,7 +569,7 @@ hipError_t dma_launch_split(GemmArgs a, int n_feat, int sk, const SplitKWs *ws, 
     size_t lds = 2 * (size_t)(BMt + BNt) * 64 * sizeof(float);
     const size_t red = (size_t)(KS - 1) * NWG * TM * TN * 16 * 64 * sizeof(float);
     if (red > lds) lds = red;
-    const void *fn = (const void *)prefill_gemm_dma<EPI, TM, TN, KS, PAIR, WM, WN, 1>;
+    const void *fn = dma_fn<EPI, TM, TN, KS, PAIR, WM, WN, 1>();
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const dim3 grid = dma_grid(ntx, nty, &a);
     void *params[] = {&a};
@@ -569,7 +598,7 @@ hipError_t dma_launch_kgs(GemmArgs a, int n_feat, const SplitKWs *ws, hipStream_
     if ((size_t)ntx * nty * BMt * BNt > ws->part_floats || 2 * ntx * nty > ws->cnt_ints) return hipErrorOutOfMemory;
     a.sk = 2; a.sk_part = ws->part; a.sk_cnt = ws->cnt;  // sk: the grid's z extent (dma_grid)
     const size_t lds = 2 * (size_t)(BMt + BNt) * 32 * sizeof(float);  // two stage buffers of half rows
-    const void *fn = (const void *)prefill_gemm_dma<EPI, TM, TN, KS, PAIR, WM, WN, 2>;
+    const void *fn = dma_fn<EPI, TM, TN, KS, PAIR, WM, WN, 2>();
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const dim3 grid = dma_grid(ntx, nty, &a);
     void *params[] = {&a};
@@ -675,10 +704,10 @@ hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float 
     // tokens x (features of W1 + the same features of W3) per block, chosen like the unpaired tiles
     const TileForm tf = choose_tile(N, P, true);
     const int tok = tf == TILE_128x64 ? 128 : tf == TILE_64x64 ? 64 : 32, feat = tf == TILE_32x32 ? 32 : 64;
-    const void *fn = tf == TILE_128x64 ? (const void *)prefill_gemm_dma<G_STORE, 2, 2, KS, true>
-                   : tf == TILE_64x64  ? (const void *)prefill_gemm_dma<G_STORE, 1, 2, KS, true>
-                   : tf == TILE_32x64  ? (const void *)prefill_gemm_dma<G_STORE, 1, 2, KS, true, 1, 2>
-                                       : (const void *)prefill_gemm_dma<G_STORE, 1, 2, KS, true, 1, 1>;
+    const void *fn = tf == TILE_128x64 ? dma_fn<G_STORE, 2, 2, KS, true>()
+                   : tf == TILE_64x64  ? dma_fn<G_STORE, 1, 2, KS, true>()
+                   : tf == TILE_32x64  ? dma_fn<G_STORE, 1, 2, KS, true, 1, 2>()
+                                       : dma_fn<G_STORE, 1, 2, KS, true, 1, 1>();
     const int threads = tf == TILE_32x64 ? 64 * 2 * KS : tf == TILE_32x32 ? 64 * KS : 256 * KS;
     size_t lds = 2 * (size_t)(tok + 2 * feat) * 64 * sizeof(float);
     const size_t red = (size_t)(KS - 1) * (threads / 64 / KS) * (tf == TILE_128x64 ? 2 : 1) * 2 * 16 * 64 * sizeof(float);  // [KS-1][waves per k-group][TM * TN tiles][16][64]
@@ -738,10 +767,10 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
     a.ldw = ldw_true;
     constexpr int KS = 2;
     const int tok = tf == TILE_128x64 ? 128 : tf == TILE_64x64 ? 64 : 32;
-    const void *fn = tf == TILE_128x64 ? (const void *)prefill_gemm_dma<G_QKV, 2, 1, KS, false>
-                   : tf == TILE_64x64  ? (const void *)prefill_gemm_dma<G_QKV, 1, 1, KS, false>
-                   : tf == TILE_32x64  ? (const void *)prefill_gemm_dma<G_QKV, 1, 1, KS, false, 1, 2>
-                                       : (const void *)prefill_gemm_dma<G_QKV, 1, 1, KS, false, 1, 1>;
+    const void *fn = tf == TILE_128x64 ? dma_fn<G_QKV, 2, 1, KS, false>()
+                   : tf == TILE_64x64  ? dma_fn<G_QKV, 1, 1, KS, false>()
+                   : tf == TILE_32x64  ? dma_fn<G_QKV, 1, 1, KS, false, 1, 2>()
+                                       : dma_fn<G_QKV, 1, 1, KS, false, 1, 1>();
     const int threads = tf == TILE_32x64 ? 64 * 2 * KS : tf == TILE_32x32 ? 64 * KS : 256 * KS;
     size_t lds = 2 * (size_t)(tok + feat) * 64 * sizeof(float);
     const size_t red = (size_t)(KS - 1) * (threads / 64 / KS) * (tf == TILE_128x64 ? 2 : 1) * 16 * 64 * sizeof(float);

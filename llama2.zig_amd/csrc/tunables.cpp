@@ -32,6 +32,7 @@ Tunables read_env()
     env_int("L2Z_PF_CHUNK", &t.pf_chunk);
     env_int("L2Z_PF_PANEL", &t.pf_panel);
     env_int("L2Z_PF_PANEL_MAX", &t.pf_panel_max);
+    env_int("L2Z_PF_X3", &t.pf_x3);
     return t;
 }
 
@@ -72,7 +73,8 @@ bool tunables_set(const char *name, long long v)
         {"L2Z_FUSE_SMALL", &t.fuse_small}, {"L2Z_NO_GRAPH", &t.no_graph}, {"L2Z_SCHEME_B", &t.scheme_b},
         {"L2Z_COMM_RCCL", &t.prefer_rccl}, {"L2Z_ARGMAX_XCHG", &t.argmax_xchg}, {"L2Z_P2P_CONSUME", &t.p2p_consume},
         {"L2Z_P2P_BULK_MB", &t.p2p_bulk_mb}, {"L2Z_PREFILL", &t.prefill}, {"L2Z_PF_CHUNK", &t.pf_chunk},
-        {"L2Z_PF_PANEL", &t.pf_panel}, {"L2Z_PF_PANEL_MAX", &t.pf_panel_max}};
+        {"L2Z_PF_PANEL", &t.pf_panel}, {"L2Z_PF_PANEL_MAX", &t.pf_panel_max},
+        {"L2Z_PF_X3", &t.pf_x3}};
     for (auto &e : ints)
         if (strcmp(e.n, name) == 0) {
             *e.p = (int)v;

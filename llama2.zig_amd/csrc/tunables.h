@@ -40,6 +40,8 @@ struct Tunables {
     int pf_panel = 1;          // L2Z_PF_PANEL        0: chunks of 17 ... 96 tokens keep the short-prompt / tile GEMMs instead of the K-range panel
                                //                     kernel (changes rounding: the ranges are part of the arithmetic); panel: 32 / 64 / 96 tokens
                                //                     8.8 / 12.5 / 17.6 -> 6.6 / 10.5 / 14.6 ms at 7B
+    int pf_x3 = 1;             // L2Z_PF_X3           0: the tile GEMMs of the batched prefill multiply on the f32 matrix cores (v_mfma_f32_32x32x2_f32)
+                               //                     instead of the bf16 ones over three-term splits of both operands (changes rounding)
     int pf_panel_max = -1;     // L2Z_PF_PANEL_MAX    longest chunk that takes the panel kernel (default and maximum 96 tokens): tests of both sides
                                //                     of the switch-over
 
