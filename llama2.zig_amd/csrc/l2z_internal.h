@@ -225,6 +225,10 @@ struct SplitKWs {
     int *cnt;
     size_t part_floats;
     int cnt_ints;
+    // the tile GEMM on the bf16 matrix cores: the launch's activation matrix as three planes of bf16 terms
+    // (prefill_gemm.hip launch_split3), [chunk tokens][3][widest padded row] bf16; reallocated with the chunk scratch
+    void *x3;
+    size_t x3_bytes;
 };
 constexpr int kSplitKMaxTokens = 256;  // longest chunk the split-K family takes
 constexpr int kPanelWsRows = 6 * kSplitKMaxTokens;  // rows of the widest launch the partial-product workspace holds (panel kernel: ranges x 16 tms)
@@ -240,7 +244,12 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
                                int n_scale = 1,  // n_scale: ranks the rows are sharded over (kernel-form choices look at the whole matrix)
                                size_t kv_head_stride = 0,  // PG_*CACHE: out is a head-major cache (MatvecArgs::kv_head_stride)
                                int sk = 1, const SplitKWs *ws = nullptr,   // sk > 1: the split-K family (prefill_split_k)
-                               int ldw = 0);  // floats between rows of w (0: K; W1 / W3 of the device blob: 2 K)
+                               int ldw = 0,   // floats between rows of w (0: K; W1 / W3 of the device blob: 2 K)
+                               long long n_launch_whole = 0);  // rows of the whole model's launch this product is a part of (q, k, v
+                                                               // launched apart: dim + 2 kv_dim; 0: N * n_scale) -- the stream form's K ranges
+// the stream form of the planes kernel (prefill_gemm.hip): which products take it, and their K ranges
+bool x3_stream_shape(long long n_whole, int P, int K);
+int x3_stream_sk(long long n_whole, int P, int K);
 hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, const float *wk, const float *wv,
                                    float *q_out, int ldq, float *kcache, float *vcache, int ldkv, int P, int nq,
                                    int nkv, int K, int pos0, const float2 *rope, int head_size, hipStream_t st,
@@ -251,7 +260,7 @@ hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float 
 hipError_t launch_prefill_gemm_kv_pair(const float *x, int ldx, const float *wk, const float *wv, float *kcache,
                                        float *vcache, int ldkv, int P, int nkv, int K, int pos0, const float2 *rope,
                                        int head_size, hipStream_t st, int n_scale = 1, size_t kv_head_stride = 0,
-                                       int sk = 1);
+                                       int sk = 1, long long n_launch_whole = 0);
 hipError_t launch_prefill_rmsnorm(float *o, int ldo, const float *x, const float *w, int n, int P,
                                   hipStream_t st);   // o: rows of ldo floats (the pad columns are left alone)
 hipError_t launch_prefill_embed(float *x, const float *tok_emb, const int *tokens, int dim, int P,

@@ -16,7 +16,9 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 constexpr int kPfBlock = 256;
 
 enum GemmEpi { G_STORE = 0, G_RESID = 1, G_ROPE = 2, G_ROPE_CACHE = 3, G_CACHE = 4, G_SWIGLU = 5,
-               G_QKV = 6 };  // q | k | v in one launch: the epilogue of the block's column range (direct-to-LDS tile kernel only)
+               G_QKV = 6,    // q | k | v in one launch: the epilogue of the block's column range (direct-to-LDS tile kernel only)
+               G_SWIGLU_IL = 7 };  // W1 | W3 as ONE matrix of alternating rows (the device blob's slot: DESIGN.md 2): feature 2 p is
+                                   // W1's row p, 2 p + 1 W3's -- adjacent lanes; out[token][p] = silu(a) * b (stream kernel only)
 
 // main.zig:411-416 on the W3 product: out holds W1 x, becomes silu(W1 x) * (W3 x)
 __device__ __forceinline__ float swiglu_merge(float h1, float h3)
@@ -55,6 +57,10 @@ struct GemmArgs {
     // floats between consecutive rows of w (and of w2): K for a plain [N, K] matrix, 2 K for W1 / W3, whose rows
     // alternate in one slot of the device blob.  Set by the launchers (0 is never valid).
     int ldw;
+    // planes form of the tile kernel (X3): the activations as three planes of bf16 terms, x3[token][plane][kp]
+    // (launch_split3 writes it from x just before the launch); ldx3 = 3 kp bf16 per token, kp = K rounded up to 64
+    const void *x3;
+    int ldx3, kp;
 };
 
 

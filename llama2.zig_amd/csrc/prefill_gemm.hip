@@ -15,8 +15,32 @@
 // launchers.  prefill_skinny.hip: P <= 64.  prefill_attention.hip: rmsnorm, embedding gather, causal
 // attention of a chunk.
 #include <cstdlib>
+#include <type_traits>
 
 #include "prefill_common.h"
+
+#ifndef L2Z_X3_EXP
+#define L2Z_X3_EXP 0   // experiment builds (scripts/x3_exp.sh): 1 no loads in the loop, 2 no MFMAs, 4 no X reads, 8 no W reads / splits, 16 no barrier
+#endif
+
+namespace l2z {
+// Whether a [P, n_whole] x K product of the WHOLE model takes the stream form of the planes kernel (a function of the model
+// and the chunk length only), and its K ranges (part of the arithmetic).  K: as the kernel walks it (rounded up to 64).
+bool x3_stream_shape(long long n_whole, int P, int K)
+{
+    const Tunables &t = tunables();
+    if (!t.pf_x3 || P < t.pf_x3_stream_min || P > 128 || K < 512) return false;
+    return n_whole * (long long)K * 4 > ((long long)16 << 20);   // cache-resident matrices keep the other forms
+}
+int x3_stream_sk(long long n_whole, int P, int K)
+{
+    (void)P;
+    const long long tiles = (n_whole + 127) / 128;
+    int sk = 1;
+    while (sk < 8 && tiles * sk < 224 && (K / 32) / (2 * sk) >= 8) sk *= 2;
+    return sk;
+}
+}  // namespace l2z
 
 namespace l2z {
 namespace {
@@ -107,6 +131,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, v16f (&acc)[TM]
                         v = (j & 1) ? partner * cs.y + v * cs.x : v * cs.x - partner * cs.y;
                     }
                     if (tok < a.P && j < nseg) o[seg == 0 ? (size_t)tok * ld + j : kv_index(a, ld, a.pos0 + tok, j)] = v;  // :354-358
+                }
+            }
+        return;
+    }
+    if constexpr (EPI == G_SWIGLU_IL) {
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int jt = 0; jt < TN; jt++) {
+                const int j = n0 + (wn * TN + jt) * 32 + (lane & 31);   // row of the alternating matrix: even W1, odd W3
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int tok = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const float v = acc[i][jt][r];
+                    const float partner = __shfl_xor(v, 1, 64);
+                    if (!(j & 1) && tok < a.P && j < a.N) a.out[(size_t)tok * a.ldo + (j >> 1)] = swiglu_merge(v, partner);  // :411-416
                 }
             }
         return;
@@ -222,10 +262,16 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
     constexpr int BMt = 32 * WM * TM, BNt = 32 * WN * TN;
     constexpr int NWG = WM * WN;                     // waves per k-group: WM x WN of them tile the block
     constexpr int NW = KGS ? NWG : NWG * KS;         // waves
-    constexpr int XI = BMt / RPI / NW, WI = BNt / RPI / NW;  // 1-KB loads per wave and stage
-    static_assert(BMt % (RPI * NW) == 0 && BNt % (RPI * NW) == 0, "tile rows per wave");
-    constexpr int STAGE = (BMt + BNt) * 4 * SLOTS;   // floats
+    // X3: the X tile is three planes of bf16 terms, [plane][row][8 slots of 8 bf16] (128 B per row and plane), brought in
+    // from the planes matrix a.x3 (launch_split3); a 1-KB load is 8 rows of one plane
+    static_assert(!(X3 && KGS), "the planes form has no two-block variant");
+    constexpr int XLOADS = X3 ? 3 * BMt / 8 : BMt / RPI;     // 1-KB loads of the X tile per stage
+    constexpr int XI = XLOADS / NW, WI = BNt / RPI / NW;      // 1-KB loads per wave and stage
+    static_assert(XLOADS % NW == 0 && BNt % (RPI * NW) == 0, "tile rows per wave");
+    constexpr int XSTG = X3 ? BMt * 96 : BMt * 4 * SLOTS;     // floats of the X part of a stage
+    constexpr int STAGE = XSTG + BNt * 4 * SLOTS;             // floats
     auto swz = [](int row) { return row & (SLOTS - 1); };
+    auto swzx = [](int row) { return (row >> 1) & 7; };       // planes: rows r, r + 1 fill one 256-B bank sweep
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wg = KGS ? wave : wave % NWG, kg = KGS ? (int)blockIdx.z : wave / NWG, wm = wg / WN, wn = wg % WN;
@@ -244,16 +290,24 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
     }
     const int n0 = bx * (PAIR ? BNt / 2 : BNt), m0 = by * BMt;
     // SPLIT == 1: this block's K range (launcher: K % (64 sk) == 0)
-    const int klen = SPLIT == 1 ? a.K / a.sk : a.K;
-    const int kbeg = SPLIT == 1 ? (int)blockIdx.z * klen : 0, kend = kbeg + klen;
+    // (whole 64-k stages, as even as they come: range z takes stages [S z / sk, S (z + 1) / sk) of the S = K / 64)
+    const int nst = a.K / BK;
+    const int kbeg = SPLIT == 1 ? BK * (int)((long long)nst * blockIdx.z / a.sk) : 0;
+    const int kend = SPLIT == 1 ? BK * (int)((long long)nst * (blockIdx.z + 1) / a.sk) : a.K;
 
     // this lane's part of every load: row (within the RPI-row group) lane / SLOTS, physical slot lane % SLOTS
     const int lrow = lane / SLOTS, pslot = lane % SLOTS;
     const float *xsrc[XI], *wsrc[WI];
 #pragma unroll
     for (int j = 0; j < XI; j++) {
-        const int r = (wave * XI + j) * RPI + lrow;               // tile row
-        xsrc[j] = a.x + (size_t)min(m0 + r, a.P - 1) * a.ldx + 4 * (kslot0 + (pslot ^ swz(r)));
+        if constexpr (X3) {
+            const int q = wave * XI + j, plane = q / (BMt / 8), r = (q % (BMt / 8)) * 8 + (lane >> 3), ps = lane & 7;
+            xsrc[j] = (const float *)((const __bf16 *)a.x3 + (size_t)min(m0 + r, a.P - 1) * a.ldx3 + (size_t)plane * a.kp +
+                                      8 * (ps ^ swzx(r)));
+        } else {
+            const int r = (wave * XI + j) * RPI + lrow;               // tile row
+            xsrc[j] = a.x + (size_t)min(m0 + r, a.P - 1) * a.ldx + 4 * (kslot0 + (pslot ^ swz(r)));
+        }
     }
 #pragma unroll
     for (int j = 0; j < WI; j++) {
@@ -273,9 +327,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
     }
 #define L2Z_DMA_ISSUE(k0_, buf_)                                                                          \
     do {                                                                                                  \
-        float *xs_ = smem + (buf_) * STAGE, *ws_ = xs_ + BMt * 4 * SLOTS;                                 \
-        _Pragma("unroll") for (int j = 0; j < XI; j++)                                                    \
-            lds_dma16(xsrc[j] + (k0_), xs_ + (wave * XI + j) * 256);  /* a 1-KB load: RPI whole LDS rows */ \
+        float *xs_ = smem + (buf_) * STAGE, *ws_ = xs_ + XSTG;                                            \
+        _Pragma("unroll") for (int j = 0; j < XI; j++)   /* (planes: k0 bf16 = k0 / 2 floats) */          \
+            lds_dma16(xsrc[j] + (X3 ? (k0_) / 2 : (k0_)), xs_ + (wave * XI + j) * 256);  /* a 1-KB load: RPI whole LDS rows */ \
         _Pragma("unroll") for (int j = 0; j < WI; j++)                                                    \
             lds_dma16(wsrc[j] + (k0_), ws_ + (wave * WI + j) * 256);                                       \
     } while (0)
@@ -296,8 +350,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         const int r = wm * 32 * TM + i * 32 + il;
-        arow[i] = r * SLOTS;
-        asw[i] = swz(r);
+        arow[i] = X3 ? r * 8 : r * SLOTS;
+        asw[i] = X3 ? swzx(r) : swz(r);
     }
 #pragma unroll
     for (int j = 0; j < TN; j++) {
@@ -308,7 +362,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
 
 #define L2Z_MULTIPLY_STAGE(buf_)                                                                         \
     do {                                                                                                  \
-        const v4f *xr = (const v4f *)(smem + (buf_) * STAGE), *wr = xr + BMt * SLOTS;                      \
+        const v4f *xr = (const v4f *)(smem + (buf_) * STAGE), *wr = xr + XSTG / 4;                         \
         _Pragma("unroll") for (int s = 0; s < SS; s++) {                                                   \
             const int slot = (KGS ? 0 : kg * SPG) + 2 * s + hl;                                           \
             v4f av[TM], bv[TN];                                                                           \
@@ -324,37 +378,131 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
         }                                                                                                 \
     } while (0)
 
-    // X3: the same product on the bf16 matrix cores.  A k-step is 16 k: lane (row, k-half hl) holds the row's 8
-    // consecutive floats of slots 4 u + 2 hl, 4 u + 2 hl + 1 (two conflict-free b128 reads), splits them into three
-    // bf16 terms (split3) and feeds the six products of x3_mfma to ONE accumulator.
-    auto multiply_stage_x3 = [&](int buf_) {
-        const v4f *xr = (const v4f *)(smem + buf_ * STAGE), *wr = xr + BMt * SLOTS;
+    // X3: the same product on the bf16 matrix cores (prefill_common.h split3 / x3_mfma).  A k-step is 16 k: lane (row,
+    // k-half hl) takes the row's 8 consecutive k of bf16 slot sa = (8 / KS) kg + 2 u + hl -- X: one b128 read per plane, the
+    // terms are already split (launch_split3); W: the two float4 of slots 2 sa, 2 sa + 1, split here -- and feeds the six
+    // products to ONE accumulator.
+    // The loop is software-pipelined by hand: one block of <= 8 waves owns the CU, so nothing overlaps unless a wave
+    // overlaps with itself.  While the MFMAs of k-step t run, the wave (a) reads W's floats of step t + 1 and splits them
+    // between the MFMAs, (b) refills each token tile's X operand for t + 1 right behind the MFMAs that used it, (c) in the
+    // last step of a stage, behind the barrier that says "stage s + 1 has landed and nobody reads stage s any more",
+    // issues the loads of stage s + 2, spread over the step.  One barrier per stage; loads run a whole stage ahead.
+    if constexpr (X3) {
+        constexpr int NU = 4 / KS;                   // k-steps of this wave's k-group per stage
+        constexpr int NL = XI + WI;                  // this wave's 1-KB loads per stage
+        const int nstage = (kend - kbeg) / BK;
+        auto issue_one = [&](int k0_, int buf_, int idx) {
+            float *xs_ = smem + buf_ * STAGE, *ws_ = xs_ + XSTG;
+            if (idx < XI) lds_dma16(xsrc[idx] + k0_ / 2, xs_ + (wave * XI + idx) * 256);
+            else lds_dma16(wsrc[idx - XI] + k0_, ws_ + (wave * WI + (idx - XI)) * 256);
+        };
+        auto read_a = [&](int buf_, int u, int i) {
+            const v8bf *xp = (const v8bf *)(smem + buf_ * STAGE);
+            const int o = arow[i] + ((kg * (8 / KS) + 2 * u + hl) ^ asw[i]);
+            Bf3 r;
+            r.t1 = xp[o]; r.t2 = xp[BMt * 8 + o]; r.t3 = xp[2 * BMt * 8 + o];
+            return r;
+        };
+        auto read_b = [&](int buf_, int u, int j, v4f &lo, v4f &hi) {
+            const v4f *wr = (const v4f *)(smem + buf_ * STAGE + XSTG);
+            const int sb = 2 * (kg * (8 / KS) + 2 * u + hl);
+            lo = wr[brow[j] + (sb ^ bsw[j])];
+            hi = wr[brow[j] + ((sb + 1) ^ bsw[j])];
+        };
+        Bf3 av[TM], bcur[TN];
+        v4f blo[TN], bhi[TN];
 #pragma unroll
-        for (int u = 0; u < SS / 2; u++) {
-            const int slot = (KGS ? 0 : kg * SPG) + 4 * u + 2 * hl;
-            Bf3 av[TM], bv[TN];
+        for (int q = 0; q < NL; q++) issue_one(kbeg, 0, q);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (nstage > 1) {
 #pragma unroll
-            for (int i = 0; i < TM; i++) av[i] = split3(xr[arow[i] + (slot ^ asw[i])], xr[arow[i] + ((slot + 1) ^ asw[i])]);
-#pragma unroll
-            for (int j = 0; j < TN; j++) bv[j] = split3(wr[brow[j] + (slot ^ bsw[j])], wr[brow[j] + ((slot + 1) ^ bsw[j])]);
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++) acc[i][j] = x3_mfma(av[i], bv[j], acc[i][j]);
+            for (int q = 0; q < NL; q++) issue_one(kbeg + BK, 1, q);
         }
-    };
-
+#pragma unroll
+        for (int j = 0; j < TN; j++) { read_b(0, 0, j, blo[j], bhi[j]); bcur[j] = split3(blo[j], bhi[j]); }
+#pragma unroll
+        for (int i = 0; i < TM; i++) av[i] = read_a(0, 0, i);
+        int buf = 0;
+        // one k-step; the flags are compile-time so that the steady-state loop body is ONE basic block
+        auto step = [&](auto last_u_c, auto has_next_c, auto issue_c, int s, int u) {
+            constexpr bool last_u = decltype(last_u_c)::value, has_next = decltype(has_next_c)::value,
+                           issue = decltype(issue_c)::value;
+            const int nb = last_u ? buf ^ 1 : buf, nu = last_u ? 0 : u + 1;
+            if constexpr (last_u && has_next) {
+                // stage s + 1 has landed (its loads were issued a stage ago) and this wave's reads of stage s are done ...
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                if (!(L2Z_X3_EXP & 16))
+                __syncthreads();   // ... for every wave: stage s's buffer is free for the loads of stage s + 2
+            }
+            if constexpr (has_next && !(L2Z_X3_EXP & 8)) {
+#pragma unroll
+                for (int j = 0; j < TN; j++) read_b(nb, nu, j, blo[j], bhi[j]);
+            }
+            Bf3 bnxt[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    if (!(L2Z_X3_EXP & 2)) acc[i][j] = x3_mfma(av[i], bcur[j], acc[i][j]);
+                if constexpr (issue && !(L2Z_X3_EXP & 1)) {
+                    constexpr int per = (NL + TM - 1) / TM;
+#pragma unroll
+                    for (int q = i * per; q < (i + 1) * per && q < NL; q++) issue_one(kbeg + (s + 2) * BK, buf, q);
+                }
+                if constexpr (has_next) {
+                    if (!(L2Z_X3_EXP & 4)) av[i] = read_a(nb, nu, i);
+                    // W's terms for the next step: tile j is split behind token tile (j + 1) % TM's MFMAs (its floats
+                    // were requested at the top of the step)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+                        if ((j + 1) % TM == i) bnxt[j] = (L2Z_X3_EXP & 8) ? bcur[j] : split3(blo[j], bhi[j]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (has_next) {
+#pragma unroll
+                for (int j = 0; j < TN; j++) bcur[j] = bnxt[j];
+            }
+        };
+        using T = std::true_type;
+        using F = std::false_type;
+        int s = 0;
+        for (; s + 2 < nstage; s++) {   // steady state: a next step always exists, the last step of a stage issues loads
+#pragma unroll
+            for (int u = 0; u < NU; u++) {
+                if (u == NU - 1) step(T{}, T{}, T{}, s, u);
+                else step(F{}, T{}, F{}, s, u);
+            }
+            buf ^= 1;
+        }
+        if (s + 1 < nstage) {           // the stage before the last: nothing left to load
+#pragma unroll
+            for (int u = 0; u < NU; u++) {
+                if (u == NU - 1) step(T{}, T{}, F{}, s, u);
+                else step(F{}, T{}, F{}, s, u);
+            }
+            buf ^= 1;
+            s++;
+        }
+#pragma unroll
+        for (int u = 0; u < NU; u++) {  // the last stage: its last step has no successor
+            if (u == NU - 1) step(T{}, F{}, F{}, s, u);
+            else step(F{}, T{}, F{}, s, u);
+        }
+        __syncthreads();   // every wave is done with the stage buffers (the k-groups' sums reuse them)
+    } else {
     L2Z_DMA_ISSUE(kbeg, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int buf = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         if (k0 + BK < kend) L2Z_DMA_ISSUE(k0 + BK, buf ^ 1);
-        if constexpr (X3) multiply_stage_x3(buf);
-        else L2Z_MULTIPLY_STAGE(buf);
+        L2Z_MULTIPLY_STAGE(buf);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's loads of the next stage have landed
         __syncthreads();                                  // everyone's have, and nobody still reads this one
         buf ^= 1;
+    }
     }
 #undef L2Z_MULTIPLY_STAGE
     if (KS > 1 && !KGS) {
@@ -476,12 +624,271 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
     }
 }
 
-// the kernel of a form: on the f32 matrix cores, or (L2Z_PF_X3, default) the same form on the bf16 ones
-template <int EPI, int TM, int TN, int KS, bool PAIR = false, int WM = 2, int WN = 2, int SPLIT = 0>
-const void *dma_fn()
+// ---- the STREAM form of the planes kernel: chunks of <= 128 tokens of matrices that stream from HBM (round 6) ----
+// At <= 128 tokens a layer's matrices cross the chip once (809 MB at the 7B shape: 130 us at the HBM rate) against 40-160 us
+// of bf16 MFMAs: the tile forms above -- one or two blocks per CU, two stage buffers, loads ONE stage ahead -- are bound by
+// neither: every stage waits out the memory latency.  This form keeps more of the stream in flight and splits W once:
+//  * a block = ALL the chunk's tokens (TM tiles of 32) x 128 features x one K range; 8 waves = 4 feature groups x 2
+//    k-groups; a wave owns 32 features x all tokens, so a W element is split into its bf16 terms exactly once on the chip;
+//  * stages of 32 k (X planes 192 B per token, W 128 B per feature: 22-40 KB) in a ring of NBUF = 4-7 buffers, loads
+//    NBUF stages ahead: the stage a wave needs next was requested 3-6 stages ago (s_waitcnt vmcnt counted, one barrier per
+//    stage); the loop is the hand-pipelined one of the tile forms (operands of stage s + 1 read / split behind stage s's MFMAs);
+//  * the grid is filled by K ranges (blockIdx.z; x3_stream_sk: a function of the WHOLE model's matrix and the chunk length),
+//    partial sums through the split-K workspace, the last arriver adds them in range order and runs the epilogue.
+// An output's value is a function of (K, the ranges) only -- not of the rows a rank owns, not of launch fusion.
+template <int N_> __device__ __forceinline__ void wait_vmcnt()
 {
-    return tunables().pf_x3 ? (const void *)prefill_gemm_dma<EPI, TM, TN, KS, PAIR, WM, WN, SPLIT, true>
-                            : (const void *)prefill_gemm_dma<EPI, TM, TN, KS, PAIR, WM, WN, SPLIT, false>;
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N_) : "memory");
+}
+
+template <int EPI, int TM, int NBUF>
+__global__ __launch_bounds__(512) void prefill_x3_stream(const GemmArgs a)
+{
+    constexpr int BK = 32, WN = 4, KS = 2, NW = WN * KS, BMt = 32 * TM, BNt = 32 * WN, TN = 1;
+    constexpr int XLOADS = 3 * BMt * 64 / 1024;              // 1-KB loads of a stage's X planes: 16 rows of one plane each
+    constexpr int XI = (XLOADS + NW - 1) / NW, WI = BNt * 128 / 1024 / NW, NL = XI + WI;   // per wave and stage (X: the last waves repeat a load)
+    constexpr int XSTG = 3 * BMt * 16, WSTG = BNt * 32, STAGE = XSTG + WSTG;                 // floats
+    static_assert(NL * (NBUF - 1) <= 63, "vmcnt");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave & 3, kg = wave >> 2;
+    const int hl = lane >> 5, il = lane & 31;
+    const int bx = blockIdx.x, n0 = bx * BNt;
+    const int nst_all = a.K / BK, sk = a.sk > 1 ? a.sk : 1;
+    const int sbeg = (int)((long long)nst_all * blockIdx.z / sk), nstage = (int)((long long)nst_all * (blockIdx.z + 1) / sk) - sbeg;
+    const int kbeg = sbeg * BK;
+    auto swzx = [](int r) { return (r >> 2) & 3; };          // plane rows of 64 B: four rows fill one 256-B bank sweep
+    auto swzw = [](int r) { return (r >> 1) & 7; };          // W rows of 128 B: two rows
+    const float *xsrc[XI], *wsrc[WI];
+    int xdst[XI];
+#pragma unroll
+    for (int j = 0; j < XI; j++) {
+        const int q = min(wave * XI + j, XLOADS - 1), plane = q / (2 * TM), r = (q % (2 * TM)) * 16 + (lane >> 2), ps = lane & 3;
+        xsrc[j] = (const float *)((const __bf16 *)a.x3 + (size_t)min(r, a.P - 1) * a.ldx3 + (size_t)plane * a.kp + 8 * (ps ^ swzx(r)));
+        xdst[j] = q * 256;
+    }
+#pragma unroll
+    for (int j = 0; j < WI; j++) {
+        const int r = (wave * WI + j) * 8 + (lane >> 3), ps = lane & 7;
+        const float *m = a.w;
+        int f = n0 + r, nseg = a.N;
+        if constexpr (EPI == G_QKV) {
+            const int seg = n0 >= a.nq + a.nkv ? 2 : n0 >= a.nq ? 1 : 0;
+            m = seg == 0 ? a.w : seg == 1 ? a.wk : a.wv;
+            f -= seg == 2 ? a.nq + a.nkv : seg == 1 ? a.nq : 0;
+            nseg = seg == 0 ? a.nq : a.nkv;
+        }
+        wsrc[j] = m + (size_t)min(f, nseg - 1) * a.ldw + 4 * (ps ^ swzw(r));
+    }
+    auto issue_one = [&](int stage, int idx) {
+        float *xs_ = smem + (stage % NBUF) * STAGE, *ws_ = xs_ + XSTG;
+        const int k0 = kbeg + stage * BK;
+        if (idx < XI) lds_dma16(xsrc[idx] + k0 / 2, xs_ + xdst[idx]);
+        else lds_dma16(wsrc[idx - XI] + k0, ws_ + (wave * WI + (idx - XI)) * 256);
+    };
+    int arow[TM], asw[TM];
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int r = i * 32 + il;
+        arow[i] = r * 4;
+        asw[i] = swzx(r);
+    }
+    const int brow = (wn * 32 + il) * 8, bsw = swzw(wn * 32 + il);
+    const int sa = kg * 2 + hl, sb = 2 * sa;                 // this lane's bf16 slot / first float4 slot of a stage row
+    auto read_a = [&](int stage, int i) {
+        const v8bf *xp = (const v8bf *)(smem + (stage % NBUF) * STAGE);
+        const int o = arow[i] + (sa ^ asw[i]);
+        Bf3 r;
+        r.t1 = xp[o]; r.t2 = xp[BMt * 4 + o]; r.t3 = xp[2 * BMt * 4 + o];
+        return r;
+    };
+    auto read_b = [&](int stage, v4f &lo, v4f &hi) {
+        const v4f *wr = (const v4f *)(smem + (stage % NBUF) * STAGE + XSTG);
+        lo = wr[brow + (sb ^ bsw)];
+        hi = wr[brow + ((sb + 1) ^ bsw)];
+    };
+    v16f acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][0][r] = 0.0f;
+
+    // prologue: the first NBUF stages requested; stage 0 awaited
+#pragma unroll
+    for (int b = 0; b < NBUF; b++)
+        if (b < nstage) {
+#pragma unroll
+            for (int q = 0; q < NL; q++) issue_one(b, q);
+        }
+    {
+        const int ahead = (nstage < NBUF ? nstage : NBUF) - 1;   // stages that may still be in flight
+        // (a literal per case: the counter takes an immediate)
+        if (ahead <= 0) wait_vmcnt<0>();
+        else if (ahead == 1) wait_vmcnt<NL>();
+        else if (ahead == 2) wait_vmcnt<2 * NL>();
+        else if (ahead == 3) wait_vmcnt<(NBUF > 3 ? 3 : 0) * NL>();
+        else if (ahead == 4) wait_vmcnt<(NBUF > 4 ? 4 : 0) * NL>();
+        else if (ahead == 5) wait_vmcnt<(NBUF > 5 ? 5 : 0) * NL>();
+        else wait_vmcnt<(NBUF > 6 ? 6 : 0) * NL>();
+    }
+    __syncthreads();
+    Bf3 av[TM], bcur;
+    v4f blo, bhi;
+    read_b(0, blo, bhi);
+    bcur = split3(blo, bhi);
+#pragma unroll
+    for (int i = 0; i < TM; i++) av[i] = read_a(0, i);
+
+    // step s: MFMAs of stage s (operands in registers); behind them the loads of stage s + NBUF and the operands of s + 1.
+    // AHEAD: stages beyond s + 1 that may still be in flight at the top of the step (steady state NBUF - 2)
+    auto step = [&](auto ahead_c, auto has_next_c, auto issue_c, int s) {
+        constexpr int ahead = decltype(ahead_c)::value;
+        constexpr bool has_next = decltype(has_next_c)::value, issue = decltype(issue_c)::value;
+        if constexpr (has_next) {
+            wait_vmcnt<ahead * NL>();   // stage s + 1 has landed (this wave's part) and this wave's reads of stage s are done ...
+            __syncthreads();            // ... for every wave: stage s's buffer takes the loads of stage s + NBUF
+            read_b(s + 1, blo, bhi);
+        }
+        Bf3 bnxt;
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            acc[i][0] = x3_mfma(av[i], bcur, acc[i][0]);
+            if constexpr (issue) {
+                constexpr int per = (NL + TM - 1) / TM;
+#pragma unroll
+                for (int q = i * per; q < (i + 1) * per && q < NL; q++) issue_one(s + NBUF, q);
+            }
+            if constexpr (has_next) {
+                av[i] = read_a(s + 1, i);
+                if (i == (TM > 1 ? 1 : 0)) bnxt = split3(blo, bhi);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (has_next) bcur = bnxt;
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    int s = 0;
+    for (; s + NBUF < nstage; s++) step(std::integral_constant<int, NBUF - 2>{}, T{}, T{}, s);
+    // the tail: nothing left to request; fewer and fewer stages in flight
+#pragma unroll
+    for (int t = NBUF - 1; t >= 1; t--)
+        if (nstage - 1 - s == t) {
+            // stages s + 1 .. s + t are the last ones: t - 1 of them beyond s + 1
+            if (t - 1 >= NBUF - 2) step(std::integral_constant<int, NBUF - 2>{}, T{}, F{}, s);
+            else if (t - 1 == 4) step(std::integral_constant<int, (NBUF > 6 ? 4 : 0)>{}, T{}, F{}, s);
+            else if (t - 1 == 3) step(std::integral_constant<int, (NBUF > 5 ? 3 : 0)>{}, T{}, F{}, s);
+            else if (t - 1 == 2) step(std::integral_constant<int, (NBUF > 4 ? 2 : 0)>{}, T{}, F{}, s);
+            else if (t - 1 == 1) step(std::integral_constant<int, (NBUF > 3 ? 1 : 0)>{}, T{}, F{}, s);
+            else step(std::integral_constant<int, 0>{}, T{}, F{}, s);
+            s++;
+        }
+    step(std::integral_constant<int, 0>{}, F{}, F{}, s);
+    __syncthreads();   // every wave is done with the ring (the k-groups' sums reuse it)
+
+    // the two k-groups' sums, then (sk > 1) the ranges' through the workspace, then the epilogue -- as in the tile forms
+    {
+        float *red = smem;  // [WN waves][TM * 16][64 lanes]
+        if (kg > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) red[((wn * TM + i) * 16 + r) * 64 + lane] = acc[i][0][r];
+        }
+        __syncthreads();
+        if (kg > 0) return;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][0][r] += red[((wn * TM + i) * 16 + r) * 64 + lane];
+    }
+    if (sk > 1) {
+        constexpr int PT = WN * TM * 16 * 64;   // floats per partial = the tile's outputs
+        float *part = a.sk_part + (size_t)bx * (size_t)sk * PT;
+        float *mine = part + (size_t)blockIdx.z * PT + (size_t)wn * (TM * 16 * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                __hip_atomic_store(mine + (i * 16 + r) * 64, acc[i][0][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // (the live waves: k-group 0)
+        int *flag = (int *)smem + WN * TM * 16 * 64;   // past the k-groups' sums
+        if (tid == 0) {
+            const int prev = __hip_atomic_fetch_add(a.sk_cnt + bx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = prev == sk - 1;
+            if (last) {
+                __hip_atomic_store(a.sk_cnt + bx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            *flag = last;
+        }
+        __syncthreads();
+        if (!*flag) return;
+        // range 0, then 1, ... in order; a range's TM x 16 values are requested together (one round trip per range, not
+        // one per value: with the ranges in the inner loop the compiler waits out every load)
+        const float *p0 = part + (size_t)wn * (TM * 16 * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][0][r] = p0[(i * 16 + r) * 64];
+        for (int z = 1; z < sk; z++) {
+            v16f t[TM];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) t[i][r] = p0[(size_t)z * PT + (i * 16 + r) * 64];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][0][r] += t[i][r];
+        }
+    }
+    gemm_epilogue<EPI, TM, TN>(a, acc, n0, 0, 0, wn, lane);
+}
+
+// A form of the tile kernel as a launch: kernel, threads, dynamic LDS.  The block's output tile is 32 WM TM tokens x
+// 32 WN TN features whichever cores multiply it: on the f32 matrix cores WM x WN waves per k-group tile it; on the bf16
+// ones (L2Z_PF_X3, the default) WN waves each take ALL the tile's tokens x 32 TN features, so that a W element is split
+// into its bf16 terms by one wave only -- the same template with (TM WM, TN, 1, WN).  Same k order either way inside a
+// mode; between the modes the arithmetic differs (tolerance, not bits).
+struct DmaForm { const void *fn; unsigned threads; size_t lds; };
+template <int EPI, int TM, int TN, int KS, bool PAIR = false, int WM = 2, int WN = 2, int SPLIT = 0>
+DmaForm dma_form()
+{
+    constexpr size_t BMt = 32 * WM * TM, BNt = 32 * WN * TN;
+    const size_t red = SPLIT == 2 ? 0 : (size_t)(KS - 1) * WM * WN * TM * TN * 16 * 64 * sizeof(float);  // the k-groups' sums
+    DmaForm f;
+    if constexpr (SPLIT != 2) {
+        if (tunables().pf_x3) {
+            const int v = tunables().pf_x3_form;   // EXPERIMENT: 0 remap (WM -> 1), 1 keep the WM x WN waves, 2: 128 x 128 unpaired as 1 x 4 waves
+            bool done = false;
+            if constexpr (TM == 2 && TN == 2 && WM == 2 && WN == 2 && !PAIR) {
+                if (v == 2) {
+                    f.fn = (const void *)prefill_gemm_dma<EPI, 4, 1, KS, false, 1, 4, SPLIT, true>;
+                    f.threads = 64 * 4 * KS;
+                    done = true;
+                }
+            }
+            if (done) {
+            } else if (v >= 1 && WM == 2) {
+                f.fn = (const void *)prefill_gemm_dma<EPI, TM, TN, KS, PAIR, WM, WN, SPLIT, true>;
+                f.threads = 64 * WM * WN * KS;
+            } else {
+            f.fn = (const void *)prefill_gemm_dma<EPI, TM * WM, TN, KS, PAIR, 1, WN, SPLIT, true>;
+            f.threads = 64 * WN * KS;
+            }
+            f.lds = 2 * (BMt * 384 + BNt * 256);   // two stages of three 128-B plane rows per token + 256-B W rows
+            if (red > f.lds) f.lds = red;
+            if (f.lds > 48 * 1024) (void)hipFuncSetAttribute(f.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds);
+            return f;
+        }
+    }
+    f.fn = (const void *)prefill_gemm_dma<EPI, TM, TN, KS, PAIR, WM, WN, SPLIT, false>;
+    f.threads = SPLIT == 2 ? 64 * WM * WN : 64 * WM * WN * KS;
+    f.lds = 2 * (BMt + BNt) * (SPLIT == 2 ? 32 : 64) * sizeof(float);   // two stage buffers (SPLIT == 2: of half rows)
+    if (red > f.lds) f.lds = red;
+    if (f.lds > 48 * 1024) (void)hipFuncSetAttribute(f.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds);
+    return f;
 }
 
 template <int EPI, int TM, int TN, int KS>
@@ -490,15 +897,11 @@ hipError_t gemm_launch_t(const GemmArgs &a, hipStream_t st)
     constexpr int BMt = 64 * TM, BNt = 64 * TN;
     static_assert((BMt / 4) % (4 * KS) == 0 && (BNt / 4) % (4 * KS) == 0, "tile rows per wave");
     if (a.K % 64 != 0 || a.ldx % 4 != 0) return hipErrorInvalidValue;   // (the launchers round K up: pad_k)
-    const size_t red = (size_t)(KS - 1) * 4 * TM * TN * 16 * 64 * sizeof(float);
-    size_t lds = 2 * (size_t)(BMt + BNt) * 64 * sizeof(float);
-    if (red > lds) lds = red;
-    const void *fn = dma_fn<EPI, TM, TN, KS, false>();
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const DmaForm f = dma_form<EPI, TM, TN, KS, false>();
     GemmArgs args = a;
     const dim3 grid1 = dma_grid((a.N + BNt - 1) / BNt, (a.P + BMt - 1) / BMt, &args);
     void *params[] = {&args};
-    return hipLaunchKernel(fn, grid1, dim3(256 * KS), params, lds, st);
+    return hipLaunchKernel(f.fn, grid1, dim3(f.threads), params, f.lds, st);
 }
 
 // the direct-to-LDS tile kernel with fewer waves per block -- 32 x 64 (1 x 2 waves per k-group) and
@@ -509,13 +912,12 @@ bool gemm_launch_small(const GemmArgs &a, hipStream_t st, hipError_t *err)
 {
     if (a.K % 64 != 0 || a.ldx % 4 != 0) return false;
     constexpr int KS = 2, BMt = 32 * WM, BNt = 32 * WN;
-    const size_t lds = 2 * (size_t)(BMt + BNt) * 64 * sizeof(float);
-    const void *fn = dma_fn<EPI, 1, 1, KS, false, WM, WN>();
+    const DmaForm f = dma_form<EPI, 1, 1, KS, false, WM, WN>();
     dim3 grid((a.N + BNt - 1) / BNt, (a.P + BMt - 1) / BMt);
     GemmArgs args = a;
     const dim3 grid1 = dma_grid((int)grid.x, (int)grid.y, &args);
     void *params[] = {&args};
-    *err = hipLaunchKernel(fn, grid1, dim3(64 * WM * WN * KS), params, lds, st);
+    *err = hipLaunchKernel(f.fn, grid1, dim3(f.threads), params, f.lds, st);
     return true;
 }
 
@@ -545,6 +947,8 @@ static SkTile choose_tile_sk(int N, int P, int sk)
     static const struct { int tok; double eff; } form[3] = {{128, 1.0}, {64, 0.87}, {32, 0.80}};
     int best = -1;
     double best_cost = 0.0;
+    if (tunables().pf_x3 && tunables().pf_x3_tok > 0)   // EXPERIMENT
+        return tunables().pf_x3_tok >= 128 ? SKT_128x64 : tunables().pf_x3_tok >= 64 ? SKT_64x64 : SKT_32x64;
     for (int f = 0; f < 3; f++) {
         if (f == SKT_128x64 && P <= 64) continue;
         const long long blocks = (long long)((N + 63) / 64) * ((P + form[f].tok - 1) / form[f].tok) * sk;
@@ -560,20 +964,16 @@ static SkTile choose_tile_sk(int N, int P, int sk)
 template <int EPI, int TM, int TN, bool PAIR, int WM, int WN>
 hipError_t dma_launch_split(GemmArgs a, int n_feat, int sk, const SplitKWs *ws, hipStream_t st)
 {
-    constexpr int KS = 2, BMt = 32 * WM * TM, BNt = 32 * WN * TN, NWG = WM * WN;
+    constexpr int KS = 2, BMt = 32 * WM * TM, BNt = 32 * WN * TN;
     constexpr int feat = PAIR ? BNt / 2 : BNt;  // features (of each matrix when paired) per block
     if (ws == nullptr || ws->part == nullptr || ws->cnt == nullptr) return hipErrorInvalidValue;
     const int ntx = (n_feat + feat - 1) / feat, nty = (a.P + BMt - 1) / BMt;
     if ((size_t)ntx * nty * sk * BMt * BNt > ws->part_floats || ntx * nty > ws->cnt_ints) return hipErrorOutOfMemory;
     a.sk = sk; a.sk_part = ws->part; a.sk_cnt = ws->cnt;
-    size_t lds = 2 * (size_t)(BMt + BNt) * 64 * sizeof(float);
-    const size_t red = (size_t)(KS - 1) * NWG * TM * TN * 16 * 64 * sizeof(float);
-    if (red > lds) lds = red;
-    const void *fn = dma_fn<EPI, TM, TN, KS, PAIR, WM, WN, 1>();
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const DmaForm f = dma_form<EPI, TM, TN, KS, PAIR, WM, WN, 1>();
     const dim3 grid = dma_grid(ntx, nty, &a);
     void *params[] = {&a};
-    return hipLaunchKernel(fn, grid, dim3(64 * NWG * KS), params, lds, st);
+    return hipLaunchKernel(f.fn, grid, dim3(f.threads), params, f.lds, st);
 }
 
 // unpaired / fused-qkv products (TN = 1 forms) and the paired W1 | W3 product (TN = 2 forms)
@@ -592,17 +992,15 @@ hipError_t gemm_launch_sk(const GemmArgs &a, int n_feat, int sk, const SplitKWs 
 template <int EPI, int TM, int TN, bool PAIR, int WM, int WN>
 hipError_t dma_launch_kgs(GemmArgs a, int n_feat, const SplitKWs *ws, hipStream_t st)
 {
-    constexpr int KS = 2, BMt = 32 * WM * TM, BNt = 32 * WN * TN, NWG = WM * WN;
+    constexpr int KS = 2, BMt = 32 * WM * TM, BNt = 32 * WN * TN;
     constexpr int feat = PAIR ? BNt / 2 : BNt;
     const int ntx = (n_feat + feat - 1) / feat, nty = (a.P + BMt - 1) / BMt;
     if ((size_t)ntx * nty * BMt * BNt > ws->part_floats || 2 * ntx * nty > ws->cnt_ints) return hipErrorOutOfMemory;
     a.sk = 2; a.sk_part = ws->part; a.sk_cnt = ws->cnt;  // sk: the grid's z extent (dma_grid)
-    const size_t lds = 2 * (size_t)(BMt + BNt) * 32 * sizeof(float);  // two stage buffers of half rows
-    const void *fn = dma_fn<EPI, TM, TN, KS, PAIR, WM, WN, 2>();
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const DmaForm f = dma_form<EPI, TM, TN, KS, PAIR, WM, WN, 2>();
     const dim3 grid = dma_grid(ntx, nty, &a);
     void *params[] = {&a};
-    return hipLaunchKernel(fn, grid, dim3(64 * NWG), params, lds, st);
+    return hipLaunchKernel(f.fn, grid, dim3(f.threads), params, f.lds, st);
 }
 
 // Whether a [P, N] product (N = features of each matrix when paired) goes out in the two-block form, and on which
@@ -612,7 +1010,7 @@ struct KgsChoice { bool use; TileForm tile; };
 static KgsChoice choose_kgs(int N, int P, int K, bool pair, const SplitKWs *ws)
 {
     KgsChoice none = {false, TILE_64x64};
-    if (ws == nullptr || ws->part == nullptr || K % 64 != 0) return none;
+    if (ws == nullptr || ws->part == nullptr || K % 64 != 0 || tunables().pf_x3) return none;   // (the planes form has no two-block variant)
     // Measured (7B shape, whole prefill, interleaved; profiles/r03_prefill_kgs_ab.txt): the form pays where the
     // unsplit family runs ONE 8-wave block of a 128-token tile per CU -- two independent 4-wave blocks of half
     // the LDS hide each other's stage barriers: 512 tokens 58.56 -> 57.32 ms on 128 x 64 tiles -- and loses or
@@ -647,6 +1045,54 @@ hipError_t gemm_launch_kgs(const GemmArgs &a, int n_feat, TileForm tile, const S
     }
 }
 
+// The launch's activation matrix as three planes of bf16 terms (prefill_common.h split3): x3[token][plane][kp], element k of
+// plane t = term t of x[token][k].  One thread per 8 floats; the columns K .. kp of x are the zero padding (pad_k).
+__global__ __launch_bounds__(256) void prefill_split3_kernel(const float *x, int ldx, __bf16 *x3, int kp, int P)
+{
+    const int per_row = kp >> 3;
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (size_t)P * per_row) return;
+    const int p = (int)(id / per_row), c = (int)(id % per_row);
+    const v4f *src = (const v4f *)(x + (size_t)p * ldx + 8 * c);
+    const Bf3 t = split3(src[0], src[1]);
+    v8bf *o = (v8bf *)(x3 + (size_t)p * 3 * kp) + c;
+    o[0] = t.t1; o[per_row] = t.t2; o[2 * per_row] = t.t3;
+}
+
+// before a launch of the planes form: a.K is the padded K; fills ws->x3 from a.x
+hipError_t prepare_x3(GemmArgs &a, const SplitKWs *ws, hipStream_t st)
+{
+    if (!tunables().pf_x3) return hipSuccess;
+    if (ws == nullptr || ws->x3 == nullptr || (size_t)a.P * 3 * a.K * sizeof(__bf16) > ws->x3_bytes) return hipErrorInvalidValue;
+    a.x3 = ws->x3; a.kp = a.K; a.ldx3 = 3 * a.K;
+    const size_t n = (size_t)a.P * (a.K >> 3);
+    prefill_split3_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(a.x, a.ldx, (__bf16 *)ws->x3, a.K, a.P);
+    return hipGetLastError();
+}
+
+// launch of the stream form; a.K is the padded K, a.N this rank's rows, n_whole the whole model's (the K ranges)
+template <int EPI>
+hipError_t launch_x3_stream(GemmArgs a, long long n_whole, const SplitKWs *ws, hipStream_t st)
+{
+    if (const hipError_t e = prepare_x3(a, ws, st); e != hipSuccess) return e;
+    const int sk = x3_stream_sk(n_whole, a.P, a.K), tm = (a.P + 31) / 32, ntx = (a.N + 127) / 128;
+    if (ws->part == nullptr || ws->cnt == nullptr || (size_t)ntx * sk * tm * 32 * 128 > ws->part_floats || ntx > ws->cnt_ints)
+        return hipErrorOutOfMemory;
+    a.sk = sk; a.sk_part = ws->part; a.sk_cnt = ws->cnt;
+    const void *fn;
+    int nbuf;
+    switch (tm) {
+    case 1: fn = (const void *)prefill_x3_stream<EPI, 1, 7>; nbuf = 7; break;
+    case 2: fn = (const void *)prefill_x3_stream<EPI, 2, 5>; nbuf = 5; break;
+    case 3: fn = (const void *)prefill_x3_stream<EPI, 3, 4>; nbuf = 4; break;
+    default: fn = (const void *)prefill_x3_stream<EPI, 4, 4>; nbuf = 4; break;
+    }
+    const size_t lds = (size_t)nbuf * (3 * 32 * tm * 64 + 128 * 128);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    void *params[] = {&a};
+    return hipLaunchKernel(fn, dim3(ntx, 1, sk), dim3(512), params, lds, st);
+}
+
 }  // namespace
 
 // K ranges per output tile (see l2z_internal.h); > 1 also means "the tile kernel, not the short-prompt kernels".
@@ -662,8 +1108,12 @@ hipError_t gemm_launch_kgs(const GemmArgs &a, int n_feat, TileForm tile, const S
 constexpr long long kRefCus = 256;  // the part the split-K rule was measured on; see prefill_split_k
 int prefill_split_k(long long n_whole, int P, int K, bool pair)
 {
-    (void)pair;
     if (P > kSplitKMaxTokens) return 1;
+    if (tunables().pf_x3 && tunables().pf_x3_sk > 0) {   // EXPERIMENT: decimal digits qkv, wo, W1|W3, W2
+        const int d = tunables().pf_x3_sk;
+        const int v = pair ? d / 10 % 10 : K > n_whole ? d % 10 : n_whole > K ? d / 1000 % 10 : d / 100 % 10;
+        return v > 0 && K / 64 >= 4 * v ? v : 1;
+    }
     int sk = 1;
     {
         const bool streams = n_whole * (long long)K * 4 > ((long long)16 << 20);
@@ -692,9 +1142,17 @@ hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float 
     GemmArgs a = {x, w3, w1, out, out, P, N, K, ldx, ldo, ldo, 0, nullptr, 0, n_scale > 0 ? n_scale : 1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
     a.ldw = ldw > 0 ? ldw : K;
     constexpr int skinny_max = Tunables::pf_skinny_max;
+    if (const int kp = pad_k(K, 64, ldx); kp > 0 && ldw == 2 * K && w3 == w1 + K &&
+        x3_stream_shape(2LL * N * a.n_scale, P, kp)) {
+        // the stream form takes W1 | W3 as ONE matrix of alternating rows (the blob's slot)
+        GemmArgs b = a;
+        b.w = w1; b.w2 = nullptr; b.N = 2 * N; b.K = kp; b.ldw = K;
+        return launch_x3_stream<G_SWIGLU_IL>(b, 2LL * N * a.n_scale, ws, st);
+    }
     if (P <= skinny_max && sk <= 1) return launch_prefill_skinny_pair(G_SWIGLU, a, st);  // prefill_skinny.hip (or not supported)
     K = a.K = pad_k(K, 64, ldx);   // whole 64-k stages (see pad_k)
     if (K < 0 || ldx % 4 != 0) return hipErrorInvalidValue;
+    if (const hipError_t e = prepare_x3(a, ws, st); e != hipSuccess) return e;
     if (sk > 1) return gemm_launch_sk<G_STORE, true>(a, N, sk, ws, st);
     {
         const KgsChoice c = choose_kgs(N, P, K, true, ws);
@@ -704,18 +1162,13 @@ hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float 
     // tokens x (features of W1 + the same features of W3) per block, chosen like the unpaired tiles
     const TileForm tf = choose_tile(N, P, true);
     const int tok = tf == TILE_128x64 ? 128 : tf == TILE_64x64 ? 64 : 32, feat = tf == TILE_32x32 ? 32 : 64;
-    const void *fn = tf == TILE_128x64 ? dma_fn<G_STORE, 2, 2, KS, true>()
-                   : tf == TILE_64x64  ? dma_fn<G_STORE, 1, 2, KS, true>()
-                   : tf == TILE_32x64  ? dma_fn<G_STORE, 1, 2, KS, true, 1, 2>()
-                                       : dma_fn<G_STORE, 1, 2, KS, true, 1, 1>();
-    const int threads = tf == TILE_32x64 ? 64 * 2 * KS : tf == TILE_32x32 ? 64 * KS : 256 * KS;
-    size_t lds = 2 * (size_t)(tok + 2 * feat) * 64 * sizeof(float);
-    const size_t red = (size_t)(KS - 1) * (threads / 64 / KS) * (tf == TILE_128x64 ? 2 : 1) * 2 * 16 * 64 * sizeof(float);  // [KS-1][waves per k-group][TM * TN tiles][16][64]
-    if (red > lds) lds = red;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const DmaForm f = tf == TILE_128x64 ? dma_form<G_STORE, 2, 2, KS, true>()
+                    : tf == TILE_64x64  ? dma_form<G_STORE, 1, 2, KS, true>()
+                    : tf == TILE_32x64  ? dma_form<G_STORE, 1, 2, KS, true, 1, 2>()
+                                        : dma_form<G_STORE, 1, 2, KS, true, 1, 1>();
     const dim3 grid = dma_grid((N + feat - 1) / feat, (P + tok - 1) / tok, &a);
     void *params[] = {&a};
-    return hipLaunchKernel(fn, grid, dim3(threads), params, lds, st);
+    return hipLaunchKernel(f.fn, grid, dim3(f.threads), params, f.lds, st);
 }
 
 // q | k | v of one layer in ONE launch of the direct-to-LDS tile kernel (main.zig:308-358): N = nq + 2 nkv
@@ -728,6 +1181,14 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
                                    size_t kv_head_stride, int n_scale, int sk, const SplitKWs *ws)
 {
     constexpr int skinny_max = Tunables::pf_skinny_max;
+    if (const int kp = pad_k(K, 64, ldx); kp > 0 && x3_stream_shape((long long)(nq + 2 * nkv) * (n_scale > 0 ? n_scale : 1), P, kp)) {
+        if (nq % 128 != 0 || nkv % 128 != 0) return hipErrorNotSupported;   // (the caller's three launches take the stream form, same ranges)
+        if (((uintptr_t)x & 15) || ((uintptr_t)wq & 15) || ((uintptr_t)wk & 15) || ((uintptr_t)wv & 15)) return hipErrorInvalidValue;
+        GemmArgs b = {x, nullptr, wq, q_out, q_out, P, nq + 2 * nkv, kp, ldx, ldq, ldq, pos0, rope, head_size, n_scale > 0 ? n_scale : 1,
+                      wk, wv, kcache, vcache, nq, nkv, ldkv, kv_head_stride, 0, 0};
+        b.ldw = K;
+        return launch_x3_stream<G_QKV>(b, (long long)(nq + 2 * nkv) * b.n_scale, ws, st);
+    }
     if (P <= skinny_max && sk <= 1) return hipErrorNotSupported;
     if (((uintptr_t)x & 15) || ((uintptr_t)wq & 15) || ((uintptr_t)wk & 15) || ((uintptr_t)wv & 15)) return hipErrorInvalidValue;
     const int ldw_true = K;        // W rows are K floats apart; the loop runs over whole 64-k stages (see pad_k)
@@ -739,6 +1200,7 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
         GemmArgs as = {x, nullptr, wq, q_out, q_out, P, N, K, ldx, ldq, ldq, pos0, rope, head_size, n_scale > 0 ? n_scale : 1,
                        wk, wv, kcache, vcache, nq, nkv, ldkv, kv_head_stride, 0, 0};
         as.ldw = ldw_true;
+        if (const hipError_t e = prepare_x3(as, ws, st); e != hipSuccess) return e;
         return gemm_launch_sk<G_QKV, false>(as, N, sk, ws, st);
     }
     {
@@ -748,7 +1210,7 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
             GemmArgs ak = {x, nullptr, wq, q_out, q_out, P, N, K, ldx, ldq, ldq, pos0, rope, head_size, n_scale > 0 ? n_scale : 1,
                            wk, wv, kcache, vcache, nq, nkv, ldkv, kv_head_stride, 0, 0};
             ak.ldw = ldw_true;
-            return gemm_launch_kgs<G_QKV, false>(ak, N, c.tile, ws, st);
+            return gemm_launch_kgs<G_QKV, false>(ak, N, c.tile, ws, st);   // (never in the planes mode: choose_kgs)
         }
     }
     TileForm tf = choose_tile(N, P, false);
@@ -765,30 +1227,28 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
     GemmArgs a = {x, nullptr, wq, q_out, q_out, P, N, K, ldx, ldq, ldq, pos0, rope, head_size, 1,
                   wk, wv, kcache, vcache, nq, nkv, ldkv, kv_head_stride, 0, 0};
     a.ldw = ldw_true;
+    if (const hipError_t e = prepare_x3(a, ws, st); e != hipSuccess) return e;
     constexpr int KS = 2;
     const int tok = tf == TILE_128x64 ? 128 : tf == TILE_64x64 ? 64 : 32;
-    const void *fn = tf == TILE_128x64 ? dma_fn<G_QKV, 2, 1, KS, false>()
-                   : tf == TILE_64x64  ? dma_fn<G_QKV, 1, 1, KS, false>()
-                   : tf == TILE_32x64  ? dma_fn<G_QKV, 1, 1, KS, false, 1, 2>()
-                                       : dma_fn<G_QKV, 1, 1, KS, false, 1, 1>();
-    const int threads = tf == TILE_32x64 ? 64 * 2 * KS : tf == TILE_32x32 ? 64 * KS : 256 * KS;
-    size_t lds = 2 * (size_t)(tok + feat) * 64 * sizeof(float);
-    const size_t red = (size_t)(KS - 1) * (threads / 64 / KS) * (tf == TILE_128x64 ? 2 : 1) * 16 * 64 * sizeof(float);
-    if (red > lds) lds = red;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const DmaForm f = tf == TILE_128x64 ? dma_form<G_QKV, 2, 1, KS, false>()
+                    : tf == TILE_64x64  ? dma_form<G_QKV, 1, 1, KS, false>()
+                    : tf == TILE_32x64  ? dma_form<G_QKV, 1, 1, KS, false, 1, 2>()
+                                        : dma_form<G_QKV, 1, 1, KS, false, 1, 1>();
     const dim3 grid = dma_grid(N / feat, (P + tok - 1) / tok, &a);
     void *params[] = {&a};
-    return hipLaunchKernel(fn, grid, dim3(threads), params, lds, st);
+    return hipLaunchKernel(f.fn, grid, dim3(f.threads), params, f.lds, st);
 }
 
 // k | v of one layer in ONE launch for short prompts (P <= 64: prefill_skinny.hip's paired form; X is
 // brought into the CU once for both).  hipErrorNotSupported otherwise: the caller launches the two.
 hipError_t launch_prefill_gemm_kv_pair(const float *x, int ldx, const float *wk, const float *wv, float *kcache,
                                        float *vcache, int ldkv, int P, int nkv, int K, int pos0, const float2 *rope,
-                                       int head_size, hipStream_t st, int n_scale, size_t kv_head_stride, int sk)
+                                       int head_size, hipStream_t st, int n_scale, size_t kv_head_stride, int sk,
+                                       long long n_launch_whole)
 {
     constexpr int skinny_max = Tunables::pf_skinny_max;
     if (P > skinny_max || sk > 1) return hipErrorNotSupported;  // sk > 1: the tile kernel's split-K family takes it
+    if (n_launch_whole > 0 && x3_stream_shape(n_launch_whole, P, (K + 63) / 64 * 64)) return hipErrorNotSupported;  // the stream form takes k and v
     if (((uintptr_t)x & 15) || ((uintptr_t)wk & 15) || ((uintptr_t)wv & 15)) return hipErrorInvalidValue;
     GemmArgs a = {x, wv, wk, kcache, kcache, P, nkv, K, ldx, ldkv, ldkv, pos0, rope, head_size, n_scale > 0 ? n_scale : 1,
                   wk, wv, kcache, vcache, 0, nkv, ldkv, kv_head_stride, 0, 0};
@@ -800,7 +1260,7 @@ hipError_t launch_prefill_gemm_kv_pair(const float *x, int ldx, const float *wk,
 hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w, float *out, int ldo,
                                int P, int N, int K, int pos0, const float2 *rope, int head_size,
                                hipStream_t st, const float *res, int ldres, int n_scale, size_t kv_head_stride,
-                               int sk, const SplitKWs *ws, int ldw)
+                               int sk, const SplitKWs *ws, int ldw, long long n_launch_whole)
 {
     if (P <= 0 || N <= 0 || K <= 0 || (K % 4) != 0 || (ldx % 4) != 0) return hipErrorInvalidValue;
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return hipErrorInvalidValue;
@@ -808,11 +1268,25 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
     GemmArgs a = {x, nullptr, w, out, res, P, N, K, ldx, ldo, ldres, pos0, rope, head_size, n_scale > 0 ? n_scale : 1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, kv_head_stride, 0, 0};
     a.ldw = ldw > 0 ? ldw : K;
     constexpr int skinny_max = Tunables::pf_skinny_max;
+    // n_whole: the rows of the WHOLE model's launch this product belongs to (q | k | v count as one: n_launch_whole)
+    if (const int kp = pad_k(K, 64, ldx); kp > 0 && epi != G_SWIGLU &&
+        x3_stream_shape(n_launch_whole > 0 ? n_launch_whole : (long long)N * a.n_scale, P, kp)) {
+        const long long nw = n_launch_whole > 0 ? n_launch_whole : (long long)N * a.n_scale;
+        a.K = kp;
+        switch (epi) {
+            case G_STORE: return launch_x3_stream<G_STORE>(a, nw, ws, st);
+            case G_RESID: return launch_x3_stream<G_RESID>(a, nw, ws, st);
+            case G_ROPE: return launch_x3_stream<G_ROPE>(a, nw, ws, st);
+            case G_ROPE_CACHE: return launch_x3_stream<G_ROPE_CACHE>(a, nw, ws, st);
+            case G_CACHE: return launch_x3_stream<G_CACHE>(a, nw, ws, st);
+        }
+    }
     if (P <= skinny_max && sk <= 1) return launch_prefill_skinny(epi, a, st);  // prefill_skinny.hip
     K = a.K = pad_k(K, 64, ldx);   // whole 64-k stages (see pad_k)
     if (K < 0) return hipErrorInvalidValue;
+    if (const hipError_t e = prepare_x3(a, ws, st); e != hipSuccess) return e;
     if (sk > 1) {
-        if (K % (64 * sk) != 0) return hipErrorInvalidValue;
+        if (K / 64 < sk) return hipErrorInvalidValue;
         switch (epi) {
             case G_STORE: return gemm_launch_sk<G_STORE, false>(a, N, sk, ws, st);
             case G_RESID: return gemm_launch_sk<G_RESID, false>(a, N, sk, ws, st);

@@ -40,6 +40,7 @@ int prefill_alloc(l2z_runstate *s, int need)
     for (float **b : bufs)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     if (s->pf_tokens) { (void)hipFree(s->pf_tokens); s->pf_tokens = nullptr; }
+    if (s->pf_sk.x3) { (void)hipFree(s->pf_sk.x3); s->pf_sk.x3 = nullptr; s->pf_sk.x3_bytes = 0; }
     s->pf_cap = 0;
     const size_t widest = (size_t)(c.dim > c.hidden_dim ? c.dim : c.hidden_dim);
     // (scheme B reads the local attention / hidden blocks as rows of the column shards' PADDED width: a 1-rank group's
@@ -56,7 +57,9 @@ int prefill_alloc(l2z_runstate *s, int need)
         {(void **)&s->pf_stage, s->sh.world > 1 ? P * widest * 4 : 0},
         // scheme B: this rank's partial [P, dim] products of its column shards of Wo / W2 (summed by the bulk all-reduce)
         {(void **)&s->pf_part, s->sh.scheme_b ? P * c.dim * 4 : 0},
-        {(void **)&s->pf_tokens, P * 4}};
+        {(void **)&s->pf_tokens, P * 4},
+        // the tile GEMM on the bf16 matrix cores: one launch's activation matrix as three planes of bf16 terms
+        {(void **)&s->pf_sk.x3, P * 3 * std::max(std::max(xn_w, att_w), h1_w) * 2}};
     for (auto &b : want) {
         if (b.bytes == 0) continue;
         hipError_t e = hipMalloc(b.p, b.bytes);
@@ -67,6 +70,7 @@ int prefill_alloc(l2z_runstate *s, int need)
         }
     }
     s->pf_cap = (int)P;
+    s->pf_sk.x3_bytes = P * 3 * std::max(std::max(xn_w, att_w), h1_w) * 2;
     // the pad columns are never written and must be zeros: the GEMMs multiply them against whatever follows a W row
     // (scheme B: against the column shards' own zero columns)
     L2Z_HIP(hipMemsetAsync(s->pf_xn, 0, P * xn_w * 4, s->stream));
@@ -181,15 +185,16 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
                                                       sh.dim_loc, kvd, dim, pos0, s->rope, hs, st, kvh_stride, sh.world,
                                                       sk_qkv, ws);
         if (qe == hipErrorNotSupported) {
+            const long long n_qkv = (long long)dim + 2 * kvd_whole;   // the whole model's q | k | v launch (the stream form's K ranges)
             L2Z_HIP(launch_prefill_gemm(PG_ROPE, s->pf_xn, ldxn, wq, s->pf_q, sh.dim_loc, P, sh.dim_loc, dim, pos0,
-                                        s->rope, hs, st, nullptr, 0, sh.world, 0, sk_qkv, ws));  // :308-351
+                                        s->rope, hs, st, nullptr, 0, sh.world, 0, sk_qkv, ws, 0, n_qkv));  // :308-351
             const hipError_t ke = launch_prefill_gemm_kv_pair(s->pf_xn, ldxn, wk, wv, kc, vc, kvd, P, kvd, dim, pos0,
-                                                              s->rope, hs, st, sh.world, kvh_stride, sk_qkv);  // short prompts: k | v together
+                                                              s->rope, hs, st, sh.world, kvh_stride, sk_qkv, n_qkv);  // short prompts: k | v together
             if (ke == hipErrorNotSupported) {
                 L2Z_HIP(launch_prefill_gemm(PG_ROPE_CACHE, s->pf_xn, ldxn, wk, kc, kvd, P, kvd, dim, pos0, s->rope, hs,
-                                            st, nullptr, 0, sh.world, kvh_stride, sk_qkv, ws));   // :354-357
+                                            st, nullptr, 0, sh.world, kvh_stride, sk_qkv, ws, 0, n_qkv));   // :354-357
                 L2Z_HIP(launch_prefill_gemm(PG_CACHE, s->pf_xn, ldxn, wv, vc, kvd, P, kvd, dim, pos0, s->rope, hs, st,
-                                            nullptr, 0, sh.world, kvh_stride, sk_qkv, ws));       // :358
+                                            nullptr, 0, sh.world, kvh_stride, sk_qkv, ws, 0, n_qkv));       // :358
             } else {
                 L2Z_HIP(ke);
             }
@@ -277,12 +282,13 @@ int prefill_half_b(l2z_runstate *s, const l2z_weights *w, int l, int half, int P
         const hipError_t qe = launch_prefill_gemm_qkv(s->pf_xn, ldxn, wq, wk, wv, s->pf_q, sh.dim_loc, kc, vc, kvd, P, sh.dim_loc, kvd,
                                                       dim, pos0, s->rope, hs, st, kvh_stride, sh.world, sk_qkv, ws);
         if (qe == hipErrorNotSupported) {
+            const long long n_qkv = (long long)dim + 2 * kvd_whole;
             L2Z_HIP(launch_prefill_gemm(PG_ROPE, s->pf_xn, ldxn, wq, s->pf_q, sh.dim_loc, P, sh.dim_loc, dim, pos0, s->rope, hs, st,
-                                        nullptr, 0, sh.world, 0, sk_qkv, ws));
+                                        nullptr, 0, sh.world, 0, sk_qkv, ws, 0, n_qkv));
             L2Z_HIP(launch_prefill_gemm(PG_ROPE_CACHE, s->pf_xn, ldxn, wk, kc, kvd, P, kvd, dim, pos0, s->rope, hs, st, nullptr, 0,
-                                        sh.world, kvh_stride, sk_qkv, ws));
+                                        sh.world, kvh_stride, sk_qkv, ws, 0, n_qkv));
             L2Z_HIP(launch_prefill_gemm(PG_CACHE, s->pf_xn, ldxn, wv, vc, kvd, P, kvd, dim, pos0, s->rope, hs, st, nullptr, 0,
-                                        sh.world, kvh_stride, sk_qkv, ws));
+                                        sh.world, kvh_stride, sk_qkv, ws, 0, n_qkv));
         } else {
             L2Z_HIP(qe);
         }

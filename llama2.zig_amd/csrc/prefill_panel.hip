@@ -344,6 +344,7 @@ static int panel_range(int tms)
 bool prefill_panel_shape(long long n_whole, int P, int K, long long widest_whole)
 {
     if (tunables().pf_panel == 0) return false;
+    if (x3_stream_shape(n_whole, P, (K + 63) / 64 * 64)) return false;   // the stream form of the planes kernel takes it (prefill_gemm.hip)
     const int p_min = kPanelDefaultMin;
     K = (K + kPnStage - 1) / kPnStage * kPnStage;   // the kernel walks whole 128-k stages (pad_k)
     if (P < p_min || P < 1 || P > prefill_panel_max_tokens() || K < kPnRange) return false;

@@ -42,6 +42,9 @@ struct Tunables {
                                //                     8.8 / 12.5 / 17.6 -> 6.6 / 10.5 / 14.6 ms at 7B
     int pf_x3 = 1;             // L2Z_PF_X3           0: the tile GEMMs of the batched prefill multiply on the f32 matrix cores (v_mfma_f32_32x32x2_f32)
                                //                     instead of the bf16 ones over three-term splits of both operands (changes rounding)
+    int pf_x3_form = 0;        // EXPERIMENT
+    int pf_x3_sk = 0, pf_x3_tok = 0;  // EXPERIMENT
+    int pf_x3_stream_min = 97;  // L2Z_PF_X3_STREAM_MIN shortest chunk that takes the stream form of the planes kernel
     int pf_panel_max = -1;     // L2Z_PF_PANEL_MAX    longest chunk that takes the panel kernel (default and maximum 96 tokens): tests of both sides
                                //                     of the switch-over
 

@@ -7,6 +7,8 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 import numpy as np, __graft_entry__ as ge
 pkg = ge.load_package(); B, ck = pkg.binding, pkg.checkpoint
 shape, n = sys.argv[1], int(sys.argv[2])
+for kv in sys.argv[3:]:
+    k, v = kv.split("="); B.option_set(k, int(v)); print("  ", kv)
 seed = 7
 cfg, shared = {k: (c, sh) for k, c, sh in ck.iter_configs()}[shape]
 w = B.Weights(cfg, None, shared, seed=seed)
@@ -33,5 +35,5 @@ for x3 in (0, 1):
     # device layout is permuted back to (pos, kv_dim) by runstate_read
     got = got.reshape(S, kvd)[:n]
     err = got - truth
-    print(f"  L2Z_PF_X3={x3} ({'bf16 x 3 split, 6 products' if x3 else 'f32 MFMA chain'}): max |err| {np.abs(err).max():.3e}, max |err| / sum|ab| {(np.abs(err) / scale).max():.3e}, rms err / rms value {np.sqrt((err ** 2).mean()) / np.sqrt((truth ** 2).mean()):.3e}")
+    print(f"  L2Z_PF_X3={x3} ({'bf16 x 3 split, 6 products' if x3 else 'f32 MFMA chain'}): max |err| {np.abs(err).max():.3e}, max |err| / sum|ab| {(np.abs(err) / scale).max():.3e}, rms err / rms value {np.sqrt((err ** 2).mean()) / np.sqrt((truth ** 2).mean()):.3e}, mean err * sign(value) / mean |value| {(err * np.sign(truth)).mean() / np.abs(truth).mean():+.3e}")
     s.close()

@@ -281,7 +281,11 @@ def test_7b_prefill_equals_stepped_loop(gpu, model7b, n):
     worst_kv = max(float(np.abs(s2.read(nm, l * S * kvd, n * kvd) - a).max()) for (nm, l), a in ref_kv.items())
     print(f"7B prefill of {n} tokens vs the stepped loop: max |logit diff| {float(np.abs(got - ref).max()):.3e}, "
           f"max |KV diff| {worst_kv:.3e}")
-    np.testing.assert_allclose(got, ref, rtol=5e-5, atol=5e-5)
+    # Both sides are approximations of the same pass, each held to 5e-5 + 5e-5 |x| of the oracle by its own tests
+    # (test_7b_full_forward_logits_vs_oracle, test_7b_prefill_vs_oracle_32_tokens): against each other the bar is the sum.
+    # Observed at 300 tokens: 3.3e-5 with the GEMMs on the f32 matrix cores, 5.8e-5 on the bf16 ones (three-term split) --
+    # against float64 the two prefills carry the same error (scripts/x3_e2e.py: rms 5.1e-6 / 5.3e-6 at the 110M dims).
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
     assert s2.argmax() == int(np.argmax(ref)) or np.sort(ref)[-1] - np.sort(ref)[-2] < 1e-4
     for (nm, l), a in ref_kv.items():
         np.testing.assert_allclose(s2.read(nm, l * S * kvd, n * kvd), a, rtol=5e-5, atol=5e-5,
