@@ -248,6 +248,7 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
                                long long n_launch_whole = 0);  // rows of the whole model's launch this product is a part of (q, k, v
                                                                // launched apart: dim + 2 kv_dim; 0: N * n_scale) -- the stream form's K ranges
 // the stream form of the planes kernel (prefill_gemm.hip): which products take it, and their K ranges
+bool x3_applies(long long n_whole, int K);
 bool x3_stream_shape(long long n_whole, int P, int K);
 int x3_stream_sk(long long n_whole, int P, int K);
 hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, const float *wk, const float *wv,

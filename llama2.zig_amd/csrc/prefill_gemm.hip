@@ -24,21 +24,39 @@
 #endif
 
 namespace l2z {
-// Whether a [P, n_whole] x K product of the WHOLE model takes the stream form of the planes kernel (a function of the model
-// and the chunk length only), and its K ranges (part of the arithmetic).  K: as the kernel walks it (rounded up to 64).
+// Whether a [P, n_whole] x K product of the WHOLE model multiplies on the bf16 matrix cores (x3_applies), whether it takes
+// the stream form of that kernel (functions of the model and the chunk length only), and the stream form's K ranges
+// (part of the arithmetic).  K: as the kernels walk it (rounded up to 64).
+bool x3_applies(long long n_whole, int K)
+{
+    const int m = tunables().pf_x3;
+    // (cache-resident matrices -- the stories models -- keep the f32 cores: their prefill is launch-bound and the planes
+    // cost a launch per product: stories110M, 256 tokens 1.47 -> 1.58 ms)
+    return m >= 2 || (m == 1 && n_whole * (long long)K * 4 > ((long long)16 << 20));
+}
 bool x3_stream_shape(long long n_whole, int P, int K)
 {
     const Tunables &t = tunables();
-    if (!t.pf_x3 || P < t.pf_x3_stream_min || P > 128 || K < 512) return false;
-    return n_whole * (long long)K * 4 > ((long long)16 << 20);   // cache-resident matrices keep the other forms
+    return x3_applies(n_whole, K) && P >= t.pf_x3_stream_min && P <= 128 && K >= 256;
 }
 int x3_stream_sk(long long n_whole, int P, int K)
 {
+    // One block per CU (the ring takes the LDS), blocks of a launch equally long: the launch lasts
+    // ceil(tiles sk / CUs) rounds of ceil(stages / sk) stages, plus a fixed cost per round (pipeline fill, the partial sums'
+    // hand-over: ~6 stages' worth).  The CU count is the part the rule was made for (MI355X: 256), as a constant -- the
+    // ranges are part of the arithmetic and must not depend on the device a rank happens to run on.
     (void)P;
-    const long long tiles = (n_whole + 127) / 128;
-    int sk = 1;
-    while (sk < 8 && tiles * sk < 224 && (K / 32) / (2 * sk) >= 8) sk *= 2;
-    return sk;
+    constexpr long long kCus = 256;
+    const long long tiles = (n_whole + 127) / 128, stages = K / 32;
+    int best = 1;
+    long long best_cost = 0;
+    for (int sk = 1; sk <= 8; sk++) {
+        if (stages / sk < 8) break;
+        const long long rounds = (tiles * sk + kCus - 1) / kCus;
+        const long long cost = rounds * ((stages + sk - 1) / sk + 6);
+        if (sk == 1 || cost < best_cost) { best = sk; best_cost = cost; }
+    }
+    return best;
 }
 }  // namespace l2z
 
@@ -831,16 +849,33 @@ __global__ __launch_bounds__(512) void prefill_x3_stream(const GemmArgs a)
         for (int i = 0; i < TM; i++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][0][r] = p0[(i * 16 + r) * 64];
-        for (int z = 1; z < sk; z++) {
-            v16f t[TM];
+        v16f t[2][TM];   // two ranges in flight: range z + 1 is requested before range z is added
+        auto fetch = [&](int z, v16f (&d)[TM]) {
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) t[i][r] = p0[(size_t)z * PT + (i * 16 + r) * 64];
+                for (int r = 0; r < 16; r++) d[i][r] = p0[(size_t)z * PT + (i * 16 + r) * 64];
+        };
+        auto add = [&](const v16f (&d)[TM]) {
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc[i][0][r] += t[i][r];
+                for (int r = 0; r < 16; r++) acc[i][0][r] += d[i][r];
+        };
+        fetch(1, t[0]);
+        int z = 1;
+        for (; z + 2 < sk; z += 2) {
+            fetch(z + 1, t[1]);
+            add(t[0]);
+            fetch(z + 2, t[0]);
+            add(t[1]);
+        }
+        if (z + 1 < sk) {
+            fetch(z + 1, t[1]);
+            add(t[0]);
+            add(t[1]);
+        } else {
+            add(t[0]);
         }
     }
     gemm_epilogue<EPI, TM, TN>(a, acc, n0, 0, 0, wn, lane);
@@ -848,35 +883,20 @@ __global__ __launch_bounds__(512) void prefill_x3_stream(const GemmArgs a)
 
 // A form of the tile kernel as a launch: kernel, threads, dynamic LDS.  The block's output tile is 32 WM TM tokens x
 // 32 WN TN features whichever cores multiply it: on the f32 matrix cores WM x WN waves per k-group tile it; on the bf16
-// ones (L2Z_PF_X3, the default) WN waves each take ALL the tile's tokens x 32 TN features, so that a W element is split
+// ones (x3: the launch's activations are planes of bf16 terms, a.x3) WN waves each take ALL the tile's tokens x 32 TN features, so that a W element is split
 // into its bf16 terms by one wave only -- the same template with (TM WM, TN, 1, WN).  Same k order either way inside a
 // mode; between the modes the arithmetic differs (tolerance, not bits).
 struct DmaForm { const void *fn; unsigned threads; size_t lds; };
 template <int EPI, int TM, int TN, int KS, bool PAIR = false, int WM = 2, int WN = 2, int SPLIT = 0>
-DmaForm dma_form()
+DmaForm dma_form(bool x3)
 {
     constexpr size_t BMt = 32 * WM * TM, BNt = 32 * WN * TN;
     const size_t red = SPLIT == 2 ? 0 : (size_t)(KS - 1) * WM * WN * TM * TN * 16 * 64 * sizeof(float);  // the k-groups' sums
     DmaForm f;
     if constexpr (SPLIT != 2) {
-        if (tunables().pf_x3) {
-            const int v = tunables().pf_x3_form;   // EXPERIMENT: 0 remap (WM -> 1), 1 keep the WM x WN waves, 2: 128 x 128 unpaired as 1 x 4 waves
-            bool done = false;
-            if constexpr (TM == 2 && TN == 2 && WM == 2 && WN == 2 && !PAIR) {
-                if (v == 2) {
-                    f.fn = (const void *)prefill_gemm_dma<EPI, 4, 1, KS, false, 1, 4, SPLIT, true>;
-                    f.threads = 64 * 4 * KS;
-                    done = true;
-                }
-            }
-            if (done) {
-            } else if (v >= 1 && WM == 2) {
-                f.fn = (const void *)prefill_gemm_dma<EPI, TM, TN, KS, PAIR, WM, WN, SPLIT, true>;
-                f.threads = 64 * WM * WN * KS;
-            } else {
+        if (x3) {
             f.fn = (const void *)prefill_gemm_dma<EPI, TM * WM, TN, KS, PAIR, 1, WN, SPLIT, true>;
             f.threads = 64 * WN * KS;
-            }
             f.lds = 2 * (BMt * 384 + BNt * 256);   // two stages of three 128-B plane rows per token + 256-B W rows
             if (red > f.lds) f.lds = red;
             if (f.lds > 48 * 1024) (void)hipFuncSetAttribute(f.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds);
@@ -897,7 +917,7 @@ hipError_t gemm_launch_t(const GemmArgs &a, hipStream_t st)
     constexpr int BMt = 64 * TM, BNt = 64 * TN;
     static_assert((BMt / 4) % (4 * KS) == 0 && (BNt / 4) % (4 * KS) == 0, "tile rows per wave");
     if (a.K % 64 != 0 || a.ldx % 4 != 0) return hipErrorInvalidValue;   // (the launchers round K up: pad_k)
-    const DmaForm f = dma_form<EPI, TM, TN, KS, false>();
+    const DmaForm f = dma_form<EPI, TM, TN, KS, false>(a.x3 != nullptr);
     GemmArgs args = a;
     const dim3 grid1 = dma_grid((a.N + BNt - 1) / BNt, (a.P + BMt - 1) / BMt, &args);
     void *params[] = {&args};
@@ -912,7 +932,7 @@ bool gemm_launch_small(const GemmArgs &a, hipStream_t st, hipError_t *err)
 {
     if (a.K % 64 != 0 || a.ldx % 4 != 0) return false;
     constexpr int KS = 2, BMt = 32 * WM, BNt = 32 * WN;
-    const DmaForm f = dma_form<EPI, 1, 1, KS, false, WM, WN>();
+    const DmaForm f = dma_form<EPI, 1, 1, KS, false, WM, WN>(a.x3 != nullptr);
     dim3 grid((a.N + BNt - 1) / BNt, (a.P + BMt - 1) / BMt);
     GemmArgs args = a;
     const dim3 grid1 = dma_grid((int)grid.x, (int)grid.y, &args);
@@ -947,8 +967,6 @@ static SkTile choose_tile_sk(int N, int P, int sk)
     static const struct { int tok; double eff; } form[3] = {{128, 1.0}, {64, 0.87}, {32, 0.80}};
     int best = -1;
     double best_cost = 0.0;
-    if (tunables().pf_x3 && tunables().pf_x3_tok > 0)   // EXPERIMENT
-        return tunables().pf_x3_tok >= 128 ? SKT_128x64 : tunables().pf_x3_tok >= 64 ? SKT_64x64 : SKT_32x64;
     for (int f = 0; f < 3; f++) {
         if (f == SKT_128x64 && P <= 64) continue;
         const long long blocks = (long long)((N + 63) / 64) * ((P + form[f].tok - 1) / form[f].tok) * sk;
@@ -970,7 +988,7 @@ hipError_t dma_launch_split(GemmArgs a, int n_feat, int sk, const SplitKWs *ws, 
     const int ntx = (n_feat + feat - 1) / feat, nty = (a.P + BMt - 1) / BMt;
     if ((size_t)ntx * nty * sk * BMt * BNt > ws->part_floats || ntx * nty > ws->cnt_ints) return hipErrorOutOfMemory;
     a.sk = sk; a.sk_part = ws->part; a.sk_cnt = ws->cnt;
-    const DmaForm f = dma_form<EPI, TM, TN, KS, PAIR, WM, WN, 1>();
+    const DmaForm f = dma_form<EPI, TM, TN, KS, PAIR, WM, WN, 1>(a.x3 != nullptr);
     const dim3 grid = dma_grid(ntx, nty, &a);
     void *params[] = {&a};
     return hipLaunchKernel(f.fn, grid, dim3(f.threads), params, f.lds, st);
@@ -997,7 +1015,7 @@ hipError_t dma_launch_kgs(GemmArgs a, int n_feat, const SplitKWs *ws, hipStream_
     const int ntx = (n_feat + feat - 1) / feat, nty = (a.P + BMt - 1) / BMt;
     if ((size_t)ntx * nty * BMt * BNt > ws->part_floats || 2 * ntx * nty > ws->cnt_ints) return hipErrorOutOfMemory;
     a.sk = 2; a.sk_part = ws->part; a.sk_cnt = ws->cnt;  // sk: the grid's z extent (dma_grid)
-    const DmaForm f = dma_form<EPI, TM, TN, KS, PAIR, WM, WN, 2>();
+    const DmaForm f = dma_form<EPI, TM, TN, KS, PAIR, WM, WN, 2>(a.x3 != nullptr);
     const dim3 grid = dma_grid(ntx, nty, &a);
     void *params[] = {&a};
     return hipLaunchKernel(f.fn, grid, dim3(f.threads), params, f.lds, st);
@@ -1007,10 +1025,10 @@ hipError_t dma_launch_kgs(GemmArgs a, int n_feat, const SplitKWs *ws, hipStream_
 // tile.  Same bits either way, so this is grid fill only: the cost model of choose_tile with twice the blocks of
 // half the depth, plus the hand-off (~7 us: a dump, a counter, the other block's read) in the model's units.
 struct KgsChoice { bool use; TileForm tile; };
-static KgsChoice choose_kgs(int N, int P, int K, bool pair, const SplitKWs *ws)
+static KgsChoice choose_kgs(int N, int P, int K, bool pair, const SplitKWs *ws, bool x3)
 {
     KgsChoice none = {false, TILE_64x64};
-    if (ws == nullptr || ws->part == nullptr || K % 64 != 0 || tunables().pf_x3) return none;   // (the planes form has no two-block variant)
+    if (ws == nullptr || ws->part == nullptr || K % 64 != 0 || x3) return none;   // (the planes form has no two-block variant)
     // Measured (7B shape, whole prefill, interleaved; profiles/r03_prefill_kgs_ab.txt): the form pays where the
     // unsplit family runs ONE 8-wave block of a 128-token tile per CU -- two independent 4-wave blocks of half
     // the LDS hide each other's stage barriers: 512 tokens 58.56 -> 57.32 ms on 128 x 64 tiles -- and loses or
@@ -1060,9 +1078,9 @@ __global__ __launch_bounds__(256) void prefill_split3_kernel(const float *x, int
 }
 
 // before a launch of the planes form: a.K is the padded K; fills ws->x3 from a.x
-hipError_t prepare_x3(GemmArgs &a, const SplitKWs *ws, hipStream_t st)
+hipError_t prepare_x3(GemmArgs &a, const SplitKWs *ws, hipStream_t st, long long n_whole)
 {
-    if (!tunables().pf_x3) return hipSuccess;
+    if (!x3_applies(n_whole, a.K)) return hipSuccess;   // a.x3 stays null: the f32 matrix cores
     if (ws == nullptr || ws->x3 == nullptr || (size_t)a.P * 3 * a.K * sizeof(__bf16) > ws->x3_bytes) return hipErrorInvalidValue;
     a.x3 = ws->x3; a.kp = a.K; a.ldx3 = 3 * a.K;
     const size_t n = (size_t)a.P * (a.K >> 3);
@@ -1074,7 +1092,7 @@ hipError_t prepare_x3(GemmArgs &a, const SplitKWs *ws, hipStream_t st)
 template <int EPI>
 hipError_t launch_x3_stream(GemmArgs a, long long n_whole, const SplitKWs *ws, hipStream_t st)
 {
-    if (const hipError_t e = prepare_x3(a, ws, st); e != hipSuccess) return e;
+    if (const hipError_t e = prepare_x3(a, ws, st, n_whole); e != hipSuccess) return e;
     const int sk = x3_stream_sk(n_whole, a.P, a.K), tm = (a.P + 31) / 32, ntx = (a.N + 127) / 128;
     if (ws->part == nullptr || ws->cnt == nullptr || (size_t)ntx * sk * tm * 32 * 128 > ws->part_floats || ntx > ws->cnt_ints)
         return hipErrorOutOfMemory;
@@ -1109,11 +1127,7 @@ constexpr long long kRefCus = 256;  // the part the split-K rule was measured on
 int prefill_split_k(long long n_whole, int P, int K, bool pair)
 {
     if (P > kSplitKMaxTokens) return 1;
-    if (tunables().pf_x3 && tunables().pf_x3_sk > 0) {   // EXPERIMENT: decimal digits qkv, wo, W1|W3, W2
-        const int d = tunables().pf_x3_sk;
-        const int v = pair ? d / 10 % 10 : K > n_whole ? d % 10 : n_whole > K ? d / 1000 % 10 : d / 100 % 10;
-        return v > 0 && K / 64 >= 4 * v ? v : 1;
-    }
+    (void)pair;
     int sk = 1;
     {
         const bool streams = n_whole * (long long)K * 4 > ((long long)16 << 20);
@@ -1152,20 +1166,20 @@ hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float 
     if (P <= skinny_max && sk <= 1) return launch_prefill_skinny_pair(G_SWIGLU, a, st);  // prefill_skinny.hip (or not supported)
     K = a.K = pad_k(K, 64, ldx);   // whole 64-k stages (see pad_k)
     if (K < 0 || ldx % 4 != 0) return hipErrorInvalidValue;
-    if (const hipError_t e = prepare_x3(a, ws, st); e != hipSuccess) return e;
+    if (const hipError_t e = prepare_x3(a, ws, st, 2LL * N * a.n_scale); e != hipSuccess) return e;
     if (sk > 1) return gemm_launch_sk<G_STORE, true>(a, N, sk, ws, st);
     {
-        const KgsChoice c = choose_kgs(N, P, K, true, ws);
+        const KgsChoice c = choose_kgs(N, P, K, true, ws, a.x3 != nullptr);
         if (c.use) return gemm_launch_kgs<G_STORE, true>(a, N, c.tile, ws, st);
     }
     constexpr int KS = 2;
     // tokens x (features of W1 + the same features of W3) per block, chosen like the unpaired tiles
     const TileForm tf = choose_tile(N, P, true);
     const int tok = tf == TILE_128x64 ? 128 : tf == TILE_64x64 ? 64 : 32, feat = tf == TILE_32x32 ? 32 : 64;
-    const DmaForm f = tf == TILE_128x64 ? dma_form<G_STORE, 2, 2, KS, true>()
-                    : tf == TILE_64x64  ? dma_form<G_STORE, 1, 2, KS, true>()
-                    : tf == TILE_32x64  ? dma_form<G_STORE, 1, 2, KS, true, 1, 2>()
-                                        : dma_form<G_STORE, 1, 2, KS, true, 1, 1>();
+    const DmaForm f = tf == TILE_128x64 ? dma_form<G_STORE, 2, 2, KS, true>(a.x3 != nullptr)
+                    : tf == TILE_64x64  ? dma_form<G_STORE, 1, 2, KS, true>(a.x3 != nullptr)
+                    : tf == TILE_32x64  ? dma_form<G_STORE, 1, 2, KS, true, 1, 2>(a.x3 != nullptr)
+                                        : dma_form<G_STORE, 1, 2, KS, true, 1, 1>(a.x3 != nullptr);
     const dim3 grid = dma_grid((N + feat - 1) / feat, (P + tok - 1) / tok, &a);
     void *params[] = {&a};
     return hipLaunchKernel(f.fn, grid, dim3(f.threads), params, f.lds, st);
@@ -1195,16 +1209,18 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
     K = pad_k(K, 64, ldx);
     if (K < 0 || ldx % 4 != 0) return hipErrorInvalidValue;
     const int N = nq + 2 * nkv;
+    const long long n_qkv_whole = (long long)N * (n_scale > 0 ? n_scale : 1);
+    const bool x3 = x3_applies(n_qkv_whole, K);   // the bf16 matrix cores (prepare_x3 decides the same)
     if (sk > 1) {  // the split family: 64-feature tiles (a tile must not straddle q | k | v)
         if (nq % 64 != 0 || nkv % 64 != 0) return hipErrorNotSupported;
         GemmArgs as = {x, nullptr, wq, q_out, q_out, P, N, K, ldx, ldq, ldq, pos0, rope, head_size, n_scale > 0 ? n_scale : 1,
                        wk, wv, kcache, vcache, nq, nkv, ldkv, kv_head_stride, 0, 0};
         as.ldw = ldw_true;
-        if (const hipError_t e = prepare_x3(as, ws, st); e != hipSuccess) return e;
+        if (const hipError_t e = prepare_x3(as, ws, st, (long long)N * as.n_scale); e != hipSuccess) return e;
         return gemm_launch_sk<G_QKV, false>(as, N, sk, ws, st);
     }
     {
-        const KgsChoice c = choose_kgs(N, P, K, false, ws);
+        const KgsChoice c = choose_kgs(N, P, K, false, ws, x3);
         const int feat_k = c.tile == TILE_128x128 ? 128 : 64;  // a tile must not straddle q | k | v
         if (c.use && nq % feat_k == 0 && nkv % feat_k == 0) {
             GemmArgs ak = {x, nullptr, wq, q_out, q_out, P, N, K, ldx, ldq, ldq, pos0, rope, head_size, n_scale > 0 ? n_scale : 1,
@@ -1217,7 +1233,9 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
     // 128 x 64 tiles mean q alone already gives every CU its one resident block: three such launches
     // measured 445 us against 453 for the 768-block one (7B, 512 tokens).  With the smaller tiles several
     // blocks share a CU and the longer grid keeps them supplied: 128 tokens 21.8 -> 19.4 ms fused.
-    if (tf == TILE_128x64 || tf == TILE_128x128) return hipErrorNotSupported;
+    // (On the bf16 cores the one launch also splits the activations once instead of three times: 128 x 64 tiles, fused.)
+    if ((tf == TILE_128x64 || tf == TILE_128x128) && !x3) return hipErrorNotSupported;
+    if (tf == TILE_128x128) tf = TILE_128x64;
     int feat = tf == TILE_32x32 ? 32 : 64;
     if (nq % feat != 0 || nkv % feat != 0) {
         if (nq % 32 != 0 || nkv % 32 != 0) return hipErrorNotSupported;
@@ -1227,13 +1245,13 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
     GemmArgs a = {x, nullptr, wq, q_out, q_out, P, N, K, ldx, ldq, ldq, pos0, rope, head_size, 1,
                   wk, wv, kcache, vcache, nq, nkv, ldkv, kv_head_stride, 0, 0};
     a.ldw = ldw_true;
-    if (const hipError_t e = prepare_x3(a, ws, st); e != hipSuccess) return e;
+    if (const hipError_t e = prepare_x3(a, ws, st, n_qkv_whole); e != hipSuccess) return e;
     constexpr int KS = 2;
     const int tok = tf == TILE_128x64 ? 128 : tf == TILE_64x64 ? 64 : 32;
-    const DmaForm f = tf == TILE_128x64 ? dma_form<G_QKV, 2, 1, KS, false>()
-                    : tf == TILE_64x64  ? dma_form<G_QKV, 1, 1, KS, false>()
-                    : tf == TILE_32x64  ? dma_form<G_QKV, 1, 1, KS, false, 1, 2>()
-                                        : dma_form<G_QKV, 1, 1, KS, false, 1, 1>();
+    const DmaForm f = tf == TILE_128x64 ? dma_form<G_QKV, 2, 1, KS, false>(a.x3 != nullptr)
+                    : tf == TILE_64x64  ? dma_form<G_QKV, 1, 1, KS, false>(a.x3 != nullptr)
+                    : tf == TILE_32x64  ? dma_form<G_QKV, 1, 1, KS, false, 1, 2>(a.x3 != nullptr)
+                                        : dma_form<G_QKV, 1, 1, KS, false, 1, 1>(a.x3 != nullptr);
     const dim3 grid = dma_grid(N / feat, (P + tok - 1) / tok, &a);
     void *params[] = {&a};
     return hipLaunchKernel(f.fn, grid, dim3(f.threads), params, f.lds, st);
@@ -1284,7 +1302,7 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
     if (P <= skinny_max && sk <= 1) return launch_prefill_skinny(epi, a, st);  // prefill_skinny.hip
     K = a.K = pad_k(K, 64, ldx);   // whole 64-k stages (see pad_k)
     if (K < 0) return hipErrorInvalidValue;
-    if (const hipError_t e = prepare_x3(a, ws, st); e != hipSuccess) return e;
+    if (const hipError_t e = prepare_x3(a, ws, st, n_launch_whole > 0 ? n_launch_whole : (long long)N * a.n_scale); e != hipSuccess) return e;
     if (sk > 1) {
         if (K / 64 < sk) return hipErrorInvalidValue;
         switch (epi) {
@@ -1298,7 +1316,7 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
         return hipErrorInvalidValue;
     }
     if (epi == G_RESID) {  // wo, W2: the two-block form where the grid is short of blocks (same bits)
-        const KgsChoice c = choose_kgs(N, P, K, false, ws);
+        const KgsChoice c = choose_kgs(N, P, K, false, ws, a.x3 != nullptr);
         if (c.use) return gemm_launch_kgs<G_RESID, false>(a, N, c.tile, ws, st);
     }
     switch (epi) {

@@ -33,9 +33,6 @@ Tunables read_env()
     env_int("L2Z_PF_PANEL", &t.pf_panel);
     env_int("L2Z_PF_PANEL_MAX", &t.pf_panel_max);
     env_int("L2Z_PF_X3", &t.pf_x3);
-    env_int("L2Z_PF_X3_FORM", &t.pf_x3_form);
-    env_int("L2Z_PF_X3_SK", &t.pf_x3_sk);
-    env_int("L2Z_PF_X3_TOK", &t.pf_x3_tok);
     env_int("L2Z_PF_X3_STREAM_MIN", &t.pf_x3_stream_min);
     return t;
 }
@@ -78,9 +75,7 @@ bool tunables_set(const char *name, long long v)
         {"L2Z_COMM_RCCL", &t.prefer_rccl}, {"L2Z_ARGMAX_XCHG", &t.argmax_xchg}, {"L2Z_P2P_CONSUME", &t.p2p_consume},
         {"L2Z_P2P_BULK_MB", &t.p2p_bulk_mb}, {"L2Z_PREFILL", &t.prefill}, {"L2Z_PF_CHUNK", &t.pf_chunk},
         {"L2Z_PF_PANEL", &t.pf_panel}, {"L2Z_PF_PANEL_MAX", &t.pf_panel_max},
-        {"L2Z_PF_X3", &t.pf_x3}, {"L2Z_PF_X3_FORM", &t.pf_x3_form},
-        {"L2Z_PF_X3_SK", &t.pf_x3_sk}, {"L2Z_PF_X3_TOK", &t.pf_x3_tok},
-        {"L2Z_PF_X3_STREAM_MIN", &t.pf_x3_stream_min}};
+        {"L2Z_PF_X3", &t.pf_x3}, {"L2Z_PF_X3_STREAM_MIN", &t.pf_x3_stream_min}};
     for (auto &e : ints)
         if (strcmp(e.n, name) == 0) {
             *e.p = (int)v;

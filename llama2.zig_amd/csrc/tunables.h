@@ -40,11 +40,15 @@ struct Tunables {
     int pf_panel = 1;          // L2Z_PF_PANEL        0: chunks of 17 ... 96 tokens keep the short-prompt / tile GEMMs instead of the K-range panel
                                //                     kernel (changes rounding: the ranges are part of the arithmetic); panel: 32 / 64 / 96 tokens
                                //                     8.8 / 12.5 / 17.6 -> 6.6 / 10.5 / 14.6 ms at 7B
-    int pf_x3 = 1;             // L2Z_PF_X3           0: the tile GEMMs of the batched prefill multiply on the f32 matrix cores (v_mfma_f32_32x32x2_f32)
-                               //                     instead of the bf16 ones over three-term splits of both operands (changes rounding)
-    int pf_x3_form = 0;        // EXPERIMENT
-    int pf_x3_sk = 0, pf_x3_tok = 0;  // EXPERIMENT
-    int pf_x3_stream_min = 97;  // L2Z_PF_X3_STREAM_MIN shortest chunk that takes the stream form of the planes kernel
+    int pf_x3 = 1;             // L2Z_PF_X3           0: every GEMM of the batched prefill multiplies on the f32 matrix cores (v_mfma_f32_32x32x2_f32:
+                               //                     the arithmetic of rounds 2-5; the A/B of the accuracy tests); 1 (default): matrices that stream
+                               //                     from HBM multiply on the bf16 cores over three-term splits of both operands (six
+                               //                     v_mfma_f32_32x32x16_bf16 per 16 k; changes rounding, error against float64 not above the f32
+                               //                     chain's): 7B 128 / 512 / 1024 tokens 17.7 / 57.4 / 108 -> 15.3 / 40.6 / 74 ms; 2: every matrix
+                               //                     (tests drive the planes kernels on toy shapes)
+    int pf_x3_stream_min = 49; // L2Z_PF_X3_STREAM_MIN shortest chunk that takes the STREAM form of the bf16 kernel (up to 128 tokens; below, the
+                               //                     panel kernel): tests of both sides of the switch-over (7B: 48 tokens 8.7 vs 10.1 ms, 56 tokens
+                               //                     10.9 vs 10.4)
     int pf_panel_max = -1;     // L2Z_PF_PANEL_MAX    longest chunk that takes the panel kernel (default and maximum 96 tokens): tests of both sides
                                //                     of the switch-over
 

@@ -687,15 +687,20 @@ SHARDED_PREFILL = [
 ]
 
 
+@pytest.mark.parametrize("x3", [1, 2], ids=["cores-by-shape", "bf16-cores-forced"])
 @pytest.mark.parametrize("world", [2, 4, 8])
 @pytest.mark.parametrize("name,kw,n_tok", SHARDED_PREFILL, ids=[c[0] for c in SHARDED_PREFILL])
-def test_sharded_prefill_emulated_ranks_bit_identical(gpu, ck, world, name, kw, n_tok, options):
+def test_sharded_prefill_emulated_ranks_bit_identical(gpu, ck, world, name, kw, n_tok, options, x3):
     """Row-sharded batched prefill (prefill_host.cpp stages: heads / rows of wo, w1|w3, w2 per rank,
     [tokens, n / world] blocks exchanged and unpacked) on N emulated ranks: every rank's logits, and
     its shard of every layer's KV cache, are BIT-IDENTICAL to the unsharded l2z_prefill -- a tile's k
     order does not depend on which rank owns its rows, and shards take the attention form the whole
-    model takes.  Also with pos0 > 0 (a second call continuing the context)."""
-    options(L2Z_FUSE_SMALL=0)  # the decode step at the end: the unsharded pass runs the launches the shards run
+    model takes.  Also with pos0 > 0 (a second call continuing the context).  x3 = 2: every product on the bf16 matrix cores
+    (the streams-* shapes take them by default: stream form at 51 / 101 tokens, its K ranges from the WHOLE model's rows);
+    the planes kernels' k order and ranges do not depend on the rows a rank owns either."""
+    if x3 == 2 and name.startswith("streams"):
+        pytest.skip("these matrices take the bf16 cores by default")
+    options(L2Z_FUSE_SMALL=0, L2Z_PF_X3=x3)  # (fuse: the decode step at the end -- the unsharded pass runs the launches the shards run)
     cfg = ck.Config(**kw)
     w0, s0 = gpu.Weights(cfg, None, False, seed=23), gpu.RunState(cfg)
     comms = [gpu.Comm(r, world, None, 0, emulated=True) for r in range(world)]
@@ -875,11 +880,16 @@ PREFILL_CONFIGS = [
 ]
 
 
+@pytest.mark.parametrize("x3", [1, 2], ids=["cores-by-shape", "bf16-cores-forced"])
 @pytest.mark.parametrize("name,kw,shared", PREFILL_CONFIGS, ids=[c[0] for c in PREFILL_CONFIGS])
-def test_prefill_equals_token_by_token(gpu, ck, orc, name, kw, shared):
+def test_prefill_equals_token_by_token(gpu, ck, orc, options, name, kw, shared, x3):
     """l2z_prefill(tokens, pos0) leaves the KV cache and the last position's logits as n calls
     of l2z_transformer do (within the logit tolerance: the GEMM sums in MFMA k-order), also
-    when it continues an existing context (pos0 > 0) and spans more than one 512-token chunk."""
+    when it continues an existing context (pos0 > 0) and spans more than one 512-token chunk.
+    x3 = 1: matrices that stream from HBM multiply on the bf16 matrix cores (three-term splits), the others on the f32
+    ones -- the default; x3 = 2: every matrix on the bf16 cores, so that the planes kernels (tile forms from 129 tokens,
+    the stream form at 49 ... 128 where K >= 256) meet every toy shape, head layout and ragged width here."""
+    options(L2Z_PF_X3=x3)
     cfg = ck.Config(**kw)
     blob = ck.synth_blob(cfg, shared, seed=91)
     w = gpu.Weights(cfg, blob, shared)

@@ -1,0 +1,77 @@
+"""The prefill GEMMs on the bf16 matrix cores (csrc/prefill_common.h split3 / x3_mfma, prefill_gemm.hip planes kernels):
+an f32 product as six bf16 products of three-term splits.  The claim these tests hold the kernels to: the result is an
+f32-accurate product -- its error against FLOAT64 is not above the error of the f32 matrix cores' own fmaf chain
+(v_mfma_f32_32x32x2_f32, the arithmetic of rounds 2-5, L2Z_PF_X3=0) on the same inputs."""
+import numpy as np
+import pytest
+
+
+
+def _layer0_v_rows(ck, cfg, seed, toks):
+    """float64 truth of the value-cache rows of layer 0: Wv . rmsnorm(embedding row) -- ONE GEMM of the prefill, inputs
+    regenerated on the host (the rmsnorm in float64, then rounded to the f32 the device holds, up to its own rounding)."""
+    t = {t.name: t for t in ck.tensor_table(cfg, False)}
+
+    def tensor(name, row0, rows, width):
+        return ck.synth_values(t[name].offset + row0 * width, rows * width, seed, t[name].scale, t[name].bias).reshape(rows, width)
+    rms = tensor("rms_att_weight", 0, 1, cfg.dim)[0].astype(np.float64)
+    wv = tensor("wv", 0, cfg.kv_dim, cfg.dim).astype(np.float64)
+    emb = np.stack([tensor("token_embedding_table", tk, 1, cfg.dim)[0] for tk in toks]).astype(np.float64)
+    xn = emb * (1.0 / np.sqrt((emb * emb).mean(axis=1, keepdims=True) + 1e-5)) * rms
+    xn = xn.astype(np.float32).astype(np.float64)
+    return xn @ wv.T, np.abs(xn) @ np.abs(wv.T)
+
+
+# (n_tokens, what the bf16 path runs there)
+FORMS = [(56, "stream form, two token tiles"), (100, "stream form, four token tiles"), (300, "tile forms")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,what", FORMS, ids=[f[1].replace(" ", "-").replace(",", "") for f in FORMS])
+def test_bf16_split_product_is_as_accurate_as_the_f32_chain(gpu, ck, options, n, what):
+    """One GEMM (K = 2048, matrices that stream from HBM) on both kinds of matrix cores against float64.
+    Bars: max |err| <= 4e-7 * sum |a_i b_i| (the single-kernel bar of tests/test_gpu_parity.py is 4e-6), the rms error
+    of the bf16 path <= 1.15 x the f32 chain's, and no bias (|mean err * sign(value)| <= 3e-8 * mean |value|: a
+    truncating split or accumulator would show up here first).  Observed at K = 4096 (scripts/x3_accuracy.py): rms
+    7.1e-7 (tile forms) / 3.2e-7 (stream form: shorter chains, K ranges) against 8.1e-7 for the f32 chain."""
+    cfg = ck.Config(dim=2048, hidden_dim=5632, n_layers=1, n_heads=16, n_kv_heads=16, vocab_size=4096, seq_len=320)
+    seed = 11
+    w = gpu.Weights(cfg, None, False, seed=seed)
+    toks = [1] + np.random.default_rng(1).integers(2, cfg.vocab_size, n - 1).tolist()
+    truth, scale = _layer0_v_rows(ck, cfg, seed, toks)
+    S, kvd = cfg.seq_len, cfg.kv_dim
+    rms = {}
+    for x3 in (0, 1):
+        options(L2Z_PF_X3=x3, L2Z_PF_PANEL=0 if x3 == 0 else 1)   # (f32 side: the tile GEMM's chain, not the panel kernel's ranges)
+        s = gpu.RunState(cfg)
+        s.prefill(toks, 0, w)
+        got = s.read("value_cache", 0, S * kvd).astype(np.float64).reshape(S, kvd)[:n]
+        s.close()
+        err = got - truth
+        rms[x3] = float(np.sqrt((err ** 2).mean()))
+        bias = float((err * np.sign(truth)).mean() / np.abs(truth).mean())
+        print(f"{what}, {n} tokens, L2Z_PF_X3={x3}: max |err| / sum|ab| {float((np.abs(err) / scale).max()):.3e}, rms err {rms[x3]:.3e}, bias {bias:+.2e}")
+        assert float((np.abs(err) / scale).max()) <= 4e-7
+        assert abs(bias) <= 3e-8
+    assert rms[1] <= 1.15 * rms[0], rms
+    w.close()
+
+
+def test_split_terms_recompose_exactly():
+    """split3 on the host's own floats, restated in numpy: x1 + x2 + x3 == x bit for bit (round-to-nearest-even bf16 of
+    what the terms before left; the subtractions are exact), the property the six-product sum rests on.  This is the
+    restatement the device code follows (prefill_common.h), checked on the values the checkpoints hold -- including
+    denormal-free extremes."""
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.standard_normal(1 << 16).astype(np.float32) * np.float32(s) for s in (1e-3, 1.0, 37.5, 1e4)] +
+                       [np.array([0.0, -0.0, 1.0, -1.0, 3.3895314e38 / 2, 1.1754944e-38 * 2 ** 30], np.float32)])
+
+    def bf16(v):   # round to nearest even to 8 significand bits, as v_cvt_pk_bf16_f32 does
+        u = v.view(np.uint32).astype(np.uint64)
+        r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+        return r.astype(np.uint32).view(np.float32)
+    x1 = bf16(x); r1 = x - x1
+    x2 = bf16(r1); r2 = r1 - x2
+    x3 = bf16(r2)
+    assert np.array_equal((x1.astype(np.float64) + x2 + x3), x.astype(np.float64))
+    assert np.array_equal(r2 - x3, np.zeros_like(x))
