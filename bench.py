@@ -45,6 +45,7 @@ import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E vendor peak (MI355X_MICROARCH.md); ~6300 measured copy
 MFMA_F32_PEAK_TF = 157.3  # dense fp32 matrix peak (256 CUs x 256 flop/clk x 2.4 GHz)
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 matrix peak (MI355X_MICROARCH.md: ~2.5 PF; the 2:1-sparse headline is not used)
 
 # run in this order: the library collectives first.  Scheme A (rows of every matrix, 4 all-gathers per layer: bit-identical
 # to the unsharded pass) on three transports, then scheme B (Wo / W2 by columns, 2 all-reduces per layer: logit tolerance)
@@ -509,13 +510,22 @@ def single_gpu(args) -> None:
                     s.prefill(toks[:n], 0, w)  # synchronises
                 return (time.perf_counter() - t0) / reps
             dtp = time_prefill(n_p)
+            # Round 6: matrices that stream from HBM multiply on the bf16 matrix cores, an f32 product as SIX bf16 products of
+            # three-term splits (csrc/prefill_common.h) -- the flops the cores execute are 6 x the GEMM's, against the dense
+            # bf16 peak; the f32-equivalent rate and its ratio to the f32 cores' peak (what rounds 2-5 reported) ride beside.
+            on_bf16 = B.prefill_on_bf16_cores(cfg)
+            f32_equiv = flops_tok * n_p / dtp / 1e12
             prefill = {"prompt_tokens": n_p, "ms": dtp * 1e3, "tokens_per_s": n_p / dtp,
-                       "roofline": {"bound": "mfma", "achieved": flops_tok * n_p / dtp / 1e12, "peak": MFMA_F32_PEAK_TF,
-                                    "unit": "TFLOP/s", "frac": flops_tok * n_p / dtp / 1e12 / MFMA_F32_PEAK_TF,
-                                    "note": "whole prefill (GEMMs + attention + norms), GEMM flops only "
-                                            "in the numerator; v_mfma_f32_32x32x2_f32"}}
-            # shorter prompts: other kernels (<= 16 tokens: the weight-streaming bound short-prompt GEMMs; 17-96: the
-            # K-range panel kernel; 97-256: smaller tiles / split K) -- ms per prompt length, with the bound that applies
+                       "matrix_cores": "bf16, three-term split of both operands, 6 products (f32-accurate)" if on_bf16 else "f32",
+                       "roofline": {"bound": "mfma", "achieved": (6 if on_bf16 else 1) * f32_equiv,
+                                    "peak": MFMA_BF16_PEAK_TF if on_bf16 else MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                    "frac": (6 * f32_equiv / MFMA_BF16_PEAK_TF) if on_bf16 else f32_equiv / MFMA_F32_PEAK_TF,
+                                    "f32_equivalent_tflops": f32_equiv, "of_the_f32_cores_peak": f32_equiv / MFMA_F32_PEAK_TF,
+                                    "note": "whole prefill (GEMMs + attention + norms), GEMM flops only in the numerator; "
+                                            + ("v_mfma_f32_32x32x16_bf16 x 6 per 16 k" if on_bf16 else "v_mfma_f32_32x32x2_f32")}}
+            # shorter prompts: other kernels (<= 16 tokens: the weight-streaming bound short-prompt GEMMs; 17-48: the
+            # K-range panel kernel on the f32 cores; 49-128: the stream form of the bf16 kernel) -- ms per prompt length, with
+            # the bound that applies
             by_len, frac_by_len = {}, {}
             bytes_tok = weight_bytes_per_token(cfg)
             for n_s in (16, 32, 48, 64, 96, 128):   # (48 / 96: the panel kernel's three- and six-tile forms, round 6)
@@ -525,7 +535,8 @@ def single_gpu(args) -> None:
                     # both bounds: a chunk of <= ~64 tokens is nearer the weight stream's, a longer one the matrix cores'
                     frac_by_len[str(n_s)] = {"bound": "hbm" if n_s <= 48 else "mfma",
                                              "hbm_frac": bytes_tok / d / 1e9 / HBM_PEAK_GBS,
-                                             "mfma_frac": flops_tok * n_s / d / 1e12 / MFMA_F32_PEAK_TF}
+                                             "mfma_frac": (6 * flops_tok * n_s / d / 1e12 / MFMA_BF16_PEAK_TF) if on_bf16
+                                                          else flops_tok * n_s / d / 1e12 / MFMA_F32_PEAK_TF}
                     frac_by_len[str(n_s)]["frac"] = frac_by_len[str(n_s)]["hbm_frac" if n_s <= 48 else "mfma_frac"]
             prefill["ms_by_prompt_tokens"] = by_len
             prefill["frac_by_prompt_tokens"] = frac_by_len

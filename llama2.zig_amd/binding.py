@@ -134,6 +134,8 @@ def lib():
     if hasattr(L, "l2z_shard_plan"):
         L.l2z_shard_plan.argtypes = [cfgp, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
     L.l2z_prefill_tile.argtypes = [C.c_int, C.c_int, C.c_int]
+    if hasattr(L, "l2z_prefill_cores"):
+        L.l2z_prefill_cores.argtypes = [C.c_longlong, C.c_int, C.c_int]
     if hasattr(L, "l2z_prefill_split_k"):
         L.l2z_prefill_split_k.argtypes = [C.c_longlong, C.c_int, C.c_int, C.c_int]
     L.l2z_emu_prefill.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int32), C.c_int, C.c_int]
@@ -432,6 +434,20 @@ def prefill_split_k(n_features_whole: int, n_tokens: int, k: int, paired: bool =
     if r < 0:
         raise L2ZError(r, lib().l2z_last_error().decode(errors="replace"))
     return r
+
+
+def prefill_cores(n_features_whole: int, n_tokens: int, k: int) -> int:
+    """Matrix cores of a prefill product (host logic): 0 f32, 1 bf16 over three-term splits (tile forms), n >= 2 the
+    stream form of the bf16 kernel with n - 1 K ranges."""
+    r = lib().l2z_prefill_cores(n_features_whole, n_tokens, k)
+    if r < 0:
+        raise L2ZError(r, lib().l2z_last_error().decode(errors="replace"))
+    return r
+
+
+def prefill_on_bf16_cores(cfg) -> bool:
+    """Whether the model's widest product (W1 | W3) multiplies on the bf16 matrix cores in the batched prefill."""
+    return prefill_cores(2 * cfg.hidden_dim, 512, cfg.dim) > 0
 
 
 def emu_prefill(states, weights, tokens, pos0: int) -> None:

@@ -294,6 +294,14 @@ extern "C" int l2z_prefill_split_k(long long n_features_whole, int n_tokens, int
     return prefill_split_k(n_features_whole, n_tokens, k, paired != 0);
 }
 
+extern "C" int l2z_prefill_cores(long long n_features_whole, int n_tokens, int k)
+{
+    L2Z_CHECK(n_features_whole > 0 && n_tokens > 0 && k > 0, L2Z_ERR_INVALID, "l2z_prefill_cores: bad arguments");
+    const int kp = (k + 63) / 64 * 64;
+    if (!x3_applies(n_features_whole, kp)) return 0;
+    return x3_stream_shape(n_features_whole, n_tokens, kp) ? 1 + x3_stream_sk(n_features_whole, n_tokens, kp) : 1;
+}
+
 extern "C" int l2z_prefill_tile(int n_features, int n_tokens, int paired)
 {
     L2Z_CHECK(n_features > 0 && n_tokens > 0, L2Z_ERR_INVALID, "l2z_prefill_tile: bad arguments");

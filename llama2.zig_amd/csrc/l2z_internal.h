@@ -245,8 +245,9 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
                                size_t kv_head_stride = 0,  // PG_*CACHE: out is a head-major cache (MatvecArgs::kv_head_stride)
                                int sk = 1, const SplitKWs *ws = nullptr,   // sk > 1: the split-K family (prefill_split_k)
                                int ldw = 0,   // floats between rows of w (0: K; W1 / W3 of the device blob: 2 K)
-                               long long n_launch_whole = 0);  // rows of the whole model's launch this product is a part of (q, k, v
+                               long long n_launch_whole = 0,   // rows of the whole model's launch this product is a part of (q, k, v
                                                                // launched apart: dim + 2 kv_dim; 0: N * n_scale) -- the stream form's K ranges
+                               bool planes_ready = false);     // the launch before this one multiplied the same x on the bf16 cores: its planes stand
 // the stream form of the planes kernel (prefill_gemm.hip): which products take it, and their K ranges
 bool x3_applies(long long n_whole, int K);
 bool x3_stream_shape(long long n_whole, int P, int K);

@@ -1078,11 +1078,12 @@ __global__ __launch_bounds__(256) void prefill_split3_kernel(const float *x, int
 }
 
 // before a launch of the planes form: a.K is the padded K; fills ws->x3 from a.x
-hipError_t prepare_x3(GemmArgs &a, const SplitKWs *ws, hipStream_t st, long long n_whole)
+hipError_t prepare_x3(GemmArgs &a, const SplitKWs *ws, hipStream_t st, long long n_whole, bool planes_ready = false)
 {
     if (!x3_applies(n_whole, a.K)) return hipSuccess;   // a.x3 stays null: the f32 matrix cores
     if (ws == nullptr || ws->x3 == nullptr || (size_t)a.P * 3 * a.K * sizeof(__bf16) > ws->x3_bytes) return hipErrorInvalidValue;
     a.x3 = ws->x3; a.kp = a.K; a.ldx3 = 3 * a.K;
+    if (planes_ready) return hipSuccess;   // the launch before this one split the same matrix (k and v behind q)
     const size_t n = (size_t)a.P * (a.K >> 3);
     prefill_split3_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(a.x, a.ldx, (__bf16 *)ws->x3, a.K, a.P);
     return hipGetLastError();
@@ -1090,9 +1091,9 @@ hipError_t prepare_x3(GemmArgs &a, const SplitKWs *ws, hipStream_t st, long long
 
 // launch of the stream form; a.K is the padded K, a.N this rank's rows, n_whole the whole model's (the K ranges)
 template <int EPI>
-hipError_t launch_x3_stream(GemmArgs a, long long n_whole, const SplitKWs *ws, hipStream_t st)
+hipError_t launch_x3_stream(GemmArgs a, long long n_whole, const SplitKWs *ws, hipStream_t st, bool planes_ready = false)
 {
-    if (const hipError_t e = prepare_x3(a, ws, st, n_whole); e != hipSuccess) return e;
+    if (const hipError_t e = prepare_x3(a, ws, st, n_whole, planes_ready); e != hipSuccess) return e;
     const int sk = x3_stream_sk(n_whole, a.P, a.K), tm = (a.P + 31) / 32, ntx = (a.N + 127) / 128;
     if (ws->part == nullptr || ws->cnt == nullptr || (size_t)ntx * sk * tm * 32 * 128 > ws->part_floats || ntx > ws->cnt_ints)
         return hipErrorOutOfMemory;
@@ -1233,9 +1234,10 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
     // 128 x 64 tiles mean q alone already gives every CU its one resident block: three such launches
     // measured 445 us against 453 for the 768-block one (7B, 512 tokens).  With the smaller tiles several
     // blocks share a CU and the longer grid keeps them supplied: 128 tokens 21.8 -> 19.4 ms fused.
-    // (On the bf16 cores the one launch also splits the activations once instead of three times: 128 x 64 tiles, fused.)
-    if ((tf == TILE_128x64 || tf == TILE_128x128) && !x3) return hipErrorNotSupported;
-    if (tf == TILE_128x128) tf = TILE_128x64;
+    // (The same on the bf16 cores: 7B, 1024 / 512 tokens 74.3 / 40.6 ms with three launches, 80.3 / 41.6 fused on 128 x 64
+    // tiles -- the caller's k and v launches reuse q's planes: planes_ready.)
+    (void)x3;
+    if (tf == TILE_128x64 || tf == TILE_128x128) return hipErrorNotSupported;
     int feat = tf == TILE_32x32 ? 32 : 64;
     if (nq % feat != 0 || nkv % feat != 0) {
         if (nq % 32 != 0 || nkv % 32 != 0) return hipErrorNotSupported;
@@ -1278,7 +1280,7 @@ hipError_t launch_prefill_gemm_kv_pair(const float *x, int ldx, const float *wk,
 hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w, float *out, int ldo,
                                int P, int N, int K, int pos0, const float2 *rope, int head_size,
                                hipStream_t st, const float *res, int ldres, int n_scale, size_t kv_head_stride,
-                               int sk, const SplitKWs *ws, int ldw, long long n_launch_whole)
+                               int sk, const SplitKWs *ws, int ldw, long long n_launch_whole, bool planes_ready)
 {
     if (P <= 0 || N <= 0 || K <= 0 || (K % 4) != 0 || (ldx % 4) != 0) return hipErrorInvalidValue;
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return hipErrorInvalidValue;
@@ -1292,17 +1294,17 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
         const long long nw = n_launch_whole > 0 ? n_launch_whole : (long long)N * a.n_scale;
         a.K = kp;
         switch (epi) {
-            case G_STORE: return launch_x3_stream<G_STORE>(a, nw, ws, st);
-            case G_RESID: return launch_x3_stream<G_RESID>(a, nw, ws, st);
-            case G_ROPE: return launch_x3_stream<G_ROPE>(a, nw, ws, st);
-            case G_ROPE_CACHE: return launch_x3_stream<G_ROPE_CACHE>(a, nw, ws, st);
-            case G_CACHE: return launch_x3_stream<G_CACHE>(a, nw, ws, st);
+            case G_STORE: return launch_x3_stream<G_STORE>(a, nw, ws, st, planes_ready);
+            case G_RESID: return launch_x3_stream<G_RESID>(a, nw, ws, st, planes_ready);
+            case G_ROPE: return launch_x3_stream<G_ROPE>(a, nw, ws, st, planes_ready);
+            case G_ROPE_CACHE: return launch_x3_stream<G_ROPE_CACHE>(a, nw, ws, st, planes_ready);
+            case G_CACHE: return launch_x3_stream<G_CACHE>(a, nw, ws, st, planes_ready);
         }
     }
     if (P <= skinny_max && sk <= 1) return launch_prefill_skinny(epi, a, st);  // prefill_skinny.hip
     K = a.K = pad_k(K, 64, ldx);   // whole 64-k stages (see pad_k)
     if (K < 0) return hipErrorInvalidValue;
-    if (const hipError_t e = prepare_x3(a, ws, st, n_launch_whole > 0 ? n_launch_whole : (long long)N * a.n_scale); e != hipSuccess) return e;
+    if (const hipError_t e = prepare_x3(a, ws, st, n_launch_whole > 0 ? n_launch_whole : (long long)N * a.n_scale, planes_ready); e != hipSuccess) return e;
     if (sk > 1) {
         if (K / 64 < sk) return hipErrorInvalidValue;
         switch (epi) {

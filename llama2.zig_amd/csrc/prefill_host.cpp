@@ -192,9 +192,9 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
                                                               s->rope, hs, st, sh.world, kvh_stride, sk_qkv, n_qkv);  // short prompts: k | v together
             if (ke == hipErrorNotSupported) {
                 L2Z_HIP(launch_prefill_gemm(PG_ROPE_CACHE, s->pf_xn, ldxn, wk, kc, kvd, P, kvd, dim, pos0, s->rope, hs,
-                                            st, nullptr, 0, sh.world, kvh_stride, sk_qkv, ws, 0, n_qkv));   // :354-357
+                                            st, nullptr, 0, sh.world, kvh_stride, sk_qkv, ws, 0, n_qkv, true));   // :354-357 (q's planes stand)
                 L2Z_HIP(launch_prefill_gemm(PG_CACHE, s->pf_xn, ldxn, wv, vc, kvd, P, kvd, dim, pos0, s->rope, hs, st,
-                                            nullptr, 0, sh.world, kvh_stride, sk_qkv, ws, 0, n_qkv));       // :358
+                                            nullptr, 0, sh.world, kvh_stride, sk_qkv, ws, 0, n_qkv, true));       // :358
             } else {
                 L2Z_HIP(ke);
             }
@@ -286,9 +286,9 @@ int prefill_half_b(l2z_runstate *s, const l2z_weights *w, int l, int half, int P
             L2Z_HIP(launch_prefill_gemm(PG_ROPE, s->pf_xn, ldxn, wq, s->pf_q, sh.dim_loc, P, sh.dim_loc, dim, pos0, s->rope, hs, st,
                                         nullptr, 0, sh.world, 0, sk_qkv, ws, 0, n_qkv));
             L2Z_HIP(launch_prefill_gemm(PG_ROPE_CACHE, s->pf_xn, ldxn, wk, kc, kvd, P, kvd, dim, pos0, s->rope, hs, st, nullptr, 0,
-                                        sh.world, kvh_stride, sk_qkv, ws, 0, n_qkv));
+                                        sh.world, kvh_stride, sk_qkv, ws, 0, n_qkv, true));
             L2Z_HIP(launch_prefill_gemm(PG_CACHE, s->pf_xn, ldxn, wv, vc, kvd, P, kvd, dim, pos0, s->rope, hs, st, nullptr, 0,
-                                        sh.world, kvh_stride, sk_qkv, ws, 0, n_qkv));
+                                        sh.world, kvh_stride, sk_qkv, ws, 0, n_qkv, true));
         } else {
             L2Z_HIP(qe);
         }

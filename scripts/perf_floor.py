@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 DECODE_SHAPES = {"llama2-7b": 8, "stories110M": 8, "stories42M": 8, "stories15M": 8}   # shape -> position timed
-PREFILL_TOKENS = (16, 32, 48, 64, 96, 128, 512)
+PREFILL_TOKENS = (16, 32, 48, 64, 96, 128, 256, 512, 1024)
 
 
 def decode_kinds(B, ck, name, pos, w=None, s=None):

@@ -1,6 +1,7 @@
 """The perf gate's comparison rule on made-up readings (CPU; the measurements themselves need the GPU:
 tests/test_gpu_perf_gate.py).  What it must do: fail a 5 % slowdown of ONE kernel family even when that family serves
-most of the group's figures (the batched prefill: the panel kernel serves 4 of 7 chunk lengths), pass a process in which
+many of the group's figures (the batched prefill: the stream form of the bf16 kernel serves 3 of 9 chunk lengths, its tile forms
+3 more), pass a process in which
 everything runs 3 % slower, and fail when everything drifts past the common slack."""
 import json
 import os
@@ -13,7 +14,7 @@ from test_gpu_perf_gate import FLOOR, check_group
 def test_floor_file_has_every_group_and_names_its_device():
     assert FLOOR["device"]["cus"] == 256 and FLOOR["device"]["name_contains"]
     assert set(FLOOR["decode_us_per_launch"]["floors"]) == {"llama2-7b", "stories110M", "stories42M", "stories15M"}
-    assert set(FLOOR["prefill_ms"]["floors"]) == {"16", "32", "48", "64", "96", "128", "512"}
+    assert set(FLOOR["prefill_ms"]["floors"]) == {"16", "32", "48", "64", "96", "128", "256", "512", "1024"}
     assert set(FLOOR["decode_tokens_per_s"]["floors"]) == {"stories15M", "stories42M", "stories110M"}
     assert set(FLOOR["solo_rank_tokens_per_s"]["floors"]) == {"p2p-gather", "p2p-allreduce"}
     assert FLOOR["attention_us_per_layer_pos2047"]["floor"] > 0
@@ -21,12 +22,16 @@ def test_floor_file_has_every_group_and_names_its_device():
 
 def test_gate_rule_on_synthetic_readings():
     g = FLOOR["prefill_ms"]
-    f = g["floors"]
+    assert sorted(sum(g["groups"].values(), [])) == sorted(g["floors"])
+    f = {k: g["floors"][k] for k in g["groups"]["bf16 cores (stream form, tile forms)"]}
     ok = {k: v * 1.03 for k, v in f.items()}                       # a slow process: everything + 3 %
     check_group("prefill", ok, f, g["slack"], g["common_slack"])
-    panel = {k: v * (1.05 * 0.85 + 0.15 if k in ("32", "48", "64", "96") else 1.0) for k, v in f.items()}  # panel kernel + 5 %: 85 % of those chunks' time
-    with pytest.raises(AssertionError, match="48"):
-        check_group("prefill", panel, f, g["slack"], g["common_slack"])
+    stream = {k: v * (1.05 * 0.85 + 0.15 if k in ("64", "96", "128") else 1.0) for k, v in f.items()}  # stream kernel + 5 %: 85 % of those chunks' time
+    with pytest.raises(AssertionError, match="96"):
+        check_group("prefill", stream, f, g["slack"], g["common_slack"])
+    tiles = {k: v * (1.05 * 0.9 + 0.1 if k in ("256", "512", "1024") else 1.0) for k, v in f.items()}   # the tile forms + 5 %
+    with pytest.raises(AssertionError, match="512"):
+        check_group("prefill", tiles, f, g["slack"], g["common_slack"])
     with pytest.raises(AssertionError, match="everything"):
         check_group("prefill", {k: v * 1.08 for k, v in f.items()}, f, g["slack"], g["common_slack"])
     d = FLOOR["decode_us_per_launch"]
