@@ -43,17 +43,17 @@ int x3_stream_sk(long long n_whole, int P, int K)
 {
     // One block per CU (the ring takes the LDS), blocks of a launch equally long: the launch lasts
     // ceil(tiles sk / CUs) rounds of ceil(stages / sk) stages, plus a fixed cost per round (pipeline fill, the partial sums'
-    // hand-over: ~6 stages' worth).  The CU count is the part the rule was made for (MI355X: 256), as a constant -- the
+    // hand-over: ~10 stages' worth).  The CU count is the part the rule was made for (MI355X: 256), as a constant -- the
     // ranges are part of the arithmetic and must not depend on the device a rank happens to run on.
     (void)P;
     constexpr long long kCus = 256;
     const long long tiles = (n_whole + 127) / 128, stages = K / 32;
     int best = 1;
     long long best_cost = 0;
-    for (int sk = 1; sk <= 8; sk++) {
+    for (int sk = 1; sk <= 8; sk *= 2) {   // (1, 2, 4, 8: the ranges share the tile's epilogue in equal parts)
         if (stages / sk < 8) break;
         const long long rounds = (tiles * sk + kCus - 1) / kCus;
-        const long long cost = rounds * ((stages + sk - 1) / sk + 6);
+        const long long cost = rounds * ((stages + sk - 1) / sk + 10);
         if (sk == 1 || cost < best_cost) { best = sk; best_cost = cost; }
     }
     return best;
@@ -124,8 +124,9 @@ static dim3 dma_grid(int ntx, int nty, GemmArgs *a)
 // epilogue shared by the two tile kernels: per MFMA tile a lane owns one feature and 16 tokens
 template <int EPI, int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, v16f (&acc)[TM][TN], int n0, int m0, int wm,
-                                              int wn, int lane)
+                                              int wn, int lane, int lo = 0, int hi = 1 << 30)
 {
+    // [lo, hi): the values i * 16 + r this call finishes (the stream form's ranges share a tile's epilogue; default all)
     if constexpr (EPI == G_QKV) {
         // a block's columns lie in ONE of the three ranges (launcher: nq and nkv are multiples of the tile)
         const int seg = n0 >= a.nq + a.nkv ? 2 : n0 >= a.nq ? 1 : 0;
@@ -148,7 +149,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, v16f (&acc)[TM]
                         const float2 cs = a.rope[(size_t)pos * (size_t)(hs >> 1) + (size_t)(((j < nseg ? j : 0) % hs) >> 1)];
                         v = (j & 1) ? partner * cs.y + v * cs.x : v * cs.x - partner * cs.y;
                     }
-                    if (tok < a.P && j < nseg) o[seg == 0 ? (size_t)tok * ld + j : kv_index(a, ld, a.pos0 + tok, j)] = v;  // :354-358
+                    if (tok < a.P && i * 16 + r >= lo && i * 16 + r < hi && j < nseg) o[seg == 0 ? (size_t)tok * ld + j : kv_index(a, ld, a.pos0 + tok, j)] = v;  // :354-358
                 }
             }
         return;
@@ -164,7 +165,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, v16f (&acc)[TM]
                     const int tok = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     const float v = acc[i][jt][r];
                     const float partner = __shfl_xor(v, 1, 64);
-                    if (!(j & 1) && tok < a.P && j < a.N) a.out[(size_t)tok * a.ldo + (j >> 1)] = swiglu_merge(v, partner);  // :411-416
+                    if (!(j & 1) && tok < a.P && i * 16 + r >= lo && i * 16 + r < hi && j < a.N) a.out[(size_t)tok * a.ldo + (j >> 1)] = swiglu_merge(v, partner);  // :411-416
                 }
             }
         return;
@@ -188,7 +189,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, v16f (&acc)[TM]
                     v = (j & 1) ? partner * cs.y + v * cs.x    // v0*fci + v1*fcr
                                 : v * cs.x - partner * cs.y;   // v0*fcr - v1*fci
                 }
-                if (tok < a.P && j < a.N) {
+                if (tok < a.P && i * 16 + r >= lo && i * 16 + r < hi && j < a.N) {
                     if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + j] = v;
                     else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + j] = a.res[(size_t)tok * a.ldres + j] + v;  // main.zig:711
                     else if (EPI == G_SWIGLU)
@@ -642,6 +643,42 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
     }
 }
 
+// The epilogue of ONE value (the stream form's shared reduction finishes values by their flat index, not by register):
+// feature j of the launch (lane & 31 within the wave's 32), token tok; every lane of the wave calls it together (the RoPE /
+// SwiGLU partner is the adjacent lane's value of the same index).  Same arithmetic as gemm_epilogue.
+template <int EPI>
+__device__ __forceinline__ void epi_one(const GemmArgs &a, float v, int n0, int j_in_tile, int tok, bool valid)
+{
+    const float partner = __shfl_xor(v, 1, 64);
+    if constexpr (EPI == G_QKV) {
+        const int seg = n0 >= a.nq + a.nkv ? 2 : n0 >= a.nq ? 1 : 0;
+        const int f0 = n0 - (seg == 2 ? a.nq + a.nkv : seg == 1 ? a.nq : 0), nseg = seg == 0 ? a.nq : a.nkv;
+        float *o = seg == 0 ? a.out : seg == 1 ? a.outk : a.outv;
+        const int ld = seg == 0 ? a.ldo : a.ldkv, j = f0 + j_in_tile;
+        if (seg < 2) {
+            const int hs = a.head_size, pos = a.pos0 + (tok < a.P ? tok : 0);
+            const float2 cs = a.rope[(size_t)pos * (size_t)(hs >> 1) + (size_t)(((j < nseg ? j : 0) % hs) >> 1)];
+            v = (j & 1) ? partner * cs.y + v * cs.x : v * cs.x - partner * cs.y;   // main.zig:346-349
+        }
+        if (valid && tok < a.P && j < nseg) o[seg == 0 ? (size_t)tok * ld + j : kv_index(a, ld, a.pos0 + tok, j)] = v;  // :354-358
+    } else if constexpr (EPI == G_SWIGLU_IL) {
+        const int j = n0 + j_in_tile;   // row of the alternating matrix: even W1, odd W3
+        if (valid && !(j & 1) && tok < a.P && j < a.N) a.out[(size_t)tok * a.ldo + (j >> 1)] = swiglu_merge(v, partner);  // :411-416
+    } else {
+        const int j = n0 + j_in_tile;
+        if (EPI == G_ROPE || EPI == G_ROPE_CACHE) {
+            const int hs = a.head_size, pos = a.pos0 + (tok < a.P ? tok : 0);
+            const float2 cs = a.rope[(size_t)pos * (size_t)(hs >> 1) + (size_t)(((j < a.N ? j : 0) % hs) >> 1)];
+            v = (j & 1) ? partner * cs.y + v * cs.x : v * cs.x - partner * cs.y;
+        }
+        if (valid && tok < a.P && j < a.N) {
+            if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + j] = v;
+            else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + j] = a.res[(size_t)tok * a.ldres + j] + v;  // main.zig:711
+            else a.out[kv_index(a, a.ldo, a.pos0 + tok, j)] = v;                  // main.zig:354-358
+        }
+    }
+}
+
 // ---- the STREAM form of the planes kernel: chunks of <= 128 tokens of matrices that stream from HBM (round 6) ----
 // At <= 128 tokens a layer's matrices cross the chip once (809 MB at the 7B shape: 130 us at the HBM rate) against 40-160 us
 // of bf16 MFMAs: the tile forms above -- one or two blocks per CU, two stage buffers, loads ONE stage ahead -- are bound by
@@ -670,9 +707,14 @@ __global__ __launch_bounds__(512) void prefill_x3_stream(const GemmArgs a)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave & 3, kg = wave >> 2;
     const int hl = lane >> 5, il = lane & 31;
-    const int bx = blockIdx.x, n0 = bx * BNt;
+    // block -> (tile, range): the ranges of a tile are CONSECUTIVE block ids -- dispatched together, finishing together,
+    // so that they can share the tile's reduction and epilogue (below) without anybody waiting for a block not yet resident
     const int nst_all = a.K / BK, sk = a.sk > 1 ? a.sk : 1;
-    const int sbeg = (int)((long long)nst_all * blockIdx.z / sk), nstage = (int)((long long)nst_all * (blockIdx.z + 1) / sk) - sbeg;
+    // (a.ntx > 0: the launch does not fit the chip in one round -- range-major ids, the last arriver of a tile finishes it)
+    const bool coop = a.ntx == 0;
+    const int bx = coop ? (int)blockIdx.x / sk : (int)blockIdx.x % a.ntx, bz = coop ? (int)blockIdx.x - bx * sk : (int)blockIdx.x / a.ntx;
+    const int n0 = bx * BNt;
+    const int sbeg = (int)((long long)nst_all * bz / sk), nstage = (int)((long long)nst_all * (bz + 1) / sk) - sbeg;
     const int kbeg = sbeg * BK;
     auto swzx = [](int r) { return (r >> 2) & 3; };          // plane rows of 64 B: four rows fill one 256-B bank sweep
     auto swzw = [](int r) { return (r >> 1) & 7; };          // W rows of 128 B: two rows
@@ -763,21 +805,22 @@ __global__ __launch_bounds__(512) void prefill_x3_stream(const GemmArgs a)
         constexpr bool has_next = decltype(has_next_c)::value, issue = decltype(issue_c)::value;
         if constexpr (has_next) {
             wait_vmcnt<ahead * NL>();   // stage s + 1 has landed (this wave's part) and this wave's reads of stage s are done ...
+            if (!(L2Z_X3_EXP & 16))
             __syncthreads();            // ... for every wave: stage s's buffer takes the loads of stage s + NBUF
-            read_b(s + 1, blo, bhi);
+            if (!(L2Z_X3_EXP & 8)) read_b(s + 1, blo, bhi);
         }
         Bf3 bnxt;
 #pragma unroll
         for (int i = 0; i < TM; i++) {
-            acc[i][0] = x3_mfma(av[i], bcur, acc[i][0]);
-            if constexpr (issue) {
+            if (!(L2Z_X3_EXP & 2)) acc[i][0] = x3_mfma(av[i], bcur, acc[i][0]);
+            if constexpr (issue && !(L2Z_X3_EXP & 1)) {
                 constexpr int per = (NL + TM - 1) / TM;
 #pragma unroll
                 for (int q = i * per; q < (i + 1) * per && q < NL; q++) issue_one(s + NBUF, q);
             }
             if constexpr (has_next) {
-                av[i] = read_a(s + 1, i);
-                if (i == (TM > 1 ? 1 : 0)) bnxt = split3(blo, bhi);
+                if (!(L2Z_X3_EXP & 4)) av[i] = read_a(s + 1, i);
+                if (i == (TM > 1 ? 1 : 0)) bnxt = (L2Z_X3_EXP & 8) ? bcur : split3(blo, bhi);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -819,10 +862,12 @@ __global__ __launch_bounds__(512) void prefill_x3_stream(const GemmArgs a)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][0][r] += red[((wn * TM + i) * 16 + r) * 64 + lane];
     }
-    if (sk > 1) {
+    if (sk > 1 && !coop) {
+        // A launch of several rounds of blocks: whichever block of a tile arrives last adds the sk partials in range order
+        // (nobody waits: a waiting block would hold a CU its not-yet-resident siblings need) and runs the epilogue.
         constexpr int PT = WN * TM * 16 * 64;   // floats per partial = the tile's outputs
         float *part = a.sk_part + (size_t)bx * (size_t)sk * PT;
-        float *mine = part + (size_t)blockIdx.z * PT + (size_t)wn * (TM * 16 * 64) + lane;
+        float *mine = part + (size_t)bz * PT + (size_t)wn * (TM * 16 * 64) + lane;
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -832,29 +877,23 @@ __global__ __launch_bounds__(512) void prefill_x3_stream(const GemmArgs a)
         __syncthreads();   // (the live waves: k-group 0)
         int *flag = (int *)smem + WN * TM * 16 * 64;   // past the k-groups' sums
         if (tid == 0) {
-            const int prev = __hip_atomic_fetch_add(a.sk_cnt + bx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int prev = __hip_atomic_fetch_add(a.sk_cnt + 2 * bx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = prev == sk - 1;
-            if (last) {
-                __hip_atomic_store(a.sk_cnt + bx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
+            if (last) __hip_atomic_store(a.sk_cnt + 2 * bx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
             *flag = last;
         }
         __syncthreads();
         if (!*flag) return;
-        // range 0, then 1, ... in order; a range's TM x 16 values are requested together (one round trip per range, not
-        // one per value: with the ranges in the inner loop the compiler waits out every load)
+        // range 0, then 1, ... in order; a range's TM x 16 values are requested together, two ranges in flight (device-scope
+        // loads: served past this XCD's caches)
         const float *p0 = part + (size_t)wn * (TM * 16 * 64) + lane;
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][0][r] = p0[(i * 16 + r) * 64];
-        v16f t[2][TM];   // two ranges in flight: range z + 1 is requested before range z is added
+        v16f t[2][TM];
         auto fetch = [&](int z, v16f (&d)[TM]) {
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) d[i][r] = p0[(size_t)z * PT + (i * 16 + r) * 64];
+                for (int r = 0; r < 16; r++)
+                    d[i][r] = __hip_atomic_load(p0 + (size_t)z * PT + (i * 16 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
         auto add = [&](const v16f (&d)[TM]) {
 #pragma unroll
@@ -862,6 +901,9 @@ __global__ __launch_bounds__(512) void prefill_x3_stream(const GemmArgs a)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[i][0][r] += d[i][r];
         };
+        fetch(0, t[0]);
+#pragma unroll
+        for (int i = 0; i < TM; i++) acc[i][0] = t[0][i];
         fetch(1, t[0]);
         int z = 1;
         for (; z + 2 < sk; z += 2) {
@@ -877,6 +919,65 @@ __global__ __launch_bounds__(512) void prefill_x3_stream(const GemmArgs a)
         } else {
             add(t[0]);
         }
+    } else if (sk > 1) {
+        // The tile's K ranges: every block leaves its sums in the workspace (write-through), arrives, and waits for its sk - 1
+        // siblings (consecutive block ids: resident with it or about to be -- see the block -> tile map); then EVERY block
+        // finishes 1 / sk of the tile: values [lo, lo + PER) of each lane's TM x 16 (flat index i * 16 + r), the ranges added
+        // IN RANGE ORDER -- a range's PER values requested together, one round trip per range -- and their epilogue.
+        // (The last-arriver form: one block re-read all sk partials of the tile with its 7 siblings' CUs idle.)
+        constexpr int PT = WN * TM * 16 * 64;   // floats per partial = the tile's outputs
+        float *part = a.sk_part + (size_t)bx * (size_t)sk * PT;
+        float *mine = part + (size_t)bz * PT + (size_t)wn * (TM * 16 * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                __hip_atomic_store(mine + (i * 16 + r) * 64, acc[i][0][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // (the live waves: k-group 0) every wave's part has left
+        int *arrive = a.sk_cnt + 2 * bx, *done = arrive + 1;
+        if (tid == 0) {
+            __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the partials were written through and drained)
+            // (bounded: ~1 s; a sibling that never arrives -- a launch that failed half way -- must not hang the device)
+            for (int it = 0; __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sk && it < (1 << 24); it++)
+                __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+        const float *p0 = part + (size_t)wn * (TM * 16 * 64) + lane;
+        auto finish = [&](auto sk_c) {
+            constexpr int SK = decltype(sk_c)::value, PER = TM * 16 / SK;   // values per block
+            const int lo = bz * PER;
+            // ALL the ranges' values of this block are requested together (SK x PER = TM x 16 loads, one round trip), then
+            // added in range order.  Device-scope loads: served past this XCD's caches (an acquire fence per block would
+            // drop the whole L2).
+            float t[SK][PER];
+#pragma unroll
+            for (int z = 0; z < SK; z++)
+#pragma unroll
+                for (int k = 0; k < PER; k++)
+                    t[z][k] = __hip_atomic_load(p0 + (size_t)z * PT + (size_t)(lo + k) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int z = 1; z < SK; z++)
+#pragma unroll
+                for (int k = 0; k < PER; k++) t[0][k] += t[z][k];
+            if (tid == 0) {   // the last block to have read leaves the counters at zero for the next launch
+                const int prev = __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (prev == sk - 1) {
+                    __hip_atomic_store(arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const int idx = lo + k, i = idx >> 4, r = idx & 15;
+                epi_one<EPI>(a, t[0][k], n0, wn * 32 + (lane & 31), i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), true);
+            }
+        };
+        // (sk is 2, 4 or 8: x3_stream_sk; TM * 16 divides)
+        if (sk == 2) finish(std::integral_constant<int, 2>{});
+        else if (sk == 4) finish(std::integral_constant<int, 4>{});
+        else finish(std::integral_constant<int, 8>{});
+        return;
     }
     gemm_epilogue<EPI, TM, TN>(a, acc, n0, 0, 0, wn, lane);
 }
@@ -1095,9 +1196,12 @@ hipError_t launch_x3_stream(GemmArgs a, long long n_whole, const SplitKWs *ws, h
 {
     if (const hipError_t e = prepare_x3(a, ws, st, n_whole, planes_ready); e != hipSuccess) return e;
     const int sk = x3_stream_sk(n_whole, a.P, a.K), tm = (a.P + 31) / 32, ntx = (a.N + 127) / 128;
-    if (ws->part == nullptr || ws->cnt == nullptr || (size_t)ntx * sk * tm * 32 * 128 > ws->part_floats || ntx > ws->cnt_ints)
+    if (ws->part == nullptr || ws->cnt == nullptr || (size_t)ntx * sk * tm * 32 * 128 > ws->part_floats || 2 * ntx > ws->cnt_ints)
         return hipErrorOutOfMemory;
     a.sk = sk; a.sk_part = ws->part; a.sk_cnt = ws->cnt;
+    // one round of blocks (one per CU: the ring takes the LDS): the ranges of a tile share its reduction and epilogue
+    // (same sums in the same order either way: grid fill only, so a rank's own row count decides)
+    a.ntx = ntx * sk <= g_cus_hint() ? 0 : ntx;
     const void *fn;
     int nbuf;
     switch (tm) {
@@ -1109,7 +1213,7 @@ hipError_t launch_x3_stream(GemmArgs a, long long n_whole, const SplitKWs *ws, h
     const size_t lds = (size_t)nbuf * (3 * 32 * tm * 64 + 128 * 128);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     void *params[] = {&a};
-    return hipLaunchKernel(fn, dim3(ntx, 1, sk), dim3(512), params, lds, st);
+    return hipLaunchKernel(fn, dim3((unsigned)(ntx * sk)), dim3(512), params, lds, st);
 }
 
 }  // namespace
