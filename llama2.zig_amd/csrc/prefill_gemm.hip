@@ -884,10 +884,9 @@ __global__ __launch_bounds__(512) void prefill_x3_stream(const GemmArgs a)
         }
         __syncthreads();
         if (!*flag) return;
-        // range 0, then 1, ... in order; a range's TM x 16 values are requested together, two ranges in flight (device-scope
-        // loads: served past this XCD's caches)
+        // range 0, then 1, ... in order; a range's TM x 16 values are requested together (device-scope loads: served past this
+        // XCD's caches)
         const float *p0 = part + (size_t)wn * (TM * 16 * 64) + lane;
-        v16f t[2][TM];
         auto fetch = [&](int z, v16f (&d)[TM]) {
 #pragma unroll
             for (int i = 0; i < TM; i++)
@@ -895,29 +894,18 @@ __global__ __launch_bounds__(512) void prefill_x3_stream(const GemmArgs a)
                 for (int r = 0; r < 16; r++)
                     d[i][r] = __hip_atomic_load(p0 + (size_t)z * PT + (i * 16 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
-        auto add = [&](const v16f (&d)[TM]) {
+        {
+            v16f t[TM];
+            fetch(0, t);
 #pragma unroll
-            for (int i = 0; i < TM; i++)
+            for (int i = 0; i < TM; i++) acc[i][0] = t[i];
+            for (int z = 1; z < sk; z++) {   // (one round trip per range; two ranges in flight cost 64 more registers and spilled)
+                fetch(z, t);
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc[i][0][r] += d[i][r];
-        };
-        fetch(0, t[0]);
+                for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int i = 0; i < TM; i++) acc[i][0] = t[0][i];
-        fetch(1, t[0]);
-        int z = 1;
-        for (; z + 2 < sk; z += 2) {
-            fetch(z + 1, t[1]);
-            add(t[0]);
-            fetch(z + 2, t[0]);
-            add(t[1]);
-        }
-        if (z + 1 < sk) {
-            fetch(z + 1, t[1]);
-            add(t[0]);
-            add(t[1]);
-        } else {
-            add(t[0]);
+                    for (int r = 0; r < 16; r++) acc[i][0][r] += t[i][r];
+            }
         }
     } else if (sk > 1) {
         // The tile's K ranges: every block leaves its sums in the workspace (write-through), arrives, and waits for its sk - 1
