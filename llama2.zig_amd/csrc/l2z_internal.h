@@ -229,7 +229,15 @@ struct SplitKWs {
     // (prefill_gemm.hip launch_split3), [chunk tokens][3][widest padded row] bf16; reallocated with the chunk scratch
     void *x3;
     size_t x3_bytes;
+    // a second planes matrix: the gated hidden rows, written by the W1 | W3 launch's epilogue WHILE that launch reads its
+    // own planes from x3 (unsharded pass: the producers of an activation matrix write its planes beside it -- rmsnorm and the
+    // attention output into x3, the SwiGLU epilogue into x3b -- and the consumer's split launch is gone)
+    void *x3b;
+    size_t x3b_bytes;
 };
+// launch_prefill_gemm*'s planes argument: the consumer's planes are not there yet (the launcher splits x into ws->x3), stand
+// in ws->x3 (the launch before multiplied the same x, or x's producer wrote them), or stand in ws->x3b
+enum { PLANES_SPLIT = 0, PLANES_READY = 1, PLANES_READY_B = 2 };
 constexpr int kSplitKMaxTokens = 256;  // longest chunk the split-K family takes
 constexpr int kPanelWsRows = 6 * kSplitKMaxTokens;  // rows of the widest launch the partial-product workspace holds (panel kernel: ranges x 16 tms)
 // K ranges per output tile for a [P, K] x [n_whole, K]^T product (1: the unsplit family).  Part of the
@@ -247,7 +255,7 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
                                int ldw = 0,   // floats between rows of w (0: K; W1 / W3 of the device blob: 2 K)
                                long long n_launch_whole = 0,   // rows of the whole model's launch this product is a part of (q, k, v
                                                                // launched apart: dim + 2 kv_dim; 0: N * n_scale) -- the stream form's K ranges
-                               bool planes_ready = false);     // the launch before this one multiplied the same x on the bf16 cores: its planes stand
+                               int planes_ready = PLANES_SPLIT);   // PLANES_*: whether x's planes stand already, and where
 // the stream form of the planes kernel (prefill_gemm.hip): which products take it, and their K ranges
 bool x3_applies(long long n_whole, int K);
 bool x3_stream_shape(long long n_whole, int P, int K);
@@ -255,16 +263,21 @@ int x3_stream_sk(long long n_whole, int P, int K);
 hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, const float *wk, const float *wv,
                                    float *q_out, int ldq, float *kcache, float *vcache, int ldkv, int P, int nq,
                                    int nkv, int K, int pos0, const float2 *rope, int head_size, hipStream_t st,
-                                   size_t kv_head_stride = 0, int n_scale = 1, int sk = 1, const SplitKWs *ws = nullptr);
+                                   size_t kv_head_stride = 0, int n_scale = 1, int sk = 1, const SplitKWs *ws = nullptr,
+                                   int planes_ready = PLANES_SPLIT);
+// planes_out: the launch may ALSO leave the planes of its output (K' = N columns, kp_out >= N bf16 per plane row) in
+// ws->x3b; *planes_written says whether the form that ran did (the stream form does)
 hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float *w1, const float *w3,
                                            float *out, int ldo, int P, int N, int K, hipStream_t st,
-                                           int n_scale = 1, int sk = 1, const SplitKWs *ws = nullptr, int ldw = 0);
+                                           int n_scale = 1, int sk = 1, const SplitKWs *ws = nullptr, int ldw = 0,
+                                           int planes_ready = PLANES_SPLIT, int kp_out = 0, bool *planes_written = nullptr);
 hipError_t launch_prefill_gemm_kv_pair(const float *x, int ldx, const float *wk, const float *wv, float *kcache,
                                        float *vcache, int ldkv, int P, int nkv, int K, int pos0, const float2 *rope,
                                        int head_size, hipStream_t st, int n_scale = 1, size_t kv_head_stride = 0,
                                        int sk = 1, long long n_launch_whole = 0);
 hipError_t launch_prefill_rmsnorm(float *o, int ldo, const float *x, const float *w, int n, int P,
-                                  hipStream_t st);   // o: rows of ldo floats (the pad columns are left alone)
+                                  hipStream_t st,    // o: rows of ldo floats (the pad columns are left alone)
+                                  void *x3 = nullptr, int kp = 0);   // != null: o's planes of bf16 terms too (x3[token][3][kp], kp == n)
 hipError_t launch_prefill_embed(float *x, const float *tok_emb, const int *tokens, int dim, int P,
                                 hipStream_t st);
 // kv_row / kv_head: floats between timesteps of one kv head / between kv heads (AttnArgs)
@@ -272,7 +285,9 @@ hipError_t launch_prefill_attention(const float *q, int ldq, const float *kcache
                                     float *out, int ldo, int pos0, int P, int n_heads, int head_size,
                                     int kv_row, size_t kv_head, int kv_mul, int seq_len, hipStream_t st,
                                     int n_heads_model = 0,   // heads of the whole model when n_heads is a shard's
-                                    int form = 0);           // tests: 1 block per (head, query), 2 tiled, 3 flash; 0 by shape
+                                    int form = 0,            // tests: 1 block per (head, query), 2 tiled, 3 flash; 0 by shape
+                                    void *x3 = nullptr, int kp = 0,   // != null: out's planes of bf16 terms too (x3[token][3][kp]) ...
+                                    bool *planes_written = nullptr);  // ... if the form that ran writes them (the flash form does)
 // ---- prefill_panel.hip: chunks of <= 32 tokens of matrices that stream from HBM (K ranges with a resident X panel) ----
 enum PanelEpi { PANEL_STORE = 0, PANEL_RESID = 1, PANEL_SWIGLU = 2, PANEL_QKV = 3 };
 struct PanelProduct {

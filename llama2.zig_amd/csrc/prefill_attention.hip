@@ -7,8 +7,10 @@ namespace l2z {
 namespace {
 
 // rows of x -> rmsnorm rows (main.zig:432-468), one block per token
+// x3 != null: the rows' planes of bf16 terms too (x3[token][plane][kp]: what the GEMM on the bf16 matrix cores reads;
+// prefill_common.h) -- the consumer's own split launch is then not needed
 __global__ __launch_bounds__(kPfBlock) void prefill_rmsnorm(float *o, int ldo, const float *x, const float *w,
-                                                            int n, int P)
+                                                            int n, int P, __bf16 *x3, int kp)
 {
     __shared__ float red[8];
     const int t = blockIdx.x;
@@ -50,10 +52,15 @@ __global__ __launch_bounds__(kPfBlock) void prefill_rmsnorm(float *o, int ldo, c
                 r.x = (xv[k].x * s) * wv.x; r.y = (xv[k].y * s) * wv.y;
                 r.z = (xv[k].z * s) * wv.z; r.w = (xv[k].w * s) * wv.w;
                 ((v4f *)(o + (size_t)t * ldo))[i] = r;
+                if (x3) planes_store4(x3, kp, t, 4 * i, r);
             }
         }
     } else {
-        for (int i = threadIdx.x; i < n; i += blockDim.x) o[(size_t)t * ldo + i] = (xr[i] * s) * w[i];
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const float r = (xr[i] * s) * w[i];
+            o[(size_t)t * ldo + i] = r;
+            if (x3) planes_store1(x3, kp, t, i, r);
+        }
     }
 }
 
@@ -164,7 +171,7 @@ template <int NDT, int KH>
 __global__ __launch_bounds__(256 * KH) void prefill_attention_flash(const float *q, int ldq, const float *kcache,
                                                                     const float *vcache, float *out, int ldo,
                                                                     int pos0, int P, int kv_dim, size_t kv_head, int kv_mul,
-                                                                    int seq_len)
+                                                                    int seq_len, __bf16 *x3, int kp)
 {
     constexpr int HS = 16 * NDT, E = HS / 4;  // float4 slots per row
     constexpr int NWV = 4 * KH;               // waves: 4 query groups x KH parts of every key tile
@@ -307,6 +314,7 @@ __global__ __launch_bounds__(256 * KH) void prefill_attention_flash(const float 
 #pragma unroll
                 for (int c = 0; c < 4; c++) v[c] = ot[4 * DT + c][r] / lsum;  // :704
                 *(v4f *)(o + 64 * DT + 16 * g + 4 * r) = v;
+                if (x3) planes_store4(x3, kp, myq, h * HS + 64 * DT + 16 * g + 4 * r, v);   // (the Wo product's planes: see prefill_rmsnorm)
             }
     }
 }
@@ -435,9 +443,10 @@ __global__ __launch_bounds__(kPfBlock) void prefill_attention_tiled(const float 
 }  // namespace
 
 hipError_t launch_prefill_rmsnorm(float *o, int ldo, const float *x, const float *w, int n, int P,
-                                  hipStream_t st)
+                                  hipStream_t st, void *x3, int kp)
 {
-    hipLaunchKernelGGL(prefill_rmsnorm, dim3(P), dim3(kPfBlock), 0, st, o, ldo, x, w, n, P);
+    if (x3 != nullptr && (kp != n || (n & 3))) return hipErrorInvalidValue;   // (pad columns: the split launch writes their zeros)
+    hipLaunchKernelGGL(prefill_rmsnorm, dim3(P), dim3(kPfBlock), 0, st, o, ldo, x, w, n, P, (__bf16 *)x3, kp);
     return hipGetLastError();
 }
 
@@ -451,8 +460,9 @@ hipError_t launch_prefill_embed(float *x, const float *tok_emb, const int *token
 hipError_t launch_prefill_attention(const float *q, int ldq, const float *kcache, const float *vcache,
                                     float *out, int ldo, int pos0, int P, int n_heads, int head_size,
                                     int kv_dim, size_t kv_head, int kv_mul, int seq_len, hipStream_t st, int n_heads_model,
-                                    int form)
+                                    int form, void *x3, int kp, bool *planes_written)
 {
+    if (planes_written) *planes_written = false;
     // kv_dim here: floats between consecutive timesteps of one kv head (head-major cache: head_size)
     // the kernels round differently; a shard must take the one the unsharded pass takes
     // form (the test hook l2z_prefill_attention): 0 by shape, 1 block per (head, query), 2 tiled, 3 flash
@@ -482,8 +492,11 @@ hipError_t launch_prefill_attention(const float *q, int ldq, const float *kcache
             if (e != hipSuccess) return e;
         }
         const dim3 grid(n_heads, (P + 63) / 64);
+        if (x3 != nullptr && (kp & 3)) x3 = nullptr;
         void *params[] = {(void *)&q, (void *)&ldq, (void *)&kcache, (void *)&vcache, (void *)&out, (void *)&ldo,
-                          (void *)&pos0, (void *)&P, (void *)&kv_dim, (void *)&kv_head, (void *)&kv_mul, (void *)&seq_len};
+                          (void *)&pos0, (void *)&P, (void *)&kv_dim, (void *)&kv_head, (void *)&kv_mul, (void *)&seq_len,
+                          (void *)&x3, (void *)&kp};
+        if (planes_written) *planes_written = x3 != nullptr;
         return hipLaunchKernel(fn, grid, dim3(two ? 512 : 256), params, lds_f, st);
     }
     if (!naive && enough_blocks && lds_t <= 160 * 1024 && n_ct <= 8 && (head_size % 4) == 0 && (kv_dim % 4) == 0) {

@@ -61,6 +61,9 @@ struct GemmArgs {
     // (launch_split3 writes it from x just before the launch); ldx3 = 3 kp bf16 per token, kp = K rounded up to 64
     const void *x3;
     int ldx3, kp;
+    // G_SWIGLU_IL (stream form): != null: the gated values' planes too, x3_out[token][plane][kp_out] (the next launch's x3)
+    void *x3_out;
+    int kp_out;
 };
 
 
@@ -115,6 +118,51 @@ __device__ __forceinline__ Bf3 split3(const v4f lo, const v4f hi)
         o.t3[e] = p3[0]; o.t3[e + 1] = p3[1];
     }
     return o;
+}
+
+// the same terms of FOUR consecutive floats (the producers of an activation matrix write its planes beside it: rmsnorm,
+// the attention output -- an element's terms depend on that element alone, so these are the bits split3 gives)
+typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
+struct Bf3x4 { v4bf t1, t2, t3; };
+__device__ __forceinline__ Bf3x4 split3_4(const v4f x)
+{
+    Bf3x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) {
+        const v2f f = {x[e], x[e + 1]};
+        const v2bf p1 = __builtin_convertvector(f, v2bf);
+        const v2f r1 = f - __builtin_convertvector(p1, v2f);
+        const v2bf p2 = __builtin_convertvector(r1, v2bf);
+        const v2f r2 = r1 - __builtin_convertvector(p2, v2f);
+        const v2bf p3 = __builtin_convertvector(r2, v2bf);
+        o.t1[e] = p1[0]; o.t1[e + 1] = p1[1];
+        o.t2[e] = p2[0]; o.t2[e + 1] = p2[1];
+        o.t3[e] = p3[0]; o.t3[e + 1] = p3[1];
+    }
+    return o;
+}
+// ... and of one float
+__device__ __forceinline__ void split3_1(float x, __bf16 &t1, __bf16 &t2, __bf16 &t3)
+{
+    t1 = (__bf16)x;
+    const float r1 = x - (float)t1;
+    t2 = (__bf16)r1;
+    const float r2 = r1 - (float)t2;
+    t3 = (__bf16)r2;
+}
+// four consecutive elements k .. k + 3 of token `tok` into the planes matrix x3[token][plane][kp] (k % 4 == 0)
+__device__ __forceinline__ void planes_store4(__bf16 *x3, int kp, int tok, int k, const v4f v)
+{
+    const Bf3x4 t = split3_4(v);
+    __bf16 *o = x3 + (size_t)tok * 3 * kp + k;
+    *(v4bf *)o = t.t1; *(v4bf *)(o + kp) = t.t2; *(v4bf *)(o + 2 * kp) = t.t3;
+}
+__device__ __forceinline__ void planes_store1(__bf16 *x3, int kp, int tok, int k, float v)
+{
+    __bf16 a, b, c;
+    split3_1(v, a, b, c);
+    __bf16 *o = x3 + (size_t)tok * 3 * kp + k;
+    o[0] = a; o[kp] = b; o[2 * kp] = c;
 }
 
 // acc += sum over the lanes' 16 k of a b, smallest terms first (one fixed order: part of the arithmetic)

@@ -20,7 +20,11 @@
 #include "prefill_common.h"
 
 #ifndef L2Z_X3_EXP
-#define L2Z_X3_EXP 0   // experiment builds (scripts/x3_exp.sh): 1 no loads in the loop, 2 no MFMAs, 4 no X reads, 8 no W reads / splits, 16 no barrier
+#define L2Z_X3_EXP 0   // experiment builds (scripts/x3_exp.sh): 1 no loads in the loop, 2 no MFMAs, 4 no X reads, 8 no W reads / splits, 16 no barrier, 32 / 64 (stream form) no X / no W loads, 128 (stream form) W by the default cache policy
+#endif
+
+#ifndef L2Z_X3_NBUF2
+#define L2Z_X3_NBUF2 5   // ring depth of the stream form at two token tiles (experiment builds: 3, 4)
 #endif
 
 namespace l2z {
@@ -165,7 +169,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, v16f (&acc)[TM]
                     const int tok = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     const float v = acc[i][jt][r];
                     const float partner = __shfl_xor(v, 1, 64);
-                    if (!(j & 1) && tok < a.P && i * 16 + r >= lo && i * 16 + r < hi && j < a.N) a.out[(size_t)tok * a.ldo + (j >> 1)] = swiglu_merge(v, partner);  // :411-416
+                    if (!(j & 1) && tok < a.P && i * 16 + r >= lo && i * 16 + r < hi && j < a.N) {
+                        const float g = swiglu_merge(v, partner);  // :411-416
+                        a.out[(size_t)tok * a.ldo + (j >> 1)] = g;
+                        if (a.x3_out) planes_store1((__bf16 *)a.x3_out, a.kp_out, tok, j >> 1, g);   // the W2 launch's operand, already split
+                    }
                 }
             }
         return;
@@ -663,7 +671,11 @@ __device__ __forceinline__ void epi_one(const GemmArgs &a, float v, int n0, int 
         if (valid && tok < a.P && j < nseg) o[seg == 0 ? (size_t)tok * ld + j : kv_index(a, ld, a.pos0 + tok, j)] = v;  // :354-358
     } else if constexpr (EPI == G_SWIGLU_IL) {
         const int j = n0 + j_in_tile;   // row of the alternating matrix: even W1, odd W3
-        if (valid && !(j & 1) && tok < a.P && j < a.N) a.out[(size_t)tok * a.ldo + (j >> 1)] = swiglu_merge(v, partner);  // :411-416
+        if (valid && !(j & 1) && tok < a.P && j < a.N) {
+            const float g = swiglu_merge(v, partner);  // :411-416
+            a.out[(size_t)tok * a.ldo + (j >> 1)] = g;
+            if (a.x3_out) planes_store1((__bf16 *)a.x3_out, a.kp_out, tok, j >> 1, g);   // the W2 launch's operand, already split
+        }
     } else {
         const int j = n0 + j_in_tile;
         if (EPI == G_ROPE || EPI == G_ROPE_CACHE) {
@@ -701,7 +713,8 @@ __global__ __launch_bounds__(512) void prefill_x3_stream(const GemmArgs a)
 {
     constexpr int BK = 32, WN = 4, KS = 2, NW = WN * KS, BMt = 32 * TM, BNt = 32 * WN, TN = 1;
     constexpr int XLOADS = 3 * BMt * 64 / 1024;              // 1-KB loads of a stage's X planes: 16 rows of one plane each
-    constexpr int XI = (XLOADS + NW - 1) / NW, WI = BNt * 128 / 1024 / NW, NL = XI + WI;   // per wave and stage (X: the last waves repeat a load)
+    // per wave and stage (X: the last waves repeat a load); experiment builds 32 / 64: no X / no W loads at all
+    constexpr int XI = (L2Z_X3_EXP & 32) ? 0 : (XLOADS + NW - 1) / NW, WI = (L2Z_X3_EXP & 64) ? 0 : BNt * 128 / 1024 / NW, NL = XI + WI;
     constexpr int XSTG = 3 * BMt * 16, WSTG = BNt * 32, STAGE = XSTG + WSTG;                 // floats
     static_assert(NL * (NBUF - 1) <= 63, "vmcnt");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -718,8 +731,8 @@ __global__ __launch_bounds__(512) void prefill_x3_stream(const GemmArgs a)
     const int kbeg = sbeg * BK;
     auto swzx = [](int r) { return (r >> 2) & 3; };          // plane rows of 64 B: four rows fill one 256-B bank sweep
     auto swzw = [](int r) { return (r >> 1) & 7; };          // W rows of 128 B: two rows
-    const float *xsrc[XI], *wsrc[WI];
-    int xdst[XI];
+    const float *xsrc[XI > 0 ? XI : 1], *wsrc[WI > 0 ? WI : 1];
+    int xdst[XI > 0 ? XI : 1];
 #pragma unroll
     for (int j = 0; j < XI; j++) {
         const int q = min(wave * XI + j, XLOADS - 1), plane = q / (2 * TM), r = (q % (2 * TM)) * 16 + (lane >> 2), ps = lane & 3;
@@ -742,8 +755,11 @@ __global__ __launch_bounds__(512) void prefill_x3_stream(const GemmArgs a)
     auto issue_one = [&](int stage, int idx) {
         float *xs_ = smem + (stage % NBUF) * STAGE, *ws_ = xs_ + XSTG;
         const int k0 = kbeg + stage * BK;
+        // (W: non-temporal -- one CU reads a weight once per launch; a load-only walk of this mix streams 6.9 instead of
+        // 6.05 TB/s that way: scripts/lds_fill_probe.hip.  The planes: every block of a K range re-reads them from the L2.)
         if (idx < XI) lds_dma16(xsrc[idx] + k0 / 2, xs_ + xdst[idx]);
-        else lds_dma16(wsrc[idx - XI] + k0, ws_ + (wave * WI + (idx - XI)) * 256);
+        else if (L2Z_X3_EXP & 128) lds_dma16(wsrc[idx - XI] + k0, ws_ + (wave * WI + (idx - XI)) * 256);
+        else lds_dma16_nt(wsrc[idx - XI] + k0, ws_ + (wave * WI + (idx - XI)) * 256);
     };
     int arow[TM], asw[TM];
 #pragma unroll
@@ -805,8 +821,11 @@ __global__ __launch_bounds__(512) void prefill_x3_stream(const GemmArgs a)
         constexpr bool has_next = decltype(has_next_c)::value, issue = decltype(issue_c)::value;
         if constexpr (has_next) {
             wait_vmcnt<ahead * NL>();   // stage s + 1 has landed (this wave's part) and this wave's reads of stage s are done ...
-            if (!(L2Z_X3_EXP & 16))
-            __syncthreads();            // ... for every wave: stage s's buffer takes the loads of stage s + NBUF
+            // ... for every wave: stage s's buffer takes the loads of stage s + NBUF.  (The bare barrier: behind __syncthreads()
+            // the compiler drains vmcnt to 0 in the steps that issue nothing -- the tail -- and the last stages then land with
+            // nothing multiplying beside them.)
+            if (!(L2Z_X3_EXP & 16)) __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
             if (!(L2Z_X3_EXP & 8)) read_b(s + 1, blo, bhi);
         }
         Bf3 bnxt;
@@ -1167,12 +1186,18 @@ __global__ __launch_bounds__(256) void prefill_split3_kernel(const float *x, int
 }
 
 // before a launch of the planes form: a.K is the padded K; fills ws->x3 from a.x
-hipError_t prepare_x3(GemmArgs &a, const SplitKWs *ws, hipStream_t st, long long n_whole, bool planes_ready = false)
+hipError_t prepare_x3(GemmArgs &a, const SplitKWs *ws, hipStream_t st, long long n_whole, int planes_ready = PLANES_SPLIT)
 {
     if (!x3_applies(n_whole, a.K)) return hipSuccess;   // a.x3 stays null: the f32 matrix cores
     if (ws == nullptr || ws->x3 == nullptr || (size_t)a.P * 3 * a.K * sizeof(__bf16) > ws->x3_bytes) return hipErrorInvalidValue;
     a.x3 = ws->x3; a.kp = a.K; a.ldx3 = 3 * a.K;
-    if (planes_ready) return hipSuccess;   // the launch before this one split the same matrix (k and v behind q)
+    if (planes_ready == PLANES_READY_B) {   // the W1 | W3 launch's epilogue left them in the second planes matrix
+        if (ws->x3b == nullptr || (size_t)a.P * 3 * a.K * sizeof(__bf16) > ws->x3b_bytes) return hipErrorInvalidValue;
+        a.x3 = ws->x3b;
+        return hipSuccess;
+    }
+    // the launch before this one split the same matrix (k and v behind q), or x's producer wrote them (rmsnorm, attention)
+    if (planes_ready == PLANES_READY) return hipSuccess;
     const size_t n = (size_t)a.P * (a.K >> 3);
     prefill_split3_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(a.x, a.ldx, (__bf16 *)ws->x3, a.K, a.P);
     return hipGetLastError();
@@ -1180,7 +1205,7 @@ hipError_t prepare_x3(GemmArgs &a, const SplitKWs *ws, hipStream_t st, long long
 
 // launch of the stream form; a.K is the padded K, a.N this rank's rows, n_whole the whole model's (the K ranges)
 template <int EPI>
-hipError_t launch_x3_stream(GemmArgs a, long long n_whole, const SplitKWs *ws, hipStream_t st, bool planes_ready = false)
+hipError_t launch_x3_stream(GemmArgs a, long long n_whole, const SplitKWs *ws, hipStream_t st, int planes_ready = PLANES_SPLIT)
 {
     if (const hipError_t e = prepare_x3(a, ws, st, n_whole, planes_ready); e != hipSuccess) return e;
     const int sk = x3_stream_sk(n_whole, a.P, a.K), tm = (a.P + 31) / 32, ntx = (a.N + 127) / 128;
@@ -1194,7 +1219,7 @@ hipError_t launch_x3_stream(GemmArgs a, long long n_whole, const SplitKWs *ws, h
     int nbuf;
     switch (tm) {
     case 1: fn = (const void *)prefill_x3_stream<EPI, 1, 7>; nbuf = 7; break;
-    case 2: fn = (const void *)prefill_x3_stream<EPI, 2, 5>; nbuf = 5; break;
+    case 2: fn = (const void *)prefill_x3_stream<EPI, 2, L2Z_X3_NBUF2>; nbuf = L2Z_X3_NBUF2; break;
     case 3: fn = (const void *)prefill_x3_stream<EPI, 3, 4>; nbuf = 4; break;
     default: fn = (const void *)prefill_x3_stream<EPI, 4, 4>; nbuf = 4; break;
     }
@@ -1243,8 +1268,9 @@ int prefill_split_k(long long n_whole, int P, int K, bool pair)
 // hipErrorNotSupported when the shape does not take that kernel: the caller launches the two GEMMs.
 hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float *w1, const float *w3,
                                            float *out, int ldo, int P, int N, int K, hipStream_t st, int n_scale,
-                                           int sk, const SplitKWs *ws, int ldw)
+                                           int sk, const SplitKWs *ws, int ldw, int planes_ready, int kp_out, bool *planes_written)
 {
+    if (planes_written) *planes_written = false;
     if (((uintptr_t)x & 15) || ((uintptr_t)w1 & 15) || ((uintptr_t)w3 & 15)) return hipErrorInvalidValue;
     GemmArgs a = {x, w3, w1, out, out, P, N, K, ldx, ldo, ldo, 0, nullptr, 0, n_scale > 0 ? n_scale : 1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
     a.ldw = ldw > 0 ? ldw : K;
@@ -1254,12 +1280,18 @@ hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float 
         // the stream form takes W1 | W3 as ONE matrix of alternating rows (the blob's slot)
         GemmArgs b = a;
         b.w = w1; b.w2 = nullptr; b.N = 2 * N; b.K = kp; b.ldw = K;
-        return launch_x3_stream<G_SWIGLU_IL>(b, 2LL * N * a.n_scale, ws, st);
+        // the gated rows' planes beside them (the W2 launch's operand): only whole 64-k rows -- the split launch writes the
+        // zeros of pad columns -- and only where the second planes matrix exists (the unsharded pass)
+        if (kp_out == N && (N & 63) == 0 && ws != nullptr && ws->x3b != nullptr && (size_t)P * 3 * kp_out * sizeof(__bf16) <= ws->x3b_bytes) {
+            b.x3_out = ws->x3b; b.kp_out = kp_out;
+            if (planes_written) *planes_written = true;
+        }
+        return launch_x3_stream<G_SWIGLU_IL>(b, 2LL * N * a.n_scale, ws, st, planes_ready);
     }
     if (P <= skinny_max && sk <= 1) return launch_prefill_skinny_pair(G_SWIGLU, a, st);  // prefill_skinny.hip (or not supported)
     K = a.K = pad_k(K, 64, ldx);   // whole 64-k stages (see pad_k)
     if (K < 0 || ldx % 4 != 0) return hipErrorInvalidValue;
-    if (const hipError_t e = prepare_x3(a, ws, st, 2LL * N * a.n_scale); e != hipSuccess) return e;
+    if (const hipError_t e = prepare_x3(a, ws, st, 2LL * N * a.n_scale, planes_ready); e != hipSuccess) return e;
     if (sk > 1) return gemm_launch_sk<G_STORE, true>(a, N, sk, ws, st);
     {
         const KgsChoice c = choose_kgs(N, P, K, true, ws, a.x3 != nullptr);
@@ -1285,7 +1317,7 @@ hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float 
 hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, const float *wk, const float *wv,
                                    float *q_out, int ldq, float *kcache, float *vcache, int ldkv, int P, int nq,
                                    int nkv, int K, int pos0, const float2 *rope, int head_size, hipStream_t st,
-                                   size_t kv_head_stride, int n_scale, int sk, const SplitKWs *ws)
+                                   size_t kv_head_stride, int n_scale, int sk, const SplitKWs *ws, int planes_ready)
 {
     constexpr int skinny_max = Tunables::pf_skinny_max;
     if (const int kp = pad_k(K, 64, ldx); kp > 0 && x3_stream_shape((long long)(nq + 2 * nkv) * (n_scale > 0 ? n_scale : 1), P, kp)) {
@@ -1294,7 +1326,7 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
         GemmArgs b = {x, nullptr, wq, q_out, q_out, P, nq + 2 * nkv, kp, ldx, ldq, ldq, pos0, rope, head_size, n_scale > 0 ? n_scale : 1,
                       wk, wv, kcache, vcache, nq, nkv, ldkv, kv_head_stride, 0, 0};
         b.ldw = K;
-        return launch_x3_stream<G_QKV>(b, (long long)(nq + 2 * nkv) * b.n_scale, ws, st);
+        return launch_x3_stream<G_QKV>(b, (long long)(nq + 2 * nkv) * b.n_scale, ws, st, planes_ready);
     }
     if (P <= skinny_max && sk <= 1) return hipErrorNotSupported;
     if (((uintptr_t)x & 15) || ((uintptr_t)wq & 15) || ((uintptr_t)wk & 15) || ((uintptr_t)wv & 15)) return hipErrorInvalidValue;
@@ -1309,7 +1341,7 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
         GemmArgs as = {x, nullptr, wq, q_out, q_out, P, N, K, ldx, ldq, ldq, pos0, rope, head_size, n_scale > 0 ? n_scale : 1,
                        wk, wv, kcache, vcache, nq, nkv, ldkv, kv_head_stride, 0, 0};
         as.ldw = ldw_true;
-        if (const hipError_t e = prepare_x3(as, ws, st, (long long)N * as.n_scale); e != hipSuccess) return e;
+        if (const hipError_t e = prepare_x3(as, ws, st, (long long)N * as.n_scale, planes_ready); e != hipSuccess) return e;
         return gemm_launch_sk<G_QKV, false>(as, N, sk, ws, st);
     }
     {
@@ -1339,7 +1371,7 @@ hipError_t launch_prefill_gemm_qkv(const float *x, int ldx, const float *wq, con
     GemmArgs a = {x, nullptr, wq, q_out, q_out, P, N, K, ldx, ldq, ldq, pos0, rope, head_size, 1,
                   wk, wv, kcache, vcache, nq, nkv, ldkv, kv_head_stride, 0, 0};
     a.ldw = ldw_true;
-    if (const hipError_t e = prepare_x3(a, ws, st, n_qkv_whole); e != hipSuccess) return e;
+    if (const hipError_t e = prepare_x3(a, ws, st, n_qkv_whole, planes_ready); e != hipSuccess) return e;
     constexpr int KS = 2;
     const int tok = tf == TILE_128x64 ? 128 : tf == TILE_64x64 ? 64 : 32;
     const DmaForm f = tf == TILE_128x64 ? dma_form<G_QKV, 2, 1, KS, false>(a.x3 != nullptr)
@@ -1372,7 +1404,7 @@ hipError_t launch_prefill_gemm_kv_pair(const float *x, int ldx, const float *wk,
 hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w, float *out, int ldo,
                                int P, int N, int K, int pos0, const float2 *rope, int head_size,
                                hipStream_t st, const float *res, int ldres, int n_scale, size_t kv_head_stride,
-                               int sk, const SplitKWs *ws, int ldw, long long n_launch_whole, bool planes_ready)
+                               int sk, const SplitKWs *ws, int ldw, long long n_launch_whole, int planes_ready)
 {
     if (P <= 0 || N <= 0 || K <= 0 || (K % 4) != 0 || (ldx % 4) != 0) return hipErrorInvalidValue;
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return hipErrorInvalidValue;

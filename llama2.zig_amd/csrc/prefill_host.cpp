@@ -41,6 +41,7 @@ int prefill_alloc(l2z_runstate *s, int need)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     if (s->pf_tokens) { (void)hipFree(s->pf_tokens); s->pf_tokens = nullptr; }
     if (s->pf_sk.x3) { (void)hipFree(s->pf_sk.x3); s->pf_sk.x3 = nullptr; s->pf_sk.x3_bytes = 0; }
+    if (s->pf_sk.x3b) { (void)hipFree(s->pf_sk.x3b); s->pf_sk.x3b = nullptr; s->pf_sk.x3b_bytes = 0; }
     s->pf_cap = 0;
     const size_t widest = (size_t)(c.dim > c.hidden_dim ? c.dim : c.hidden_dim);
     // (scheme B reads the local attention / hidden blocks as rows of the column shards' PADDED width: a 1-rank group's
@@ -59,7 +60,9 @@ int prefill_alloc(l2z_runstate *s, int need)
         {(void **)&s->pf_part, s->sh.scheme_b ? P * c.dim * 4 : 0},
         {(void **)&s->pf_tokens, P * 4},
         // the tile GEMM on the bf16 matrix cores: one launch's activation matrix as three planes of bf16 terms
-        {(void **)&s->pf_sk.x3, P * 3 * std::max(std::max(xn_w, att_w), h1_w) * 2}};
+        {(void **)&s->pf_sk.x3, P * 3 * std::max(std::max(xn_w, att_w), h1_w) * 2},
+        // ... and the gated hidden rows' planes, written by the W1 | W3 launch while it reads its own (unsharded pass)
+        {(void **)&s->pf_sk.x3b, s->sh.world > 1 ? 0 : P * 3 * h1_w * 2}};
     for (auto &b : want) {
         if (b.bytes == 0) continue;
         hipError_t e = hipMalloc(b.p, b.bytes);
@@ -71,6 +74,7 @@ int prefill_alloc(l2z_runstate *s, int need)
     }
     s->pf_cap = (int)P;
     s->pf_sk.x3_bytes = P * 3 * std::max(std::max(xn_w, att_w), h1_w) * 2;
+    s->pf_sk.x3b_bytes = s->sh.world > 1 ? 0 : P * 3 * h1_w * 2;
     // the pad columns are never written and must be zeros: the GEMMs multiply them against whatever follows a W row
     // (scheme B: against the column shards' own zero columns)
     L2Z_HIP(hipMemsetAsync(s->pf_xn, 0, P * xn_w * 4, s->stream));
@@ -164,8 +168,25 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
         return L2Z_OK;
     };
     bool taken = false;
-    if (k == PF_ATT || k == PF_H1)   // :305 / :398
-        L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, ldxn, s->pf_x, (k == PF_ATT ? w->rms_att : w->rms_ffn) + (size_t)l * dim, dim, P, st));
+    // The unsharded pass: the PRODUCER of an activation matrix writes its planes of bf16 terms beside it where the consumer
+    // multiplies on the bf16 matrix cores (rmsnorm -> q | k | v and W1 | W3; the attention output -> Wo; the SwiGLU epilogue
+    // -> W2), so the consumer's split launch (prefill_gemm.hip prepare_x3) is not needed: four launches less per layer.
+    // The same bits as the split launch's (an element's terms depend on that element alone).  Rows whose K is not a whole
+    // number of 64-k stages keep the split launch (it writes the pad columns' zeros); a shard's operands arrive through
+    // the exchange and keep it too.  planes_for: whether a [P, K] x [n_whole, K]^T product reads planes at all.
+    auto planes_for = [&](long long n_whole, int K, int sk) {
+        const int kp = (K + 63) / 64 * 64;
+        return !sharded && tunables().pf_fuse_planes != 0 && kp == K && x3_applies(n_whole, kp) &&
+               (x3_stream_shape(n_whole, P, kp) || P > Tunables::pf_skinny_max || sk > 1) && ws->x3 != nullptr &&
+               (size_t)P * 3 * kp * 2 <= ws->x3_bytes;
+    };
+    int xn_planes = PLANES_SPLIT;
+    if (k == PF_ATT || k == PF_H1) {  // :305 / :398
+        const bool pl = k == PF_ATT ? planes_for((long long)dim + 2 * kvd_whole, dim, sk_qkv) : planes_for(2LL * hid, dim, sk_h1);
+        L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, ldxn, s->pf_x, (k == PF_ATT ? w->rms_att : w->rms_ffn) + (size_t)l * dim, dim, P, st,
+                                       pl ? ws->x3 : nullptr, dim));
+        if (pl) xn_planes = PLANES_READY;
+    }
     if (k == PF_ATT) {
         {
             PanelProduct pp = {};
@@ -183,18 +204,18 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
                     *wv = w->wv + (size_t)l * kvd * dim;
         const hipError_t qe = launch_prefill_gemm_qkv(s->pf_xn, ldxn, wq, wk, wv, s->pf_q, sh.dim_loc, kc, vc, kvd, P,
                                                       sh.dim_loc, kvd, dim, pos0, s->rope, hs, st, kvh_stride, sh.world,
-                                                      sk_qkv, ws);
+                                                      sk_qkv, ws, xn_planes);
         if (qe == hipErrorNotSupported) {
             const long long n_qkv = (long long)dim + 2 * kvd_whole;   // the whole model's q | k | v launch (the stream form's K ranges)
             L2Z_HIP(launch_prefill_gemm(PG_ROPE, s->pf_xn, ldxn, wq, s->pf_q, sh.dim_loc, P, sh.dim_loc, dim, pos0,
-                                        s->rope, hs, st, nullptr, 0, sh.world, 0, sk_qkv, ws, 0, n_qkv));  // :308-351
+                                        s->rope, hs, st, nullptr, 0, sh.world, 0, sk_qkv, ws, 0, n_qkv, xn_planes));  // :308-351
             const hipError_t ke = launch_prefill_gemm_kv_pair(s->pf_xn, ldxn, wk, wv, kc, vc, kvd, P, kvd, dim, pos0,
                                                               s->rope, hs, st, sh.world, kvh_stride, sk_qkv, n_qkv);  // short prompts: k | v together
             if (ke == hipErrorNotSupported) {
                 L2Z_HIP(launch_prefill_gemm(PG_ROPE_CACHE, s->pf_xn, ldxn, wk, kc, kvd, P, kvd, dim, pos0, s->rope, hs,
-                                            st, nullptr, 0, sh.world, kvh_stride, sk_qkv, ws, 0, n_qkv, true));   // :354-357 (q's planes stand)
+                                            st, nullptr, 0, sh.world, kvh_stride, sk_qkv, ws, 0, n_qkv, PLANES_READY));   // :354-357 (q's planes stand)
                 L2Z_HIP(launch_prefill_gemm(PG_CACHE, s->pf_xn, ldxn, wv, vc, kvd, P, kvd, dim, pos0, s->rope, hs, st,
-                                            nullptr, 0, sh.world, kvh_stride, sk_qkv, ws, 0, n_qkv, true));       // :358
+                                            nullptr, 0, sh.world, kvh_stride, sk_qkv, ws, 0, n_qkv, PLANES_READY));       // :358
             } else {
                 L2Z_HIP(ke);
             }
@@ -202,8 +223,13 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
             L2Z_HIP(qe);
         }
         }
+        // (the attention output's planes for the Wo product: nothing reads ws->x3 any more -- q | k | v are done)
+        bool att_planes = false;
+        const bool want = planes_for(dim, dim, sk_wo);
         L2Z_HIP(launch_prefill_attention(s->pf_q, sh.dim_loc, kc, vc, out, ldo, pos0, P, sh.heads_loc, hs,
-                                         hs, kvh_stride, c.n_heads / c.n_kv_heads, c.seq_len, st, c.n_heads));  // :361-389
+                                         hs, kvh_stride, c.n_heads / c.n_kv_heads, c.seq_len, st, c.n_heads, 0,
+                                         want ? ws->x3 : nullptr, dim, &att_planes));  // :361-389
+        s->pf_planes_att = att_planes ? PLANES_READY : PLANES_SPLIT;
     } else if (k == PF_WO) {
         const float *res = s->pf_x + sh.dim0;
         {
@@ -214,7 +240,9 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
         }
         if (!taken)
         L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_att, ldatt, w->wo + (size_t)l * sh.dim_loc * dim, out, ldo,
-                                    P, sh.dim_loc, dim, pos0, s->rope, hs, st, res, dim, sh.world, 0, sk_wo, ws));   // :392-395
+                                    P, sh.dim_loc, dim, pos0, s->rope, hs, st, res, dim, sh.world, 0, sk_wo, ws, 0, 0,
+                                    sharded ? PLANES_SPLIT : s->pf_planes_att));   // :392-395
+        s->pf_planes_att = PLANES_SPLIT;
     } else if (k == PF_H1) {
         // :405-416: W1 and W3 in one launch with silu(a) * b as its epilogue where the tile kernel
         // takes the shape, else two GEMMs, the second one merging into the first one's output
@@ -226,14 +254,19 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
             pp.mode = PANEL_SWIGLU; pp.out = out; pp.ldo = ldo;
             L2Z_TRY(panel(pp, 2LL * hid, &taken));
         }
+        s->pf_planes_h1 = PLANES_SPLIT;
         if (taken) return L2Z_OK;
+        bool h1_planes = false;
         const hipError_t pe = launch_prefill_gemm_swiglu_pair(s->pf_xn, ldxn, w1, w3, out, ldo, P, sh.hid_loc, dim, st, sh.world,
-                                                              sk_h1, ws, 2 * dim);
+                                                              sk_h1, ws, 2 * dim, xn_planes,
+                                                              planes_for(dim, hid, sk_w2) ? hid : 0, &h1_planes);
+        if (pe == hipSuccess && h1_planes) s->pf_planes_h1 = PLANES_READY_B;
         if (pe == hipErrorNotSupported) {
             L2Z_HIP(launch_prefill_gemm(PG_STORE, s->pf_xn, ldxn, w1, out, ldo, P, sh.hid_loc, dim, pos0, s->rope,
-                                        hs, st, nullptr, 0, sh.world, 0, sk_h1, ws, 2 * dim));                      // :405
+                                        hs, st, nullptr, 0, sh.world, 0, sk_h1, ws, 2 * dim, 0, xn_planes));                      // :405
             L2Z_HIP(launch_prefill_gemm(PG_SWIGLU, s->pf_xn, ldxn, w3, out, ldo, P, sh.hid_loc, dim, pos0, s->rope,
-                                        hs, st, nullptr, 0, sh.world, 0, sk_h1, ws, 2 * dim));  // :408 + :411-416 in the epilogue
+                                        hs, st, nullptr, 0, sh.world, 0, sk_h1, ws, 2 * dim, 0,
+                                        xn_planes));  // :408 + :411-416 in the epilogue (W1's planes stand -- or rmsnorm's)
         } else {
             L2Z_HIP(pe);
         }
@@ -247,7 +280,9 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
         }
         if (!taken)
         L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_h1, ldh1, w->w2 + (size_t)l * sh.dim_loc * hid, out, ldo,
-                                    P, sh.dim_loc, hid, pos0, s->rope, hs, st, res, dim, sh.world, 0, sk_w2, ws));   // :419-422
+                                    P, sh.dim_loc, hid, pos0, s->rope, hs, st, res, dim, sh.world, 0, sk_w2, ws, 0, 0,
+                                    sharded ? PLANES_SPLIT : s->pf_planes_h1));   // :419-422
+        s->pf_planes_h1 = PLANES_SPLIT;
     }
     return L2Z_OK;
 }

@@ -172,7 +172,7 @@ extern "C" void l2z_runstate_free(l2z_runstate *s)
     void *ptrs[] = {s->x, s->xb, s->hb, s->q, s->logits, s->key_cache, s->value_cache, s->rope,
                     s->d_token, s->d_pos, s->d_prompt, s->d_n_prompt, s->d_out_tokens, s->d_argmax,
                     s->d_probs, s->d_part_val, s->d_part_idx, s->d_attn_part, s->d_attn_cnt, s->pf_x, s->pf_xn, s->pf_q,
-                    s->pf_att, s->pf_h1, s->pf_stage, s->pf_part, s->pf_tokens, s->d_push, s->pf_sk.part, s->pf_sk.cnt, s->pf_sk.x3, s->part};
+                    s->pf_att, s->pf_h1, s->pf_stage, s->pf_part, s->pf_tokens, s->d_push, s->pf_sk.part, s->pf_sk.cnt, s->pf_sk.x3, s->pf_sk.x3b, s->part};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (s->h_stage) (void)hipHostFree(s->h_stage);

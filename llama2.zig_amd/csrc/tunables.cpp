@@ -34,6 +34,7 @@ Tunables read_env()
     env_int("L2Z_PF_PANEL_MAX", &t.pf_panel_max);
     env_int("L2Z_PF_X3", &t.pf_x3);
     env_int("L2Z_PF_X3_STREAM_MIN", &t.pf_x3_stream_min);
+    env_int("L2Z_PF_FUSE_PLANES", &t.pf_fuse_planes);
     return t;
 }
 
@@ -75,7 +76,8 @@ bool tunables_set(const char *name, long long v)
         {"L2Z_COMM_RCCL", &t.prefer_rccl}, {"L2Z_ARGMAX_XCHG", &t.argmax_xchg}, {"L2Z_P2P_CONSUME", &t.p2p_consume},
         {"L2Z_P2P_BULK_MB", &t.p2p_bulk_mb}, {"L2Z_PREFILL", &t.prefill}, {"L2Z_PF_CHUNK", &t.pf_chunk},
         {"L2Z_PF_PANEL", &t.pf_panel}, {"L2Z_PF_PANEL_MAX", &t.pf_panel_max},
-        {"L2Z_PF_X3", &t.pf_x3}, {"L2Z_PF_X3_STREAM_MIN", &t.pf_x3_stream_min}};
+        {"L2Z_PF_X3", &t.pf_x3}, {"L2Z_PF_X3_STREAM_MIN", &t.pf_x3_stream_min},
+        {"L2Z_PF_FUSE_PLANES", &t.pf_fuse_planes}};
     for (auto &e : ints)
         if (strcmp(e.n, name) == 0) {
             *e.p = (int)v;

@@ -49,6 +49,9 @@ struct Tunables {
     int pf_x3_stream_min = 49; // L2Z_PF_X3_STREAM_MIN shortest chunk that takes the STREAM form of the bf16 kernel (up to 128 tokens; below, the
                                //                     panel kernel): tests of both sides of the switch-over (7B: 48 tokens 8.7 vs 10.1 ms, 56 tokens
                                //                     10.9 vs 10.4)
+    int pf_fuse_planes = 1;    // L2Z_PF_FUSE_PLANES  0: every GEMM on the bf16 cores splits its activation matrix in a launch of its own just
+                               //                     before it (same bits; the A/B of the fused producers: rmsnorm, attention output, SwiGLU
+                               //                     epilogue -- four launches per layer)
     int pf_panel_max = -1;     // L2Z_PF_PANEL_MAX    longest chunk that takes the panel kernel (default and maximum 96 tokens): tests of both sides
                                //                     of the switch-over
 

@@ -75,3 +75,25 @@ def test_split_terms_recompose_exactly():
     x3 = bf16(r2)
     assert np.array_equal((x1.astype(np.float64) + x2 + x3), x.astype(np.float64))
     assert np.array_equal(r2 - x3, np.zeros_like(x))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [56, 100, 128, 300])
+def test_planes_written_by_the_producers_equal_the_split_launch(gpu, ck, options, n):
+    """The unsharded pass writes an activation matrix's planes of bf16 terms in the kernel that PRODUCES the matrix
+    (rmsnorm, the attention output, the SwiGLU epilogue of the stream form; prefill_host.cpp planes_for) instead of a split
+    launch before every GEMM: an element's three terms depend on that element alone, so logits, the KV cache and the
+    activations must come out BIT-identical with L2Z_PF_FUSE_PLANES=0 (every consumer splits for itself).  Stream form at
+    two / four token tiles and the tile forms; a model wide enough that every product takes the bf16 cores."""
+    cfg = ck.Config(dim=2048, hidden_dim=5632, n_layers=2, n_heads=16, n_kv_heads=16, vocab_size=4096, seq_len=320)
+    w = gpu.Weights(cfg, None, False, seed=5)
+    toks = [1] + np.random.default_rng(2).integers(2, cfg.vocab_size, n - 1).tolist()
+    got = {}
+    for fuse in (0, 1):
+        options(L2Z_PF_FUSE_PLANES=fuse)
+        s = gpu.RunState(cfg)
+        s.prefill(toks, 0, w)
+        S, kvd, L = cfg.seq_len, cfg.kv_dim, cfg.n_layers - 1   # (the last layer's rows: every launch of every layer before feeds them)
+        got[fuse] = (s.logits().copy(), s.read("key_cache", L * S * kvd, n * kvd), s.read("value_cache", L * S * kvd, n * kvd))
+    for a, b, what in zip(got[0], got[1], ("logits", "key cache", "value cache")):
+        assert np.array_equal(a, b), f"{n} tokens: {what} differ between fused and split planes (max |diff| {np.abs(a - b).max():.3e})"
