@@ -43,15 +43,23 @@ bool x3_stream_shape(long long n_whole, int P, int K)
     const Tunables &t = tunables();
     return x3_applies(n_whole, K) && P >= t.pf_x3_stream_min && P <= 128 && K >= 256;
 }
+// Features per block of the stream form: chunks of <= 64 tokens (one / two token tiles: <= 128 registers per lane) run SIXTEEN
+// waves -- 8 feature groups x 2 k-groups, 256 features -- the longer ones eight (128 features).  A block's stage time is set
+// by its waves' instruction streams (a dependent chain of six MFMAs per token tile, the direct-to-LDS requests, the W split),
+// not by the memory system: at two token tiles 1800 cycles per stage whether 32 or 256 blocks run (profiles/r06s); four
+// waves per SIMD instead of two cover each other, and the planes cross the chip once per 256 features instead of once per 128.
+int x3_stream_tile(int P) { return P <= 64 ? 256 : 128; }
 int x3_stream_sk(long long n_whole, int P, int K)
 {
     // One block per CU (the ring takes the LDS), blocks of a launch equally long: the launch lasts
     // ceil(tiles sk / CUs) rounds of ceil(stages / sk) stages, plus a fixed cost per round (pipeline fill, the partial sums'
     // hand-over: ~10 stages' worth).  The CU count is the part the rule was made for (MI355X: 256), as a constant -- the
     // ranges are part of the arithmetic and must not depend on the device a rank happens to run on.
-    (void)P;
+#ifdef L2Z_X3_SK_FORCE
+    { int f = L2Z_X3_SK_FORCE; while (f > 1 && K / 32 / f < 8) f >>= 1; (void)n_whole; return f; }   // experiment builds
+#endif
     constexpr long long kCus = 256;
-    const long long tiles = (n_whole + 127) / 128, stages = K / 32;
+    const long long tile = x3_stream_tile(P), tiles = (n_whole + tile - 1) / tile, stages = K / 32;
     int best = 1;
     long long best_cost = 0;
     for (int sk = 1; sk <= 8; sk *= 2) {   // (1, 2, 4, 8: the ranges share the tile's epilogue in equal parts)
@@ -708,17 +716,17 @@ template <int N_> __device__ __forceinline__ void wait_vmcnt()
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N_) : "memory");
 }
 
-template <int EPI, int TM, int NBUF>
-__global__ __launch_bounds__(512) void prefill_x3_stream(const GemmArgs a)
+template <int EPI, int TM, int NBUF, int WN>
+__global__ __launch_bounds__(128 * WN) void prefill_x3_stream(const GemmArgs a)
 {
-    constexpr int BK = 32, WN = 4, KS = 2, NW = WN * KS, BMt = 32 * TM, BNt = 32 * WN, TN = 1;
+    constexpr int BK = 32, KS = 2, NW = WN * KS, BMt = 32 * TM, BNt = 32 * WN, TN = 1;
     constexpr int XLOADS = 3 * BMt * 64 / 1024;              // 1-KB loads of a stage's X planes: 16 rows of one plane each
     // per wave and stage (X: the last waves repeat a load); experiment builds 32 / 64: no X / no W loads at all
     constexpr int XI = (L2Z_X3_EXP & 32) ? 0 : (XLOADS + NW - 1) / NW, WI = (L2Z_X3_EXP & 64) ? 0 : BNt * 128 / 1024 / NW, NL = XI + WI;
     constexpr int XSTG = 3 * BMt * 16, WSTG = BNt * 32, STAGE = XSTG + WSTG;                 // floats
     static_assert(NL * (NBUF - 1) <= 63, "vmcnt");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave & 3, kg = wave >> 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave % WN, kg = wave / WN;
     const int hl = lane >> 5, il = lane & 31;
     // block -> (tile, range): the ranges of a tile are CONSECUTIVE block ids -- dispatched together, finishing together,
     // so that they can share the tile's reduction and epilogue (below) without anybody waiting for a block not yet resident
@@ -1208,8 +1216,15 @@ template <int EPI>
 hipError_t launch_x3_stream(GemmArgs a, long long n_whole, const SplitKWs *ws, hipStream_t st, int planes_ready = PLANES_SPLIT)
 {
     if (const hipError_t e = prepare_x3(a, ws, st, n_whole, planes_ready); e != hipSuccess) return e;
-    const int sk = x3_stream_sk(n_whole, a.P, a.K), tm = (a.P + 31) / 32, ntx = (a.N + 127) / 128;
-    if (ws->part == nullptr || ws->cnt == nullptr || (size_t)ntx * sk * tm * 32 * 128 > ws->part_floats || 2 * ntx > ws->cnt_ints)
+    // the 16-wave form where its 256-feature tiles fit the launch (q | k | v: no tile across two of the matrices); the K ranges
+    // -- the arithmetic -- are x3_stream_sk's either way
+    const int sk = x3_stream_sk(n_whole, a.P, a.K), tm = (a.P + 31) / 32;
+    // ... and where they are more than half a round of blocks: wo and W2 of the 7B shape (16 such tiles x 8 ranges) keep 256
+    // blocks of eight waves (W2 68 against 87 us: a 16-wave block streams no faster than an 8-wave one, profiles/r06s)
+    const bool fat = x3_stream_tile(a.P) == 256 && tm <= 2 && (EPI != G_QKV || (a.nq % 256 == 0 && a.nkv % 256 == 0)) &&
+                     (long long)((a.N + 255) / 256) * sk > g_cus_hint() / 2;
+    const int feat = fat ? 256 : 128, ntx = (a.N + feat - 1) / feat;
+    if (ws->part == nullptr || ws->cnt == nullptr || (size_t)ntx * sk * tm * 32 * feat > ws->part_floats || 2 * ntx > ws->cnt_ints)
         return hipErrorOutOfMemory;
     a.sk = sk; a.sk_part = ws->part; a.sk_cnt = ws->cnt;
     // one round of blocks (one per CU: the ring takes the LDS): the ranges of a tile share its reduction and epilogue
@@ -1217,16 +1232,21 @@ hipError_t launch_x3_stream(GemmArgs a, long long n_whole, const SplitKWs *ws, h
     a.ntx = ntx * sk <= g_cus_hint() ? 0 : ntx;
     const void *fn;
     int nbuf;
-    switch (tm) {
-    case 1: fn = (const void *)prefill_x3_stream<EPI, 1, 7>; nbuf = 7; break;
-    case 2: fn = (const void *)prefill_x3_stream<EPI, 2, L2Z_X3_NBUF2>; nbuf = L2Z_X3_NBUF2; break;
-    case 3: fn = (const void *)prefill_x3_stream<EPI, 3, 4>; nbuf = 4; break;
-    default: fn = (const void *)prefill_x3_stream<EPI, 4, 4>; nbuf = 4; break;
+    if (fat) {
+        if (tm == 1) { fn = (const void *)prefill_x3_stream<EPI, 1, 4, 8>; nbuf = 4; }
+        else { fn = (const void *)prefill_x3_stream<EPI, 2, 3, 8>; nbuf = 3; }
+    } else {
+        switch (tm) {
+        case 1: fn = (const void *)prefill_x3_stream<EPI, 1, 7, 4>; nbuf = 7; break;
+        case 2: fn = (const void *)prefill_x3_stream<EPI, 2, L2Z_X3_NBUF2, 4>; nbuf = L2Z_X3_NBUF2; break;
+        case 3: fn = (const void *)prefill_x3_stream<EPI, 3, 4, 4>; nbuf = 4; break;
+        default: fn = (const void *)prefill_x3_stream<EPI, 4, 4, 4>; nbuf = 4; break;
+        }
     }
-    const size_t lds = (size_t)nbuf * (3 * 32 * tm * 64 + 128 * 128);
+    const size_t lds = (size_t)nbuf * (3 * 32 * tm * 64 + feat * 128);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     void *params[] = {&a};
-    return hipLaunchKernel(fn, dim3((unsigned)(ntx * sk)), dim3(512), params, lds, st);
+    return hipLaunchKernel(fn, dim3((unsigned)(ntx * sk)), dim3(fat ? 1024 : 512), params, lds, st);
 }
 
 }  // namespace

@@ -138,7 +138,8 @@ int main()
         run(fill<2, 8>, "shared 3 MB  to registers, 8 ahead", grid, (size_t)3 << 20, pc, 1, 8);
     }
     // every block streams its own 8 MB (2 GB in all at 256 blocks): HBM
-    for (int grid : {256}) {
+    for (int grid : {256, 192, 128, 64, 16}) {
+        run(fill<0, 2>, "own 8 MB  direct-to-LDS, 2 ahead", grid, (size_t)8 << 20, pc, 0, 2);
         run(fill<0, 4>, "own 8 MB  direct-to-LDS, 4 ahead", grid, (size_t)8 << 20, pc, 0, 4);
         run(fill<0, 8>, "own 8 MB  direct-to-LDS, 8 ahead", grid, (size_t)8 << 20, pc, 0, 8);
         run(fill<1, 8>, "own 8 MB  direct-to-LDS nt, 8 ahead", grid, (size_t)8 << 20, pc, 0, 8);
