@@ -140,16 +140,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, v16f (&acc)[TM]
 {
     // [lo, hi): the values i * 16 + r this call finishes (the stream form's ranges share a tile's epilogue; default all)
     if constexpr (EPI == G_QKV) {
-        // a block's columns lie in ONE of the three ranges (launcher: nq and nkv are multiples of the tile)
-        const int seg = n0 >= a.nq + a.nkv ? 2 : n0 >= a.nq ? 1 : 0;
-        const int f0 = n0 - (seg == 2 ? a.nq + a.nkv : seg == 1 ? a.nq : 0), nseg = seg == 0 ? a.nq : a.nkv;
-        float *o = seg == 0 ? a.out : seg == 1 ? a.outk : a.outv;
-        const int ld = seg == 0 ? a.ldo : a.ldkv;
+        // a wave's 32 columns lie in ONE of the three ranges (launchers: nq and nkv are multiples of 32; a block's tile may
+        // lie across two of them -- the stream form's 192-feature tiles)
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
             for (int jt = 0; jt < TN; jt++) {
-                const int j = f0 + (wn * TN + jt) * 32 + (lane & 31);
+                const int nb = n0 + (wn * TN + jt) * 32;
+                const int seg = nb >= a.nq + a.nkv ? 2 : nb >= a.nq ? 1 : 0;
+                const int f0 = nb - (seg == 2 ? a.nq + a.nkv : seg == 1 ? a.nq : 0), nseg = seg == 0 ? a.nq : a.nkv;
+                float *o = seg == 0 ? a.out : seg == 1 ? a.outk : a.outv;
+                const int ld = seg == 0 ? a.ldo : a.ldkv;
+                const int j = f0 + (lane & 31);
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int tok = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -667,10 +669,11 @@ __device__ __forceinline__ void epi_one(const GemmArgs &a, float v, int n0, int 
 {
     const float partner = __shfl_xor(v, 1, 64);
     if constexpr (EPI == G_QKV) {
-        const int seg = n0 >= a.nq + a.nkv ? 2 : n0 >= a.nq ? 1 : 0;
-        const int f0 = n0 - (seg == 2 ? a.nq + a.nkv : seg == 1 ? a.nq : 0), nseg = seg == 0 ? a.nq : a.nkv;
+        const int nb = n0 + (j_in_tile & ~31);   // the wave's 32 columns: one of the three ranges (see gemm_epilogue)
+        const int seg = nb >= a.nq + a.nkv ? 2 : nb >= a.nq ? 1 : 0;
+        const int f0 = nb - (seg == 2 ? a.nq + a.nkv : seg == 1 ? a.nq : 0), nseg = seg == 0 ? a.nq : a.nkv;
         float *o = seg == 0 ? a.out : seg == 1 ? a.outk : a.outv;
-        const int ld = seg == 0 ? a.ldo : a.ldkv, j = f0 + j_in_tile;
+        const int ld = seg == 0 ? a.ldo : a.ldkv, j = f0 + (j_in_tile & 31);
         if (seg < 2) {
             const int hs = a.head_size, pos = a.pos0 + (tok < a.P ? tok : 0);
             const float2 cs = a.rope[(size_t)pos * (size_t)(hs >> 1) + (size_t)(((j < nseg ? j : 0) % hs) >> 1)];
@@ -753,7 +756,7 @@ __global__ __launch_bounds__(128 * WN) void prefill_x3_stream(const GemmArgs a)
         const float *m = a.w;
         int f = n0 + r, nseg = a.N;
         if constexpr (EPI == G_QKV) {
-            const int seg = n0 >= a.nq + a.nkv ? 2 : n0 >= a.nq ? 1 : 0;
+            const int seg = f >= a.nq + a.nkv ? 2 : f >= a.nq ? 1 : 0;   // (per row: a tile may lie across two of the matrices)
             m = seg == 0 ? a.w : seg == 1 ? a.wk : a.wv;
             f -= seg == 2 ? a.nq + a.nkv : seg == 1 ? a.nq : 0;
             nseg = seg == 0 ? a.nq : a.nkv;
@@ -1216,25 +1219,33 @@ template <int EPI>
 hipError_t launch_x3_stream(GemmArgs a, long long n_whole, const SplitKWs *ws, hipStream_t st, int planes_ready = PLANES_SPLIT)
 {
     if (const hipError_t e = prepare_x3(a, ws, st, n_whole, planes_ready); e != hipSuccess) return e;
-    // the 16-wave form where its 256-feature tiles fit the launch (q | k | v: no tile across two of the matrices); the K ranges
-    // -- the arithmetic -- are x3_stream_sk's either way
-    const int sk = x3_stream_sk(n_whole, a.P, a.K), tm = (a.P + 31) / 32;
-    // ... and where they are more than half a round of blocks: wo and W2 of the 7B shape (16 such tiles x 8 ranges) keep 256
-    // blocks of eight waves (W2 68 against 87 us: a 16-wave block streams no faster than an 8-wave one, profiles/r06s)
-    const bool fat = x3_stream_tile(a.P) == 256 && tm <= 2 && (EPI != G_QKV || (a.nq % 256 == 0 && a.nkv % 256 == 0)) &&
-                     (long long)((a.N + 255) / 256) * sk > g_cus_hint() / 2;
-    const int feat = fat ? 256 : 128, ntx = (a.N + feat - 1) / feat;
+    // Features per block (grid fill only: the K ranges -- the arithmetic -- are x3_stream_sk's whatever the tile).  Chunks of
+    // <= 64 tokens may run 192 features on twelve waves or 256 on sixteen instead of 128 on eight: a block streams its W at
+    // ~20 GB/s whatever its width (profiles/r06s), so the launch wants as many blocks as fit ONE round -- the narrowest tile
+    // that does -- and the wider tiles send the planes through the L2 less often.  (q | k | v: a tile may lie across two of the matrices; a wave's 32 features never do.)  7B shape: q | k | v 192 features (256 blocks of 4 ranges), W1 | W3 192 (230 blocks of 2
+    // ranges: 85 us against 105 with 172 blocks of 256 features), wo / W2 128 (256 blocks of 8 ranges).
+    const int sk = x3_stream_sk(n_whole, a.P, a.K), tm = (a.P + 31) / 32, cus = g_cus_hint();
+    int feat = 128;
+    if (x3_stream_tile(a.P) == 256 && tm <= 2 && (long long)((a.N + 127) / 128) * sk > cus) {
+        // the NARROWEST tile whose blocks fit one round (the most blocks: the least W per block)
+        for (int f : {192, 256})
+            if ((long long)((a.N + f - 1) / f) * sk <= cus) { feat = f; break; }
+    }
+    const int ntx = (a.N + feat - 1) / feat;
     if (ws->part == nullptr || ws->cnt == nullptr || (size_t)ntx * sk * tm * 32 * feat > ws->part_floats || 2 * ntx > ws->cnt_ints)
         return hipErrorOutOfMemory;
     a.sk = sk; a.sk_part = ws->part; a.sk_cnt = ws->cnt;
     // one round of blocks (one per CU: the ring takes the LDS): the ranges of a tile share its reduction and epilogue
     // (same sums in the same order either way: grid fill only, so a rank's own row count decides)
-    a.ntx = ntx * sk <= g_cus_hint() ? 0 : ntx;
+    a.ntx = ntx * sk <= cus ? 0 : ntx;
     const void *fn;
     int nbuf;
-    if (fat) {
+    if (feat == 256) {
         if (tm == 1) { fn = (const void *)prefill_x3_stream<EPI, 1, 4, 8>; nbuf = 4; }
         else { fn = (const void *)prefill_x3_stream<EPI, 2, 3, 8>; nbuf = 3; }
+    } else if (feat == 192) {
+        if (tm == 1) { fn = (const void *)prefill_x3_stream<EPI, 1, 5, 6>; nbuf = 5; }
+        else { fn = (const void *)prefill_x3_stream<EPI, 2, 4, 6>; nbuf = 4; }
     } else {
         switch (tm) {
         case 1: fn = (const void *)prefill_x3_stream<EPI, 1, 7, 4>; nbuf = 7; break;
@@ -1246,7 +1257,7 @@ hipError_t launch_x3_stream(GemmArgs a, long long n_whole, const SplitKWs *ws, h
     const size_t lds = (size_t)nbuf * (3 * 32 * tm * 64 + feat * 128);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     void *params[] = {&a};
-    return hipLaunchKernel(fn, dim3((unsigned)(ntx * sk)), dim3(fat ? 1024 : 512), params, lds, st);
+    return hipLaunchKernel(fn, dim3((unsigned)(ntx * sk)), dim3((unsigned)(feat * 4)), params, lds, st);
 }
 
 }  // namespace
