@@ -52,8 +52,9 @@ int x3_stream_tile(int P) { return P <= 64 ? 256 : 128; }
 int x3_stream_sk(long long n_whole, int P, int K)
 {
     // One block per CU (the ring takes the LDS), blocks of a launch equally long: the launch lasts
-    // ceil(tiles sk / CUs) rounds of ceil(stages / sk) stages, plus a fixed cost per round (pipeline fill, the partial sums'
-    // hand-over: ~10 stages' worth).  The CU count is the part the rule was made for (MI355X: 256), as a constant -- the
+    // ceil(tiles sk / CUs) rounds of ceil(stages / sk) stages, plus a fixed cost per round (launch, pipeline fill, the partial
+    // sums' hand-over: ~15 us = 20 stages' worth; every product of the 7B shape with every range count, 64 and 128 tokens:
+    // profiles/r06r_stream_sk_scan.txt -- with 10, W1 | W3 took 4 ranges in 2.7 rounds: 164 against 154 us unsplit at 128 tokens).  The CU count is the part the rule was made for (MI355X: 256), as a constant -- the
     // ranges are part of the arithmetic and must not depend on the device a rank happens to run on.
 #ifdef L2Z_X3_SK_FORCE
     { int f = L2Z_X3_SK_FORCE; while (f > 1 && K / 32 / f < 8) f >>= 1; (void)n_whole; return f; }   // experiment builds
@@ -65,7 +66,7 @@ int x3_stream_sk(long long n_whole, int P, int K)
     for (int sk = 1; sk <= 8; sk *= 2) {   // (1, 2, 4, 8: the ranges share the tile's epilogue in equal parts)
         if (stages / sk < 8) break;
         const long long rounds = (tiles * sk + kCus - 1) / kCus;
-        const long long cost = rounds * ((stages + sk - 1) / sk + 10);
+        const long long cost = rounds * ((stages + sk - 1) / sk + 20);
         if (sk == 1 || cost < best_cost) { best = sk; best_cost = cost; }
     }
     return best;
@@ -133,88 +134,100 @@ static dim3 dma_grid(int ntx, int nty, GemmArgs *a)
     return dim3((unsigned)((ntx + 7) / 8 * 8 * nty), 1, z);
 }
 
-// epilogue shared by the two tile kernels: per MFMA tile a lane owns one feature and 16 tokens
+// The epilogue of NV values of ONE lane: feature nb + (lane & 31) (nb: the first of the wave's 32 features in the launch), tokens
+// tok[k], stored where on[k].  Everything that depends on the feature alone -- the q | k | v range, the head, the RoPE pair,
+// the output column -- is worked out once, the RoPE factors / residuals of all NV values are requested together, then the values
+// are finished and stored.  (Until round 6 every value did its own two integer divisions and its own dependent table load
+// behind the previous value's store: 16.5 us for the 32 values per lane of the 7B q | k | v launch at 128 tokens.)
+// Every lane of the wave calls it together (the RoPE / SwiGLU partner is the adjacent lane's value of the same index).
+template <int EPI, int NV>
+__device__ __forceinline__ void epi_values(const GemmArgs &a, float (&v)[NV], const int (&tok)[NV], const bool (&on)[NV], int nb, int lane)
+{
+    int j = nb + (lane & 31), nseg = a.N, seg = 0, ld = a.ldo;
+    float *o = a.out;
+    if constexpr (EPI == G_QKV) {
+        // a wave's 32 columns lie in ONE of the three ranges (launchers: nq and nkv are multiples of 32; a block's tile may
+        // lie across two of them -- the stream form's 192-feature tiles)
+        seg = nb >= a.nq + a.nkv ? 2 : nb >= a.nq ? 1 : 0;
+        j -= seg == 2 ? a.nq + a.nkv : seg == 1 ? a.nq : 0;
+        nseg = seg == 0 ? a.nq : a.nkv;
+        o = seg == 0 ? a.out : seg == 1 ? a.outk : a.outv;
+        ld = seg == 0 ? a.ldo : a.ldkv;
+    }
+    const bool inr = j < nseg;
+    if constexpr (EPI == G_SWIGLU_IL) {
+        // row j of the alternating matrix: even W1, odd W3; out[token][j / 2] = silu(a) * b (main.zig:411-416)
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            const float partner = __shfl_xor(v[k], 1, 64);
+            if (on[k] && !(j & 1) && inr) {
+                const float g = swiglu_merge(v[k], partner);
+                a.out[(size_t)tok[k] * a.ldo + (j >> 1)] = g;
+                if (a.x3_out) planes_store1((__bf16 *)a.x3_out, a.kp_out, tok[k], j >> 1, g);   // the W2 launch's operand, already split
+            }
+        }
+        return;
+    }
+    constexpr bool kRope = EPI == G_ROPE || EPI == G_ROPE_CACHE || EPI == G_QKV;
+    const bool rope = EPI == G_QKV ? seg < 2 : kRope;                                         // (wave-uniform)
+    const bool cache = EPI == G_QKV ? seg > 0 : (EPI == G_ROPE_CACHE || EPI == G_CACHE);
+    const int hs = a.head_size, jj = inr ? j : 0;
+    if constexpr (kRope) {
+        if (rope) {   // the pair (j, j + 1) sits in adjacent lanes (main.zig:346-349)
+            const float2 *rp = a.rope + ((jj % hs) >> 1);
+            float2 cs[NV];
+#pragma unroll
+            for (int k = 0; k < NV; k++) cs[k] = rp[(size_t)(a.pos0 + (tok[k] < a.P ? tok[k] : 0)) * (size_t)(hs >> 1)];
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+                const float partner = __shfl_xor(v[k], 1, 64);
+                v[k] = (j & 1) ? partner * cs[k].y + v[k] * cs[k].x    // v0*fci + v1*fcr
+                               : v[k] * cs[k].x - partner * cs[k].y;   // v0*fcr - v1*fci
+            }
+        }
+    }
+    if constexpr (EPI == G_RESID) {   // main.zig:711 (in place too: a lane reads the addresses it writes, nobody else's)
+        float rs[NV];
+#pragma unroll
+        for (int k = 0; k < NV; k++) rs[k] = on[k] && inr ? a.res[(size_t)tok[k] * a.ldres + j] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < NV; k++) v[k] = rs[k] + v[k];
+    }
+    if constexpr (EPI == G_SWIGLU) {
+        float h[NV];
+#pragma unroll
+        for (int k = 0; k < NV; k++) h[k] = on[k] && inr ? a.out[(size_t)tok[k] * a.ldo + j] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < NV; k++) v[k] = swiglu_merge(h[k], v[k]);
+    }
+    // (token, feature j) -> base + row * pitch: rows of ld floats, or a head-major cache's rows of head_size (kv_index; :354-358)
+    size_t base = (size_t)j, pitch = (size_t)ld;
+    if (cache && a.kv_head_stride) { base = (size_t)(jj / hs) * a.kv_head_stride + (size_t)(jj % hs); pitch = (size_t)hs; }
+#pragma unroll
+    for (int k = 0; k < NV; k++)
+        if (on[k] && inr) o[base + (size_t)(cache ? a.pos0 + tok[k] : tok[k]) * pitch] = v[k];
+}
+
+// epilogue shared by the tile kernels: per MFMA tile a lane owns one feature and 16 tokens
 template <int EPI, int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, v16f (&acc)[TM][TN], int n0, int m0, int wm,
                                               int wn, int lane, int lo = 0, int hi = 1 << 30)
 {
     // [lo, hi): the values i * 16 + r this call finishes (the stream form's ranges share a tile's epilogue; default all)
-    if constexpr (EPI == G_QKV) {
-        // a wave's 32 columns lie in ONE of the three ranges (launchers: nq and nkv are multiples of 32; a block's tile may
-        // lie across two of them -- the stream form's 192-feature tiles)
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int jt = 0; jt < TN; jt++) {
-                const int nb = n0 + (wn * TN + jt) * 32;
-                const int seg = nb >= a.nq + a.nkv ? 2 : nb >= a.nq ? 1 : 0;
-                const int f0 = nb - (seg == 2 ? a.nq + a.nkv : seg == 1 ? a.nq : 0), nseg = seg == 0 ? a.nq : a.nkv;
-                float *o = seg == 0 ? a.out : seg == 1 ? a.outk : a.outv;
-                const int ld = seg == 0 ? a.ldo : a.ldkv;
-                const int j = f0 + (lane & 31);
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int tok = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    float v = acc[i][jt][r];
-                    const float partner = __shfl_xor(v, 1, 64);  // as G_ROPE below (main.zig:346-349)
-                    if (seg < 2) {
-                        const int hs = a.head_size;
-                        const int pos = a.pos0 + (tok < a.P ? tok : 0);
-                        const float2 cs = a.rope[(size_t)pos * (size_t)(hs >> 1) + (size_t)(((j < nseg ? j : 0) % hs) >> 1)];
-                        v = (j & 1) ? partner * cs.y + v * cs.x : v * cs.x - partner * cs.y;
-                    }
-                    if (tok < a.P && i * 16 + r >= lo && i * 16 + r < hi && j < nseg) o[seg == 0 ? (size_t)tok * ld + j : kv_index(a, ld, a.pos0 + tok, j)] = v;  // :354-358
-                }
-            }
-        return;
-    }
-    if constexpr (EPI == G_SWIGLU_IL) {
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int jt = 0; jt < TN; jt++) {
-                const int j = n0 + (wn * TN + jt) * 32 + (lane & 31);   // row of the alternating matrix: even W1, odd W3
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int tok = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const float v = acc[i][jt][r];
-                    const float partner = __shfl_xor(v, 1, 64);
-                    if (!(j & 1) && tok < a.P && i * 16 + r >= lo && i * 16 + r < hi && j < a.N) {
-                        const float g = swiglu_merge(v, partner);  // :411-416
-                        a.out[(size_t)tok * a.ldo + (j >> 1)] = g;
-                        if (a.x3_out) planes_store1((__bf16 *)a.x3_out, a.kp_out, tok, j >> 1, g);   // the W2 launch's operand, already split
-                    }
-                }
-            }
-        return;
-    }
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
         for (int jt = 0; jt < TN; jt++) {
-            const int j = n0 + (wn * TN + jt) * 32 + (lane & 31);
+            float v[16];
+            int tok[16];
+            bool on[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int tok = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float v = acc[i][jt][r];
-                if (EPI == G_ROPE || EPI == G_ROPE_CACHE) {
-                    // RoPE pair (j, j+1) sits in adjacent lanes (main.zig:346-349)
-                    const float partner = __shfl_xor(v, 1, 64);
-                    const int hs = a.head_size;
-                    const int pos = a.pos0 + (tok < a.P ? tok : 0);
-                    const float2 cs = a.rope[(size_t)pos * (size_t)(hs >> 1) +
-                                             (size_t)(((j < a.N ? j : 0) % hs) >> 1)];
-                    v = (j & 1) ? partner * cs.y + v * cs.x    // v0*fci + v1*fcr
-                                : v * cs.x - partner * cs.y;   // v0*fcr - v1*fci
-                }
-                if (tok < a.P && i * 16 + r >= lo && i * 16 + r < hi && j < a.N) {
-                    if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + j] = v;
-                    else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + j] = a.res[(size_t)tok * a.ldres + j] + v;  // main.zig:711
-                    else if (EPI == G_SWIGLU)
-                        a.out[(size_t)tok * a.ldo + j] = swiglu_merge(a.out[(size_t)tok * a.ldo + j], v);
-                    else a.out[kv_index(a, a.ldo, a.pos0 + tok, j)] = v;                  // main.zig:354-358
-                }
+                v[r] = acc[i][jt][r];
+                tok[r] = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                on[r] = tok[r] < a.P && i * 16 + r >= lo && i * 16 + r < hi;
             }
+            epi_values<EPI, 16>(a, v, tok, on, n0 + (wn * TN + jt) * 32, lane);
         }
 }
 
@@ -661,47 +674,6 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
     }
 }
 
-// The epilogue of ONE value (the stream form's shared reduction finishes values by their flat index, not by register):
-// feature j of the launch (lane & 31 within the wave's 32), token tok; every lane of the wave calls it together (the RoPE /
-// SwiGLU partner is the adjacent lane's value of the same index).  Same arithmetic as gemm_epilogue.
-template <int EPI>
-__device__ __forceinline__ void epi_one(const GemmArgs &a, float v, int n0, int j_in_tile, int tok, bool valid)
-{
-    const float partner = __shfl_xor(v, 1, 64);
-    if constexpr (EPI == G_QKV) {
-        const int nb = n0 + (j_in_tile & ~31);   // the wave's 32 columns: one of the three ranges (see gemm_epilogue)
-        const int seg = nb >= a.nq + a.nkv ? 2 : nb >= a.nq ? 1 : 0;
-        const int f0 = nb - (seg == 2 ? a.nq + a.nkv : seg == 1 ? a.nq : 0), nseg = seg == 0 ? a.nq : a.nkv;
-        float *o = seg == 0 ? a.out : seg == 1 ? a.outk : a.outv;
-        const int ld = seg == 0 ? a.ldo : a.ldkv, j = f0 + (j_in_tile & 31);
-        if (seg < 2) {
-            const int hs = a.head_size, pos = a.pos0 + (tok < a.P ? tok : 0);
-            const float2 cs = a.rope[(size_t)pos * (size_t)(hs >> 1) + (size_t)(((j < nseg ? j : 0) % hs) >> 1)];
-            v = (j & 1) ? partner * cs.y + v * cs.x : v * cs.x - partner * cs.y;   // main.zig:346-349
-        }
-        if (valid && tok < a.P && j < nseg) o[seg == 0 ? (size_t)tok * ld + j : kv_index(a, ld, a.pos0 + tok, j)] = v;  // :354-358
-    } else if constexpr (EPI == G_SWIGLU_IL) {
-        const int j = n0 + j_in_tile;   // row of the alternating matrix: even W1, odd W3
-        if (valid && !(j & 1) && tok < a.P && j < a.N) {
-            const float g = swiglu_merge(v, partner);  // :411-416
-            a.out[(size_t)tok * a.ldo + (j >> 1)] = g;
-            if (a.x3_out) planes_store1((__bf16 *)a.x3_out, a.kp_out, tok, j >> 1, g);   // the W2 launch's operand, already split
-        }
-    } else {
-        const int j = n0 + j_in_tile;
-        if (EPI == G_ROPE || EPI == G_ROPE_CACHE) {
-            const int hs = a.head_size, pos = a.pos0 + (tok < a.P ? tok : 0);
-            const float2 cs = a.rope[(size_t)pos * (size_t)(hs >> 1) + (size_t)(((j < a.N ? j : 0) % hs) >> 1)];
-            v = (j & 1) ? partner * cs.y + v * cs.x : v * cs.x - partner * cs.y;
-        }
-        if (valid && tok < a.P && j < a.N) {
-            if (EPI == G_STORE || EPI == G_ROPE) a.out[(size_t)tok * a.ldo + j] = v;
-            else if (EPI == G_RESID) a.out[(size_t)tok * a.ldo + j] = a.res[(size_t)tok * a.ldres + j] + v;  // main.zig:711
-            else a.out[kv_index(a, a.ldo, a.pos0 + tok, j)] = v;                  // main.zig:354-358
-        }
-    }
-}
-
 // ---- the STREAM form of the planes kernel: chunks of <= 128 tokens of matrices that stream from HBM (round 6) ----
 // At <= 128 tokens a layer's matrices cross the chip once (809 MB at the 7B shape: 130 us at the HBM rate) against 40-160 us
 // of bf16 MFMAs: the tile forms above -- one or two blocks per CU, two stage buffers, loads ONE stage ahead -- are bound by
@@ -714,6 +686,17 @@ __device__ __forceinline__ void epi_one(const GemmArgs &a, float v, int n0, int 
 //  * the grid is filled by K ranges (blockIdx.z; x3_stream_sk: a function of the WHOLE model's matrix and the chunk length),
 //    partial sums through the split-K workspace, the last arriver adds them in range order and runs the epilogue.
 // An output's value is a function of (K, the ranges) only -- not of the rows a rank owns, not of launch fusion.
+#ifdef L2Z_X3_TIMELINE
+// measurement build (scripts/x3_timeline.sh): wall-clock stamps (100 MHz) of every block of the LAST launch of each epilogue
+// kind: [0] entry, [1] first stage landed, [2] loop done, [3] k-groups summed, [4] partial sums drained, [5] siblings arrived,
+// [6] the ranges' sums read and added, [7] end
+constexpr int kXtlBlocks = 1024;
+__device__ long long g_xtl[8 * kXtlBlocks * 8];
+#define L2Z_XTL(i) tl[i] = wall_clock64()
+#else
+#define L2Z_XTL(i) do { } while (0)
+#endif
+
 template <int N_> __device__ __forceinline__ void wait_vmcnt()
 {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N_) : "memory");
@@ -729,6 +712,17 @@ __global__ __launch_bounds__(128 * WN) void prefill_x3_stream(const GemmArgs a)
     constexpr int XSTG = 3 * BMt * 16, WSTG = BNt * 32, STAGE = XSTG + WSTG;                 // floats
     static_assert(NL * (NBUF - 1) <= 63, "vmcnt");
     extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef L2Z_X3_TIMELINE
+    long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto tl_store = [&]() {
+        tl[7] = wall_clock64();
+        if (threadIdx.x == 0 && blockIdx.x < kXtlBlocks)
+            for (int i = 0; i < 8; i++) g_xtl[((size_t)EPI * kXtlBlocks + blockIdx.x) * 8 + i] = tl[i];
+    };
+#else
+    auto tl_store = []() {};
+#endif
+    L2Z_XTL(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave % WN, kg = wave / WN;
     const int hl = lane >> 5, il = lane & 31;
     // block -> (tile, range): the ranges of a tile are CONSECUTIVE block ids -- dispatched together, finishing together,
@@ -818,6 +812,7 @@ __global__ __launch_bounds__(128 * WN) void prefill_x3_stream(const GemmArgs a)
         else wait_vmcnt<(NBUF > 6 ? 6 : 0) * NL>();
     }
     __syncthreads();
+    L2Z_XTL(1);
     Bf3 av[TM], bcur;
     v4f blo, bhi;
     read_b(0, blo, bhi);
@@ -875,6 +870,7 @@ __global__ __launch_bounds__(128 * WN) void prefill_x3_stream(const GemmArgs a)
         }
     step(std::integral_constant<int, 0>{}, F{}, F{}, s);
     __syncthreads();   // every wave is done with the ring (the k-groups' sums reuse it)
+    L2Z_XTL(2);
 
     // the two k-groups' sums, then (sk > 1) the ranges' through the workspace, then the epilogue -- as in the tile forms
     {
@@ -892,6 +888,7 @@ __global__ __launch_bounds__(128 * WN) void prefill_x3_stream(const GemmArgs a)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][0][r] += red[((wn * TM + i) * 16 + r) * 64 + lane];
     }
+    L2Z_XTL(3);
     if (sk > 1 && !coop) {
         // A launch of several rounds of blocks: whichever block of a tile arrives last adds the sk partials in range order
         // (nobody waits: a waiting block would hold a CU its not-yet-resident siblings need) and runs the epilogue.
@@ -953,6 +950,7 @@ __global__ __launch_bounds__(128 * WN) void prefill_x3_stream(const GemmArgs a)
                 __hip_atomic_store(mine + (i * 16 + r) * 64, acc[i][0][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // (the live waves: k-group 0) every wave's part has left
+        L2Z_XTL(4);
         int *arrive = a.sk_cnt + 2 * bx, *done = arrive + 1;
         if (tid == 0) {
             __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the partials were written through and drained)
@@ -961,6 +959,7 @@ __global__ __launch_bounds__(128 * WN) void prefill_x3_stream(const GemmArgs a)
                 __builtin_amdgcn_s_sleep(1);
         }
         __syncthreads();
+        L2Z_XTL(5);
         const float *p0 = part + (size_t)wn * (TM * 16 * 64) + lane;
         auto finish = [&](auto sk_c) {
             constexpr int SK = decltype(sk_c)::value, PER = TM * 16 / SK;   // values per block
@@ -985,19 +984,26 @@ __global__ __launch_bounds__(128 * WN) void prefill_x3_stream(const GemmArgs a)
                     __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
+            L2Z_XTL(6);
+            int tok[PER];
+            bool on[PER];
 #pragma unroll
             for (int k = 0; k < PER; k++) {
                 const int idx = lo + k, i = idx >> 4, r = idx & 15;
-                epi_one<EPI>(a, t[0][k], n0, wn * 32 + (lane & 31), i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), true);
+                tok[k] = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                on[k] = tok[k] < a.P;
             }
+            epi_values<EPI, PER>(a, t[0], tok, on, n0 + wn * 32, lane);
         };
         // (sk is 2, 4 or 8: x3_stream_sk; TM * 16 divides)
         if (sk == 2) finish(std::integral_constant<int, 2>{});
         else if (sk == 4) finish(std::integral_constant<int, 4>{});
         else finish(std::integral_constant<int, 8>{});
+        tl_store();
         return;
     }
     gemm_epilogue<EPI, TM, TN>(a, acc, n0, 0, 0, wn, lane);
+    tl_store();
 }
 
 // A form of the tile kernel as a launch: kernel, threads, dynamic LDS.  The block's output tile is 32 WM TM tokens x
@@ -1491,3 +1497,10 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
 int prefill_tile_form(int N, int P, int pair) { return (int)choose_tile(N, P, pair != 0); }
 
 }  // namespace l2z
+
+#ifdef L2Z_X3_TIMELINE
+extern "C" int l2z_x3_timeline_dump(long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(l2z::g_xtl), sizeof(long long) * 8 * l2z::kXtlBlocks * 8) != hipSuccess;
+}
+#endif
