@@ -156,14 +156,20 @@ __device__ __forceinline__ void epi_values(const GemmArgs &a, float (&v)[NV], co
     }
     const bool inr = j < nseg;
     if constexpr (EPI == G_SWIGLU_IL) {
-        // row j of the alternating matrix: even W1, odd W3; out[token][j / 2] = silu(a) * b (main.zig:411-416)
+        // row j of the alternating matrix: even W1, odd W3; out[token][j / 2] = silu(a) * b (main.zig:411-416).  Both lanes of
+        // a pair hold both factors after the exchange: the even lane finishes the pair's even values, the odd lane the odd
+        // ones -- every store instruction has all 64 lanes at work (half the stores, half the exponentials per lane)
+        static_assert(NV % 2 == 0, "values in pairs");
+        const int odd = j & 1;
 #pragma unroll
-        for (int k = 0; k < NV; k++) {
-            const float partner = __shfl_xor(v[k], 1, 64);
-            if (on[k] && !(j & 1) && inr) {
-                const float g = swiglu_merge(v[k], partner);
-                a.out[(size_t)tok[k] * a.ldo + (j >> 1)] = g;
-                if (a.x3_out) planes_store1((__bf16 *)a.x3_out, a.kp_out, tok[k], j >> 1, g);   // the W2 launch's operand, already split
+        for (int k = 0; k < NV; k += 2) {
+            const float p0 = __shfl_xor(v[k], 1, 64), p1 = __shfl_xor(v[k + 1], 1, 64);
+            const float h1 = odd ? p1 : v[k], h3 = odd ? v[k + 1] : p0;
+            const int t = odd ? tok[k + 1] : tok[k];
+            if ((odd ? on[k + 1] : on[k]) && inr) {
+                const float g = swiglu_merge(h1, h3);
+                a.out[(size_t)t * a.ldo + (j >> 1)] = g;
+                if (a.x3_out) planes_store1((__bf16 *)a.x3_out, a.kp_out, t, j >> 1, g);   // the W2 launch's operand, already split
             }
         }
         return;
