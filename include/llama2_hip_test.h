@@ -122,7 +122,7 @@ int l2z_prefill_split_k(long long n_features_whole, int n_tokens, int k, int pai
 /* The matrix cores of an [n_tokens, k] x [n_features_whole, k]^T product (round 6): 0 the f32 ones
  * (v_mfma_f32_32x32x2_f32, an fmaf chain), 1 the bf16 ones over three-term splits of both operands (six
  * v_mfma_f32_32x32x16_bf16 per 16 k; matrices that stream from HBM, or all with L2Z_PF_X3=2) in the tile forms, n >= 2: the
- * STREAM form of that kernel (chunks of L2Z_PF_X3_STREAM_MIN ... 128 tokens) with n - 1 K ranges per output tile -- part of
+ * STREAM form of that kernel (chunks of L2Z_PF_X3_STREAM_MIN = 33 ... 128 tokens) with n - 1 K ranges per output tile -- part of
  * the arithmetic, a function of the chunk length and the WHOLE model's matrix.  k: the product's K (rounded up to 64 here). */
 int l2z_prefill_cores(long long n_features_whole, int n_tokens, int k);
 

@@ -46,9 +46,9 @@ struct Tunables {
                                //                     v_mfma_f32_32x32x16_bf16 per 16 k; changes rounding, error against float64 not above the f32
                                //                     chain's): 7B 128 / 512 / 1024 tokens 17.7 / 57.4 / 108 -> 15.3 / 40.6 / 74 ms; 2: every matrix
                                //                     (tests drive the planes kernels on toy shapes)
-    int pf_x3_stream_min = 49; // L2Z_PF_X3_STREAM_MIN shortest chunk that takes the STREAM form of the bf16 kernel (up to 128 tokens; below, the
-                               //                     panel kernel): tests of both sides of the switch-over (7B: 48 tokens 8.7 vs 10.1 ms, 56 tokens
-                               //                     10.9 vs 10.4)
+    int pf_x3_stream_min = 33; // L2Z_PF_X3_STREAM_MIN shortest chunk that takes the STREAM form of the bf16 kernel (up to 128 tokens; below, the
+                               //                     panel kernel): tests of both sides of the switch-over (7B, ms: 32 tokens 6.6 vs 7.3,
+                               //                     36 / 40 / 48 tokens 8.6 / 8.7 / 8.8 vs 8.0 / 8.2 / 8.2: profiles/r06t)
     int pf_fuse_planes = 1;    // L2Z_PF_FUSE_PLANES  0: every GEMM on the bf16 cores splits its activation matrix in a launch of its own just
                                //                     before it (same bits; the A/B of the fused producers: rmsnorm, attention output, SwiGLU
                                //                     epilogue -- four launches per layer)

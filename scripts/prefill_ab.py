@@ -8,7 +8,7 @@ variants = sys.argv[4:] or [""]
 cfg, shared = {k: (c, sh) for k, c, sh in ck.iter_configs()}[shape]
 w = B.Weights(cfg, None, shared, seed=1); s = B.RunState(cfg)
 toks = [1] + np.random.default_rng(1).integers(2, cfg.vocab_size, n - 1).tolist()
-DEF = {"L2Z_PF_FUSE_PLANES": 1, "L2Z_PF_CHUNK": 0, "L2Z_PF_PANEL": 1, "L2Z_PF_PANEL_MAX": -1, "L2Z_PREFILL": 1, "L2Z_PF_X3": 1, "L2Z_PF_X3_STREAM_MIN": 49}   # (round 6: the other prefill knobs are gone)
+DEF = {"L2Z_PF_FUSE_PLANES": 1, "L2Z_PF_CHUNK": 0, "L2Z_PF_PANEL": 1, "L2Z_PF_PANEL_MAX": -1, "L2Z_PREFILL": 1, "L2Z_PF_X3": 1, "L2Z_PF_X3_STREAM_MIN": 33}   # (round 6: the other prefill knobs are gone)
 res = [[] for _ in variants]
 logits = [None for _ in variants]
 flops = 2.0 * n * (cfg.n_layers * (2 * cfg.dim * cfg.dim + 2 * cfg.dim * cfg.kv_dim + 3 * cfg.dim * cfg.hidden_dim))

@@ -57,7 +57,7 @@ def options(gpu):
     at first use, so tests go through l2z_option_set) and put the defaults back afterwards."""
     defaults = {"L2Z_ATTN_SPLIT": -1, "L2Z_ATTN_SPLIT_POS": -1, "L2Z_FUSE_SMALL": 1, "L2Z_PREFILL": 1, "L2Z_NO_GRAPH": 0,
                 "L2Z_PF_CHUNK": 0, "L2Z_PF_PANEL": 1, "L2Z_PF_PANEL_MAX": -1, "L2Z_ARGMAX_XCHG": 1, "L2Z_GRID_CAP": 0,
-                "L2Z_P2P_CONSUME": -1, "L2Z_SCHEME_B": 0, "L2Z_PF_X3": 1, "L2Z_PF_X3_STREAM_MIN": 49, "L2Z_PF_FUSE_PLANES": 1}
+                "L2Z_P2P_CONSUME": -1, "L2Z_SCHEME_B": 0, "L2Z_PF_X3": 1, "L2Z_PF_X3_STREAM_MIN": 33, "L2Z_PF_FUSE_PLANES": 1}
     touched = []
 
     def set_options(**kw):

@@ -123,12 +123,12 @@ def test_prefill_planning_is_pinned(B, ck):
 def test_prefill_matrix_cores_and_stream_ranges_are_pinned(B):
     """Which matrix cores a prefill product takes, and the stream form's K ranges (host logic, no device; round 6).
     Matrices that stream from HBM (> 16 MB over the whole model) multiply on the bf16 cores over three-term splits; chunks
-    of 49 ... 128 tokens of them take the stream form, whose K ranges -- part of the arithmetic -- follow from the WHOLE
+    of 33 ... 128 tokens of them take the stream form, whose K ranges -- part of the arithmetic -- follow from the WHOLE
     model's rows by a round count on the 256-CU part the rule was made for: q | k | v of the 7B shape (96 tiles of 128
     features) 2 ranges (1, 2, 4 or 8: the ranges of a tile share its epilogue in equal parts), wo 8, W1 | W3 (172 tiles: one round unsplit) 1, W2 (K = 11008) 8."""
     cores = {(12288, 512, 4096): 1, (4096, 1024, 4096): 1, (22016, 300, 4096): 1, (4096, 129, 11008): 1,   # tile forms
              (12288, 128, 4096): 1 + 2, (4096, 128, 4096): 1 + 8, (22016, 100, 4096): 1 + 1, (4096, 64, 11008): 1 + 8,
-             (4096, 49, 4096): 1 + 8, (4096, 48, 4096): 1,          # below the switch-over: the panel kernel (f32 cores) takes the chunk
+             (4096, 49, 4096): 1 + 8, (4096, 33, 4096): 1 + 8, (4096, 32, 4096): 1,          # below the switch-over: the panel kernel (f32 cores) takes the chunk
              (768, 300, 768): 0, (4096, 300, 288): 0, (32000, 64, 288): 1 + 1,   # stories110M / 15M: cache resident; a wide classifier-like matrix streams
              (2304, 100, 768): 0}
     for (n, p, k), want in cores.items():

@@ -966,15 +966,19 @@ def test_prefill_panel_kernel_vs_oracle(gpu, ck, orc, options, kv_heads):
             ref[pos + 1] = lg
     ref_cache = {nm: m.state(nm, cfg.n_layers * S * kvd).reshape(cfg.n_layers, S, kvd) for nm in ("key_cache", "value_cache")}
     worst = 0.0
-    for n in lens:
-        s.prefill(toks[:n], 0, w)
-        got = s.logits()
-        worst = max(worst, float(np.abs(got - ref[n]).max()))
-        np.testing.assert_allclose(got, ref[n], rtol=LOGIT_RTOL, atol=LOGIT_ATOL, err_msg=f"{n} tokens")
-        for l in range(cfg.n_layers):
-            for nm in ("key_cache", "value_cache"):
-                np.testing.assert_allclose(s.read(nm, l * S * kvd, n * kvd), ref_cache[nm][l, :n].ravel(), rtol=2e-5, atol=2e-5,
-                                           err_msg=f"{nm} l={l} n={n}")
+    # L2Z_PF_X3=0 first: every GEMM on the f32 matrix cores -- the panel kernel at all of 17 ... 96 tokens (by default chunks
+    # of 33 ... 128 tokens of such matrices take the stream form of the bf16-core kernel); then the defaults
+    for x3 in (0, 1):
+        options(L2Z_PF_X3=x3)
+        for n in lens:
+            s.prefill(toks[:n], 0, w)
+            got = s.logits()
+            worst = max(worst, float(np.abs(got - ref[n]).max()))
+            np.testing.assert_allclose(got, ref[n], rtol=LOGIT_RTOL, atol=LOGIT_ATOL, err_msg=f"{n} tokens, L2Z_PF_X3={x3}")
+            for l in range(cfg.n_layers):
+                for nm in ("key_cache", "value_cache"):
+                    np.testing.assert_allclose(s.read(nm, l * S * kvd, n * kvd), ref_cache[nm][l, :n].ravel(), rtol=2e-5, atol=2e-5,
+                                               err_msg=f"{nm} l={l} n={n} L2Z_PF_X3={x3}")
     # a second call continuing the context (pos0 = 96), 8 more tokens
     s.prefill(toks[96:104], 96, w)
     np.testing.assert_allclose(s.logits(), ref[104], rtol=LOGIT_RTOL, atol=LOGIT_ATOL)
