@@ -523,21 +523,21 @@ def single_gpu(args) -> None:
                                     "f32_equivalent_tflops": f32_equiv, "of_the_f32_cores_peak": f32_equiv / MFMA_F32_PEAK_TF,
                                     "note": "whole prefill (GEMMs + attention + norms), GEMM flops only in the numerator; "
                                             + ("v_mfma_f32_32x32x16_bf16 x 6 per 16 k" if on_bf16 else "v_mfma_f32_32x32x2_f32")}}
-            # shorter prompts: other kernels (<= 16 tokens: the weight-streaming bound short-prompt GEMMs; 17-48: the
-            # K-range panel kernel on the f32 cores; 49-128: the stream form of the bf16 kernel) -- ms per prompt length, with
+            # shorter prompts: other kernels (<= 16 tokens: the weight-streaming bound short-prompt GEMMs; 17-32: the
+            # K-range panel kernel on the f32 cores; 33-128: the stream form of the bf16 kernel) -- ms per prompt length, with
             # the bound that applies
             by_len, frac_by_len = {}, {}
             bytes_tok = weight_bytes_per_token(cfg)
-            for n_s in (16, 32, 48, 64, 96, 128):   # (48 / 96: the panel kernel's three- and six-tile forms, round 6)
+            for n_s in (16, 32, 48, 64, 96, 128):   # (48 / 64: the stream form on twelve / sixteen waves; 96 / 128: on eight)
                 if n_s < cfg.seq_len:
                     d = time_prefill(n_s)
                     by_len[str(n_s)] = d * 1e3
                     # both bounds: a chunk of <= ~64 tokens is nearer the weight stream's, a longer one the matrix cores'
-                    frac_by_len[str(n_s)] = {"bound": "hbm" if n_s <= 48 else "mfma",
+                    frac_by_len[str(n_s)] = {"bound": "hbm" if n_s <= 64 else "mfma",
                                              "hbm_frac": bytes_tok / d / 1e9 / HBM_PEAK_GBS,
                                              "mfma_frac": (6 * flops_tok * n_s / d / 1e12 / MFMA_BF16_PEAK_TF) if on_bf16
                                                           else flops_tok * n_s / d / 1e12 / MFMA_F32_PEAK_TF}
-                    frac_by_len[str(n_s)]["frac"] = frac_by_len[str(n_s)]["hbm_frac" if n_s <= 48 else "mfma_frac"]
+                    frac_by_len[str(n_s)]["frac"] = frac_by_len[str(n_s)]["hbm_frac" if n_s <= 64 else "mfma_frac"]
             prefill["ms_by_prompt_tokens"] = by_len
             prefill["frac_by_prompt_tokens"] = frac_by_len
         except Exception as e:  # noqa: BLE001

@@ -32,17 +32,25 @@ for c in acc:
         elif epi == 1: key = "wo" if n1 % 2 == 0 else "w2"; n1 += 1
         else: continue
         acc[c][key] += float(r["Counter_Value"])
-        if c == "FETCH_SIZE": cnt[key] += 1; grid[key] = (int(r["Grid_Size"]) // int(r["Workgroup_Size"]), int(r["Workgroup_Size"]))
+        if c == "FETCH_SIZE": cnt[key] += 1; grid[key] = (int(r.get("Grid_Size", 0)) // max(int(r.get("Workgroup_Size", 1)), 1), int(r.get("Workgroup_Size", 0)))
+import os
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+import __graft_entry__ as ge
+B = ge.load_package().binding
+sk = {k: max(B.prefill_cores(N[k], n, K[k]) - 1, 1) for k in N}      # K ranges per tile (host logic: l2z_prefill_cores)
 print(f"# PMC HBM traffic per launch, stream form of the bf16-core prefill GEMM, {n} tokens, llama2-7b shape\n")
 print("FETCH_SIZE (KB) x 1024 x 2 (gfx950: half of a wide coalesced stream is reported, MI355X_MICROARCH.md HBM section) + WRITE_SIZE (KB) x 1024; "
-      "separate --pmc passes, kernel-trace only (scripts/stream_pmc_traffic.sh).  W = the product's weight bytes, read by ONE block each; "
-      "X = the activation planes [tokens][3][K] bf16 that every block of a K range reads from its XCD's L2 (memory-side: up to 8 x); "
-      "out = the product's f32 output (+ its planes where the SwiGLU epilogue writes them) + the K ranges' partial sums.\n")
-print("| product | launches | blocks x threads | read bytes | written bytes | W bytes | X bytes | read / W | (read - W) / X | written bytes / output bytes |\n|---|---:|---|---:|---:|---:|---:|---:|---:|---:|")
+      "separate --pmc passes, kernel-trace only (scripts/stream_pmc_traffic.sh).  W = the product's weight bytes: every element is requested by ONE "
+      "block, once.  partials = ranges x tokens x features x 4 bytes: the K ranges' sums, written through and read back once by the blocks "
+      "that finish the tile (nothing with one range).  X = the activation planes [tokens][3][K] bf16: every block of a K range reads them "
+      "through its XCD's L2, so the memory side sees them up to 8 x.  out = the f32 output (+ its planes where the SwiGLU epilogue writes them).\n")
+print("| product | launches | blocks x threads | K ranges | read bytes | W bytes | partial bytes | X bytes | read / W | (read - partials) / W | (read - W - partials) / X | written bytes | written / (partials + out) |\n|---|---:|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
 for key in ("qkv", "wo", "w13", "w2"):
     c = max(cnt[key], 1)
     rd = acc["FETCH_SIZE"][key] / c * 1024 * 2; wr = acc["WRITE_SIZE"][key] / c * 1024
     x = n * K[key] * 6
+    tok = (n + 31) // 32 * 32
+    part = sk[key] * tok * N[key] * 4 if sk[key] > 1 else 0
     out = n * N[key] * 4 if key != "w13" else n * hid * 4 + n * hid * 6
-    print(f"| {names[key]} | {cnt[key]} | {grid.get(key)} | {rd:.0f} | {wr:.0f} | {wbytes[key]} | {x} | {rd / wbytes[key]:.3f} | {(rd - wbytes[key]) / x:.2f} | {wr / out:.2f} |")
+    print(f"| {names[key]} | {cnt[key]} | {grid.get(key)} | {sk[key]} | {rd:.0f} | {wbytes[key]} | {part} | {x} | {rd / wbytes[key]:.3f} | {(rd - part) / wbytes[key]:.3f} | {(rd - wbytes[key] - part) / x:.2f} | {wr:.0f} | {wr / (part + out):.2f} |")
 PY

@@ -69,10 +69,10 @@ def test_small_model_tokens_per_s_stay_at_their_floor(gpu, ck, pf):
 
 
 def test_prefill_and_long_context_attention_stay_at_their_floor(gpu, ck, pf):
-    """the batched prefill of the 7B shape at 16 (short-prompt GEMMs), 32 / 48 (the K-range panel kernel's two / three token
-    tiles, f32 matrix cores), 64 / 96 / 128 (the stream form of the bf16-core kernel: two / three / four token tiles) and
-    256 / 512 / 1024 tokens (its tile forms), best of 6; and the split decode attention at the last position of the
-    2048-token context"""
+    """the batched prefill of the 7B shape at 16 (short-prompt GEMMs), 32 (the K-range panel kernel, f32 matrix cores),
+    48 / 64 / 96 / 128 (the stream form of the bf16-core kernel: two token tiles on twelve / sixteen waves, three / four on
+    eight) and 256 / 512 / 1024 tokens (its tile forms), best of 6; and the split decode attention at the last position of
+    the 2048-token context"""
     cfg = ck.LLAMA2_7B
     w, s = gpu.Weights(cfg, None, False, seed=2024), gpu.RunState(cfg)
     try:
