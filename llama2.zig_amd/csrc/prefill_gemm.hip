@@ -156,20 +156,16 @@ __device__ __forceinline__ void epi_values(const GemmArgs &a, float (&v)[NV], co
     }
     const bool inr = j < nseg;
     if constexpr (EPI == G_SWIGLU_IL) {
-        // row j of the alternating matrix: even W1, odd W3; out[token][j / 2] = silu(a) * b (main.zig:411-416).  Both lanes of
-        // a pair hold both factors after the exchange: the even lane finishes the pair's even values, the odd lane the odd
-        // ones -- every store instruction has all 64 lanes at work (half the stores, half the exponentials per lane)
-        static_assert(NV % 2 == 0, "values in pairs");
-        const int odd = j & 1;
+        // row j of the alternating matrix: even W1, odd W3; out[token][j / 2] = silu(a) * b (main.zig:411-416)
+        // (sharing a pair's values between its two lanes -- every store with 64 lanes at work -- measured no faster and cost
+        // the kernel 80 bytes of scratch: not kept)
 #pragma unroll
-        for (int k = 0; k < NV; k += 2) {
-            const float p0 = __shfl_xor(v[k], 1, 64), p1 = __shfl_xor(v[k + 1], 1, 64);
-            const float h1 = odd ? p1 : v[k], h3 = odd ? v[k + 1] : p0;
-            const int t = odd ? tok[k + 1] : tok[k];
-            if ((odd ? on[k + 1] : on[k]) && inr) {
-                const float g = swiglu_merge(h1, h3);
-                a.out[(size_t)t * a.ldo + (j >> 1)] = g;
-                if (a.x3_out) planes_store1((__bf16 *)a.x3_out, a.kp_out, t, j >> 1, g);   // the W2 launch's operand, already split
+        for (int k = 0; k < NV; k++) {
+            const float partner = __shfl_xor(v[k], 1, 64);
+            if (on[k] && !(j & 1) && inr) {
+                const float g = swiglu_merge(v[k], partner);
+                a.out[(size_t)tok[k] * a.ldo + (j >> 1)] = g;
+                if (a.x3_out) planes_store1((__bf16 *)a.x3_out, a.kp_out, tok[k], j >> 1, g);   // the W2 launch's operand, already split
             }
         }
         return;
@@ -1240,8 +1236,10 @@ hipError_t launch_x3_stream(GemmArgs a, long long n_whole, const SplitKWs *ws, h
     int feat = 128;
     if (x3_stream_tile(a.P) == 256 && tm <= 2 && (long long)((a.N + 127) / 128) * sk > cus) {
         // the NARROWEST tile whose blocks fit one round (the most blocks: the least W per block)
-        for (int f : {192, 256})
+        for (int f : {192, 256}) {
+            if (f == 256 && (EPI == G_ROPE || EPI == G_ROPE_CACHE)) continue;   // (sixteen waves of these would spill: 128 registers)
             if ((long long)((a.N + f - 1) / f) * sk <= cus) { feat = f; break; }
+        }
     }
     const int ntx = (a.N + feat - 1) / feat;
     if (ws->part == nullptr || ws->cnt == nullptr || (size_t)ntx * sk * tm * 32 * feat > ws->part_floats || 2 * ntx > ws->cnt_ints)
@@ -1253,7 +1251,8 @@ hipError_t launch_x3_stream(GemmArgs a, long long n_whole, const SplitKWs *ws, h
     const void *fn;
     int nbuf;
     if (feat == 256) {
-        if (tm == 1) { fn = (const void *)prefill_x3_stream<EPI, 1, 4, 8>; nbuf = 4; }
+        if constexpr (EPI == G_ROPE || EPI == G_ROPE_CACHE) return hipErrorInvalidValue;   // (never chosen above)
+        else if (tm == 1) { fn = (const void *)prefill_x3_stream<EPI, 1, 4, 8>; nbuf = 4; }
         else { fn = (const void *)prefill_x3_stream<EPI, 2, 3, 8>; nbuf = 3; }
     } else if (feat == 192) {
         if (tm == 1) { fn = (const void *)prefill_x3_stream<EPI, 1, 5, 6>; nbuf = 5; }
