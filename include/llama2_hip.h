@@ -135,9 +135,12 @@ int l2z_greedy_run(const l2z_config *config, l2z_runstate *s, const l2z_weights 
  * Same state change as l2z_transformer(tokens[i], pos0 + i) for i = 0 .. n_tokens-1 -- the
  * KV-cache rows pos0 .. pos0+n_tokens-1 of every layer are written and the logits of the LAST
  * position are left in the runstate (l2z_argmax / l2z_logits_read) -- but each weight matrix is
- * streamed once per chunk of up to 1024 tokens and multiplied as a dense GEMM on the fp32 matrix
- * cores (v_mfma_f32_32x32x2_f32).  Values agree with the token-by-token path up to summation
- * order.  Dims must be multiples of 4 (else L2Z_ERR_INVALID, and the caller loops over
+ * streamed once per chunk of up to 1024 tokens and multiplied as a dense GEMM on the matrix cores:
+ * the fp32 ones (v_mfma_f32_32x32x2_f32) for models whose matrices stay in the caches; for matrices
+ * that stream from HBM the bf16 ones, f32-ACCURATELY -- both operands cut into three bf16 terms
+ * (exact splits), the six products of order >= 2^-16 summed in f32 (error against float64 not above
+ * the fp32 cores' own chain; L2Z_PF_X3=0 in the environment keeps the fp32 cores everywhere).  Values
+ * agree with the token-by-token path up to summation order.  Dims must be multiples of 4 (else L2Z_ERR_INVALID, and the caller loops over
  * l2z_transformer).  On a sharded runstate every rank of the group makes the same call: the pass is
  * row-sharded like the decode pass and bit-identical to the unsharded one; it needs a transport for
  * [1024, hidden_dim] matrices -- the peer-write arena's bulk regions (allocated by

@@ -26,13 +26,24 @@ for wl in stories15M stories42M; do
   rocprofv3 --kernel-trace --stats -d /tmp/prof_$wl -o p -- python $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 64 --warmup 2 --no-cpu-baseline --no-extra > /tmp/prof_$wl.log 2>&1 || tail -5 /tmp/prof_$wl.log
   python $GRAFT_REPO_ROOT/scripts/rocprof_summary.py $(find /tmp/prof_$wl -name "*.db" | head -1) "round 6 (r06): rocprofv3 --kernel-trace --stats -- python bench.py --workload $wl --steps 64 --warmup 2 --no-cpu-baseline --no-extra" > $GRAFT_REPO_ROOT/$O/r06_final_${wl}_kernel_stats.md
 done
-for n in 48 96; do
+for n in 48 64 96 128; do
   rm -rf /tmp/prof_pf$n
   rocprofv3 --kernel-trace --stats -d /tmp/prof_pf$n -o p -- python $GRAFT_REPO_ROOT/scripts/prefill_prof.py llama2-7b $n > /tmp/prof_pf$n.log 2>&1 || tail -5 /tmp/prof_pf$n.log
   python $GRAFT_REPO_ROOT/scripts/rocprof_summary.py $(find /tmp/prof_pf$n -name "*.db" | head -1) "round 6 (r06): rocprofv3 --kernel-trace --stats -- python scripts/prefill_prof.py llama2-7b $n (3 prefills)" > $GRAFT_REPO_ROOT/$O/r06_final_prefill${n}_llama2-7b.md
 done )
 head -14 $O/r06_final_llama2-7b_kernel_stats.md
 bash scripts/pmc_traffic.sh r06 > $O/r06_final_pmc.log 2>&1; tail -9 $O/r06_final_pmc.log
+# the stream form of the bf16-core prefill GEMM: HBM traffic of its four launches by the counters, and its blocks' own clocks
+for n in 64 128; do bash scripts/stream_pmc_traffic.sh $n > $O/r06_final_stream_pmc_traffic_$n.md 2>&1; tail -5 $O/r06_final_stream_pmc_traffic_$n.md; done
+for n in 64 128; do L2Z_LIB=$PWD/llama2.zig_amd/exp/libl2z_x3tl.so timeout 300 python scripts/x3_timeline.py llama2-7b $n; done > $O/r06_final_stream_timeline.txt 2>&1; grep -E "^[qW]" $O/r06_final_stream_timeline.txt
+# perf floors of this tree: two runs (profiles/perf_floor.json holds the worse reading of each)
+python scripts/perf_floor.py > $O/r06_final_perf_floor_a.json 2> $O/r06_final_perf_floor_a.err
+python scripts/perf_floor.py > $O/r06_final_perf_floor_b.json 2> $O/r06_final_perf_floor_b.err
+python -c "
+import json
+a=json.load(open('$O/r06_final_perf_floor_a.json')); b=json.load(open('$O/r06_final_perf_floor_b.json'))
+print('prefill a', {k: round(v, 2) for k, v in a['prefill_ms'].items()}); print('prefill b', {k: round(v, 2) for k, v in b['prefill_ms'].items()})"
+
 timeout 600 python -u scripts/solo_rank.py llama2-7b 128 > $O/r06_solo_rank.md 2>&1; tail -12 $O/r06_solo_rank.md
 # two and four ranks on this one GPU, all five legs (a proxy for the control path, the structures' ranking, and the new per-leg diagnostics)
 for n in 2 4; do

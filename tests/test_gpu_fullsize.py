@@ -261,11 +261,12 @@ def test_stories110M_across_the_attention_switch_over(gpu, ck, orc):
 
 @pytest.mark.parametrize("n", [16, 20, 40, 60, 100, 300, 1024])
 def test_7b_prefill_equals_stepped_loop(gpu, model7b, n):
-    """Batched prefill at the full 7B shape (16x16x4 skinny kernels for 16, 20 and 40 tokens, the tile GEMM's
-    split-K family for 60 (4 K ranges per tile) and 100 tokens (2), the direct-to-LDS 32x32x2 GEMM with
-    128x64 tiles for 300, one 1024-token chunk with 128x128 tiles and the flash-form attention for 1024) leaves the logits and KV rows the stepped loop leaves, within the
-    LOGIT tolerance of the oracle tests (5e-5: fp32 sums in a different order, nothing else) -- the
-    stepped loop itself is pinned against the oracle at this shape (test_7b_full_forward_logits_vs_oracle)."""
+    """Batched prefill at the full 7B shape -- the short-prompt GEMMs for 16 tokens, the K-range panel kernel for 20 (f32
+    cores), the stream form of the bf16-core kernel for 40 and 60 (two token tiles: q|k|v and W1|W3 on twelve waves x 192
+    features -- q|k|v tiles lie across the three matrices -- wo / W2 on eight x 128) and 100 tokens (four tiles, eight waves),
+    its tile forms for 300 and one 1024-token chunk (128x128 tiles, flash-form attention) -- leaves the logits and KV rows
+    the stepped loop leaves, within the LOGIT tolerance of the oracle tests (fp32 sums in a different order, nothing
+    else) -- the stepped loop itself is pinned against the oracle at this shape (test_7b_full_forward_logits_vs_oracle)."""
     cfg, w, s = model7b
     rng = np.random.default_rng(n)
     toks = [1] + rng.integers(2, cfg.vocab_size, n - 1).tolist()

@@ -888,7 +888,7 @@ def test_prefill_equals_token_by_token(gpu, ck, orc, options, name, kw, shared, 
     when it continues an existing context (pos0 > 0) and spans more than one 512-token chunk.
     x3 = 1: matrices that stream from HBM multiply on the bf16 matrix cores (three-term splits), the others on the f32
     ones -- the default; x3 = 2: every matrix on the bf16 cores, so that the planes kernels (tile forms from 129 tokens,
-    the stream form at 49 ... 128 where K >= 256) meet every toy shape, head layout and ragged width here."""
+    the stream form at 33 ... 128 where K >= 256) meet every toy shape, head layout and ragged width here."""
     options(L2Z_PF_X3=x3)
     cfg = ck.Config(**kw)
     blob = ck.synth_blob(cfg, shared, seed=91)
