@@ -1,5 +1,5 @@
 """The perf gate's comparison rule on made-up readings (CPU; the measurements themselves need the GPU:
-tests/test_gpu_perf_gate.py).  What it must do: fail a 5 % slowdown of ONE kernel family even when that family serves
+tests/test_gpu_perf_gate.py).  What it must do: fail a 7 % slowdown of ONE kernel family even when that family serves
 many of the group's figures (the batched prefill: the stream form of the bf16 kernel serves 4 of 9 chunk lengths, its tile forms
 3 more), pass a process in which
 everything runs 3 % slower, and fail when everything drifts past the common slack."""
@@ -26,10 +26,10 @@ def test_gate_rule_on_synthetic_readings():
     f = {k: g["floors"][k] for k in g["groups"]["bf16 cores (stream form, tile forms)"]}
     ok = {k: v * 1.03 for k, v in f.items()}                       # a slow process: everything + 3 %
     check_group("prefill", ok, f, g["slack"], g["common_slack"])
-    stream = {k: v * (1.05 * 0.85 + 0.15 if k in ("48", "64", "96", "128") else 1.0) for k, v in f.items()}  # stream kernel + 5 %: 85 % of those chunks' time
+    stream = {k: v * (1.07 * 0.85 + 0.15 if k in ("48", "64", "96", "128") else 1.0) for k, v in f.items()}  # stream kernel + 7 %: 85 % of those chunks' time
     with pytest.raises(AssertionError, match="96"):
         check_group("prefill", stream, f, g["slack"], g["common_slack"])
-    tiles = {k: v * (1.05 * 0.9 + 0.1 if k in ("256", "512", "1024") else 1.0) for k, v in f.items()}   # the tile forms + 5 %
+    tiles = {k: v * (1.07 * 0.9 + 0.1 if k in ("256", "512", "1024") else 1.0) for k, v in f.items()}   # the tile forms + 7 %
     with pytest.raises(AssertionError, match="512"):
         check_group("prefill", tiles, f, g["slack"], g["common_slack"])
     with pytest.raises(AssertionError, match="everything"):
