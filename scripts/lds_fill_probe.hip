@@ -106,6 +106,34 @@ __global__ __launch_bounds__(512) void mix(const float *src, size_t own_floats, 
     if (s == 123.456f) out[blockIdx.x] = s;
 }
 
+// The stream form's W walk: a block owns 128 rows of a [rows][4096] f32 matrix (16 KB apart) and walks k in stages of PIECE
+// bytes per row; a wave-instruction brings 1024 / PIECE rows x PIECE bytes.  AHEAD stages in flight per wave.
+template <int PIECE, int AHEAD>
+__global__ __launch_bounds__(512) void rowwalk(const float *src, int tiles_per_block, float *out)
+{
+    extern __shared__ float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int LPR = PIECE / 16, RPI = 64 / LPR, IPS = 16 / RPI;   // lanes per row, rows per instruction, instructions per wave and stage
+    constexpr int NST = 16384 / PIECE;                               // stages per tile
+    int issued = 0;
+    for (int t = 0; t < tiles_per_block; t++) {
+        const float *tile = src + ((size_t)(blockIdx.x * tiles_per_block + t) * 128) * 4096;
+        for (int st = 0; st < NST; st++) {
+#pragma unroll
+            for (int i = 0; i < IPS; i++) {
+                const int row = wave * 16 + i * RPI + lane / LPR;
+                if (issued >= AHEAD * IPS) wait_vm<AHEAD * IPS - 1>();
+                __builtin_amdgcn_global_load_lds(tile + (size_t)row * 4096 + st * (PIECE / 4) + 4 * (lane % LPR),
+                                                 smem + ((wave * AHEAD + (st % AHEAD)) * IPS + i) * 256, 16, 0, 2);
+                issued++;
+            }
+        }
+    }
+    wait_vm<0>();
+    __syncthreads();
+    if (smem[threadIdx.x] == 123.456f) out[blockIdx.x] = 1.0f;
+}
+
 int main()
 {
     const size_t total = (size_t)3 << 30;   // 3 GB
@@ -170,5 +198,26 @@ int main()
     runmix(mix<1, 2, 4>, "mix 1 : 2, planes to registers, 4 steps ahead", 2, 4);
     runmix(mix<0, 1, 8>, "mix 1 : 1, planes direct-to-LDS, 8 steps ahead", 1, 8);
     runmix(mix<1, 1, 8>, "mix 1 : 1, planes to registers, 8 steps ahead", 1, 8);
+    // the stream form's W walk (non-temporal): 256 blocks x 2 tiles of 128 rows x 16 KB = 1 GB
+    auto runrow = [&](auto kern, const char *name, int ahead, int ips) {
+        float best = 1e9;
+        const size_t lds = (size_t)8 * ahead * ips * 1024;
+        hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        for (int it = 0; it < 6; it++) {
+            hipEventRecord(a);
+            hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, 0, buf, 2, out);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            if (it >= 1 && ms < best) best = ms;
+        }
+        const double bytes = 256.0 * 2 * 128 * 16384;
+        printf("%-60s %8.1f us  %5.2f TB/s\n", name, best * 1e3, bytes / (best * 1e-3) / 1e12);
+    };
+    runrow(rowwalk<128, 4>, "row walk, 128-byte pieces (32 k), 4 stages ahead", 4, 2);
+    runrow(rowwalk<128, 8>, "row walk, 128-byte pieces (32 k), 8 stages ahead", 8, 2);
+    runrow(rowwalk<256, 2>, "row walk, 256-byte pieces (64 k), 2 stages ahead", 2, 4);
+    runrow(rowwalk<256, 4>, "row walk, 256-byte pieces (64 k), 4 stages ahead", 4, 4);
+    runrow(rowwalk<512, 2>, "row walk, 512-byte pieces (128 k), 2 stages ahead", 2, 8);
+    runrow(rowwalk<1024, 1>, "row walk, 1-KB pieces (256 k), 1 stage ahead", 1, 16);
     return 0;
 }
