@@ -97,3 +97,33 @@ def test_planes_written_by_the_producers_equal_the_split_launch(gpu, ck, options
         got[fuse] = (s.logits().copy(), s.read("key_cache", L * S * kvd, n * kvd), s.read("value_cache", L * S * kvd, n * kvd))
     for a, b, what in zip(got[0], got[1], ("logits", "key cache", "value cache")):
         assert np.array_equal(a, b), f"{n} tokens: {what} differ between fused and split planes (max |diff| {np.abs(a - b).max():.3e})"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [40, 64])
+def test_stream_form_tiles_of_every_width_equal_the_stepped_loop(gpu, ck, options, n):
+    """Chunks of <= 64 tokens pick their tile by grid fill (prefill_gemm.hip launch_x3_stream: the narrowest of 128 / 192 / 256
+    features -- eight / twelve / sixteen waves -- whose blocks fit one round of 256): a shape whose four products take all
+    three.  dim 2048, hidden_dim 14336: q | k | v (6144 features, 8 K ranges) 32 tiles of 192 -- tiles lie across the three
+    matrices; wo (16 MB: cache resident) stays on the f32 cores; W1 | W3 (28672 features, 2 ranges: 150 tiles of 192 would be
+    300 blocks) 112 tiles of 256 on SIXTEEN waves; W2 (K = 14336, 8 ranges) 16 tiles of 128 (rocprofv3 of this test:
+    prefill_x3_stream<7, 2, 3, 8>, <1, 2, 5, 4>, <6, 2, 4, 6>).  The K ranges -- the arithmetic -- do not depend on the tile.  Logits and
+    KV rows against the stepped loop of f32 mat-vec kernels (itself pinned against the oracle), at the bar of
+    test_7b_prefill_equals_stepped_loop."""
+    cfg = ck.Config(dim=2048, hidden_dim=14336, n_layers=2, n_heads=16, n_kv_heads=16, vocab_size=4096, seq_len=96)
+    w = gpu.Weights(cfg, None, False, seed=17)
+    toks = [1] + np.random.default_rng(n).integers(2, cfg.vocab_size, n - 1).tolist()
+    s = gpu.RunState(cfg)
+    for pos, t in enumerate(toks):
+        s.transformer(t, pos, w)
+    ref = s.logits()
+    S, kvd = cfg.seq_len, cfg.kv_dim
+    ref_kv = {(nm, l): s.read(nm, l * S * kvd, n * kvd) for nm in ("key_cache", "value_cache") for l in range(cfg.n_layers)}
+    s2 = gpu.RunState(cfg)
+    s2.prefill(toks, 0, w)
+    got = s2.logits()
+    print(f"stream form, tiles of 128 / 192 / 256 features, {n} tokens: max |logit diff| {float(np.abs(got - ref).max()):.3e}")
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+    for (nm, l), a in ref_kv.items():
+        np.testing.assert_allclose(s2.read(nm, l * S * kvd, n * kvd), a, rtol=5e-5, atol=5e-5, err_msg=f"{nm} layer {l}")
+    s.close(); s2.close(); w.close()
