@@ -235,6 +235,15 @@ struct SplitKWs {
     void *x3b;
     size_t x3b_bytes;
 };
+// A residual product (Wo, W2) of the stream form whose K ranges' sums were LEFT in the workspace (unsharded pass): the rmsnorm
+// launch that reads the residual stream next adds them -- range 0, 1, ... in order, then the residual: the sums the launch's
+// own hand-over forms -- writes x back and normalises it.  The producing launch ends at its loop: no write-through, no
+// arrival counter, no wait for the slowest sibling, no second pass over the sums (7-13 us per launch by the blocks' clocks).
+struct DeferredSum {
+    const float *part;   // [tile][range][feat / 32 waves][tm * 16][64 lanes]: the MFMA accumulators as the blocks held them
+    int sk, feat, tm;    // K ranges per tile, features per tile (128 / 192 / 256), token tiles of 32
+    bool valid;
+};
 // launch_prefill_gemm*'s planes argument: the consumer's planes are not there yet (the launcher splits x into ws->x3), stand
 // in ws->x3 (the launch before multiplied the same x, or x's producer wrote them), or stand in ws->x3b
 enum { PLANES_SPLIT = 0, PLANES_READY = 1, PLANES_READY_B = 2 };
@@ -255,7 +264,9 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
                                int ldw = 0,   // floats between rows of w (0: K; W1 / W3 of the device blob: 2 K)
                                long long n_launch_whole = 0,   // rows of the whole model's launch this product is a part of (q, k, v
                                                                // launched apart: dim + 2 kv_dim; 0: N * n_scale) -- the stream form's K ranges
-                               int planes_ready = PLANES_SPLIT);   // PLANES_*: whether x's planes stand already, and where
+                               int planes_ready = PLANES_SPLIT,    // PLANES_*: whether x's planes stand already, and where
+                               DeferredSum *defer = nullptr);      // PG_RESID: != null: the launch MAY leave its K ranges' sums to the next
+                                                                   // rmsnorm launch (sets valid; the stream form with > 1 range does)
 // the stream form of the planes kernel (prefill_gemm.hip): which products take it, and their K ranges
 bool x3_applies(long long n_whole, int K);
 bool x3_stream_shape(long long n_whole, int P, int K);
@@ -277,7 +288,8 @@ hipError_t launch_prefill_gemm_kv_pair(const float *x, int ldx, const float *wk,
                                        int sk = 1, long long n_launch_whole = 0);
 hipError_t launch_prefill_rmsnorm(float *o, int ldo, const float *x, const float *w, int n, int P,
                                   hipStream_t st,    // o: rows of ldo floats (the pad columns are left alone)
-                                  void *x3 = nullptr, int kp = 0);   // != null: o's planes of bf16 terms too (x3[token][3][kp], kp == n)
+                                  void *x3 = nullptr, int kp = 0,    // != null: o's planes of bf16 terms too (x3[token][3][kp], kp == n)
+                                  const DeferredSum *pending = nullptr);   // valid: x += the ranges' sums first (x is written back)
 hipError_t launch_prefill_embed(float *x, const float *tok_emb, const int *tokens, int dim, int P,
                                 hipStream_t st);
 // kv_row / kv_head: floats between timesteps of one kv head / between kv heads (AttnArgs)

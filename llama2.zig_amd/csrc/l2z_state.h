@@ -96,6 +96,7 @@ struct l2z_runstate {
     float *pf_stage = nullptr;  // sharded: [world][P, n_loc] blocks of the matrix being gathered
     float *pf_part = nullptr;   // scheme B: this rank's partial [P, dim] product of its column shard of Wo / W2
     int *pf_tokens = nullptr;
+    l2z::DeferredSum pf_pending = {nullptr, 1, 128, 1, false};   // K ranges' sums of Wo / W2 the next rmsnorm launch adds (prefill_host.cpp)
     int pf_planes_att = 0, pf_planes_h1 = 0;   // PLANES_*: whether the attention output's / the gated rows' planes stand (prefill_host.cpp)
     l2z::SplitKWs pf_sk = {nullptr, nullptr, 0, 0, nullptr, 0, nullptr, 0};  // split-K workspace of the tile GEMM (chunks of <= 256 tokens)
     int pf_cap = 0;             // tokens per chunk the scratch above was allocated for

@@ -1,6 +1,8 @@
 // prefill_attention.hip -- the non-GEMM kernels of the batched prompt pass: batched rmsnorm, embedding
 // gather, causal attention of a chunk (one block per (head, token) with the decode kernel's arithmetic,
 // or one block per (head, 64 queries) on the fp32 matrix cores).
+#include <type_traits>
+
 #include "prefill_common.h"
 
 namespace l2z {
@@ -9,15 +11,26 @@ namespace {
 // rows of x -> rmsnorm rows (main.zig:432-468), one block per token
 // x3 != null: the rows' planes of bf16 terms too (x3[token][plane][kp]: what the GEMM on the bf16 matrix cores reads;
 // prefill_common.h) -- the consumer's own split launch is then not needed
-__global__ __launch_bounds__(kPfBlock) void prefill_rmsnorm(float *o, int ldo, const float *x, const float *w,
-                                                            int n, int P, __bf16 *x3, int kp)
+// pend.valid: the residual product before this norm (Wo / W2 on the stream form) left its K ranges' sums in the workspace:
+// x[t][f] += range 0 + range 1 + ... (in that order, then the residual: the sums its own hand-over forms) first, and x is
+// written back (l2z_internal.h DeferredSum; the sums lie as the blocks' MFMA accumulators held them: prefill_gemm.hip)
+__device__ __forceinline__ const float *deferred_at(const DeferredSum &d, int t, int f)
+{
+    const int bx = f / d.feat, fw = f - bx * d.feat, row = t & 31;
+    const int lane = (fw & 31) + 32 * ((row >> 2) & 1), r = (row & 3) + 4 * (row >> 3);
+    return d.part + ((size_t)bx * d.sk * (d.feat >> 5) + (fw >> 5)) * (size_t)(d.tm * 16 * 64) + (size_t)(((t >> 5) * 16 + r) * 64 + lane);
+}
+
+__global__ __launch_bounds__(kPfBlock) void prefill_rmsnorm(float *o, int ldo, float *x, const float *w,
+                                                            int n, int P, __bf16 *x3, int kp, const DeferredSum pend)
 {
     __shared__ float red[8];
     const int t = blockIdx.x;
-    const float *xr = x + (size_t)t * n;
+    float *xr = x + (size_t)t * n;
     const int n4 = n >> 2;  // n % 4 == 0 on this path
     constexpr int R = 8;    // float4 kept in registers per lane: one round trip up to n = 8192
     const bool in_regs = n4 <= R * kPfBlock;
+    const size_t zstride = (size_t)(pend.feat >> 5) * (size_t)(pend.tm * 16 * 64);   // floats between a tile's ranges
     v4f xv[R];
     float ss = 0.0f;
     if (in_regs) {
@@ -26,13 +39,45 @@ __global__ __launch_bounds__(kPfBlock) void prefill_rmsnorm(float *o, int ldo, c
             const int i = threadIdx.x + kPfBlock * k;
             xv[k] = i < n4 ? ((const v4f *)xr)[i] : v4f{0.f, 0.f, 0.f, 0.f};
         }
+        if (pend.valid) {
+            // (the ranges of a float4 requested together -- a literal count per case -- then added in order)
+            auto add_ranges = [&](auto sk_c) {
+                constexpr int SK = decltype(sk_c)::value;
+#pragma unroll
+                for (int k = 0; k < R; k++) {
+                    const int i = threadIdx.x + kPfBlock * k;
+                    if (i < n4) {
+                        const float *p = deferred_at(pend, t, 4 * i);   // four features = four adjacent lanes of one wave's fragment
+                        v4f pv[SK];
+#pragma unroll
+                        for (int z = 0; z < SK; z++) pv[z] = *(const v4f *)(p + z * zstride);
+                        v4f v = pv[0];
+#pragma unroll
+                        for (int z = 1; z < SK; z++) v += pv[z];
+                        xv[k] = xv[k] + v;   // main.zig:711
+                        ((v4f *)xr)[i] = xv[k];
+                    }
+                }
+            };
+            if (pend.sk == 2) add_ranges(std::integral_constant<int, 2>{});
+            else if (pend.sk == 4) add_ranges(std::integral_constant<int, 4>{});
+            else add_ranges(std::integral_constant<int, 8>{});
+        }
 #pragma unroll
         for (int k = 0; k < R; k++) {
             ss = fmaf(xv[k].x, xv[k].x, ss); ss = fmaf(xv[k].y, xv[k].y, ss);
             ss = fmaf(xv[k].z, xv[k].z, ss); ss = fmaf(xv[k].w, xv[k].w, ss);
         }
     } else {
-        for (int i = threadIdx.x; i < n; i += blockDim.x) ss = fmaf(xr[i], xr[i], ss);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            if (pend.valid) {
+                const float *p = deferred_at(pend, t, i);
+                float v = p[0];
+                for (int z = 1; z < pend.sk; z++) v += p[z * zstride];
+                xr[i] = xr[i] + v;
+            }
+            ss = fmaf(xr[i], xr[i], ss);
+        }
     }
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
@@ -443,10 +488,16 @@ __global__ __launch_bounds__(kPfBlock) void prefill_attention_tiled(const float 
 }  // namespace
 
 hipError_t launch_prefill_rmsnorm(float *o, int ldo, const float *x, const float *w, int n, int P,
-                                  hipStream_t st, void *x3, int kp)
+                                  hipStream_t st, void *x3, int kp, const DeferredSum *pending)
 {
     if (x3 != nullptr && (kp != n || (n & 3))) return hipErrorInvalidValue;   // (pad columns: the split launch writes their zeros)
-    hipLaunchKernelGGL(prefill_rmsnorm, dim3(P), dim3(kPfBlock), 0, st, o, ldo, x, w, n, P, (__bf16 *)x3, kp);
+    DeferredSum pend = {nullptr, 1, 128, 1, false};
+    if (pending != nullptr && pending->valid) {
+        if (pending->part == nullptr || (pending->sk != 2 && pending->sk != 4 && pending->sk != 8) || (pending->feat & 31) || pending->tm * 32 < P)
+            return hipErrorInvalidValue;
+        pend = *pending;
+    }
+    hipLaunchKernelGGL(prefill_rmsnorm, dim3(P), dim3(kPfBlock), 0, st, o, ldo, const_cast<float *>(x), w, n, P, (__bf16 *)x3, kp, pend);
     return hipGetLastError();
 }
 

@@ -64,6 +64,9 @@ struct GemmArgs {
     // G_SWIGLU_IL (stream form): != null: the gated values' planes too, x3_out[token][plane][kp_out] (the next launch's x3)
     void *x3_out;
     int kp_out;
+    // G_RESID (stream form, sk > 1): != 0: the blocks leave their K range's sums in sk_part and END -- the next rmsnorm
+    // launch adds them and the residual (l2z_internal.h DeferredSum)
+    int defer;
 };
 
 

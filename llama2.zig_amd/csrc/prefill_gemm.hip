@@ -891,6 +891,18 @@ __global__ __launch_bounds__(128 * WN) void prefill_x3_stream(const GemmArgs a)
             for (int r = 0; r < 16; r++) acc[i][0][r] += red[((wn * TM + i) * 16 + r) * 64 + lane];
     }
     L2Z_XTL(3);
+    if constexpr (EPI == G_RESID) {
+        if (sk > 1 && a.defer) {
+            // the sums stay as they are: the next rmsnorm launch adds the ranges in order and the residual (DeferredSum)
+            float *mine = a.sk_part + ((size_t)bx * (size_t)sk + (size_t)bz) * (WN * TM * 16 * 64) + (size_t)wn * (TM * 16 * 64) + lane;
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) mine[(i * 16 + r) * 64] = acc[i][0][r];
+            tl_store();
+            return;
+        }
+    }
     if (sk > 1 && !coop) {
         // A launch of several rounds of blocks: whichever block of a tile arrives last adds the sk partials in range order
         // (nobody waits: a waiting block would hold a CU its not-yet-resident siblings need) and runs the epilogue.
@@ -1224,8 +1236,10 @@ hipError_t prepare_x3(GemmArgs &a, const SplitKWs *ws, hipStream_t st, long long
 
 // launch of the stream form; a.K is the padded K, a.N this rank's rows, n_whole the whole model's (the K ranges)
 template <int EPI>
-hipError_t launch_x3_stream(GemmArgs a, long long n_whole, const SplitKWs *ws, hipStream_t st, int planes_ready = PLANES_SPLIT)
+hipError_t launch_x3_stream(GemmArgs a, long long n_whole, const SplitKWs *ws, hipStream_t st, int planes_ready = PLANES_SPLIT,
+                            DeferredSum *defer = nullptr)
 {
+    if (defer) defer->valid = false;
     if (const hipError_t e = prepare_x3(a, ws, st, n_whole, planes_ready); e != hipSuccess) return e;
     // Features per block (grid fill only: the K ranges -- the arithmetic -- are x3_stream_sk's whatever the tile).  Chunks of
     // <= 64 tokens may run 192 features on twelve waves or 256 on sixteen instead of 128 on eight: a block streams its W at
@@ -1245,6 +1259,10 @@ hipError_t launch_x3_stream(GemmArgs a, long long n_whole, const SplitKWs *ws, h
     if (ws->part == nullptr || ws->cnt == nullptr || (size_t)ntx * sk * tm * 32 * feat > ws->part_floats || 2 * ntx > ws->cnt_ints)
         return hipErrorOutOfMemory;
     a.sk = sk; a.sk_part = ws->part; a.sk_cnt = ws->cnt;
+    if (EPI == G_RESID && defer != nullptr && sk > 1 && a.res == a.out && a.ldres == a.ldo) {   // (in place: x += the product)
+        a.defer = 1;
+        defer->part = ws->part; defer->sk = sk; defer->feat = feat; defer->tm = tm; defer->valid = true;
+    }
     // one round of blocks (one per CU: the ring takes the LDS): the ranges of a tile share its reduction and epilogue
     // (same sums in the same order either way: grid fill only, so a rank's own row count decides)
     a.ntx = ntx * sk <= cus ? 0 : ntx;
@@ -1446,10 +1464,11 @@ hipError_t launch_prefill_gemm_kv_pair(const float *x, int ldx, const float *wk,
 hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w, float *out, int ldo,
                                int P, int N, int K, int pos0, const float2 *rope, int head_size,
                                hipStream_t st, const float *res, int ldres, int n_scale, size_t kv_head_stride,
-                               int sk, const SplitKWs *ws, int ldw, long long n_launch_whole, int planes_ready)
+                               int sk, const SplitKWs *ws, int ldw, long long n_launch_whole, int planes_ready, DeferredSum *defer)
 {
     if (P <= 0 || N <= 0 || K <= 0 || (K % 4) != 0 || (ldx % 4) != 0) return hipErrorInvalidValue;
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return hipErrorInvalidValue;
+    if (defer) defer->valid = false;
     if (res == nullptr) { res = out; ldres = ldo; }  // PG_RESID in place
     GemmArgs a = {x, nullptr, w, out, res, P, N, K, ldx, ldo, ldres, pos0, rope, head_size, n_scale > 0 ? n_scale : 1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, kv_head_stride, 0, 0};
     a.ldw = ldw > 0 ? ldw : K;
@@ -1461,7 +1480,7 @@ hipError_t launch_prefill_gemm(int epi, const float *x, int ldx, const float *w,
         a.K = kp;
         switch (epi) {
             case G_STORE: return launch_x3_stream<G_STORE>(a, nw, ws, st, planes_ready);
-            case G_RESID: return launch_x3_stream<G_RESID>(a, nw, ws, st, planes_ready);
+            case G_RESID: return launch_x3_stream<G_RESID>(a, nw, ws, st, planes_ready, defer);
             case G_ROPE: return launch_x3_stream<G_ROPE>(a, nw, ws, st, planes_ready);
             case G_ROPE_CACHE: return launch_x3_stream<G_ROPE_CACHE>(a, nw, ws, st, planes_ready);
             case G_CACHE: return launch_x3_stream<G_CACHE>(a, nw, ws, st, planes_ready);

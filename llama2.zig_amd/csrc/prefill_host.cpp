@@ -183,10 +183,16 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
     int xn_planes = PLANES_SPLIT;
     if (k == PF_ATT || k == PF_H1) {  // :305 / :398
         const bool pl = k == PF_ATT ? planes_for((long long)dim + 2 * kvd_whole, dim, sk_qkv) : planes_for(2LL * hid, dim, sk_h1);
+        // (... and adds the K ranges' sums the residual product before it left behind: DeferredSum)
         L2Z_HIP(launch_prefill_rmsnorm(s->pf_xn, ldxn, s->pf_x, (k == PF_ATT ? w->rms_att : w->rms_ffn) + (size_t)l * dim, dim, P, st,
-                                       pl ? ws->x3 : nullptr, dim));
+                                       pl ? ws->x3 : nullptr, dim, &s->pf_pending));
+        s->pf_pending.valid = false;
         if (pl) xn_planes = PLANES_READY;
     }
+    L2Z_CHECK(!s->pf_pending.valid, L2Z_ERR_INVALID, "batched prefill: a residual product's sums were left for a norm that did not run (stage %d)", k);
+    // Wo / W2 may leave their K ranges' sums to the rmsnorm launch that reads the residual stream next (the unsharded pass; W2
+    // of the last layer finishes itself: the classifier reads x)
+    const bool may_defer = !sharded && tunables().pf_fuse_planes != 0;
     if (k == PF_ATT) {
         {
             PanelProduct pp = {};
@@ -241,7 +247,7 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
         if (!taken)
         L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_att, ldatt, w->wo + (size_t)l * sh.dim_loc * dim, out, ldo,
                                     P, sh.dim_loc, dim, pos0, s->rope, hs, st, res, dim, sh.world, 0, sk_wo, ws, 0, 0,
-                                    sharded ? PLANES_SPLIT : s->pf_planes_att));   // :392-395
+                                    sharded ? PLANES_SPLIT : s->pf_planes_att, may_defer ? &s->pf_pending : nullptr));   // :392-395
         s->pf_planes_att = PLANES_SPLIT;
     } else if (k == PF_H1) {
         // :405-416: W1 and W3 in one launch with silu(a) * b as its epilogue where the tile kernel
@@ -281,7 +287,8 @@ int prefill_stage(l2z_runstate *s, const l2z_weights *w, int l, int k, int P, in
         if (!taken)
         L2Z_HIP(launch_prefill_gemm(PG_RESID, s->pf_h1, ldh1, w->w2 + (size_t)l * sh.dim_loc * hid, out, ldo,
                                     P, sh.dim_loc, hid, pos0, s->rope, hs, st, res, dim, sh.world, 0, sk_w2, ws, 0, 0,
-                                    sharded ? PLANES_SPLIT : s->pf_planes_h1));   // :419-422
+                                    sharded ? PLANES_SPLIT : s->pf_planes_h1,
+                                    may_defer && l + 1 < c.n_layers ? &s->pf_pending : nullptr));   // :419-422
         s->pf_planes_h1 = PLANES_SPLIT;
     }
     return L2Z_OK;
@@ -355,6 +362,7 @@ int prefill_half_b(l2z_runstate *s, const l2z_weights *w, int l, int half, int P
 
 int prefill_begin_chunk(l2z_runstate *s, const l2z_weights *w, const int32_t *tokens, int P)
 {
+    s->pf_pending.valid = false;
     // the split forms' arrival counters and flags are left at zero by every launch that completes; a pass that was
     // cut short (a peer-write wait that timed out, a failed launch) must not leave a later one a half-counted tile
     if (s->pf_sk.cnt)

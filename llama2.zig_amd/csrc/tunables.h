@@ -50,8 +50,10 @@ struct Tunables {
                                //                     panel kernel): tests of both sides of the switch-over (7B, ms: 32 tokens 6.6 vs 7.3,
                                //                     36 / 40 / 48 tokens 8.6 / 8.7 / 8.8 vs 8.0 / 8.2 / 8.2: profiles/r06t)
     int pf_fuse_planes = 1;    // L2Z_PF_FUSE_PLANES  0: every GEMM on the bf16 cores splits its activation matrix in a launch of its own just
-                               //                     before it (same bits; the A/B of the fused producers: rmsnorm, attention output, SwiGLU
-                               //                     epilogue -- four launches per layer)
+                               //                     before it, and Wo / W2 add their K ranges' sums themselves (same bits; the A/B of the
+                               //                     unsharded pass's cross-kernel work: planes written by rmsnorm, the attention output, the
+                               //                     SwiGLU epilogue -- four launches per layer -- and the ranges' sums of Wo / W2 added by
+                               //                     the rmsnorm launch behind them)
     int pf_panel_max = -1;     // L2Z_PF_PANEL_MAX    longest chunk that takes the panel kernel (default and maximum 96 tokens): tests of both sides
                                //                     of the switch-over
 
