@@ -70,16 +70,18 @@ def test_small_model_tokens_per_s_stay_at_their_floor(gpu, ck, pf):
 
 def test_prefill_and_long_context_attention_stay_at_their_floor(gpu, ck, pf):
     """the batched prefill of the 7B shape at 16 (short-prompt GEMMs), 32 (the K-range panel kernel, f32 matrix cores),
-    48 / 64 / 96 / 128 (the stream form of the bf16-core kernel: two token tiles on twelve / sixteen waves, three / four on
-    eight) and 256 / 512 / 1024 tokens (its tile forms), best of 6; and the split decode attention at the last position of
-    the 2048-token context"""
+    48 / 64 (the stream form of the bf16-core kernel at two token tiles: the weight stream's pace) and 96 / 128 (three / four
+    token tiles) / 256 / 512 / 1024 tokens (its tile forms: the matrix cores' pace, which differs by 7 % between boxes -- that
+    group's common factor may reach 12 %), best of 6; and the split decode attention at the last position of the
+    2048-token context"""
     cfg = ck.LLAMA2_7B
     w, s = gpu.Weights(cfg, None, False, seed=2024), gpu.RunState(cfg)
     try:
         g = FLOOR["prefill_ms"]
         got = {n: pf.prefill_ms(gpu, ck, w, s, cfg, int(n)) for n in g["floors"]}
         for name, keys in g["groups"].items():   # (the bf16-core kernels move together with the clock: their own common factor)
-            check_group(f"7B prefill, ms, {name}", {k: got[k] for k in keys}, {k: g["floors"][k] for k in keys}, g["slack"], g["common_slack"])
+            check_group(f"7B prefill, ms, {name}", {k: got[k] for k in keys}, {k: g["floors"][k] for k in keys}, g["slack"],
+                        g.get("common_slack_by_group", {}).get(name, g["common_slack"]))
         s.greedy_begin([]); s.greedy_run(w, 2)
         a = FLOOR["attention_us_per_layer_pos2047"]
         us = pf.attention_long_us(gpu, w, s)

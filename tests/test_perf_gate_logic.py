@@ -23,17 +23,19 @@ def test_floor_file_has_every_group_and_names_its_device():
 def test_gate_rule_on_synthetic_readings():
     g = FLOOR["prefill_ms"]
     assert sorted(sum(g["groups"].values(), [])) == sorted(g["floors"])
-    f = {k: g["floors"][k] for k in g["groups"]["bf16 cores (stream form, tile forms)"]}
-    ok = {k: v * 1.03 for k, v in f.items()}                       # a slow process: everything + 3 %
-    check_group("prefill", ok, f, g["slack"], g["common_slack"])
-    stream = {k: v * (1.07 * 0.85 + 0.15 if k in ("48", "64", "96", "128") else 1.0) for k, v in f.items()}  # stream kernel + 7 %: 85 % of those chunks' time
+    name = [n for n in g["groups"] if "matrix cores' pace" in n][0]
+    f = {k: g["floors"][k] for k in g["groups"][name]}
+    cs = g["common_slack_by_group"][name]
+    ok = {k: v * 1.07 for k, v in f.items()}                       # a box whose matrix cores clock 7 % lower: everything + 7 %
+    check_group("prefill", ok, f, g["slack"], cs)
+    stream = {k: v * (1.07 * 0.85 + 0.15 if k in ("96", "128") else 1.0) for k, v in f.items()}  # stream kernel + 7 %: 85 % of those chunks' time
     with pytest.raises(AssertionError, match="96"):
-        check_group("prefill", stream, f, g["slack"], g["common_slack"])
+        check_group("prefill", stream, f, g["slack"], cs)
     tiles = {k: v * (1.07 * 0.9 + 0.1 if k in ("256", "512", "1024") else 1.0) for k, v in f.items()}   # the tile forms + 7 %
     with pytest.raises(AssertionError, match="512"):
-        check_group("prefill", tiles, f, g["slack"], g["common_slack"])
+        check_group("prefill", tiles, f, g["slack"], cs)
     with pytest.raises(AssertionError, match="everything"):
-        check_group("prefill", {k: v * 1.08 for k, v in f.items()}, f, g["slack"], g["common_slack"])
+        check_group("prefill", {k: v * 1.14 for k, v in f.items()}, f, g["slack"], cs)
     d = FLOOR["decode_us_per_launch"]
     f15 = d["floors"]["stories15M"]
     fused = dict(f15, qkv=f15["qkv"] * 1.2)                         # fused_qkv_attn_kernel + 20 % (launch-floor launches: 15 % per launch; tok/s: 4 %)
