@@ -323,9 +323,9 @@ struct PanelProduct {
 bool prefill_panel_shape(long long n_whole, int P, int K, long long widest_whole);
 int prefill_panel_max_tokens();
 // The next chunk of THIS model's batched prompt pass: the planner's (tunables.cpp prefill_next_chunk), except that a tail
-// of 65 ... 96 tokens on a model whose matrices take the panel kernel is cut in two chunks inside that kernel's range
-// (7B shape: one chunk of 65 ... 128 tokens costs 17.4 ... 17.8 ms whatever its length, 48 + 32 tokens 8.7 + 6.5 ms), and
-// a tail of 129 ... 160 / 257 ... 288 tokens into 128 / 256 + the rest.
+// past a step of the tile GEMM's cost staircase is cut into the step's worth + the rest on a model whose matrices take the
+// short-chunk kernels: 129 ... 224 tokens = 128 + rest and 257 ... 384 = 256 + rest on the bf16 cores (129 ... 160 and
+// 257 ... 288 on the f32 cores).
 // A function of the WHOLE model's shape and the tokens left: every rank of a shard group cuts the same chunks.
 int prefill_next_chunk_of(const l2z_config &c, int remaining);
 // hipErrorNotSupported: this rank's rows / pointers / workspace do not take the kernel (rows % 16, alignment) -- callers that

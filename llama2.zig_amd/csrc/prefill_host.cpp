@@ -486,10 +486,18 @@ int prefill_next_chunk_of(const l2z_config &c, int remaining)
         const int first = remaining <= 80 ? 48 : 64;  // 65 ... 80: 48 + 17 ... 32; 81 ... 96: 64 + 17 ... 32
         return panel(first) && panel(remaining - first) ? first : P;
     }
-    // just past a step of the tile GEMM's cost (7B: 128 tokens 17.8 ms, 129 ... 160 25.4; 256 tokens 31.6, 288 40.2): the
-    // step's worth first, the <= 32 tokens left on the short-chunk kernels (5.5 ... 6.5 ms)
-    for (int q : {128, 256})
-        if (remaining > q && remaining <= q + 32) return panel(32) ? q : P;
+    // Past a step of the tile GEMM's cost staircase the step's worth goes first and the rest -- at most 96 tokens -- to the
+    // short-chunk kernels.  On the bf16 cores (round 6; 7B, ms, one chunk against the cut: profiles/r06z_chunk_plan.txt) the
+    // tile forms cost 20.9 ... 24.6 for ANY chunk of 129 ... 256 tokens and ~35 for 257 ... 384, the stream form 12.5 at 128 and
+    // 5.6 ... 10.5 for a rest of 16 ... 96: 176 / 192 / 224 tokens 23.7 / 24.0 / 24.6 -> 20.2 / 20.3 / 22.8 as 128 + rest (240:
+    // 23.1 whole against 25.0), 272 / 320 tokens 34.9 / 35.9 -> 30.2 / 31.1 as 256 + rest.  On the f32 cores the steps were
+    // worth 32 tokens only (128 tokens 17.8 ms, 129 ... 160 25.4; 256 tokens 31.6, 288 40.2).
+    // (353 ... 384 tokens: 44.2 whole against 35.9 as 256 + 97 ... 128; 225 ... 256 whole: 23.0 against 25.4 as 128 + 97 ... 128)
+    const bool stream = x3_stream_shape(c.dim, 96, (c.dim + 63) / 64 * 64);
+    for (int q : {128, 256}) {
+        const int rest_max = !stream ? 32 : q == 128 ? 96 : 128;
+        if (remaining > q && remaining <= q + rest_max) return panel(32) ? q : P;
+    }
     return P;
 }
 

@@ -97,7 +97,10 @@ def test_prefill_planning_is_pinned(B, ck):
     # two chunks of that kernel's range; small models and other lengths keep the plain plan
     c7b, c110 = ck.Config(4096, 11008, 32, 32, 32, 32000, 2048), ck.Config(768, 2048, 12, 12, 12, 32000, 1024)
     assert [B.prefill_plan(n, c7b) for n in (64, 65, 80, 81, 96, 97, 600)] == [[64], [65], [80], [81], [96], [97], [512, 88]]   # (round 6: the panel kernel takes up to 96 tokens itself)
-    assert [B.prefill_plan(n, c7b) for n in (128, 129, 160, 161, 256, 257, 288, 289, 650)] == [[128], [128, 1], [128, 32], [161], [256], [256, 1], [256, 32], [289], [512, 128, 10]]
+    # ... and a tail past a step of the tile GEMM's cost staircase gives the step's worth to the tile forms and the rest to the
+    # short-chunk kernels: on the bf16 cores 129 ... 224 tokens = 128 + rest (<= 96), 257 ... 384 = 256 + rest (<= 128)
+    assert [B.prefill_plan(n, c7b) for n in (128, 129, 160, 161, 224, 225, 256, 257, 288, 289, 384, 385, 650)] == \
+        [[128], [128, 1], [128, 32], [128, 33], [128, 96], [225], [256], [256, 1], [256, 32], [256, 33], [256, 128], [385], [512, 128, 10]]
     assert [B.prefill_plan(n, c110) for n in (65, 96, 140, 600)] == [[65], [96], [140], [512, 88]]
     want = {(4096, 512, False): "128x64",    # 7B q / k / v / wo / W2: one 128 x 64 tile per CU
             (4096, 1024, False): "128x128",  # a 1024-token chunk: fewer bytes per flop into the CU
