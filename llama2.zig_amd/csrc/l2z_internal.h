@@ -325,7 +325,7 @@ int prefill_panel_max_tokens();
 // The next chunk of THIS model's batched prompt pass: the planner's (tunables.cpp prefill_next_chunk), except that a tail
 // past a step of the tile GEMM's cost staircase is cut into the step's worth + the rest on a model whose matrices take the
 // short-chunk kernels: 129 ... 224 tokens = 128 + rest and 257 ... 384 = 256 + rest on the bf16 cores (129 ... 160 and
-// 257 ... 288 on the f32 cores).
+// 257 ... 288 on the f32 cores), and 673 ... 1023 tokens are ONE chunk on the bf16 cores.
 // A function of the WHOLE model's shape and the tokens left: every rank of a shard group cuts the same chunks.
 int prefill_next_chunk_of(const l2z_config &c, int remaining);
 // hipErrorNotSupported: this rank's rows / pointers / workspace do not take the kernel (rows % 16, alignment) -- callers that

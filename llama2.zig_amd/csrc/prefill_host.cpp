@@ -477,6 +477,10 @@ int prefill_check(const l2z_config *config, const l2z_runstate *s)
 int prefill_next_chunk_of(const l2z_config &c, int remaining)
 {
     const int P = prefill_next_chunk(remaining);
+    // 513 ... 1023 tokens on the bf16 cores: 512 first only where the rest is cheap (<= 160 tokens: 576 / 640 tokens 58.0 / 61.2 ms
+    // whole, 47.5 / 51.7 cut); beyond, ONE chunk (800 / 832 / 900 / 960 tokens 72.6 / 72.4 / 80.6 / 77.3 cut, 65.8 / 66.0 / 74.4 /
+    // 74.9 whole; 704 / 768 tokens equal within 2 %: profiles/r06z_chunk_plan.txt)
+    if (tunables().pf_chunk == 0 && remaining > 672 && remaining < 1024 && x3_stream_shape(c.dim, 96, (c.dim + 63) / 64 * 64)) return remaining;
     if (tunables().pf_chunk > 0 || P != remaining || remaining <= prefill_panel_max_tokens()) return P;
     const long long kvd = (long long)c.dim / c.n_heads * c.n_kv_heads;
     const long long widest_whole = std::max((long long)c.dim + 2 * kvd, 2LL * c.hidden_dim) + 128;

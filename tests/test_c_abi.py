@@ -101,6 +101,8 @@ def test_prefill_planning_is_pinned(B, ck):
     # short-chunk kernels: on the bf16 cores 129 ... 224 tokens = 128 + rest (<= 96), 257 ... 384 = 256 + rest (<= 128)
     assert [B.prefill_plan(n, c7b) for n in (128, 129, 160, 161, 224, 225, 256, 257, 288, 289, 384, 385, 650)] == \
         [[128], [128, 1], [128, 32], [128, 33], [128, 96], [225], [256], [256, 1], [256, 32], [256, 33], [256, 128], [385], [512, 128, 10]]
+    # ... and 673 ... 1023 tokens are ONE chunk there (512 first only where the rest is cheap); 1500 tokens: 1024 + 476
+    assert [B.prefill_plan(n, c7b) for n in (672, 673, 900, 1023, 1500, 1900)] == [[512, 128, 32], [673], [900], [1023], [1024, 476], [1024, 876]]
     assert [B.prefill_plan(n, c110) for n in (65, 96, 140, 600)] == [[65], [96], [140], [512, 88]]
     want = {(4096, 512, False): "128x64",    # 7B q / k / v / wo / W2: one 128 x 64 tile per CU
             (4096, 1024, False): "128x128",  # a 1024-token chunk: fewer bytes per flop into the CU
