@@ -38,7 +38,7 @@ def test_gate_rule_on_synthetic_readings():
         check_group("prefill", {k: v * 1.14 for k, v in f.items()}, f, g["slack"], cs)
     d = FLOOR["decode_us_per_launch"]
     f15 = d["floors"]["stories15M"]
-    fused = dict(f15, qkv=f15["qkv"] * 1.2)                         # fused_qkv_attn_kernel + 20 % (launch-floor launches: 15 % per launch; tok/s: 4 %)
+    fused = dict(f15, qkv=f15["qkv"] * 1.5)                         # fused_qkv_attn_kernel + 50 % (launch-floor launches: 40 % per launch; tok/s: 4 %)
     with pytest.raises(AssertionError, match="qkv"):
         check_group("15M", fused, f15, d["slack_by_shape"]["stories15M"], d["common_slack"], slack_by_key=d["slack_by_kind"])
     noisy = dict(f15, cls=f15["cls"] * 0.97, wo=f15["wo"] * 1.03)   # one reading 3 % under its floor must not fail the others
