@@ -35,6 +35,7 @@ head -14 $O/r06_final_llama2-7b_kernel_stats.md
 bash scripts/pmc_traffic.sh r06 > $O/r06_final_pmc.log 2>&1; tail -9 $O/r06_final_pmc.log
 # the stream form of the bf16-core prefill GEMM: HBM traffic of its four launches by the counters, and its blocks' own clocks
 for n in 64 128; do bash scripts/stream_pmc_traffic.sh $n > $O/r06_final_stream_pmc_traffic_$n.md 2>&1; tail -5 $O/r06_final_stream_pmc_traffic_$n.md; done
+[ -f llama2.zig_amd/exp/libl2z_x3tl.so ] || bash scripts/x3_timeline.sh > /dev/null 2>&1   # (the measurement build: ~90 s of hipcc)
 for n in 64 128; do L2Z_LIB=$PWD/llama2.zig_amd/exp/libl2z_x3tl.so timeout 300 python scripts/x3_timeline.py llama2-7b $n; done > $O/r06_final_stream_timeline.txt 2>&1; grep -E "^[qW]" $O/r06_final_stream_timeline.txt
 # perf floors of this tree: two runs (profiles/perf_floor.json holds the worse reading of each)
 python scripts/perf_floor.py > $O/r06_final_perf_floor_a.json 2> $O/r06_final_perf_floor_a.err
