@@ -42,15 +42,16 @@ print(f"# PMC HBM traffic per launch, stream form of the bf16-core prefill GEMM,
 print("FETCH_SIZE (KB) x 1024 x 2 (gfx950: half of a wide coalesced stream is reported, MI355X_MICROARCH.md HBM section) + WRITE_SIZE (KB) x 1024; "
       "separate --pmc passes, kernel-trace only (scripts/stream_pmc_traffic.sh).  W = the product's weight bytes: every element is requested by ONE "
       "block, once.  partials = ranges x tokens x features x 4 bytes: the K ranges' sums, written through and read back once by the blocks "
-      "that finish the tile (nothing with one range).  X = the activation planes [tokens][3][K] bf16: every block of a K range reads them "
+      "that finish the tile (nothing with one range; Wo and W2 leave theirs to the next rmsnorm launch, which reads them: written here, not read).  X = the activation planes [tokens][3][K] bf16: every block of a K range reads them "
       "through its XCD's L2, so the memory side sees them up to 8 x.  out = the f32 output (+ its planes where the SwiGLU epilogue writes them).\n")
-print("| product | launches | blocks x threads | K ranges | read bytes | W bytes | partial bytes | X bytes | read / W | (read - partials) / W | (read - W - partials) / X | written bytes | written / (partials + out) |\n|---|---:|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
+print("| product | launches | blocks x threads | K ranges | read bytes | W bytes | partial bytes | X bytes | read / W | (read - partials read back) / W | (read - W - partials read back) / X | written bytes | written / (partials + out) |\n|---|---:|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
 for key in ("qkv", "wo", "w13", "w2"):
     c = max(cnt[key], 1)
     rd = acc["FETCH_SIZE"][key] / c * 1024 * 2; wr = acc["WRITE_SIZE"][key] / c * 1024
     x = n * K[key] * 6
     tok = (n + 31) // 32 * 32
     part = sk[key] * tok * N[key] * 4 if sk[key] > 1 else 0
+    part_read = 0 if key in ("wo", "w2") else part     # (deferred: the next rmsnorm launch reads them)
     out = n * N[key] * 4 if key != "w13" else n * hid * 4 + n * hid * 6
-    print(f"| {names[key]} | {cnt[key]} | {grid.get(key)} | {sk[key]} | {rd:.0f} | {wbytes[key]} | {part} | {x} | {rd / wbytes[key]:.3f} | {(rd - part) / wbytes[key]:.3f} | {(rd - wbytes[key] - part) / x:.2f} | {wr:.0f} | {wr / (part + out):.2f} |")
+    print(f"| {names[key]} | {cnt[key]} | {grid.get(key)} | {sk[key]} | {rd:.0f} | {wbytes[key]} | {part} | {x} | {rd / wbytes[key]:.3f} | {(rd - part_read) / wbytes[key]:.3f} | {(rd - wbytes[key] - part_read) / x:.2f} | {wr:.0f} | {wr / (part + out):.2f} |")
 PY
