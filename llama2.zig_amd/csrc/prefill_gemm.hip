@@ -668,8 +668,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void prefill_gemm_dma(const Gemm
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int tok = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (tok < a.P && j < a.N)
-                    a.out[(size_t)tok * a.ldo + j] = swiglu_merge(acc[i][0][r], acc[i][1][r]);  // :411-416
+                if (tok < a.P && j < a.N) {
+                    const float g = swiglu_merge(acc[i][0][r], acc[i][1][r]);  // :411-416
+                    a.out[(size_t)tok * a.ldo + j] = g;
+                    if (a.x3_out) planes_store1((__bf16 *)a.x3_out, a.kp_out, tok, j, g);   // the W2 launch's operand, already split
+                }
             }
     } else {
         gemm_epilogue<EPI, TM, TN>(a, acc, n0, m0, wm, wn, lane);
@@ -1352,6 +1355,11 @@ hipError_t launch_prefill_gemm_swiglu_pair(const float *x, int ldx, const float 
     K = a.K = pad_k(K, 64, ldx);   // whole 64-k stages (see pad_k)
     if (K < 0 || ldx % 4 != 0) return hipErrorInvalidValue;
     if (const hipError_t e = prepare_x3(a, ws, st, 2LL * N * a.n_scale, planes_ready); e != hipSuccess) return e;
+    // (the gated rows' planes beside them, as in the stream form: every paired tile form finishes in the same epilogue)
+    if (a.x3 != nullptr && kp_out == N && (N & 63) == 0 && ws != nullptr && ws->x3b != nullptr && (size_t)P * 3 * kp_out * sizeof(__bf16) <= ws->x3b_bytes) {
+        a.x3_out = ws->x3b; a.kp_out = kp_out;
+        if (planes_written) *planes_written = true;
+    }
     if (sk > 1) return gemm_launch_sk<G_STORE, true>(a, N, sk, ws, st);
     {
         const KgsChoice c = choose_kgs(N, P, K, true, ws, a.x3 != nullptr);
